@@ -1,0 +1,222 @@
+/*
+ * zkmpc_hip.h -- C ABI of libzkmpc_hip.so: the MI355X (gfx950) implementation of zk-mpc's
+ * Groth16 proving hot path over BLS12-377 (plain or additively secret-shared witnesses).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * Yoii-Inc/zk-mpc tree).  The Rust-side binding a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns 0 (ZK_OK) or a negative error code; zk_last_error() has the text.
+ *    Nothing aborts or throws across the boundary.
+ *  - "host" pointers are caller-owned and never retained.  "dev" pointers are HIP device
+ *    pointers on the context's device.  Opaque handles are library-owned.
+ *  - Field elements use the reference's in-memory form: little-endian u64 limbs in
+ *    Montgomery form (Fr: 4 limbs, R = 2^256; Fq: 6 limbs, R = 2^384),
+ *    arkworks/algebra/ff/src/fields/macros.rs:107-112.  Every output is fully reduced.
+ *  - Points: zk_g1_affine = x|y (96 B), zk_g2_affine = x.c0|x.c1|y.c0|y.c1 (192 B); the point
+ *    at infinity is all-zero bytes (the binding maps GroupAffine.infinity to that).
+ *    Projective results are Jacobian (X,Y,Z) like GroupProjective, normalised to Z = 1
+ *    (or (1,1,0) for zero, short_weierstrass_jacobian.rs zero()).
+ *  - All calls on one context are serialised on that context's HIP stream; contexts are
+ *    independent (one per MPC party / GPU, several per process allowed).
+ */
+#ifndef ZKMPC_HIP_H
+#define ZKMPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_OK 0
+#define ZK_ERR_HIP -1
+#define ZK_ERR_ARG -2
+#define ZK_ERR_NOMEM -3
+#define ZK_ERR_STATE -4
+
+typedef struct zk_ctx zk_ctx;
+typedef struct zk_bases zk_bases;   /* device-resident MSM base table (G1 or G2) */
+typedef struct zk_r1cs zk_r1cs;     /* device-resident ConstraintMatrices (CSR) */
+typedef struct zk_pk zk_pk;         /* device-resident Groth16 ProvingKey */
+
+typedef struct { uint64_t l[4]; } zk_fr;                 /* Fp256<FrParameters> */
+typedef struct { uint64_t l[6]; } zk_fq;                 /* Fp384<FqParameters> */
+typedef struct { zk_fq x, y; } zk_g1_affine;             /* GroupAffine<g1::Parameters> sans flag */
+typedef struct { zk_fq x, y, z; } zk_g1_projective;      /* GroupProjective<g1::Parameters> */
+typedef struct { zk_fq x[2], y[2]; } zk_g2_affine;       /* x = c0 + c1 u */
+typedef struct { zk_fq x[2], y[2], z[2]; } zk_g2_projective;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* One per party; replaces the task-local MpcMultiNet + implicit CPU state
+ * (mpc-net/src/multi.rs:598-663). */
+int zk_ctx_create(int device, int party_id, int n_parties, zk_ctx** out);
+int zk_ctx_destroy(zk_ctx* ctx);
+const char* zk_last_error(zk_ctx* ctx);
+int zk_ctx_sync(zk_ctx* ctx);
+void* zk_ctx_stream(zk_ctx* ctx);          /* hipStream_t, for event timing by the caller */
+int zk_version(void);
+
+int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** dev_out);
+int zk_dev_free(zk_ctx* ctx, void* dev);
+int zk_memcpy_h2d(zk_ctx* ctx, void* dev, const void* host, size_t bytes);
+int zk_memcpy_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes);
+
+/* ---- Fr vector arithmetic ---------------------------------------- */
+#define ZK_OP_MUL 0
+#define ZK_OP_ADD 1
+#define ZK_OP_SUB 2
+/* out[i] = a[i] (op) b[i], device buffers of n zk_fr (out may alias a or b).
+ * Fp256::{mul,add,sub}_assign: ff/src/fields/arithmetic.rs:7-57, macros.rs:698-717. */
+int zk_fr_vec_op_dev(zk_ctx* ctx, int op, const void* a_dev, const void* b_dev, void* out_dev, size_t n);
+/* out[i] = a[i] * k  (k: one host zk_fr). */
+int zk_fr_vec_scale_dev(zk_ctx* ctx, const void* a_dev, const zk_fr* k_host, void* out_dev, size_t n);
+/* Field::batch_product_in_place(selfs, others): ff/src/fields/mod.rs:216-220 (host slices). */
+int zk_fr_batch_product_in_place(zk_ctx* ctx, zk_fr* selfs_host, const zk_fr* others_host, size_t n);
+
+/* ---- radix-2 NTT (row a7) -------------------------------------------------------------- */
+/* In-place size-2^log_n transform of a device vector of zk_fr, in-order in and out.
+ * inverse=0,coset=0: EvaluationDomain::fft_in_place        (poly/src/domain/radix2/mod.rs:98-101)
+ * inverse=1,coset=0: ifft_in_place (includes * size_inv)   (:104-107, radix2/fft.rs:26-29)
+ * inverse=0,coset=1: coset_fft_in_place  (x g^i first)     (domain/mod.rs:138-141)
+ * inverse=1,coset=1: coset_ifft_in_place (x g^-i after)    (radix2/mod.rs:110-113, fft.rs:31-35) */
+int zk_fr_ntt_dev(zk_ctx* ctx, void* buf_dev, uint32_t log_n, int inverse, int coset);
+/* Host-slice form (the trait methods take &mut Vec<F>): `n` elements are read, zero-padded to
+ * 2^log_n (Vec::resize in the reference), transformed; 2^log_n elements are written back. */
+int zk_fr_fft_in_place(zk_ctx* ctx, zk_fr* vec_host, size_t n, uint32_t log_n, int inverse, int coset);
+/* EvaluationDomain::divide_by_vanishing_poly_on_coset_in_place (domain/mod.rs:183-190). */
+int zk_fr_divide_by_vanishing_on_coset_dev(zk_ctx* ctx, void* evals_dev, uint32_t log_n);
+
+/* ---- variable-base MSM (rows a5, a6) ---------------------------------------------------- */
+/* AffineCurve::multi_scalar_mul(bases, scalars) (ec/src/lib.rs:305-314) for G1 / G2:
+ * scalars are Montgomery-form zk_fr (the callee converts, like into_repr at :308-310);
+ * uses min(n_bases, n_scalars) terms (msm/variable_base.rs:15-17). */
+int zk_msm_g1(zk_ctx* ctx, const zk_g1_affine* bases_host, size_t n_bases,
+              const zk_fr* scalars_host, size_t n_scalars, zk_g1_projective* out_host);
+int zk_msm_g2(zk_ctx* ctx, const zk_g2_affine* bases_host, size_t n_bases,
+              const zk_fr* scalars_host, size_t n_scalars, zk_g2_projective* out_host);
+/* Resident bases: upload once (proving-key queries), then MSM against device scalars. */
+int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* bases_host, size_t n, zk_bases** out);
+int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* bases_host, size_t n, zk_bases** out);
+int zk_bases_free(zk_ctx* ctx, zk_bases* b);
+size_t zk_bases_len(const zk_bases* b);
+/* out = sum_{i<n} scalars[i] * bases[base_offset + i]; scalars_dev: n Montgomery zk_fr on device. */
+int zk_msm_g1_dev(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev,
+                  size_t n, zk_g1_projective* out_host);
+int zk_msm_g2_dev(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev,
+                  size_t n, zk_g2_projective* out_host);
+/* Fixed-base batch: out[i] = scalars[i] * G (G1/G2 generator scaled by gen_k), affine results on
+ * device as a zk_bases table.  FixedBaseMSM::multi_scalar_mul + batch_normalization_into_affine
+ * (ec/src/msm/fixed_base.rs:11-95, arkworks/groth16/src/generator.rs:130-215). */
+int zk_fixed_base_g1_dev(zk_ctx* ctx, const zk_fr* gen_k_host, const void* scalars_dev, size_t n, zk_bases** out);
+int zk_fixed_base_g2_dev(zk_ctx* ctx, const zk_fr* gen_k_host, const void* scalars_dev, size_t n, zk_bases** out);
+int zk_bases_download_g1(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, zk_g1_affine* out_host);
+int zk_bases_download_g2(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, zk_g2_affine* out_host);
+
+/* ---- host-side group helpers (O(1) work per proof; rows a10, a12) ------------------------ */
+int zk_g1_add(const zk_g1_projective* a, const zk_g1_projective* b, zk_g1_projective* out);
+int zk_g2_add(const zk_g2_projective* a, const zk_g2_projective* b, zk_g2_projective* out);
+int zk_g1_neg(const zk_g1_projective* a, zk_g1_projective* out);
+int zk_g1_mul(const zk_g1_projective* a, const zk_fr* k, zk_g1_projective* out);   /* ProjectiveCurve::mul */
+int zk_g2_mul(const zk_g2_projective* a, const zk_fr* k, zk_g2_projective* out);
+int zk_g1_from_affine(const zk_g1_affine* a, zk_g1_projective* out);
+int zk_g2_from_affine(const zk_g2_affine* a, zk_g2_projective* out);
+/* CanonicalSerialize compressed: 48 / 96 bytes (short_weierstrass_jacobian.rs:847-859). */
+int zk_g1_serialize(const zk_g1_projective* a, uint8_t out[48]);
+int zk_g2_serialize(const zk_g2_projective* a, uint8_t out[96]);
+/* Fr helpers for the share algebra done on the host (scalars r, s and Beaver opens). */
+int zk_fr_add(const zk_fr* a, const zk_fr* b, zk_fr* out);
+int zk_fr_sub(const zk_fr* a, const zk_fr* b, zk_fr* out);
+int zk_fr_mul(const zk_fr* a, const zk_fr* b, zk_fr* out);
+int zk_fr_from_canonical(const uint64_t canon[4], zk_fr* out);   /* from_repr, macros.rs:464-474 */
+int zk_fr_to_canonical(const zk_fr* a, uint64_t canon[4]);       /* into_repr, arithmetic.rs:59-83 */
+
+/* ---- R1CS + Groth16 (rows a9, a10) ----------------------------------------------------- */
+/* ConstraintMatrices{a,b,c} as CSR (relations/src/r1cs/constraint_system.rs:650-676):
+ * row_ptr has num_constraints+1 entries; coeffs are Montgomery zk_fr; col indexes the full
+ * assignment (instance first, instance[0] = 1, then witness). */
+typedef struct {
+    size_t num_constraints, num_instance, num_witness;
+    const uint32_t* a_row_ptr; const uint32_t* a_col; const zk_fr* a_coeff;
+    const uint32_t* b_row_ptr; const uint32_t* b_col; const zk_fr* b_coeff;
+    const uint32_t* c_row_ptr; const uint32_t* c_col; const zk_fr* c_coeff;
+} zk_r1cs_host;
+int zk_r1cs_upload(zk_ctx* ctx, const zk_r1cs_host* m, zk_r1cs** out);
+int zk_r1cs_free(zk_ctx* ctx, zk_r1cs* r);
+/* The SURVEY 8(d) synthetic "mul-chain" R1CS built directly on the device: w_i*w_{i+1}=w_{i+2},
+ * n constraints, 2 instance variables (1, last product), n+1 witness variables. */
+int zk_r1cs_mul_chain(zk_ctx* ctx, size_t n, zk_r1cs** out);
+/* ... and its satisfying full assignment from seeds w0, w1 (device vector of n+3 zk_fr). */
+int zk_mul_chain_assignment_dev(zk_ctx* ctx, size_t n, const zk_fr* w0, const zk_fr* w1, void* z_dev);
+
+/* ProvingKey (arkworks/groth16/src/data_structures.rs:133-151), host view for upload. */
+typedef struct {
+    zk_g1_affine alpha_g1, beta_g1, delta_g1;
+    zk_g2_affine beta_g2, delta_g2;
+    const zk_g1_affine* a_query;    size_t a_len;
+    const zk_g1_affine* b_g1_query; size_t b_g1_len;
+    const zk_g2_affine* b_g2_query; size_t b_g2_len;
+    const zk_g1_affine* h_query;    size_t h_len;
+    const zk_g1_affine* l_query;    size_t l_len;
+} zk_pk_host;
+int zk_pk_upload(zk_ctx* ctx, const zk_pk_host* pk, zk_pk** out);
+int zk_pk_free(zk_ctx* ctx, zk_pk* pk);
+/* generate_parameters with explicit toxic waste (arkworks/groth16/src/generator.rs:44-231);
+ * `tau` is the evaluation point the reference samples with sample_element_outside_domain.
+ * g1 = g1_k * G1 generator, g2 = g2_k * G2 generator.  The key stays resident on the device. */
+int zk_groth16_setup(zk_ctx* ctx, const zk_r1cs* r1cs, const zk_fr* alpha, const zk_fr* beta,
+                     const zk_fr* gamma, const zk_fr* delta, const zk_fr* tau,
+                     const zk_fr* g1_k, const zk_fr* g2_k, zk_pk** out);
+/* Sizes / elements of a resident key, for inspection by tests and serialisers.
+ * which: 0=a_query 1=b_g1_query 2=b_g2_query 3=h_query 4=l_query 5=gamma_abc_g1 */
+size_t zk_pk_query_len(const zk_pk* pk, int which);
+int zk_pk_download_g1(zk_ctx* ctx, const zk_pk* pk, int which, size_t offset, size_t n, zk_g1_affine* out);
+int zk_pk_download_g2(zk_ctx* ctx, const zk_pk* pk, int which, size_t offset, size_t n, zk_g2_affine* out);
+/* vk elements: 0=alpha_g1 1=beta_g1 2=delta_g1 (G1);  0=beta_g2 1=delta_g2 2=gamma_g2 (G2) */
+int zk_pk_vk_g1(const zk_pk* pk, int which, zk_g1_affine* out);
+int zk_pk_vk_g2(const zk_pk* pk, int which, zk_g2_affine* out);
+
+/* R1CStoQAP::witness_map (src/groth16.rs:240-306): z_dev = full assignment (num_instance +
+ * num_witness zk_fr on device); h_dev receives domain_size zk_fr. */
+int zk_groth16_witness_map_dev(zk_ctx* ctx, const zk_r1cs* r1cs, const void* z_dev, void* h_dev);
+uint32_t zk_r1cs_domain_log(const zk_r1cs* r1cs);
+/* Collaborative form, split at the one shared x shared product (src/groth16.rs:285):
+ *  pre : a,b,c <- coset_fft(ifft(M z))                    (local: linear in the shares)
+ *  post: h <- coset_ifft((ab - c) / Z(g)), ab supplied by the caller (Beaver batch_mul). */
+int zk_groth16_witness_map_pre_dev(zk_ctx* ctx, const zk_r1cs* r1cs, const void* z_dev,
+                                   int include_instance, void* a_dev, void* b_dev, void* c_dev);
+int zk_groth16_witness_map_post_dev(zk_ctx* ctx, const zk_r1cs* r1cs, void* ab_dev, const void* c_dev);
+/* The five MSMs of create_proof (src/groth16.rs:106,110,137,148,160) on a resident key:
+ * out = [h_acc, l_aux_acc, a_acc, b_g1_acc] and b_g2_acc; z_dev as above, h_dev from witness_map.
+ * (For shares these are the party-local MSMs of multi_scale_pub_group, share/additive.rs:517-520.) */
+int zk_groth16_msms_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const void* z_dev,
+                        const void* h_dev, zk_g1_projective out_g1[4], zk_g2_projective* out_g2);
+/* create_proof (src/groth16.rs:68-183 / arkworks/groth16/src/prover.rs:44-153) for a plain
+ * (non-shared) assignment resident on the device; proof = a||b||c compressed, 192 bytes. */
+int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const void* z_dev,
+                         const zk_fr* r, const zk_fr* s, uint8_t proof_out[192]);
+/* Same with the assignment in host memory (instance then witness). */
+int zk_groth16_prove(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const zk_fr* z_host,
+                     const zk_fr* r, const zk_fr* s, uint8_t proof_out[192]);
+
+/* ---- share algebra on device vectors (rows a11, a13) ------------------------------------- */
+/* out[i] = sum_p gathered[p*n + i] mod r: the receive side of AdditiveFieldShare::batch_open
+ * (mpc-algebra/src/share/additive.rs:124-131) after an all-gather of the parties' vectors. */
+int zk_fr_sum_parties_dev(zk_ctx* ctx, const void* gathered_dev, size_t n_parties, size_t n, void* out_dev);
+/* Local tail of FieldShare::batch_mul (share/field.rs:118-128):
+ * out = tz - sx*ty - oy*tx (+ sx*oy on the leader); tx,ty,tz = this party's triple shares or
+ * NULL for DummyFieldTripleSource (wire/field.rs:49-63: leader holds 1, the rest 0). */
+int zk_beaver_combine_dev(zk_ctx* ctx, const void* sx_open_dev, const void* oy_open_dev,
+                          const void* tx_dev, const void* ty_dev, const void* tz_dev,
+                          void* out_dev, size_t n);
+
+/* ---- instrumentation -------------------------------------------------------------------- */
+/* Per-phase device times (ms, HIP events on the context stream) of the last prove/MSM call.
+ * Returns the number of entries written; names are NUL-terminated, `name_stride` bytes apart. */
+int zk_last_timers(zk_ctx* ctx, char* names, size_t name_stride, float* ms, int max_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKMPC_HIP_H */

@@ -1,0 +1,149 @@
+"""GPU parity: Groth16 setup + prove through the C ABI against the oracle: proving-key elements,
+proof bytes (bit-exact), known-trapdoor prediction and the pairing verifier."""
+import numpy as np
+import pytest
+
+import zkref as O
+import zk_mpc_amd.convert as cv
+
+pytestmark = pytest.mark.gpu
+
+
+def trapdoor(rng):
+    return O.Trapdoor(rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr())
+
+
+def td_args(td):
+    m = cv.fr_to_mont([td.alpha, td.beta, td.gamma, td.delta, td.tau, td.g1_k, td.g2_k])
+    return [m[i] for i in range(7)]
+
+
+def csr(rows):
+    rp, col, coeff = [0], [], []
+    for r in rows:
+        for c, i in r:
+            col.append(i)
+            coeff.append(c)
+        rp.append(len(col))
+    return (np.array(rp, dtype=np.uint32), np.array(col, dtype=np.uint32),
+            cv.fr_to_mont(coeff) if coeff else np.zeros((0, 4), dtype=np.uint64))
+
+
+def upload_r1cs(ctx, r1cs):
+    return ctx.r1cs_upload(r1cs.num_instance, r1cs.num_witness, csr(r1cs.a), csr(r1cs.b), csr(r1cs.c))
+
+
+def my_simple_circuit(a, b):
+    """MySimpleCircuit (src/circuits/circuit.rs:85-111): c = a*b public, constraint a*b=c six times."""
+    c = a * b % O.R_MOD
+    A = [[(1, 2)] for _ in range(6)]
+    B = [[(1, 3)] for _ in range(6)]
+    Cm = [[(1, 1)] for _ in range(6)]
+    return O.R1CS(2, 2, A, B, Cm), [1, c, a, b]
+
+
+def general_r1cs(rng, nc, ni, nw):
+    """Random satisfiable R1CS with non-unit coefficients and multi-term rows."""
+    nv = ni + nw
+    z = [1] + [rng.fr() for _ in range(nv - 1)]
+    A, B, Cm = [], [], []
+    for i in range(nc):
+        ra = [(rng.fr(), rng.u64() % nv) for _ in range(1 + rng.u64() % 3)]
+        rb = [(rng.fr(), rng.u64() % nv) for _ in range(1 + rng.u64() % 3)]
+        va, vb = O.evaluate_constraint(ra, z), O.evaluate_constraint(rb, z)
+        # c row: k * z[j] with k chosen so the constraint holds (z[j] != 0)
+        j = ni + (i % nw)
+        k = va * vb * pow(z[j], -1, O.R_MOD) % O.R_MOD
+        A.append(ra); B.append(rb); Cm.append([(k, j)])
+    return O.R1CS(ni, nw, A, B, Cm), z
+
+
+def check_pk(ctx, pk, opk):
+    assert cv.g1_array_to_affine(pk.download("a_query")) == opk.a_query
+    assert cv.g1_array_to_affine(pk.download("b_g1_query")) == opk.b_g1_query
+    assert cv.g2_array_to_affine(pk.download("b_g2_query")) == opk.b_g2_query
+    assert cv.g1_array_to_affine(pk.download("h_query")) == opk.h_query
+    assert cv.g1_array_to_affine(pk.download("l_query")) == opk.l_query
+    assert cv.g1_array_to_affine(pk.download("gamma_abc_g1")) == opk.gamma_abc_g1
+    assert cv.g1_array_to_affine([pk.vk_g1(i) for i in range(3)]) == [opk.alpha_g1, opk.beta_g1, opk.delta_g1]
+    assert cv.g2_array_to_affine([pk.vk_g2(i) for i in range(3)]) == [opk.beta_g2, opk.delta_g2, opk.gamma_g2]
+
+
+def test_config1_my_simple_circuit(ctx):
+    """BASELINE config 1 (bin_test_groth16: MySimpleCircuit, 6 constraints, domain 8), local prove."""
+    rng = O.Prng(0x5EED0001)
+    r1cs, z = my_simple_circuit(rng.fr(), rng.fr())
+    td = trapdoor(rng)
+    pks = O.ProvingKeyScalars(r1cs, td)
+    opk = O.ProvingKey(pks)
+    dr = upload_r1cs(ctx, r1cs)
+    assert dr.domain_log == 3
+    pk = ctx.groth16_setup(dr, *td_args(td))
+    check_pk(ctx, pk, opk)
+    r, s = rng.fr(), rng.fr()
+    proof = ctx.create_proof(pk, dr, cv.fr_to_mont(z), cv.fr_to_mont([r])[0], cv.fr_to_mont([s])[0])
+    oproof = O.create_proof(r1cs, opk, z, r, s)
+    assert proof == O.proof_serialize(*oproof)
+    assert oproof == O.predict_proof(r1cs, pks, z, r, s)
+    assert O.verify_proof(opk, oproof, z[1:2])
+    assert not O.verify_proof(opk, oproof, [(z[1] + 1) % O.R_MOD])
+    # no-zk variant (create_proof_no_zk, src/groth16.rs:52-64)
+    zero = cv.fr_to_mont([0])[0]
+    assert ctx.create_proof(pk, dr, cv.fr_to_mont(z), zero, zero) == O.proof_serialize(*O.create_proof(r1cs, opk, z, 0, 0))
+
+
+def test_pk_upload_path(ctx):
+    """A key produced elsewhere (the oracle) uploaded through zk_pk_upload gives the same proof."""
+    rng = O.Prng(77)
+    r1cs, z = O.mul_chain_r1cs(9, rng.fr(), rng.fr())
+    td = trapdoor(rng)
+    opk = O.ProvingKey(O.ProvingKeyScalars(r1cs, td))
+    dr = upload_r1cs(ctx, r1cs)
+    pk = ctx.pk_upload(cv.g1_affine_to_array([opk.alpha_g1])[0], cv.g1_affine_to_array([opk.beta_g1])[0],
+                       cv.g1_affine_to_array([opk.delta_g1])[0], cv.g2_affine_to_array([opk.beta_g2])[0],
+                       cv.g2_affine_to_array([opk.delta_g2])[0], cv.g1_affine_to_array(opk.a_query),
+                       cv.g1_affine_to_array(opk.b_g1_query), cv.g2_affine_to_array(opk.b_g2_query),
+                       cv.g1_affine_to_array(opk.h_query), cv.g1_affine_to_array(opk.l_query))
+    r, s = rng.fr(), rng.fr()
+    proof = ctx.create_proof(pk, dr, cv.fr_to_mont(z), cv.fr_to_mont([r])[0], cv.fr_to_mont([s])[0])
+    assert proof == O.proof_serialize(*O.create_proof(r1cs, opk, z, r, s))
+
+
+def test_general_r1cs(ctx):
+    rng = O.Prng(78)
+    r1cs, z = general_r1cs(rng, nc=50, ni=3, nw=20)
+    td = trapdoor(rng)
+    pks = O.ProvingKeyScalars(r1cs, td)
+    opk = O.ProvingKey(pks)
+    dr = upload_r1cs(ctx, r1cs)
+    pk = ctx.groth16_setup(dr, *td_args(td))
+    check_pk(ctx, pk, opk)
+    # witness map alone
+    dz = ctx.upload(cv.fr_to_mont(z))
+    D = 1 << dr.domain_log
+    dh = ctx.alloc(D * 32)
+    ctx.witness_map_dev(dr, dz.ptr, dh.ptr)
+    assert cv.fr_from_mont(ctx.download(dh, (D, 4))) == O.witness_map(r1cs, z)
+    r, s = rng.fr(), rng.fr()
+    proof = ctx.create_proof(pk, dr, cv.fr_to_mont(z), cv.fr_to_mont([r])[0], cv.fr_to_mont([s])[0])
+    oproof = O.predict_proof(r1cs, pks, z, r, s)
+    assert proof == O.proof_serialize(*oproof)
+    assert O.verify_proof(opk, oproof, z[1:3])
+
+
+@pytest.mark.parametrize("n", [1, 62, 1000])
+def test_mul_chain_device_builder(ctx, n):
+    """zk_r1cs_mul_chain / zk_mul_chain_assignment_dev equal the oracle's mul-chain family, and the
+    proof equals the known-trapdoor prediction (exact bytes)."""
+    rng = O.Prng(500 + n)
+    w0, w1 = rng.fr(), rng.fr()
+    r1cs, z = O.mul_chain_r1cs(n, w0, w1)
+    dr = ctx.r1cs_mul_chain(n)
+    dz = ctx.mul_chain_assignment_dev(n, cv.fr_to_mont([w0])[0], cv.fr_to_mont([w1])[0])
+    assert cv.fr_from_mont(ctx.download(dz, (n + 3, 4))) == z
+    td = trapdoor(rng)
+    pks = O.ProvingKeyScalars(r1cs, td)
+    pk = ctx.groth16_setup(dr, *td_args(td))
+    r, s = rng.fr(), rng.fr()
+    proof = ctx.create_proof_dev(pk, dr, dz.ptr, cv.fr_to_mont([r])[0], cv.fr_to_mont([s])[0])
+    assert proof == O.proof_serialize(*O.predict_proof(r1cs, pks, z, r, s))

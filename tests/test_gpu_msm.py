@@ -1,0 +1,145 @@
+"""GPU parity: variable-base MSM on G1 / G2 against the oracle (Pippenger restatement == naive)."""
+import numpy as np
+import pytest
+
+import zkref as O
+import zk_mpc_amd.convert as cv
+
+pytestmark = pytest.mark.gpu
+
+
+def g1_points(rng, n):
+    return [O.g1_mul(O.G1_GEN, rng.fr()) for _ in range(n)]
+
+
+def g2_points(rng, n):
+    return [O.g2_mul(O.G2_GEN, rng.fr()) for _ in range(n)]
+
+
+def run_g1(ctx, bases, scalars):
+    out = ctx.multi_scalar_mul_g1(cv.g1_affine_to_array(bases), cv.fr_to_mont(scalars))
+    return cv.g1_projective_to_affine(out)
+
+
+def run_g2(ctx, bases, scalars):
+    out = ctx.multi_scalar_mul_g2(cv.g2_affine_to_array(bases), cv.fr_to_mont(scalars))
+    return cv.g2_projective_to_affine(out)
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 100, 700])
+def test_msm_g1_random(ctx, n):
+    rng = O.Prng(300 + n)
+    bases, scalars = g1_points(rng, n), [rng.fr() for _ in range(n)]
+    assert run_g1(ctx, bases, scalars) == O.msm_pippenger(bases, scalars, O.FqOps)
+
+
+@pytest.mark.parametrize("n", [1, 3, 40, 200])
+def test_msm_g2_random(ctx, n):
+    rng = O.Prng(400 + n)
+    bases, scalars = g2_points(rng, n), [rng.fr() for _ in range(n)]
+    assert run_g2(ctx, bases, scalars) == O.msm_pippenger(bases, scalars, O.Fq2Ops)
+
+
+def test_msm_edge_cases_g1(ctx):
+    rng = O.Prng(55)
+    P = g1_points(rng, 6)
+    r = O.R_MOD
+    cases = [
+        ([], []),                                            # empty
+        (P[:3], [0, 0, 0]),                                  # all-zero scalars -> infinity
+        (P[:3], [1, 1, 1]),                                  # unit scalars (variable_base.rs:45-49 fast path)
+        (P[:1] * 50, [7] * 50),                              # equal bases, equal scalars: P+P inside buckets
+        ([P[0], O.g1_neg(P[0])], [5, 5]),                    # cancels to infinity
+        ([P[0], O.g1_neg(P[0]), P[1]], [9, 9, 3]),
+        ([None, P[1], None], [5, 6, 7]),                     # bases at infinity
+        (P[:4], [r - 1, r - 2, 1, (r - 1) // 2]),            # extreme scalars
+        (P[:5], [1 << 252, (1 << 253) % r, 2 ** 16 - 1, 2 ** 16, 2 ** 15]),  # window-boundary digits
+        (P[:6], [3, 5]),                                     # more bases than scalars: min(len)
+        (P[:2], [3, 5, 7, 9]),                               # more scalars than bases
+    ]
+    for bases, scalars in cases:
+        n = min(len(bases), len(scalars))
+        assert run_g1(ctx, bases, scalars) == O.msm_naive(bases[:n], scalars[:n], O.FqOps), (len(bases), scalars[:4])
+
+
+def test_msm_edge_cases_g2(ctx):
+    rng = O.Prng(56)
+    P = g2_points(rng, 4)
+    cases = [
+        ([], []),
+        (P[:2], [0, 0]),
+        (P[:1] * 20, [11] * 20),
+        ([P[0], O.g2_neg(P[0])], [5, 5]),
+        ([None, P[1]], [5, 6]),
+        (P[:3], [O.R_MOD - 1, 1, 2]),
+    ]
+    for bases, scalars in cases:
+        assert run_g2(ctx, bases, scalars) == O.msm_naive(bases, scalars, O.Fq2Ops)
+
+
+def test_msm_witness_like_scalars(ctx):
+    """0/1-heavy scalars, as real witnesses are (booleans): one very heavy bucket."""
+    rng = O.Prng(57)
+    n = 600
+    bases = g1_points(rng, 40) * 15
+    scalars = [(rng.u64() & 1) if i % 7 else rng.fr() for i in range(n)]
+    assert run_g1(ctx, bases, scalars) == O.msm_naive(bases, scalars, O.FqOps)
+
+
+def test_fixed_base_and_resident_msm(ctx):
+    """zk_fixed_base_* (setup-side) against k_i * G, then a resident-bases MSM with an offset."""
+    rng = O.Prng(58)
+    n = 300
+    ks = [rng.fr() for _ in range(n)]
+    ks[0], ks[1] = 0, 1
+    gk = rng.fr()
+    dk = ctx.upload(cv.fr_to_mont(ks))
+    b1 = ctx.fixed_base(dk.ptr, n, 1, cv.fr_to_mont([gk])[0])
+    got = cv.g1_array_to_affine(b1.download())
+    g = O.g1_mul(O.G1_GEN, gk)
+    assert got == [O.g1_mul(g, k) for k in ks]
+    b2 = ctx.fixed_base(dk.ptr, 40, 2, cv.fr_to_mont([gk])[0])
+    g2 = O.g2_mul(O.G2_GEN, gk)
+    assert cv.g2_array_to_affine(b2.download()) == [O.g2_mul(g2, k) for k in ks[:40]]
+    sc = [rng.fr() for _ in range(n - 1)]
+    ds = ctx.upload(cv.fr_to_mont(sc))
+    out = cv.g1_projective_to_affine(ctx.msm_dev(b1, 1, ds.ptr, n - 1))
+    # sum sc_i * ks_{i+1} * g
+    e = sum(s * k for s, k in zip(sc, ks[1:])) % O.R_MOD
+    assert out == O.g1_mul(g, e)
+
+
+@pytest.mark.parametrize("log_n", [16, 20])
+def test_msm_large_discrete_log_check(ctx, log_n):
+    """Full-size check without a CPU MSM: bases = k_i * G (device fixed-base), so
+    sum s_i (k_i G) must equal (sum s_i k_i mod r) * G -- an Fr inner product on the host."""
+    n = 1 << log_n
+    rs = np.random.RandomState(7 + log_n)
+
+    def rand_mont(m):
+        a = rs.randint(0, 1 << 62, size=(m, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+
+    km, sm = rand_mont(n), rand_mont(n)
+    dk, ds = ctx.upload(km), ctx.upload(sm)
+    one = cv.fr_to_mont([1])[0]
+    for group in (1, 2):
+        m = n if group == 1 else n // 4
+        bases = ctx.fixed_base(dk.ptr, m, group, one)
+        out = ctx.msm_dev(bases, 0, ds.ptr, m)
+        # inner product on the device too (vector mul), summed on the host in Python ints
+        prod = ctx.alloc(m * 32)
+        ctx.fr_vec_op_dev(0, dk.ptr, ds.ptr, prod.ptr, m)
+        pr = ctx.download(prod, (m, 4))
+        # sum of Montgomery residues is the Montgomery residue of the sum
+        tot = 0
+        for j in range(4):
+            tot += int(pr[:, j].astype(object).sum()) << (64 * j)
+        e = cv.fr_from_mont(cv.fr_raw([tot % O.R_MOD]))[0]
+        if group == 1:
+            assert cv.g1_projective_to_affine(out) == O.g1_mul(O.G1_GEN, e)
+        else:
+            assert cv.g2_projective_to_affine(out) == O.g2_mul(O.G2_GEN, e)
+        bases.free()
+        prod.free()

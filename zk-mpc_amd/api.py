@@ -1,0 +1,404 @@
+"""Host-side mirror of the reference's operator interface for the Groth16 proving path.
+
+Method names follow the trait methods the reference dispatches through:
+  Field::batch_product_in_place              (arkworks/algebra/ff/src/fields/mod.rs:216)
+  EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place, divide_by_vanishing_poly_on_coset_in_place
+                                             (arkworks/algebra/poly/src/domain/mod.rs:78-190)
+  AffineCurve::multi_scalar_mul              (arkworks/algebra/ec/src/lib.rs:305)
+  create_proof / generate_parameters         (src/groth16.rs:68, arkworks/groth16/src/generator.rs:44)
+All arithmetic happens in libzkmpc_hip.so; this file only moves buffers and checks return codes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ZkError
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _fr_struct(limbs4) -> _lib.Fr:
+    f = _lib.Fr()
+    for i in range(4):
+        f.l[i] = int(limbs4[i])
+    return f
+
+
+class DevBuf:
+    """A device allocation owned by a Context."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = nbytes
+        p = C.c_void_p()
+        ctx._ck(ctx.lib.zk_dev_alloc(ctx.h, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def at(self, byte_offset: int) -> int:
+        return self.ptr + byte_offset
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.zk_dev_free(self.ctx.h, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One MPC party / one GPU (zk_ctx)."""
+
+    def __init__(self, device: int = 0, party_id: int = 0, n_parties: int = 1):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.zk_ctx_create(device, party_id, n_parties, C.byref(h))
+        if rc != 0:
+            raise ZkError("zk_ctx_create failed (rc=%d): no usable HIP device %d -- this library has no CPU path" % (rc, device))
+        self.h = h
+        self.device, self.party_id, self.n_parties = device, party_id, n_parties
+
+    def close(self):
+        if self.h:
+            self.lib.zk_ctx_destroy(self.h)
+            self.h = None
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise ZkError("libzkmpc_hip error %d: %s" % (rc, (self.lib.zk_last_error(self.h) or b"").decode()))
+
+    # ---- buffers ----
+    def alloc(self, nbytes: int) -> DevBuf:
+        return DevBuf(self, nbytes)
+
+    def upload(self, arr: np.ndarray) -> DevBuf:
+        arr = np.ascontiguousarray(arr)
+        b = DevBuf(self, max(arr.nbytes, 16))
+        if arr.nbytes:
+            self._ck(self.lib.zk_memcpy_h2d(self.h, C.c_void_p(b.ptr), _ptr(arr), arr.nbytes))
+        return b
+
+    def download(self, buf, shape, dtype=np.uint64, byte_offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        ptr = buf.ptr if isinstance(buf, DevBuf) else int(buf)
+        if out.nbytes:
+            self._ck(self.lib.zk_memcpy_d2h(self.h, _ptr(out), C.c_void_p(ptr + byte_offset), out.nbytes))
+        return out
+
+    def sync(self):
+        self._ck(self.lib.zk_ctx_sync(self.h))
+
+    def stream(self) -> int:
+        return self.lib.zk_ctx_stream(self.h)
+
+    def timers(self) -> dict:
+        names = C.create_string_buffer(64 * 32)
+        ms = (C.c_float * 32)()
+        k = self.lib.zk_last_timers(self.h, names, 64, ms, 32)
+        return {names.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode(): float(ms[i]) for i in range(k)}
+
+    # ---- Fr vectors ----
+    def fr_vec_op_dev(self, op: int, a, b, out, n: int):
+        self._ck(self.lib.zk_fr_vec_op_dev(self.h, op, C.c_void_p(int(a)), C.c_void_p(int(b)), C.c_void_p(int(out)), n))
+
+    def fr_vec_scale_dev(self, a, k_mont4, out, n: int):
+        k = _fr_struct(k_mont4)
+        self._ck(self.lib.zk_fr_vec_scale_dev(self.h, C.c_void_p(int(a)), C.byref(k), C.c_void_p(int(out)), n))
+
+    def batch_product_in_place(self, selfs: np.ndarray, others: np.ndarray):
+        """Field::batch_product_in_place on host slices ((n,4) uint64 Montgomery)."""
+        assert selfs.dtype == np.uint64 and selfs.flags.c_contiguous
+        others = np.ascontiguousarray(others, dtype=np.uint64)
+        n = min(selfs.shape[0], others.shape[0])
+        self._ck(self.lib.zk_fr_batch_product_in_place(self.h, _ptr(selfs), _ptr(others), n))
+
+    # ---- EvaluationDomain ----
+    def ntt_dev(self, buf, log_n: int, inverse: bool, coset: bool):
+        self._ck(self.lib.zk_fr_ntt_dev(self.h, C.c_void_p(int(buf)), log_n, int(inverse), int(coset)))
+
+    def _fft_host(self, vec: np.ndarray, log_n: int, inverse: int, coset: int) -> np.ndarray:
+        n = vec.shape[0]
+        N = 1 << log_n
+        out = np.zeros((N, 4), dtype=np.uint64)
+        out[:n] = vec
+        self._ck(self.lib.zk_fr_fft_in_place(self.h, _ptr(out), n, log_n, inverse, coset))
+        return out
+
+    def fft_in_place(self, vec, log_n):        return self._fft_host(vec, log_n, 0, 0)
+    def ifft_in_place(self, vec, log_n):       return self._fft_host(vec, log_n, 1, 0)
+    def coset_fft_in_place(self, vec, log_n):  return self._fft_host(vec, log_n, 0, 1)
+    def coset_ifft_in_place(self, vec, log_n): return self._fft_host(vec, log_n, 1, 1)
+
+    def divide_by_vanishing_poly_on_coset_in_place_dev(self, buf, log_n: int):
+        self._ck(self.lib.zk_fr_divide_by_vanishing_on_coset_dev(self.h, C.c_void_p(int(buf)), log_n))
+
+    # ---- AffineCurve::multi_scalar_mul ----
+    def multi_scalar_mul_g1(self, bases: np.ndarray, scalars: np.ndarray) -> np.ndarray:
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        out = np.zeros(18, dtype=np.uint64)
+        self._ck(self.lib.zk_msm_g1(self.h, _ptr(bases), bases.shape[0], _ptr(scalars), scalars.shape[0], _ptr(out)))
+        return out
+
+    def multi_scalar_mul_g2(self, bases: np.ndarray, scalars: np.ndarray) -> np.ndarray:
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        out = np.zeros(36, dtype=np.uint64)
+        self._ck(self.lib.zk_msm_g2(self.h, _ptr(bases), bases.shape[0], _ptr(scalars), scalars.shape[0], _ptr(out)))
+        return out
+
+    def bases_upload(self, arr: np.ndarray, group: int) -> "Bases":
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        h = C.c_void_p()
+        fn = self.lib.zk_bases_upload_g1 if group == 1 else self.lib.zk_bases_upload_g2
+        self._ck(fn(self.h, _ptr(arr), arr.shape[0], C.byref(h)))
+        return Bases(self, h, group)
+
+    def fixed_base(self, scalars_dev, n: int, group: int, gen_k_mont4) -> "Bases":
+        h = C.c_void_p()
+        k = _fr_struct(gen_k_mont4)
+        fn = self.lib.zk_fixed_base_g1_dev if group == 1 else self.lib.zk_fixed_base_g2_dev
+        self._ck(fn(self.h, C.byref(k), C.c_void_p(int(scalars_dev)), n, C.byref(h)))
+        return Bases(self, h, group)
+
+    def msm_dev(self, bases: "Bases", base_offset: int, scalars_dev, n: int) -> np.ndarray:
+        out = np.zeros(18 if bases.group == 1 else 36, dtype=np.uint64)
+        fn = self.lib.zk_msm_g1_dev if bases.group == 1 else self.lib.zk_msm_g2_dev
+        self._ck(fn(self.h, bases.h, base_offset, C.c_void_p(int(scalars_dev)), n, _ptr(out)))
+        return out
+
+    # ---- share algebra ----
+    def fr_sum_parties_dev(self, gathered, n_parties: int, n: int, out):
+        self._ck(self.lib.zk_fr_sum_parties_dev(self.h, C.c_void_p(int(gathered)), n_parties, n, C.c_void_p(int(out))))
+
+    def beaver_combine_dev(self, sx, oy, out, n: int, triple=None):
+        tx, ty, tz = (None, None, None) if triple is None else [C.c_void_p(int(t)) for t in triple]
+        self._ck(self.lib.zk_beaver_combine_dev(self.h, C.c_void_p(int(sx)), C.c_void_p(int(oy)), tx, ty, tz,
+                                                C.c_void_p(int(out)), n))
+
+    # ---- host group helpers ----
+    def g1_add(self, a, b):
+        out = np.zeros(18, dtype=np.uint64)
+        self._ck(self.lib.zk_g1_add(_ptr(a), _ptr(b), _ptr(out)))
+        return out
+
+    def g2_add(self, a, b):
+        out = np.zeros(36, dtype=np.uint64)
+        self._ck(self.lib.zk_g2_add(_ptr(a), _ptr(b), _ptr(out)))
+        return out
+
+    def g1_neg(self, a):
+        out = np.zeros(18, dtype=np.uint64)
+        self._ck(self.lib.zk_g1_neg(_ptr(a), _ptr(out)))
+        return out
+
+    def g1_mul(self, a, k_mont4):
+        out = np.zeros(18, dtype=np.uint64)
+        k = np.ascontiguousarray(k_mont4, dtype=np.uint64)
+        self._ck(self.lib.zk_g1_mul(_ptr(a), _ptr(k), _ptr(out)))
+        return out
+
+    def g2_mul(self, a, k_mont4):
+        out = np.zeros(36, dtype=np.uint64)
+        k = np.ascontiguousarray(k_mont4, dtype=np.uint64)
+        self._ck(self.lib.zk_g2_mul(_ptr(a), _ptr(k), _ptr(out)))
+        return out
+
+    def g1_from_affine(self, a12):
+        out = np.zeros(18, dtype=np.uint64)
+        a12 = np.ascontiguousarray(a12, dtype=np.uint64)
+        self._ck(self.lib.zk_g1_from_affine(_ptr(a12), _ptr(out)))
+        return out
+
+    def g2_from_affine(self, a24):
+        out = np.zeros(36, dtype=np.uint64)
+        a24 = np.ascontiguousarray(a24, dtype=np.uint64)
+        self._ck(self.lib.zk_g2_from_affine(_ptr(a24), _ptr(out)))
+        return out
+
+    def g1_serialize(self, a) -> bytes:
+        out = np.zeros(48, dtype=np.uint8)
+        self._ck(self.lib.zk_g1_serialize(_ptr(a), _ptr(out)))
+        return out.tobytes()
+
+    def g2_serialize(self, a) -> bytes:
+        out = np.zeros(96, dtype=np.uint8)
+        self._ck(self.lib.zk_g2_serialize(_ptr(a), _ptr(out)))
+        return out.tobytes()
+
+    def fr_op(self, name: str, a4, b4):
+        out = np.zeros(4, dtype=np.uint64)
+        a4 = np.ascontiguousarray(a4, dtype=np.uint64)
+        b4 = np.ascontiguousarray(b4, dtype=np.uint64)
+        self._ck(getattr(self.lib, "zk_fr_" + name)(_ptr(a4), _ptr(b4), _ptr(out)))
+        return out
+
+    # ---- R1CS / Groth16 ----
+    def r1cs_upload(self, num_instance: int, num_witness: int, a, b, c) -> "R1cs":
+        """a, b, c: (row_ptr uint32[nc+1], col uint32[nnz], coeff uint64[nnz,4] Montgomery)."""
+        keep = []
+        h = _lib.R1csHost()
+        h.num_constraints = len(a[0]) - 1
+        h.num_instance, h.num_witness = num_instance, num_witness
+        for name, (rp, col, coeff) in zip("abc", (a, b, c)):
+            rp = np.ascontiguousarray(rp, dtype=np.uint32)
+            col = np.ascontiguousarray(col, dtype=np.uint32)
+            coeff = np.ascontiguousarray(coeff, dtype=np.uint64)
+            keep += [rp, col, coeff]
+            setattr(h, name + "_row_ptr", rp.ctypes.data)
+            setattr(h, name + "_col", col.ctypes.data)
+            setattr(h, name + "_coeff", coeff.ctypes.data)
+        out = C.c_void_p()
+        self._ck(self.lib.zk_r1cs_upload(self.h, C.byref(h), C.byref(out)))
+        return R1cs(self, out, h.num_constraints, num_instance, num_witness)
+
+    def r1cs_mul_chain(self, n: int) -> "R1cs":
+        out = C.c_void_p()
+        self._ck(self.lib.zk_r1cs_mul_chain(self.h, n, C.byref(out)))
+        return R1cs(self, out, n, 2, n + 1)
+
+    def mul_chain_assignment_dev(self, n: int, w0_mont4, w1_mont4) -> DevBuf:
+        z = self.alloc((n + 3) * 32)
+        a, b = _fr_struct(w0_mont4), _fr_struct(w1_mont4)
+        self._ck(self.lib.zk_mul_chain_assignment_dev(self.h, n, C.byref(a), C.byref(b), C.c_void_p(z.ptr)))
+        return z
+
+    def groth16_setup(self, r1cs: "R1cs", alpha, beta, gamma, delta, tau, g1_k, g2_k) -> "ProvingKey":
+        """generate_parameters with explicit toxic waste; all arguments (4,) uint64 Montgomery."""
+        s = [_fr_struct(x) for x in (alpha, beta, gamma, delta, tau, g1_k, g2_k)]
+        out = C.c_void_p()
+        self._ck(self.lib.zk_groth16_setup(self.h, r1cs.h, *[C.byref(x) for x in s], C.byref(out)))
+        return ProvingKey(self, out)
+
+    def pk_upload(self, alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query, b_g1_query, b_g2_query, h_query,
+                  l_query) -> "ProvingKey":
+        h = _lib.PkHost()
+        keep = []
+
+        def put(field, arr, n):
+            arr = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1)
+            assert arr.size == n
+            C.memmove(C.addressof(getattr(h, field)), arr.ctypes.data, n * 8)
+
+        put("alpha_g1", alpha_g1, 12); put("beta_g1", beta_g1, 12); put("delta_g1", delta_g1, 12)
+        put("beta_g2", beta_g2, 24); put("delta_g2", delta_g2, 24)
+        for name, arr in (("a_query", a_query), ("b_g1_query", b_g1_query), ("b_g2_query", b_g2_query),
+                          ("h_query", h_query), ("l_query", l_query)):
+            arr = np.ascontiguousarray(arr, dtype=np.uint64)
+            keep.append(arr)
+            setattr(h, name, arr.ctypes.data)
+            setattr(h, name.replace("_query", "_len"), arr.shape[0])
+        out = C.c_void_p()
+        self._ck(self.lib.zk_pk_upload(self.h, C.byref(h), C.byref(out)))
+        return ProvingKey(self, out)
+
+    def witness_map_dev(self, r1cs: "R1cs", z_dev, h_dev):
+        self._ck(self.lib.zk_groth16_witness_map_dev(self.h, r1cs.h, C.c_void_p(int(z_dev)), C.c_void_p(int(h_dev))))
+
+    def witness_map_pre_dev(self, r1cs, z_dev, a, b, c, include_instance=True):
+        self._ck(self.lib.zk_groth16_witness_map_pre_dev(self.h, r1cs.h, C.c_void_p(int(z_dev)), int(include_instance),
+                                                         C.c_void_p(int(a)), C.c_void_p(int(b)), C.c_void_p(int(c))))
+
+    def witness_map_post_dev(self, r1cs, ab, c):
+        self._ck(self.lib.zk_groth16_witness_map_post_dev(self.h, r1cs.h, C.c_void_p(int(ab)), C.c_void_p(int(c))))
+
+    def groth16_msms_dev(self, pk: "ProvingKey", r1cs: "R1cs", z_dev, h_dev):
+        g1 = np.zeros((4, 18), dtype=np.uint64)
+        g2 = np.zeros(36, dtype=np.uint64)
+        self._ck(self.lib.zk_groth16_msms_dev(self.h, pk.h, r1cs.h, C.c_void_p(int(z_dev)), C.c_void_p(int(h_dev)),
+                                              _ptr(g1), _ptr(g2)))
+        return g1, g2
+
+    def create_proof_dev(self, pk: "ProvingKey", r1cs: "R1cs", z_dev, r_mont4, s_mont4) -> bytes:
+        """create_proof (src/groth16.rs:68): 192-byte compressed proof a||b||c."""
+        r, s = _fr_struct(r_mont4), _fr_struct(s_mont4)
+        out = np.zeros(192, dtype=np.uint8)
+        self._ck(self.lib.zk_groth16_prove_dev(self.h, pk.h, r1cs.h, C.c_void_p(int(z_dev)), C.byref(r), C.byref(s), _ptr(out)))
+        return out.tobytes()
+
+    def create_proof(self, pk: "ProvingKey", r1cs: "R1cs", z_mont: np.ndarray, r_mont4, s_mont4) -> bytes:
+        z = np.ascontiguousarray(z_mont, dtype=np.uint64)
+        assert z.shape[0] == r1cs.num_instance + r1cs.num_witness
+        r, s = _fr_struct(r_mont4), _fr_struct(s_mont4)
+        out = np.zeros(192, dtype=np.uint8)
+        self._ck(self.lib.zk_groth16_prove(self.h, pk.h, r1cs.h, _ptr(z), C.byref(r), C.byref(s), _ptr(out)))
+        return out.tobytes()
+
+
+class Bases:
+    def __init__(self, ctx: Context, h, group: int):
+        self.ctx, self.h, self.group = ctx, h, group
+
+    def __len__(self):
+        return self.ctx.lib.zk_bases_len(self.h)
+
+    def download(self, offset: int = 0, n: int = None) -> np.ndarray:
+        n = len(self) - offset if n is None else n
+        out = np.zeros((n, 12 if self.group == 1 else 24), dtype=np.uint64)
+        fn = self.ctx.lib.zk_bases_download_g1 if self.group == 1 else self.ctx.lib.zk_bases_download_g2
+        self.ctx._ck(fn(self.ctx.h, self.h, offset, n, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.zk_bases_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class R1cs:
+    def __init__(self, ctx: Context, h, nc: int, ni: int, nw: int):
+        self.ctx, self.h = ctx, h
+        self.num_constraints, self.num_instance, self.num_witness = nc, ni, nw
+
+    @property
+    def domain_log(self) -> int:
+        return self.ctx.lib.zk_r1cs_domain_log(self.h)
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.zk_r1cs_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class ProvingKey:
+    QUERIES = {"a_query": 0, "b_g1_query": 1, "b_g2_query": 2, "h_query": 3, "l_query": 4, "gamma_abc_g1": 5}
+
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.h = ctx, h
+
+    def query_len(self, name: str) -> int:
+        return self.ctx.lib.zk_pk_query_len(self.h, self.QUERIES[name])
+
+    def download(self, name: str, offset: int = 0, n: int = None) -> np.ndarray:
+        which = self.QUERIES[name]
+        n = self.query_len(name) - offset if n is None else n
+        if which == 2:
+            out = np.zeros((n, 24), dtype=np.uint64)
+            self.ctx._ck(self.ctx.lib.zk_pk_download_g2(self.ctx.h, self.h, which, offset, n, _ptr(out)))
+        else:
+            out = np.zeros((n, 12), dtype=np.uint64)
+            self.ctx._ck(self.ctx.lib.zk_pk_download_g1(self.ctx.h, self.h, which, offset, n, _ptr(out)))
+        return out
+
+    def vk_g1(self, which: int) -> np.ndarray:
+        out = np.zeros(12, dtype=np.uint64)
+        self.ctx._ck(self.ctx.lib.zk_pk_vk_g1(self.h, which, _ptr(out)))
+        return out
+
+    def vk_g2(self, which: int) -> np.ndarray:
+        out = np.zeros(24, dtype=np.uint64)
+        self.ctx._ck(self.ctx.lib.zk_pk_vk_g2(self.h, which, _ptr(out)))
+        return out
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.zk_pk_free(self.ctx.h, self.h)
+            self.h = None

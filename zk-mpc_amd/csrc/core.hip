@@ -1,0 +1,105 @@
+// core.hip -- context, device memory, scratch arena, timers.
+#include "../../include/zkmpc_hip.h"
+#include "ctx.hpp"
+#include "internal.hpp"
+#include <string.h>
+
+extern "C" int zk_version(void) { return 1; }
+
+extern "C" int zk_ctx_create(int device, int party_id, int n_parties, zk_ctx** out) {
+    if (!out || n_parties < 1 || party_id < 0 || party_id >= n_parties) return ZK_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ZK_ERR_HIP;  // no CPU fallback
+    if (device < 0 || device >= ndev) return ZK_ERR_ARG;
+    zk_ctx* c = new zk_ctx();
+    c->device = device;
+    c->party_id = party_id;
+    c->n_parties = n_parties;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return ZK_ERR_HIP;
+    }
+    *out = c;
+    return ZK_OK;
+}
+
+extern "C" int zk_ctx_destroy(zk_ctx* ctx) {
+    if (!ctx) return ZK_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->slots)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    zk_domains_free(ctx);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return ZK_OK;
+}
+
+extern "C" const char* zk_last_error(zk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+extern "C" int zk_ctx_sync(zk_ctx* ctx) {
+    if (!ctx) return ZK_ERR_ARG;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+extern "C" void* zk_ctx_stream(zk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** dev_out) {
+    if (!ctx || !dev_out) return ZK_ERR_ARG;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    ZK_HIP(ctx, hipMalloc(dev_out, bytes ? bytes : 16));
+    return ZK_OK;
+}
+
+extern "C" int zk_dev_free(zk_ctx* ctx, void* dev) {
+    if (!ctx) return ZK_ERR_ARG;
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, hipFree(dev));
+    return ZK_OK;
+}
+
+extern "C" int zk_memcpy_h2d(zk_ctx* ctx, void* dev, const void* host, size_t bytes) {
+    if (!ctx) return ZK_ERR_ARG;
+    ZK_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+extern "C" int zk_memcpy_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes) {
+    if (!ctx) return ZK_ERR_ARG;
+    ZK_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out) {
+    auto& s = ctx->slots[name];
+    if (s.bytes < bytes) {
+        if (s.p) {
+            ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ZK_HIP(ctx, hipFree(s.p));
+            s.p = nullptr;
+            s.bytes = 0;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        ZK_HIP(ctx, hipMalloc(&s.p, want));
+        s.bytes = want;
+    }
+    *out = s.p;
+    return ZK_OK;
+}
+
+extern "C" int zk_last_timers(zk_ctx* ctx, char* names, size_t name_stride, float* ms, int max_entries) {
+    if (!ctx) return ZK_ERR_ARG;
+    int k = 0;
+    for (auto& kv : ctx->timers) {
+        if (k >= max_entries) break;
+        strncpy(names + k * name_stride, kv.first.c_str(), name_stride - 1);
+        names[k * name_stride + name_stride - 1] = 0;
+        ms[k] = kv.second;
+        k++;
+    }
+    ctx->timers.clear();
+    return k;
+}

@@ -1,0 +1,68 @@
+// ctx.hpp -- per-party context of libzkmpc_hip: device, stream, error string, device arena,
+// NTT domain cache.  One context per MPC party / GPU; nothing is process-global, so several
+// parties can live in one process (the reference's LocalTestNet does that,
+// mpc-net/src/multi.rs:419-443).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#define ZK_OK 0
+#define ZK_ERR_HIP -1
+#define ZK_ERR_ARG -2
+#define ZK_ERR_NOMEM -3
+#define ZK_ERR_STATE -4
+
+struct zk_domain;  // ntt.hip
+
+struct zk_ctx {
+    int device = 0;
+    int party_id = 0;
+    int n_parties = 1;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    // grow-only scratch arena: named slots, each re-used across calls (no hipMalloc on the hot path)
+    struct Slot { void* p = nullptr; size_t bytes = 0; };
+    std::map<std::string, Slot> slots;
+    std::map<uint32_t, zk_domain*> domains;  // keyed by log2(size)
+    std::mutex mu;
+    // timing of the most recent instrumented call (ms), filled when ZK_PROFILE env or explicit request
+    std::map<std::string, float> timers;
+};
+
+#define ZK_HIP(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            char _b[512];                                                                         \
+            snprintf(_b, sizeof _b, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            (ctx)->last_error = _b;                                                               \
+            return ZK_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+#define ZK_FAIL(ctx, code, msg)         \
+    do {                                \
+        (ctx)->last_error = (msg);      \
+        return (code);                  \
+    } while (0)
+
+#define ZK_TRY(expr)                    \
+    do {                                \
+        int _r = (expr);                \
+        if (_r != ZK_OK) return _r;     \
+    } while (0)
+
+// Returns a device buffer of at least `bytes` bound to `name`; contents are unspecified.
+int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out);
+
+static inline unsigned zk_grid(size_t work, unsigned block, unsigned cap = 256 * 16) {
+    size_t g = (work + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g == 0) g = 1;
+    return (unsigned)g;
+}

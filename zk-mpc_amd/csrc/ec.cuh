@@ -1,0 +1,174 @@
+// ec.cuh -- short-Weierstrass (a = 0) group arithmetic for BLS12-377 G1 (over Fq) and G2 (over Fq2).
+//
+// Replaces (reference): arkworks/algebra/ec/src/models/short_weierstrass_jacobian.rs
+//   add_assign_mixed :628-693, double_in_place :557-623, add_assign :721-784,
+//   From<Projective> for Affine :823-845.
+// The reference accumulates in Jacobian coordinates; here the accumulators are extended Jacobian
+// "XYZZ" (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2): a mixed add is 8M+2S instead of 7M+4S and, unlike the
+// Jacobian madd, needs no field doubling chains.  The group law is the same, so every result is the
+// same group element; bit-exactness is established on the affine (canonical) form.
+//
+// Coordinates are in the device "internal" Montgomery form (fp29.cuh).
+// Point at infinity: affine (0,0) (not on either curve: b != 0); XYZZ with ZZ = 0.
+#pragma once
+#include "fp29.cuh"
+
+namespace zk {
+
+template <class F>
+struct Affine {
+    typename F::T x, y;
+};
+
+template <class F>
+struct XYZZ {
+    typename F::T x, y, zz, zzz;
+};
+
+template <class F>
+ZK_HD bool aff_is_inf(const Affine<F>& p) { return F::is_zero(p.x) && F::is_zero(p.y); }
+
+template <class F>
+ZK_HD Affine<F> aff_inf() { return Affine<F>{F::zero(), F::zero()}; }
+
+template <class F>
+ZK_HD Affine<F> aff_neg(const Affine<F>& p) { return Affine<F>{p.x, F::neg(p.y)}; }  // -(0,0) = (0,0)
+
+template <class F>
+ZK_HD XYZZ<F> xyzz_inf() { return XYZZ<F>{F::zero(), F::zero(), F::zero(), F::zero()}; }
+
+template <class F>
+ZK_HD bool xyzz_is_inf(const XYZZ<F>& p) { return F::is_zero(p.zz); }
+
+template <class F>
+ZK_HD XYZZ<F> xyzz_from_affine(const Affine<F>& p) {
+    if (aff_is_inf<F>(p)) return xyzz_inf<F>();
+    return XYZZ<F>{p.x, p.y, F::one(), F::one()};
+}
+
+template <class F>
+ZK_HD XYZZ<F> xyzz_neg(const XYZZ<F>& p) { return XYZZ<F>{p.x, F::neg(p.y), p.zz, p.zzz}; }
+
+// 2*(x,y) for an affine point that is not infinity ("mdbl-2008-s-1", a = 0).
+template <class F>
+ZK_HD XYZZ<F> xyzz_dbl_affine(const Affine<F>& p) {
+    using T = typename F::T;
+    T u = F::dbl(p.y);
+    if (F::is_zero(u)) return xyzz_inf<F>();  // order-2 point (none in the prime-order subgroups)
+    T v = F::sqr(u);
+    T w = F::mul(u, v);
+    T s = F::mul(p.x, v);
+    T xx = F::sqr(p.x);
+    T m = F::add(F::dbl(xx), xx);
+    T x3 = F::sub(F::sqr(m), F::dbl(s));
+    T y3 = F::sub(F::mul(m, F::sub(s, x3)), F::mul(w, p.y));
+    return XYZZ<F>{x3, y3, v, w};
+}
+
+// 2*P ("dbl-2008-s-1", a = 0).
+template <class F>
+ZK_HD XYZZ<F> xyzz_dbl(const XYZZ<F>& p) {
+    using T = typename F::T;
+    if (xyzz_is_inf<F>(p)) return p;
+    T u = F::dbl(p.y);
+    if (F::is_zero(u)) return xyzz_inf<F>();
+    T v = F::sqr(u);
+    T w = F::mul(u, v);
+    T s = F::mul(p.x, v);
+    T xx = F::sqr(p.x);
+    T m = F::add(F::dbl(xx), xx);
+    T x3 = F::sub(F::sqr(m), F::dbl(s));
+    T y3 = F::sub(F::mul(m, F::sub(s, x3)), F::mul(w, p.y));
+    return XYZZ<F>{x3, y3, F::mul(v, p.zz), F::mul(w, p.zzz)};
+}
+
+// acc + q, q affine ("madd-2008-s"), complete: handles acc = inf, q = inf, q = +-acc.
+template <class F>
+ZK_HD XYZZ<F> xyzz_madd(const XYZZ<F>& acc, const Affine<F>& q) {
+    using T = typename F::T;
+    if (aff_is_inf<F>(q)) return acc;
+    if (xyzz_is_inf<F>(acc)) return XYZZ<F>{q.x, q.y, F::one(), F::one()};
+    T u2 = F::mul(q.x, acc.zz);
+    T s2 = F::mul(q.y, acc.zzz);
+    T p = F::sub(u2, acc.x);
+    T r = F::sub(s2, acc.y);
+    if (F::is_zero(p)) {
+        if (F::is_zero(r)) return xyzz_dbl_affine<F>(q);
+        return xyzz_inf<F>();
+    }
+    T pp = F::sqr(p);
+    T ppp = F::mul(p, pp);
+    T qq = F::mul(acc.x, pp);
+    T x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
+    T y3 = F::sub(F::mul(r, F::sub(qq, x3)), F::mul(acc.y, ppp));
+    return XYZZ<F>{x3, y3, F::mul(acc.zz, pp), F::mul(acc.zzz, ppp)};
+}
+
+// a + b ("add-2008-s"), complete.
+template <class F>
+ZK_HD XYZZ<F> xyzz_add(const XYZZ<F>& a, const XYZZ<F>& b) {
+    using T = typename F::T;
+    if (xyzz_is_inf<F>(a)) return b;
+    if (xyzz_is_inf<F>(b)) return a;
+    T u1 = F::mul(a.x, b.zz);
+    T u2 = F::mul(b.x, a.zz);
+    T s1 = F::mul(a.y, b.zzz);
+    T s2 = F::mul(b.y, a.zzz);
+    T p = F::sub(u2, u1);
+    T r = F::sub(s2, s1);
+    if (F::is_zero(p)) {
+        if (F::is_zero(r)) return xyzz_dbl<F>(a);
+        return xyzz_inf<F>();
+    }
+    T pp = F::sqr(p);
+    T ppp = F::mul(p, pp);
+    T qq = F::mul(u1, pp);
+    T x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
+    T y3 = F::sub(F::mul(r, F::sub(qq, x3)), F::mul(s1, ppp));
+    return XYZZ<F>{x3, y3, F::mul(F::mul(a.zz, b.zz), pp), F::mul(F::mul(a.zzz, b.zzz), ppp)};
+}
+
+// Canonical affine form (one field inversion).
+template <class F>
+ZK_HD Affine<F> xyzz_to_affine(const XYZZ<F>& p) {
+    using T = typename F::T;
+    if (xyzz_is_inf<F>(p)) return aff_inf<F>();
+    // 1/ZZZ, then 1/ZZ = ZZZ^-1 * ZZZ * ZZ^-1 ... cheaper: zi3 = 1/ZZZ ; zi2 = (zi3 * ZZ)^2 since ZZ^3 = ZZZ^2
+    T zi3 = F::inv(p.zzz);
+    T zi = F::mul(zi3, p.zz);  // = ZZ/ZZZ = 1/Z
+    T zi2 = F::sqr(zi);        // = 1/ZZ
+    return Affine<F>{F::mul(p.x, zi2), F::mul(p.y, zi3)};
+}
+
+// k * P by double-and-add, MSB first, k given as `nwords` 32-bit words (plain integer).
+template <class F>
+ZK_HD XYZZ<F> xyzz_scalar_mul(const Affine<F>& p, const uint32_t* k, int nwords) {
+    XYZZ<F> r = xyzz_inf<F>();
+    for (int i = nwords - 1; i >= 0; i--)
+        for (int b = 31; b >= 0; b--) {
+            r = xyzz_dbl<F>(r);
+            if ((k[i] >> b) & 1) r = xyzz_madd<F>(r, p);
+        }
+    return r;
+}
+
+// ---- packed memory formats (internal Montgomery form, 32-bit words) ----
+//  affine: x | y                        (2 * F::WORDS words)  G1: 96 B, G2: 192 B
+//  xyzz  : x | y | zz | zzz             (4 * F::WORDS words)  G1: 192 B, G2: 384 B
+template <class F>
+ZK_HD Affine<F> aff_load(const uint32_t* w) { return Affine<F>{F::load(w), F::load(w + F::WORDS)}; }
+template <class F>
+ZK_HD void aff_store(uint32_t* w, const Affine<F>& p) { F::store(w, p.x); F::store(w + F::WORDS, p.y); }
+template <class F>
+ZK_HD XYZZ<F> xyzz_load(const uint32_t* w) {
+    return XYZZ<F>{F::load(w), F::load(w + F::WORDS), F::load(w + 2 * F::WORDS), F::load(w + 3 * F::WORDS)};
+}
+template <class F>
+ZK_HD void xyzz_store(uint32_t* w, const XYZZ<F>& p) {
+    F::store(w, p.x); F::store(w + F::WORDS, p.y); F::store(w + 2 * F::WORDS, p.zz); F::store(w + 3 * F::WORDS, p.zzz);
+}
+
+using G1Field = FqField;
+using G2Field = Fq2Field;
+
+}  // namespace zk

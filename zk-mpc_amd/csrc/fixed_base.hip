@@ -1,0 +1,131 @@
+// fixed_base.hip -- batch fixed-base scalar multiplication out[i] = s_i * g and batch normalisation.
+//
+// Replaces FixedBaseMSM::{get_window_table, multi_scalar_mul} (arkworks/algebra/ec/src/msm/fixed_base.rs:11-95)
+// and ProjectiveCurve::batch_normalization_into_affine (ec/src/models/short_weierstrass_jacobian.rs:536-550)
+// as used by generate_parameters (arkworks/groth16/src/generator.rs:130-215).  Setup-side only: it
+// produces the proving-key queries on the device (the bench's and the tests' input), it is not on
+// the proving path.
+//
+// 8-bit windows: table[j][d] = d * 2^(8 j) * g (32 x 256 affine points), one thread per scalar does
+// 32 mixed additions; normalisation is Montgomery's trick over chunks of 16 points per thread
+// (one field inversion per chunk).
+#include "../../include/zkmpc_hip.h"
+#include "devutil.cuh"
+#include "internal.hpp"
+
+using namespace zk;
+
+namespace {
+
+constexpr int FB_WINDOWS = 32;  // 8-bit windows over 256 bits
+constexpr int NORM_CHUNK = 16;
+
+template <class F>
+struct AffArg { uint32_t w[2 * F::WORDS]; };
+
+template <class F>
+__global__ void __launch_bounds__(64) k_fb_table(uint32_t* table, AffArg<F> gen) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= FB_WINDOWS * 256) return;
+    uint32_t j = t >> 8, d = t & 255;
+    Affine<F> g = aff_load<F>(gen.w);
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    k[j >> 2] = d << (8 * (j & 3));
+    XYZZ<F> r = xyzz_scalar_mul<F>(g, k, (int)(j >> 2) + 1);
+    aff_store16<F>(table, t, xyzz_to_affine<F>(r));
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_fixed_base(const uint32_t* __restrict__ table, const void* scalars, size_t n, uint32_t* out_xyzz) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = fp_ext_to_canon<FrParams>(fr_load(scalars, i));
+    uint32_t w[8];
+    fp_pack<FrParams>(w, s);
+    XYZZ<F> acc = xyzz_inf<F>();
+#pragma unroll 1
+    for (int j = 0; j < FB_WINDOWS; j++) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) word = (j >> 2) == q ? w[q] : word;
+        uint32_t d = (word >> (8 * (j & 3))) & 255;
+        if (d) acc = xyzz_madd<F>(acc, aff_load16<F>(table, (size_t)j * 256 + d));
+    }
+    xyzz_store16<F>(out_xyzz, i, acc);
+}
+
+// Montgomery's trick on ZZZ over a chunk; scratch holds the running products.
+template <class F>
+__global__ void __launch_bounds__(64) k_batch_affine(const uint32_t* in_xyzz, uint32_t* out_aff, uint32_t* scratch, size_t n) {
+    using T = typename F::T;
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t lo = t * NORM_CHUNK;
+    if (lo >= n) return;
+    size_t hi = lo + NORM_CHUNK < n ? lo + NORM_CHUNK : n;
+    T run = F::one();
+    for (size_t i = lo; i < hi; i++) {
+        felt_store16<F>(scratch + i * F::WORDS, run);  // product of the non-zero zzz before i
+        T zzz = felt_load16<F>(in_xyzz + i * 4 * F::WORDS + 3 * F::WORDS);
+        if (!F::is_zero(zzz)) run = F::mul(run, zzz);
+    }
+    T inv = F::inv(run);
+    for (size_t i = hi; i-- > lo;) {
+        XYZZ<F> p = xyzz_load16<F>(in_xyzz, i);
+        if (xyzz_is_inf<F>(p)) {
+            aff_store16<F>(out_aff, i, aff_inf<F>());
+            continue;
+        }
+        T before = felt_load16<F>(scratch + i * F::WORDS);
+        T zi3 = F::mul(inv, before);   // 1/zzz_i
+        inv = F::mul(inv, p.zzz);
+        T zi = F::mul(zi3, p.zz);      // 1/z
+        T zi2 = F::sqr(zi);            // 1/zz
+        aff_store16<F>(out_aff, i, Affine<F>{F::mul(p.x, zi2), F::mul(p.y, zi3)});
+    }
+}
+
+Affine<G1Field> g1_generator() {
+    return Affine<G1Field>{fp_const<FqParams>(FqParams::G1_GEN_X), fp_const<FqParams>(FqParams::G1_GEN_Y)};
+}
+Affine<G2Field> g2_generator() {
+    return Affine<G2Field>{Fq2{fp_const<FqParams>(FqParams::G2_GEN_X0), fp_const<FqParams>(FqParams::G2_GEN_X1)},
+                           Fq2{fp_const<FqParams>(FqParams::G2_GEN_Y0), fp_const<FqParams>(FqParams::G2_GEN_Y1)}};
+}
+
+template <class F>
+int fixed_base_run(zk_ctx* ctx, const Affine<F>& gen_base, const zk_fr* gen_k, const void* scalars, size_t n, int group, zk_bases** out) {
+    if (!ctx || !gen_k || !out || (n && !scalars)) return ZK_ERR_ARG;
+    Fr k = fp_ext_to_canon<FrParams>(host_load_ext<FrParams>(gen_k->l));
+    uint32_t kw[8];
+    fp_pack<FrParams>(kw, k);
+    Affine<F> g = xyzz_to_affine<F>(xyzz_scalar_mul<F>(gen_base, kw, 8));
+    AffArg<F> ga;
+    aff_store<F>(ga.w, g);
+
+    zk_bases* b = new zk_bases();
+    b->group = group;
+    b->n = n;
+    *out = b;
+    if (!n) return ZK_OK;
+    uint32_t *table, *xy, *scr;
+    ZK_TRY(zk_scratch(ctx, "fb_table", (size_t)FB_WINDOWS * 256 * 2 * F::WORDS * 4, (void**)&table));
+    ZK_TRY(zk_scratch(ctx, "fb_xyzz", n * 4 * F::WORDS * 4, (void**)&xy));
+    ZK_TRY(zk_scratch(ctx, "fb_scr", n * F::WORDS * 4, (void**)&scr));
+    if (hipMalloc((void**)&b->dev, n * 2 * F::WORDS * 4) != hipSuccess) { delete b; *out = nullptr; ZK_FAIL(ctx, ZK_ERR_NOMEM, "fixed base: hipMalloc failed"); }
+    hipLaunchKernelGGL(k_fb_table<F>, FB_WINDOWS * 256 / 64, 64, 0, ctx->stream, table, ga);
+    hipLaunchKernelGGL(k_fixed_base<F>, (unsigned)((n + 255) / 256), 256, 0, ctx->stream, table, scalars, n, xy);
+    size_t chunks = (n + NORM_CHUNK - 1) / NORM_CHUNK;
+    hipLaunchKernelGGL(k_batch_affine<F>, (unsigned)((chunks + 63) / 64), 64, 0, ctx->stream, xy, b->dev, scr, n);
+    ZK_HIP(ctx, hipGetLastError());
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" int zk_fixed_base_g1_dev(zk_ctx* ctx, const zk_fr* gen_k, const void* scalars, size_t n, zk_bases** out) {
+    return fixed_base_run<G1Field>(ctx, g1_generator(), gen_k, scalars, n, 1, out);
+}
+extern "C" int zk_fixed_base_g2_dev(zk_ctx* ctx, const zk_fr* gen_k, const void* scalars, size_t n, zk_bases** out) {
+    return fixed_base_run<G2Field>(ctx, g2_generator(), gen_k, scalars, n, 2, out);
+}

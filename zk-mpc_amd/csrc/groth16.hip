@@ -1,0 +1,502 @@
+// groth16.hip -- R1CS -> QAP witness map, Groth16 prover and known-trapdoor setup on the device.
+//
+// Replaces (reference):
+//   R1CStoQAP::witness_map + evaluate_constraint      src/groth16.rs:205-306
+//                                                     (stock: arkworks/groth16/src/r1cs_to_qap.rs:94-160)
+//   create_proof / calculate_coeff                    src/groth16.rs:68-201 (stock prover.rs:44-153,189-203)
+//   generate_parameters                               arkworks/groth16/src/generator.rs:44-231
+//   R1CStoQAP::instance_map_with_evaluation           arkworks/groth16/src/r1cs_to_qap.rs:47-92
+//   ConstraintMatrices                                arkworks/snark/relations/src/r1cs/constraint_system.rs:650-676
+//
+// Device layout: the three matrices are CSR (row_ptr u32, col u32, coeff = Fr in the device's
+// internal Montgomery form so coeff * z needs no conversion); assignment, QAP vectors and h are
+// Fr vectors in the reference's form.  The proving key's five queries are zk_bases tables.
+#include "../../include/zkmpc_hip.h"
+#include "devutil.cuh"
+#include "hostgroup.hpp"
+#include "internal.hpp"
+#include <vector>
+
+using namespace zk;
+
+struct zk_r1cs {
+    size_t nc = 0, ni = 0, nw = 0;
+    uint32_t log_d = 0;
+    struct Mat {
+        uint32_t* row_ptr = nullptr;
+        uint32_t* col = nullptr;
+        uint32_t* coeff = nullptr;  // nnz * 8 words, internal form
+        size_t nnz = 0;
+        bool all_one = false;       // every coefficient is 1: the product is skipped (src/groth16.rs:220-224)
+        std::vector<uint32_t> h_row_ptr, h_col;
+        std::vector<Fr> h_coeff;    // internal form (empty when all_one)
+    } m[3];
+};
+
+struct zk_pk {
+    zk_bases *a = nullptr, *b_g1 = nullptr, *b_g2 = nullptr, *h = nullptr, *l = nullptr, *gamma_abc = nullptr;
+    Affine<G1Field> alpha_g1, beta_g1, delta_g1, a0, b0_g1;
+    Affine<G2Field> beta_g2, delta_g2, gamma_g2, b0_g2;
+};
+
+namespace {
+
+uint32_t domain_log(size_t num_coeffs) {
+    uint32_t lg = 0;
+    while (((size_t)1 << lg) < num_coeffs) lg++;
+    return lg;
+}
+
+// out[row] = sum_k coeff[k] * z[col[k]]  for row < nc;  out[nc + i] = z[i] for i < n_copy; rest 0.
+__global__ void __launch_bounds__(256)
+k_spmv(const uint32_t* row_ptr, const uint32_t* col, const uint32_t* coeff, int all_one, const void* z, size_t nc,
+       size_t n_copy, size_t D, void* out) {
+    for (size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x; r < D; r += (size_t)gridDim.x * blockDim.x) {
+        Fr acc = fp_zero<FrParams>();
+        if (r < nc) {
+            uint32_t lo = row_ptr[r], hi = row_ptr[r + 1];
+            for (uint32_t k = lo; k < hi; k++) {
+                Fr v = fr_load(z, col[k]);
+                if (!all_one) v = fr_mul(v, fr_load(coeff, k));
+                acc = fr_add(acc, v);
+            }
+        } else if (r < nc + n_copy) {
+            acc = fr_load(z, r - nc);
+        }
+        fr_store(out, r, acc);
+    }
+}
+
+int upload_mat(zk_ctx* ctx, zk_r1cs::Mat& m, size_t nc, const uint32_t* rp, const uint32_t* col, const zk_fr* coeff) {
+    m.nnz = rp[nc];
+    m.h_row_ptr.assign(rp, rp + nc + 1);
+    m.h_col.assign(col, col + m.nnz);
+    m.h_coeff.resize(m.nnz);
+    const Fr one = fp_one<FrParams>();
+    m.all_one = true;
+    for (size_t k = 0; k < m.nnz; k++) {
+        m.h_coeff[k] = fp_ext_to_int<FrParams>(host_load_ext<FrParams>(coeff[k].l));
+        if (!fp_eq<FrParams>(m.h_coeff[k], one)) m.all_one = false;
+    }
+    ZK_HIP(ctx, hipMalloc((void**)&m.row_ptr, (nc + 1) * 4));
+    ZK_HIP(ctx, hipMalloc((void**)&m.col, (m.nnz ? m.nnz : 1) * 4));
+    ZK_HIP(ctx, hipMemcpy(m.row_ptr, rp, (nc + 1) * 4, hipMemcpyHostToDevice));
+    if (m.nnz) ZK_HIP(ctx, hipMemcpy(m.col, col, m.nnz * 4, hipMemcpyHostToDevice));
+    if (!m.all_one) {
+        std::vector<uint32_t> packed(m.nnz * 8);
+        for (size_t k = 0; k < m.nnz; k++) fp_pack<FrParams>(&packed[8 * k], m.h_coeff[k]);
+        ZK_HIP(ctx, hipMalloc((void**)&m.coeff, m.nnz * 32));
+        ZK_HIP(ctx, hipMemcpy(m.coeff, packed.data(), m.nnz * 32, hipMemcpyHostToDevice));
+    } else {
+        m.h_coeff.clear();
+        m.h_coeff.shrink_to_fit();
+    }
+    return ZK_OK;
+}
+
+int spmv(zk_ctx* ctx, const zk_r1cs* r, int which, const void* z, size_t n_copy, void* out) {
+    const auto& m = r->m[which];
+    size_t D = (size_t)1 << r->log_d;
+    hipLaunchKernelGGL(k_spmv, zk_grid(D, 256), 256, 0, ctx->stream, m.row_ptr, m.col, m.coeff, m.all_one ? 1 : 0, z, r->nc,
+                       n_copy, D, out);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+Fr host_fr_from_u64(uint64_t v) {
+    Fr t = fp_zero<FrParams>();
+    t.l[0] = (uint32_t)(v & MASK29);
+    t.l[1] = (uint32_t)((v >> 29) & MASK29);
+    t.l[2] = (uint32_t)(v >> 58);
+    return fp_canon_to_int<FrParams>(t);
+}
+
+Fr host_fr_pow(const Fr& a, uint64_t e) {
+    Fr r = fp_one<FrParams>();
+    bool started = false;
+    for (int b = 63; b >= 0; b--) {
+        if (started) r = fp_sqr<FrParams>(r);
+        if ((e >> b) & 1) { r = started ? fp_mul<FrParams>(r, a) : a; started = true; }
+    }
+    return r;
+}
+
+void host_batch_inverse(std::vector<Fr>& v) {  // Montgomery's trick (ff/src/fields/mod.rs:597-659); zeros stay zero
+    std::vector<Fr> pre(v.size());
+    Fr run = fp_one<FrParams>();
+    for (size_t i = 0; i < v.size(); i++) {
+        pre[i] = run;
+        if (!fp_is_zero<FrParams>(v[i])) run = fp_mul<FrParams>(run, v[i]);
+    }
+    Fr inv = fp_inv<FrParams>(run);
+    for (size_t i = v.size(); i-- > 0;) {
+        if (fp_is_zero<FrParams>(v[i])) continue;
+        Fr t = fp_mul<FrParams>(inv, pre[i]);
+        inv = fp_mul<FrParams>(inv, v[i]);
+        v[i] = t;
+    }
+}
+
+// upload a host vector of internal-form Fr as reference-form device vector
+int upload_fr(zk_ctx* ctx, const std::vector<Fr>& v, const char* slot, void** dev) {
+    std::vector<uint32_t> packed(v.size() * 8 + 8);
+    for (size_t i = 0; i < v.size(); i++) fp_pack<FrParams>(&packed[8 * i], fp_int_to_ext<FrParams>(v[i]));
+    ZK_TRY(zk_scratch(ctx, slot, v.size() * 32 + 32, dev));
+    ZK_HIP(ctx, hipMemcpyAsync(*dev, packed.data(), v.size() * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+template <class F>
+Affine<F> host_gen_mul(const Affine<F>& g, const Fr& k_int) {
+    uint32_t kw[8];
+    fp_pack<FrParams>(kw, fp_int_to_canon<FrParams>(k_int));
+    return xyzz_to_affine<F>(xyzz_scalar_mul<F>(g, kw, 8));
+}
+
+Affine<G1Field> g1_gen() { return Affine<G1Field>{fp_const<FqParams>(FqParams::G1_GEN_X), fp_const<FqParams>(FqParams::G1_GEN_Y)}; }
+Affine<G2Field> g2_gen() {
+    return Affine<G2Field>{Fq2{fp_const<FqParams>(FqParams::G2_GEN_X0), fp_const<FqParams>(FqParams::G2_GEN_X1)},
+                           Fq2{fp_const<FqParams>(FqParams::G2_GEN_Y0), fp_const<FqParams>(FqParams::G2_GEN_Y1)}};
+}
+
+template <class F>
+int first_point(zk_ctx* ctx, const zk_bases* b, Affine<F>* out) {
+    if (!b || b->n == 0) { *out = aff_inf<F>(); return ZK_OK; }
+    uint32_t w[2 * F::WORDS];
+    ZK_HIP(ctx, hipMemcpy(w, b->dev, sizeof w, hipMemcpyDeviceToHost));
+    *out = aff_load<F>(w);
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" uint32_t zk_r1cs_domain_log(const zk_r1cs* r) { return r ? r->log_d : 0; }
+
+extern "C" int zk_r1cs_upload(zk_ctx* ctx, const zk_r1cs_host* h, zk_r1cs** out) {
+    if (!ctx || !h || !out || h->num_instance == 0) return ZK_ERR_ARG;
+    zk_r1cs* r = new zk_r1cs();
+    r->nc = h->num_constraints; r->ni = h->num_instance; r->nw = h->num_witness;
+    r->log_d = domain_log(r->nc + r->ni);  // src/groth16.rs:256-257
+    int rc = upload_mat(ctx, r->m[0], r->nc, h->a_row_ptr, h->a_col, h->a_coeff);
+    if (rc == ZK_OK) rc = upload_mat(ctx, r->m[1], r->nc, h->b_row_ptr, h->b_col, h->b_coeff);
+    if (rc == ZK_OK) rc = upload_mat(ctx, r->m[2], r->nc, h->c_row_ptr, h->c_col, h->c_coeff);
+    if (rc != ZK_OK) { zk_r1cs_free(ctx, r); return rc; }
+    *out = r;
+    return ZK_OK;
+}
+
+extern "C" int zk_r1cs_free(zk_ctx* ctx, zk_r1cs* r) {
+    if (!r) return ZK_OK;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& m : r->m) {
+        if (m.row_ptr) (void)hipFree(m.row_ptr);
+        if (m.col) (void)hipFree(m.col);
+        if (m.coeff) (void)hipFree(m.coeff);
+    }
+    delete r;
+    return ZK_OK;
+}
+
+extern "C" int zk_r1cs_mul_chain(zk_ctx* ctx, size_t n, zk_r1cs** out) {
+    if (!ctx || !out || n == 0 || n > ((size_t)1 << 27)) return ZK_ERR_ARG;
+    // variables: [1, pub] ++ witness[w_0..w_n]; w_{n+1} is the public input (index 1)
+    auto idx = [n](size_t j) -> uint32_t { return j <= n ? (uint32_t)(2 + j) : 1u; };
+    std::vector<uint32_t> rp(n + 1), ca(n), cb(n), cc(n);
+    for (size_t i = 0; i <= n; i++) rp[i] = (uint32_t)i;
+    for (size_t i = 0; i < n; i++) { ca[i] = idx(i); cb[i] = idx(i + 1); cc[i] = idx(i + 2); }
+    zk_fr one_ext;
+    host_store_ext<FrParams>(one_ext.l, fp_int_to_ext<FrParams>(fp_one<FrParams>()));
+    std::vector<zk_fr> ones(n, one_ext);
+    zk_r1cs_host h;
+    h.num_constraints = n; h.num_instance = 2; h.num_witness = n + 1;
+    h.a_row_ptr = h.b_row_ptr = h.c_row_ptr = rp.data();
+    h.a_col = ca.data(); h.b_col = cb.data(); h.c_col = cc.data();
+    h.a_coeff = h.b_coeff = h.c_coeff = ones.data();
+    return zk_r1cs_upload(ctx, &h, out);
+}
+
+extern "C" int zk_mul_chain_assignment_dev(zk_ctx* ctx, size_t n, const zk_fr* w0, const zk_fr* w1, void* z_dev) {
+    if (!ctx || !w0 || !w1 || !z_dev || n == 0) return ZK_ERR_ARG;
+    // the chain is inherently sequential: computed on the host (input generation, not on the proving path)
+    std::vector<Fr> w(n + 2);
+    w[0] = fp_ext_to_int<FrParams>(host_load_ext<FrParams>(w0->l));
+    w[1] = fp_ext_to_int<FrParams>(host_load_ext<FrParams>(w1->l));
+    for (size_t i = 0; i < n; i++) w[i + 2] = fp_mul<FrParams>(w[i], w[i + 1]);
+    std::vector<uint32_t> packed((n + 3) * 8);
+    fp_pack<FrParams>(&packed[0], fp_int_to_ext<FrParams>(fp_one<FrParams>()));
+    fp_pack<FrParams>(&packed[8], fp_int_to_ext<FrParams>(w[n + 1]));
+    for (size_t j = 0; j <= n; j++) fp_pack<FrParams>(&packed[8 * (2 + j)], fp_int_to_ext<FrParams>(w[j]));
+    ZK_HIP(ctx, hipMemcpyAsync(z_dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+// ---- witness map -----------------------------------------------------------------------------
+
+extern "C" int zk_groth16_witness_map_pre_dev(zk_ctx* ctx, const zk_r1cs* r, const void* z, int include_instance, void* a,
+                                              void* b, void* c) {
+    if (!ctx || !r || !z || !a || !b || !c) return ZK_ERR_ARG;
+    // a[nc..nc+ni] = instance assignment (src/groth16.rs:272-276).  For shares, z already holds each
+    // party's share of the instance (the leader holds the public value, the others zero), so the
+    // copy is the same linear operation; include_instance=0 lets a caller suppress it.
+    ZK_TRY(spmv(ctx, r, 0, z, include_instance ? r->ni : 0, a));
+    ZK_TRY(spmv(ctx, r, 1, z, 0, b));
+    ZK_TRY(spmv(ctx, r, 2, z, 0, c));
+    void* v[3] = {a, b, c};
+    for (int k = 0; k < 3; k++) {
+        ZK_TRY(zk_ntt_launch(ctx, v[k], r->log_d, 1, 0));  // ifft          (:278-279,295)
+        ZK_TRY(zk_ntt_launch(ctx, v[k], r->log_d, 0, 1));  // coset_fft     (:281-282,296)
+    }
+    return ZK_OK;
+}
+
+extern "C" int zk_groth16_witness_map_post_dev(zk_ctx* ctx, const zk_r1cs* r, void* ab, const void* c) {
+    if (!ctx || !r || !ab || !c) return ZK_ERR_ARG;
+    uint32_t zinv[9];
+    ZK_TRY(zk_ntt_vanishing_inv(ctx, r->log_d, zinv));
+    ZK_TRY(zk_vec_sub_scale_launch(ctx, ab, c, zinv, ab, (size_t)1 << r->log_d));  // (ab - c) / Z(g)   (:298-302)
+    return zk_ntt_launch(ctx, ab, r->log_d, 1, 1);                                   // coset_ifft        (:303)
+}
+
+extern "C" int zk_groth16_witness_map_dev(zk_ctx* ctx, const zk_r1cs* r, const void* z, void* h) {
+    if (!ctx || !r || !z || !h) return ZK_ERR_ARG;
+    size_t D = (size_t)1 << r->log_d;
+    void *b, *c;
+    ZK_TRY(zk_scratch(ctx, "wm_b", D * 32, &b));
+    ZK_TRY(zk_scratch(ctx, "wm_c", D * 32, &c));
+    ZK_TRY(zk_groth16_witness_map_pre_dev(ctx, r, z, 1, h, b, c));
+    ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_MUL, h, b, h, D));  // batch_product_in_place (:285)
+    return zk_groth16_witness_map_post_dev(ctx, r, h, c);
+}
+
+// ---- proving key -----------------------------------------------------------------------------
+
+extern "C" int zk_pk_free(zk_ctx* ctx, zk_pk* pk) {
+    if (!pk) return ZK_OK;
+    zk_bases* all[6] = {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l, pk->gamma_abc};
+    for (auto* b : all) zk_bases_free(ctx, b);
+    delete pk;
+    return ZK_OK;
+}
+
+extern "C" int zk_pk_upload(zk_ctx* ctx, const zk_pk_host* h, zk_pk** out) {
+    if (!ctx || !h || !out) return ZK_ERR_ARG;
+    zk_pk* pk = new zk_pk();
+    int rc = zk_bases_upload_g1(ctx, h->a_query, h->a_len, &pk->a);
+    if (rc == ZK_OK) rc = zk_bases_upload_g1(ctx, h->b_g1_query, h->b_g1_len, &pk->b_g1);
+    if (rc == ZK_OK) rc = zk_bases_upload_g2(ctx, h->b_g2_query, h->b_g2_len, &pk->b_g2);
+    if (rc == ZK_OK) rc = zk_bases_upload_g1(ctx, h->h_query, h->h_len, &pk->h);
+    if (rc == ZK_OK) rc = zk_bases_upload_g1(ctx, h->l_query, h->l_len, &pk->l);
+    if (rc != ZK_OK) { zk_pk_free(ctx, pk); return rc; }
+    pk->alpha_g1 = host_aff_from_abi<G1Field>((const uint64_t*)&h->alpha_g1);
+    pk->beta_g1 = host_aff_from_abi<G1Field>((const uint64_t*)&h->beta_g1);
+    pk->delta_g1 = host_aff_from_abi<G1Field>((const uint64_t*)&h->delta_g1);
+    pk->beta_g2 = host_aff_from_abi<G2Field>((const uint64_t*)&h->beta_g2);
+    pk->delta_g2 = host_aff_from_abi<G2Field>((const uint64_t*)&h->delta_g2);
+    pk->gamma_g2 = aff_inf<G2Field>();
+    pk->a0 = h->a_len ? host_aff_from_abi<G1Field>((const uint64_t*)&h->a_query[0]) : aff_inf<G1Field>();
+    pk->b0_g1 = h->b_g1_len ? host_aff_from_abi<G1Field>((const uint64_t*)&h->b_g1_query[0]) : aff_inf<G1Field>();
+    pk->b0_g2 = h->b_g2_len ? host_aff_from_abi<G2Field>((const uint64_t*)&h->b_g2_query[0]) : aff_inf<G2Field>();
+    *out = pk;
+    return ZK_OK;
+}
+
+extern "C" size_t zk_pk_query_len(const zk_pk* pk, int which) {
+    if (!pk) return 0;
+    const zk_bases* all[6] = {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l, pk->gamma_abc};
+    return (which >= 0 && which < 6 && all[which]) ? all[which]->n : 0;
+}
+extern "C" int zk_pk_download_g1(zk_ctx* ctx, const zk_pk* pk, int which, size_t off, size_t n, zk_g1_affine* out) {
+    if (!pk || which == 2 || which < 0 || which > 5) return ZK_ERR_ARG;
+    const zk_bases* all[6] = {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l, pk->gamma_abc};
+    return zk_bases_download_g1(ctx, all[which], off, n, out);
+}
+extern "C" int zk_pk_download_g2(zk_ctx* ctx, const zk_pk* pk, int which, size_t off, size_t n, zk_g2_affine* out) {
+    if (!pk || which != 2) return ZK_ERR_ARG;
+    return zk_bases_download_g2(ctx, pk->b_g2, off, n, out);
+}
+extern "C" int zk_pk_vk_g1(const zk_pk* pk, int which, zk_g1_affine* out) {
+    if (!pk || !out || which < 0 || which > 2) return ZK_ERR_ARG;
+    const Affine<G1Field>* v[3] = {&pk->alpha_g1, &pk->beta_g1, &pk->delta_g1};
+    host_aff_to_abi<G1Field>((uint64_t*)out, *v[which]);
+    return ZK_OK;
+}
+extern "C" int zk_pk_vk_g2(const zk_pk* pk, int which, zk_g2_affine* out) {
+    if (!pk || !out || which < 0 || which > 2) return ZK_ERR_ARG;
+    const Affine<G2Field>* v[3] = {&pk->beta_g2, &pk->delta_g2, &pk->gamma_g2};
+    host_aff_to_abi<G2Field>((uint64_t*)out, *v[which]);
+    return ZK_OK;
+}
+
+// generate_parameters with explicit toxic waste (generator.rs:44-231)
+extern "C" int zk_groth16_setup(zk_ctx* ctx, const zk_r1cs* r, const zk_fr* alpha_, const zk_fr* beta_, const zk_fr* gamma_,
+                                const zk_fr* delta_, const zk_fr* tau_, const zk_fr* g1_k, const zk_fr* g2_k, zk_pk** out) {
+    if (!ctx || !r || !alpha_ || !beta_ || !gamma_ || !delta_ || !tau_ || !g1_k || !g2_k || !out) return ZK_ERR_ARG;
+    auto ld = [](const zk_fr* x) { return fp_ext_to_int<FrParams>(host_load_ext<FrParams>(x->l)); };
+    const Fr alpha = ld(alpha_), beta = ld(beta_), gamma = ld(gamma_), delta = ld(delta_), t = ld(tau_);
+    const Fr one = fp_one<FrParams>();
+    const size_t D = (size_t)1 << r->log_d, nc = r->nc, ni = r->ni;
+    const size_t nvars = (ni - 1) + r->nw;
+    if (fp_is_zero<FrParams>(gamma) || fp_is_zero<FrParams>(delta)) ZK_FAIL(ctx, ZK_ERR_ARG, "setup: gamma/delta must be non-zero");
+
+    // domain constants
+    Fr w = fp_const<FrParams>(FrParams::TWO_ADIC_ROOT);
+    for (uint32_t i = 0; i < (uint32_t)FR_TWO_ADICITY - r->log_d; i++) w = fp_sqr<FrParams>(w);
+    const Fr size_inv = fp_inv<FrParams>(host_fr_from_u64(D));
+    const Fr zt = fp_sub<FrParams>(host_fr_pow(t, D), one);  // evaluate_vanishing_polynomial(t)
+    if (fp_is_zero<FrParams>(zt)) ZK_FAIL(ctx, ZK_ERR_ARG, "setup: tau lies in the evaluation domain");
+
+    // evaluate_all_lagrange_coefficients(t): u_i = (zt/D) w^i / (t - w^i)   (radix2/mod.rs:116-165)
+    std::vector<Fr> u(D), den(D);
+    {
+        Fr l = fp_mul<FrParams>(zt, size_inv), rr = one;
+        for (size_t i = 0; i < D; i++) {
+            den[i] = fp_sub<FrParams>(t, rr);
+            u[i] = l;
+            l = fp_mul<FrParams>(l, w);
+            rr = fp_mul<FrParams>(rr, w);
+        }
+        host_batch_inverse(den);
+        for (size_t i = 0; i < D; i++) u[i] = fp_mul<FrParams>(u[i], den[i]);
+        den.clear(); den.shrink_to_fit();
+    }
+    // instance_map_with_evaluation (r1cs_to_qap.rs:47-92)
+    std::vector<Fr> a(nvars + 1, fp_zero<FrParams>()), b(nvars + 1, fp_zero<FrParams>()), c(nvars + 1, fp_zero<FrParams>());
+    for (size_t i = 0; i < ni; i++) a[i] = u[nc + i];
+    std::vector<Fr>* abc[3] = {&a, &b, &c};
+    for (int k = 0; k < 3; k++) {
+        const auto& m = r->m[k];
+        auto& dst = *abc[k];
+        for (size_t i = 0; i < nc; i++)
+            for (uint32_t e = m.h_row_ptr[i]; e < m.h_row_ptr[i + 1]; e++) {
+                Fr term = m.all_one ? u[i] : fp_mul<FrParams>(u[i], m.h_coeff[e]);
+                dst[m.h_col[e]] = fp_add<FrParams>(dst[m.h_col[e]], term);
+            }
+    }
+    u.clear(); u.shrink_to_fit();
+    const Fr gamma_inv = fp_inv<FrParams>(gamma), delta_inv = fp_inv<FrParams>(delta);
+    std::vector<Fr> gamma_abc(ni), l(nvars + 1 - ni);
+    for (size_t i = 0; i <= nvars; i++) {
+        Fr s = fp_add<FrParams>(fp_add<FrParams>(fp_mul<FrParams>(beta, a[i]), fp_mul<FrParams>(alpha, b[i])), c[i]);
+        if (i < ni) gamma_abc[i] = fp_mul<FrParams>(s, gamma_inv);
+        else l[i - ni] = fp_mul<FrParams>(s, delta_inv);
+    }
+    c.clear(); c.shrink_to_fit();
+    std::vector<Fr> hq(D - 1);
+    {
+        Fr p = fp_mul<FrParams>(zt, delta_inv);
+        for (size_t i = 0; i + 1 < D; i++) { hq[i] = p; p = fp_mul<FrParams>(p, t); }
+    }
+
+    zk_pk* pk = new zk_pk();
+    void* dev;
+    int rc = upload_fr(ctx, a, "setup_scalars", &dev);
+    if (rc == ZK_OK) rc = zk_fixed_base_g1_dev(ctx, g1_k, dev, a.size(), &pk->a);
+    if (rc == ZK_OK) rc = upload_fr(ctx, b, "setup_scalars", &dev);
+    if (rc == ZK_OK) rc = zk_fixed_base_g1_dev(ctx, g1_k, dev, b.size(), &pk->b_g1);
+    if (rc == ZK_OK) rc = zk_fixed_base_g2_dev(ctx, g2_k, dev, b.size(), &pk->b_g2);
+    if (rc == ZK_OK) rc = upload_fr(ctx, hq, "setup_scalars", &dev);
+    if (rc == ZK_OK) rc = zk_fixed_base_g1_dev(ctx, g1_k, dev, hq.size(), &pk->h);
+    if (rc == ZK_OK) rc = upload_fr(ctx, l, "setup_scalars", &dev);
+    if (rc == ZK_OK) rc = zk_fixed_base_g1_dev(ctx, g1_k, dev, l.size(), &pk->l);
+    if (rc == ZK_OK) rc = upload_fr(ctx, gamma_abc, "setup_scalars", &dev);
+    if (rc == ZK_OK) rc = zk_fixed_base_g1_dev(ctx, g1_k, dev, gamma_abc.size(), &pk->gamma_abc);
+    if (rc != ZK_OK) { zk_pk_free(ctx, pk); return rc; }
+
+    const Fr k1 = ld(g1_k), k2 = ld(g2_k);
+    const Affine<G1Field> g1 = host_gen_mul<G1Field>(g1_gen(), k1);
+    const Affine<G2Field> g2 = host_gen_mul<G2Field>(g2_gen(), k2);
+    pk->alpha_g1 = host_gen_mul<G1Field>(g1, alpha);
+    pk->beta_g1 = host_gen_mul<G1Field>(g1, beta);
+    pk->delta_g1 = host_gen_mul<G1Field>(g1, delta);
+    pk->beta_g2 = host_gen_mul<G2Field>(g2, beta);
+    pk->delta_g2 = host_gen_mul<G2Field>(g2, delta);
+    pk->gamma_g2 = host_gen_mul<G2Field>(g2, gamma);
+    rc = first_point<G1Field>(ctx, pk->a, &pk->a0);
+    if (rc == ZK_OK) rc = first_point<G1Field>(ctx, pk->b_g1, &pk->b0_g1);
+    if (rc == ZK_OK) rc = first_point<G2Field>(ctx, pk->b_g2, &pk->b0_g2);
+    if (rc != ZK_OK) { zk_pk_free(ctx, pk); return rc; }
+    *out = pk;
+    return ZK_OK;
+}
+
+// ---- prover ----------------------------------------------------------------------------------
+
+extern "C" int zk_groth16_msms_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const void* h,
+                                   zk_g1_projective out_g1[4], zk_g2_projective* out_g2) {
+    if (!ctx || !pk || !r || !z || !h || !out_g1 || !out_g2) return ZK_ERR_ARG;
+    const size_t D = (size_t)1 << r->log_d;
+    const size_t nvars = (r->ni - 1) + r->nw;
+    const char* zb = (const char*)z;
+    if (pk->a->n != nvars + 1 || pk->b_g1->n != nvars + 1 || pk->b_g2->n != nvars + 1 || pk->l->n != r->nw)
+        ZK_FAIL(ctx, ZK_ERR_ARG, "groth16: proving key does not match the constraint system");
+    // h_acc: min(len) rule (variable_base.rs:15-17): h_query has D-1 entries, h has D
+    ZK_TRY(zk_msm_run(ctx, pk->h, 0, h, std::min(pk->h->n, D), &out_g1[0]));                // src/groth16.rs:106
+    ZK_TRY(zk_msm_run(ctx, pk->l, 0, zb + r->ni * 32, r->nw, &out_g1[1]));                   // :110
+    ZK_TRY(zk_msm_run(ctx, pk->a, 1, zb + 32, nvars, &out_g1[2]));                           // :137 (query[1..])
+    ZK_TRY(zk_msm_run(ctx, pk->b_g1, 1, zb + 32, nvars, &out_g1[3]));                        // :148
+    ZK_TRY(zk_msm_run(ctx, pk->b_g2, 1, zb + 32, nvars, out_g2));                            // :160
+    return ZK_OK;
+}
+
+extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const zk_fr* r_, const zk_fr* s_,
+                                    uint8_t proof[192]) {
+    if (!ctx || !pk || !r || !z || !r_ || !s_ || !proof) return ZK_ERR_ARG;
+    const size_t D = (size_t)1 << r->log_d;
+    void* h;
+    ZK_TRY(zk_scratch(ctx, "prove_h", D * 32, &h));
+    {
+        ZkPhaseTimer tm(ctx);
+        tm.begin("witness_map");
+        ZK_TRY(zk_groth16_witness_map_dev(ctx, r, z, h));
+        tm.end();
+        tm.resolve();
+    }
+    zk_g1_projective m1[4];
+    zk_g2_projective m2;
+    ZK_TRY(zk_groth16_msms_dev(ctx, pk, r, z, h, m1, &m2));
+
+    using X1 = XYZZ<G1Field>;
+    using X2 = XYZZ<G2Field>;
+    uint32_t rw[8], sw[8];
+    fr_abi_to_canon_words(r_->l, rw);
+    fr_abi_to_canon_words(s_->l, sw);
+    const X1 h_acc = host_proj_from_abi<G1Field>((const uint64_t*)&m1[0]);
+    const X1 l_acc = host_proj_from_abi<G1Field>((const uint64_t*)&m1[1]);
+    const X1 a_acc = host_proj_from_abi<G1Field>((const uint64_t*)&m1[2]);
+    const X1 b1_acc = host_proj_from_abi<G1Field>((const uint64_t*)&m1[3]);
+    const X2 b2_acc = host_proj_from_abi<G2Field>((const uint64_t*)&m2);
+    const X1 delta1 = xyzz_from_affine<G1Field>(pk->delta_g1);
+    const X2 delta2 = xyzz_from_affine<G2Field>(pk->delta_g2);
+
+    // calculate_coeff (src/groth16.rs:185-201): initial + query[0] + acc + vk_param
+    const X1 r_g1 = host_scalar_mul<G1Field>(delta1, rw);
+    const X1 r_s_delta = host_scalar_mul<G1Field>(r_g1, sw);                                         // :115
+    X1 g_a = xyzz_madd<G1Field>(xyzz_add<G1Field>(xyzz_madd<G1Field>(r_g1, pk->a0), a_acc), pk->alpha_g1);
+    const X1 s_g_a = host_scalar_mul<G1Field>(g_a, sw);                                              // :140
+    const X1 s_g1 = host_scalar_mul<G1Field>(delta1, sw);
+    const X1 g1_b = xyzz_madd<G1Field>(xyzz_add<G1Field>(xyzz_madd<G1Field>(s_g1, pk->b0_g1), b1_acc), pk->beta_g1);
+    const X2 s_g2 = host_scalar_mul<G2Field>(delta2, sw);
+    const X2 g2_b = xyzz_madd<G2Field>(xyzz_add<G2Field>(xyzz_madd<G2Field>(s_g2, pk->b0_g2), b2_acc), pk->beta_g2);
+    const X1 r_g1_b = host_scalar_mul<G1Field>(g1_b, rw);                                            // :161
+    X1 g_c = xyzz_add<G1Field>(s_g_a, r_g1_b);                                                       // :169-174
+    g_c = xyzz_add<G1Field>(g_c, xyzz_neg<G1Field>(r_s_delta));
+    g_c = xyzz_add<G1Field>(g_c, l_acc);
+    g_c = xyzz_add<G1Field>(g_c, h_acc);
+
+    g1_serialize(xyzz_to_affine<G1Field>(g_a), proof);
+    g2_serialize(xyzz_to_affine<G2Field>(g2_b), proof + 48);
+    g1_serialize(xyzz_to_affine<G1Field>(g_c), proof + 144);
+    return ZK_OK;
+}
+
+extern "C" int zk_groth16_prove(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const zk_fr* z_host, const zk_fr* r_, const zk_fr* s_,
+                                uint8_t proof[192]) {
+    if (!ctx || !pk || !r || !z_host) return ZK_ERR_ARG;
+    size_t m = r->ni + r->nw;
+    void* z;
+    ZK_TRY(zk_scratch(ctx, "prove_z", m * 32, &z));
+    ZK_HIP(ctx, hipMemcpyAsync(z, z_host, m * 32, hipMemcpyHostToDevice, ctx->stream));
+    return zk_groth16_prove_dev(ctx, pk, r, z, r_, s_, proof);
+}

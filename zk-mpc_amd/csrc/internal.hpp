@@ -1,0 +1,37 @@
+// internal.hpp -- declarations shared between the translation units of libzkmpc_hip.
+#pragma once
+#include "ctx.hpp"
+#include <stddef.h>
+#include <stdint.h>
+
+// ntt.hip
+void zk_domains_free(zk_ctx* ctx);
+int zk_ntt_launch(zk_ctx* ctx, void* buf_dev, uint32_t log_n, int inverse, int coset);
+int zk_ntt_vanishing_inv(zk_ctx* ctx, uint32_t log_n, uint32_t out9[9]);  // 1/(g^N - 1), internal form
+
+// vec_ops.hip
+int zk_vec_op_launch(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n);
+int zk_vec_scale_launch(zk_ctx* ctx, const void* a, const uint32_t* k_int_form9, void* out, size_t n);
+int zk_vec_sub_scale_launch(zk_ctx* ctx, const void* a, const void* b, const uint32_t* k_int_form9, void* out, size_t n);
+
+// msm.hip
+struct zk_bases {
+    int group = 1;             // 1 = G1, 2 = G2
+    size_t n = 0;              // number of points
+    uint32_t* dev = nullptr;   // packed affine, internal Montgomery form: n * (24|48) words
+    bool owned = true;
+};
+int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,
+               void* out_host_projective);
+
+// event-based phase timer (cheap: two hipEventRecord per phase; resolved lazily)
+struct ZkPhaseTimer {
+    zk_ctx* ctx;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
+    bool enabled;
+    explicit ZkPhaseTimer(zk_ctx* c);
+    ~ZkPhaseTimer();
+    void begin(const char* name);
+    void end();
+    void resolve();  // synchronises the stream and writes ctx->timers
+};

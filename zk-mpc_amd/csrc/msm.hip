@@ -1,0 +1,394 @@
+// msm.hip -- variable-base multi-scalar multiplication on G1 / G2 for gfx950.
+//
+// Replaces VariableBaseMSM::multi_scalar_mul (arkworks/algebra/ec/src/msm/variable_base.rs:11-106)
+// behind AffineCurve::multi_scalar_mul (ec/src/lib.rs:305-314) and its MPC override
+// (mpc-algebra/src/wire/pairing.rs:714-777 -> share/additive.rs:517-520 -> share/msm.rs:31-37).
+//
+// The reference: c = ln(n)+2 bit unsigned windows, one bucket array per window filled by a
+// sequential sweep, running-sum reduction, Horner over windows.  This implementation computes the
+// same group element sum_i s_i P_i with a GPU schedule:
+//   1. k_digits   : scalar -> canonical integer (one Montgomery product), + bias so that every
+//                   c-bit window becomes an independent SIGNED digit in [-2^(c-1), 2^(c-1)-1]
+//                   (halves the bucket count); histogram of |digit| per window (L2 atomics).
+//   2. k_scan     : per-window exclusive scan of the histogram -> bucket offsets.
+//   3. k_scatter  : counting sort of (point index, sign) by bucket.  Order inside a bucket is
+//                   whatever the atomics give: the group is commutative and the result is reduced
+//                   to its canonical affine form, so the output bits do not depend on it.
+//   4. k_accum    : one thread per bucket: gather its points (96 B / 192 B random reads), mixed
+//                   XYZZ additions (8M+2S in Fq / Fq2).  This is the dominant kernel; it is bound by
+//                   the integer ALU (v_mad_u64_u32), not by HBM.
+//   5. k_reduce   : sum_b b * B_b per window by chunked running sums, K=8 buckets per thread per
+//                   level, log_8(2^(c-1)) levels (all windows in one launch per level).
+//   6. host       : Horner over the <= 64 window sums, one inversion, output as Jacobian Z=1.
+// Arithmetic is exact, so zero scalars, repeated bases, P + P, P - P and infinity need no special
+// treatment beyond the complete formulas in ec.cuh.
+#include "../../include/zkmpc_hip.h"
+#include "devutil.cuh"
+#include "hostgroup.hpp"
+#include "internal.hpp"
+#include <algorithm>
+#include <vector>
+
+using namespace zk;
+
+namespace {
+
+constexpr int REDUCE_K_LOG = 3;  // 8 elements per thread per reduction level
+
+struct MsmPlan {
+    uint32_t c;       // window bits
+    uint32_t W;       // windows
+    uint32_t NB;      // buckets per window = 2^(c-1)
+    uint32_t bias[9]; // sum_w 2^(c-1) 2^(c w)
+};
+
+MsmPlan make_plan(size_t n) {
+    MsmPlan p;
+    uint32_t lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    int c = (int)lg - 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    p.c = (uint32_t)c;
+    p.W = (255 + p.c - 1) / p.c;
+    p.NB = 1u << (p.c - 1);
+    for (int i = 0; i < 9; i++) p.bias[i] = 0;
+    for (uint32_t w = 0; w < p.W; w++) {
+        uint32_t bit = w * p.c + p.c - 1;
+        p.bias[bit >> 5] |= 1u << (bit & 31);
+    }
+    return p;
+}
+
+struct Bias { uint32_t w[9]; };
+
+// dig[w*n + i] = |d| | (d<0 ? 1<<31 : 0), and counts[w*NB + |d| - 1]++ for |d| > 0.
+__global__ void __launch_bounds__(256)
+k_digits(const void* scalars, size_t n, uint32_t c, uint32_t W, uint32_t NB, Bias bias, uint32_t* dig, uint32_t* counts) {
+    __shared__ uint32_t kw[9][256];
+    const uint32_t tid = threadIdx.x;
+    for (size_t i0 = blockIdx.x * (size_t)256; i0 < n; i0 += (size_t)gridDim.x * 256) {
+        size_t i = i0 + tid;
+        if (i < n) {
+            Fr s = fp_ext_to_canon<FrParams>(fr_load(scalars, i));
+            uint32_t w8[8];
+            fp_pack<FrParams>(w8, s);
+            uint32_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                uint64_t t = (uint64_t)(k < 8 ? w8[k] : 0u) + bias.w[k] + carry;
+                kw[k][tid] = (uint32_t)t;
+                carry = (uint32_t)(t >> 32);
+            }
+            const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+            for (uint32_t w = 0; w < W; w++) {
+                uint32_t bit = w * c, wi = bit >> 5, sh = bit & 31;
+                uint64_t two = kw[wi][tid];
+                if (wi + 1 < 9) two |= (uint64_t)kw[wi + 1][tid] << 32;
+                int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (int32_t)half;
+                uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+                dig[(size_t)w * n + i] = mag | (d < 0 ? 0x80000000u : 0u);
+                if (mag) atomicAdd(&counts[(size_t)w * NB + mag - 1], 1u);
+            }
+        }
+    }
+}
+
+// One block per window: offs[w*(NB+1) + b] = exclusive prefix of counts within the window.
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* counts, uint32_t* offs, uint32_t NB) {
+    __shared__ uint32_t part[1024];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    const uint32_t per = (NB + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = min(lo + per, NB);
+    uint32_t s = 0;
+    for (uint32_t b = lo; b < hi; b++) s += counts[(size_t)w * NB + b];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0;
+    for (uint32_t b = lo; b < hi; b++) {
+        offs[(size_t)w * (NB + 1) + b] = run;
+        run += counts[(size_t)w * NB + b];
+    }
+    if (tid == 1023) offs[(size_t)w * (NB + 1) + NB] = part[1023];
+}
+
+// sorted[w*n + pos] = i | sign ; counts are consumed (count down to zero).
+__global__ void __launch_bounds__(256)
+k_scatter(const uint32_t* dig, size_t n, uint32_t W, uint32_t NB, const uint32_t* offs, uint32_t* counts, uint32_t* sorted) {
+    const size_t total = (size_t)W * n;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        uint32_t d = dig[t];
+        uint32_t mag = d & 0x7fffffffu;
+        if (!mag) continue;
+        size_t w = t / n, i = t - w * n;
+        uint32_t slot = atomicSub(&counts[w * NB + mag - 1], 1u) - 1;
+        sorted[w * n + offs[w * (NB + 1) + mag - 1] + slot] = (uint32_t)i | (d & 0x80000000u);
+    }
+}
+
+// One thread per (window, bucket).
+template <class F>
+__global__ void __launch_bounds__(256)
+k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
+        size_t n, uint32_t W, uint32_t NB, uint32_t* __restrict__ bucket_sums) {
+    const size_t total = (size_t)W * NB;
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    size_t w = t / NB, b = t - w * NB;
+    uint32_t lo = offs[w * (NB + 1) + b], hi = offs[w * (NB + 1) + b + 1];
+    XYZZ<F> acc = xyzz_inf<F>();
+    const uint32_t* srt = sorted + w * n;
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t e = srt[k];
+        Affine<F> p = aff_load16<F>(bases, e & 0x7fffffffu);
+        if (e >> 31) p.y = F::neg(p.y);
+        acc = xyzz_madd<F>(acc, p);
+    }
+    xyzz_store16<F>(bucket_sums, t, acc);
+}
+
+// One reduction level (see file header).  Elements per window: T_in; chunk = 2^klog elements.
+// in : S_in[w*T_in + t], optional W_in[w*T_in + t]
+// out: S_out[w*T_out + c] = 2^klog * sum S ; W_out[w*T_out + c] = sum W + sum (t - lo (+1)) S_t
+template <class F>
+__global__ void __launch_bounds__(64)
+k_reduce(const uint32_t* S_in, const uint32_t* W_in, uint32_t* S_out, uint32_t* W_out, uint32_t T_in,
+         uint32_t T_out, uint32_t klog, uint32_t n_windows, int one_based, int last) {
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_windows * T_out) return;
+    uint32_t w = (uint32_t)(t / T_out), c = (uint32_t)(t - (size_t)w * T_out);
+    uint32_t lo = c << klog, hi = min(lo + (1u << klog), T_in);
+    XYZZ<F> running = xyzz_inf<F>(), acc = xyzz_inf<F>(), wsum = xyzz_inf<F>();
+    for (uint32_t k = hi; k-- > lo;) {
+        size_t idx = (size_t)w * T_in + k;
+        if (W_in) wsum = xyzz_add<F>(wsum, xyzz_load16<F>(W_in, idx));
+        running = xyzz_add<F>(running, xyzz_load16<F>(S_in, idx));
+        if (k > lo || one_based) acc = xyzz_add<F>(acc, running);
+    }
+    acc = xyzz_add<F>(acc, wsum);
+    xyzz_store16<F>(W_out, t, acc);
+    if (!last) {
+        for (uint32_t k = 0; k < klog; k++) running = xyzz_dbl<F>(running);
+        xyzz_store16<F>(S_out, t, running);
+    }
+}
+
+// Arkworks-layout affine points (Montgomery R = 2^384) -> packed internal form.  all-zero = infinity stays zero.
+template <class F>
+__global__ void __launch_bounds__(256) k_bases_import(const uint32_t* in, uint32_t* out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Affine<F> p = aff_load16<F>(in, i);
+        p.x = F::ext_to_int(p.x);
+        p.y = F::ext_to_int(p.y);
+        aff_store16<F>(out, i, p);
+    }
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_bases_export(const uint32_t* in, uint32_t* out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Affine<F> p = aff_load16<F>(in, i);
+        p.x = F::int_to_ext(p.x);
+        p.y = F::int_to_ext(p.y);
+        aff_store16<F>(out, i, p);
+    }
+}
+
+template <class F>
+int msm_run_t(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars, size_t n, void* out_host) {
+    constexpr size_t XW = 4 * F::WORDS;  // words per XYZZ point
+    if (n == 0) {
+        host_write_projective<F>(aff_inf<F>(), (uint64_t*)out_host);
+        return ZK_OK;
+    }
+    if (base_offset + n > bases->n) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: base range out of bounds");
+    if (n >= ((size_t)1 << 31)) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: n must be < 2^31");
+    ZkPhaseTimer tm(ctx);
+    MsmPlan p = make_plan(n);
+    const uint32_t* bdev = bases->dev + base_offset * (2 * F::WORDS);
+    uint32_t *dig, *sorted, *counts, *offs, *bsum, *lvS[2], *lvW[2];
+    const size_t nbuck = (size_t)p.W * p.NB;
+    ZK_TRY(zk_scratch(ctx, "msm_dig", (size_t)p.W * n * 4, (void**)&dig));
+    ZK_TRY(zk_scratch(ctx, "msm_sorted", (size_t)p.W * n * 4, (void**)&sorted));
+    ZK_TRY(zk_scratch(ctx, "msm_counts", nbuck * 4, (void**)&counts));
+    ZK_TRY(zk_scratch(ctx, "msm_offs", (size_t)p.W * (p.NB + 1) * 4, (void**)&offs));
+    ZK_TRY(zk_scratch(ctx, F::WORDS == 12 ? "msm_bsum1" : "msm_bsum2", nbuck * XW * 4, (void**)&bsum));
+    const size_t lv_elems = (size_t)p.W * ((p.NB >> REDUCE_K_LOG) + 1);
+    for (int k = 0; k < 2; k++) {
+        ZK_TRY(zk_scratch(ctx, k ? "msm_lvS1" : "msm_lvS0", lv_elems * XW * 4, (void**)&lvS[k]));
+        ZK_TRY(zk_scratch(ctx, k ? "msm_lvW1" : "msm_lvW0", lv_elems * XW * 4, (void**)&lvW[k]));
+    }
+    Bias bias;
+    for (int i = 0; i < 9; i++) bias.w[i] = p.bias[i];
+
+    tm.begin("msm.sort");
+    ZK_HIP(ctx, hipMemsetAsync(counts, 0, nbuck * 4, ctx->stream));
+    hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, ctx->stream, scalars, n, p.c, p.W, p.NB, bias, dig, counts);
+    hipLaunchKernelGGL(k_scan, p.W, 1024, 0, ctx->stream, counts, offs, p.NB);
+    hipLaunchKernelGGL(k_scatter, zk_grid((size_t)p.W * n, 256), 256, 0, ctx->stream, dig, n, p.W, p.NB, offs, counts, sorted);
+    ZK_HIP(ctx, hipGetLastError());
+    tm.end();
+
+    tm.begin("msm.accum");
+    hipLaunchKernelGGL(k_accum<F>, (unsigned)((nbuck + 255) / 256), 256, 0, ctx->stream, bdev, sorted, offs, n, p.W, p.NB, bsum);
+    ZK_HIP(ctx, hipGetLastError());
+    tm.end();
+
+    tm.begin("msm.reduce");
+    const uint32_t* S_in = bsum;
+    const uint32_t* W_in = nullptr;
+    uint32_t T_in = p.NB;
+    int level = 0;
+    const uint32_t* result = nullptr;
+    while (true) {
+        uint32_t T_out = (T_in + (1u << REDUCE_K_LOG) - 1) >> REDUCE_K_LOG;
+        int last = T_out == 1;
+        uint32_t* So = lvS[level & 1];
+        uint32_t* Wo = lvW[level & 1];
+        size_t threads = (size_t)p.W * T_out;
+        hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, ctx->stream, S_in, W_in, So, Wo, T_in, T_out,
+                           (uint32_t)REDUCE_K_LOG, p.W, level == 0 ? 1 : 0, last);
+        ZK_HIP(ctx, hipGetLastError());
+        if (last) { result = Wo; break; }
+        S_in = So; W_in = Wo; T_in = T_out; level++;
+    }
+    tm.end();
+
+    std::vector<uint32_t> hw((size_t)p.W * XW);
+    ZK_HIP(ctx, hipMemcpyAsync(hw.data(), result, hw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    tm.resolve();
+    // Horner over windows, most significant first (variable_base.rs:94-105)
+    XYZZ<F> total = xyzz_inf<F>();
+    for (int w = (int)p.W - 1; w >= 0; w--) {
+        for (uint32_t k = 0; k < p.c; k++) total = xyzz_dbl<F>(total);
+        total = xyzz_add<F>(total, xyzz_load<F>(hw.data() + (size_t)w * XW));
+    }
+    host_write_projective<F>(xyzz_to_affine<F>(total), (uint64_t*)out_host);
+    return ZK_OK;
+}
+
+template <class F>
+int bases_upload_t(zk_ctx* ctx, const void* host, size_t n, int group, zk_bases** out) {
+    if (!ctx || !out || (n && !host)) return ZK_ERR_ARG;
+    zk_bases* b = new zk_bases();
+    b->group = group;
+    b->n = n;
+    const size_t bytes = n * 2 * F::WORDS * 4;
+    if (n) {
+        void* stage;
+        ZK_TRY(zk_scratch(ctx, "bases_stage", bytes, &stage));
+        if (hipMalloc((void**)&b->dev, bytes) != hipSuccess) { delete b; ZK_FAIL(ctx, ZK_ERR_NOMEM, "bases upload: hipMalloc failed"); }
+        ZK_HIP(ctx, hipMemcpyAsync(stage, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_bases_import<F>, zk_grid(n, 256), 256, 0, ctx->stream, (const uint32_t*)stage, b->dev, n);
+        ZK_HIP(ctx, hipGetLastError());
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *out = b;
+    return ZK_OK;
+}
+
+template <class F>
+int bases_download_t(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, void* out) {
+    if (!ctx || !b || (n && !out)) return ZK_ERR_ARG;
+    if (offset + n > b->n) ZK_FAIL(ctx, ZK_ERR_ARG, "bases download: range out of bounds");
+    if (!n) return ZK_OK;
+    const size_t bytes = n * 2 * F::WORDS * 4;
+    void* stage;
+    ZK_TRY(zk_scratch(ctx, "bases_stage", bytes, &stage));
+    hipLaunchKernelGGL(k_bases_export<F>, zk_grid(n, 256), 256, 0, ctx->stream, b->dev + offset * 2 * F::WORDS, (uint32_t*)stage, n);
+    ZK_HIP(ctx, hipGetLastError());
+    ZK_HIP(ctx, hipMemcpyAsync(out, stage, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+template <class F>
+int msm_host_t(zk_ctx* ctx, const void* bases_host, size_t nb, const zk_fr* scalars, size_t ns, int group, void* out) {
+    if (!ctx || !out) return ZK_ERR_ARG;
+    size_t n = std::min(nb, ns);  // variable_base.rs:15-17
+    if (n && (!bases_host || !scalars)) return ZK_ERR_ARG;
+    zk_bases* b = nullptr;
+    ZK_TRY(bases_upload_t<F>(ctx, bases_host, n, group, &b));
+    void* sdev = nullptr;
+    int rc = ZK_OK;
+    if (n) {
+        rc = zk_scratch(ctx, "msm_scalars_host", n * 32, &sdev);
+        if (rc == ZK_OK && hipMemcpyAsync(sdev, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
+    }
+    if (rc == ZK_OK) rc = msm_run_t<F>(ctx, b, 0, sdev, n, out);
+    zk_bases_free(ctx, b);
+    return rc;
+}
+
+}  // namespace
+
+// ---- phase timer ----
+ZkPhaseTimer::ZkPhaseTimer(zk_ctx* c) : ctx(c) { enabled = getenv("ZK_PROFILE") != nullptr; }
+ZkPhaseTimer::~ZkPhaseTimer() {
+    for (auto& e : ev) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+}
+void ZkPhaseTimer::begin(const char* name) {
+    if (!enabled) return;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, ctx->stream);
+    ev.push_back({name, {a, b}});
+}
+void ZkPhaseTimer::end() {
+    if (!enabled || ev.empty()) return;
+    (void)hipEventRecord(ev.back().second.second, ctx->stream);
+}
+void ZkPhaseTimer::resolve() {
+    if (!enabled) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& e : ev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.second.first, e.second.second) == hipSuccess) ctx->timers[e.first] += ms;
+    }
+}
+
+int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n, void* out) {
+    if (bases->group == 1) return msm_run_t<G1Field>(ctx, bases, base_offset, scalars_dev, n, out);
+    return msm_run_t<G2Field>(ctx, bases, base_offset, scalars_dev, n, out);
+}
+
+extern "C" int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* h, size_t n, zk_bases** out) { return bases_upload_t<G1Field>(ctx, h, n, 1, out); }
+extern "C" int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* h, size_t n, zk_bases** out) { return bases_upload_t<G2Field>(ctx, h, n, 2, out); }
+extern "C" int zk_bases_free(zk_ctx* ctx, zk_bases* b) {
+    if (!b) return ZK_OK;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (b->owned && b->dev) (void)hipFree(b->dev);
+    delete b;
+    return ZK_OK;
+}
+extern "C" size_t zk_bases_len(const zk_bases* b) { return b ? b->n : 0; }
+extern "C" int zk_bases_download_g1(zk_ctx* ctx, const zk_bases* b, size_t off, size_t n, zk_g1_affine* out) {
+    if (b && b->group != 1) return ZK_ERR_ARG;
+    return bases_download_t<G1Field>(ctx, b, off, n, out);
+}
+extern "C" int zk_bases_download_g2(zk_ctx* ctx, const zk_bases* b, size_t off, size_t n, zk_g2_affine* out) {
+    if (b && b->group != 2) return ZK_ERR_ARG;
+    return bases_download_t<G2Field>(ctx, b, off, n, out);
+}
+
+extern "C" int zk_msm_g1(zk_ctx* ctx, const zk_g1_affine* bases, size_t nb, const zk_fr* scalars, size_t ns, zk_g1_projective* out) {
+    return msm_host_t<G1Field>(ctx, bases, nb, scalars, ns, 1, out);
+}
+extern "C" int zk_msm_g2(zk_ctx* ctx, const zk_g2_affine* bases, size_t nb, const zk_fr* scalars, size_t ns, zk_g2_projective* out) {
+    return msm_host_t<G2Field>(ctx, bases, nb, scalars, ns, 2, out);
+}
+extern "C" int zk_msm_g1_dev(zk_ctx* ctx, const zk_bases* bases, size_t off, const void* scalars, size_t n, zk_g1_projective* out) {
+    if (!ctx || !bases || !out || bases->group != 1 || (n && !scalars)) return ZK_ERR_ARG;
+    return msm_run_t<G1Field>(ctx, bases, off, scalars, n, out);
+}
+extern "C" int zk_msm_g2_dev(zk_ctx* ctx, const zk_bases* bases, size_t off, const void* scalars, size_t n, zk_g2_projective* out) {
+    if (!ctx || !bases || !out || bases->group != 2 || (n && !scalars)) return ZK_ERR_ARG;
+    return msm_run_t<G2Field>(ctx, bases, off, scalars, n, out);
+}

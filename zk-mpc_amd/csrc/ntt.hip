@@ -1,0 +1,307 @@
+// ntt.hip -- radix-2 NTT over BLS12-377 Fr for gfx950.
+//
+// Replaces Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place
+// (arkworks/algebra/poly/src/domain/radix2/mod.rs:98-114, radix2/fft.rs:22-70,185-307,
+//  domain/mod.rs:92-157) and the domain constants of radix2/mod.rs:51-82.
+//
+// Same transform, different schedule.  The reference runs log2(N) butterfly sweeps over the whole
+// vector (DIF "io" then a bit-reversal, or bit-reversal then DIT "oi").  Here the log2(N) DIF
+// levels are grouped into ceil(log2(N)/10) passes; a pass gives each workgroup a tile of
+// M x C elements (M = 2^logM points of C neighbouring sub-transforms, C*32 B contiguous runs),
+// keeps the tile in LDS (limb-major, conflict-free b32 accesses) for its logM butterfly levels,
+// applies the inter-pass twiddle w_B^(l*q) on the way out, and writes the tile back in place.
+// A final kernel does the bit-reversal (as an in-place swap) fused with the iFFT's 1/N or the
+// coset iFFT's g^-i/N scaling; the coset FFT's g^i scaling is fused into the first pass's load.
+// The inverse transform uses the same kernels with the twiddle index negated (w^-e = w^(N-e)).
+//
+// Data stays in the reference's Montgomery form (R = 2^256); table entries are kept in the
+// device's internal form (x * 2^261), so mmul(data, table) = data * x with no conversion.
+// Work: (N/2) log2 N butterflies (the last level of every pass multiplies by 1 and is skipped),
+// + N inter-pass twiddles per pass boundary.  Traffic: 2 * 32 B * N per pass + the swap pass.
+#include "../../include/zkmpc_hip.h"
+#include "devutil.cuh"
+#include "internal.hpp"
+
+using namespace zk;
+
+struct zk_domain {
+    uint32_t log_n = 0;
+    uint32_t* tw = nullptr;     // w^i, i < N          (internal form, 8 words each)
+    uint32_t* cos = nullptr;    // g^i                  (coset FFT pre-scale)
+    uint32_t* icos = nullptr;   // g^-i / N             (coset iFFT post-scale)
+    Fr size_inv;                // 1/N, internal form
+    Fr zinv;                    // 1 / (g^N - 1), internal form (divide_by_vanishing_poly_on_coset)
+};
+
+namespace {
+
+constexpr int LOGM_MAX = 10;
+constexpr int TILE_ELEMS = 4096;  // 128 KiB of LDS
+
+struct FrK { uint32_t l[9]; };
+__device__ __forceinline__ Fr frk(const FrK& k) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = k.l[i];
+    return r;
+}
+FrK to_frk(const Fr& a) {
+    FrK k;
+    for (int i = 0; i < 9; i++) k.l[i] = a.l[i];
+    return k;
+}
+
+// out[i] = start * base^i  (internal form in, internal form out)
+__global__ void __launch_bounds__(256) k_powers(uint32_t* out, FrK base_k, FrK start_k, size_t n) {
+    constexpr int CH = 32;
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t i0 = t * CH;
+    if (i0 >= n) return;
+    Fr base = frk(base_k);
+    // base^i0 by square-and-multiply
+    Fr p = fp_one<FrParams>();
+    bool started = false;
+    for (int b = 63; b >= 0; b--) {
+        if (started) p = fp_sqr<FrParams>(p);
+        if ((i0 >> b) & 1) { p = started ? fr_mul(p, base) : base; started = true; }
+    }
+    p = fr_mul(p, frk(start_k));
+    for (int j = 0; j < CH && i0 + j < n; j++) {
+        fr_store(out, i0 + j, p);
+        p = fr_mul(p, base);
+    }
+}
+
+__device__ __forceinline__ Fr lds_load(const uint32_t* lds, uint32_t E, uint32_t li) {
+    Fr r;
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = lds[k * E + li];
+    return fp_unpack<FrParams>(w);
+}
+__device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t E, uint32_t li, const Fr& v) {
+    uint32_t w[8];
+    fp_pack<FrParams>(w, v);
+#pragma unroll
+    for (int k = 0; k < 8; k++) lds[k * E + li] = w[k];
+}
+
+// One DIF pass.  Tile = C columns x M points; column id = block * S + l.
+__global__ void __launch_bounds__(1024)
+k_ntt_pass(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ pre,
+           uint32_t log_n, uint32_t logS, uint32_t logM, uint32_t logC, int inverse) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t M = 1u << logM, C = 1u << logC, E = M * C;
+    const uint32_t N1 = (1u << log_n) - 1;
+    const uint32_t logB = logS + logM;
+    const uint32_t tid = threadIdx.x, NT = blockDim.x;
+    const uint32_t col0 = blockIdx.x << logC;
+
+    // ---- load tile (c fastest -> contiguous runs), optional coset pre-scale ----
+    for (uint32_t e = tid; e < E; e += NT) {
+        uint32_t c = e & (C - 1), m = e >> logC;
+        uint32_t col = col0 + c;
+        uint32_t idx = ((col >> logS) << logB) + (m << logS) + (col & ((1u << logS) - 1));
+        Fr v = fr_load(data, idx);
+        if (pre) v = fr_mul(v, fr_load(pre, idx));
+        lds_store(lds, E, e, v);
+    }
+    __syncthreads();
+
+    // ---- logM butterfly levels in LDS ----
+    const uint32_t nb = E >> 1;
+    for (uint32_t s = 0; s < logM; s++) {
+        const uint32_t lg = logM - 1 - s;  // log2(gap)
+        const uint32_t g = 1u << lg;
+        for (uint32_t b = tid; b < nb; b += NT) {
+            uint32_t c = b & (C - 1), j = b >> logC;
+            uint32_t jj = j & (g - 1);
+            uint32_t m_lo = ((j >> lg) << (lg + 1)) | jj;
+            uint32_t lo = (m_lo << logC) | c, hi = ((m_lo + g) << logC) | c;
+            Fr x = lds_load(lds, E, lo), y = lds_load(lds, E, hi);
+            Fr sum = fr_add(x, y), d = fr_sub(x, y);
+            if (jj) {
+                uint32_t ex = (jj << s) << (log_n - logM);
+                if (inverse) ex = (0u - ex) & N1;
+                d = fr_mul(d, fr_load(tw, ex));
+            }
+            lds_store(lds, E, lo, sum);
+            lds_store(lds, E, hi, d);
+        }
+        __syncthreads();
+    }
+
+    // ---- inter-pass twiddle w_B^(l*q), q = bitrev(m), and store in place ----
+    for (uint32_t e = tid; e < E; e += NT) {
+        uint32_t c = e & (C - 1), m = e >> logC;
+        uint32_t col = col0 + c;
+        uint32_t l = col & ((1u << logS) - 1);
+        uint32_t idx = ((col >> logS) << logB) + (m << logS) + l;
+        Fr v = lds_load(lds, E, e);
+        if (logS) {
+            uint32_t q = __brev(m) >> (32 - logM);
+            uint32_t lq = l * q;
+            if (lq) {
+                uint32_t ex = lq << (log_n - logB);
+                if (inverse) ex = (0u - ex) & N1;
+                v = fr_mul(v, fr_load(tw, ex));
+            }
+        }
+        fr_store(data, idx, v);
+    }
+}
+
+// In-place bit reversal fused with the post-scale: MODE 0 none, 1 constant k, 2 table post[i].
+template <int MODE>
+__global__ void __launch_bounds__(256) k_bitrev_scale(uint32_t* data, uint32_t log_n, FrK k, const uint32_t* post) {
+    const size_t n = (size_t)1 << log_n;
+    const Fr kk = frk(k);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = log_n ? (size_t)(__brev((uint32_t)i) >> (32 - log_n)) : 0;
+        if (i > r) continue;
+        Fr a = fr_load(data, i);
+        if (i == r) {
+            if (MODE == 1) a = fr_mul(a, kk);
+            if (MODE == 2) a = fr_mul(a, fr_load(post, i));
+            if (MODE) fr_store(data, i, a);
+        } else {
+            Fr b = fr_load(data, r);
+            if (MODE == 1) { a = fr_mul(a, kk); b = fr_mul(b, kk); }
+            if (MODE == 2) { a = fr_mul(a, fr_load(post, r)); b = fr_mul(b, fr_load(post, i)); }
+            fr_store(data, i, b);
+            fr_store(data, r, a);
+        }
+    }
+}
+
+Fr host_pow_u64(const Fr& a, uint64_t e) {
+    Fr r = fp_one<FrParams>();
+    for (int b = 63; b >= 0; b--) {
+        r = fp_sqr<FrParams>(r);
+        if ((e >> b) & 1) r = fp_mul<FrParams>(r, a);
+    }
+    return r;
+}
+
+int build_powers(zk_ctx* ctx, uint32_t** out, const Fr& base, const Fr& start, size_t n) {
+    ZK_HIP(ctx, hipMalloc((void**)out, n * 32));
+    size_t threads = (n + 31) / 32;
+    hipLaunchKernelGGL(k_powers, (unsigned)((threads + 255) / 256), 256, 0, ctx->stream, *out, to_frk(base), to_frk(start), n);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+int get_domain(zk_ctx* ctx, uint32_t log_n, bool need_coset, zk_domain** out) {
+    if (log_n > (uint32_t)FR_TWO_ADICITY || log_n > 28) ZK_FAIL(ctx, ZK_ERR_ARG, "NTT size unsupported (log_n > 28)");
+    zk_domain* d = nullptr;
+    auto it = ctx->domains.find(log_n);
+    if (it != ctx->domains.end()) d = it->second;
+    const size_t n = (size_t)1 << log_n;
+    if (!d) {
+        d = new zk_domain();
+        d->log_n = log_n;
+        // group_gen = two_adic_root^(2^(47 - log_n))   (ff get_root_of_unity; radix2/mod.rs:67-69)
+        Fr w = fp_const<FrParams>(FrParams::TWO_ADIC_ROOT);
+        for (uint32_t i = 0; i < (uint32_t)FR_TWO_ADICITY - log_n; i++) w = fp_sqr<FrParams>(w);
+        Fr n_int = fp_canon_to_int<FrParams>([&] { Fr t = fp_zero<FrParams>(); t.l[0] = (uint32_t)(n & MASK29); t.l[1] = (uint32_t)(n >> 29); return t; }());
+        d->size_inv = fp_inv<FrParams>(n_int);
+        Fr g = fp_const<FrParams>(FrParams::GENERATOR);
+        Fr gn = host_pow_u64(g, n);
+        d->zinv = fp_inv<FrParams>(fp_sub<FrParams>(gn, fp_one<FrParams>()));
+        ZK_TRY(build_powers(ctx, &d->tw, w, fp_one<FrParams>(), n));
+        ctx->domains[log_n] = d;
+    }
+    if (need_coset && !d->cos) {
+        Fr g = fp_const<FrParams>(FrParams::GENERATOR);
+        Fr gi = fp_const<FrParams>(FrParams::GENERATOR_INV);
+        ZK_TRY(build_powers(ctx, &d->cos, g, fp_one<FrParams>(), n));
+        ZK_TRY(build_powers(ctx, &d->icos, gi, d->size_inv, n));
+    }
+    *out = d;
+    return ZK_OK;
+}
+
+}  // namespace
+
+void zk_domains_free(zk_ctx* ctx) {
+    for (auto& kv : ctx->domains) {
+        zk_domain* d = kv.second;
+        if (d->tw) (void)hipFree(d->tw);
+        if (d->cos) (void)hipFree(d->cos);
+        if (d->icos) (void)hipFree(d->icos);
+        delete d;
+    }
+    ctx->domains.clear();
+}
+
+int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset) {
+    zk_domain* d;
+    ZK_TRY(get_domain(ctx, log_n, coset != 0, &d));
+    uint32_t* data = (uint32_t*)buf;
+    if (log_n > 0) {
+        uint32_t passes = (log_n + LOGM_MAX - 1) / LOGM_MAX;
+        uint32_t base = log_n / passes, extra = log_n % passes;
+        uint32_t remaining = log_n;
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELEMS * 32));
+        for (uint32_t p = 0; p < passes; p++) {
+            uint32_t logM = base + (p < extra ? 1 : 0);
+            uint32_t logS = remaining - logM;
+            uint32_t logE = log_n < 12 ? log_n : 12;      // tile elements = min(N, 4096)
+            uint32_t logC = logE - logM;
+            uint32_t E = 1u << logE;
+            uint32_t nt = E / 2 > 1024 ? 1024 : (E / 2 < 64 ? 64 : E / 2);
+            uint32_t tiles = 1u << (log_n - logE);
+            const uint32_t* pre = (p == 0 && coset && !inverse) ? d->cos : nullptr;
+            hipLaunchKernelGGL(k_ntt_pass, tiles, nt, E * 32, ctx->stream, data, d->tw, pre, log_n, logS, logM, logC, inverse);
+            ZK_HIP(ctx, hipGetLastError());
+            remaining = logS;
+        }
+    } else if (coset && !inverse) {
+        // N = 1: g^0 = 1, nothing to do
+    }
+    unsigned g = zk_grid((size_t)1 << log_n, 256);
+    FrK zero{};
+    if (!inverse) {
+        if (log_n > 1) hipLaunchKernelGGL(k_bitrev_scale<0>, g, 256, 0, ctx->stream, data, log_n, zero, nullptr);
+    } else if (!coset) {
+        hipLaunchKernelGGL(k_bitrev_scale<1>, g, 256, 0, ctx->stream, data, log_n, to_frk(d->size_inv), nullptr);
+    } else {
+        hipLaunchKernelGGL(k_bitrev_scale<2>, g, 256, 0, ctx->stream, data, log_n, zero, d->icos);
+    }
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+extern "C" int zk_fr_ntt_dev(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset) {
+    if (!ctx || !buf) return ZK_ERR_ARG;
+    return zk_ntt_launch(ctx, buf, log_n, inverse, coset);
+}
+
+extern "C" int zk_fr_fft_in_place(zk_ctx* ctx, zk_fr* vec, size_t n, uint32_t log_n, int inverse, int coset) {
+    if (!ctx || !vec) return ZK_ERR_ARG;
+    size_t N = (size_t)1 << log_n;
+    if (n > N) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_fr_fft_in_place: n exceeds the domain size");
+    void* d;
+    ZK_TRY(zk_scratch(ctx, "fft_host", N * 32, &d));
+    ZK_HIP(ctx, hipMemcpyAsync(d, vec, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (N > n) ZK_HIP(ctx, hipMemsetAsync((char*)d + n * 32, 0, (N - n) * 32, ctx->stream));
+    ZK_TRY(zk_ntt_launch(ctx, d, log_n, inverse, coset));
+    ZK_HIP(ctx, hipMemcpyAsync(vec, d, N * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+extern "C" int zk_fr_divide_by_vanishing_on_coset_dev(zk_ctx* ctx, void* evals, uint32_t log_n) {
+    if (!ctx || !evals) return ZK_ERR_ARG;
+    zk_domain* d;
+    ZK_TRY(get_domain(ctx, log_n, false, &d));
+    return zk_vec_scale_launch(ctx, evals, d->zinv.l, evals, (size_t)1 << log_n);
+}
+
+// used by groth16.hip: (ab - c) / Z(g) fused
+int zk_ntt_vanishing_inv(zk_ctx* ctx, uint32_t log_n, uint32_t out9[9]) {
+    zk_domain* d;
+    ZK_TRY(get_domain(ctx, log_n, false, &d));
+    for (int i = 0; i < 9; i++) out9[i] = d->zinv.l[i];
+    return ZK_OK;
+}

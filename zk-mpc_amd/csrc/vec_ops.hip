@@ -1,0 +1,166 @@
+// vec_ops.hip -- element-wise Fr kernels on device vectors in the reference's layout.
+// Replaces: Field::batch_product_in_place (ff/src/fields/mod.rs:216-220), the `ab -= c` loop and
+// divide_by_vanishing_poly_on_coset_in_place of witness_map (src/groth16.rs:285-302,
+// poly/src/domain/mod.rs:183-190), AdditiveFieldShare::{add,sub,scale} on vectors
+// (mpc-algebra/src/share/additive.rs:133-152), batch_open's sum and batch_mul's tail
+// (share/additive.rs:124-131, share/field.rs:118-128).
+// HBM-bound: 96 B of traffic per element for a binary op (2 x 32 B in, 32 B out).
+#include "../../include/zkmpc_hip.h"
+#include "devutil.cuh"
+#include "internal.hpp"
+
+using namespace zk;
+
+namespace {
+
+struct FrK { uint32_t l[9]; };  // a field constant passed by value (internal form)
+
+__device__ __forceinline__ Fr frk(const FrK& k) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = k.l[i];
+    return r;
+}
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_vec_op(const void* a, const void* b, void* out, size_t n) {
+    const Fr fix = fp_const<FrParams>(FrParams::EXT_TO_INT);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr x = fr_load(a, i), y = fr_load(b, i), z;
+        if (OP == ZK_OP_MUL) z = fr_mul(fr_mul(x, y), fix);  // ext*ext -> ext needs one fix-up product
+        else if (OP == ZK_OP_ADD) z = fr_add(x, y);
+        else z = fr_sub(x, y);
+        fr_store(out, i, z);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_vec_scale(const void* a, FrK k, void* out, size_t n) {
+    const Fr kk = frk(k);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        fr_store(out, i, fr_mul(fr_load(a, i), kk));
+}
+
+// out = (a - b) * k
+__global__ void __launch_bounds__(256) k_vec_sub_scale(const void* a, const void* b, FrK k, void* out, size_t n) {
+    const Fr kk = frk(k);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        fr_store(out, i, fr_mul(fr_sub(fr_load(a, i), fr_load(b, i)), kk));
+}
+
+__global__ void __launch_bounds__(256) k_sum_parties(const void* g, size_t np, size_t n, void* out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr acc = fr_load(g, i);
+        for (size_t p = 1; p < np; p++) acc = fr_add(acc, fr_load(g, p * n + i));
+        fr_store(out, i, acc);
+    }
+}
+
+// out = tz - sx*ty - oy*tx (+ sx*oy if leader).  DUMMY: tx=ty=tz = (leader ? 1 : 0).
+template <bool DUMMY>
+__global__ void __launch_bounds__(256) k_beaver(const void* sx, const void* oy, const void* tx, const void* ty,
+                                                const void* tz, void* out, size_t n, int leader) {
+    const Fr fix = fp_const<FrParams>(FrParams::EXT_TO_INT);
+    // 1 in external form = 2^256 mod r = mmul(ONE_internal, INT_TO_EXT)
+    const Fr one_ext = fr_mul(fp_one<FrParams>(), fp_const<FrParams>(FrParams::INT_TO_EXT));
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr a = fr_load(sx, i), b = fr_load(oy, i), z;
+        if (DUMMY) {
+            if (leader) {
+                // 1 - a - b + ab
+                z = fr_add(fr_sub(fr_sub(one_ext, a), b), fr_mul(fr_mul(a, b), fix));
+            } else {
+                z = fp_zero<FrParams>();
+            }
+        } else {
+            Fr x = fr_load(tx, i), y = fr_load(ty, i);
+            z = fr_load(tz, i);
+            z = fr_sub(z, fr_mul(fr_mul(a, y), fix));
+            z = fr_sub(z, fr_mul(fr_mul(b, x), fix));
+            if (leader) z = fr_add(z, fr_mul(fr_mul(a, b), fix));
+        }
+        fr_store(out, i, z);
+    }
+}
+
+FrK to_frk(const uint32_t* l) {
+    FrK k;
+    for (int i = 0; i < 9; i++) k.l[i] = l[i];
+    return k;
+}
+
+}  // namespace
+
+int zk_vec_op_launch(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n) {
+    if (n == 0) return ZK_OK;
+    unsigned g = zk_grid(n, 256);
+    switch (op) {
+        case ZK_OP_MUL: hipLaunchKernelGGL(k_vec_op<ZK_OP_MUL>, g, 256, 0, ctx->stream, a, b, out, n); break;
+        case ZK_OP_ADD: hipLaunchKernelGGL(k_vec_op<ZK_OP_ADD>, g, 256, 0, ctx->stream, a, b, out, n); break;
+        case ZK_OP_SUB: hipLaunchKernelGGL(k_vec_op<ZK_OP_SUB>, g, 256, 0, ctx->stream, a, b, out, n); break;
+        default: ZK_FAIL(ctx, ZK_ERR_ARG, "zk_fr_vec_op_dev: unknown op");
+    }
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+int zk_vec_scale_launch(zk_ctx* ctx, const void* a, const uint32_t* k9, void* out, size_t n) {
+    if (n == 0) return ZK_OK;
+    hipLaunchKernelGGL(k_vec_scale, zk_grid(n, 256), 256, 0, ctx->stream, a, to_frk(k9), out, n);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+int zk_vec_sub_scale_launch(zk_ctx* ctx, const void* a, const void* b, const uint32_t* k9, void* out, size_t n) {
+    if (n == 0) return ZK_OK;
+    hipLaunchKernelGGL(k_vec_sub_scale, zk_grid(n, 256), 256, 0, ctx->stream, a, b, to_frk(k9), out, n);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+extern "C" int zk_fr_vec_op_dev(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n) {
+    if (!ctx || (n && (!a || !b || !out))) return ZK_ERR_ARG;
+    return zk_vec_op_launch(ctx, op, a, b, out, n);
+}
+
+extern "C" int zk_fr_vec_scale_dev(zk_ctx* ctx, const void* a, const zk_fr* k, void* out, size_t n) {
+    if (!ctx || !k || (n && (!a || !out))) return ZK_ERR_ARG;
+    Fr kk = fp_ext_to_int<FrParams>(host_load_ext<FrParams>(k->l));
+    return zk_vec_scale_launch(ctx, a, kk.l, out, n);
+}
+
+extern "C" int zk_fr_batch_product_in_place(zk_ctx* ctx, zk_fr* selfs, const zk_fr* others, size_t n) {
+    if (!ctx || (n && (!selfs || !others))) return ZK_ERR_ARG;
+    if (n == 0) return ZK_OK;
+    void *da, *db;
+    ZK_TRY(zk_scratch(ctx, "bp_a", n * 32, &da));
+    ZK_TRY(zk_scratch(ctx, "bp_b", n * 32, &db));
+    ZK_HIP(ctx, hipMemcpyAsync(da, selfs, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(db, others, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_MUL, da, db, da, n));
+    ZK_HIP(ctx, hipMemcpyAsync(selfs, da, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+extern "C" int zk_fr_sum_parties_dev(zk_ctx* ctx, const void* g, size_t np, size_t n, void* out) {
+    if (!ctx || np == 0 || (n && (!g || !out))) return ZK_ERR_ARG;
+    if (n == 0) return ZK_OK;
+    hipLaunchKernelGGL(k_sum_parties, zk_grid(n, 256), 256, 0, ctx->stream, g, np, n, out);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+extern "C" int zk_beaver_combine_dev(zk_ctx* ctx, const void* sx, const void* oy, const void* tx, const void* ty,
+                                     const void* tz, void* out, size_t n) {
+    if (!ctx || (n && (!sx || !oy || !out))) return ZK_ERR_ARG;
+    if (n == 0) return ZK_OK;
+    int leader = ctx->party_id == 0;
+    bool dummy = !tx && !ty && !tz;
+    if (!dummy && (!tx || !ty || !tz)) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_beaver_combine_dev: give all of tx,ty,tz or none");
+    if (dummy)
+        hipLaunchKernelGGL(k_beaver<true>, zk_grid(n, 256), 256, 0, ctx->stream, sx, oy, tx, ty, tz, out, n, leader);
+    else
+        hipLaunchKernelGGL(k_beaver<false>, zk_grid(n, 256), 256, 0, ctx->stream, sx, oy, tx, ty, tz, out, n, leader);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
