@@ -212,9 +212,12 @@ int zk_beaver_combine_dev(zk_ctx* ctx, const void* sx_open_dev, const void* oy_o
                           void* out_dev, size_t n);
 
 /* ---- instrumentation -------------------------------------------------------------------- */
-/* Per-phase device times (ms, HIP events on the context stream) of the last prove/MSM call.
- * Returns the number of entries written; names are NUL-terminated, `name_stride` bytes apart. */
-int zk_last_timers(zk_ctx* ctx, char* names, size_t name_stride, float* ms, int max_entries);
+/* zk_set_profiling(ctx, 1): bracket every phase (witness map, MSM sort / accumulate / reduce) with
+ * HIP events on the context stream; zk_last_timers returns the accumulated device time (ms) and
+ * launch count per phase since the last call and resets them.  Names are NUL-terminated,
+ * `name_stride` bytes apart; returns the number of entries written. */
+int zk_set_profiling(zk_ctx* ctx, int on);
+int zk_last_timers(zk_ctx* ctx, char* names, size_t name_stride, float* ms, int* counts, int max_entries);
 
 #ifdef __cplusplus
 }

@@ -99,11 +99,16 @@ class Context:
     def stream(self) -> int:
         return self.lib.zk_ctx_stream(self.h)
 
+    def set_profiling(self, on: bool):
+        self._ck(self.lib.zk_set_profiling(self.h, int(on)))
+
     def timers(self) -> dict:
-        names = C.create_string_buffer(64 * 32)
-        ms = (C.c_float * 32)()
-        k = self.lib.zk_last_timers(self.h, names, 64, ms, 32)
-        return {names.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode(): float(ms[i]) for i in range(k)}
+        """{phase: (total device ms, launches)} since the previous call."""
+        names = C.create_string_buffer(64 * 64)
+        ms = (C.c_float * 64)()
+        cnt = (C.c_int * 64)()
+        k = self.lib.zk_last_timers(self.h, names, 64, ms, cnt, 64)
+        return {names.raw[i * 64:(i + 1) * 64].split(b"\0")[0].decode(): (float(ms[i]), int(cnt[i])) for i in range(k)}
 
     # ---- Fr vectors ----
     def fr_vec_op_dev(self, op: int, a, b, out, n: int):

@@ -30,6 +30,7 @@ extern "C" int zk_ctx_destroy(zk_ctx* ctx) {
     for (auto& kv : ctx->slots)
         if (kv.second.p) (void)hipFree(kv.second.p);
     zk_domains_free(ctx);
+    for (auto st : ctx->aux) (void)hipStreamDestroy(st);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return ZK_OK;
@@ -90,14 +91,22 @@ int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out) {
     return ZK_OK;
 }
 
-extern "C" int zk_last_timers(zk_ctx* ctx, char* names, size_t name_stride, float* ms, int max_entries) {
+extern "C" int zk_set_profiling(zk_ctx* ctx, int on) {
+    if (!ctx) return ZK_ERR_ARG;
+    ctx->profiling = on != 0;
+    ctx->timers.clear();
+    return ZK_OK;
+}
+
+extern "C" int zk_last_timers(zk_ctx* ctx, char* names, size_t name_stride, float* ms, int* counts, int max_entries) {
     if (!ctx) return ZK_ERR_ARG;
     int k = 0;
     for (auto& kv : ctx->timers) {
         if (k >= max_entries) break;
         strncpy(names + k * name_stride, kv.first.c_str(), name_stride - 1);
         names[k * name_stride + name_stride - 1] = 0;
-        ms[k] = kv.second;
+        ms[k] = kv.second.ms;
+        if (counts) counts[k] = kv.second.count;
         k++;
     }
     ctx->timers.clear();

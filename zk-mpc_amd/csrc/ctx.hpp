@@ -24,6 +24,7 @@ struct zk_ctx {
     int party_id = 0;
     int n_parties = 1;
     hipStream_t stream = nullptr;
+    std::vector<hipStream_t> aux;   // extra streams for concurrent MSMs (created on first use)
     std::string last_error;
     // grow-only scratch arena: named slots, each re-used across calls (no hipMalloc on the hot path)
     struct Slot { void* p = nullptr; size_t bytes = 0; };
@@ -31,7 +32,9 @@ struct zk_ctx {
     std::map<uint32_t, zk_domain*> domains;  // keyed by log2(size)
     std::mutex mu;
     // timing of the most recent instrumented call (ms), filled when ZK_PROFILE env or explicit request
-    std::map<std::string, float> timers;
+    struct Timer { float ms = 0; int count = 0; };
+    std::map<std::string, Timer> timers;
+    bool profiling = false;
 };
 
 #define ZK_HIP(ctx, expr)                                                                         \

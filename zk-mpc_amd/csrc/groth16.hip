@@ -423,21 +423,72 @@ extern "C" int zk_groth16_setup(zk_ctx* ctx, const zk_r1cs* r, const zk_fr* alph
 
 // ---- prover ----------------------------------------------------------------------------------
 
-extern "C" int zk_groth16_msms_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const void* h,
-                                   zk_g1_projective out_g1[4], zk_g2_projective* out_g2) {
-    if (!ctx || !pk || !r || !z || !h || !out_g1 || !out_g2) return ZK_ERR_ARG;
+namespace {
+
+int ensure_aux(zk_ctx* ctx, size_t k) {
+    while (ctx->aux.size() < k) {
+        hipStream_t st;
+        ZK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ctx->aux.push_back(st);
+    }
+    return ZK_OK;
+}
+
+// The five MSMs of create_proof as a pipeline over five streams.  Order: B in G2 first (longest
+// reduce tail), then A, B in G1, L -- all of which depend only on z -- and H last, because h comes
+// out of the witness map, which (when h_in == nullptr) runs on the main stream concurrently with
+// the first jobs.  Accumulate kernels are chained by events so they run one at a time; the sort
+// and reduce phases of neighbouring jobs overlap with them.
+int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const void* h_in, void* h_scratch,
+             zk_g1_projective out_g1[4], zk_g2_projective* out_g2) {
     const size_t D = (size_t)1 << r->log_d;
     const size_t nvars = (r->ni - 1) + r->nw;
     const char* zb = (const char*)z;
     if (pk->a->n != nvars + 1 || pk->b_g1->n != nvars + 1 || pk->b_g2->n != nvars + 1 || pk->l->n != r->nw)
         ZK_FAIL(ctx, ZK_ERR_ARG, "groth16: proving key does not match the constraint system");
+    ZK_TRY(ensure_aux(ctx, 5));
+    hipEvent_t e0, e1;
+    ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    ZK_HIP(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    ZK_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int k = 0; k < 5; k++) ZK_HIP(ctx, hipStreamWaitEvent(ctx->aux[k], e0, 0));
+    ZkMsmJob jobs[5];
+    int rc = zk_msm_enqueue(ctx, &jobs[0], pk->b_g2, 1, zb + 32, nvars, ctx->aux[0], 1, nullptr);                           // src/groth16.rs:160
+    if (rc == ZK_OK) rc = zk_msm_enqueue(ctx, &jobs[1], pk->a, 1, zb + 32, nvars, ctx->aux[1], 2, jobs[0].accum_done);       // :137 (query[1..])
+    if (rc == ZK_OK) rc = zk_msm_enqueue(ctx, &jobs[2], pk->b_g1, 1, zb + 32, nvars, ctx->aux[2], 3, jobs[1].accum_done);    // :148
+    if (rc == ZK_OK) rc = zk_msm_enqueue(ctx, &jobs[3], pk->l, 0, zb + r->ni * 32, r->nw, ctx->aux[3], 4, jobs[2].accum_done); // :110
+    const void* h = h_in;
+    if (rc == ZK_OK && !h_in) {
+        ZkPhaseTimer tm(ctx);
+        tm.begin("witness_map");
+        rc = zk_groth16_witness_map_dev(ctx, r, z, h_scratch);
+        tm.end();
+        h = h_scratch;
+        if (rc == ZK_OK) {
+            ZK_HIP(ctx, hipEventRecord(e1, ctx->stream));
+            ZK_HIP(ctx, hipStreamWaitEvent(ctx->aux[4], e1, 0));
+            tm.resolve();
+        }
+    }
     // h_acc: min(len) rule (variable_base.rs:15-17): h_query has D-1 entries, h has D
-    ZK_TRY(zk_msm_run(ctx, pk->h, 0, h, std::min(pk->h->n, D), &out_g1[0]));                // src/groth16.rs:106
-    ZK_TRY(zk_msm_run(ctx, pk->l, 0, zb + r->ni * 32, r->nw, &out_g1[1]));                   // :110
-    ZK_TRY(zk_msm_run(ctx, pk->a, 1, zb + 32, nvars, &out_g1[2]));                           // :137 (query[1..])
-    ZK_TRY(zk_msm_run(ctx, pk->b_g1, 1, zb + 32, nvars, &out_g1[3]));                        // :148
-    ZK_TRY(zk_msm_run(ctx, pk->b_g2, 1, zb + 32, nvars, out_g2));                            // :160
-    return ZK_OK;
+    if (rc == ZK_OK) rc = zk_msm_enqueue(ctx, &jobs[4], pk->h, 0, h, std::min(pk->h->n, D), ctx->aux[4], 5, jobs[3].accum_done);  // :106
+    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[4], &out_g1[0]);
+    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[3], &out_g1[1]);
+    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[1], &out_g1[2]);
+    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[2], &out_g1[3]);
+    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[0], out_g2);
+    for (int k = 0; k < 5; k++) (void)hipStreamSynchronize(ctx->aux[k]);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int zk_groth16_msms_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const void* h,
+                                   zk_g1_projective out_g1[4], zk_g2_projective* out_g2) {
+    if (!ctx || !pk || !r || !z || !h || !out_g1 || !out_g2) return ZK_ERR_ARG;
+    return run_msms(ctx, pk, r, z, h, nullptr, out_g1, out_g2);
 }
 
 extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const zk_fr* r_, const zk_fr* s_,
@@ -446,16 +497,9 @@ extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs*
     const size_t D = (size_t)1 << r->log_d;
     void* h;
     ZK_TRY(zk_scratch(ctx, "prove_h", D * 32, &h));
-    {
-        ZkPhaseTimer tm(ctx);
-        tm.begin("witness_map");
-        ZK_TRY(zk_groth16_witness_map_dev(ctx, r, z, h));
-        tm.end();
-        tm.resolve();
-    }
     zk_g1_projective m1[4];
     zk_g2_projective m2;
-    ZK_TRY(zk_groth16_msms_dev(ctx, pk, r, z, h, m1, &m2));
+    ZK_TRY(run_msms(ctx, pk, r, z, nullptr, h, m1, &m2));
 
     using X1 = XYZZ<G1Field>;
     using X2 = XYZZ<G2Field>;

@@ -24,14 +24,31 @@ struct zk_bases {
 int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,
                void* out_host_projective);
 
-// event-based phase timer (cheap: two hipEventRecord per phase; resolved lazily)
+// event-based phase timer (two hipEventRecord per phase on the given stream; resolved lazily)
 struct ZkPhaseTimer {
     zk_ctx* ctx;
+    hipStream_t stream;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
     bool enabled;
-    explicit ZkPhaseTimer(zk_ctx* c);
+    bool resolved = false;
+    explicit ZkPhaseTimer(zk_ctx* c, hipStream_t st = nullptr);
     ~ZkPhaseTimer();
     void begin(const char* name);
     void end();
-    void resolve();  // synchronises the stream and writes ctx->timers
+    void resolve();  // synchronises the stream and accumulates into ctx->timers
 };
+
+// An MSM whose device work has been enqueued on a stream (msm.hip).
+struct ZkMsmJob {
+    int group = 1;
+    size_t n = 0;
+    uint32_t c = 0, W = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t accum_done = nullptr;  // recorded after the accumulate kernel
+    std::vector<uint32_t> hw;         // window sums (XYZZ, internal form), filled by an async copy
+    ZkPhaseTimer* timer = nullptr;
+    ~ZkMsmJob();
+};
+int zk_msm_enqueue(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,
+                   hipStream_t st, int slot, hipEvent_t wait_accum);
+int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out_host_projective);

@@ -94,30 +94,6 @@ k_digits(const void* scalars, size_t n, uint32_t c, uint32_t W, uint32_t NB, Bia
     }
 }
 
-// One block per window: offs[w*(NB+1) + b] = exclusive prefix of counts within the window.
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* counts, uint32_t* offs, uint32_t NB) {
-    __shared__ uint32_t part[1024];
-    const uint32_t w = blockIdx.x, tid = threadIdx.x;
-    const uint32_t per = (NB + 1023) / 1024;
-    const uint32_t lo = tid * per, hi = min(lo + per, NB);
-    uint32_t s = 0;
-    for (uint32_t b = lo; b < hi; b++) s += counts[(size_t)w * NB + b];
-    part[tid] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t run = tid ? part[tid - 1] : 0;
-    for (uint32_t b = lo; b < hi; b++) {
-        offs[(size_t)w * (NB + 1) + b] = run;
-        run += counts[(size_t)w * NB + b];
-    }
-    if (tid == 1023) offs[(size_t)w * (NB + 1) + NB] = part[1023];
-}
-
 // sorted[w*n + pos] = i | sign ; counts are consumed (count down to zero).
 __global__ void __launch_bounds__(256)
 k_scatter(const uint32_t* dig, size_t n, uint32_t W, uint32_t NB, const uint32_t* offs, uint32_t* counts, uint32_t* sorted) {
@@ -132,25 +108,178 @@ k_scatter(const uint32_t* dig, size_t n, uint32_t W, uint32_t NB, const uint32_t
     }
 }
 
-// One thread per (window, bucket).
+// ---- segments -------------------------------------------------------------------------------
+// A bucket with cnt points is cut into max(1, ceil(cnt / SEG)) segments.  Single-segment buckets
+// write their sum straight to sums[key]; the segments of a split ("heavy") bucket write partial
+// sums to sums[n_keys + ...] and k_fold_heavy adds them up.  SEG is ~4x the mean bucket size, so
+// for uniformly random scalars no bucket is split; splitting is what keeps 0/1-heavy witness
+// vectors, repeated scalars and a nearly empty top window from serialising on one thread.
+struct SegDesc { uint32_t start, len, dst; };
+struct HeavyDesc { uint32_t key, first, nseg; };
+
+// One block per window: exclusive scans of counts (-> offs) and of the per-bucket segment counts.
+__global__ void __launch_bounds__(1024)
+k_scan(const uint32_t* counts, uint32_t* offs, uint32_t* seg_local, uint32_t* win_segs, uint32_t NB, uint32_t seg) {
+    __shared__ uint32_t part[1024], part2[1024];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    const uint32_t per = (NB + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = min(lo + per, NB);
+    uint32_t s = 0, s2 = 0;
+    for (uint32_t b = lo; b < hi; b++) {
+        uint32_t c = counts[(size_t)w * NB + b];
+        s += c;
+        s2 += c ? (c + seg - 1) / seg : 1;
+    }
+    part[tid] = s;
+    part2[tid] = s2;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = tid >= d ? part[tid - d] : 0, v2 = tid >= d ? part2[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        part2[tid] += v2;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0, run2 = tid ? part2[tid - 1] : 0;
+    for (uint32_t b = lo; b < hi; b++) {
+        uint32_t c = counts[(size_t)w * NB + b];
+        offs[(size_t)w * (NB + 1) + b] = run;
+        seg_local[(size_t)w * NB + b] = run2;
+        run += c;
+        run2 += c ? (c + seg - 1) / seg : 1;
+    }
+    if (tid == 1023) {
+        offs[(size_t)w * (NB + 1) + NB] = part[1023];
+        win_segs[w] = part2[1023];
+    }
+}
+
+// ctr[0] = heavy buckets, ctr[1] = heavy segments, ctr[2] = total segments; hist[len] = #segments of that length
+__global__ void __launch_bounds__(256)
+k_build_segs(const uint32_t* offs, const uint32_t* seg_local, const uint32_t* win_segs, size_t n, uint32_t W, uint32_t NB,
+             uint32_t seg, SegDesc* desc, HeavyDesc* heavy, uint32_t* ctr, uint32_t* hist) {
+    extern __shared__ uint32_t lh[];  // seg + 1 bins
+    for (uint32_t i = threadIdx.x; i <= seg; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const size_t total = (size_t)W * NB;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        uint32_t w = (uint32_t)(t / NB), b = (uint32_t)(t - (size_t)w * NB);
+        uint32_t base = 0;
+        for (uint32_t k = 0; k < w; k++) base += win_segs[k];
+        base += seg_local[t];
+        uint32_t lo = offs[(size_t)w * (NB + 1) + b], hi = offs[(size_t)w * (NB + 1) + b + 1];
+        uint32_t cnt = hi - lo, start = (uint32_t)(w * n) + lo;
+        if (cnt <= seg) {
+            desc[base] = SegDesc{start, cnt, (uint32_t)t};
+            atomicAdd(&lh[cnt], 1u);
+        } else {
+            uint32_t ns = (cnt + seg - 1) / seg;
+            uint32_t first = atomicAdd(&ctr[1], ns);
+            heavy[atomicAdd(&ctr[0], 1u)] = HeavyDesc{(uint32_t)t, (uint32_t)total + first, ns};
+            for (uint32_t j = 0; j < ns; j++) {
+                uint32_t l = min(seg, cnt - j * seg);
+                desc[base + j] = SegDesc{start + j * seg, l, (uint32_t)total + first + j};
+                atomicAdd(&lh[l], 1u);
+            }
+        }
+        if (t == total - 1) ctr[2] = base + (cnt <= seg ? 1 : (cnt + seg - 1) / seg);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= seg; i += blockDim.x)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// bin_start[len] for a DESCENDING order by length (longest segments first); one block.
+__global__ void __launch_bounds__(1024) k_len_scan(const uint32_t* hist, uint32_t* bin_start, uint32_t* bin_cursor, uint32_t seg) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, nb = seg + 1;
+    const uint32_t per = (nb + 1023) / 1024;
+    // position p = seg - len  (p = 0 is the longest)
+    uint32_t lo = tid * per, hi = min(lo + per, nb), s = 0;
+    for (uint32_t p = lo; p < hi; p++) s += hist[seg - p];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0;
+    for (uint32_t p = lo; p < hi; p++) {
+        bin_start[seg - p] = run;
+        bin_cursor[seg - p] = run;
+        run += hist[seg - p];
+    }
+}
+
+// order[pos] = segment id, grouped by length (descending).  Per-block LDS counting, one global atomic per (block, bin).
+__global__ void __launch_bounds__(256)
+k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t seg, uint32_t* order) {
+    extern __shared__ uint32_t lh[];  // [0..seg]: counts then base
+    const uint32_t S = ctr[2];
+    const uint32_t per_block = (S + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = blockIdx.x * per_block, hi = min(lo + per_block, S);
+    for (uint32_t i = threadIdx.x; i <= seg; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    for (uint32_t s = lo + threadIdx.x; s < hi; s += blockDim.x) atomicAdd(&lh[desc[s].len], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= seg; i += blockDim.x) {
+        uint32_t c = lh[i];
+        lh[i] = c ? atomicAdd(&bin_cursor[i], c) : 0;
+    }
+    __syncthreads();
+    for (uint32_t s = lo + threadIdx.x; s < hi; s += blockDim.x) order[atomicAdd(&lh[desc[s].len], 1u)] = s;
+}
+
+// One thread per segment, longest first; the next point is fetched while the current one is added.
 template <class F>
 __global__ void __launch_bounds__(256)
-k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
-        size_t n, uint32_t W, uint32_t NB, uint32_t* __restrict__ bucket_sums) {
-    const size_t total = (size_t)W * NB;
+k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
+        const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums) {
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    size_t w = t / NB, b = t - w * NB;
-    uint32_t lo = offs[w * (NB + 1) + b], hi = offs[w * (NB + 1) + b + 1];
+    if (t >= ctr[2]) return;
+    const SegDesc d = desc[order[t]];
     XYZZ<F> acc = xyzz_inf<F>();
-    const uint32_t* srt = sorted + w * n;
-    for (uint32_t k = lo; k < hi; k++) {
-        uint32_t e = srt[k];
+    if (d.len) {
+        const uint32_t* srt = sorted + d.start;
+        uint32_t e = srt[0];
         Affine<F> p = aff_load16<F>(bases, e & 0x7fffffffu);
-        if (e >> 31) p.y = F::neg(p.y);
-        acc = xyzz_madd<F>(acc, p);
+        for (uint32_t k = 0; k < d.len; k++) {
+            Affine<F> cur = p;
+            const uint32_t ce = e;
+            if (k + 1 < d.len) {
+                e = srt[k + 1];
+                p = aff_load16<F>(bases, e & 0x7fffffffu);
+            }
+            if (ce >> 31) cur.y = F::neg(cur.y);
+            acc = xyzz_madd<F>(acc, cur);
+        }
     }
-    xyzz_store16<F>(bucket_sums, t, acc);
+    xyzz_store16<F>(sums, d.dst, acc);
+}
+
+// One 64-lane block per split bucket: lanes add strided partial sums, then a shuffle-free LDS tree.
+template <class F>
+__global__ void __launch_bounds__(64)
+k_fold_heavy(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums) {
+    constexpr int XW = 4 * F::WORDS;
+    extern __shared__ uint32_t lds[];  // 64 * XW words
+    if (blockIdx.x >= ctr[0]) return;
+    const HeavyDesc h = heavy[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (uint32_t j = tid; j < h.nseg; j += 64) acc = xyzz_add<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
+    xyzz_store<F>(lds + tid * XW, acc);
+    __syncthreads();
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        if (tid < d) {
+            XYZZ<F> a = xyzz_load<F>(lds + tid * XW), b = xyzz_load<F>(lds + (tid + d) * XW);
+            xyzz_store<F>(lds + tid * XW, xyzz_add<F>(a, b));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) xyzz_store16<F>(sums, h.key, xyzz_load<F>(lds));
 }
 
 // One reduction level (see file header).  Elements per window: T_in; chunk = 2^klog elements.
@@ -199,48 +328,88 @@ __global__ void __launch_bounds__(256) k_bases_export(const uint32_t* in, uint32
     }
 }
 
+// All device work of one MSM, enqueued on `st`; the (<= 64) window sums land in job->hw.
+// `wait_accum` (optional) orders this job's accumulate kernel after another job's, so that when
+// several MSMs are in flight on different streams their sort / reduce phases overlap with the
+// accumulate kernels but the (throughput-bound) accumulate kernels themselves run one at a time.
 template <class F>
-int msm_run_t(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars, size_t n, void* out_host) {
+int msm_enqueue_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base_offset, const void* scalars, size_t n,
+                  hipStream_t st, int slot, hipEvent_t wait_accum) {
     constexpr size_t XW = 4 * F::WORDS;  // words per XYZZ point
-    if (n == 0) {
-        host_write_projective<F>(aff_inf<F>(), (uint64_t*)out_host);
-        return ZK_OK;
-    }
+    job->group = bases->group;
+    job->n = n;
+    job->stream = st;
+    job->timer = new ZkPhaseTimer(ctx, st);
+    if (n == 0) return ZK_OK;
     if (base_offset + n > bases->n) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: base range out of bounds");
-    if (n >= ((size_t)1 << 31)) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: n must be < 2^31");
-    ZkPhaseTimer tm(ctx);
-    MsmPlan p = make_plan(n);
+    if (n >= ((size_t)1 << 27)) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: n must be < 2^27");
+    ZkPhaseTimer& tm = *job->timer;
+    const MsmPlan p = make_plan(n);
+    job->c = p.c;
+    job->W = p.W;
     const uint32_t* bdev = bases->dev + base_offset * (2 * F::WORDS);
-    uint32_t *dig, *sorted, *counts, *offs, *bsum, *lvS[2], *lvW[2];
     const size_t nbuck = (size_t)p.W * p.NB;
-    ZK_TRY(zk_scratch(ctx, "msm_dig", (size_t)p.W * n * 4, (void**)&dig));
-    ZK_TRY(zk_scratch(ctx, "msm_sorted", (size_t)p.W * n * 4, (void**)&sorted));
-    ZK_TRY(zk_scratch(ctx, "msm_counts", nbuck * 4, (void**)&counts));
-    ZK_TRY(zk_scratch(ctx, "msm_offs", (size_t)p.W * (p.NB + 1) * 4, (void**)&offs));
-    ZK_TRY(zk_scratch(ctx, F::WORDS == 12 ? "msm_bsum1" : "msm_bsum2", nbuck * XW * 4, (void**)&bsum));
+    uint32_t mean = (uint32_t)(n / p.NB);
+    uint32_t seg = 64;
+    while (seg < 4 * mean && seg < 4096) seg <<= 1;
+    const size_t max_segs = nbuck + (size_t)p.W * n / seg + p.W;       // every bucket >= 1 segment
+    const size_t max_heavy_segs = 2 * ((size_t)p.W * n / seg) + p.W;   // segments of split buckets
+    const size_t max_heavy = (size_t)p.W * n / seg + 1;
+    char nm[64];
+    auto slotname = [&](const char* base) { snprintf(nm, sizeof nm, "%s.%d", base, slot); return nm; };
+    uint32_t *dig, *sorted, *counts, *offs, *seg_local, *small, *order, *sums, *lvS[2], *lvW[2];
+    SegDesc* desc;
+    HeavyDesc* heavy;
+    ZK_TRY(zk_scratch(ctx, slotname("msm_dig"), (size_t)p.W * n * 4, (void**)&dig));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_sorted"), (size_t)p.W * n * 4, (void**)&sorted));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_counts"), nbuck * 4, (void**)&counts));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_offs"), (size_t)p.W * (p.NB + 1) * 4, (void**)&offs));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_segl"), nbuck * 4, (void**)&seg_local));
+    // small: win_segs[64] | ctr[4] | hist[seg+1] | bin_start[seg+1] | bin_cursor[seg+1]
+    const size_t small_words = 64 + 4 + 3 * (size_t)(seg + 1);
+    ZK_TRY(zk_scratch(ctx, slotname("msm_small"), small_words * 4, (void**)&small));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_desc"), max_segs * sizeof(SegDesc), (void**)&desc));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_heavy"), max_heavy * sizeof(HeavyDesc), (void**)&heavy));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_order"), max_segs * 4, (void**)&order));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_sums"), (nbuck + max_heavy_segs) * XW * 4, (void**)&sums));
     const size_t lv_elems = (size_t)p.W * ((p.NB >> REDUCE_K_LOG) + 1);
     for (int k = 0; k < 2; k++) {
-        ZK_TRY(zk_scratch(ctx, k ? "msm_lvS1" : "msm_lvS0", lv_elems * XW * 4, (void**)&lvS[k]));
-        ZK_TRY(zk_scratch(ctx, k ? "msm_lvW1" : "msm_lvW0", lv_elems * XW * 4, (void**)&lvW[k]));
+        ZK_TRY(zk_scratch(ctx, slotname(k ? "msm_lvS1" : "msm_lvS0"), lv_elems * XW * 4, (void**)&lvS[k]));
+        ZK_TRY(zk_scratch(ctx, slotname(k ? "msm_lvW1" : "msm_lvW0"), lv_elems * XW * 4, (void**)&lvW[k]));
     }
+    uint32_t* win_segs = small;
+    uint32_t* ctr = small + 64;
+    uint32_t* hist = small + 68;
+    uint32_t* bin_start = hist + (seg + 1);
+    uint32_t* bin_cursor = bin_start + (seg + 1);
     Bias bias;
     for (int i = 0; i < 9; i++) bias.w[i] = p.bias[i];
+    const bool g1 = F::WORDS == 12;
 
-    tm.begin("msm.sort");
-    ZK_HIP(ctx, hipMemsetAsync(counts, 0, nbuck * 4, ctx->stream));
-    hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, ctx->stream, scalars, n, p.c, p.W, p.NB, bias, dig, counts);
-    hipLaunchKernelGGL(k_scan, p.W, 1024, 0, ctx->stream, counts, offs, p.NB);
-    hipLaunchKernelGGL(k_scatter, zk_grid((size_t)p.W * n, 256), 256, 0, ctx->stream, dig, n, p.W, p.NB, offs, counts, sorted);
+    tm.begin(g1 ? "msm_g1.sort" : "msm_g2.sort");
+    ZK_HIP(ctx, hipMemsetAsync(counts, 0, nbuck * 4, st));
+    ZK_HIP(ctx, hipMemsetAsync(small, 0, small_words * 4, st));
+    hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, scalars, n, p.c, p.W, p.NB, bias, dig, counts);
+    hipLaunchKernelGGL(k_scan, p.W, 1024, 0, st, counts, offs, seg_local, win_segs, p.NB, seg);
+    hipLaunchKernelGGL(k_scatter, zk_grid((size_t)p.W * n, 256), 256, 0, st, dig, n, p.W, p.NB, offs, counts, sorted);
+    hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, offs, seg_local, win_segs, n, p.W, p.NB,
+                       seg, desc, heavy, ctr, hist);
+    hipLaunchKernelGGL(k_len_scan, 1, 1024, 0, st, hist, bin_start, bin_cursor, seg);
+    hipLaunchKernelGGL(k_order, 512, 256, (seg + 1) * 4, st, desc, ctr, bin_cursor, seg, order);
     ZK_HIP(ctx, hipGetLastError());
     tm.end();
 
-    tm.begin("msm.accum");
-    hipLaunchKernelGGL(k_accum<F>, (unsigned)((nbuck + 255) / 256), 256, 0, ctx->stream, bdev, sorted, offs, n, p.W, p.NB, bsum);
+    if (wait_accum) ZK_HIP(ctx, hipStreamWaitEvent(st, wait_accum, 0));
+    tm.begin(g1 ? "msm_g1.accum" : "msm_g2.accum");
+    hipLaunchKernelGGL(k_accum<F>, (unsigned)((max_segs + 255) / 256), 256, 0, st, bdev, sorted, desc, order, ctr, sums);
     ZK_HIP(ctx, hipGetLastError());
     tm.end();
+    ZK_HIP(ctx, hipEventCreateWithFlags(&job->accum_done, hipEventDisableTiming));
+    ZK_HIP(ctx, hipEventRecord(job->accum_done, st));
 
-    tm.begin("msm.reduce");
-    const uint32_t* S_in = bsum;
+    tm.begin(g1 ? "msm_g1.reduce" : "msm_g2.reduce");
+    hipLaunchKernelGGL(k_fold_heavy<F>, (unsigned)max_heavy, 64, 64 * XW * 4, st, heavy, ctr, sums);
+    const uint32_t* S_in = sums;
     const uint32_t* W_in = nullptr;
     uint32_t T_in = p.NB;
     int level = 0;
@@ -251,26 +420,43 @@ int msm_run_t(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void
         uint32_t* So = lvS[level & 1];
         uint32_t* Wo = lvW[level & 1];
         size_t threads = (size_t)p.W * T_out;
-        hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, ctx->stream, S_in, W_in, So, Wo, T_in, T_out,
+        hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, S_in, W_in, So, Wo, T_in, T_out,
                            (uint32_t)REDUCE_K_LOG, p.W, level == 0 ? 1 : 0, last);
         ZK_HIP(ctx, hipGetLastError());
         if (last) { result = Wo; break; }
         S_in = So; W_in = Wo; T_in = T_out; level++;
     }
     tm.end();
+    job->hw.resize((size_t)p.W * XW);
+    ZK_HIP(ctx, hipMemcpyAsync(job->hw.data(), result, job->hw.size() * 4, hipMemcpyDeviceToHost, st));
+    return ZK_OK;
+}
 
-    std::vector<uint32_t> hw((size_t)p.W * XW);
-    ZK_HIP(ctx, hipMemcpyAsync(hw.data(), result, hw.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    tm.resolve();
+template <class F>
+int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
+    constexpr size_t XW = 4 * F::WORDS;
+    if (job->n == 0) {
+        host_write_projective<F>(aff_inf<F>(), (uint64_t*)out_host);
+        return ZK_OK;
+    }
+    ZK_HIP(ctx, hipStreamSynchronize(job->stream));
+    job->timer->resolve();
     // Horner over windows, most significant first (variable_base.rs:94-105)
     XYZZ<F> total = xyzz_inf<F>();
-    for (int w = (int)p.W - 1; w >= 0; w--) {
-        for (uint32_t k = 0; k < p.c; k++) total = xyzz_dbl<F>(total);
-        total = xyzz_add<F>(total, xyzz_load<F>(hw.data() + (size_t)w * XW));
+    for (int w = (int)job->W - 1; w >= 0; w--) {
+        for (uint32_t k = 0; k < job->c; k++) total = xyzz_dbl<F>(total);
+        total = xyzz_add<F>(total, xyzz_load<F>(job->hw.data() + (size_t)w * XW));
     }
     host_write_projective<F>(xyzz_to_affine<F>(total), (uint64_t*)out_host);
     return ZK_OK;
+}
+
+template <class F>
+int msm_run_t(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars, size_t n, void* out_host) {
+    ZkMsmJob job;
+    int rc = msm_enqueue_t<F>(ctx, &job, bases, base_offset, scalars, n, ctx->stream, 0, nullptr);
+    if (rc == ZK_OK) rc = msm_finish_t<F>(ctx, &job, out_host);
+    return rc;
 }
 
 template <class F>
@@ -329,7 +515,7 @@ int msm_host_t(zk_ctx* ctx, const void* bases_host, size_t nb, const zk_fr* scal
 }  // namespace
 
 // ---- phase timer ----
-ZkPhaseTimer::ZkPhaseTimer(zk_ctx* c) : ctx(c) { enabled = getenv("ZK_PROFILE") != nullptr; }
+ZkPhaseTimer::ZkPhaseTimer(zk_ctx* c, hipStream_t st) : ctx(c), stream(st ? st : c->stream) { enabled = c->profiling; }
 ZkPhaseTimer::~ZkPhaseTimer() {
     for (auto& e : ev) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
 }
@@ -338,20 +524,39 @@ void ZkPhaseTimer::begin(const char* name) {
     hipEvent_t a, b;
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);
-    (void)hipEventRecord(a, ctx->stream);
+    (void)hipEventRecord(a, stream);
     ev.push_back({name, {a, b}});
 }
 void ZkPhaseTimer::end() {
     if (!enabled || ev.empty()) return;
-    (void)hipEventRecord(ev.back().second.second, ctx->stream);
+    (void)hipEventRecord(ev.back().second.second, stream);
 }
 void ZkPhaseTimer::resolve() {
-    if (!enabled) return;
-    (void)hipStreamSynchronize(ctx->stream);
+    if (!enabled || resolved) return;
+    resolved = true;
+    (void)hipStreamSynchronize(stream);
     for (auto& e : ev) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, e.second.first, e.second.second) == hipSuccess) ctx->timers[e.first] += ms;
+        if (hipEventElapsedTime(&ms, e.second.first, e.second.second) == hipSuccess) {
+            ctx->timers[e.first].ms += ms;
+            ctx->timers[e.first].count += 1;
+        }
     }
+}
+
+ZkMsmJob::~ZkMsmJob() {
+    delete timer;
+    if (accum_done) (void)hipEventDestroy(accum_done);
+}
+
+int zk_msm_enqueue(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,
+                   hipStream_t st, int slot, hipEvent_t wait_accum) {
+    if (bases->group == 1) return msm_enqueue_t<G1Field>(ctx, job, bases, base_offset, scalars_dev, n, st, slot, wait_accum);
+    return msm_enqueue_t<G2Field>(ctx, job, bases, base_offset, scalars_dev, n, st, slot, wait_accum);
+}
+int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out) {
+    if (job->group == 1) return msm_finish_t<G1Field>(ctx, job, out);
+    return msm_finish_t<G2Field>(ctx, job, out);
 }
 
 int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n, void* out) {
