@@ -1,0 +1,54 @@
+"""Shared test helpers (oracle <-> ABI array conversions, fixtures)."""
+import json
+import os
+
+import numpy as np
+
+import zkref as O
+import zk_mpc_amd.convert as cv
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    return json.load(open(os.path.join(GOLDEN, name)))
+
+
+def ih(x):
+    return int(x, 16)
+
+
+def g1_from_json(p):
+    return None if p is None else (ih(p[0]), ih(p[1]))
+
+
+def g2_from_json(p):
+    return None if p is None else ((ih(p[0][0]), ih(p[0][1])), (ih(p[1][0]), ih(p[1][1])))
+
+
+def csr(rows):
+    rp, col, coeff = [0], [], []
+    for r in rows:
+        for c, i in r:
+            col.append(i)
+            coeff.append(c)
+        rp.append(len(col))
+    return (np.array(rp, dtype=np.uint32), np.array(col, dtype=np.uint32),
+            cv.fr_to_mont(coeff) if coeff else np.zeros((0, 4), dtype=np.uint64))
+
+
+def r1cs_from_json(j):
+    rows = lambda m: [[(ih(c), i) for c, i in row] for row in m]
+    return O.R1CS(j["num_instance"], j["num_witness"], rows(j["a"]), rows(j["b"]), rows(j["c"]))
+
+
+def trapdoor_from_json(t):
+    return O.Trapdoor(*[ih(t[k]) for k in ("alpha", "beta", "gamma", "delta", "tau", "g1_k", "g2_k")])
+
+
+def td_mont(td):
+    return cv.fr_to_mont([td.alpha, td.beta, td.gamma, td.delta, td.tau, td.g1_k, td.g2_k])
+
+
+def mont1(v):
+    return cv.fr_to_mont([v])[0]

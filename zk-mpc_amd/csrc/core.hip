@@ -29,8 +29,11 @@ extern "C" int zk_ctx_destroy(zk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->slots)
         if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : ctx->pinned)
+        if (kv.second.p) (void)hipHostFree(kv.second.p);
     zk_domains_free(ctx);
     for (auto st : ctx->aux) (void)hipStreamDestroy(st);
+    if (ctx->acc_stream) (void)hipStreamDestroy(ctx->acc_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return ZK_OK;

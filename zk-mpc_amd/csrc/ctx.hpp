@@ -24,11 +24,13 @@ struct zk_ctx {
     int party_id = 0;
     int n_parties = 1;
     hipStream_t stream = nullptr;
-    std::vector<hipStream_t> aux;   // extra streams for concurrent MSMs (created on first use)
+    std::vector<hipStream_t> aux;   // high-priority helper streams for concurrent MSMs (created on first use)
+    hipStream_t acc_stream = nullptr;  // stream carrying the accumulate kernels back to back
     std::string last_error;
     // grow-only scratch arena: named slots, each re-used across calls (no hipMalloc on the hot path)
     struct Slot { void* p = nullptr; size_t bytes = 0; };
     std::map<std::string, Slot> slots;
+    std::map<int, Slot> pinned;     // pinned host staging per MSM slot
     std::map<uint32_t, zk_domain*> domains;  // keyed by log2(size)
     std::mutex mu;
     // timing of the most recent instrumented call (ms), filled when ZK_PROFILE env or explicit request

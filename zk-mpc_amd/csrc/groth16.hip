@@ -14,7 +14,10 @@
 #include "../../include/zkmpc_hip.h"
 #include "devutil.cuh"
 #include "hostgroup.hpp"
+#include "hostfield64.hpp"
 #include "internal.hpp"
+#include <chrono>
+#include <future>
 #include <vector>
 
 using namespace zk;
@@ -431,14 +434,17 @@ int ensure_aux(zk_ctx* ctx, size_t k) {
         ZK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         ctx->aux.push_back(st);
     }
+    if (!ctx->acc_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->acc_stream, hipStreamNonBlocking));
     return ZK_OK;
 }
 
-// The five MSMs of create_proof as a pipeline over five streams.  Order: B in G2 first (longest
-// reduce tail), then A, B in G1, L -- all of which depend only on z -- and H last, because h comes
-// out of the witness map, which (when h_in == nullptr) runs on the main stream concurrently with
-// the first jobs.  Accumulate kernels are chained by events so they run one at a time; the sort
-// and reduce phases of neighbouring jobs overlap with them.
+// The five MSMs of create_proof as a pipeline over THREE streams (the runtime maps streams onto ~3
+// usable hardware queues; a fourth stream lands on an occupied queue and serialises behind it):
+//   main       : witness map, then the sort of the H job (its scalars come out of the witness map)
+//   sort/reduce: sort of the z-dependent jobs first (B-in-G2 / A / B-in-G1 share one sort: same scalars
+//                z[1..]), then, as the accumulate kernels complete, each job's reduce phase in job order
+//   accum      : the five accumulate kernels back to back, B-in-G2 first (longest reduce), H last;
+//                the first one is gated on the witness map, which would otherwise be starved 15x beside it
 int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const void* h_in, void* h_scratch,
              zk_g1_projective out_g1[4], zk_g2_projective* out_g2) {
     const size_t D = (size_t)1 << r->log_d;
@@ -446,38 +452,54 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     const char* zb = (const char*)z;
     if (pk->a->n != nvars + 1 || pk->b_g1->n != nvars + 1 || pk->b_g2->n != nvars + 1 || pk->l->n != r->nw)
         ZK_FAIL(ctx, ZK_ERR_ARG, "groth16: proving key does not match the constraint system");
-    ZK_TRY(ensure_aux(ctx, 5));
+    ZK_TRY(ensure_aux(ctx, 1));
+    hipStream_t s_sort = ctx->aux[0], s_red = ctx->aux[0], s_acc = ctx->acc_stream;
     hipEvent_t e0, e1;
     ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    for (int k = 0; k < 5; k++) ZK_HIP(ctx, hipStreamWaitEvent(ctx->aux[k], e0, 0));
-    ZkMsmJob jobs[5];
-    int rc = zk_msm_enqueue(ctx, &jobs[0], pk->b_g2, 1, zb + 32, nvars, ctx->aux[0], 1, nullptr);                           // src/groth16.rs:160
-    if (rc == ZK_OK) rc = zk_msm_enqueue(ctx, &jobs[1], pk->a, 1, zb + 32, nvars, ctx->aux[1], 2, jobs[0].accum_done);       // :137 (query[1..])
-    if (rc == ZK_OK) rc = zk_msm_enqueue(ctx, &jobs[2], pk->b_g1, 1, zb + 32, nvars, ctx->aux[2], 3, jobs[1].accum_done);    // :148
-    if (rc == ZK_OK) rc = zk_msm_enqueue(ctx, &jobs[3], pk->l, 0, zb + r->ni * 32, r->nw, ctx->aux[3], 4, jobs[2].accum_done); // :110
+    ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e0, 0));
+    ZkMsmJob jobs[5];  // 0: B in G2, 1: A, 2: B in G1, 3: L, 4: H
+    int rc = zk_msm_prepare(ctx, &jobs[0], pk->b_g2, 1, zb + 32, nvars, 1);                       // src/groth16.rs:160 (query[1..])
+    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &jobs[1], pk->a, 1, zb + 32, nvars, 2);              // :137
+    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &jobs[2], pk->b_g1, 1, zb + 32, nvars, 3);           // :148
+    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &jobs[3], pk->l, 0, zb + r->ni * 32, r->nw, 4);      // :110
+    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[0], s_sort, nullptr);
+    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[1], s_sort, &jobs[0]);
+    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[2], s_sort, &jobs[0]);
     const void* h = h_in;
+    ZkPhaseTimer tm(ctx);
     if (rc == ZK_OK && !h_in) {
-        ZkPhaseTimer tm(ctx);
         tm.begin("witness_map");
         rc = zk_groth16_witness_map_dev(ctx, r, z, h_scratch);
         tm.end();
         h = h_scratch;
-        if (rc == ZK_OK) {
-            ZK_HIP(ctx, hipEventRecord(e1, ctx->stream));
-            ZK_HIP(ctx, hipStreamWaitEvent(ctx->aux[4], e1, 0));
-            tm.resolve();
-        }
     }
     // h_acc: min(len) rule (variable_base.rs:15-17): h_query has D-1 entries, h has D
-    if (rc == ZK_OK) rc = zk_msm_enqueue(ctx, &jobs[4], pk->h, 0, h, std::min(pk->h->n, D), ctx->aux[4], 5, jobs[3].accum_done);  // :106
-    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[4], &out_g1[0]);
-    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[3], &out_g1[1]);
+    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &jobs[4], pk->h, 0, h, std::min(pk->h->n, D), 5);   // :106
+    if (rc == ZK_OK) {
+        ZK_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e1, 0));
+        rc = zk_msm_enqueue_sort(ctx, &jobs[4], ctx->stream, nullptr);
+    }
+    // L's sort after the witness map (it is not needed before the fourth accumulate kernel)
+    if (rc == ZK_OK) {
+        ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e1, 0));
+        rc = zk_msm_enqueue_sort(ctx, &jobs[3], s_sort, nullptr);
+    }
+    for (int k = 0; k < 5 && rc == ZK_OK; k++) rc = zk_msm_enqueue_accum(ctx, &jobs[k], s_acc);
+    for (int k = 0; k < 5 && rc == ZK_OK; k++) rc = zk_msm_enqueue_reduce(ctx, &jobs[k], s_red);
+    // finish in completion order: the host-side Horner of an early job overlaps the GPU work of the later ones
+    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[0], out_g2);
     if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[1], &out_g1[2]);
     if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[2], &out_g1[3]);
-    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[0], out_g2);
-    for (int k = 0; k < 5; k++) (void)hipStreamSynchronize(ctx->aux[k]);
+    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[3], &out_g1[1]);
+    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[4], &out_g1[0]);
+    (void)hipStreamSynchronize(s_sort);
+    (void)hipStreamSynchronize(s_acc);
+    (void)hipStreamSynchronize(s_red);
+    (void)hipStreamSynchronize(ctx->stream);
+    tm.resolve();
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
@@ -501,37 +523,57 @@ extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs*
     zk_g2_projective m2;
     ZK_TRY(run_msms(ctx, pk, r, z, nullptr, h, m1, &m2));
 
-    using X1 = XYZZ<G1Field>;
-    using X2 = XYZZ<G2Field>;
+    // ---- O(1) tail on the host, 64-bit limbs, three independent chains on three threads ----
+    const auto t_tail = std::chrono::steady_clock::now();
+    using H1 = Fq64Field;
+    using H2 = Fq264Field;
+    using X1 = XYZZ<H1>;
+    using X2 = XYZZ<H2>;
     uint32_t rw[8], sw[8];
     fr_abi_to_canon_words(r_->l, rw);
     fr_abi_to_canon_words(s_->l, sw);
-    const X1 h_acc = host_proj_from_abi<G1Field>((const uint64_t*)&m1[0]);
-    const X1 l_acc = host_proj_from_abi<G1Field>((const uint64_t*)&m1[1]);
-    const X1 a_acc = host_proj_from_abi<G1Field>((const uint64_t*)&m1[2]);
-    const X1 b1_acc = host_proj_from_abi<G1Field>((const uint64_t*)&m1[3]);
-    const X2 b2_acc = host_proj_from_abi<G2Field>((const uint64_t*)&m2);
-    const X1 delta1 = xyzz_from_affine<G1Field>(pk->delta_g1);
-    const X2 delta2 = xyzz_from_affine<G2Field>(pk->delta_g2);
+    const X1 h_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[0]);
+    const X1 l_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[1]);
+    const X1 a_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[2]);
+    const X1 b1_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[3]);
+    const X2 b2_acc = host64_proj_from_abi<H2>((const uint64_t*)&m2);
+    const X1 delta1 = xyzz_from_affine<H1>(aff_to_host64<G1Field>(pk->delta_g1));
+    const X2 delta2 = xyzz_from_affine<H2>(aff_to_host64<G2Field>(pk->delta_g2));
+    const Affine<H1> a0 = aff_to_host64<G1Field>(pk->a0), alpha = aff_to_host64<G1Field>(pk->alpha_g1);
+    const Affine<H1> b0 = aff_to_host64<G1Field>(pk->b0_g1), beta1 = aff_to_host64<G1Field>(pk->beta_g1);
+    const Affine<H2> b02 = aff_to_host64<G2Field>(pk->b0_g2), beta2 = aff_to_host64<G2Field>(pk->beta_g2);
 
     // calculate_coeff (src/groth16.rs:185-201): initial + query[0] + acc + vk_param
-    const X1 r_g1 = host_scalar_mul<G1Field>(delta1, rw);
-    const X1 r_s_delta = host_scalar_mul<G1Field>(r_g1, sw);                                         // :115
-    X1 g_a = xyzz_madd<G1Field>(xyzz_add<G1Field>(xyzz_madd<G1Field>(r_g1, pk->a0), a_acc), pk->alpha_g1);
-    const X1 s_g_a = host_scalar_mul<G1Field>(g_a, sw);                                              // :140
-    const X1 s_g1 = host_scalar_mul<G1Field>(delta1, sw);
-    const X1 g1_b = xyzz_madd<G1Field>(xyzz_add<G1Field>(xyzz_madd<G1Field>(s_g1, pk->b0_g1), b1_acc), pk->beta_g1);
-    const X2 s_g2 = host_scalar_mul<G2Field>(delta2, sw);
-    const X2 g2_b = xyzz_madd<G2Field>(xyzz_add<G2Field>(xyzz_madd<G2Field>(s_g2, pk->b0_g2), b2_acc), pk->beta_g2);
-    const X1 r_g1_b = host_scalar_mul<G1Field>(g1_b, rw);                                            // :161
-    X1 g_c = xyzz_add<G1Field>(s_g_a, r_g1_b);                                                       // :169-174
-    g_c = xyzz_add<G1Field>(g_c, xyzz_neg<G1Field>(r_s_delta));
-    g_c = xyzz_add<G1Field>(g_c, l_acc);
-    g_c = xyzz_add<G1Field>(g_c, h_acc);
+    X1 g_a, s_g_a, r_s_delta, r_g1_b;
+    auto chain_a = std::async(std::launch::async, [&] {
+        const X1 r_g1 = host64_scalar_mul<H1>(delta1, rw);
+        r_s_delta = host64_scalar_mul<H1>(r_g1, sw);                                                     // :115
+        g_a = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(r_g1, a0), a_acc), alpha);
+        s_g_a = host64_scalar_mul<H1>(g_a, sw);                                                           // :140
+    });
+    auto chain_b = std::async(std::launch::async, [&] {
+        const X1 s_g1 = host64_scalar_mul<H1>(delta1, sw);
+        const X1 g1_b = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(s_g1, b0), b1_acc), beta1);
+        r_g1_b = host64_scalar_mul<H1>(g1_b, rw);                                                         // :161
+    });
+    const X2 s_g2 = host64_scalar_mul<H2>(delta2, sw);
+    const X2 g2_b = xyzz_madd<H2>(xyzz_add<H2>(xyzz_madd<H2>(s_g2, b02), b2_acc), beta2);
+    const Affine<H2> b_aff = xyzz_to_affine<H2>(g2_b);
+    chain_a.get();
+    chain_b.get();
+    X1 g_c = xyzz_add<H1>(s_g_a, r_g1_b);                                                                 // :169-174
+    g_c = xyzz_add<H1>(g_c, xyzz_neg<H1>(r_s_delta));
+    g_c = xyzz_add<H1>(g_c, l_acc);
+    g_c = xyzz_add<H1>(g_c, h_acc);
 
-    g1_serialize(xyzz_to_affine<G1Field>(g_a), proof);
-    g2_serialize(xyzz_to_affine<G2Field>(g2_b), proof + 48);
-    g1_serialize(xyzz_to_affine<G1Field>(g_c), proof + 144);
+    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<H1>(g_a)), proof);
+    g2_serialize(aff_from_host64<G2Field>(b_aff), proof + 48);
+    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<H1>(g_c)), proof + 144);
+    if (ctx->profiling) {
+        auto& t = ctx->timers["host.tail"];
+        t.ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_tail).count();
+        t.count += 1;
+    }
     return ZK_OK;
 }
 

@@ -1,0 +1,228 @@
+// hostfield64.hpp -- host-only Fq / Fq2 with 64-bit limbs (Montgomery R = 2^384, i.e. exactly the
+// reference's in-memory form), used for the O(1)-per-proof tail of the prover: Horner over the
+// window sums, the r/s scalar multiplications of create_proof (src/groth16.rs:115-174) and the
+// affine conversion before serialisation.  Same static interface as FqField / Fq2Field in
+// fp29.cuh, so the curve templates in ec.cuh are reused unchanged; about 3x faster on x86 than
+// running the 29-bit device representation on the host.
+#pragma once
+#include <stdint.h>
+#include "ec.cuh"
+
+namespace zk {
+
+struct Fq64 { uint64_t l[6]; };
+
+namespace host64 {
+static const uint64_t P[6] = {0x8508c00000000001ull, 0x170b5d4430000000ull, 0x1ef3622fba094800ull,
+                              0x1a22d9f300f5138full, 0xc63b05c06ca1493bull, 0x01ae3a4617c510eaull};
+static const uint64_t ONE[6] = {202099033278250856ull, 5854854902718660529ull, 11492539364873682930ull,
+                                8885205928937022213ull, 5545221690922665192ull, 39800542322357402ull};  // R mod p
+static const uint64_t INV = 9586122913090633727ull;  // -p^-1 mod 2^64
+typedef unsigned __int128 u128;
+
+inline int cmp(const uint64_t* a, const uint64_t* b) {
+    for (int i = 5; i >= 0; i--) {
+        if (a[i] < b[i]) return -1;
+        if (a[i] > b[i]) return 1;
+    }
+    return 0;
+}
+inline void sub_raw(uint64_t* a, const uint64_t* b) {
+    u128 br = 0;
+    for (int i = 0; i < 6; i++) {
+        u128 t = (u128)a[i] - b[i] - br;
+        a[i] = (uint64_t)t;
+        br = (t >> 64) & 1;
+    }
+}
+}  // namespace host64
+
+struct Fq64Field {
+    using T = Fq64;
+    static T zero() { return T{{0, 0, 0, 0, 0, 0}}; }
+    static T one() { T r; for (int i = 0; i < 6; i++) r.l[i] = host64::ONE[i]; return r; }
+    static bool is_zero(const T& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3] | a.l[4] | a.l[5]) == 0; }
+    static bool eq(const T& a, const T& b) {
+        uint64_t o = 0;
+        for (int i = 0; i < 6; i++) o |= a.l[i] ^ b.l[i];
+        return o == 0;
+    }
+    static T add(const T& a, const T& b) {
+        T r;
+        host64::u128 c = 0;
+        for (int i = 0; i < 6; i++) { c += (host64::u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+        if (host64::cmp(r.l, host64::P) >= 0) host64::sub_raw(r.l, host64::P);
+        return r;
+    }
+    static T sub(const T& a, const T& b) {
+        T r = a;
+        if (host64::cmp(b.l, r.l) > 0) {
+            host64::u128 c = 0;
+            for (int i = 0; i < 6; i++) { c += (host64::u128)r.l[i] + host64::P[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+        }
+        host64::sub_raw(r.l, b.l);
+        return r;
+    }
+    static T dbl(const T& a) { return add(a, a); }
+    static T neg(const T& a) { return is_zero(a) ? a : sub(zero(), a); }
+    static T mul(const T& a, const T& b) {
+        using host64::u128;
+        uint64_t r[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 6; i++) {
+            u128 t = (u128)a.l[0] * b.l[i] + r[0];
+            uint64_t r0 = (uint64_t)t, c1 = (uint64_t)(t >> 64);
+            uint64_t k = r0 * host64::INV;
+            t = (u128)k * host64::P[0] + r0;
+            uint64_t c2 = (uint64_t)(t >> 64);
+            for (int j = 1; j < 6; j++) {
+                t = (u128)a.l[j] * b.l[i] + r[j] + c1;
+                uint64_t rj = (uint64_t)t;
+                c1 = (uint64_t)(t >> 64);
+                t = (u128)k * host64::P[j] + rj + c2;
+                r[j - 1] = (uint64_t)t;
+                c2 = (uint64_t)(t >> 64);
+            }
+            r[5] = c1 + c2;
+        }
+        T o;
+        for (int i = 0; i < 6; i++) o.l[i] = r[i];
+        if (host64::cmp(o.l, host64::P) >= 0) host64::sub_raw(o.l, host64::P);
+        return o;
+    }
+    static T sqr(const T& a) { return mul(a, a); }
+    static T inv(const T& a) {  // a^(p-2)
+        uint64_t e[6];
+        for (int i = 0; i < 6; i++) e[i] = host64::P[i];
+        e[0] -= 2;
+        T r = one();
+        for (int i = 5; i >= 0; i--)
+            for (int b = 63; b >= 0; b--) {
+                r = sqr(r);
+                if ((e[i] >> b) & 1) r = mul(r, a);
+            }
+        return r;
+    }
+    static T select(bool c, const T& a, const T& b) { return c ? a : b; }
+    static constexpr int WORDS = 12;
+    static T load(const uint32_t* w) {  // ext-form words
+        T r;
+        for (int i = 0; i < 6; i++) r.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+        return r;
+    }
+    static void store(uint32_t* w, const T& a) {
+        for (int i = 0; i < 6; i++) { w[2 * i] = (uint32_t)a.l[i]; w[2 * i + 1] = (uint32_t)(a.l[i] >> 32); }
+    }
+    // conversions with the device representation (internal form, 29-bit limbs)
+    static T from_dev(const Fq& a) {
+        uint32_t w[12];
+        fp_pack<FqParams>(w, fp_int_to_ext<FqParams>(a));
+        return load(w);
+    }
+    static Fq to_dev(const T& a) {
+        uint32_t w[12];
+        store(w, a);
+        return fp_ext_to_int<FqParams>(fp_unpack<FqParams>(w));
+    }
+};
+
+struct Fq264 { Fq64 c0, c1; };
+
+struct Fq264Field {
+    using T = Fq264;
+    using B = Fq64Field;
+    static T zero() { return T{B::zero(), B::zero()}; }
+    static T one() { return T{B::one(), B::zero()}; }
+    static T add(const T& a, const T& b) { return T{B::add(a.c0, b.c0), B::add(a.c1, b.c1)}; }
+    static T sub(const T& a, const T& b) { return T{B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
+    static T dbl(const T& a) { return T{B::dbl(a.c0), B::dbl(a.c1)}; }
+    static T neg(const T& a) { return T{B::neg(a.c0), B::neg(a.c1)}; }
+    static Fq64 mul5(const Fq64& a) { Fq64 t = B::dbl(B::dbl(a)); return B::add(t, a); }
+    static T mul(const T& a, const T& b) {
+        Fq64 v0 = B::mul(a.c0, b.c0), v1 = B::mul(a.c1, b.c1);
+        Fq64 s = B::mul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
+        return T{B::sub(v0, mul5(v1)), B::sub(B::sub(s, v0), v1)};
+    }
+    static T sqr(const T& a) { return mul(a, a); }
+    static T inv(const T& a) {
+        Fq64 n = B::add(B::sqr(a.c0), mul5(B::sqr(a.c1)));
+        Fq64 ni = B::inv(n);
+        return T{B::mul(a.c0, ni), B::neg(B::mul(a.c1, ni))};
+    }
+    static bool is_zero(const T& a) { return B::is_zero(a.c0) && B::is_zero(a.c1); }
+    static bool eq(const T& a, const T& b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1); }
+    static constexpr int WORDS = 24;
+    static T load(const uint32_t* w) { return T{B::load(w), B::load(w + 12)}; }
+    static void store(uint32_t* w, const T& a) { B::store(w, a.c0); B::store(w + 12, a.c1); }
+    static T from_dev(const Fq2& a) { return T{B::from_dev(a.c0), B::from_dev(a.c1)}; }
+    static Fq2 to_dev(const T& a) { return Fq2{B::to_dev(a.c0), B::to_dev(a.c1)}; }
+};
+
+// device-field <-> host-field mapping used by the generic tail code
+template <class F> struct Host64Of;
+template <> struct Host64Of<FqField> { using type = Fq64Field; };
+template <> struct Host64Of<Fq2Field> { using type = Fq264Field; };
+
+template <class F>
+inline XYZZ<typename Host64Of<F>::type> xyzz_to_host64(const XYZZ<F>& p) {
+    using H = typename Host64Of<F>::type;
+    return XYZZ<H>{H::from_dev(p.x), H::from_dev(p.y), H::from_dev(p.zz), H::from_dev(p.zzz)};
+}
+template <class F>
+inline Affine<typename Host64Of<F>::type> aff_to_host64(const Affine<F>& p) {
+    using H = typename Host64Of<F>::type;
+    return Affine<H>{H::from_dev(p.x), H::from_dev(p.y)};
+}
+template <class F>
+inline Affine<F> aff_from_host64(const Affine<typename Host64Of<F>::type>& p) {
+    using H = typename Host64Of<F>::type;
+    return Affine<F>{H::to_dev(p.x), H::to_dev(p.y)};
+}
+
+// affine (host field, ext form) -> C-ABI Jacobian with Z = 1; zero = (1,1,0)
+template <class H>
+inline void host64_write_projective(const Affine<H>& a, uint64_t* out) {
+    constexpr int FE = H::WORDS / 2;
+    uint32_t w[H::WORDS];
+    auto put = [&](uint64_t* dst, const typename H::T& v) {
+        H::store(w, v);
+        for (int i = 0; i < FE; i++) dst[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    };
+    if (aff_is_inf<H>(a)) {
+        put(out, H::one());
+        put(out + FE, H::one());
+        for (int i = 0; i < FE; i++) out[2 * FE + i] = 0;
+        return;
+    }
+    put(out, a.x);
+    put(out + FE, a.y);
+    put(out + 2 * FE, H::one());
+}
+
+// C-ABI Jacobian (X,Y,Z) -> XYZZ over the host field
+template <class H>
+inline XYZZ<H> host64_proj_from_abi(const uint64_t* p) {
+    constexpr int FE = H::WORDS / 2;
+    uint32_t w[H::WORDS];
+    auto get = [&](const uint64_t* src) {
+        for (int i = 0; i < FE; i++) { w[2 * i] = (uint32_t)src[i]; w[2 * i + 1] = (uint32_t)(src[i] >> 32); }
+        return H::load(w);
+    };
+    typename H::T z = get(p + 2 * FE);
+    if (H::is_zero(z)) return xyzz_inf<H>();
+    typename H::T zz = H::sqr(z);
+    return XYZZ<H>{get(p), get(p + FE), zz, H::mul(zz, z)};
+}
+
+template <class H>
+inline XYZZ<H> host64_scalar_mul(const XYZZ<H>& p, const uint32_t k[8]) {
+    XYZZ<H> r = xyzz_inf<H>();
+    bool started = false;
+    for (int i = 7; i >= 0; i--)
+        for (int b = 31; b >= 0; b--) {
+            if (started) r = xyzz_dbl<H>(r);
+            if ((k[i] >> b) & 1) { r = xyzz_add<H>(r, p); started = true; }
+        }
+    return r;
+}
+
+}  // namespace zk

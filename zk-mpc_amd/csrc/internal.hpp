@@ -38,17 +38,25 @@ struct ZkPhaseTimer {
     void resolve();  // synchronises the stream and accumulates into ctx->timers
 };
 
-// An MSM whose device work has been enqueued on a stream (msm.hip).
+// An MSM in flight (msm.hip): prepare -> enqueue_sort -> enqueue_accum -> enqueue_reduce -> finish.
 struct ZkMsmJob {
-    int group = 1;
-    size_t n = 0;
-    uint32_t c = 0, W = 0;
-    hipStream_t stream = nullptr;
+    int group = 1, slot = 0;
+    size_t n = 0, max_segs = 0, max_heavy = 0;
+    uint32_t c = 0, W = 0, NB = 0, seg = 0, T1 = 0, nbits = 0;
+    const uint32_t* bases_dev = nullptr;
+    const void* scalars = nullptr;
+    hipStream_t stream = nullptr;     // the stream the reduce phase (and the copy to hw) is on
+    hipEvent_t sort_done = nullptr;   // recorded once sorted/desc/order are final
     hipEvent_t accum_done = nullptr;  // recorded after the accumulate kernel
-    std::vector<uint32_t> hw;         // window sums (XYZZ, internal form), filled by an async copy
-    ZkPhaseTimer* timer = nullptr;
+    uint32_t* hw = nullptr;           // partial window sums (XYZZ, internal form) in pinned host memory
+    // the sort products, so that a later job over the same scalar vector can reuse them
+    uint32_t *sorted = nullptr, *order = nullptr, *ctr = nullptr;
+    void *desc = nullptr, *heavy = nullptr;
+    std::vector<ZkPhaseTimer*> timers;
     ~ZkMsmJob();
 };
-int zk_msm_enqueue(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,
-                   hipStream_t st, int slot, hipEvent_t wait_accum);
+int zk_msm_prepare(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n, int slot);
+int zk_msm_enqueue_sort(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJob* share_sort);
+int zk_msm_enqueue_accum(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st);
+int zk_msm_enqueue_reduce(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st);
 int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out_host_projective);

@@ -25,6 +25,7 @@
 #include "../../include/zkmpc_hip.h"
 #include "devutil.cuh"
 #include "hostgroup.hpp"
+#include "hostfield64.hpp"
 #include "internal.hpp"
 #include <algorithm>
 #include <vector>
@@ -44,8 +45,8 @@ struct MsmPlan {
 
 MsmPlan make_plan(size_t n) {
     MsmPlan p;
-    uint32_t lg = 0;
-    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    uint32_t lg = 0;                                   // round(log2 n)
+    while (((size_t)3 << lg) <= 2 * n) lg++;           // 1.5 * 2^lg <= n  ->  round up
     int c = (int)lg - 4;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
@@ -265,21 +266,24 @@ __global__ void __launch_bounds__(64)
 k_fold_heavy(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums) {
     constexpr int XW = 4 * F::WORDS;
     extern __shared__ uint32_t lds[];  // 64 * XW words
-    if (blockIdx.x >= ctr[0]) return;
-    const HeavyDesc h = heavy[blockIdx.x];
+    const uint32_t nheavy = ctr[0];
     const uint32_t tid = threadIdx.x;
-    XYZZ<F> acc = xyzz_inf<F>();
-    for (uint32_t j = tid; j < h.nseg; j += 64) acc = xyzz_add<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
-    xyzz_store<F>(lds + tid * XW, acc);
-    __syncthreads();
-    for (uint32_t d = 32; d >= 1; d >>= 1) {
-        if (tid < d) {
-            XYZZ<F> a = xyzz_load<F>(lds + tid * XW), b = xyzz_load<F>(lds + (tid + d) * XW);
-            xyzz_store<F>(lds + tid * XW, xyzz_add<F>(a, b));
+    for (uint32_t hb = blockIdx.x; hb < nheavy; hb += gridDim.x) {
+        const HeavyDesc h = heavy[hb];
+        XYZZ<F> acc = xyzz_inf<F>();
+        for (uint32_t j = tid; j < h.nseg; j += 64) acc = xyzz_add<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
+        xyzz_store<F>(lds + tid * XW, acc);
+        __syncthreads();
+        for (uint32_t d = 32; d >= 1; d >>= 1) {
+            if (tid < d) {
+                XYZZ<F> a = xyzz_load<F>(lds + tid * XW), b = xyzz_load<F>(lds + (tid + d) * XW);
+                xyzz_store<F>(lds + tid * XW, xyzz_add<F>(a, b));
+            }
+            __syncthreads();
         }
+        if (tid == 0) xyzz_store16<F>(sums, h.key, xyzz_load<F>(lds));
         __syncthreads();
     }
-    if (tid == 0) xyzz_store16<F>(sums, h.key, xyzz_load<F>(lds));
 }
 
 // One reduction level (see file header).  Elements per window: T_in; chunk = 2^klog elements.
@@ -308,6 +312,36 @@ k_reduce(const uint32_t* S_in, const uint32_t* W_in, uint32_t* S_out, uint32_t* 
     }
 }
 
+// Upper part of the bucket reduction in ONE launch.  After the first chunk level a window holds T
+// pairs (S_t, W_t) and its sum is  sum_t W_t + sum_t t*S_t = sum_t W_t + sum_j 2^j * (sum_{t: bit j of t} S_t).
+// Block (w, j) computes the j-th inner sum (j < nbits) or sum_t W_t (j == nbits) with 256 lanes:
+// strided serial adds, then an LDS tree.  Depth ~ T/256 + 8 additions instead of ~24 per extra chunk level.
+template <class F>
+__global__ void __launch_bounds__(256)
+k_bitsum(const uint32_t* S_in, const uint32_t* W_in, uint32_t* out, uint32_t T, uint32_t nbits) {
+    constexpr int XW = 4 * F::WORDS;
+    extern __shared__ uint32_t lds[];  // 256 * XW words
+    const uint32_t w = blockIdx.x / (nbits + 1), j = blockIdx.x % (nbits + 1);
+    const uint32_t tid = threadIdx.x;
+    XYZZ<F> acc = xyzz_inf<F>();
+    if (j == nbits) {
+        for (uint32_t t = tid; t < T; t += 256) acc = xyzz_add<F>(acc, xyzz_load16<F>(W_in, (size_t)w * T + t));
+    } else {
+        for (uint32_t t = tid; t < T; t += 256)
+            if ((t >> j) & 1) acc = xyzz_add<F>(acc, xyzz_load16<F>(S_in, (size_t)w * T + t));
+    }
+    xyzz_store<F>(lds + tid * XW, acc);
+    __syncthreads();
+    for (uint32_t d = 128; d >= 1; d >>= 1) {
+        if (tid < d) {
+            XYZZ<F> a = xyzz_load<F>(lds + tid * XW), b = xyzz_load<F>(lds + (tid + d) * XW);
+            xyzz_store<F>(lds + tid * XW, xyzz_add<F>(a, b));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) xyzz_store16<F>(out, blockIdx.x, xyzz_load<F>(lds));
+}
+
 // Arkworks-layout affine points (Montgomery R = 2^384) -> packed internal form.  all-zero = infinity stays zero.
 template <class F>
 __global__ void __launch_bounds__(256) k_bases_import(const uint32_t* in, uint32_t* out, size_t n) {
@@ -328,107 +362,167 @@ __global__ void __launch_bounds__(256) k_bases_export(const uint32_t* in, uint32
     }
 }
 
-// All device work of one MSM, enqueued on `st`; the (<= 64) window sums land in job->hw.
-// `wait_accum` (optional) orders this job's accumulate kernel after another job's, so that when
-// several MSMs are in flight on different streams their sort / reduce phases overlap with the
-// accumulate kernels but the (throughput-bound) accumulate kernels themselves run one at a time.
+// The device work of one MSM in three phases that can sit on different streams:
+//   sort   (digits, histogram, counting sort, segment list)        latency / atomics bound
+//   accum  (bucket accumulation)                                    integer-ALU bound, fills the chip
+//   reduce (fold split buckets, chunk level, bit-decomposition sums, async copy of the partial sums)
+// With several MSMs in flight the accumulate kernels go back to back on one stream while the sort
+// and reduce phases of the neighbouring jobs run beside them on other streams.
 template <class F>
-int msm_enqueue_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base_offset, const void* scalars, size_t n,
-                  hipStream_t st, int slot, hipEvent_t wait_accum) {
-    constexpr size_t XW = 4 * F::WORDS;  // words per XYZZ point
+struct MsmBufs {
+    uint32_t *dig, *sorted, *counts, *offs, *seg_local, *small, *order, *sums, *lvS, *lvW, *bits;
+    SegDesc* desc;
+    HeavyDesc* heavy;
+};
+
+template <class F>
+int msm_prepare_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base_offset, const void* scalars, size_t n, int slot) {
+    constexpr size_t XW = 4 * F::WORDS;
     job->group = bases->group;
     job->n = n;
-    job->stream = st;
-    job->timer = new ZkPhaseTimer(ctx, st);
+    job->slot = slot;
+    job->scalars = scalars;
     if (n == 0) return ZK_OK;
     if (base_offset + n > bases->n) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: base range out of bounds");
     if (n >= ((size_t)1 << 27)) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: n must be < 2^27");
-    ZkPhaseTimer& tm = *job->timer;
     const MsmPlan p = make_plan(n);
-    job->c = p.c;
-    job->W = p.W;
-    const uint32_t* bdev = bases->dev + base_offset * (2 * F::WORDS);
-    const size_t nbuck = (size_t)p.W * p.NB;
-    uint32_t mean = (uint32_t)(n / p.NB);
-    uint32_t seg = 64;
+    job->c = p.c; job->W = p.W; job->NB = p.NB;
+    job->bases_dev = bases->dev + base_offset * (2 * F::WORDS);
+    uint32_t mean = (uint32_t)(n / p.NB), seg = 64;
     while (seg < 4 * mean && seg < 4096) seg <<= 1;
-    const size_t max_segs = nbuck + (size_t)p.W * n / seg + p.W;       // every bucket >= 1 segment
-    const size_t max_heavy_segs = 2 * ((size_t)p.W * n / seg) + p.W;   // segments of split buckets
-    const size_t max_heavy = (size_t)p.W * n / seg + 1;
+    job->seg = seg;
+    job->T1 = (p.NB + (1u << REDUCE_K_LOG) - 1) >> REDUCE_K_LOG;
+    uint32_t nbits = 0;
+    while ((1u << nbits) < job->T1) nbits++;
+    job->nbits = nbits;
+    return ZK_OK;
+}
+
+template <class F>
+int msm_bufs_t(zk_ctx* ctx, ZkMsmJob* job, MsmBufs<F>& b, bool need_sort) {
+    constexpr size_t XW = 4 * F::WORDS;
+    const size_t n = job->n, W = job->W, NB = job->NB, seg = job->seg;
+    const size_t nbuck = W * NB;
+    job->max_segs = nbuck + W * n / seg + W;                  // every bucket >= 1 segment
+    const size_t max_heavy_segs = 2 * (W * n / seg) + W;      // segments of split buckets
+    job->max_heavy = W * n / seg + 1;
     char nm[64];
-    auto slotname = [&](const char* base) { snprintf(nm, sizeof nm, "%s.%d", base, slot); return nm; };
-    uint32_t *dig, *sorted, *counts, *offs, *seg_local, *small, *order, *sums, *lvS[2], *lvW[2];
-    SegDesc* desc;
-    HeavyDesc* heavy;
-    ZK_TRY(zk_scratch(ctx, slotname("msm_dig"), (size_t)p.W * n * 4, (void**)&dig));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_sorted"), (size_t)p.W * n * 4, (void**)&sorted));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_counts"), nbuck * 4, (void**)&counts));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_offs"), (size_t)p.W * (p.NB + 1) * 4, (void**)&offs));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_segl"), nbuck * 4, (void**)&seg_local));
-    // small: win_segs[64] | ctr[4] | hist[seg+1] | bin_start[seg+1] | bin_cursor[seg+1]
-    const size_t small_words = 64 + 4 + 3 * (size_t)(seg + 1);
-    ZK_TRY(zk_scratch(ctx, slotname("msm_small"), small_words * 4, (void**)&small));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_desc"), max_segs * sizeof(SegDesc), (void**)&desc));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_heavy"), max_heavy * sizeof(HeavyDesc), (void**)&heavy));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_order"), max_segs * 4, (void**)&order));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_sums"), (nbuck + max_heavy_segs) * XW * 4, (void**)&sums));
-    const size_t lv_elems = (size_t)p.W * ((p.NB >> REDUCE_K_LOG) + 1);
-    for (int k = 0; k < 2; k++) {
-        ZK_TRY(zk_scratch(ctx, slotname(k ? "msm_lvS1" : "msm_lvS0"), lv_elems * XW * 4, (void**)&lvS[k]));
-        ZK_TRY(zk_scratch(ctx, slotname(k ? "msm_lvW1" : "msm_lvW0"), lv_elems * XW * 4, (void**)&lvW[k]));
+    auto slotname = [&](const char* base) { snprintf(nm, sizeof nm, "%s.%d", base, job->slot); return nm; };
+    if (need_sort) {
+        ZK_TRY(zk_scratch(ctx, slotname("msm_dig"), W * n * 4, (void**)&b.dig));
+        ZK_TRY(zk_scratch(ctx, slotname("msm_sorted"), W * n * 4, (void**)&b.sorted));
+        ZK_TRY(zk_scratch(ctx, slotname("msm_counts"), nbuck * 4, (void**)&b.counts));
+        ZK_TRY(zk_scratch(ctx, slotname("msm_offs"), W * (NB + 1) * 4, (void**)&b.offs));
+        ZK_TRY(zk_scratch(ctx, slotname("msm_segl"), nbuck * 4, (void**)&b.seg_local));
+        // small: win_segs[64] | ctr[4] | hist[seg+1] | bin_start[seg+1] | bin_cursor[seg+1]
+        ZK_TRY(zk_scratch(ctx, slotname("msm_small"), (64 + 4 + 3 * (seg + 1)) * 4, (void**)&b.small));
+        ZK_TRY(zk_scratch(ctx, slotname("msm_desc"), job->max_segs * sizeof(SegDesc), (void**)&b.desc));
+        ZK_TRY(zk_scratch(ctx, slotname("msm_heavy"), job->max_heavy * sizeof(HeavyDesc), (void**)&b.heavy));
+        ZK_TRY(zk_scratch(ctx, slotname("msm_order"), job->max_segs * 4, (void**)&b.order));
     }
-    uint32_t* win_segs = small;
-    uint32_t* ctr = small + 64;
-    uint32_t* hist = small + 68;
-    uint32_t* bin_start = hist + (seg + 1);
-    uint32_t* bin_cursor = bin_start + (seg + 1);
+    ZK_TRY(zk_scratch(ctx, slotname("msm_sums"), (nbuck + max_heavy_segs) * XW * 4, (void**)&b.sums));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_lvS"), W * job->T1 * XW * 4, (void**)&b.lvS));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_lvW"), W * job->T1 * XW * 4, (void**)&b.lvW));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_bits"), W * (job->nbits + 1) * XW * 4, (void**)&b.bits));
+    return ZK_OK;
+}
+
+template <class F>
+int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJob* share) {
+    if (job->n == 0) return ZK_OK;
+    const bool g1 = F::WORDS == 12;
+    const size_t n = job->n;
+    if (share && share->n == n && share->scalars == job->scalars && share->sorted) {
+        // same scalar vector as an earlier job (A, B-in-G1 and B-in-G2 all use z[1..]): reuse its sort
+        job->sorted = share->sorted; job->desc = share->desc; job->order = share->order; job->ctr = share->ctr; job->heavy = share->heavy;
+        ZK_HIP(ctx, hipEventCreateWithFlags(&job->sort_done, hipEventDisableTiming));
+        ZK_HIP(ctx, hipStreamWaitEvent(st, share->sort_done, 0));
+        ZK_HIP(ctx, hipEventRecord(job->sort_done, st));
+        return ZK_OK;
+    }
+    MsmBufs<F> b;
+    ZK_TRY(msm_bufs_t<F>(ctx, job, b, true));
+    const uint32_t W = job->W, NB = job->NB, seg = job->seg;
+    const size_t nbuck = (size_t)W * NB;
+    const MsmPlan p = make_plan(n);
     Bias bias;
     for (int i = 0; i < 9; i++) bias.w[i] = p.bias[i];
-    const bool g1 = F::WORDS == 12;
-
-    tm.begin(g1 ? "msm_g1.sort" : "msm_g2.sort");
-    ZK_HIP(ctx, hipMemsetAsync(counts, 0, nbuck * 4, st));
-    ZK_HIP(ctx, hipMemsetAsync(small, 0, small_words * 4, st));
-    hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, scalars, n, p.c, p.W, p.NB, bias, dig, counts);
-    hipLaunchKernelGGL(k_scan, p.W, 1024, 0, st, counts, offs, seg_local, win_segs, p.NB, seg);
-    hipLaunchKernelGGL(k_scatter, zk_grid((size_t)p.W * n, 256), 256, 0, st, dig, n, p.W, p.NB, offs, counts, sorted);
-    hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, offs, seg_local, win_segs, n, p.W, p.NB,
-                       seg, desc, heavy, ctr, hist);
+    uint32_t* win_segs = b.small;
+    uint32_t* ctr = b.small + 64;
+    uint32_t* hist = b.small + 68;
+    uint32_t* bin_start = hist + (seg + 1);
+    uint32_t* bin_cursor = bin_start + (seg + 1);
+    ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
+    job->timers.push_back(tm);
+    tm->begin(g1 ? "msm_g1.sort" : "msm_g2.sort");
+    ZK_HIP(ctx, hipMemsetAsync(b.counts, 0, nbuck * 4, st));
+    ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 4 + 3 * (size_t)(seg + 1)) * 4, st));
+    hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, job->c, W, NB, bias, b.dig, b.counts);
+    hipLaunchKernelGGL(k_scan, W, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NB, seg);
+    hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted);
+    hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs, n, W, NB,
+                       seg, b.desc, b.heavy, ctr, hist);
     hipLaunchKernelGGL(k_len_scan, 1, 1024, 0, st, hist, bin_start, bin_cursor, seg);
-    hipLaunchKernelGGL(k_order, 512, 256, (seg + 1) * 4, st, desc, ctr, bin_cursor, seg, order);
+    hipLaunchKernelGGL(k_order, 512, 256, (seg + 1) * 4, st, b.desc, ctr, bin_cursor, seg, b.order);
     ZK_HIP(ctx, hipGetLastError());
-    tm.end();
+    tm->end();
+    job->sorted = b.sorted; job->desc = b.desc; job->order = b.order; job->ctr = ctr; job->heavy = b.heavy;
+    ZK_HIP(ctx, hipEventCreateWithFlags(&job->sort_done, hipEventDisableTiming));
+    ZK_HIP(ctx, hipEventRecord(job->sort_done, st));
+    return ZK_OK;
+}
 
-    if (wait_accum) ZK_HIP(ctx, hipStreamWaitEvent(st, wait_accum, 0));
-    tm.begin(g1 ? "msm_g1.accum" : "msm_g2.accum");
-    hipLaunchKernelGGL(k_accum<F>, (unsigned)((max_segs + 255) / 256), 256, 0, st, bdev, sorted, desc, order, ctr, sums);
+template <class F>
+int msm_enqueue_accum_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
+    if (job->n == 0) return ZK_OK;
+    const bool g1 = F::WORDS == 12;
+    MsmBufs<F> b;
+    ZK_TRY(msm_bufs_t<F>(ctx, job, b, false));
+    ZK_HIP(ctx, hipStreamWaitEvent(st, job->sort_done, 0));
+    ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
+    job->timers.push_back(tm);
+    tm->begin(g1 ? "msm_g1.accum" : "msm_g2.accum");
+    hipLaunchKernelGGL(k_accum<F>, (unsigned)((job->max_segs + 255) / 256), 256, 0, st, job->bases_dev, job->sorted,
+                       (const SegDesc*)job->desc, job->order, job->ctr, b.sums);
     ZK_HIP(ctx, hipGetLastError());
-    tm.end();
+    tm->end();
     ZK_HIP(ctx, hipEventCreateWithFlags(&job->accum_done, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventRecord(job->accum_done, st));
+    return ZK_OK;
+}
 
-    tm.begin(g1 ? "msm_g1.reduce" : "msm_g2.reduce");
-    hipLaunchKernelGGL(k_fold_heavy<F>, (unsigned)max_heavy, 64, 64 * XW * 4, st, heavy, ctr, sums);
-    const uint32_t* S_in = sums;
-    const uint32_t* W_in = nullptr;
-    uint32_t T_in = p.NB;
-    int level = 0;
-    const uint32_t* result = nullptr;
-    while (true) {
-        uint32_t T_out = (T_in + (1u << REDUCE_K_LOG) - 1) >> REDUCE_K_LOG;
-        int last = T_out == 1;
-        uint32_t* So = lvS[level & 1];
-        uint32_t* Wo = lvW[level & 1];
-        size_t threads = (size_t)p.W * T_out;
-        hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, S_in, W_in, So, Wo, T_in, T_out,
-                           (uint32_t)REDUCE_K_LOG, p.W, level == 0 ? 1 : 0, last);
-        ZK_HIP(ctx, hipGetLastError());
-        if (last) { result = Wo; break; }
-        S_in = So; W_in = Wo; T_in = T_out; level++;
+template <class F>
+int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
+    constexpr size_t XW = 4 * F::WORDS;
+    job->stream = st;
+    if (job->n == 0) return ZK_OK;
+    const bool g1 = F::WORDS == 12;
+    MsmBufs<F> b;
+    ZK_TRY(msm_bufs_t<F>(ctx, job, b, false));
+    ZK_HIP(ctx, hipStreamWaitEvent(st, job->accum_done, 0));
+    ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
+    job->timers.push_back(tm);
+    tm->begin(g1 ? "msm_g1.reduce" : "msm_g2.reduce");
+    hipLaunchKernelGGL(k_fold_heavy<F>, (unsigned)std::min<size_t>(job->max_heavy, 128), 64, 64 * XW * 4, st,
+                       (const HeavyDesc*)job->heavy, job->ctr, b.sums);
+    const size_t threads = (size_t)job->W * job->T1;
+    hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, b.sums, nullptr, b.lvS, b.lvW, job->NB, job->T1,
+                       (uint32_t)REDUCE_K_LOG, job->W, 1, 0);
+    if (256 * XW * 4 > 64 * 1024)
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_bitsum<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * XW * 4)));
+    hipLaunchKernelGGL(k_bitsum<F>, job->W * (job->nbits + 1), 256, 256 * XW * 4, st, b.lvS, b.lvW, b.bits, job->T1, job->nbits);
+    ZK_HIP(ctx, hipGetLastError());
+    tm->end();
+    // pinned destination: a pageable one would make the "async" copy block the host until this job is done
+    auto& pin = ctx->pinned[job->slot];
+    const size_t bytes = (size_t)64 * 17 * XW * 4;
+    if (pin.bytes < bytes) {
+        if (pin.p) (void)hipHostFree(pin.p);
+        ZK_HIP(ctx, hipHostMalloc(&pin.p, bytes, hipHostMallocDefault));
+        pin.bytes = bytes;
     }
-    tm.end();
-    job->hw.resize((size_t)p.W * XW);
-    ZK_HIP(ctx, hipMemcpyAsync(job->hw.data(), result, job->hw.size() * 4, hipMemcpyDeviceToHost, st));
+    job->hw = (uint32_t*)pin.p;
+    ZK_HIP(ctx, hipMemcpyAsync(job->hw, b.bits, (size_t)job->W * (job->nbits + 1) * XW * 4, hipMemcpyDeviceToHost, st));
     return ZK_OK;
 }
 
@@ -440,21 +534,34 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
         return ZK_OK;
     }
     ZK_HIP(ctx, hipStreamSynchronize(job->stream));
-    job->timer->resolve();
-    // Horner over windows, most significant first (variable_base.rs:94-105)
-    XYZZ<F> total = xyzz_inf<F>();
+    for (auto* t : job->timers) t->resolve();
+    // window sum = W-part + sum_j 2^j * bit-sum_j ; then Horner over windows, most significant first
+    // (variable_base.rs:94-105).  All in the 64-bit host field.
+    using H = typename Host64Of<F>::type;
+    const uint32_t nb1 = job->nbits + 1;
+    XYZZ<H> total = xyzz_inf<H>();
     for (int w = (int)job->W - 1; w >= 0; w--) {
-        for (uint32_t k = 0; k < job->c; k++) total = xyzz_dbl<F>(total);
-        total = xyzz_add<F>(total, xyzz_load<F>(job->hw.data() + (size_t)w * XW));
+        for (uint32_t k = 0; k < job->c; k++) total = xyzz_dbl<H>(total);
+        const uint32_t* base = job->hw + (size_t)w * nb1 * XW;
+        XYZZ<H> ws = xyzz_inf<H>();
+        for (int j = (int)job->nbits - 1; j >= 0; j--) {
+            ws = xyzz_dbl<H>(ws);
+            ws = xyzz_add<H>(ws, xyzz_to_host64<F>(xyzz_load<F>(base + (size_t)j * XW)));
+        }
+        ws = xyzz_add<H>(ws, xyzz_to_host64<F>(xyzz_load<F>(base + (size_t)job->nbits * XW)));
+        total = xyzz_add<H>(total, ws);
     }
-    host_write_projective<F>(xyzz_to_affine<F>(total), (uint64_t*)out_host);
+    host64_write_projective<H>(xyzz_to_affine<H>(total), (uint64_t*)out_host);
     return ZK_OK;
 }
 
 template <class F>
 int msm_run_t(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars, size_t n, void* out_host) {
     ZkMsmJob job;
-    int rc = msm_enqueue_t<F>(ctx, &job, bases, base_offset, scalars, n, ctx->stream, 0, nullptr);
+    int rc = msm_prepare_t<F>(ctx, &job, bases, base_offset, scalars, n, 0);
+    if (rc == ZK_OK) rc = msm_enqueue_sort_t<F>(ctx, &job, ctx->stream, nullptr);
+    if (rc == ZK_OK) rc = msm_enqueue_accum_t<F>(ctx, &job, ctx->stream);
+    if (rc == ZK_OK) rc = msm_enqueue_reduce_t<F>(ctx, &job, ctx->stream);
     if (rc == ZK_OK) rc = msm_finish_t<F>(ctx, &job, out_host);
     return rc;
 }
@@ -545,14 +652,26 @@ void ZkPhaseTimer::resolve() {
 }
 
 ZkMsmJob::~ZkMsmJob() {
-    delete timer;
+    for (auto* t : timers) delete t;
     if (accum_done) (void)hipEventDestroy(accum_done);
+    if (sort_done) (void)hipEventDestroy(sort_done);
 }
 
-int zk_msm_enqueue(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,
-                   hipStream_t st, int slot, hipEvent_t wait_accum) {
-    if (bases->group == 1) return msm_enqueue_t<G1Field>(ctx, job, bases, base_offset, scalars_dev, n, st, slot, wait_accum);
-    return msm_enqueue_t<G2Field>(ctx, job, bases, base_offset, scalars_dev, n, st, slot, wait_accum);
+int zk_msm_prepare(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n, int slot) {
+    if (bases->group == 1) return msm_prepare_t<G1Field>(ctx, job, bases, base_offset, scalars_dev, n, slot);
+    return msm_prepare_t<G2Field>(ctx, job, bases, base_offset, scalars_dev, n, slot);
+}
+int zk_msm_enqueue_sort(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJob* share) {
+    if (job->group == 1) return msm_enqueue_sort_t<G1Field>(ctx, job, st, share);
+    return msm_enqueue_sort_t<G2Field>(ctx, job, st, share);
+}
+int zk_msm_enqueue_accum(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
+    if (job->group == 1) return msm_enqueue_accum_t<G1Field>(ctx, job, st);
+    return msm_enqueue_accum_t<G2Field>(ctx, job, st);
+}
+int zk_msm_enqueue_reduce(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
+    if (job->group == 1) return msm_enqueue_reduce_t<G1Field>(ctx, job, st);
+    return msm_enqueue_reduce_t<G2Field>(ctx, job, st);
 }
 int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out) {
     if (job->group == 1) return msm_finish_t<G1Field>(ctx, job, out);

@@ -1,0 +1,386 @@
+"""Collaborative (N-party) Groth16 proving over additive shares: one party per GPU.
+
+Mirrors the reference's MPC path (paths relative to the Yoii-Inc/zk-mpc tree):
+  create_proof over MpcField / MpcGroup                  src/groth16.rs:68-183
+  FieldShare::batch_mul (Beaver, two vector opens)       mpc-algebra/src/share/field.rs:97-129
+  AdditiveFieldShare::{batch_open, reveal, from_public}  mpc-algebra/src/share/additive.rs:81-131
+  GroupShare::scale (group Beaver, two scalar opens)     mpc-algebra/src/share/group.rs:72-111
+  DummyFieldTripleSource / DummyGroupTripleSource        mpc-algebra/src/wire/{field.rs:49-63, group.rs:41-71}
+  shift() adds public constants on the leader only       share/additive.rs:147-152
+  Proof::reveal                                          arkworks/groth16/src/reveal.rs:7-10
+  MpcSerNet::broadcast / MpcNet::broadcast_bytes         mpc-algebra/src/channel.rs:12-28, mpc-net/src/multi.rs:469-525
+
+Everything that is linear in the shares (sparse mat-vec, 7 NTTs, 5 MSMs) is local to a party and runs
+in libzkmpc_hip on that party's GPU.  An "open" of a length-n share vector is an all-gather of the
+parties' vectors (RCCL over xGMI when the transport is torch.distributed/nccl; the reference's
+broadcast returns all payloads ordered by party id and the caller sums) followed by one HIP kernel
+that sums the N vectors mod r.  Elements travel as raw Montgomery limbs: addition commutes with
+the Montgomery factor, so no (de)serialisation is needed.
+
+The protocol code below is written against two small interfaces:
+  backend : the arithmetic (GpuBackend = libzkmpc_hip through zk_mpc_amd.api.Context).  Tests may
+            inject another backend to exercise the protocol and transport logic without a GPU; the
+            product ships only GpuBackend and has no CPU arithmetic.
+  net     : the transport (DistNet = torch.distributed; LocalNet = N parties as threads of one
+            process, the analogue of the reference's LocalTestNet, mpc-net/src/multi.rs:357-453).
+"""
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------------
+# transports
+# ------------------------------------------------------------------------------------------------
+
+
+class DistNet:
+    """torch.distributed transport: backend "nccl" (= RCCL) for device buffers, "gloo" on CPU."""
+
+    def __init__(self, dist, device=None):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.rank = dist.get_rank()
+        self.n = dist.get_world_size()
+        self.device = device if device is not None else torch.device("cpu")
+
+    def is_leader(self) -> bool:
+        return self.rank == 0
+
+    def new_buffer(self, nbytes: int):
+        """A transport-visible buffer of nbytes (multiple of 8); returns (tensor, address)."""
+        t = self.torch.empty(nbytes // 8, dtype=self.torch.int64, device=self.device)
+        return t, t.data_ptr()
+
+    def all_gather(self, send_tensor, recv_tensor):
+        """recv = concat over parties (ordered by party id) of send  (MpcNet::broadcast_bytes)."""
+        self.dist.all_gather_into_tensor(recv_tensor, send_tensor)
+        if self.device.type == "cuda":
+            self.torch.cuda.current_stream().synchronize()
+
+    def all_gather_small(self, arr: np.ndarray) -> list:
+        t = self.torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).copy()).to(self.device)
+        out = self.torch.empty(self.n * t.numel(), dtype=self.torch.int64, device=self.device)
+        self.dist.all_gather_into_tensor(out, t)
+        res = out.cpu().numpy().view(arr.dtype).reshape((self.n,) + arr.shape)
+        return [res[p] for p in range(self.n)]
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+class LocalNet:
+    """N parties as threads of one process sharing host-visible buffers (LocalTestNet analogue)."""
+
+    class _Shared:
+        def __init__(self, n):
+            self.n = n
+            self.barrier = threading.Barrier(n)
+            self.slots = [None] * n
+
+    @staticmethod
+    def create(n):
+        sh = LocalNet._Shared(n)
+        return [LocalNet(sh, p) for p in range(n)]
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.n = shared, rank, shared.n
+
+    def is_leader(self):
+        return self.rank == 0
+
+    def exchange(self, obj) -> list:
+        self.sh.slots[self.rank] = obj
+        self.sh.barrier.wait()
+        out = list(self.sh.slots)
+        self.sh.barrier.wait()
+        return out
+
+    def all_gather_small(self, arr):
+        return self.exchange(np.array(arr, copy=True))
+
+    def barrier(self):
+        self.sh.barrier.wait()
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU backend (the product)
+# ------------------------------------------------------------------------------------------------
+
+
+class GpuBackend:
+    """Arithmetic on this party's GPU through libzkmpc_hip.  Vectors are device addresses."""
+
+    def __init__(self, ctx, net):
+        self.ctx, self.net = ctx, net
+        self._bufs = {}
+        self._const = {}
+        self._tensors = {}
+
+    # -- buffers --
+    def vec(self, name, n):
+        """A named device vector of n field elements.  With a torch.distributed transport the storage
+        is a torch tensor, so the vector can be handed to all_gather without a copy."""
+        key = (name, n)
+        if key not in self._bufs:
+            if isinstance(self.net, DistNet):
+                t, ptr = self.net.new_buffer(n * 32)
+                self._bufs[key] = (t, ptr)
+                self._tensors[ptr] = t
+            else:
+                b = self.ctx.alloc(n * 32)
+                self._bufs[key] = (b, b.ptr)
+        return self._bufs[key][1]
+
+    def const_vec(self, value_mont4, n):
+        """n copies of one field element (used for the dummy triples)."""
+        key = (tuple(int(x) for x in value_mont4), n)
+        if key not in self._const:
+            self._const[key] = self.ctx.upload(np.tile(np.asarray(value_mont4, dtype=np.uint64), (n, 1)))
+        return self._const[key].ptr
+
+    # -- vector arithmetic --
+    def add(self, a, b, out, n):
+        self.ctx.fr_vec_op_dev(1, a, b, out, n)
+
+    def sub(self, a, b, out, n):
+        self.ctx.fr_vec_op_dev(2, a, b, out, n)
+
+    def open_vec(self, v, out, n):
+        """out = sum over parties of v (AdditiveFieldShare::batch_open)."""
+        net, ctx = self.net, self.ctx
+        if isinstance(net, DistNet):
+            st = self._tensors.get(v)
+            if st is None:                       # not one of our tensors: stage it
+                sp = self.vec("xchg_send", n)
+                st = self._tensors[sp]
+                ctx.fr_vec_op_dev(1, v, self.const_vec(np.zeros(4, dtype=np.uint64), n), sp, n)
+            rp = self.vec("xchg_recv", net.n * n)
+            ctx.sync()                           # the vector kernels ran on the context's stream
+            net.all_gather(st, self._tensors[rp])
+            ctx.fr_sum_parties_dev(rp, net.n, n, out)
+        else:  # LocalNet: parties share one process; stage through host memory
+            mine = ctx.download(v, (n, 4))
+            allv = net.exchange(mine)
+            g = ctx.upload(np.concatenate(allv, axis=0))
+            ctx.fr_sum_parties_dev(g.ptr, net.n, n, out)
+            ctx.sync()
+            g.free()
+
+    def beaver_combine(self, sx, oy, tx, ty, tz, out, n):
+        self.ctx.beaver_combine_dev(sx, oy, out, n, triple=(tx, ty, tz))
+
+    # -- Groth16 pieces --
+    def domain_size(self, r1cs):
+        return 1 << r1cs.domain_log
+
+    def witness_map_pre(self, r1cs, z, a, b, c):
+        self.ctx.witness_map_pre_dev(r1cs, z, a, b, c, True)
+
+    def witness_map_post(self, r1cs, ab, c):
+        self.ctx.witness_map_post_dev(r1cs, ab, c)
+
+    def msms(self, pk, r1cs, z, h):
+        return self.ctx.groth16_msms_dev(pk, r1cs, z, h)
+
+    # -- host-side group / field helpers (O(1) per proof) --
+    def g1_add(self, a, b): return self.ctx.g1_add(a, b)
+    def g2_add(self, a, b): return self.ctx.g2_add(a, b)
+    def g1_neg(self, a): return self.ctx.g1_neg(a)
+    def g1_mul(self, a, k): return self.ctx.g1_mul(a, k)
+    def g2_mul(self, a, k): return self.ctx.g2_mul(a, k)
+    def g1_from_affine(self, a): return self.ctx.g1_from_affine(a)
+    def g2_from_affine(self, a): return self.ctx.g2_from_affine(a)
+    def g1_serialize(self, a): return self.ctx.g1_serialize(a)
+    def g2_serialize(self, a): return self.ctx.g2_serialize(a)
+    def fr_add(self, a, b): return self.ctx.fr_op("add", a, b)
+    def fr_sub(self, a, b): return self.ctx.fr_op("sub", a, b)
+    def fr_mul(self, a, b): return self.ctx.fr_op("mul", a, b)
+
+    def g1_zero(self): return self.ctx.g1_from_affine(np.zeros(12, dtype=np.uint64))
+    def g2_zero(self): return self.ctx.g2_from_affine(np.zeros(24, dtype=np.uint64))
+
+    def pk_points(self, pk):
+        """Public key elements the assembly needs: alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2 and query[0]s."""
+        f1, f2 = self.ctx.g1_from_affine, self.ctx.g2_from_affine
+        return dict(alpha_g1=f1(pk.vk_g1(0)), beta_g1=f1(pk.vk_g1(1)), delta_g1=f1(pk.vk_g1(2)),
+                    beta_g2=f2(pk.vk_g2(0)), delta_g2=f2(pk.vk_g2(1)),
+                    a0=f1(pk.download("a_query", 0, 1)[0]), b0_g1=f1(pk.download("b_g1_query", 0, 1)[0]),
+                    b0_g2=f2(pk.download("b_g2_query", 0, 1)[0]))
+
+    def fr_one(self):
+        out = np.zeros(4, dtype=np.uint64)
+        canon = np.array([1, 0, 0, 0], dtype=np.uint64)
+        import ctypes as C
+        self.ctx._ck(self.ctx.lib.zk_fr_from_canonical(canon.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# the protocol
+# ------------------------------------------------------------------------------------------------
+
+
+class Party:
+    """One MPC party: holds additive shares, runs the collaborative prover."""
+
+    def __init__(self, ctx=None, dist=None, net=None, backend=None):
+        if net is None:
+            import torch
+            dev = torch.device("cuda", ctx.device) if (dist.get_backend() == "nccl") else torch.device("cpu")
+            net = DistNet(dist, dev)
+        self.net = net
+        self.be = backend if backend is not None else GpuBackend(ctx, net)
+        self.ctx = ctx
+        self._pk_cache = {}
+        self.bytes_sent = 0   # payload bytes this party contributed to opens (cf. mpc-net/src/multi.rs:527-536)
+
+    @property
+    def leader(self) -> bool:
+        return self.net.is_leader()
+
+    # ---- sharing helpers (input distribution; not on the proving path) ----
+    def share_scalars(self, values, seed: int):
+        """Deterministic additive shares of public test scalars: every party derives all N shares from
+        the seed and keeps its own (stands in for async_king_share, share/additive.rs:98-107)."""
+        from .convert import fr_to_mont, R_MOD
+        rs = np.random.RandomState(seed & 0x7FFFFFFF)
+        out = []
+        for v in values:
+            sh = [int.from_bytes(rs.bytes(40), "little") % R_MOD for _ in range(self.net.n - 1)]
+            sh.append((int(v) - sum(sh)) % R_MOD)
+            out.append(fr_to_mont([sh[self.net.rank]])[0])
+        return out
+
+    def share_assignment_dev(self, z_dev, r1cs, seed: int):
+        """This party's additive share of a full assignment that is resident on its own device
+        (bench / test input generation).  Instance variables are public: the leader holds them, the
+        others hold zero (Reveal::from_public, share/additive.rs:89-93); witness variables are split
+        into N shares, shares 0..N-2 pseudo-random and share N-1 the difference."""
+        import torch
+        ctx, net = self.ctx, self.net
+        ni, nw = r1cs.num_instance, r1cs.num_witness
+        m = ni + nw
+        dev = torch.device("cuda", ctx.device)
+        mine = torch.zeros((m, 4), dtype=torch.int64, device=dev)
+
+        def rnd(p):
+            g = torch.Generator(device=dev)
+            g.manual_seed(seed * 1000 + p)
+            t = torch.randint(0, 1 << 62, (nw, 4), dtype=torch.int64, device=dev, generator=g)
+            t[:, 3] &= (1 << 60) - 1          # < 2^252 < r: a valid residue
+            return t
+
+        zsrc = z_dev.ptr if hasattr(z_dev, "ptr") else int(z_dev)
+        if net.rank < net.n - 1:
+            mine[ni:] = rnd(net.rank)
+            torch.cuda.synchronize()
+        else:
+            acc = torch.empty((nw, 4), dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            ctx._ck(0)
+            # acc = z_witness - sum_{p<N-1} share_p
+            ctx.fr_vec_op_dev(1, zsrc + ni * 32, self.be.const_vec(np.zeros(4, dtype=np.uint64), nw), acc.data_ptr(), nw)
+            for p in range(net.n - 1):
+                s = rnd(p)
+                torch.cuda.synchronize()
+                ctx.fr_vec_op_dev(2, acc.data_ptr(), s.data_ptr(), acc.data_ptr(), nw)
+                ctx.sync()
+            mine[ni:] = acc
+            torch.cuda.synchronize()
+        if net.is_leader():
+            pub = ctx.download(zsrc, (ni, 4))
+            mine[:ni] = torch.from_numpy(pub.view(np.int64)).to(dev)
+            torch.cuda.synchronize()
+        self._keep = mine
+        return mine.data_ptr()
+
+    # ---- field Beaver (vector) ----
+    def beaver_batch_mul(self, x, y, out, n, triple=None):
+        """FieldShare::batch_mul: out = shares of x*y.  triple = (tx, ty, tz) device vectors or None for
+        DummyFieldTripleSource (the leader holds 1, everybody else 0)."""
+        be = self.be
+        if triple is None:
+            c = be.fr_one() if self.leader else np.zeros(4, dtype=np.uint64)
+            tx = ty = tz = be.const_vec(c, n)
+        else:
+            tx, ty, tz = triple
+        sx_l, oy_l = be.vec("bv_sx_l", n), be.vec("bv_oy_l", n)
+        sx, oy = be.vec("bv_sx", n), be.vec("bv_oy", n)
+        be.add(x, tx, sx_l, n)                   # s + x
+        be.add(y, ty, oy_l, n)                   # o + y
+        be.open_vec(sx_l, sx, n)                 # open(s + x)
+        be.open_vec(oy_l, oy, n)                 # open(o + y)
+        self.bytes_sent += 2 * n * 32
+        be.beaver_combine(sx, oy, tx, ty, tz, out, n)   # z - sx*y - oy*x (+ sx*oy on the leader)
+
+    # ---- group Beaver: shared point * shared scalar (GroupShare::scale) ----
+    def _open_g(self, p, add):
+        parts = self.net.all_gather_small(np.ascontiguousarray(p, dtype=np.uint64))
+        self.bytes_sent += p.nbytes
+        acc = parts[0]
+        for q in parts[1:]:
+            acc = add(acc, q)
+        return acc
+
+    def _open_fr(self, s):
+        parts = self.net.all_gather_small(np.ascontiguousarray(s, dtype=np.uint64))
+        self.bytes_sent += 32
+        acc = parts[0]
+        for q in parts[1:]:
+            acc = self.be.fr_add(acc, q)
+        return acc
+
+    def scale_g1(self, s_pt, o_sc):
+        """GroupShare::scale with DummyGroupTripleSource: x = 0, y = [leader ? 1 : 0], z = 0."""
+        be = self.be
+        y = be.fr_one() if self.leader else np.zeros(4, dtype=np.uint64)
+        sx = self._open_g(s_pt, be.g1_add)                         # open(s + x), x = 0
+        oy = self._open_fr(be.fr_add(o_sc, y))                     # open(o + y)
+        out = be.g1_neg(be.g1_mul(sx, y))                          # z - scale_pub_group(sx, y)       (z = 0)
+        # - x * oy with x = 0 contributes nothing
+        if self.leader:
+            out = be.g1_add(out, be.g1_mul(sx, oy))                # shift(sx * oy): leader only
+        return out
+
+    # ---- reveal ----
+    def reveal_g1(self, p): return self._open_g(p, self.be.g1_add)
+    def reveal_g2(self, p): return self._open_g(p, self.be.g2_add)
+
+    # ---- the collaborative prover ----
+    def create_proof_shared(self, pk, r1cs, z_share, r_share, s_share, triple=None) -> bytes:
+        """create_proof over additive shares (src/groth16.rs:68-183 with E = MpcPairingEngine).
+        z_share: this party's share of the full assignment (device vector); r_share, s_share: (4,) uint64.
+        Returns the revealed 192-byte proof (identical on every party)."""
+        be = self.be
+        D = be.domain_size(r1cs)
+        a, b, c = be.vec("wm_a", D), be.vec("wm_b", D), be.vec("wm_c", D)
+        be.witness_map_pre(r1cs, z_share, a, b, c)                 # local: linear in the shares
+        self.beaver_batch_mul(a, b, a, D, triple)                  # the one shared x shared vector product (:285)
+        be.witness_map_post(r1cs, a, c)                            # h shares in `a`
+        g1, g2 = be.msms(pk, r1cs, z_share, a)                     # party-local MSMs (multi_scale_pub_group)
+        h_acc, l_acc, a_acc, b1_acc = g1[0], g1[1], g1[2], g1[3]
+        key = id(pk)
+        if key not in self._pk_cache:
+            self._pk_cache[key] = be.pk_points(pk)
+        P = self._pk_cache[key]
+        pub1 = (lambda x: x) if self.leader else (lambda x: be.g1_zero())   # shift(): leader only
+        pub2 = (lambda x: x) if self.leader else (lambda x: be.g2_zero())
+        r_g1 = be.g1_mul(P["delta_g1"], r_share)                   # public point * shared scalar: local
+        r_s_delta = self.scale_g1(r_g1, s_share)                   # :115
+        g_a = be.g1_add(be.g1_add(be.g1_add(r_g1, pub1(P["a0"])), a_acc), pub1(P["alpha_g1"]))   # calculate_coeff
+        s_g_a = self.scale_g1(g_a, s_share)                        # :140
+        s_g1 = be.g1_mul(P["delta_g1"], s_share)
+        g1_b = be.g1_add(be.g1_add(be.g1_add(s_g1, pub1(P["b0_g1"])), b1_acc), pub1(P["beta_g1"]))
+        s_g2 = be.g2_mul(P["delta_g2"], s_share)
+        g2_b = be.g2_add(be.g2_add(be.g2_add(s_g2, pub2(P["b0_g2"])), g2), pub2(P["beta_g2"]))
+        r_g1_b = self.scale_g1(g1_b, r_share)                      # :161
+        g_c = be.g1_add(s_g_a, r_g1_b)                             # :169-174
+        g_c = be.g1_add(g_c, be.g1_neg(r_s_delta))
+        g_c = be.g1_add(g_c, l_acc)
+        g_c = be.g1_add(g_c, h_acc)
+        A, B, C = self.reveal_g1(g_a), self.reveal_g2(g2_b), self.reveal_g1(g_c)     # Proof::reveal
+        return be.g1_serialize(A) + be.g2_serialize(B) + be.g1_serialize(C)
