@@ -40,14 +40,38 @@ def seeded_fr(seed: int):
     return int.from_bytes(h[:40], "little") % cv.R_MOD
 
 
-def cpu_baseline(n_sample_log: int, threads: int):
-    """Time the oracle's C restatement of the reference prover (oracle/zkref.c) on a bounded sample."""
+def cpu_baseline(ctx, td, sample_log: int, threads: int):
+    """Time the oracle's C restatement of the reference prover (oracle/zkref.c: arkworks' CIOS field
+    arithmetic, Jacobian formulas, Pippenger with c = ln(n)+2, in-order radix-2 FFT, src/groth16.rs
+    pipeline) on a bounded sample of the same workload, on this host's cores.  The proving key is the
+    device's (downloaded), and the CPU proof must equal the device's proof for the same inputs."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     try:
-        import zkref_c
+        import zkref_c as OC
     except Exception as e:  # oracle not built: report, never substitute
-        return {"value": None, "unit": "constraints/s", "cores": threads, "kind": "port", "sample": "oracle/libzkref.so unavailable: %s" % e}
-    return zkref_c.bench_prove(n_sample_log, threads)
+        return {"value": None, "unit": "constraints/s", "cores": threads, "kind": "port", "sample": "oracle unavailable: %s" % e}
+    import zk_mpc_amd.convert as cv
+    n = (1 << sample_log) - 2
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    w0, w1, r_, s_ = mont(seeded_fr(100)), mont(seeded_fr(101)), mont(seeded_fr(200)), mont(seeded_fr(201))
+    r1cs = ctx.r1cs_mul_chain(n)
+    pk = ctx.groth16_setup(r1cs, *td)
+    z = ctx.mul_chain_assignment_dev(n, w0, w1)
+    gpu_proof = ctx.create_proof_dev(pk, r1cs, z.ptr, r_, s_)
+    hp = OC.Pk(pk.vk_g1(0), pk.vk_g1(1), pk.vk_g1(2), pk.vk_g2(0), pk.vk_g2(1), pk.download("a_query"),
+               pk.download("b_g1_query"), pk.download("b_g2_query"), pk.download("h_query"), pk.download("l_query"))
+    t_all, proof_all, ph = OC.bench_mul_chain_prove(n, w0, w1, hp, r_, s_, threads)
+    ok = proof_all == gpu_proof
+    t_one, proof_one, _ = OC.bench_mul_chain_prove(n, w0, w1, hp, r_, s_, 1)
+    ok = ok and proof_one == gpu_proof
+    for o in (z, ):
+        o.free()
+    pk.free(); r1cs.free()
+    return {"value": round(n / t_all, 1), "unit": "constraints/s", "cores": threads, "kind": "port",
+            "sample": "mul-chain prove, n=2^%d-2 constraints (bounded sample of the 2^20 workload), device's proving key; "
+                      "%.2f s on %d threads (witness map %.2f s, MSMs %.2f s); single thread (the reference's build: no rayon): "
+                      "%.2f s = %.0f constraints/s" % (sample_log, t_all, threads, ph[0], ph[1], t_one, n / t_one),
+            "single_thread_value": round(n / t_one, 1), "proof_matches_device": bool(ok)}
 
 
 def main():
@@ -57,7 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log", type=int, default=14)
+    ap.add_argument("--cpu-sample-log", type=int, default=16)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -167,7 +191,7 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(ctx, td, args.cpu_sample_log, os.cpu_count() or 1)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -1,0 +1,96 @@
+"""GPU: N-party collaborative Groth16 on one device (parties = threads with their own zk_ctx, transport =
+LocalNet, the analogue of the reference's LocalTestNet).  Parity: every party's revealed proof equals the
+oracle's known-trapdoor prediction for the summed inputs, bit for bit (SURVEY 8c MPC parity)."""
+import threading
+
+import numpy as np
+import pytest
+
+import zkref as O
+import zkref_c as OC
+import zk_mpc_amd as Z
+import zk_mpc_amd.convert as cv
+from zk_mpc_amd import mpc
+from helpers import td_mont, mont1
+from oracle_backend import additive_shares
+
+pytestmark = pytest.mark.gpu
+
+
+def run_parties(n_parties, fn):
+    nets = mpc.LocalNet.create(n_parties)
+    out, err = [None] * n_parties, []
+
+    def work(p):
+        ctx = Z.Context(0, p, n_parties)
+        try:
+            out[p] = fn(p, ctx, nets[p])
+        except Exception as e:  # pragma: no cover
+            import traceback
+            err.append("party %d: %s\n%s" % (p, e, traceback.format_exc()))
+            try:
+                nets[p].sh.barrier.abort()
+            except Exception:
+                pass
+        finally:
+            ctx.close()
+
+    ts = [threading.Thread(target=work, args=(p,)) for p in range(n_parties)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not err, "\n".join(err)
+    return out
+
+
+@pytest.mark.parametrize("n_parties", [2, 3])
+def test_beaver_batch_mul_real_and_dummy_triples(n_parties):
+    rng = O.Prng(900 + n_parties)
+    n = 1000
+    xs, ys = [rng.fr() for _ in range(n)], [rng.fr() for _ in range(n)]
+    ta, tb = [rng.fr() for _ in range(n)], [rng.fr() for _ in range(n)]
+    tc = [a * b % O.R_MOD for a, b in zip(ta, tb)]
+    sh = {k: additive_shares(v, n_parties, rng) for k, v in dict(x=xs, y=ys, ta=ta, tb=tb, tc=tc).items()}
+
+    def fn(p, ctx, net):
+        party = mpc.Party(ctx, net=net)
+        up = {k: ctx.upload(cv.fr_to_mont(v[p])) for k, v in sh.items()}
+        out = ctx.alloc(n * 32)
+        party.beaver_batch_mul(up["x"].ptr, up["y"].ptr, out.ptr, n, triple=(up["ta"].ptr, up["tb"].ptr, up["tc"].ptr))
+        real = cv.fr_from_mont(ctx.download(out, (n, 4)))
+        party.beaver_batch_mul(up["x"].ptr, up["y"].ptr, out.ptr, n)           # DummyFieldTripleSource
+        dummy = cv.fr_from_mont(ctx.download(out, (n, 4)))
+        return real, dummy
+
+    res = run_parties(n_parties, fn)
+    want = [a * b % O.R_MOD for a, b in zip(xs, ys)]
+    assert [sum(c) % O.R_MOD for c in zip(*[r[0] for r in res])] == want
+    assert [sum(c) % O.R_MOD for c in zip(*[r[1] for r in res])] == want
+    assert all(v == 0 for v in res[1][1])      # dummy triples: everything lands on the leader (wire/field.rs:49-63)
+
+
+@pytest.mark.parametrize("n_parties,n", [(3, 6), (3, 1000), (2, (1 << 12) - 2)])
+def test_collaborative_prove(n_parties, n):
+    """BASELINE config 3 shape (3-party additive, mul-chain) at test size."""
+    rng = O.Prng(1000 + n)
+    w0, w1 = rng.fr(), rng.fr()
+    r1cs, z = O.mul_chain_r1cs(n, w0, w1)
+    td = O.Trapdoor(rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr())
+    r, s = rng.fr(), rng.fr()
+    zs = additive_shares(z, n_parties, rng, public_prefix=2)
+    rsh, ssh = O.additive_share(r, n_parties, rng), O.additive_share(s, n_parties, rng)
+    tdm = td_mont(td)
+
+    def fn(p, ctx, net):
+        party = mpc.Party(ctx, net=net)
+        dr = ctx.r1cs_mul_chain(n)
+        pk = ctx.groth16_setup(dr, *[tdm[i] for i in range(7)])
+        dz = ctx.upload(cv.fr_to_mont(zs[p]))
+        return party.create_proof_shared(pk, dr, dz.ptr, mont1(rsh[p]), mont1(ssh[p])), party.bytes_sent
+
+    res = run_parties(n_parties, fn)
+    cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))
+    zm = cv.fr_to_mont(z)
+    want = OC.groth16_predict(cr, tdm, zm, OC.witness_map(cr, zm), mont1(r), mont1(s))
+    assert all(pr == want for pr, _ in res)
+    D = 1 << cr.domain_log
+    assert all(b == 2 * D * 32 + 3 * (144 + 32) + 144 + 288 + 144 for _, b in res)   # Appendix C traffic

@@ -55,12 +55,8 @@ def _worker(rank, world, port, q):
         T = tuple(be.put(nm, cv.fr_to_mont(sh(v))) for nm, v in (("ta", ta), ("tb", tb), ("tc", tc)))
         out = be.vec("out", n)
         party.beaver_batch_mul(X, Y, out, n, triple=T)
-        prod_share = cv.fr_from_mont(be.store[out])
-        tot = [sum(col) % O.R_MOD for col in zip(*[np.array(p, dtype=object) for p in net.all_gather_small(
-            np.array([[v >> (64 * j) & (2**64 - 1) for j in range(4)] for v in prod_share], dtype=np.uint64))
-            and [cv._limbs_to_ints(a) for a in net.all_gather_small(
-                np.array([[v >> (64 * j) & (2**64 - 1) for j in range(4)] for v in prod_share], dtype=np.uint64))]])]
-        assert tot == [a * b % O.R_MOD for a, b in zip(xs, ys)]
+        parts = [cv.fr_from_mont(a) for a in net.all_gather_small(be.store[out])]
+        assert [sum(c) % O.R_MOD for c in zip(*parts)] == [a * b % O.R_MOD for a, b in zip(xs, ys)]
         # (2) dummy triple (the reference's DummyFieldTripleSource)
         party.beaver_batch_mul(X, Y, out, n)
         parts = [cv.fr_from_mont(a) for a in net.all_gather_small(be.store[out])]

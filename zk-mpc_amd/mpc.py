@@ -62,7 +62,7 @@ class DistNet:
             self.torch.cuda.current_stream().synchronize()
 
     def all_gather_small(self, arr: np.ndarray) -> list:
-        t = self.torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).copy()).to(self.device)
+        t = self.torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).reshape(-1).copy()).to(self.device)
         out = self.torch.empty(self.n * t.numel(), dtype=self.torch.int64, device=self.device)
         self.dist.all_gather_into_tensor(out, t)
         res = out.cpu().numpy().view(arr.dtype).reshape((self.n,) + arr.shape)
