@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-constraints", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-mpc", action="store_true", help="run the collaborative code path even with one rank (1-party: exercises transport + share plumbing)")
     ap.add_argument("--cpu-sample-log", type=int, default=16)
     args = ap.parse_args()
 
@@ -99,10 +100,12 @@ def main():
         sys.exit("bench.py needs a GPU: libzkmpc_hip has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_mpc:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n = (1 << args.log_constraints) - 2      # + 2 instance variables -> domain 2^L exactly
     ctx = Z.Context(local_rank, rank, world)
@@ -116,7 +119,7 @@ def main():
     z = ctx.mul_chain_assignment_dev(n, mont(seeded_fr(100)), mont(seeded_fr(101)))
     r_, s_ = mont(seeded_fr(200)), mont(seeded_fr(201))
 
-    if world == 1:
+    if dist is None:
         def step():
             return ctx.create_proof_dev(pk, r1cs, z.ptr, r_, s_)
     else:
@@ -182,7 +185,7 @@ def main():
             "dtype": "u32x13 (29-bit limbs, int64 accumulate)", "data": "synthetic",
             "config": {"workload": "mul-chain R1CS, n=2^%d-2 constraints, QAP domain 2^%d, %s" % (
                 args.log_constraints, r1cs.domain_log,
-                "local prove" if world == 1 else "%d-party additive-share collaborative prove" % world),
+                "local prove" if dist is None else "%d-party additive-share collaborative prove" % world),
                 "constraints": n, "parties": world},
             "proof_constraints_per_s": round(per_proof, 1),
             "phases_ms_per_proof": {k: round(v[0] / K, 3) for k, v in sorted(timers.items())},

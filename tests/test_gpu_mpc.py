@@ -94,3 +94,40 @@ def test_collaborative_prove(n_parties, n):
     assert all(pr == want for pr, _ in res)
     D = 1 << cr.domain_log
     assert all(b == 2 * D * 32 + 3 * (144 + 32) + 144 + 288 + 144 for _, b in res)   # Appendix C traffic
+
+
+def test_distnet_nccl_single_rank():
+    """The bench's N>1 plumbing (torch.distributed/nccl transport over device tensors, share generation on the
+    device) exercised with a 1-rank process group: the 1-party "collaborative" proof must equal the local one."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29544")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    ctx = Z.Context(0, 0, 1)
+    try:
+        rng = O.Prng(77)
+        n = 1000
+        w0, w1 = rng.fr(), rng.fr()
+        r, s = rng.fr(), rng.fr()
+        td = O.Trapdoor(rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr())
+        tdm = td_mont(td)
+        dr = ctx.r1cs_mul_chain(n)
+        pk = ctx.groth16_setup(dr, *[tdm[i] for i in range(7)])
+        dz = ctx.mul_chain_assignment_dev(n, mont1(w0), mont1(w1))
+        party = mpc.Party(ctx, dist)
+        zshare = party.share_assignment_dev(dz, dr, seed=5)
+        assert np.array_equal(ctx.download(zshare, (n + 3, 4)), ctx.download(dz, (n + 3, 4)))   # 1 party: share == value
+        rs = party.share_scalars([r, s], seed=9)
+        assert cv.fr_from_mont(np.stack(rs)) == [r, s]
+        proof = party.create_proof_shared(pk, dr, zshare, rs[0], rs[1])
+        assert proof == ctx.create_proof_dev(pk, dr, dz.ptr, mont1(r), mont1(s))
+        # vector open through the nccl all-gather path
+        a = ctx.upload(cv.fr_to_mont([rng.fr() for _ in range(64)]))
+        out = party.be.vec("t_out", 64)
+        party.be.open_vec(a.ptr, out, 64)
+        assert np.array_equal(ctx.download(out, (64, 4)), ctx.download(a, (64, 4)))
+    finally:
+        ctx.close()
+        dist.destroy_process_group()

@@ -19,6 +19,8 @@ extern "C" int zk_ctx_create(int device, int party_id, int n_parties, zk_ctx** o
         delete c;
         return ZK_ERR_HIP;
     }
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
     *out = c;
     return ZK_OK;
 }

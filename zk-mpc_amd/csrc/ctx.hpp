@@ -23,6 +23,7 @@ struct zk_ctx {
     int device = 0;
     int party_id = 0;
     int n_parties = 1;
+    int n_cu = 256;                 // compute units of the device
     hipStream_t stream = nullptr;
     std::vector<hipStream_t> aux;   // high-priority helper streams for concurrent MSMs (created on first use)
     hipStream_t acc_stream = nullptr;  // stream carrying the accumulate kernels back to back

@@ -233,34 +233,56 @@ k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t
     for (uint32_t s = lo + threadIdx.x; s < hi; s += blockDim.x) order[atomicAdd(&lh[desc[s].len], 1u)] = s;
 }
 
-// One thread per segment, longest first; the next point is fetched while the current one is added.
+// Persistent lanes over the length-sorted segment list: the grid is exactly 2 blocks per CU and thread g
+// takes segments g, g + G, g + 2G, ... (G = total threads).  Neighbouring lanes always hold segments of
+// (nearly) equal length, every thread gets the same long-to-short mix, and -- unlike a grid with one thread
+// per segment -- the kernel never has thousands of blocks queued in front of the small sort / reduce
+// kernels of the other in-flight MSMs (which were starved for milliseconds behind that queue).  The next
+// point is fetched while the current one is added.
 template <class F>
 __global__ void __launch_bounds__(256)
 k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
         const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums) {
-    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= ctr[2]) return;
-    const SegDesc d = desc[order[t]];
-    XYZZ<F> acc = xyzz_inf<F>();
-    if (d.len) {
-        const uint32_t* srt = sorted + d.start;
-        uint32_t e = srt[0];
-        Affine<F> p = aff_load16<F>(bases, e & 0x7fffffffu);
-        for (uint32_t k = 0; k < d.len; k++) {
-            Affine<F> cur = p;
-            const uint32_t ce = e;
-            if (k + 1 < d.len) {
-                e = srt[k + 1];
-                p = aff_load16<F>(bases, e & 0x7fffffffu);
+    const uint32_t S = ctr[2];
+    const uint32_t G = gridDim.x * blockDim.x;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < S; t += G) {
+        const SegDesc d = desc[order[t]];
+        XYZZ<F> acc = xyzz_inf<F>();
+        if (d.len) {
+            const uint32_t* srt = sorted + d.start;
+            uint32_t e = srt[0];
+            Affine<F> p = aff_load16<F>(bases, e & 0x7fffffffu);
+            for (uint32_t k = 0; k < d.len; k++) {
+                Affine<F> cur = p;
+                const uint32_t ce = e;
+                if (k + 1 < d.len) {
+                    e = srt[k + 1];
+                    p = aff_load16<F>(bases, e & 0x7fffffffu);
+                }
+                if (ce >> 31) cur.y = F::neg(cur.y);
+                acc = xyzz_madd<F>(acc, cur);
             }
-            if (ce >> 31) cur.y = F::neg(cur.y);
-            acc = xyzz_madd<F>(acc, cur);
         }
+        xyzz_store16<F>(sums, d.dst, acc);
     }
-    xyzz_store16<F>(sums, d.dst, acc);
 }
 
-// One 64-lane block per split bucket: lanes add strided partial sums, then a shuffle-free LDS tree.
+// Split buckets with few segments: one thread per bucket adds them up serially.
+template <class F>
+__global__ void __launch_bounds__(64)
+k_fold_light(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums) {
+    const uint32_t nheavy = ctr[0];
+    for (uint32_t hb = blockIdx.x * blockDim.x + threadIdx.x; hb < nheavy; hb += gridDim.x * blockDim.x) {
+        const HeavyDesc h = heavy[hb];
+        if (h.nseg > 32) continue;
+        XYZZ<F> acc = xyzz_load16<F>(sums, (size_t)h.first);
+        for (uint32_t j = 1; j < h.nseg; j++) acc = xyzz_add<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
+        xyzz_store16<F>(sums, h.key, acc);
+    }
+}
+
+// Split buckets with many segments (very heavy: repeated scalars, 0/1 witnesses): one 64-lane block per
+// bucket; lanes add strided partial sums, then an LDS tree.
 template <class F>
 __global__ void __launch_bounds__(64)
 k_fold_heavy(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums) {
@@ -270,6 +292,7 @@ k_fold_heavy(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums) {
     const uint32_t tid = threadIdx.x;
     for (uint32_t hb = blockIdx.x; hb < nheavy; hb += gridDim.x) {
         const HeavyDesc h = heavy[hb];
+        if (h.nseg <= 32) continue;
         XYZZ<F> acc = xyzz_inf<F>();
         for (uint32_t j = tid; j < h.nseg; j += 64) acc = xyzz_add<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
         xyzz_store<F>(lds + tid * XW, acc);
@@ -388,8 +411,13 @@ int msm_prepare_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base
     const MsmPlan p = make_plan(n);
     job->c = p.c; job->W = p.W; job->NB = p.NB;
     job->bases_dev = bases->dev + base_offset * (2 * F::WORDS);
-    uint32_t mean = (uint32_t)(n / p.NB), seg = 64;
-    while (seg < 4 * mean && seg < 4096) seg <<= 1;
+    // Segment length: long enough that a typical bucket (mean n/NB points) is one segment, short enough that
+    // (a) there are at least as many segments as resident lanes (2 waves per SIMD) and (b) the longest serial
+    // chain -- seg mixed additions by one lane, ~9 us each -- stays a small part of the kernel.
+    const size_t lanes = (size_t)ctx->n_cu * 4 * 64 * 2;
+    const size_t per_lane = ((size_t)n * p.W + lanes - 1) / lanes;
+    uint32_t seg = 32;
+    while (seg < per_lane && seg < 4096) seg <<= 1;
     job->seg = seg;
     job->T1 = (p.NB + (1u << REDUCE_K_LOG) - 1) >> REDUCE_K_LOG;
     uint32_t nbits = 0;
@@ -482,7 +510,11 @@ int msm_enqueue_accum_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
     job->timers.push_back(tm);
     tm->begin(g1 ? "msm_g1.accum" : "msm_g2.accum");
-    hipLaunchKernelGGL(k_accum<F>, (unsigned)((job->max_segs + 255) / 256), 256, 0, st, job->bases_dev, job->sorted,
+    // blocks per CU of the (grid-striding) accumulate kernel; 0 = one thread per segment.  Tunable for experiments.
+    static const int bpc = getenv("ZK_ACCUM_BPC") ? atoi(getenv("ZK_ACCUM_BPC")) : 0;
+    const size_t full_grid = (job->max_segs + 255) / 256;
+    const unsigned accum_blocks = (unsigned)(bpc > 0 ? std::min<size_t>(full_grid, (size_t)ctx->n_cu * bpc) : full_grid);
+    hipLaunchKernelGGL(k_accum<F>, accum_blocks, 256, 0, st, job->bases_dev, job->sorted,
                        (const SegDesc*)job->desc, job->order, job->ctr, b.sums);
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
@@ -503,7 +535,9 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
     job->timers.push_back(tm);
     tm->begin(g1 ? "msm_g1.reduce" : "msm_g2.reduce");
-    hipLaunchKernelGGL(k_fold_heavy<F>, (unsigned)std::min<size_t>(job->max_heavy, 128), 64, 64 * XW * 4, st,
+    hipLaunchKernelGGL(k_fold_light<F>, (unsigned)std::min<size_t>((job->max_heavy + 63) / 64, 512), 64, 0, st,
+                       (const HeavyDesc*)job->heavy, job->ctr, b.sums);
+    hipLaunchKernelGGL(k_fold_heavy<F>, (unsigned)std::min<size_t>(job->max_heavy, 64), 64, 64 * XW * 4, st,
                        (const HeavyDesc*)job->heavy, job->ctr, b.sums);
     const size_t threads = (size_t)job->W * job->T1;
     hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, b.sums, nullptr, b.lvS, b.lvW, job->NB, job->T1,
