@@ -143,3 +143,64 @@ def test_msm_large_discrete_log_check(ctx, log_n):
             assert cv.g2_projective_to_affine(out) == O.g2_mul(O.G2_GEN, e)
         bases.free()
         prod.free()
+
+
+@pytest.mark.parametrize("group,n", [(1, 5000), (1, 1 << 16), (2, 6000)])
+def test_msm_precomputed_window_multiples(ctx, group, n):
+    """Resident bases with precomputed 2^(16w) multiples (one bucket set for all windows): random scalars,
+    witness-like 0/1-heavy scalars, all-equal scalars (every point in one bucket per window), extreme scalars and
+    an offset sub-range must give the same group element as the discrete-log identity."""
+    rs = np.random.RandomState(group * 100 + (n & 0xff))
+    km = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    km[:, 3] &= np.uint64((1 << 60) - 1)
+    dk = ctx.upload(km)
+    one = cv.fr_to_mont([1])[0]
+    bases = ctx.fixed_base(dk.ptr, n, group, one)
+    bases.precompute()
+    ks = cv.fr_from_mont(km)
+    r = O.R_MOD
+
+    def check(scalars, off=0):
+        m = len(scalars)
+        ds = ctx.upload(cv.fr_to_mont(scalars))
+        out = ctx.msm_dev(bases, off, ds.ptr, m)
+        e = sum(s * k for s, k in zip(scalars, ks[off:off + m])) % r
+        if group == 1:
+            assert cv.g1_projective_to_affine(out) == O.g1_mul(O.G1_GEN, e)
+        else:
+            assert cv.g2_projective_to_affine(out) == O.g2_mul(O.G2_GEN, e)
+        ds.free()
+
+    prng = O.Prng(n)
+    check([prng.fr() for _ in range(n)])
+    check([(prng.u64() & 1) if i % 5 else prng.fr() for i in range(n)])          # boolean-heavy witness
+    check([12345678901234567890123] * n)                                          # all equal
+    check([r - 1, r - 2, 1, 0, (r - 1) // 2, 1 << 252, (1 << 16) - 1, 1 << 16] * (n // 8))
+    check([prng.fr() for _ in range(n - 7)], off=7)                               # offset + shorter
+    bases.free()
+
+
+def test_groth16_precomputed_key_matches_plain(ctx):
+    """The same proof bytes with and without the precomputed proving-key tables (n >= 4096 enables them)."""
+    import os
+    n = 4500
+    rng = O.Prng(4500)
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    td = [mont(rng.fr()) for _ in range(7)]
+    w0, w1, rr, ss = mont(rng.fr()), mont(rng.fr()), mont(rng.fr()), mont(rng.fr())
+    dr = ctx.r1cs_mul_chain(n)
+    dz = ctx.mul_chain_assignment_dev(n, w0, w1)
+    pk0 = ctx.groth16_setup(dr, *td)
+    p0 = ctx.create_proof_dev(pk0, dr, dz.ptr, rr, ss)
+    os.environ["ZK_PRECOMP"] = "1"
+    try:
+        pk1 = ctx.groth16_setup(dr, *td)
+    finally:
+        del os.environ["ZK_PRECOMP"]
+    p1 = ctx.create_proof_dev(pk1, dr, dz.ptr, rr, ss)
+    assert p0 == p1
+    import zkref_c as OC
+    zarr = ctx.download(dz, (n + 3, 4))
+    cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))
+    assert p1 == OC.groth16_predict(cr, np.stack(td), zarr, OC.witness_map(cr, zarr), rr, ss)
+    pk0.free(); pk1.free()

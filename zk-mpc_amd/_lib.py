@@ -88,6 +88,7 @@ PROTOTYPES = {
     "zk_bases_upload_g1": (_I, [_P, _P, _SZ, C.POINTER(_P)]),
     "zk_bases_upload_g2": (_I, [_P, _P, _SZ, C.POINTER(_P)]),
     "zk_bases_free": (_I, [_P, _P]),
+    "zk_bases_precompute": (_I, [_P, _P]),
     "zk_bases_len": (_SZ, [_P]),
     "zk_msm_g1_dev": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
     "zk_msm_g2_dev": (_I, [_P, _P, _SZ, _P, _SZ, _P]),

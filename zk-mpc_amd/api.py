@@ -345,6 +345,10 @@ class Bases:
     def __len__(self):
         return self.ctx.lib.zk_bases_len(self.h)
 
+    def precompute(self):
+        """Store the window multiples of this resident table (16x memory, one bucket set per MSM)."""
+        self.ctx._ck(self.ctx.lib.zk_bases_precompute(self.ctx.h, self.h))
+
     def download(self, offset: int = 0, n: int = None) -> np.ndarray:
         n = len(self) - offset if n is None else n
         out = np.zeros((n, 12 if self.group == 1 else 24), dtype=np.uint64)

@@ -291,6 +291,8 @@ extern "C" int zk_pk_upload(zk_ctx* ctx, const zk_pk_host* h, zk_pk** out) {
     if (rc == ZK_OK) rc = zk_bases_upload_g2(ctx, h->b_g2_query, h->b_g2_len, &pk->b_g2);
     if (rc == ZK_OK) rc = zk_bases_upload_g1(ctx, h->h_query, h->h_len, &pk->h);
     if (rc == ZK_OK) rc = zk_bases_upload_g1(ctx, h->l_query, h->l_len, &pk->l);
+    for (zk_bases* q : {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l})
+        if (rc == ZK_OK) rc = zk_bases_precompute_auto(ctx, q);
     if (rc != ZK_OK) { zk_pk_free(ctx, pk); return rc; }
     pk->alpha_g1 = host_aff_from_abi<G1Field>((const uint64_t*)&h->alpha_g1);
     pk->beta_g1 = host_aff_from_abi<G1Field>((const uint64_t*)&h->beta_g1);
@@ -405,6 +407,8 @@ extern "C" int zk_groth16_setup(zk_ctx* ctx, const zk_r1cs* r, const zk_fr* alph
     if (rc == ZK_OK) rc = zk_fixed_base_g1_dev(ctx, g1_k, dev, l.size(), &pk->l);
     if (rc == ZK_OK) rc = upload_fr(ctx, gamma_abc, "setup_scalars", &dev);
     if (rc == ZK_OK) rc = zk_fixed_base_g1_dev(ctx, g1_k, dev, gamma_abc.size(), &pk->gamma_abc);
+    for (zk_bases* q : {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l})
+        if (rc == ZK_OK) rc = zk_bases_precompute_auto(ctx, q);
     if (rc != ZK_OK) { zk_pk_free(ctx, pk); return rc; }
 
     const Fr k1 = ld(g1_k), k2 = ld(g2_k);

@@ -4,61 +4,77 @@
 //   CanonicalSerialize for points (:847-883), Fp256 add/sub/mul, from_repr / into_repr.
 #include "../../include/zkmpc_hip.h"
 #include "hostgroup.hpp"
+#include "hostfield64.hpp"
 
 using namespace zk;
 
+// Group helpers run in the 64-bit-limb host field (hostfield64.hpp): the C-ABI structs already hold the
+// reference's Montgomery form, which is that field's native form, so there is no conversion at all.
 namespace {
-template <class F>
+template <class H>
 int add_t(const uint64_t* a, const uint64_t* b, uint64_t* out) {
     if (!a || !b || !out) return ZK_ERR_ARG;
-    host_write_projective<F>(xyzz_add<F>(host_proj_from_abi<F>(a), host_proj_from_abi<F>(b)), out);
+    host64_write_projective<H>(xyzz_to_affine<H>(xyzz_add<H>(host64_proj_from_abi<H>(a), host64_proj_from_abi<H>(b))), out);
     return ZK_OK;
 }
-template <class F>
+template <class H>
 int mul_t(const uint64_t* a, const zk_fr* k, uint64_t* out) {
     if (!a || !k || !out) return ZK_ERR_ARG;
     uint32_t kw[8];
     fr_abi_to_canon_words(k->l, kw);
-    host_write_projective<F>(host_scalar_mul<F>(host_proj_from_abi<F>(a), kw), out);
+    host64_write_projective<H>(xyzz_to_affine<H>(host64_scalar_mul<H>(host64_proj_from_abi<H>(a), kw)), out);
     return ZK_OK;
+}
+template <class H>
+Affine<H> aff_from_abi64(const uint64_t* p) {
+    constexpr int FE = H::WORDS / 2;
+    uint32_t w[H::WORDS];
+    bool zero = true;
+    for (int i = 0; i < 2 * FE; i++) zero = zero && p[i] == 0;
+    if (zero) return aff_inf<H>();
+    auto get = [&](const uint64_t* src) {
+        for (int i = 0; i < FE; i++) { w[2 * i] = (uint32_t)src[i]; w[2 * i + 1] = (uint32_t)(src[i] >> 32); }
+        return H::load(w);
+    };
+    return Affine<H>{get(p), get(p + FE)};
 }
 }  // namespace
 
 extern "C" int zk_g1_add(const zk_g1_projective* a, const zk_g1_projective* b, zk_g1_projective* out) {
-    return add_t<G1Field>((const uint64_t*)a, (const uint64_t*)b, (uint64_t*)out);
+    return add_t<Fq64Field>((const uint64_t*)a, (const uint64_t*)b, (uint64_t*)out);
 }
 extern "C" int zk_g2_add(const zk_g2_projective* a, const zk_g2_projective* b, zk_g2_projective* out) {
-    return add_t<G2Field>((const uint64_t*)a, (const uint64_t*)b, (uint64_t*)out);
+    return add_t<Fq264Field>((const uint64_t*)a, (const uint64_t*)b, (uint64_t*)out);
 }
 extern "C" int zk_g1_neg(const zk_g1_projective* a, zk_g1_projective* out) {
     if (!a || !out) return ZK_ERR_ARG;
-    host_write_projective<G1Field>(xyzz_neg<G1Field>(host_proj_from_abi<G1Field>((const uint64_t*)a)), (uint64_t*)out);
+    host64_write_projective<Fq64Field>(xyzz_to_affine<Fq64Field>(xyzz_neg<Fq64Field>(host64_proj_from_abi<Fq64Field>((const uint64_t*)a))), (uint64_t*)out);
     return ZK_OK;
 }
 extern "C" int zk_g1_mul(const zk_g1_projective* a, const zk_fr* k, zk_g1_projective* out) {
-    return mul_t<G1Field>((const uint64_t*)a, k, (uint64_t*)out);
+    return mul_t<Fq64Field>((const uint64_t*)a, k, (uint64_t*)out);
 }
 extern "C" int zk_g2_mul(const zk_g2_projective* a, const zk_fr* k, zk_g2_projective* out) {
-    return mul_t<G2Field>((const uint64_t*)a, k, (uint64_t*)out);
+    return mul_t<Fq264Field>((const uint64_t*)a, k, (uint64_t*)out);
 }
 extern "C" int zk_g1_from_affine(const zk_g1_affine* a, zk_g1_projective* out) {
     if (!a || !out) return ZK_ERR_ARG;
-    host_write_projective<G1Field>(host_aff_from_abi<G1Field>((const uint64_t*)a), (uint64_t*)out);
+    host64_write_projective<Fq64Field>(aff_from_abi64<Fq64Field>((const uint64_t*)a), (uint64_t*)out);
     return ZK_OK;
 }
 extern "C" int zk_g2_from_affine(const zk_g2_affine* a, zk_g2_projective* out) {
     if (!a || !out) return ZK_ERR_ARG;
-    host_write_projective<G2Field>(host_aff_from_abi<G2Field>((const uint64_t*)a), (uint64_t*)out);
+    host64_write_projective<Fq264Field>(aff_from_abi64<Fq264Field>((const uint64_t*)a), (uint64_t*)out);
     return ZK_OK;
 }
 extern "C" int zk_g1_serialize(const zk_g1_projective* a, uint8_t out[48]) {
     if (!a || !out) return ZK_ERR_ARG;
-    g1_serialize(xyzz_to_affine<G1Field>(host_proj_from_abi<G1Field>((const uint64_t*)a)), out);
+    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<Fq64Field>(host64_proj_from_abi<Fq64Field>((const uint64_t*)a))), out);
     return ZK_OK;
 }
 extern "C" int zk_g2_serialize(const zk_g2_projective* a, uint8_t out[96]) {
     if (!a || !out) return ZK_ERR_ARG;
-    g2_serialize(xyzz_to_affine<G2Field>(host_proj_from_abi<G2Field>((const uint64_t*)a)), out);
+    g2_serialize(aff_from_host64<G2Field>(xyzz_to_affine<Fq264Field>(host64_proj_from_abi<Fq264Field>((const uint64_t*)a))), out);
     return ZK_OK;
 }
 

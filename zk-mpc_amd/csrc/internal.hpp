@@ -20,7 +20,13 @@ struct zk_bases {
     size_t n = 0;              // number of points
     uint32_t* dev = nullptr;   // packed affine, internal Montgomery form: n * (24|48) words
     bool owned = true;
+    // optional window multiples for resident bases: pre[w*n + i] = 2^(c_pre*w) * base_i, w < W_pre (pre[0..n) = dev copy).
+    // With them every window of an MSM drops into ONE bucket set (fixed_base.hip: zk_bases_precompute).
+    uint32_t* pre = nullptr;
+    uint32_t c_pre = 0, W_pre = 0;
 };
+extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b);   // no-op for tables under 4096 points
+int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b);             // only when ZK_PRECOMP=1 (off by default: see fixed_base.hip)
 int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,
                void* out_host_projective);
 
@@ -43,6 +49,8 @@ struct ZkMsmJob {
     int group = 1, slot = 0;
     size_t n = 0, max_segs = 0, max_heavy = 0;
     uint32_t c = 0, W = 0, NB = 0, seg = 0, T1 = 0, nbits = 0;
+    uint32_t Wb = 0;                  // bucket sets: W, or 1 when the bases carry precomputed window multiples
+    uint32_t n_tab = 0, tab_off = 0;  // merged mode: table stride and offset of this MSM's first base
     const uint32_t* bases_dev = nullptr;
     const void* scalars = nullptr;
     hipStream_t stream = nullptr;     // the stream the reduce phase (and the copy to hw) is on

@@ -43,13 +43,14 @@ struct MsmPlan {
     uint32_t bias[9]; // sum_w 2^(c-1) 2^(c w)
 };
 
-MsmPlan make_plan(size_t n) {
+MsmPlan make_plan(size_t n, uint32_t forced_c = 0) {
     MsmPlan p;
     uint32_t lg = 0;                                   // round(log2 n)
     while (((size_t)3 << lg) <= 2 * n) lg++;           // 1.5 * 2^lg <= n  ->  round up
     int c = (int)lg - 4;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
+    if (forced_c) c = (int)forced_c;
     p.c = (uint32_t)c;
     p.W = (255 + p.c - 1) / p.c;
     p.NB = 1u << (p.c - 1);
@@ -65,7 +66,7 @@ struct Bias { uint32_t w[9]; };
 
 // dig[w*n + i] = |d| | (d<0 ? 1<<31 : 0), and counts[w*NB + |d| - 1]++ for |d| > 0.
 __global__ void __launch_bounds__(256)
-k_digits(const void* scalars, size_t n, uint32_t c, uint32_t W, uint32_t NB, Bias bias, uint32_t* dig, uint32_t* counts) {
+k_digits(const void* scalars, size_t n, uint32_t c, uint32_t W, uint32_t NB, Bias bias, uint32_t* dig, uint32_t* counts, int merged) {
     __shared__ uint32_t kw[9][256];
     const uint32_t tid = threadIdx.x;
     for (size_t i0 = blockIdx.x * (size_t)256; i0 < n; i0 += (size_t)gridDim.x * 256) {
@@ -89,23 +90,30 @@ k_digits(const void* scalars, size_t n, uint32_t c, uint32_t W, uint32_t NB, Bia
                 int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (int32_t)half;
                 uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
                 dig[(size_t)w * n + i] = mag | (d < 0 ? 0x80000000u : 0u);
-                if (mag) atomicAdd(&counts[(size_t)w * NB + mag - 1], 1u);
+                if (mag) atomicAdd(&counts[(merged ? 0 : (size_t)w * NB) + mag - 1], 1u);
             }
         }
     }
 }
 
 // sorted[w*n + pos] = i | sign ; counts are consumed (count down to zero).
+// merged (precomputed window multiples): one bucket set; the entry is the TABLE index w*n_tab + tab_off + i.
 __global__ void __launch_bounds__(256)
-k_scatter(const uint32_t* dig, size_t n, uint32_t W, uint32_t NB, const uint32_t* offs, uint32_t* counts, uint32_t* sorted) {
+k_scatter(const uint32_t* dig, size_t n, uint32_t W, uint32_t NB, const uint32_t* offs, uint32_t* counts, uint32_t* sorted,
+          int merged, uint32_t n_tab, uint32_t tab_off) {
     const size_t total = (size_t)W * n;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         uint32_t d = dig[t];
         uint32_t mag = d & 0x7fffffffu;
         if (!mag) continue;
         size_t w = t / n, i = t - w * n;
-        uint32_t slot = atomicSub(&counts[w * NB + mag - 1], 1u) - 1;
-        sorted[w * n + offs[w * (NB + 1) + mag - 1] + slot] = (uint32_t)i | (d & 0x80000000u);
+        if (merged) {
+            uint32_t slot = atomicSub(&counts[mag - 1], 1u) - 1;
+            sorted[offs[mag - 1] + slot] = (uint32_t)(w * n_tab + tab_off + i) | (d & 0x80000000u);
+        } else {
+            uint32_t slot = atomicSub(&counts[w * NB + mag - 1], 1u) - 1;
+            sorted[w * n + offs[w * (NB + 1) + mag - 1] + slot] = (uint32_t)i | (d & 0x80000000u);
+        }
     }
 }
 
@@ -408,9 +416,19 @@ int msm_prepare_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base
     if (n == 0) return ZK_OK;
     if (base_offset + n > bases->n) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: base range out of bounds");
     if (n >= ((size_t)1 << 27)) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: n must be < 2^27");
-    const MsmPlan p = make_plan(n);
+    const bool merged = bases->pre != nullptr && n >= 4096;
+    const MsmPlan p = make_plan(n, merged ? bases->c_pre : 0);
     job->c = p.c; job->W = p.W; job->NB = p.NB;
-    job->bases_dev = bases->dev + base_offset * (2 * F::WORDS);
+    if (merged) {
+        if (p.W > bases->W_pre) ZK_FAIL(ctx, ZK_ERR_STATE, "msm: precomputed table has too few windows");
+        job->Wb = 1;
+        job->bases_dev = bases->pre;
+        job->n_tab = (uint32_t)bases->n;
+        job->tab_off = (uint32_t)base_offset;
+    } else {
+        job->Wb = p.W;
+        job->bases_dev = bases->dev + base_offset * (2 * F::WORDS);
+    }
     // Segment length: long enough that a typical bucket (mean n/NB points) is one segment, short enough that
     // (a) there are at least as many segments as resident lanes (2 waves per SIMD) and (b) the longest serial
     // chain -- seg mixed additions by one lane, ~9 us each -- stays a small part of the kernel.
@@ -429,8 +447,8 @@ int msm_prepare_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base
 template <class F>
 int msm_bufs_t(zk_ctx* ctx, ZkMsmJob* job, MsmBufs<F>& b, bool need_sort) {
     constexpr size_t XW = 4 * F::WORDS;
-    const size_t n = job->n, W = job->W, NB = job->NB, seg = job->seg;
-    const size_t nbuck = W * NB;
+    const size_t n = job->n, W = job->W, NB = job->NB, seg = job->seg, Wb = job->Wb;
+    const size_t nbuck = Wb * NB;
     job->max_segs = nbuck + W * n / seg + W;                  // every bucket >= 1 segment
     const size_t max_heavy_segs = 2 * (W * n / seg) + W;      // segments of split buckets
     job->max_heavy = W * n / seg + 1;
@@ -440,7 +458,7 @@ int msm_bufs_t(zk_ctx* ctx, ZkMsmJob* job, MsmBufs<F>& b, bool need_sort) {
         ZK_TRY(zk_scratch(ctx, slotname("msm_dig"), W * n * 4, (void**)&b.dig));
         ZK_TRY(zk_scratch(ctx, slotname("msm_sorted"), W * n * 4, (void**)&b.sorted));
         ZK_TRY(zk_scratch(ctx, slotname("msm_counts"), nbuck * 4, (void**)&b.counts));
-        ZK_TRY(zk_scratch(ctx, slotname("msm_offs"), W * (NB + 1) * 4, (void**)&b.offs));
+        ZK_TRY(zk_scratch(ctx, slotname("msm_offs"), Wb * (NB + 1) * 4, (void**)&b.offs));
         ZK_TRY(zk_scratch(ctx, slotname("msm_segl"), nbuck * 4, (void**)&b.seg_local));
         // small: win_segs[64] | ctr[4] | hist[seg+1] | bin_start[seg+1] | bin_cursor[seg+1]
         ZK_TRY(zk_scratch(ctx, slotname("msm_small"), (64 + 4 + 3 * (seg + 1)) * 4, (void**)&b.small));
@@ -449,9 +467,9 @@ int msm_bufs_t(zk_ctx* ctx, ZkMsmJob* job, MsmBufs<F>& b, bool need_sort) {
         ZK_TRY(zk_scratch(ctx, slotname("msm_order"), job->max_segs * 4, (void**)&b.order));
     }
     ZK_TRY(zk_scratch(ctx, slotname("msm_sums"), (nbuck + max_heavy_segs) * XW * 4, (void**)&b.sums));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_lvS"), W * job->T1 * XW * 4, (void**)&b.lvS));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_lvW"), W * job->T1 * XW * 4, (void**)&b.lvW));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_bits"), W * (job->nbits + 1) * XW * 4, (void**)&b.bits));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_lvS"), Wb * job->T1 * XW * 4, (void**)&b.lvS));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_lvW"), Wb * job->T1 * XW * 4, (void**)&b.lvW));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_bits"), Wb * (job->nbits + 1) * XW * 4, (void**)&b.bits));
     return ZK_OK;
 }
 
@@ -460,7 +478,8 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     if (job->n == 0) return ZK_OK;
     const bool g1 = F::WORDS == 12;
     const size_t n = job->n;
-    if (share && share->n == n && share->scalars == job->scalars && share->sorted) {
+    if (share && share->n == n && share->scalars == job->scalars && share->sorted && share->Wb == job->Wb &&
+        share->n_tab == job->n_tab && share->tab_off == job->tab_off && share->c == job->c) {
         // same scalar vector as an earlier job (A, B-in-G1 and B-in-G2 all use z[1..]): reuse its sort
         job->sorted = share->sorted; job->desc = share->desc; job->order = share->order; job->ctr = share->ctr; job->heavy = share->heavy;
         ZK_HIP(ctx, hipEventCreateWithFlags(&job->sort_done, hipEventDisableTiming));
@@ -470,9 +489,10 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     }
     MsmBufs<F> b;
     ZK_TRY(msm_bufs_t<F>(ctx, job, b, true));
-    const uint32_t W = job->W, NB = job->NB, seg = job->seg;
-    const size_t nbuck = (size_t)W * NB;
-    const MsmPlan p = make_plan(n);
+    const uint32_t W = job->W, NB = job->NB, seg = job->seg, Wb = job->Wb;
+    const int merged = Wb == 1 && W > 1;
+    const size_t nbuck = (size_t)Wb * NB;
+    const MsmPlan p = make_plan(n, job->c);
     Bias bias;
     for (int i = 0; i < 9; i++) bias.w[i] = p.bias[i];
     uint32_t* win_segs = b.small;
@@ -485,11 +505,12 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     tm->begin(g1 ? "msm_g1.sort" : "msm_g2.sort");
     ZK_HIP(ctx, hipMemsetAsync(b.counts, 0, nbuck * 4, st));
     ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 4 + 3 * (size_t)(seg + 1)) * 4, st));
-    hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, job->c, W, NB, bias, b.dig, b.counts);
-    hipLaunchKernelGGL(k_scan, W, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NB, seg);
-    hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted);
-    hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs, n, W, NB,
-                       seg, b.desc, b.heavy, ctr, hist);
+    hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, job->c, W, NB, bias, b.dig, b.counts, merged);
+    hipLaunchKernelGGL(k_scan, Wb, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NB, seg);
+    hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted, merged,
+                       job->n_tab, job->tab_off);
+    hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
+                       merged ? (size_t)0 : n, Wb, NB, seg, b.desc, b.heavy, ctr, hist);
     hipLaunchKernelGGL(k_len_scan, 1, 1024, 0, st, hist, bin_start, bin_cursor, seg);
     hipLaunchKernelGGL(k_order, 512, 256, (seg + 1) * 4, st, b.desc, ctr, bin_cursor, seg, b.order);
     ZK_HIP(ctx, hipGetLastError());
@@ -539,12 +560,12 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
                        (const HeavyDesc*)job->heavy, job->ctr, b.sums);
     hipLaunchKernelGGL(k_fold_heavy<F>, (unsigned)std::min<size_t>(job->max_heavy, 64), 64, 64 * XW * 4, st,
                        (const HeavyDesc*)job->heavy, job->ctr, b.sums);
-    const size_t threads = (size_t)job->W * job->T1;
+    const size_t threads = (size_t)job->Wb * job->T1;
     hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, b.sums, nullptr, b.lvS, b.lvW, job->NB, job->T1,
-                       (uint32_t)REDUCE_K_LOG, job->W, 1, 0);
+                       (uint32_t)REDUCE_K_LOG, job->Wb, 1, 0);
     if (256 * XW * 4 > 64 * 1024)
         ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_bitsum<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * XW * 4)));
-    hipLaunchKernelGGL(k_bitsum<F>, job->W * (job->nbits + 1), 256, 256 * XW * 4, st, b.lvS, b.lvW, b.bits, job->T1, job->nbits);
+    hipLaunchKernelGGL(k_bitsum<F>, job->Wb * (job->nbits + 1), 256, 256 * XW * 4, st, b.lvS, b.lvW, b.bits, job->T1, job->nbits);
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
     // pinned destination: a pageable one would make the "async" copy block the host until this job is done
@@ -556,7 +577,7 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
         pin.bytes = bytes;
     }
     job->hw = (uint32_t*)pin.p;
-    ZK_HIP(ctx, hipMemcpyAsync(job->hw, b.bits, (size_t)job->W * (job->nbits + 1) * XW * 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(ctx, hipMemcpyAsync(job->hw, b.bits, (size_t)job->Wb * (job->nbits + 1) * XW * 4, hipMemcpyDeviceToHost, st));
     return ZK_OK;
 }
 
@@ -574,7 +595,7 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
     using H = typename Host64Of<F>::type;
     const uint32_t nb1 = job->nbits + 1;
     XYZZ<H> total = xyzz_inf<H>();
-    for (int w = (int)job->W - 1; w >= 0; w--) {
+    for (int w = (int)job->Wb - 1; w >= 0; w--) {
         for (uint32_t k = 0; k < job->c; k++) total = xyzz_dbl<H>(total);
         const uint32_t* base = job->hw + (size_t)w * nb1 * XW;
         XYZZ<H> ws = xyzz_inf<H>();
@@ -723,6 +744,7 @@ extern "C" int zk_bases_free(zk_ctx* ctx, zk_bases* b) {
     if (!b) return ZK_OK;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     if (b->owned && b->dev) (void)hipFree(b->dev);
+    if (b->pre) (void)hipFree(b->pre);
     delete b;
     return ZK_OK;
 }
