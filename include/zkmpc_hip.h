@@ -215,6 +215,10 @@ int zk_beaver_combine_dev(zk_ctx* ctx, const void* sx_open_dev, const void* oy_o
                           const void* tx_dev, const void* ty_dev, const void* tz_dev,
                           void* out_dev, size_t n);
 
+/* *is_zero = 1 iff every element of the device vector is 0: the MAC check of SpdzFieldShare::batch_open
+ * (assert!(sum.is_zero()) per element, mpc-algebra/src/share/spdz.rs:188-195) as one reduction. */
+int zk_fr_vec_is_zero_dev(zk_ctx* ctx, const void* v_dev, size_t n, int* is_zero);
+
 /* ---- instrumentation -------------------------------------------------------------------- */
 /* zk_set_profiling(ctx, 1): bracket every phase (witness map, MSM sort / accumulate / reduce) with
  * HIP events on the context stream; zk_last_timers returns the accumulated device time (ms) and

@@ -112,7 +112,9 @@ class OracleBackend:
     def g1_serialize(self, a): return O.g1_serialize(self._a1(a))
     def g2_serialize(self, a): return O.g2_serialize(self._a2(a))
     def fr_add(self, a, b): return OC.fr_vec_op(1, np.asarray(a).reshape(1, 4), np.asarray(b).reshape(1, 4))[0]
+    def fr_sub(self, a, b): return OC.fr_vec_op(2, np.asarray(a).reshape(1, 4), np.asarray(b).reshape(1, 4))[0]
     def fr_one(self): return cv.fr_to_mont([1])[0]
+    def is_zero_vec(self, v, n): return not np.any(self.store[v])
 
     def pk_points(self, pk: OraclePk):
         k = pk.pk

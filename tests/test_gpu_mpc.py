@@ -96,6 +96,47 @@ def test_collaborative_prove(n_parties, n):
     assert all(b == 2 * D * 32 + 3 * (144 + 32) + 144 + 288 + 144 for _, b in res)   # Appendix C traffic
 
 
+@pytest.mark.parametrize("n_parties,n", [(2, 100), (3, 5000)])
+def test_collaborative_prove_spdz(n_parties, n):
+    """The reference's `malicious` backend (SpdzFieldShare / SpdzGroupShare, key alpha = 1): two-lane shares, MAC-checked
+    opens; the revealed proof equals the local proof, and a corrupted MAC share is detected."""
+    rng = O.Prng(2000 + n)
+    w0, w1 = rng.fr(), rng.fr()
+    r1cs, z = O.mul_chain_r1cs(n, w0, w1)
+    td = O.Trapdoor(rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr())
+    r, s = rng.fr(), rng.fr()
+    zs = additive_shares(z, n_parties, rng, public_prefix=2)
+    zm = additive_shares(z, n_parties, rng, public_prefix=2)          # independent sharing of alpha*z, alpha = 1
+    rsh, ssh = O.additive_share(r, n_parties, rng), O.additive_share(s, n_parties, rng)
+    rm, sm = O.additive_share(r, n_parties, rng), O.additive_share(s, n_parties, rng)
+    tdm = td_mont(td)
+
+    def fn(p, ctx, net):
+        party = mpc.SpdzParty(ctx, net=net)
+        dr = ctx.r1cs_mul_chain(n)
+        pk = ctx.groth16_setup(dr, *[tdm[i] for i in range(7)])
+        dzs, dzm = ctx.upload(cv.fr_to_mont(zs[p])), ctx.upload(cv.fr_to_mont(zm[p]))
+        rr, ss = (mont1(rsh[p]), mont1(rm[p])), (mont1(ssh[p]), mont1(sm[p]))
+        good = party.create_proof_shared_spdz(pk, dr, (dzs.ptr, dzm.ptr), rr, ss)
+        bad = cv.fr_to_mont(zm[p])
+        if p == n_parties - 1:
+            bad[5, 0] ^= np.uint64(1)
+        dbad = ctx.upload(bad)
+        try:
+            party.create_proof_shared_spdz(pk, dr, (dzs.ptr, dbad.ptr), rr, ss)
+            caught = False
+        except mpc.MacCheckError:
+            caught = True
+        return good, caught
+
+    res = run_parties(n_parties, fn)
+    cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))
+    zmnt = cv.fr_to_mont(z)
+    want = OC.groth16_predict(cr, tdm, zmnt, OC.witness_map(cr, zmnt), mont1(r), mont1(s))
+    assert all(g == want for g, _ in res)
+    assert all(c for _, c in res)
+
+
 def test_distnet_nccl_single_rank():
     """The bench's N>1 plumbing (torch.distributed/nccl transport over device tensors, share generation on the
     device) exercised with a 1-rank process group: the 1-party "collaborative" proof must equal the local one."""

@@ -67,6 +67,25 @@ def _worker(rank, world, port, q):
         want = O.proof_serialize(*O.predict_proof(r1cs, pks, z, r, s))
         assert proof == want, "revealed %d-party proof differs from the local proof on the summed inputs" % world
         assert party.bytes_sent >= 2 * be.dom.size * 32
+        # (4) SPDZ (malicious backend): two-lane shares, MAC-checked opens; mac shares are independent sharings (key alpha = 1)
+        sp = mpc.SpdzParty(net=net, backend=be)
+        zm = additive_shares(z, world, rng, public_prefix=r1cs.num_instance)
+        Zs = (be.put("zs", cv.fr_to_mont(zs[rank])), be.put("zm", cv.fr_to_mont(zm[rank])))
+        m1 = lambda v: cv.fr_to_mont([v])[0]
+        rm, sm = O.additive_share(r, world, rng), O.additive_share(s, world, rng)
+        proof2 = sp.create_proof_shared_spdz(pk, r1cs, Zs, (m1(rsh[rank]), m1(rm[rank])), (m1(ssh[rank]), m1(sm[rank])))
+        assert proof2 == want, "SPDZ proof differs"
+        # a corrupted MAC share must be caught by the next open
+        bad = np.array(be.store[Zs[1]], copy=True)
+        if rank == world - 1:
+            bad[3, 0] ^= np.uint64(1)
+        Zbad = (Zs[0], be.put("zbad", bad))
+        caught = False
+        try:
+            sp.create_proof_shared_spdz(pk, r1cs, Zbad, (m1(rsh[rank]), m1(rm[rank])), (m1(ssh[rank]), m1(sm[rank])))
+        except mpc.MacCheckError:
+            caught = True
+        assert caught, "corrupted MAC share was not detected"
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback

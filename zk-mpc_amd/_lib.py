@@ -131,6 +131,7 @@ PROTOTYPES = {
     "zk_groth16_prove": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "zk_fr_sum_parties_dev": (_I, [_P, _P, _SZ, _SZ, _P]),
     "zk_beaver_combine_dev": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ]),
+    "zk_fr_vec_is_zero_dev": (_I, [_P, _P, _SZ, _P]),
     "zk_set_profiling": (_I, [_P, _I]),
     "zk_last_timers": (_I, [_P, _P, _SZ, _P, _P, _I]),
 }

@@ -184,6 +184,11 @@ class Context:
     def fr_sum_parties_dev(self, gathered, n_parties: int, n: int, out):
         self._ck(self.lib.zk_fr_sum_parties_dev(self.h, C.c_void_p(int(gathered)), n_parties, n, C.c_void_p(int(out))))
 
+    def fr_vec_is_zero_dev(self, v, n: int) -> bool:
+        f = C.c_int(0)
+        self._ck(self.lib.zk_fr_vec_is_zero_dev(self.h, C.c_void_p(int(v)), n, C.byref(f)))
+        return bool(f.value)
+
     def beaver_combine_dev(self, sx, oy, out, n: int, triple=None):
         tx, ty, tz = (None, None, None) if triple is None else [C.c_void_p(int(t)) for t in triple]
         self._ck(self.lib.zk_beaver_combine_dev(self.h, C.c_void_p(int(sx)), C.c_void_p(int(oy)), tx, ty, tz,

@@ -275,6 +275,23 @@ k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
     }
 }
 
+// LDS staging of one XYZZ point per lane, word-major (word k of lane t at lds[k * NT + t]): consecutive lanes hit
+// consecutive banks.  (A lane-major layout has a stride of 48/96 words between lanes = every lane on one bank.)
+template <class F, int NT>
+__device__ __forceinline__ void lds_put_xyzz(uint32_t* lds, uint32_t t, const XYZZ<F>& p) {
+    uint32_t w[4 * F::WORDS];
+    xyzz_store<F>(w, p);
+#pragma unroll
+    for (int k = 0; k < 4 * F::WORDS; k++) lds[k * NT + t] = w[k];
+}
+template <class F, int NT>
+__device__ __forceinline__ XYZZ<F> lds_get_xyzz(const uint32_t* lds, uint32_t t) {
+    uint32_t w[4 * F::WORDS];
+#pragma unroll
+    for (int k = 0; k < 4 * F::WORDS; k++) w[k] = lds[k * NT + t];
+    return xyzz_load<F>(w);
+}
+
 // Split buckets with few segments: one thread per bucket adds them up serially.
 template <class F>
 __global__ void __launch_bounds__(64)
@@ -303,16 +320,13 @@ k_fold_heavy(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums) {
         if (h.nseg <= 32) continue;
         XYZZ<F> acc = xyzz_inf<F>();
         for (uint32_t j = tid; j < h.nseg; j += 64) acc = xyzz_add<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
-        xyzz_store<F>(lds + tid * XW, acc);
+        lds_put_xyzz<F, 64>(lds, tid, acc);
         __syncthreads();
         for (uint32_t d = 32; d >= 1; d >>= 1) {
-            if (tid < d) {
-                XYZZ<F> a = xyzz_load<F>(lds + tid * XW), b = xyzz_load<F>(lds + (tid + d) * XW);
-                xyzz_store<F>(lds + tid * XW, xyzz_add<F>(a, b));
-            }
+            if (tid < d) lds_put_xyzz<F, 64>(lds, tid, xyzz_add<F>(lds_get_xyzz<F, 64>(lds, tid), lds_get_xyzz<F, 64>(lds, tid + d)));
             __syncthreads();
         }
-        if (tid == 0) xyzz_store16<F>(sums, h.key, xyzz_load<F>(lds));
+        if (tid == 0) xyzz_store16<F>(sums, h.key, lds_get_xyzz<F, 64>(lds, 0));
         __syncthreads();
     }
 }
@@ -361,16 +375,13 @@ k_bitsum(const uint32_t* S_in, const uint32_t* W_in, uint32_t* out, uint32_t T, 
         for (uint32_t t = tid; t < T; t += 256)
             if ((t >> j) & 1) acc = xyzz_add<F>(acc, xyzz_load16<F>(S_in, (size_t)w * T + t));
     }
-    xyzz_store<F>(lds + tid * XW, acc);
+    lds_put_xyzz<F, 256>(lds, tid, acc);
     __syncthreads();
     for (uint32_t d = 128; d >= 1; d >>= 1) {
-        if (tid < d) {
-            XYZZ<F> a = xyzz_load<F>(lds + tid * XW), b = xyzz_load<F>(lds + (tid + d) * XW);
-            xyzz_store<F>(lds + tid * XW, xyzz_add<F>(a, b));
-        }
+        if (tid < d) lds_put_xyzz<F, 256>(lds, tid, xyzz_add<F>(lds_get_xyzz<F, 256>(lds, tid), lds_get_xyzz<F, 256>(lds, tid + d)));
         __syncthreads();
     }
-    if (tid == 0) xyzz_store16<F>(out, blockIdx.x, xyzz_load<F>(lds));
+    if (tid == 0) xyzz_store16<F>(out, blockIdx.x, lds_get_xyzz<F, 256>(lds, 0));
 }
 
 // Arkworks-layout affine points (Montgomery R = 2^384) -> packed internal form.  all-zero = infinity stays zero.

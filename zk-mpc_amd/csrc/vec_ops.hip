@@ -82,6 +82,17 @@ __global__ void __launch_bounds__(256) k_beaver(const void* sx, const void* oy, 
     }
 }
 
+// flag |= (any word of v non-zero)
+__global__ void __launch_bounds__(256) k_any_nonzero(const void* v, size_t n, uint32_t* flag) {
+    const uint4* p = reinterpret_cast<const uint4*>(v);
+    uint32_t acc = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < 2 * n; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 w = p[i];
+        acc |= w.x | w.y | w.z | w.w;
+    }
+    if (acc) atomicOr(flag, 1u);
+}
+
 FrK to_frk(const uint32_t* l) {
     FrK k;
     for (int i = 0; i < 9; i++) k.l[i] = l[i];
@@ -162,5 +173,18 @@ extern "C" int zk_beaver_combine_dev(zk_ctx* ctx, const void* sx, const void* oy
     else
         hipLaunchKernelGGL(k_beaver<false>, zk_grid(n, 256), 256, 0, ctx->stream, sx, oy, tx, ty, tz, out, n, leader);
     ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+extern "C" int zk_fr_vec_is_zero_dev(zk_ctx* ctx, const void* v, size_t n, int* is_zero) {
+    if (!ctx || !is_zero || (n && !v)) return ZK_ERR_ARG;
+    uint32_t* flag;
+    ZK_TRY(zk_scratch(ctx, "vec_flag", 16, (void**)&flag));
+    ZK_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    if (n) hipLaunchKernelGGL(k_any_nonzero, zk_grid(2 * n, 256), 256, 0, ctx->stream, v, n, flag);
+    uint32_t h = 0;
+    ZK_HIP(ctx, hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *is_zero = h == 0;
     return ZK_OK;
 }

@@ -173,6 +173,9 @@ class GpuBackend:
     def beaver_combine(self, sx, oy, tx, ty, tz, out, n):
         self.ctx.beaver_combine_dev(sx, oy, out, n, triple=(tx, ty, tz))
 
+    def is_zero_vec(self, v, n) -> bool:
+        return self.ctx.fr_vec_is_zero_dev(v, n)
+
     # -- Groth16 pieces --
     def domain_size(self, r1cs):
         return 1 << r1cs.domain_log
@@ -384,3 +387,152 @@ class Party:
         g_c = be.g1_add(g_c, h_acc)
         A, B, C = self.reveal_g1(g_a), self.reveal_g2(g2_b), self.reveal_g1(g_c)     # Proof::reveal
         return be.g1_serialize(A) + be.g2_serialize(B) + be.g1_serialize(C)
+
+
+# ------------------------------------------------------------------------------------------------
+# SPDZ (malicious-majority backend): every share carries a MAC share; opens are MAC-checked
+# ------------------------------------------------------------------------------------------------
+
+
+class MacCheckError(RuntimeError):
+    pass
+
+
+class SpdzParty(Party):
+    """The reference's `malicious` backend (mpc-algebra/src/share/spdz.rs).  A shared value is a pair
+    (sh, mac) of additive shares with sum(mac) = alpha * sum(sh); the MAC key alpha is itself shared
+    (mac_share(): the reference's stand-in key is the constant 1 held by the leader, spdz.rs:31-37).
+
+      SpdzFieldShare::{add,sub,scale,shift}   spdz.rs:197-219   both lanes; shift adds mac_share*c to the mac lane
+      SpdzFieldShare::batch_open               spdz.rs:177-196   open sh, then dx = mac_share*x - mac, open dx, assert sum = 0
+      FieldShare::batch_mul (default body)     share/field.rs:97-129 over SPDZ shares
+      SpdzGroupShare::{batch_open, reveal, scale_pub_group, shift}   spdz.rs:284-309,425-480
+      multi_scale_pub_group                    spdz.rs:482-488   (the reference feeds the SHARE values to both MSMs; with
+                                                                  its key alpha = 1 that equals the MSM over the mac values
+                                                                  that is computed here)
+    Everything linear runs twice (share lane and mac lane); every open costs a second all-gather."""
+
+    # ---- vectors: a value is a pair (sh, mac) of backend vectors ----
+    def spdz_open_vec(self, v, out, n):
+        be = self.be
+        sh, mac = v
+        be.open_vec(sh, out, n)                                    # x = sum of shares
+        dx = be.vec("spdz_dx", n)
+        zero = be.const_vec(np.zeros(4, dtype=np.uint64), n)
+        be.sub(out if self.leader else zero, mac, dx, n)           # mac_share * x - mac
+        chk = be.vec("spdz_chk", n)
+        be.open_vec(dx, chk, n)
+        self.bytes_sent += 2 * n * 32
+        if not be.is_zero_vec(chk, n):
+            raise MacCheckError("SPDZ MAC check failed on a vector open")
+
+    def spdz_beaver_batch_mul(self, x, y, out, n, triple=None):
+        """x, y, out: (sh, mac) pairs.  triple = ((tx_sh, tx_mac), (ty..), (tz..)) or None for the dummy source
+        (from_public(1): the leader holds 1 in both lanes)."""
+        be = self.be
+        if triple is None:
+            c = be.fr_one() if self.leader else np.zeros(4, dtype=np.uint64)
+            one = be.const_vec(c, n)
+            triple = ((one, one), (one, one), (one, one))
+        tx, ty, tz = triple
+        sxl = (be.vec("sp_sx_l0", n), be.vec("sp_sx_l1", n))
+        oyl = (be.vec("sp_oy_l0", n), be.vec("sp_oy_l1", n))
+        for lane in (0, 1):
+            be.add(x[lane], tx[lane], sxl[lane], n)
+            be.add(y[lane], ty[lane], oyl[lane], n)
+        sx, oy = be.vec("sp_sx", n), be.vec("sp_oy", n)
+        self.spdz_open_vec(sxl, sx, n)
+        self.spdz_open_vec(oyl, oy, n)
+        for lane in (0, 1):   # z - sx*y - oy*x + [leader] sx*oy : the shift lands on the leader in BOTH lanes (mac_share)
+            be.beaver_combine(sx, oy, tx[lane], ty[lane], tz[lane], out[lane], n)
+
+    # ---- scalars and group elements: pairs of host arrays ----
+    def _check_fr(self, x, mac):
+        dx = self.be.fr_sub(x if self.leader else np.zeros(4, dtype=np.uint64), mac)
+        parts = self.net.all_gather_small(np.ascontiguousarray(dx, dtype=np.uint64))
+        self.bytes_sent += 32
+        acc = parts[0]
+        for q in parts[1:]:
+            acc = self.be.fr_add(acc, q)
+        if np.any(acc):
+            raise MacCheckError("SPDZ MAC check failed on a scalar open")
+
+    def spdz_open_fr(self, v):
+        x = self._open_fr(v[0])
+        self._check_fr(x, v[1])
+        return x
+
+    def _spdz_open_g(self, v, add, neg, zero, ser):
+        x = self._open_g(v[0], add)
+        dx = add(x if self.leader else zero(), neg(v[1]))
+        tot = self._open_g(dx, add)
+        if ser(tot) != ser(zero()):
+            raise MacCheckError("SPDZ MAC check failed on a group open")
+        return x
+
+    def spdz_open_g1(self, v):
+        be = self.be
+        return self._spdz_open_g(v, be.g1_add, be.g1_neg, be.g1_zero, be.g1_serialize)
+
+    def spdz_open_g2(self, v):
+        be = self.be
+        neg2 = lambda p: be.g2_mul(p, self._minus_one())
+        return self._spdz_open_g(v, be.g2_add, neg2, be.g2_zero, be.g2_serialize)
+
+    def _minus_one(self):
+        return self.be.fr_sub(np.zeros(4, dtype=np.uint64), self.be.fr_one())
+
+    def spdz_scale_g1(self, s_pt, o_sc):
+        """GroupShare::scale over SPDZ shares with DummyGroupTripleSource (x = 0, y = from_add_shared(leader?1:0), z = 0)."""
+        be = self.be
+        y = be.fr_one() if self.leader else np.zeros(4, dtype=np.uint64)
+        sx = self.spdz_open_g1(s_pt)                                              # x = 0
+        oy = self.spdz_open_fr((be.fr_add(o_sc[0], y), be.fr_add(o_sc[1], y)))    # from_add_shared: mac = share (key 1)
+        out = []
+        for lane in (0, 1):
+            t = be.g1_neg(be.g1_mul(sx, y))                                       # - scale_pub_group(sx, y)
+            if self.leader:
+                t = be.g1_add(t, be.g1_mul(sx, oy))                               # shift: sh on the leader, mac += mac_share * G
+            out.append(t)
+        return tuple(out)
+
+    def create_proof_shared_spdz(self, pk, r1cs, z_share, r_share, s_share, triple=None) -> bytes:
+        """create_proof with E = MpcPairingEngine<_, SpdzPairingShare> (the `malicious` feature).
+        z_share = (sh, mac) device vectors; r_share, s_share = (sh, mac) scalars."""
+        be = self.be
+        D = be.domain_size(r1cs)
+        lanes = []
+        for lane in (0, 1):
+            a, b, c = be.vec("wm_a%d" % lane, D), be.vec("wm_b%d" % lane, D), be.vec("wm_c%d" % lane, D)
+            be.witness_map_pre(r1cs, z_share[lane], a, b, c)
+            lanes.append((a, b, c))
+        A = (lanes[0][0], lanes[1][0])
+        B = (lanes[0][1], lanes[1][1])
+        self.spdz_beaver_batch_mul(A, B, A, D, triple)
+        msm = []
+        for lane in (0, 1):
+            be.witness_map_post(r1cs, lanes[lane][0], lanes[lane][2])
+            msm.append(be.msms(pk, r1cs, z_share[lane], lanes[lane][0]))       # 2 x 5 MSMs (spdz.rs:482-488)
+        key = id(pk)
+        if key not in self._pk_cache:
+            self._pk_cache[key] = be.pk_points(pk)
+        P = self._pk_cache[key]
+        pair = lambda f: tuple(f(lane) for lane in (0, 1))
+        pub1 = (lambda x: x) if self.leader else (lambda x: be.g1_zero())      # shift: leader's sh; mac += mac_share * G
+        pub2 = (lambda x: x) if self.leader else (lambda x: be.g2_zero())
+        add1 = lambda u, v: (be.g1_add(u[0], v[0]), be.g1_add(u[1], v[1]))
+        neg1 = lambda u: (be.g1_neg(u[0]), be.g1_neg(u[1]))
+        h_acc, l_acc, a_acc, b1_acc = [pair(lambda lane, k=k: msm[lane][0][k]) for k in range(4)]
+        b2_acc = pair(lambda lane: msm[lane][1])
+        r_g1 = pair(lambda lane: be.g1_mul(P["delta_g1"], r_share[lane]))
+        r_s_delta = self.spdz_scale_g1(r_g1, s_share)
+        g_a = pair(lambda lane: be.g1_add(be.g1_add(be.g1_add(r_g1[lane], pub1(P["a0"])), a_acc[lane]), pub1(P["alpha_g1"])))
+        s_g_a = self.spdz_scale_g1(g_a, s_share)
+        s_g1 = pair(lambda lane: be.g1_mul(P["delta_g1"], s_share[lane]))
+        g1_b = pair(lambda lane: be.g1_add(be.g1_add(be.g1_add(s_g1[lane], pub1(P["b0_g1"])), b1_acc[lane]), pub1(P["beta_g1"])))
+        s_g2 = pair(lambda lane: be.g2_mul(P["delta_g2"], s_share[lane]))
+        g2_b = pair(lambda lane: be.g2_add(be.g2_add(be.g2_add(s_g2[lane], pub2(P["b0_g2"])), b2_acc[lane]), pub2(P["beta_g2"])))
+        r_g1_b = self.spdz_scale_g1(g1_b, r_share)
+        g_c = add1(add1(add1(add1(s_g_a, r_g1_b), neg1(r_s_delta)), l_acc), h_acc)
+        Ap, Bp, Cp = self.spdz_open_g1(g_a), self.spdz_open_g2(g2_b), self.spdz_open_g1(g_c)   # SpdzGroupShare::reveal
+        return be.g1_serialize(Ap) + be.g2_serialize(Bp) + be.g1_serialize(Cp)
