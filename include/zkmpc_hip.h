@@ -133,6 +133,11 @@ int zk_g2_serialize(const zk_g2_projective* a, uint8_t out[96]);
 int zk_fr_add(const zk_fr* a, const zk_fr* b, zk_fr* out);
 int zk_fr_sub(const zk_fr* a, const zk_fr* b, zk_fr* out);
 int zk_fr_mul(const zk_fr* a, const zk_fr* b, zk_fr* out);
+/* Fp384 add / sub / mul on Montgomery-form values (macros.rs:698-717, arithmetic.rs:7-57), computed with the
+ * device's own field templates (radix 2^29) on the host. */
+int zk_fq_add(const zk_fq* a, const zk_fq* b, zk_fq* out);
+int zk_fq_sub(const zk_fq* a, const zk_fq* b, zk_fq* out);
+int zk_fq_mul(const zk_fq* a, const zk_fq* b, zk_fq* out);
 int zk_fr_from_canonical(const uint64_t canon[4], zk_fr* out);   /* from_repr, macros.rs:464-474 */
 int zk_fr_to_canonical(const zk_fr* a, uint64_t canon[4]);       /* into_repr, arithmetic.rs:59-83 */
 

@@ -77,3 +77,44 @@ def test_host_group_helpers_against_oracle():
         assert cv.fr_from_mont(h.fr_op("mul", am, bm)) == [a * b % O.R_MOD]
         assert cv.fr_from_mont(h.fr_op("add", am, bm)) == [(a + b) % O.R_MOD]
         assert cv.fr_from_mont(h.fr_op("sub", am, bm)) == [(a - b) % O.R_MOD]
+
+
+def test_field_add_sub_boundaries():
+    """fp_add / fp_sub / the final reduction of fp_mul decide `>= p` from the top 29-bit limb and fall back to an exact
+    slow path when that limb is within 1 of p's: hit every side of that decision, for Fr and Fq, on the host build of
+    the very templates the kernels use."""
+    import ctypes as C
+    lib = Z.load()
+
+    def run(fn, a6, b6, n):
+        out = np.zeros(n, dtype=np.uint64)
+        a6 = np.ascontiguousarray(a6, dtype=np.uint64); b6 = np.ascontiguousarray(b6, dtype=np.uint64)
+        assert fn(a6.ctypes.data_as(C.c_void_p), b6.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+        return out
+
+    rng = O.Prng(99)
+    for mod, nl, topshift, add, sub, mul, to_m, from_m in (
+            (O.R_MOD, 4, 29 * 8, lib.zk_fr_add, lib.zk_fr_sub, lib.zk_fr_mul,
+             lambda v: cv.fr_to_mont([v])[0], lambda a: cv.fr_from_mont(a.reshape(1, 4))[0]),
+            (O.Q_MOD, 6, 29 * 12, lib.zk_fq_add, lib.zk_fq_sub, lib.zk_fq_mul,
+             lambda v: cv._ints_to_limbs([cv.fq_to_mont_int(v)], 6)[0], lambda a: cv.fq_from_mont_int(cv._limbs_to_ints(a.reshape(1, 6))[0]))):
+        R = (1 << (64 * nl)) % mod
+        Rinv = pow(R, -1, mod)
+        ptop = mod >> topshift
+        # Montgomery residues (what the limbs hold) with chosen top limbs: pick raw values, convert back to field values
+        raws = []
+        for t in (0, 1, 2, ptop - 3, ptop - 2, ptop - 1, ptop, (ptop // 2) - 1, ptop // 2, (ptop // 2) + 1):
+            for low in (0, 1, (1 << topshift) - 1, rng.fq() % (1 << topshift)):
+                v = (t << topshift) | low
+                if v < mod:
+                    raws.append(v)
+        raws += [mod - 1, mod - 2, 0, 1]
+        vals = [(x * Rinv) % mod for x in raws]          # field values whose Montgomery residue is the crafted raw
+        for x in vals:
+            for y in vals[::3]:
+                xm, ym = to_m(x), to_m(y)
+                assert from_m(run(add, xm, ym, nl)) == (x + y) % mod
+                assert from_m(run(sub, xm, ym, nl)) == (x - y) % mod
+        for x in vals[::2]:
+            for y in vals[::5]:
+                assert from_m(run(mul, to_m(x), to_m(y), nl)) == (x * y) % mod

@@ -108,6 +108,9 @@ PROTOTYPES = {
     "zk_fr_add": (_I, [_P, _P, _P]),
     "zk_fr_sub": (_I, [_P, _P, _P]),
     "zk_fr_mul": (_I, [_P, _P, _P]),
+    "zk_fq_add": (_I, [_P, _P, _P]),
+    "zk_fq_sub": (_I, [_P, _P, _P]),
+    "zk_fq_mul": (_I, [_P, _P, _P]),
     "zk_fr_from_canonical": (_I, [_P, _P]),
     "zk_fr_to_canonical": (_I, [_P, _P]),
     "zk_r1cs_upload": (_I, [_P, _P, C.POINTER(_P)]),

@@ -104,3 +104,22 @@ extern "C" int zk_fr_to_canonical(const zk_fr* a, uint64_t canon[4]) {
     host_store_ext<FrParams>(canon, fp_ext_to_canon<FrParams>(host_load_ext<FrParams>(a->l)));
     return ZK_OK;
 }
+
+// Fp384 (Fq) host helpers in the DEVICE representation (29-bit limbs): the same add / sub / mul templates the
+// kernels run, exposed so that their top-limb decision logic can be tested on crafted boundary values.
+extern "C" int zk_fq_add(const zk_fq* a, const zk_fq* b, zk_fq* out) {
+    if (!a || !b || !out) return ZK_ERR_ARG;
+    host_store_ext<FqParams>(out->l, fp_add<FqParams>(host_load_ext<FqParams>(a->l), host_load_ext<FqParams>(b->l)));
+    return ZK_OK;
+}
+extern "C" int zk_fq_sub(const zk_fq* a, const zk_fq* b, zk_fq* out) {
+    if (!a || !b || !out) return ZK_ERR_ARG;
+    host_store_ext<FqParams>(out->l, fp_sub<FqParams>(host_load_ext<FqParams>(a->l), host_load_ext<FqParams>(b->l)));
+    return ZK_OK;
+}
+extern "C" int zk_fq_mul(const zk_fq* a, const zk_fq* b, zk_fq* out) {
+    if (!a || !b || !out) return ZK_ERR_ARG;
+    Fq t = fp_mul<FqParams>(host_load_ext<FqParams>(a->l), host_load_ext<FqParams>(b->l));
+    host_store_ext<FqParams>(out->l, fp_mul<FqParams>(t, fp_const<FqParams>(FqParams::EXT_TO_INT)));
+    return ZK_OK;
+}

@@ -50,6 +50,8 @@ MsmPlan make_plan(size_t n, uint32_t forced_c = 0) {
     int c = (int)lg - 4;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
+    static const int env_c = getenv("ZK_MSM_C") ? atoi(getenv("ZK_MSM_C")) : 0;   // experiments: window bits for n >= 2^19
+    if (env_c >= 4 && env_c <= 20 && n >= ((size_t)1 << 19)) c = env_c;
     if (forced_c) c = (int)forced_c;
     p.c = (uint32_t)c;
     p.W = (255 + p.c - 1) / p.c;
