@@ -180,6 +180,8 @@ int zk_groth16_setup(zk_ctx* ctx, const zk_r1cs* r1cs, const zk_fr* alpha, const
 /* Sizes / elements of a resident key, for inspection by tests and serialisers.
  * which: 0=a_query 1=b_g1_query 2=b_g2_query 3=h_query 4=l_query 5=gamma_abc_g1 */
 size_t zk_pk_query_len(const zk_pk* pk, int which);
+/* Borrowed handle to one query table (same `which`); owned by the key, valid until zk_pk_free. */
+const zk_bases* zk_pk_query_bases(const zk_pk* pk, int which);
 int zk_pk_download_g1(zk_ctx* ctx, const zk_pk* pk, int which, size_t offset, size_t n, zk_g1_affine* out);
 int zk_pk_download_g2(zk_ctx* ctx, const zk_pk* pk, int which, size_t offset, size_t n, zk_g2_affine* out);
 /* vk elements: 0=alpha_g1 1=beta_g1 2=delta_g1 (G1);  0=beta_g2 1=delta_g2 2=gamma_g2 (G2) */

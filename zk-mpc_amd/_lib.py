@@ -121,6 +121,7 @@ PROTOTYPES = {
     "zk_pk_free": (_I, [_P, _P]),
     "zk_groth16_setup": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_P)]),
     "zk_pk_query_len": (_SZ, [_P, _I]),
+    "zk_pk_query_bases": (_P, [_P, _I]),
     "zk_pk_download_g1": (_I, [_P, _P, _I, _SZ, _SZ, _P]),
     "zk_pk_download_g2": (_I, [_P, _P, _I, _SZ, _SZ, _P]),
     "zk_pk_vk_g1": (_I, [_P, _I, _P]),

@@ -312,6 +312,12 @@ extern "C" size_t zk_pk_query_len(const zk_pk* pk, int which) {
     const zk_bases* all[6] = {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l, pk->gamma_abc};
     return (which >= 0 && which < 6 && all[which]) ? all[which]->n : 0;
 }
+// Borrowed handle to one query table of a resident key (valid until zk_pk_free; do not free it).
+extern "C" const zk_bases* zk_pk_query_bases(const zk_pk* pk, int which) {
+    if (!pk || which < 0 || which > 5) return nullptr;
+    const zk_bases* all[6] = {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l, pk->gamma_abc};
+    return all[which];
+}
 extern "C" int zk_pk_download_g1(zk_ctx* ctx, const zk_pk* pk, int which, size_t off, size_t n, zk_g1_affine* out) {
     if (!pk || which == 2 || which < 0 || which > 5) return ZK_ERR_ARG;
     const zk_bases* all[6] = {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l, pk->gamma_abc};

@@ -37,12 +37,19 @@ namespace {
 constexpr int REDUCE_K_LOG = 3;  // 8 elements per thread per reduction level
 
 struct MsmPlan {
-    uint32_t c;       // window bits
-    uint32_t W;       // windows
-    uint32_t NB;      // buckets per window = 2^(c-1)
-    uint32_t bias[9]; // sum_w 2^(c-1) 2^(c w)
+    uint32_t c;        // widest window (bits): buckets per window NB = 2^(c-1)
+    uint32_t W;        // windows
+    uint32_t NB;       // buckets per window
+    uint32_t bias[9];  // sum_w 2^(off[w+1]-1): makes every window an independent signed digit
+    uint16_t off[65];  // window w covers bits [off[w], off[w+1])
 };
 
+// 253-bit scalars + 2 bits of headroom for the signed-digit bias = 255 bits.  Uniform c-bit windows leave a nearly
+// empty TOP window for most c (253 mod c is 1 for c = 12 and 14, 0 for c = 11, ...): two or three buckets then
+// receive half of all points each, and the histogram / scatter atomics serialise on them (measured: the sort
+// phase of a 2^18 MSM took 3.7 ms instead of ~0.5 ms).  So the 255 bits are spread EVENLY: W = ceil(255/c)
+// windows of floor(255/W) or ceil(255/W) bits.  With precomputed window multiples (forced_c) the windows must
+// be uniform, because the table holds 2^(c w) * base.
 MsmPlan make_plan(size_t n, uint32_t forced_c = 0) {
     MsmPlan p;
     uint32_t lg = 0;                                   // round(log2 n)
@@ -53,22 +60,33 @@ MsmPlan make_plan(size_t n, uint32_t forced_c = 0) {
     static const int env_c = getenv("ZK_MSM_C") ? atoi(getenv("ZK_MSM_C")) : 0;   // experiments: window bits for n >= 2^19
     if (env_c >= 4 && env_c <= 20 && n >= ((size_t)1 << 19)) c = env_c;
     if (forced_c) c = (int)forced_c;
-    p.c = (uint32_t)c;
-    p.W = (255 + p.c - 1) / p.c;
-    p.NB = 1u << (p.c - 1);
+    p.W = (255 + (uint32_t)c - 1) / (uint32_t)c;
     for (int i = 0; i < 9; i++) p.bias[i] = 0;
+    if (forced_c) {
+        for (uint32_t w = 0; w <= p.W; w++) p.off[w] = (uint16_t)(w * c);
+        p.c = (uint32_t)c;
+    } else {
+        const uint32_t base = 255 / p.W, extra = 255 % p.W;   // the `extra` lowest windows get one more bit
+        uint32_t o = 0;
+        for (uint32_t w = 0; w < p.W; w++) { p.off[w] = (uint16_t)o; o += base + (w < extra ? 1 : 0); }
+        p.off[p.W] = (uint16_t)o;
+        p.c = base + (extra ? 1 : 0);
+    }
+    p.NB = 1u << (p.c - 1);
     for (uint32_t w = 0; w < p.W; w++) {
-        uint32_t bit = w * p.c + p.c - 1;
+        uint32_t bit = p.off[w + 1] - 1u;
         p.bias[bit >> 5] |= 1u << (bit & 31);
     }
     return p;
 }
 
+struct WinOff { uint16_t off[66]; };
+
 struct Bias { uint32_t w[9]; };
 
 // dig[w*n + i] = |d| | (d<0 ? 1<<31 : 0), and counts[w*NB + |d| - 1]++ for |d| > 0.
 __global__ void __launch_bounds__(256)
-k_digits(const void* scalars, size_t n, uint32_t c, uint32_t W, uint32_t NB, Bias bias, uint32_t* dig, uint32_t* counts, int merged) {
+k_digits(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, uint32_t* dig, uint32_t* counts, int merged) {
     __shared__ uint32_t kw[9][256];
     const uint32_t tid = threadIdx.x;
     for (size_t i0 = blockIdx.x * (size_t)256; i0 < n; i0 += (size_t)gridDim.x * 256) {
@@ -84,9 +102,10 @@ k_digits(const void* scalars, size_t n, uint32_t c, uint32_t W, uint32_t NB, Bia
                 kw[k][tid] = (uint32_t)t;
                 carry = (uint32_t)(t >> 32);
             }
-            const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
             for (uint32_t w = 0; w < W; w++) {
-                uint32_t bit = w * c, wi = bit >> 5, sh = bit & 31;
+                const uint32_t bit = wo.off[w], cw = wo.off[w + 1] - bit;
+                const uint32_t half = 1u << (cw - 1), mask = (1u << cw) - 1;
+                const uint32_t wi = bit >> 5, sh = bit & 31;
                 uint64_t two = kw[wi][tid];
                 if (wi + 1 < 9) two |= (uint64_t)kw[wi + 1][tid] << 32;
                 int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (int32_t)half;
@@ -432,6 +451,7 @@ int msm_prepare_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base
     const bool merged = bases->pre != nullptr && n >= 4096;
     const MsmPlan p = make_plan(n, merged ? bases->c_pre : 0);
     job->c = p.c; job->W = p.W; job->NB = p.NB;
+    for (int i = 0; i < 65; i++) job->off[i] = p.off[i];
     if (merged) {
         if (p.W > bases->W_pre) ZK_FAIL(ctx, ZK_ERR_STATE, "msm: precomputed table has too few windows");
         job->Wb = 1;
@@ -505,8 +525,11 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     const uint32_t W = job->W, NB = job->NB, seg = job->seg, Wb = job->Wb;
     const int merged = Wb == 1 && W > 1;
     const size_t nbuck = (size_t)Wb * NB;
-    const MsmPlan p = make_plan(n, job->c);
+    const MsmPlan p = make_plan(n, merged ? job->c : 0);
     Bias bias;
+    WinOff wo;
+    for (int i = 0; i < 65; i++) wo.off[i] = job->off[i];
+    wo.off[65] = 0;
     for (int i = 0; i < 9; i++) bias.w[i] = p.bias[i];
     uint32_t* win_segs = b.small;
     uint32_t* ctr = b.small + 64;
@@ -518,7 +541,7 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     tm->begin(g1 ? "msm_g1.sort" : "msm_g2.sort");
     ZK_HIP(ctx, hipMemsetAsync(b.counts, 0, nbuck * 4, st));
     ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 4 + 3 * (size_t)(seg + 1)) * 4, st));
-    hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, job->c, W, NB, bias, b.dig, b.counts, merged);
+    hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, b.counts, merged);
     hipLaunchKernelGGL(k_scan, Wb, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NB, seg);
     hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted, merged,
                        job->n_tab, job->tab_off);
@@ -609,7 +632,8 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
     const uint32_t nb1 = job->nbits + 1;
     XYZZ<H> total = xyzz_inf<H>();
     for (int w = (int)job->Wb - 1; w >= 0; w--) {
-        for (uint32_t k = 0; k < job->c; k++) total = xyzz_dbl<H>(total);
+        const uint32_t cw = (uint32_t)(job->off[w + 1] - job->off[w]);   // 2^cw * (sum of the higher windows) + this window
+        for (uint32_t k = 0; k < cw; k++) total = xyzz_dbl<H>(total);
         const uint32_t* base = job->hw + (size_t)w * nb1 * XW;
         XYZZ<H> ws = xyzz_inf<H>();
         for (int j = (int)job->nbits - 1; j >= 0; j--) {
