@@ -211,6 +211,28 @@ int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, cons
 int zk_groth16_prove(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const zk_fr* z_host,
                      const zk_fr* r, const zk_fr* s, uint8_t proof_out[192]);
 
+/* ---- dense polynomials over Fr and KZG10 (row a14: the data-parallel pieces of the Marlin / poly-commit path) ---- */
+/* out[i] = start * base^i, i < n (device vector). */
+int zk_fr_powers_dev(zk_ctx* ctx, const zk_fr* base, const zk_fr* start, size_t n, void* out_dev);
+/* ark_ff::batch_inversion in place; zero entries stay zero (ff/src/fields/mod.rs:597-659). */
+int zk_fr_batch_inverse_dev(zk_ctx* ctx, void* v_dev, size_t n);
+/* DensePolynomial::evaluate (poly/src/polynomial/univariate/dense.rs:53-75); n coefficients, low degree first. */
+int zk_poly_evaluate_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, const zk_fr* point, zk_fr* out);
+/* p / (X - z): quotient (n-1 coefficients) and remainder p(z) (KZG10::compute_witness_polynomial, kzg10/mod.rs:212-235). */
+int zk_poly_divide_by_linear_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, const zk_fr* z, void* q_dev, zk_fr* rem);
+/* DensePolynomial::divide_by_vanishing_poly for the radix-2 domain of size 2^log_domain (dense.rs:166-173):
+ * q gets max(n - N, 0) coefficients, r gets N (both zero-padded, not truncated). */
+int zk_poly_divide_by_vanishing_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, uint32_t log_domain, void* q_dev, void* r_dev);
+/* DensePolynomial multiplication via FFT (dense.rs:568-584): out gets na + nb - 1 coefficients. */
+int zk_poly_mul_dev(zk_ctx* ctx, const void* a_dev, size_t na, const void* b_dev, size_t nb, void* out_dev);
+/* KZG10::commit (poly-commit/src/kzg10/mod.rs:142-205): MSM(powers_of_g, coeffs) [+ MSM(powers_of_gamma_g, blinding)]. */
+int zk_kzg_commit_dev(zk_ctx* ctx, const zk_bases* powers_g, const void* coeffs_dev, size_t n,
+                      const zk_bases* powers_gamma_g, const void* blind_dev, size_t n_blind, zk_g1_projective* out);
+/* KZG10::open (kzg10/mod.rs:212-293): w = commit(p/(X-z)) [+ commit_gamma(blind/(X-z)), random_v = blind(z)]. */
+int zk_kzg_open_dev(zk_ctx* ctx, const zk_bases* powers_g, const void* coeffs_dev, size_t n, const zk_fr* point,
+                    const zk_bases* powers_gamma_g, const void* blind_dev, size_t n_blind,
+                    zk_g1_projective* w_out, zk_fr* random_v_out);
+
 /* ---- share algebra on device vectors (rows a11, a13) ------------------------------------- */
 /* out[i] = sum_p gathered[p*n + i] mod r: the receive side of AdditiveFieldShare::batch_open
  * (mpc-algebra/src/share/additive.rs:124-131) after an all-gather of the parties' vectors. */

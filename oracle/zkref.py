@@ -813,6 +813,86 @@ def verify_proof(pk: ProvingKey, proof, public_inputs: List[int]) -> bool:
 
 
 # --------------------------------------------------------------------------------------
+# Dense polynomials and KZG10 (poly/src/polynomial/univariate/dense.rs, poly-commit/src/kzg10/mod.rs)
+# --------------------------------------------------------------------------------------
+
+
+def batch_inversion(v):
+    """ark_ff::batch_inversion (ff/src/fields/mod.rs:597-659): zeros stay zero."""
+    return [0 if x % R_MOD == 0 else pow(x, -1, R_MOD) for x in v]
+
+
+def poly_evaluate(c, z):
+    acc = 0
+    for coeff in reversed(c):       # horner_evaluate, dense.rs:68-72
+        acc = (acc * z + coeff) % R_MOD
+    return acc
+
+
+def poly_mul(a, b):
+    out = [0] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        for j, y in enumerate(b):
+            out[i + j] = (out[i + j] + x * y) % R_MOD
+    return out
+
+
+def poly_divide_with_q_and_r(num, den):
+    """DenseOrSparsePolynomial::divide_with_q_and_r (poly/src/polynomial/univariate/mod.rs:133-176): schoolbook long division."""
+    num, den = list(num), list(den)
+    while den and den[-1] == 0:
+        den.pop()
+    q = [0] * max(len(num) - len(den) + 1, 0)
+    r = list(num)
+    dl = pow(den[-1], -1, R_MOD)
+    for k in range(len(num) - len(den), -1, -1):
+        coef = (r[k + len(den) - 1] * dl) % R_MOD
+        q[k] = coef
+        for i, d in enumerate(den):
+            r[k + i] = (r[k + i] - coef * d) % R_MOD
+    return q, r[:len(den) - 1]
+
+
+class KzgParams:
+    """KZG10::setup with explicit toxic waste (kzg10/mod.rs:44-135): g = g_k*G1, gamma_g = gg_k*G1, h = h_k*G2."""
+
+    def __init__(self, max_degree, beta, g_k=1, gg_k=7, h_k=1):
+        self.beta = beta % R_MOD
+        self.g, self.gamma_g, self.h = g1_mul(G1_GEN, g_k), g1_mul(G1_GEN, gg_k), g2_mul(G2_GEN, h_k)
+        self.powers_of_beta = [pow(self.beta, i, R_MOD) for i in range(max_degree + 2)]
+        self.powers_of_g = [g1_mul(self.g, b) for b in self.powers_of_beta[:max_degree + 1]]
+        self.powers_of_gamma_g = [g1_mul(self.gamma_g, b) for b in self.powers_of_beta]   # one extra power (:85-87)
+        self.beta_h = g2_mul(self.h, self.beta)
+
+
+def kzg_commit(pp, coeffs, blind=None):
+    c = msm_naive(pp.powers_of_g, coeffs, FqOps)
+    if blind:
+        c = g1_add(c, msm_naive(pp.powers_of_gamma_g, blind, FqOps))
+    return c
+
+
+def kzg_open(pp, coeffs, z, blind=None):
+    q, _ = poly_divide_with_q_and_r(coeffs, [(-z) % R_MOD, 1])
+    w = msm_naive(pp.powers_of_g, q, FqOps)
+    rv = None
+    if blind:
+        qb, _ = poly_divide_with_q_and_r(blind, [(-z) % R_MOD, 1])
+        w = g1_add(w, msm_naive(pp.powers_of_gamma_g, qb, FqOps))
+        rv = poly_evaluate(blind, z)
+    return w, rv
+
+
+def kzg_check(pp, comm, z, value, w, random_v=None):
+    """KZG10::check (kzg10/mod.rs:320-343): e(C - v g - rv gamma_g, h) = e(w, beta_h - z h)."""
+    inner = g1_add(comm, g1_neg(g1_mul(pp.g, value)))
+    if random_v is not None:
+        inner = g1_add(inner, g1_neg(g1_mul(pp.gamma_g, random_v)))
+    rhs_g2 = g2_add(pp.beta_h, g2_neg(g2_mul(pp.h, z)))
+    return pairing_product_is_one([(inner, pp.h), (g1_neg(w), rhs_g2)])
+
+
+# --------------------------------------------------------------------------------------
 # Deterministic test-vector PRNG (SHA-256 counter mode; NOT the reference's ChaCha rng)
 # --------------------------------------------------------------------------------------
 

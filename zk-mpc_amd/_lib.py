@@ -133,6 +133,14 @@ PROTOTYPES = {
     "zk_groth16_msms_dev": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "zk_groth16_prove_dev": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "zk_groth16_prove": (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    "zk_fr_powers_dev": (_I, [_P, _P, _P, _SZ, _P]),
+    "zk_fr_batch_inverse_dev": (_I, [_P, _P, _SZ]),
+    "zk_poly_evaluate_dev": (_I, [_P, _P, _SZ, _P, _P]),
+    "zk_poly_divide_by_linear_dev": (_I, [_P, _P, _SZ, _P, _P, _P]),
+    "zk_poly_divide_by_vanishing_dev": (_I, [_P, _P, _SZ, _U32, _P, _P]),
+    "zk_poly_mul_dev": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
+    "zk_kzg_commit_dev": (_I, [_P, _P, _P, _SZ, _P, _P, _SZ, _P]),
+    "zk_kzg_open_dev": (_I, [_P, _P, _P, _SZ, _P, _P, _P, _SZ, _P, _P]),
     "zk_fr_sum_parties_dev": (_I, [_P, _P, _SZ, _SZ, _P]),
     "zk_beaver_combine_dev": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ]),
     "zk_fr_vec_is_zero_dev": (_I, [_P, _P, _SZ, _P]),

@@ -180,6 +180,49 @@ class Context:
         self._ck(fn(self.h, bases.h, base_offset, C.c_void_p(int(scalars_dev)), n, _ptr(out)))
         return out
 
+    # ---- dense polynomials / KZG10 (names follow DensePolynomial / KZG10 in the reference) ----
+    def fr_powers_dev(self, base4, start4, n: int, out):
+        b, s_ = _fr_struct(base4), _fr_struct(start4)
+        self._ck(self.lib.zk_fr_powers_dev(self.h, C.byref(b), C.byref(s_), n, C.c_void_p(int(out))))
+
+    def batch_inversion_dev(self, v, n: int):
+        self._ck(self.lib.zk_fr_batch_inverse_dev(self.h, C.c_void_p(int(v)), n))
+
+    def poly_evaluate_dev(self, coeffs, n: int, point4) -> np.ndarray:
+        pt = _fr_struct(point4)
+        out = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.zk_poly_evaluate_dev(self.h, C.c_void_p(int(coeffs)), n, C.byref(pt), _ptr(out)))
+        return out
+
+    def poly_divide_by_linear_dev(self, coeffs, n: int, z4, q):
+        z = _fr_struct(z4)
+        rem = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.zk_poly_divide_by_linear_dev(self.h, C.c_void_p(int(coeffs)), n, C.byref(z), C.c_void_p(int(q)), _ptr(rem)))
+        return rem
+
+    def poly_divide_by_vanishing_dev(self, coeffs, n: int, log_domain: int, q, r):
+        self._ck(self.lib.zk_poly_divide_by_vanishing_dev(self.h, C.c_void_p(int(coeffs)), n, log_domain,
+                                                          C.c_void_p(int(q)) if q else None, C.c_void_p(int(r))))
+
+    def poly_mul_dev(self, a, na: int, b, nb: int, out):
+        self._ck(self.lib.zk_poly_mul_dev(self.h, C.c_void_p(int(a)), na, C.c_void_p(int(b)), nb, C.c_void_p(int(out))))
+
+    def kzg_commit_dev(self, powers_g: "Bases", coeffs, n: int, powers_gamma_g: "Bases" = None, blind=None, n_blind: int = 0):
+        out = np.zeros(18, dtype=np.uint64)
+        self._ck(self.lib.zk_kzg_commit_dev(self.h, powers_g.h, C.c_void_p(int(coeffs)), n,
+                                            powers_gamma_g.h if powers_gamma_g else None,
+                                            C.c_void_p(int(blind)) if blind else None, n_blind, _ptr(out)))
+        return out
+
+    def kzg_open_dev(self, powers_g: "Bases", coeffs, n: int, point4, powers_gamma_g: "Bases" = None, blind=None, n_blind: int = 0):
+        pt = _fr_struct(point4)
+        w = np.zeros(18, dtype=np.uint64)
+        rv = np.zeros(4, dtype=np.uint64)
+        self._ck(self.lib.zk_kzg_open_dev(self.h, powers_g.h, C.c_void_p(int(coeffs)), n, C.byref(pt),
+                                          powers_gamma_g.h if powers_gamma_g else None,
+                                          C.c_void_p(int(blind)) if blind else None, n_blind, _ptr(w), _ptr(rv)))
+        return w, rv
+
     # ---- share algebra ----
     def fr_sum_parties_dev(self, gathered, n_parties: int, n: int, out):
         self._ck(self.lib.zk_fr_sum_parties_dev(self.h, C.c_void_p(int(gathered)), n_parties, n, C.c_void_p(int(out))))

@@ -1,0 +1,275 @@
+// poly.hip -- dense-polynomial kernels over Fr and KZG10 commit / open on top of the MSM: the data-parallel
+// pieces of the Marlin / poly-commit path.
+//
+// Replaces (reference):
+//   ark_ff::batch_inversion                                arkworks/algebra/ff/src/fields/mod.rs:597-659
+//   DensePolynomial::evaluate (Horner)                     arkworks/algebra/poly/src/polynomial/univariate/dense.rs:53-75
+//   DensePolynomial mul via FFT                            dense.rs:568-584
+//   DensePolynomial::divide_by_vanishing_poly              dense.rs:166-173 (-> divide_with_q_and_r, univariate/mod.rs:133-176)
+//   p / (X - z)  (KZG10::compute_witness_polynomial)       arkworks/poly-commit/src/kzg10/mod.rs:212-235
+//   KZG10::commit / open_with_witness_polynomial           kzg10/mod.rs:142-205, 237-293
+//
+// Polynomials are coefficient vectors of Fr in the reference's form (device memory).  Every product here has one
+// operand that the host supplies (the point z, its powers), converted once to the device's internal Montgomery
+// form, so data * constant needs a single Montgomery product (fp29.cuh header).
+//
+// Horner and synthetic division are first-order linear recurrences Q_j = c_j + z * Q_{j+1}.  They are solved as a
+// two-level scan: every thread folds a chunk of 64 coefficients (giving the chunk's value for carry-in 0), the
+// chunk heads obey the same recurrence with multiplier z^64 and are solved recursively, then every thread replays
+// its chunk from the now-known carry-in.  2n products, fully coalesced-by-chunk traffic, HBM-light.
+#include "../../include/zkmpc_hip.h"
+#include "devutil.cuh"
+#include "hostgroup.hpp"
+#include "internal.hpp"
+#include <vector>
+
+using namespace zk;
+
+namespace {
+
+constexpr int CH = 64;       // recurrence chunk per thread
+constexpr int INV_CH = 32;   // batch-inversion chunk per thread
+
+struct FrK { uint32_t l[9]; };
+__device__ __forceinline__ Fr frk(const FrK& k) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = k.l[i];
+    return r;
+}
+FrK to_frk(const Fr& a) {
+    FrK k;
+    for (int i = 0; i < 9; i++) k.l[i] = a.l[i];
+    return k;
+}
+Fr host_int(const zk_fr* x) { return fp_ext_to_int<FrParams>(host_load_ext<FrParams>(x->l)); }
+Fr host_pow(const Fr& a, uint64_t e) {
+    Fr r = fp_one<FrParams>();
+    bool started = false;
+    for (int b = 63; b >= 0; b--) {
+        if (started) r = fp_sqr<FrParams>(r);
+        if ((e >> b) & 1) { r = started ? fp_mul<FrParams>(r, a) : a; started = true; }
+    }
+    return r;
+}
+
+// heads[t] = sum_{j < CH} c[t*CH + j] * z^j   (chunk value for carry-in 0)
+__global__ void __launch_bounds__(256) k_chunk_heads(const void* c, size_t n, FrK zk_, void* heads, size_t m) {
+    const Fr z = frk(zk_);
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < m; t += (size_t)gridDim.x * blockDim.x) {
+        size_t lo = t * CH, hi = lo + CH < n ? lo + CH : n;
+        Fr acc = fp_zero<FrParams>();
+        for (size_t j = hi; j-- > lo;) acc = fr_add(fr_mul(acc, z), fr_load(c, j));
+        fr_store(heads, t, acc);
+    }
+}
+
+// Q_j = c_j + z * Q_{j+1} inside chunk t with carry-in H[t+1] (0 for the last chunk).  Writes Q_j to out[j + shift]
+// for j + shift >= 0 (shift = -1 drops Q_0, the remainder, and yields the quotient of the division by X - z).
+__global__ void __launch_bounds__(256) k_chunk_fill(const void* c, size_t n, FrK zk_, const void* H, size_t m, void* out, int shift) {
+    const Fr z = frk(zk_);
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < m; t += (size_t)gridDim.x * blockDim.x) {
+        size_t lo = t * CH, hi = lo + CH < n ? lo + CH : n;
+        Fr acc = (t + 1 < m) ? fr_load(H, t + 1) : fp_zero<FrParams>();
+        for (size_t j = hi; j-- > lo;) {
+            acc = fr_add(fr_mul(acc, z), fr_load(c, j));
+            if ((long long)j + shift >= 0) fr_store(out, (size_t)((long long)j + shift), acc);
+        }
+    }
+}
+
+// q_j = sum_{k>=1} c[j + k N]  (j < nq) ;  r_j = sum_{k>=0} c[j + k N]  (j < N)
+__global__ void __launch_bounds__(256) k_div_vanishing(const void* c, size_t n, size_t N, void* q, size_t nq, void* r) {
+    const size_t total = nq > N ? nq : N;
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+        Fr acc = fp_zero<FrParams>();
+        for (size_t i = j + N; i < n; i += N) acc = fr_add(acc, fr_load(c, i));
+        if (j < nq) fr_store(q, j, acc);
+        if (j < N) fr_store(r, j, j < n ? fr_add(acc, fr_load(c, j)) : acc);
+    }
+}
+
+// Montgomery's trick on chunks of INV_CH; zeros stay zero (ff/src/fields/mod.rs:632-658).
+__global__ void __launch_bounds__(64) k_batch_inverse(void* v, size_t n, uint32_t* scratch) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t * INV_CH < n; t += (size_t)gridDim.x * blockDim.x) {
+        size_t lo = t * INV_CH, hi = lo + INV_CH < n ? lo + INV_CH : n;
+        Fr run = fp_one<FrParams>();
+        for (size_t i = lo; i < hi; i++) {
+            fr_store(scratch, i, run);                                       // product of the non-zero elements before i (internal form)
+            Fr x = fp_ext_to_int<FrParams>(fr_load(v, i));
+            if (!fp_is_zero<FrParams>(x)) run = fr_mul(run, x);
+        }
+        Fr inv = fp_inv<FrParams>(run);
+        for (size_t i = hi; i-- > lo;) {
+            Fr x = fp_ext_to_int<FrParams>(fr_load(v, i));
+            if (fp_is_zero<FrParams>(x)) continue;
+            Fr xi = fr_mul(inv, fr_load(scratch, i));                        // 1/x, internal form
+            inv = fr_mul(inv, x);
+            fr_store(v, i, fp_int_to_ext<FrParams>(xi));
+        }
+    }
+}
+
+// out[i] = start * base^i
+__global__ void __launch_bounds__(256) k_powers(void* out, FrK base_k, FrK start_k, size_t n) {
+    constexpr int PC = 32;
+    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t i0 = t * PC;
+    if (i0 >= n) return;
+    const Fr base = frk(base_k);
+    Fr p = fp_one<FrParams>();
+    bool started = false;
+    for (int b = 63; b >= 0; b--) {
+        if (started) p = fp_sqr<FrParams>(p);
+        if ((i0 >> b) & 1) { p = started ? fr_mul(p, base) : base; started = true; }
+    }
+    p = fr_mul(fp_int_to_ext<FrParams>(p), frk(start_k));                    // ext form of start * base^i0
+    for (int j = 0; j < PC && i0 + j < n; j++) {
+        fr_store(out, i0 + j, p);
+        p = fr_mul(p, base);
+    }
+}
+
+// Solves Q_j = c_j + z Q_{j+1} (Q_n = 0).  If out != null writes Q_j to out[j + shift]; returns Q_0 in *q0.
+int solve_recurrence(zk_ctx* ctx, const void* c, size_t n, const Fr& z, void* out, int shift, Fr* q0, int depth) {
+    if (n == 0) { *q0 = fp_zero<FrParams>(); return ZK_OK; }
+    const size_t m = (n + CH - 1) / CH;
+    char name[48];
+    snprintf(name, sizeof name, "poly_heads.%d", depth);
+    void* heads;
+    ZK_TRY(zk_scratch(ctx, name, m * 32 + 32, &heads));
+    hipLaunchKernelGGL(k_chunk_heads, zk_grid(m, 256), 256, 0, ctx->stream, c, n, to_frk(z), heads, m);
+    ZK_HIP(ctx, hipGetLastError());
+    void* H = nullptr;
+    if (m > 1) {
+        snprintf(name, sizeof name, "poly_H.%d", depth);
+        ZK_TRY(zk_scratch(ctx, name, m * 32 + 32, &H));
+        Fr zc = host_pow(z, CH);
+        Fr dummy;
+        ZK_TRY(solve_recurrence(ctx, heads, m, zc, H, 0, &dummy, depth + 1));   // H[t] = Q_{t*CH}
+        if (q0) *q0 = dummy;
+    } else {
+        H = heads;
+        uint32_t w[8];
+        ZK_HIP(ctx, hipMemcpyAsync(w, heads, 32, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (q0) *q0 = fp_ext_to_int<FrParams>(fp_unpack<FrParams>(w));
+    }
+    if (out) {
+        hipLaunchKernelGGL(k_chunk_fill, zk_grid(m, 256), 256, 0, ctx->stream, c, n, to_frk(z), H, m, out, shift);
+        ZK_HIP(ctx, hipGetLastError());
+    }
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" int zk_fr_powers_dev(zk_ctx* ctx, const zk_fr* base, const zk_fr* start, size_t n, void* out_dev) {
+    if (!ctx || !base || !start || (n && !out_dev)) return ZK_ERR_ARG;
+    if (!n) return ZK_OK;
+    Fr b = host_int(base);
+    Fr s_ext = host_load_ext<FrParams>(start->l);   // kept in ext form: multiplied in after the int->ext conversion of base^i0
+    size_t threads = (n + 31) / 32;
+    hipLaunchKernelGGL(k_powers, (unsigned)((threads + 255) / 256), 256, 0, ctx->stream, out_dev, to_frk(b),
+                       to_frk(fp_ext_to_int<FrParams>(s_ext)), n);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+extern "C" int zk_fr_batch_inverse_dev(zk_ctx* ctx, void* v_dev, size_t n) {
+    if (!ctx || (n && !v_dev)) return ZK_ERR_ARG;
+    if (!n) return ZK_OK;
+    uint32_t* scr;
+    ZK_TRY(zk_scratch(ctx, "poly_inv", n * 32 + 32, (void**)&scr));
+    size_t chunks = (n + INV_CH - 1) / INV_CH;
+    hipLaunchKernelGGL(k_batch_inverse, zk_grid(chunks, 64, 8192), 64, 0, ctx->stream, v_dev, n, scr);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+extern "C" int zk_poly_evaluate_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, const zk_fr* point, zk_fr* out) {
+    if (!ctx || !point || !out || (n && !coeffs_dev)) return ZK_ERR_ARG;
+    Fr q0;
+    ZK_TRY(solve_recurrence(ctx, coeffs_dev, n, host_int(point), nullptr, 0, &q0, 0));
+    host_store_ext<FrParams>(out->l, fp_int_to_ext<FrParams>(q0));
+    return ZK_OK;
+}
+
+extern "C" int zk_poly_divide_by_linear_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, const zk_fr* z, void* q_dev, zk_fr* rem) {
+    if (!ctx || !z || (n && !coeffs_dev) || (n > 1 && !q_dev)) return ZK_ERR_ARG;
+    Fr q0;
+    ZK_TRY(solve_recurrence(ctx, coeffs_dev, n, host_int(z), n > 1 ? q_dev : nullptr, -1, &q0, 0));
+    if (rem) host_store_ext<FrParams>(rem->l, fp_int_to_ext<FrParams>(q0));
+    return ZK_OK;
+}
+
+extern "C" int zk_poly_divide_by_vanishing_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, uint32_t log_domain, void* q_dev, void* r_dev) {
+    if (!ctx || !r_dev || (n && !coeffs_dev) || log_domain > 28) return ZK_ERR_ARG;
+    const size_t N = (size_t)1 << log_domain;
+    const size_t nq = n > N ? n - N : 0;
+    if (nq && !q_dev) return ZK_ERR_ARG;
+    hipLaunchKernelGGL(k_div_vanishing, zk_grid(nq > N ? nq : N, 256), 256, 0, ctx->stream, coeffs_dev, n, N, q_dev, nq, r_dev);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+extern "C" int zk_poly_mul_dev(zk_ctx* ctx, const void* a_dev, size_t na, const void* b_dev, size_t nb, void* out_dev) {
+    if (!ctx || !out_dev || !na || !nb || !a_dev || !b_dev) return ZK_ERR_ARG;
+    const size_t nout = na + nb - 1;
+    uint32_t lg = 0;
+    while (((size_t)1 << lg) < nout) lg++;
+    const size_t N = (size_t)1 << lg;
+    void *ta, *tb;
+    ZK_TRY(zk_scratch(ctx, "poly_mul_a", N * 32, &ta));
+    ZK_TRY(zk_scratch(ctx, "poly_mul_b", N * 32, &tb));
+    ZK_HIP(ctx, hipMemcpyAsync(ta, a_dev, na * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemsetAsync((char*)ta + na * 32, 0, (N - na) * 32, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(tb, b_dev, nb * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemsetAsync((char*)tb + nb * 32, 0, (N - nb) * 32, ctx->stream));
+    ZK_TRY(zk_ntt_launch(ctx, ta, lg, 0, 0));
+    ZK_TRY(zk_ntt_launch(ctx, tb, lg, 0, 0));
+    ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_MUL, ta, tb, ta, N));
+    ZK_TRY(zk_ntt_launch(ctx, ta, lg, 1, 0));
+    ZK_HIP(ctx, hipMemcpyAsync(out_dev, ta, nout * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    return ZK_OK;
+}
+
+// KZG10::commit: MSM(powers_of_g, coeffs) + MSM(powers_of_gamma_g, blinding coeffs)
+extern "C" int zk_kzg_commit_dev(zk_ctx* ctx, const zk_bases* powers_g, const void* coeffs_dev, size_t n,
+                                 const zk_bases* powers_gamma_g, const void* blind_dev, size_t n_blind, zk_g1_projective* out) {
+    if (!ctx || !powers_g || !out || (n && !coeffs_dev) || powers_g->group != 1) return ZK_ERR_ARG;
+    if (n > powers_g->n) ZK_FAIL(ctx, ZK_ERR_ARG, "kzg commit: polynomial degree exceeds the supported degree");   // check_degree_is_too_large
+    zk_g1_projective c;
+    ZK_TRY(zk_msm_run(ctx, powers_g, 0, coeffs_dev, n, &c));
+    if (n_blind) {
+        if (!powers_gamma_g || !blind_dev || n_blind > powers_gamma_g->n) ZK_FAIL(ctx, ZK_ERR_ARG, "kzg commit: hiding bound too large");
+        zk_g1_projective r;
+        ZK_TRY(zk_msm_run(ctx, powers_gamma_g, 0, blind_dev, n_blind, &r));
+        zk_g1_add(&c, &r, &c);
+    }
+    *out = c;
+    return ZK_OK;
+}
+
+// KZG10::open: w = commit(p / (X - z)) [+ commit_gamma(blind / (X - z))], random_v = blind(z)
+extern "C" int zk_kzg_open_dev(zk_ctx* ctx, const zk_bases* powers_g, const void* coeffs_dev, size_t n, const zk_fr* point,
+                               const zk_bases* powers_gamma_g, const void* blind_dev, size_t n_blind,
+                               zk_g1_projective* w_out, zk_fr* random_v_out) {
+    if (!ctx || !powers_g || !point || !w_out || (n && !coeffs_dev) || powers_g->group != 1) return ZK_ERR_ARG;
+    void* q;
+    ZK_TRY(zk_scratch(ctx, "kzg_witness", (n ? n : 1) * 32, &q));
+    ZK_TRY(zk_poly_divide_by_linear_dev(ctx, coeffs_dev, n, point, q, nullptr));
+    zk_g1_projective w;
+    ZK_TRY(zk_msm_run(ctx, powers_g, 0, q, n > 1 ? n - 1 : 0, &w));
+    if (n_blind) {
+        if (!powers_gamma_g || !blind_dev || !random_v_out) return ZK_ERR_ARG;
+        void* qb;
+        ZK_TRY(zk_scratch(ctx, "kzg_witness_b", n_blind * 32, &qb));
+        ZK_TRY(zk_poly_divide_by_linear_dev(ctx, blind_dev, n_blind, point, qb, random_v_out));   // remainder = blind(z)
+        zk_g1_projective wb;
+        ZK_TRY(zk_msm_run(ctx, powers_gamma_g, 0, qb, n_blind > 1 ? n_blind - 1 : 0, &wb));
+        zk_g1_add(&w, &wb, &w);
+    }
+    *w_out = w;
+    return ZK_OK;
+}
