@@ -67,6 +67,7 @@ int zk_memcpy_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes);
 #define ZK_OP_MUL 0
 #define ZK_OP_ADD 1
 #define ZK_OP_SUB 2
+#define ZK_OP_NEG 3   /* SHE vectors only */
 /* out[i] = a[i] (op) b[i], device buffers of n zk_fr (out may alias a or b).
  * Fp256::{mul,add,sub}_assign: ff/src/fields/arithmetic.rs:7-57, macros.rs:698-717. */
 int zk_fr_vec_op_dev(zk_ctx* ctx, int op, const void* a_dev, const void* b_dev, void* out_dev, size_t n);
@@ -232,6 +233,32 @@ int zk_kzg_commit_dev(zk_ctx* ctx, const zk_bases* powers_g, const void* coeffs_
 int zk_kzg_open_dev(zk_ctx* ctx, const zk_bases* powers_g, const void* coeffs_dev, size_t n, const zk_fr* point,
                     const zk_bases* powers_gamma_g, const void* blind_dev, size_t n_blind,
                     zk_g1_projective* w_out, zk_fr* random_v_out);
+
+/* ---- SHE ring arithmetic of the preprocessing phase (row a15) ----
+ * Elements are ark_mnt4_753::Fq = Fp768 (12 x u64 little-endian, Montgomery R = 2^768), the `Fq` of src/she.rs:17.
+ * An Encodedtext of degree N is N consecutive elements; a Ciphertext is c0 | c1 | c2 (3N elements,
+ * src/she/ciphertext.rs:10-14); batches are contiguous.  N may be any value in 1..2^14: powers of two >= 4 use the
+ * negacyclic NTT, everything else an O(N^2) kernel; results are identical to the reference's
+ * DensePolynomial::mul + poly_remainder2 by X^N + 1. */
+typedef struct { uint64_t l[12]; } zk_fq753;
+/* Texts<Fq> add / sub / neg (src/she/texts.rs:43-127); ZK_OP_MUL is the coefficient-wise product. */
+int zk_she_vec_op_dev(zk_ctx* ctx, int op, const void* a_dev, const void* b_dev, void* out_dev, size_t n);
+/* Encodedtext * Fq, Encodedtext * BigUint (src/she/encodedtext.rs:93-113). */
+int zk_she_vec_scale_dev(zk_ctx* ctx, const void* a_dev, const zk_fq753* k, void* out_dev, size_t n);
+/* Encodedtext * Encodedtext in F_q[X]/(X^N + 1) (src/she/encodedtext.rs:115-134, src/she/polynomial.rs:152-168). */
+int zk_she_negacyclic_mul_dev(zk_ctx* ctx, const void* a_dev, const void* b_dev, void* out_dev, size_t n, size_t batch);
+/* Ciphertext * Ciphertext (src/she/ciphertext.rs:113-122): c0 = x0 y0, c1 = x0 y1 + x1 y0, c2 = -x1 y1. */
+int zk_she_ciphertext_mul_dev(zk_ctx* ctx, const void* x_dev, const void* y_dev, void* out_dev, size_t n, size_t batch);
+/* Ciphertext::encrypt_from (src/she/ciphertext.rs:46-72): e_dev = batch x N, r_dev = batch x (u | v | w), one public key
+ * (a, b), p = the plaintext modulus as an Fq element; out = batch ciphertexts. */
+int zk_she_encrypt_dev(zk_ctx* ctx, const void* e_dev, const void* pk_a_dev, const void* pk_b_dev, const void* r_dev,
+                       const zk_fq753* p, void* out_dev, size_t n, size_t batch);
+/* Ciphertext::decrypt (src/she/ciphertext.rs:74-79): out = c0 - s c1 - s s c2, batch x N. */
+int zk_she_decrypt_dev(zk_ctx* ctx, const void* ct_dev, const void* sk_dev, void* out_dev, size_t n, size_t batch);
+/* Plaintexts::encode (src/she/plaintext.rs:45-59): batch x N Fr slots -> batch x N Fq coefficients (N a power of two). */
+int zk_she_encode_dev(zk_ctx* ctx, const void* plain_fr_dev, void* out_dev, size_t n, size_t batch);
+/* Encodedtext::decode (src/she/encodedtext.rs:24-52): batch x N Fq coefficients -> batch x N Fr slots. */
+int zk_she_decode_dev(zk_ctx* ctx, const void* enc_dev, void* out_fr_dev, size_t n, size_t batch);
 
 /* ---- share algebra on device vectors (rows a11, a13) ------------------------------------- */
 /* out[i] = sum_p gathered[p*n + i] mod r: the receive side of AdditiveFieldShare::batch_open

@@ -893,6 +893,132 @@ def kzg_check(pp, comm, z, value, w, random_v=None):
 
 
 # --------------------------------------------------------------------------------------
+# SHE over MNT4-753 Fq (src/she.rs, src/she/{texts,encodedtext,ciphertext,plaintext,polynomial}.rs)
+# --------------------------------------------------------------------------------------
+
+# arkworks/curves/mnt4_753/src/fields/fq.rs:51
+Q753 = 41898490967918953402344214791240637128170709919953949071783502921025352812571106773058893763790338921418070971888253786114353726529584385201591605722013126468931404347949840543007986327743462853720628051692141265303114721689601
+Q753_R = (1 << 768) % Q753          # fq.rs:73 (Montgomery R of Fp768)
+Q753_GENERATOR = 17                 # fq.rs:105
+Q753_TWO_ADICITY = 15               # fq.rs:14
+
+
+def q753_to_mont(vals):
+    return [(v * Q753_R) % Q753 for v in vals]
+
+
+def q753_from_mont(vals):
+    ri = pow(Q753_R, -1, Q753)
+    return [(v * ri) % Q753 for v in vals]
+
+
+def _poly_mul_mod(a, b, mod):
+    out = [0] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        if x:
+            for j, y in enumerate(b):
+                out[i + j] = (out[i + j] + x * y) % mod
+    return out
+
+
+def encodedtext_mul(a, b):
+    """Encodedtext * Encodedtext (src/she/encodedtext.rs:115-134): dense product, then remainder modulo X^N + 1
+    by long division (poly_remainder2, src/she/polynomial.rs:152-168), padded to N."""
+    n = len(a)
+    assert len(b) == n
+    prod = _poly_mul_mod(a, b, Q753)
+    r = list(prod)
+    for k in range(len(r) - 1, n - 1, -1):       # divide_with_q_and_r by the monic X^n + 1
+        c = r[k]
+        r[k] = 0
+        r[k - n] = (r[k - n] - c) % Q753
+    return (r + [0] * n)[:n]
+
+
+def texts_add(a, b, mod=Q753):
+    return [(x + y) % mod for x, y in zip(a, b)]
+
+
+def texts_sub(a, b, mod=Q753):
+    return [(x - y) % mod for x, y in zip(a, b)]
+
+
+def texts_neg(a, mod=Q753):
+    return [(-x) % mod for x in a]
+
+
+def encodedtext_scale(a, k):
+    return [(x * k) % Q753 for x in a]
+
+
+def ciphertext_mul(x, y):
+    """Ciphertext * Ciphertext (src/she/ciphertext.rs:113-122); x, y = (c0, c1, c2)."""
+    c0 = encodedtext_mul(x[0], y[0])
+    c1 = texts_add(encodedtext_mul(x[0], y[1]), encodedtext_mul(x[1], y[0]))
+    c2 = encodedtext_mul(texts_neg(x[1]), y[1])
+    return (c0, c1, c2)
+
+
+def ciphertext_encrypt_from(e, pk_a, pk_b, r, p=R_MOD):
+    """Ciphertext::encrypt_from (src/she/ciphertext.rs:46-72): r = u | v | w."""
+    n = len(e)
+    u, v, w = r[:n], r[n:2 * n], r[2 * n:3 * n]
+    c0 = texts_add(texts_add(encodedtext_mul(pk_b, v), encodedtext_scale(w, p)), e)
+    c1 = texts_add(encodedtext_mul(pk_a, v), encodedtext_scale(u, p))
+    return (c0, c1, [0] * n)
+
+
+def ciphertext_decrypt(ct, sk):
+    """Ciphertext::decrypt (src/she/ciphertext.rs:74-79)."""
+    sc1 = encodedtext_mul(sk, ct[1])
+    sc2 = encodedtext_mul(encodedtext_mul(sk, sk), ct[2])
+    return texts_sub(texts_sub(ct[0], sc1), sc2)
+
+
+def public_key_gen(sk, a, e, p=R_MOD):
+    """SecretKey::public_key_gen (src/she.rs:73-80) with the randomness passed in: b = a*s + e*p."""
+    return a, texts_add(encodedtext_mul(a, sk), encodedtext_scale(e, p))
+
+
+def cyclotomic_moduli(length):
+    """src/she/polynomial.rs:107-119 over Fr: odd powers of a primitive 2*length-th root of unity."""
+    k = (2 * length - 1).bit_length()       # ark_std::log2 = ceil(log2(2*length))
+    assert k < FR_TWO_ADICITY
+    root = pow(fr_from_mont(limbs_to_int(FR_TWO_ADIC_ROOT_MONT_LIMBS)), 1 << (FR_TWO_ADICITY - k), R_MOD)
+    return [pow(root, 2 * i + 1, R_MOD) for i in range(length)]
+
+
+def plaintexts_encode(vals):
+    """Plaintexts::encode (src/she/plaintext.rs:45-59): Lagrange interpolation through (moduli[i], vals[i]) in Fr
+    (interpolate, src/she/polynomial.rs:21-69), coefficients then embedded into Fq by their canonical integers."""
+    xs = cyclotomic_moduli(len(vals))
+    n = len(xs)
+    res = [0] * n
+    for j in range(n):
+        sca, lp = 1, [1]
+        for k in range(n):
+            if k != j:
+                sca = sca * (xs[j] - xs[k]) % R_MOD
+                lp = _poly_mul_mod(lp, [(-xs[k]) % R_MOD, 1], R_MOD)
+        coef = pow(sca, -1, R_MOD) * vals[j] % R_MOD
+        for i, c in enumerate(lp):
+            res[i] = (res[i] + coef * c) % R_MOD
+    return res
+
+
+def encodedtext_decode(vals, s=None):
+    """Encodedtext::decode (src/she/encodedtext.rs:24-52): centred lift to Fr, evaluate at the cyclotomic roots."""
+    n = len(vals)
+    roots = cyclotomic_moduli(n)
+    lifted = []
+    for bu in vals:
+        if bu > Q753 // 2:
+            bu -= Q753 % R_MOD
+        lifted.append(bu % R_MOD)
+    return [sum(c * pow(x, i, R_MOD) for i, c in enumerate(lifted)) % R_MOD for x in roots[:(s or n)]]
+
+
+# --------------------------------------------------------------------------------------
 # Deterministic test-vector PRNG (SHA-256 counter mode; NOT the reference's ChaCha rng)
 # --------------------------------------------------------------------------------------
 

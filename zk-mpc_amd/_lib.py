@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libzkmpc_hip.so")
 
 ZK_OK = 0
-OP_MUL, OP_ADD, OP_SUB = 0, 1, 2
+OP_MUL, OP_ADD, OP_SUB, OP_NEG = 0, 1, 2, 3
 
 
 class ZkError(RuntimeError):
@@ -25,6 +25,10 @@ class Fr(C.Structure):
 
 class Fq(C.Structure):
     _fields_ = [("l", C.c_uint64 * 6)]
+
+
+class Fq753(C.Structure):
+    _fields_ = [("l", C.c_uint64 * 12)]
 
 
 class G1Affine(C.Structure):
@@ -141,6 +145,14 @@ PROTOTYPES = {
     "zk_poly_mul_dev": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
     "zk_kzg_commit_dev": (_I, [_P, _P, _P, _SZ, _P, _P, _SZ, _P]),
     "zk_kzg_open_dev": (_I, [_P, _P, _P, _SZ, _P, _P, _P, _SZ, _P, _P]),
+    "zk_she_vec_op_dev": (_I, [_P, _I, _P, _P, _P, _SZ]),
+    "zk_she_vec_scale_dev": (_I, [_P, _P, _P, _P, _SZ]),
+    "zk_she_negacyclic_mul_dev": (_I, [_P, _P, _P, _P, _SZ, _SZ]),
+    "zk_she_ciphertext_mul_dev": (_I, [_P, _P, _P, _P, _SZ, _SZ]),
+    "zk_she_encrypt_dev": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ, _SZ]),
+    "zk_she_decrypt_dev": (_I, [_P, _P, _P, _P, _SZ, _SZ]),
+    "zk_she_encode_dev": (_I, [_P, _P, _P, _SZ, _SZ]),
+    "zk_she_decode_dev": (_I, [_P, _P, _P, _SZ, _SZ]),
     "zk_fr_sum_parties_dev": (_I, [_P, _P, _SZ, _SZ, _P]),
     "zk_beaver_combine_dev": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ]),
     "zk_fr_vec_is_zero_dev": (_I, [_P, _P, _SZ, _P]),

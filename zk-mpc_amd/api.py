@@ -223,6 +223,40 @@ class Context:
                                           C.c_void_p(int(blind)) if blind else None, n_blind, _ptr(w), _ptr(rv)))
         return w, rv
 
+    # ---- SHE ring arithmetic (names follow src/she: Texts / Encodedtext / Ciphertext / Plaintexts) ----
+    def _fq753_struct(self, limbs12):
+        f = _lib.Fq753()
+        for i in range(12):
+            f.l[i] = int(limbs12[i])
+        return f
+
+    def she_vec_op_dev(self, op: int, a, b, out, n: int):
+        self._ck(self.lib.zk_she_vec_op_dev(self.h, op, C.c_void_p(int(a)), C.c_void_p(int(b)) if b else None, C.c_void_p(int(out)), n))
+
+    def she_vec_scale_dev(self, a, k12, out, n: int):
+        k = self._fq753_struct(k12)
+        self._ck(self.lib.zk_she_vec_scale_dev(self.h, C.c_void_p(int(a)), C.byref(k), C.c_void_p(int(out)), n))
+
+    def encodedtext_mul_dev(self, a, b, out, n: int, batch: int = 1):
+        self._ck(self.lib.zk_she_negacyclic_mul_dev(self.h, C.c_void_p(int(a)), C.c_void_p(int(b)), C.c_void_p(int(out)), n, batch))
+
+    def ciphertext_mul_dev(self, x, y, out, n: int, batch: int = 1):
+        self._ck(self.lib.zk_she_ciphertext_mul_dev(self.h, C.c_void_p(int(x)), C.c_void_p(int(y)), C.c_void_p(int(out)), n, batch))
+
+    def ciphertext_encrypt_from_dev(self, e, pk_a, pk_b, r, p12, out, n: int, batch: int = 1):
+        p = self._fq753_struct(p12)
+        self._ck(self.lib.zk_she_encrypt_dev(self.h, C.c_void_p(int(e)), C.c_void_p(int(pk_a)), C.c_void_p(int(pk_b)),
+                                             C.c_void_p(int(r)), C.byref(p), C.c_void_p(int(out)), n, batch))
+
+    def ciphertext_decrypt_dev(self, ct, sk, out, n: int, batch: int = 1):
+        self._ck(self.lib.zk_she_decrypt_dev(self.h, C.c_void_p(int(ct)), C.c_void_p(int(sk)), C.c_void_p(int(out)), n, batch))
+
+    def plaintexts_encode_dev(self, plain_fr, out, n: int, batch: int = 1):
+        self._ck(self.lib.zk_she_encode_dev(self.h, C.c_void_p(int(plain_fr)), C.c_void_p(int(out)), n, batch))
+
+    def encodedtext_decode_dev(self, enc, out_fr, n: int, batch: int = 1):
+        self._ck(self.lib.zk_she_decode_dev(self.h, C.c_void_p(int(enc)), C.c_void_p(int(out_fr)), n, batch))
+
     # ---- share algebra ----
     def fr_sum_parties_dev(self, gathered, n_parties: int, n: int, out):
         self._ck(self.lib.zk_fr_sum_parties_dev(self.h, C.c_void_p(int(gathered)), n_parties, n, C.c_void_p(int(out))))

@@ -40,6 +40,21 @@ def fr_from_mont(arr) -> list:
     return [(v * _FR_RINV) % R_MOD for v in _limbs_to_ints(np.asarray(arr).reshape(-1, 4))]
 
 
+# MNT4-753 base field, the SHE ciphertext modulus (arkworks/curves/mnt4_753/src/fields/fq.rs:51); 12 x u64, R = 2^768
+Q753_MOD = 41898490967918953402344214791240637128170709919953949071783502921025352812571106773058893763790338921418070971888253786114353726529584385201591605722013126468931404347949840543007986327743462853720628051692141265303114721689601
+_Q753_R = (1 << 768) % Q753_MOD
+_Q753_RINV = pow(_Q753_R, -1, Q753_MOD)
+
+
+def fq753_to_mont(vals) -> np.ndarray:
+    """canonical ints -> (n,12) uint64 array in Montgomery form (ark_mnt4_753::Fq layout)."""
+    return _ints_to_limbs([(int(v) % Q753_MOD) * _Q753_R % Q753_MOD for v in vals], 12)
+
+
+def fq753_from_mont(arr) -> list:
+    return [(v * _Q753_RINV) % Q753_MOD for v in _limbs_to_ints(np.asarray(arr).reshape(-1, 12))]
+
+
 def fr_raw(vals) -> np.ndarray:
     """ints -> (n,4) uint64, no Montgomery factor (canonical BigInteger256)."""
     return _ints_to_limbs([int(v) for v in vals], 4)
