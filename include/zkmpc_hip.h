@@ -62,6 +62,8 @@ int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** dev_out);
 int zk_dev_free(zk_ctx* ctx, void* dev);
 int zk_memcpy_h2d(zk_ctx* ctx, void* dev, const void* host, size_t bytes);
 int zk_memcpy_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes);
+int zk_memcpy_d2d(zk_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);   /* asynchronous on the context stream */
+int zk_dev_zero(zk_ctx* ctx, void* dev, size_t bytes);
 
 /* ---- Fr vector arithmetic ---------------------------------------- */
 #define ZK_OP_MUL 0
@@ -139,6 +141,8 @@ int zk_fr_mul(const zk_fr* a, const zk_fr* b, zk_fr* out);
 int zk_fq_add(const zk_fq* a, const zk_fq* b, zk_fq* out);
 int zk_fq_sub(const zk_fq* a, const zk_fq* b, zk_fq* out);
 int zk_fq_mul(const zk_fq* a, const zk_fq* b, zk_fq* out);
+int zk_fr_inverse(const zk_fr* a, zk_fr* out);                    /* Field::inverse (macros.rs:389-443); error on zero */
+int zk_fr_pow(const zk_fr* a, uint64_t e, zk_fr* out);           /* Field::pow */
 int zk_fr_from_canonical(const uint64_t canon[4], zk_fr* out);   /* from_repr, macros.rs:464-474 */
 int zk_fr_to_canonical(const zk_fr* a, uint64_t canon[4]);       /* into_repr, arithmetic.rs:59-83 */
 
@@ -233,6 +237,22 @@ int zk_kzg_commit_dev(zk_ctx* ctx, const zk_bases* powers_g, const void* coeffs_
 int zk_kzg_open_dev(zk_ctx* ctx, const zk_bases* powers_g, const void* coeffs_dev, size_t n, const zk_fr* point,
                     const zk_bases* powers_gamma_g, const void* blind_dev, size_t n_blind,
                     zk_g1_projective* w_out, zk_fr* random_v_out);
+
+/* ---- Marlin AHP prover pieces (row a14; marlin/src/ahp/prover.rs) ---- */
+/* out[r] = <row r of matrix which (0=A,1=B,2=C), z> for r < num_constraints, zero up to out_len (prover.rs:258-278). */
+int zk_r1cs_matvec_dev(zk_ctx* ctx, const zk_r1cs* r1cs, int which, const void* z_dev, void* out_dev, size_t out_len);
+/* out[i] = src[idx[i]], or zero where idx[i] == 0xFFFFFFFF (index re-mappings of prover.rs:335-353 and
+ * constraint_systems.rs:183-216); idx_dev is a device array of n u32. */
+int zk_fr_gather_dev(zk_ctx* ctx, const void* src_dev, const uint32_t* idx_dev, size_t n, void* out_dev);
+/* Evaluations of row / col / val (/ row_col) of A*, B*, C* on one domain: device vectors. */
+typedef struct { const void* row; const void* col; const void* val; const void* row_col; } zk_marlin_matrix_evals;
+/* f on K (prover.rs:620-641): f[i] = v_H(alpha) v_H(beta) sum_M eta_M val_M[i] / ((beta - row_M[i]) (alpha - col_M[i])). */
+int zk_marlin_round3_f_evals_dev(zk_ctx* ctx, const zk_marlin_matrix_evals on_k[3], size_t k_size, const zk_fr* alpha,
+                                 const zk_fr* beta, const zk_fr eta[3], const zk_fr* vh_alpha_vh_beta, void* f_out_dev);
+/* a and b on the domain B (prover.rs:653-698). */
+int zk_marlin_round3_ab_evals_dev(zk_ctx* ctx, const zk_marlin_matrix_evals on_b[3], size_t b_size, const zk_fr* alpha,
+                                  const zk_fr* beta, const zk_fr eta[3], const zk_fr* vh_alpha_vh_beta, void* a_out_dev,
+                                  void* b_out_dev);
 
 /* ---- SHE ring arithmetic of the preprocessing phase (row a15) ----
  * Elements are ark_mnt4_753::Fq = Fp768 (12 x u64 little-endian, Montgomery R = 2^768), the `Fq` of src/she.rs:17.

@@ -27,6 +27,10 @@ class Fq(C.Structure):
     _fields_ = [("l", C.c_uint64 * 6)]
 
 
+class MarlinMatrixEvals(C.Structure):
+    _fields_ = [("row", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("row_col", C.c_void_p)]
+
+
 class Fq753(C.Structure):
     _fields_ = [("l", C.c_uint64 * 12)]
 
@@ -145,6 +149,14 @@ PROTOTYPES = {
     "zk_poly_mul_dev": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
     "zk_kzg_commit_dev": (_I, [_P, _P, _P, _SZ, _P, _P, _SZ, _P]),
     "zk_kzg_open_dev": (_I, [_P, _P, _P, _SZ, _P, _P, _P, _SZ, _P, _P]),
+    "zk_memcpy_d2d": (_I, [_P, _P, _P, _SZ]),
+    "zk_dev_zero": (_I, [_P, _P, _SZ]),
+    "zk_fr_inverse": (_I, [_P, _P]),
+    "zk_fr_pow": (_I, [_P, C.c_uint64, _P]),
+    "zk_r1cs_matvec_dev": (_I, [_P, _P, _I, _P, _P, _SZ]),
+    "zk_fr_gather_dev": (_I, [_P, _P, _P, _SZ, _P]),
+    "zk_marlin_round3_f_evals_dev": (_I, [_P, _P, _SZ, _P, _P, _P, _P, _P]),
+    "zk_marlin_round3_ab_evals_dev": (_I, [_P, _P, _SZ, _P, _P, _P, _P, _P, _P]),
     "zk_she_vec_op_dev": (_I, [_P, _I, _P, _P, _P, _SZ]),
     "zk_she_vec_scale_dev": (_I, [_P, _P, _P, _P, _SZ]),
     "zk_she_negacyclic_mul_dev": (_I, [_P, _P, _P, _P, _SZ, _SZ]),

@@ -223,6 +223,51 @@ class Context:
                                           C.c_void_p(int(blind)) if blind else None, n_blind, _ptr(w), _ptr(rv)))
         return w, rv
 
+    # ---- Marlin AHP pieces ----
+    def memcpy_d2d(self, dst, src, nbytes: int):
+        self._ck(self.lib.zk_memcpy_d2d(self.h, C.c_void_p(int(dst)), C.c_void_p(int(src)), nbytes))
+
+    def dev_zero(self, dev, nbytes: int):
+        self._ck(self.lib.zk_dev_zero(self.h, C.c_void_p(int(dev)), nbytes))
+
+    def fr_inverse(self, a4):
+        out = np.zeros(4, dtype=np.uint64)
+        a4 = np.ascontiguousarray(a4, dtype=np.uint64)
+        self._ck(self.lib.zk_fr_inverse(_ptr(a4), _ptr(out)))
+        return out
+
+    def fr_pow(self, a4, e: int):
+        out = np.zeros(4, dtype=np.uint64)
+        a4 = np.ascontiguousarray(a4, dtype=np.uint64)
+        self._ck(self.lib.zk_fr_pow(_ptr(a4), e, _ptr(out)))
+        return out
+
+    def r1cs_matvec_dev(self, r1cs: "R1cs", which: int, z, out, out_len: int):
+        self._ck(self.lib.zk_r1cs_matvec_dev(self.h, r1cs.h, which, C.c_void_p(int(z)), C.c_void_p(int(out)), out_len))
+
+    def fr_gather_dev(self, src, idx, n: int, out):
+        self._ck(self.lib.zk_fr_gather_dev(self.h, C.c_void_p(int(src)), C.c_void_p(int(idx)), n, C.c_void_p(int(out))))
+
+    def _marlin_args(self, mats, alpha4, beta4, etas4, vv4):
+        arr = (_lib.MarlinMatrixEvals * 3)()
+        for i, m in enumerate(mats):
+            arr[i].row, arr[i].col, arr[i].val = int(m["row"]), int(m["col"]), int(m["val"])
+            arr[i].row_col = int(m["row_col"]) if m.get("row_col") else None
+        eta = (_lib.Fr * 3)()
+        for i in range(3):
+            for j in range(4):
+                eta[i].l[j] = int(etas4[i][j])
+        return arr, _fr_struct(alpha4), _fr_struct(beta4), eta, _fr_struct(vv4)
+
+    def marlin_round3_f_evals_dev(self, on_k, k_size: int, alpha4, beta4, etas4, vv4, f_out):
+        arr, a, b, eta, vv = self._marlin_args(on_k, alpha4, beta4, etas4, vv4)
+        self._ck(self.lib.zk_marlin_round3_f_evals_dev(self.h, arr, k_size, C.byref(a), C.byref(b), eta, C.byref(vv), C.c_void_p(int(f_out))))
+
+    def marlin_round3_ab_evals_dev(self, on_b, b_size: int, alpha4, beta4, etas4, vv4, a_out, b_out):
+        arr, a, b, eta, vv = self._marlin_args(on_b, alpha4, beta4, etas4, vv4)
+        self._ck(self.lib.zk_marlin_round3_ab_evals_dev(self.h, arr, b_size, C.byref(a), C.byref(b), eta, C.byref(vv),
+                                                        C.c_void_p(int(a_out)), C.c_void_p(int(b_out))))
+
     # ---- SHE ring arithmetic (names follow src/she: Texts / Encodedtext / Ciphertext / Plaintexts) ----
     def _fq753_struct(self, limbs12):
         f = _lib.Fq753()

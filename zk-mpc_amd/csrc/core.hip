@@ -79,6 +79,18 @@ extern "C" int zk_memcpy_d2h(zk_ctx* ctx, void* host, const void* dev, size_t by
     return ZK_OK;
 }
 
+extern "C" int zk_memcpy_d2d(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return ZK_ERR_ARG;
+    if (bytes) ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return ZK_OK;
+}
+
+extern "C" int zk_dev_zero(zk_ctx* ctx, void* dev, size_t bytes) {
+    if (!ctx || (bytes && !dev)) return ZK_ERR_ARG;
+    if (bytes) ZK_HIP(ctx, hipMemsetAsync(dev, 0, bytes, ctx->stream));
+    return ZK_OK;
+}
+
 int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out) {
     auto& s = ctx->slots[name];
     if (s.bytes < bytes) {

@@ -106,6 +106,22 @@ int spmv(zk_ctx* ctx, const zk_r1cs* r, int which, const void* z, size_t n_copy,
     return ZK_OK;
 }
 
+}  // namespace
+
+// out[r] = <row r of matrix `which`, z> for r < num_constraints, zero up to out_len (inner_prod_fn of the Marlin prover,
+// marlin/src/ahp/prover.rs:258-278; the same product as evaluate_constraint, src/groth16.rs:205-234).
+extern "C" int zk_r1cs_matvec_dev(zk_ctx* ctx, const zk_r1cs* r, int which, const void* z_dev, void* out_dev, size_t out_len) {
+    if (!ctx || !r || !z_dev || !out_dev || which < 0 || which > 2) return ZK_ERR_ARG;
+    if (out_len < r->nc) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_r1cs_matvec_dev: out_len is smaller than the number of constraints");
+    const auto& m = r->m[which];
+    hipLaunchKernelGGL(k_spmv, zk_grid(out_len, 256), 256, 0, ctx->stream, m.row_ptr, m.col, m.coeff, m.all_one ? 1 : 0, z_dev, r->nc,
+                       (size_t)0, out_len, out_dev);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
+namespace {
+
 Fr host_fr_from_u64(uint64_t v) {
     Fr t = fp_zero<FrParams>();
     t.l[0] = (uint32_t)(v & MASK29);

@@ -94,6 +94,23 @@ extern "C" int zk_fr_mul(const zk_fr* a, const zk_fr* b, zk_fr* out) {
     host_store_ext<FrParams>(out->l, fp_mul<FrParams>(t, fp_const<FrParams>(FrParams::EXT_TO_INT)));
     return ZK_OK;
 }
+extern "C" int zk_fr_inverse(const zk_fr* a, zk_fr* out) {   // Field::inverse; zero has no inverse (macros.rs:389-443)
+    if (!a || !out) return ZK_ERR_ARG;
+    Fr x = fp_ext_to_int<FrParams>(host_load_ext<FrParams>(a->l));
+    if (fp_is_zero<FrParams>(x)) return ZK_ERR_ARG;
+    host_store_ext<FrParams>(out->l, fp_int_to_ext<FrParams>(fp_inv<FrParams>(x)));
+    return ZK_OK;
+}
+extern "C" int zk_fr_pow(const zk_fr* a, uint64_t e, zk_fr* out) {   // Field::pow for a 64-bit exponent
+    if (!a || !out) return ZK_ERR_ARG;
+    Fr x = fp_ext_to_int<FrParams>(host_load_ext<FrParams>(a->l)), r = fp_one<FrParams>();
+    for (int b = 63; b >= 0; b--) {
+        r = fp_sqr<FrParams>(r);
+        if ((e >> b) & 1) r = fp_mul<FrParams>(r, x);
+    }
+    host_store_ext<FrParams>(out->l, fp_int_to_ext<FrParams>(r));
+    return ZK_OK;
+}
 extern "C" int zk_fr_from_canonical(const uint64_t canon[4], zk_fr* out) {
     if (!canon || !out) return ZK_ERR_ARG;
     host_store_ext<FrParams>(out->l, fp_canon_to_ext<FrParams>(host_load_ext<FrParams>(canon)));

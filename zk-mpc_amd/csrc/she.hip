@@ -35,6 +35,7 @@ using F7 = Fp<Fq753Params>;
 constexpr int L7 = 26;
 constexpr int TILE = 1024;
 constexpr int LOG_TILE = 10;
+constexpr int TILE_THREADS = 512;   // 2 waves per SIMD next to the 104 KiB tile (one workgroup per CU)
 constexpr uint32_t SHE_MAX_LOG = FQ753_TWO_ADICITY - 1;  // 2N <= 2^15
 
 __device__ __forceinline__ F7 f7_load(const void* base, size_t i) {
@@ -97,13 +98,13 @@ __global__ void __launch_bounds__(64) k_she_tables(uint32_t* psi, uint32_t* psi_
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     F7 w = fp_const<Fq753Params>(Fq753Params::TWO_ADIC_ROOT), wi = fp_const<Fq753Params>(Fq753Params::TWO_ADIC_ROOT_INV);
-    for (uint32_t i = 0; i < SHE_MAX_LOG - log_n; i++) { w = fp_sqr<Fq753Params>(w); wi = fp_sqr<Fq753Params>(wi); }
+    for (uint32_t i = 0; i < SHE_MAX_LOG - log_n; i++) { w = f7_mul(w, w); wi = f7_mul(wi, wi); }
     uint32_t e = log_n ? (__brev(k) >> (32 - log_n)) : 0;
     F7 a = fp_one<Fq753Params>(), b = a;
     for (uint32_t bit = 0; bit < log_n; bit++) {
         if ((e >> bit) & 1) { a = f7_mul(a, w); b = f7_mul(b, wi); }
-        w = fp_sqr<Fq753Params>(w);
-        wi = fp_sqr<Fq753Params>(wi);
+        w = f7_mul(w, w);
+        wi = f7_mul(wi, wi);
     }
     tab_store(psi, n, k, a);
     tab_store(psi_inv, n, k, b);
@@ -147,12 +148,12 @@ __global__ void __launch_bounds__(256) k_she_fwd_global(void* data, const uint32
 // Forward LDS pass: levels t = min(n, TILE)/2 ... 1 on one tile.  FIRST: read through the row map (n <= TILE), else
 // read dst in place (the global levels already copied).
 template <bool FIRST>
-__global__ void __launch_bounds__(256) k_she_fwd_tile(RowMap src, void* dst, const uint32_t* psi, uint32_t log_n,
+__global__ void __launch_bounds__(TILE_THREADS) k_she_fwd_tile(RowMap src, void* dst, const uint32_t* psi, uint32_t log_n,
                                                       uint64_t n_elems) {
     extern __shared__ uint32_t lds[];
     uint32_t n = 1u << log_n;
     uint64_t e0 = (uint64_t)blockIdx.x * TILE;
-    for (uint32_t l = threadIdx.x; l < TILE; l += 256) {
+    for (uint32_t l = threadIdx.x; l < TILE; l += TILE_THREADS) {
         uint64_t e = e0 + l;
         if (e < n_elems) {
             F7 v = FIRST ? f7_load(src.base, row_elem(src, n, e >> log_n, (uint32_t)(e & (n - 1)))) : f7_load(dst, e);
@@ -163,7 +164,7 @@ __global__ void __launch_bounds__(256) k_she_fwd_tile(RowMap src, void* dst, con
     int top = (int)(log_n < LOG_TILE ? log_n : LOG_TILE) - 1;
     for (int log_t = top; log_t >= 0; log_t--) {
         uint32_t t = 1u << log_t, m = n >> (log_t + 1);
-        for (uint32_t lb = threadIdx.x; lb < TILE / 2; lb += 256) {
+        for (uint32_t lb = threadIdx.x; lb < TILE / 2; lb += TILE_THREADS) {
             uint64_t g = (e0 >> 1) + lb;                     // butterfly index over the whole batch
             if (2 * g >= n_elems) continue;
             uint64_t row = log_n ? (g >> (log_n - 1)) : g;
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(256) k_she_fwd_tile(RowMap src, void* dst, con
         }
         __syncthreads();
     }
-    for (uint32_t l = threadIdx.x; l < TILE; l += 256) {
+    for (uint32_t l = threadIdx.x; l < TILE; l += TILE_THREADS) {
         uint64_t e = e0 + l;
         if (e < n_elems) f7_store(dst, e, lds_get(lds, l));
     }
@@ -193,12 +194,12 @@ struct InvArgs {
     int negate;
 };
 template <bool LAST>
-__global__ void __launch_bounds__(256) k_she_inv_tile(InvArgs a, const uint32_t* psi_inv, const uint32_t* scale,
+__global__ void __launch_bounds__(TILE_THREADS) k_she_inv_tile(InvArgs a, const uint32_t* psi_inv, const uint32_t* scale,
                                                       uint32_t log_n, uint64_t n_elems) {
     extern __shared__ uint32_t lds[];
     uint32_t n = 1u << log_n;
     uint64_t e0 = (uint64_t)blockIdx.x * TILE;
-    for (uint32_t l = threadIdx.x; l < TILE; l += 256) {
+    for (uint32_t l = threadIdx.x; l < TILE; l += TILE_THREADS) {
         uint64_t e = e0 + l;
         if (e < n_elems) {
             uint64_t row = e >> log_n;
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(256) k_she_inv_tile(InvArgs a, const uint32_t*
     int top = (int)(log_n < LOG_TILE ? log_n : LOG_TILE);
     for (int log_t = 0; log_t < top; log_t++) {
         uint32_t t = 1u << log_t, h = n >> (log_t + 1);
-        for (uint32_t lb = threadIdx.x; lb < TILE / 2; lb += 256) {
+        for (uint32_t lb = threadIdx.x; lb < TILE / 2; lb += TILE_THREADS) {
             uint64_t g = (e0 >> 1) + lb;
             if (2 * g >= n_elems) continue;
             uint64_t row = log_n ? (g >> (log_n - 1)) : g;
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(256) k_she_inv_tile(InvArgs a, const uint32_t*
 #pragma unroll
         for (int k = 0; k < L7; k++) sc.l[k] = scale[k];
     }
-    for (uint32_t l = threadIdx.x; l < TILE; l += 256) {
+    for (uint32_t l = threadIdx.x; l < TILE; l += TILE_THREADS) {
         uint64_t e = e0 + l;
         if (e >= n_elems) continue;
         F7 v = lds_get(lds, l);
@@ -447,13 +448,13 @@ int she_forward(zk_ctx* ctx, const SheTables& tb, RowMap src, void* dst, uint32_
     unsigned tiles = (unsigned)((n_elems + TILE - 1) / TILE);
     ZK_TRY(she_lds_attr(ctx));
     if (log_n <= LOG_TILE) {
-        hipLaunchKernelGGL(k_she_fwd_tile<true>, tiles, 256, LDS_BYTES, ctx->stream, src, dst, tb.psi, log_n, n_elems);
+        hipLaunchKernelGGL(k_she_fwd_tile<true>, tiles, TILE_THREADS, LDS_BYTES, ctx->stream, src, dst, tb.psi, log_n, n_elems);
     } else {
         hipLaunchKernelGGL(k_she_gather, zk_grid(n_elems, 256), 256, 0, ctx->stream, src, dst, n, n_elems);
         for (int log_t = (int)log_n - 1; log_t >= LOG_TILE; log_t--)
             hipLaunchKernelGGL(k_she_fwd_global, zk_grid(n_elems / 2, 256), 256, 0, ctx->stream, dst, tb.psi, log_n, (uint32_t)log_t,
                                n_elems / 2);
-        hipLaunchKernelGGL(k_she_fwd_tile<false>, tiles, 256, LDS_BYTES, ctx->stream, src, dst, tb.psi, log_n, n_elems);
+        hipLaunchKernelGGL(k_she_fwd_tile<false>, tiles, TILE_THREADS, LDS_BYTES, ctx->stream, src, dst, tb.psi, log_n, n_elems);
     }
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
@@ -466,10 +467,10 @@ int she_inverse(zk_ctx* ctx, const SheTables& tb, InvArgs a, uint32_t log_n, uin
     unsigned tiles = (unsigned)((n_elems + TILE - 1) / TILE);
     ZK_TRY(she_lds_attr(ctx));
     if (log_n <= LOG_TILE) {
-        hipLaunchKernelGGL(k_she_inv_tile<true>, tiles, 256, LDS_BYTES, ctx->stream, a, tb.psi_inv, tb.scale, log_n, n_elems);
+        hipLaunchKernelGGL(k_she_inv_tile<true>, tiles, TILE_THREADS, LDS_BYTES, ctx->stream, a, tb.psi_inv, tb.scale, log_n, n_elems);
     } else {
         ZK_TRY(zk_scratch(ctx, "she_inv_work", n_elems * 96, &a.work));
-        hipLaunchKernelGGL(k_she_inv_tile<false>, tiles, 256, LDS_BYTES, ctx->stream, a, tb.psi_inv, tb.scale, log_n, n_elems);
+        hipLaunchKernelGGL(k_she_inv_tile<false>, tiles, TILE_THREADS, LDS_BYTES, ctx->stream, a, tb.psi_inv, tb.scale, log_n, n_elems);
         for (uint32_t log_t = LOG_TILE; log_t < log_n; log_t++) {
             if (log_t + 1 == log_n)
                 hipLaunchKernelGGL(k_she_inv_global<true>, zk_grid(n_elems / 2, 256), 256, 0, ctx->stream, a.work, a.out, tb.psi_inv,

@@ -1,0 +1,426 @@
+"""Marlin AHP prover on the GPU: host-side orchestration of the device kernels, mirroring the reference's
+AHPForR1CS::{index, prover_init, prover_first_round, prover_second_round, prover_third_round}
+(arkworks/marlin/src/ahp/{indexer.rs:121-208, constraint_systems.rs:152-264, prover.rs:216-716}) and the KZG10
+commit / open calls of Marlin::prove (arkworks/marlin/src/lib.rs:152-319).
+
+Every polynomial lives in device memory (coefficients, low degree first, the reference's Fr layout).  This module only
+sequences C-ABI calls and builds integer index arrays (numpy); scalar field operations on the verifier's challenges go
+through the library's host helpers (zk_fr_*).  The Fiat-Shamir transcript stays with the caller, as it does on the
+Rust side of the boundary: challenges are arguments.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from . import convert as cv
+from .api import Context, DevBuf
+
+R_MOD = cv.R_MOD
+SENTINEL = np.uint32(0xFFFFFFFF)
+
+
+def _log2(n: int) -> int:
+    return max(n - 1, 0).bit_length()
+
+
+def _next_pow2(n: int) -> int:
+    return 1 << _log2(n)
+
+
+class DevPoly:
+    """n coefficients in a device buffer."""
+
+    def __init__(self, buf: DevBuf, n: int, offset: int = 0):
+        self.buf, self.n, self.offset = buf, n, offset
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.ptr + 32 * self.offset
+
+    def slice(self, start: int, n: int) -> "DevPoly":
+        return DevPoly(self.buf, n, self.offset + start)
+
+
+class HostField:
+    """Scalar Fr arithmetic through the library's host entry points; values are canonical Python ints."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    @staticmethod
+    def m(v: int):
+        return cv.fr_to_mont([v % R_MOD])[0]
+
+    @staticmethod
+    def i(limbs4) -> int:
+        return cv.fr_from_mont(np.asarray(limbs4).reshape(1, 4))[0]
+
+    def mul(self, a, b): return self.i(self.ctx.fr_op("mul", self.m(a), self.m(b)))
+    def add(self, a, b): return self.i(self.ctx.fr_op("add", self.m(a), self.m(b)))
+    def sub(self, a, b): return self.i(self.ctx.fr_op("sub", self.m(a), self.m(b)))
+    def pow(self, a, e): return self.i(self.ctx.fr_pow(self.m(a), e))
+    def inv(self, a): return self.i(self.ctx.fr_inverse(self.m(a)))
+
+
+# arkworks/curves/bls12_377/src/fields/fr.rs:34-41 (TWO_ADIC_ROOT_OF_UNITY, Montgomery limbs) and :28 (TWO_ADICITY)
+_FR_TWO_ADICITY = 47
+_FR_TWO_ADIC_ROOT_MONT = np.array([12646347781564978760, 6783048705277173164, 268534165941069093, 1121515446318641358], dtype=np.uint64)
+
+
+def reindex_by_subdomain(size_self: int, size_other: int, index: np.ndarray) -> np.ndarray:
+    """EvaluationDomain::reindex_by_subdomain (poly/src/domain/mod.rs:195-217), vectorised."""
+    index = np.asarray(index, dtype=np.int64)
+    period = size_self // size_other
+    i = index - size_other
+    x = max(period - 1, 1)
+    return np.where(index < size_other, index * period, i + i // x + 1)
+
+
+class Csr:
+    """A constraint matrix as (row_ptr, col, coeff) with coeff in the reference's Montgomery limbs."""
+
+    def __init__(self, row_ptr, col, coeff):
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+        self.col = np.ascontiguousarray(col, dtype=np.uint32)
+        self.coeff = np.ascontiguousarray(coeff, dtype=np.uint64).reshape(-1, 4)
+
+    @staticmethod
+    def from_rows(rows) -> "Csr":
+        rp, col, co = [0], [], []
+        for row in rows:
+            for c, i in row:
+                col.append(i)
+                co.append(c)
+            rp.append(len(col))
+        return Csr(rp, col, cv.fr_to_mont(co) if co else np.zeros((0, 4), dtype=np.uint64))
+
+    @property
+    def nnz(self) -> int:
+        return int(self.row_ptr[-1])
+
+    def row_of_entry(self) -> np.ndarray:
+        return np.repeat(np.arange(len(self.row_ptr) - 1, dtype=np.int64), np.diff(self.row_ptr.astype(np.int64)))
+
+    def sorted_by_column(self) -> "Csr":
+        """Rows in ascending column order (constraint_systems.rs:188-190)."""
+        rows = self.row_of_entry()
+        order = np.lexsort((self.col, rows))
+        return Csr(self.row_ptr, self.col[order], self.coeff[order])
+
+    def tuple(self):
+        return (self.row_ptr, self.col, self.coeff)
+
+
+def balance_matrices(a: Csr, b: Csr):
+    """constraint_systems.rs:23-40: walk the rows, moving the denser matrix's row to the other one."""
+    la, lb = np.diff(a.row_ptr.astype(np.int64)), np.diff(b.row_ptr.astype(np.int64))
+    a_density, b_density = int(la.sum()), int(lb.sum())
+    a_is_denser = a_density == max(a_density, b_density)
+    swap = np.zeros(len(la), dtype=bool)
+    for k in range(len(la)):
+        if a_is_denser:
+            swap[k] = True
+            a_density += int(lb[k]) - int(la[k])
+            b_density += int(la[k]) - int(lb[k])
+            a_is_denser = a_density == max(a_density, b_density)
+
+    def pick(first: Csr, second: Csr, take_second):
+        ra, rb = first.row_of_entry(), second.row_of_entry()
+        keep_a, keep_b = ~take_second[ra], take_second[rb]
+        rows = np.concatenate([ra[keep_a], rb[keep_b]])
+        col = np.concatenate([first.col[keep_a], second.col[keep_b]])
+        coeff = np.concatenate([first.coeff[keep_a], second.coeff[keep_b]])
+        order = np.argsort(rows, kind="stable")
+        rp = np.zeros(len(take_second) + 1, dtype=np.int64)
+        np.add.at(rp, rows + 1, 1)
+        return Csr(np.cumsum(rp), col[order], coeff[order])
+    return pick(a, b, swap), pick(b, a, swap)
+
+
+class Domain:
+    """Radix-2 evaluation domain handle: size, generator, and device helpers."""
+
+    def __init__(self, ctx: Context, num_coeffs: int):
+        self.ctx = ctx
+        self.size = _next_pow2(num_coeffs)
+        self.log = _log2(self.size)
+        self.F = HostField(ctx)
+        self.group_gen4 = ctx.fr_pow(_FR_TWO_ADIC_ROOT_MONT, 1 << (_FR_TWO_ADICITY - self.log))
+        self._elems = None
+
+    def elements(self) -> DevBuf:
+        if self._elems is None:
+            self._elems = self.ctx.alloc(self.size * 32)
+            self.ctx.fr_powers_dev(self.group_gen4, HostField.m(1), self.size, self._elems.ptr)
+        return self._elems
+
+    def evaluate_vanishing_polynomial(self, tau: int) -> int:
+        return self.F.sub(self.F.pow(tau, self.size), 1)
+
+    def fft(self, ctx, poly: DevPoly) -> DevBuf:
+        """evaluate_over_domain: zero-pad the coefficients to the domain size, forward transform."""
+        assert poly.n <= self.size
+        out = ctx.alloc(self.size * 32)
+        if poly.n < self.size:
+            ctx.dev_zero(out.ptr + 32 * poly.n, (self.size - poly.n) * 32)
+        ctx.memcpy_d2d(out.ptr, poly.ptr, poly.n * 32)
+        ctx.ntt_dev(out.ptr, self.log, False, False)
+        return out
+
+    def ifft_in_place(self, ctx, evals: DevBuf) -> DevPoly:
+        ctx.ntt_dev(evals.ptr, self.log, True, False)
+        return DevPoly(evals, self.size)
+
+
+class MatrixArithmetization:
+    """constraint_systems.rs:126-264 for one matrix, on the device."""
+
+    def __init__(self, ctx: Context, m: Csr, dom_k: Domain, dom_h: Domain, dom_x: Domain, dom_b: Domain):
+        m = m.sorted_by_column()
+        nnz, K, n = m.nnz, dom_k.size, dom_h.size
+        rows = m.row_of_entry()
+        cols = reindex_by_subdomain(n, dom_x.size, m.col)
+        pad = K - nnz
+        idx_row = np.concatenate([cols, np.zeros(pad, dtype=np.int64)]).astype(np.uint32)       # transposed: row <- column
+        idx_col = np.concatenate([rows, np.zeros(pad, dtype=np.int64)]).astype(np.uint32)
+        # u_H(x, x) at x = w^j is |H| w^-j (mod.rs:362-369); its inverse is w^j / |H|
+        idx_eq = np.concatenate([cols, np.full(pad, int(SENTINEL), dtype=np.int64)]).astype(np.uint32)
+        elems = dom_h.elements()
+        d_row, d_col, d_val, d_rc = (ctx.alloc(K * 32) for _ in range(4))
+        i_row, i_col, i_eq = ctx.upload(idx_row), ctx.upload(idx_col), ctx.upload(idx_eq)
+        ctx.fr_gather_dev(elems.ptr, i_row.ptr, K, d_row.ptr)
+        ctx.fr_gather_dev(elems.ptr, i_col.ptr, K, d_col.ptr)
+        ctx.fr_gather_dev(elems.ptr, i_eq.ptr, K, d_val.ptr)
+        n_inv = dom_h.F.inv(n)
+        ctx.fr_vec_scale_dev(d_val.ptr, HostField.m(n_inv), d_val.ptr, K)
+        coeff = np.zeros((K, 4), dtype=np.uint64)
+        coeff[:nnz] = m.coeff
+        d_coeff = ctx.upload(coeff)
+        ctx.fr_vec_op_dev(_lib.OP_MUL, d_val.ptr, d_coeff.ptr, d_val.ptr, K)
+        ctx.fr_vec_op_dev(_lib.OP_MUL, d_row.ptr, d_col.ptr, d_rc.ptr, K)
+        self.evals_on_K = {"row": d_row, "col": d_col, "val": d_val}
+        polys = {}
+        for name, ev in (("row", d_row), ("col", d_col), ("val", d_val), ("row_col", d_rc)):
+            c = ctx.alloc(K * 32)
+            ctx.memcpy_d2d(c.ptr, ev.ptr, K * 32)
+            polys[name] = dom_k.ifft_in_place(ctx, c)
+        self.row, self.col, self.val, self.row_col = polys["row"], polys["col"], polys["val"], polys["row_col"]
+        self.evals_on_B = {name: dom_b.fft(ctx, p) for name, p in polys.items()}
+        ctx.sync()      # the index arrays above may be released now
+
+
+class Index:
+    """AHPForR1CS::index on an already padded, square constraint system (indexer.rs:121-208)."""
+
+    def __init__(self, ctx: Context, num_instance: int, num_witness: int, a: Csr, b: Csr, c: Csr):
+        nc = len(a.row_ptr) - 1
+        if num_instance + num_witness != nc:
+            raise ValueError("NonSquareMatrix")
+        if num_instance & (num_instance - 1):
+            raise ValueError("InvalidPublicInputLength")
+        self.ctx = ctx
+        self.num_constraints = self.num_variables = nc
+        self.num_instance, self.num_witness = num_instance, num_witness
+        self.num_non_zero = max(a.nnz, b.nnz, c.nnz)
+        a, b = balance_matrices(a, b)
+        self.a, self.b, self.c = a, b, c
+        self.dom_h, self.dom_k = Domain(ctx, nc), Domain(ctx, self.num_non_zero)
+        self.dom_x, self.dom_b = Domain(ctx, num_instance), Domain(ctx, 3 * _next_pow2(self.num_non_zero) - 3)
+        self.arith = {n: MatrixArithmetization(ctx, m, self.dom_k, self.dom_h, self.dom_x, self.dom_b)
+                      for n, m in (("a", a), ("b", b), ("c", c))}
+        self.r1cs = ctx.r1cs_upload(num_instance, num_witness, a.tuple(), b.tuple(), c.tuple())
+        # transposed matrices with rows re-indexed into H, for calculate_t (prover.rs:406-423)
+        H = self.dom_h.size
+        tr = []
+        for m in (a, b, c):
+            rows_t = reindex_by_subdomain(H, self.dom_x.size, m.col)
+            order = np.argsort(rows_t, kind="stable")
+            rp = np.zeros(H + 1, dtype=np.int64)
+            np.add.at(rp, rows_t + 1, 1)
+            tr.append((np.cumsum(rp).astype(np.uint32), m.row_of_entry()[order].astype(np.uint32), m.coeff[order]))
+        self.r1cs_t = ctx.r1cs_upload(1, H - 1, *tr)
+
+    def polynomials(self):
+        out = {}
+        for m in "abc":
+            ar = self.arith[m]
+            out[m + "_row"], out[m + "_col"], out[m + "_val"], out[m + "_row_col"] = ar.row, ar.col, ar.val, ar.row_col
+        return out
+
+
+class ProverState:
+    pass
+
+
+def prover_init(index: Index, assignment_dev: DevBuf) -> ProverState:
+    """prover.rs:216-309: z_A = A z, z_B = B z.  assignment_dev: the full (padded) assignment, instance first."""
+    ctx, H = index.ctx, index.dom_h.size
+    st = ProverState()
+    st.index, st.z = index, assignment_dev
+    st.z_a, st.z_b = ctx.alloc(H * 32), ctx.alloc(H * 32)
+    ctx.r1cs_matvec_dev(index.r1cs, 0, assignment_dev.ptr, st.z_a.ptr, H)
+    ctx.r1cs_matvec_dev(index.r1cs, 1, assignment_dev.ptr, st.z_b.ptr, H)
+    st.zk_bound = 1
+    return st
+
+
+def mask_poly_degree(index: Index) -> int:
+    return 3 * index.dom_h.size + 2 * 1 - 3
+
+
+def _blind_with_vanishing(ctx, poly: DevPoly, n: int, r_dev: int) -> DevPoly:
+    """p + r (X^n - 1) for deg p < n: one more coefficient."""
+    out = ctx.alloc((n + 1) * 32)
+    ctx.memcpy_d2d(out.ptr, poly.ptr, n * 32)
+    ctx.memcpy_d2d(out.ptr + 32 * n, r_dev, 32)
+    ctx.fr_vec_op_dev(_lib.OP_SUB, out.ptr, r_dev, out.ptr, 1)
+    return DevPoly(out, n + 1)
+
+
+def prover_first_round(st: ProverState, randomness_mont: np.ndarray):
+    """prover.rs:311-404.  randomness_mont: 3 + mask_poly_degree + 1 field elements (Montgomery limbs) in the order the
+    reference draws them: w, z_a, z_b blinders, then the mask polynomial's coefficients."""
+    ix = st.index
+    ctx, H, X = ix.ctx, ix.dom_h, ix.dom_x
+    n = H.size
+    md = mask_poly_degree(ix)
+    assert randomness_mont.shape == (3 + md + 1, 4)
+    rnd = ctx.upload(randomness_mont)
+    # x(X): interpolation of the formatted input over X, then its evaluations over H
+    xb = ctx.alloc(X.size * 32)
+    ctx.memcpy_d2d(xb.ptr, st.z.ptr, X.size * 32)
+    st.x_poly = X.ifft_in_place(ctx, xb)
+    x_evals = H.fft(ctx, st.x_poly)
+    ratio = n // X.size
+    k = np.arange(n, dtype=np.int64)
+    wi = k - k // ratio - 1
+    on_x = (k % ratio) == 0
+    idx_w = np.where(on_x | (wi >= ix.num_witness), int(SENTINEL), wi + ix.num_instance).astype(np.uint32)
+    idx_x = np.where(on_x, int(SENTINEL), k).astype(np.uint32)
+    d_iw, d_ix = ctx.upload(idx_w), ctx.upload(idx_x)
+    w_evals, tmp = ctx.alloc(n * 32), ctx.alloc(n * 32)
+    ctx.fr_gather_dev(st.z.ptr, d_iw.ptr, n, w_evals.ptr)
+    ctx.fr_gather_dev(x_evals.ptr, d_ix.ptr, n, tmp.ptr)
+    ctx.fr_vec_op_dev(_lib.OP_SUB, w_evals.ptr, tmp.ptr, w_evals.ptr, n)
+    w_h = _blind_with_vanishing(ctx, H.ifft_in_place(ctx, w_evals), n, rnd.ptr)
+    wq, wr = ctx.alloc(max(n + 1 - X.size, 1) * 32), ctx.alloc(X.size * 32)
+    ctx.poly_divide_by_vanishing_dev(w_h.ptr, n + 1, X.log, wq.ptr, wr.ptr)
+    if not ctx.fr_vec_is_zero_dev(wr.ptr, X.size):
+        raise ValueError("w polynomial is not divisible by v_X")      # assert!(remainder.is_zero()), prover.rs:360
+    st.w_poly = DevPoly(wq, n + 1 - X.size)
+    za, zb = ctx.alloc(n * 32), ctx.alloc(n * 32)
+    ctx.memcpy_d2d(za.ptr, st.z_a.ptr, n * 32)
+    ctx.memcpy_d2d(zb.ptr, st.z_b.ptr, n * 32)
+    st.z_a_poly = _blind_with_vanishing(ctx, H.ifft_in_place(ctx, za), n, rnd.ptr + 32)
+    st.z_b_poly = _blind_with_vanishing(ctx, H.ifft_in_place(ctx, zb), n, rnd.ptr + 64)
+    mask = ctx.alloc((md + 1) * 32)
+    ctx.memcpy_d2d(mask.ptr, rnd.ptr + 96, (md + 1) * 32)
+    mq, mr = ctx.alloc((md + 1) * 32), ctx.alloc(n * 32)
+    ctx.poly_divide_by_vanishing_dev(mask.ptr, md + 1, H.log, mq.ptr, mr.ptr)
+    ctx.fr_vec_op_dev(_lib.OP_SUB, mask.ptr, mr.ptr, mask.ptr, 1)     # mask[0] -= remainder[0]: sum over H becomes zero
+    st.mask_poly = DevPoly(mask, md + 1)
+    ctx.sync()
+    return {"w": st.w_poly, "z_a": st.z_a_poly, "z_b": st.z_b_poly, "mask_poly": st.mask_poly}
+
+
+def prover_second_round(st: ProverState, alpha: int, eta_a: int, eta_b: int, eta_c: int):
+    """prover.rs:438-565."""
+    ix = st.index
+    ctx, H, X, F = ix.ctx, ix.dom_h, ix.dom_x, ix.dom_h.F
+    n = H.size
+    m = HostField.m
+    # summed_z_m = eta_c z_a z_b + eta_a z_a + eta_b z_b
+    zc = ctx.alloc((2 * n + 1) * 32)
+    ctx.poly_mul_dev(st.z_a_poly.ptr, n + 1, st.z_b_poly.ptr, n + 1, zc.ptr)
+    ctx.fr_vec_scale_dev(zc.ptr, m(eta_c), zc.ptr, 2 * n + 1)
+    tmp = ctx.alloc((n + 1) * 32)
+    ctx.fr_vec_scale_dev(st.z_a_poly.ptr, m(eta_a), tmp.ptr, n + 1)
+    ctx.fr_vec_op_dev(_lib.OP_ADD, zc.ptr, tmp.ptr, zc.ptr, n + 1)
+    ctx.fr_vec_scale_dev(st.z_b_poly.ptr, m(eta_b), tmp.ptr, n + 1)
+    ctx.fr_vec_op_dev(_lib.OP_ADD, zc.ptr, tmp.ptr, zc.ptr, n + 1)
+    summed = DevPoly(zc, 2 * n + 1)
+    # r(alpha, X) on H: v_H(alpha) / (alpha - h)   (mod.rs:352-360)
+    v_h_alpha = H.evaluate_vanishing_polynomial(alpha)
+    ra = ctx.alloc(n * 32)
+    ctx.fr_powers_dev(m(1), m(alpha), n, ra.ptr)                       # the constant vector alpha
+    ctx.fr_vec_op_dev(_lib.OP_SUB, ra.ptr, H.elements().ptr, ra.ptr, n)
+    ctx.batch_inversion_dev(ra.ptr, n)
+    ctx.fr_vec_scale_dev(ra.ptr, m(v_h_alpha), ra.ptr, n)
+    # t = sum_M eta_M M^T r  (calculate_t), interpolated over H
+    t_ev, t_tmp = ctx.alloc(n * 32), ctx.alloc(n * 32)
+    for which, eta in enumerate((eta_a, eta_b, eta_c)):
+        ctx.r1cs_matvec_dev(ix.r1cs_t, which, ra.ptr, t_tmp.ptr, n)
+        if which == 0:
+            ctx.fr_vec_scale_dev(t_tmp.ptr, m(eta), t_ev.ptr, n)
+        else:
+            ctx.fr_vec_scale_dev(t_tmp.ptr, m(eta), t_tmp.ptr, n)
+            ctx.fr_vec_op_dev(_lib.OP_ADD, t_ev.ptr, t_tmp.ptr, t_ev.ptr, n)
+    st.t_poly = H.ifft_in_place(ctx, t_ev)
+    r_alpha_poly = H.ifft_in_place(ctx, ra)
+    # z = w v_X + x
+    zp = ctx.alloc((n + 1) * 32)
+    nw = st.w_poly.n
+    ctx.dev_zero(zp.ptr, (n + 1) * 32)
+    ctx.memcpy_d2d(zp.ptr + 32 * X.size, st.w_poly.ptr, nw * 32)
+    ctx.fr_vec_op_dev(_lib.OP_SUB, zp.ptr, st.w_poly.ptr, zp.ptr, nw)
+    ctx.fr_vec_op_dev(_lib.OP_ADD, zp.ptr, st.x_poly.ptr, zp.ptr, X.size)
+    z_poly = DevPoly(zp, n + 1)
+    # q_1 = mask + r_alpha * summed - t * z over one multiplication domain (prover.rs:520-545)
+    mul = Domain(ctx, max(st.mask_poly.n, n + summed.n, n + z_poly.n))
+    e_r, e_s = mul.fft(ctx, r_alpha_poly), mul.fft(ctx, summed)
+    e_z, e_t = mul.fft(ctx, z_poly), mul.fft(ctx, st.t_poly)
+    ctx.fr_vec_op_dev(_lib.OP_MUL, e_r.ptr, e_s.ptr, e_r.ptr, mul.size)
+    ctx.fr_vec_op_dev(_lib.OP_MUL, e_z.ptr, e_t.ptr, e_z.ptr, mul.size)
+    ctx.fr_vec_op_dev(_lib.OP_SUB, e_r.ptr, e_z.ptr, e_r.ptr, mul.size)
+    q1 = mul.ifft_in_place(ctx, e_r)
+    ctx.fr_vec_op_dev(_lib.OP_ADD, q1.ptr, st.mask_poly.ptr, q1.ptr, st.mask_poly.n)
+    hq, hr = ctx.alloc((mul.size - n) * 32), ctx.alloc(n * 32)
+    ctx.poly_divide_by_vanishing_dev(q1.ptr, mul.size, H.log, hq.ptr, hr.ptr)
+    if not ctx.fr_vec_is_zero_dev(hr.ptr, 1):
+        raise ValueError("outer sum-check: the sum over H is not zero (unsatisfied constraint system)")
+    st.first_msg = (alpha, eta_a, eta_b, eta_c)
+    g_1 = DevPoly(hr, n - 1, 1)
+    h_1 = DevPoly(hq, min(mul.size - n, 2 * n + 2 * st.zk_bound - 1))
+    ctx.sync()
+    return {"t": st.t_poly, "g_1": g_1, "h_1": h_1}
+
+
+def prover_third_round(st: ProverState, beta: int):
+    """prover.rs:583-716."""
+    ix = st.index
+    ctx, H, K, B, F = ix.ctx, ix.dom_h, ix.dom_k, ix.dom_b, ix.dom_h.F
+    alpha, eta_a, eta_b, eta_c = st.first_msg
+    m = HostField.m
+    vv = F.mul(H.evaluate_vanishing_polynomial(alpha), H.evaluate_vanishing_polynomial(beta))
+    etas = [m(eta_a), m(eta_b), m(eta_c)]
+    on_k = [{k: v.ptr for k, v in ix.arith[n].evals_on_K.items()} for n in "abc"]
+    on_b = [{k: v.ptr for k, v in ix.arith[n].evals_on_B.items()} for n in "abc"]
+    f_ev = ctx.alloc(K.size * 32)
+    ctx.marlin_round3_f_evals_dev(on_k, K.size, m(alpha), m(beta), etas, m(vv), f_ev.ptr)
+    f = K.ifft_in_place(ctx, f_ev)
+    g_2 = f.slice(1, K.size - 1)
+    a_ev, b_ev = ctx.alloc(B.size * 32), ctx.alloc(B.size * 32)
+    ctx.marlin_round3_ab_evals_dev(on_b, B.size, m(alpha), m(beta), etas, m(vv), a_ev.ptr, b_ev.ptr)
+    a_poly, b_poly = B.ifft_in_place(ctx, a_ev), B.ifft_in_place(ctx, b_ev)
+    # h_2 = (a - b f) / v_K ; deg b <= 3(|K| - 1), so only that many coefficients enter the product
+    nb = min(B.size, 3 * K.size - 2)
+    nbf = nb + K.size - 1
+    bf = ctx.alloc(max(nbf, B.size) * 32)
+    ctx.dev_zero(bf.ptr, max(nbf, B.size) * 32)
+    ctx.poly_mul_dev(b_poly.ptr, nb, f.ptr, K.size, bf.ptr)
+    ctx.fr_vec_scale_dev(bf.ptr, m(R_MOD - 1), bf.ptr, nbf)
+    ctx.fr_vec_op_dev(_lib.OP_ADD, bf.ptr, a_poly.ptr, bf.ptr, B.size)
+    total = max(nbf, B.size)
+    if total <= K.size:
+        raise ValueError("degenerate K domain")
+    hq, hr = ctx.alloc((total - K.size) * 32), ctx.alloc(K.size * 32)
+    ctx.poly_divide_by_vanishing_dev(bf.ptr, total, K.log, hq.ptr, hr.ptr)
+    if not ctx.fr_vec_is_zero_dev(hr.ptr, K.size):
+        raise ValueError("inner sum-check: a - b f is not divisible by v_K")
+    ctx.sync()
+    return {"g_2": g_2, "h_2": DevPoly(hq, total - K.size)}
+
+
+def download_poly(ctx: Context, p: DevPoly) -> list:
+    return cv.fr_from_mont(ctx.download(p.ptr, (p.n, 4)))
