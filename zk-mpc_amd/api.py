@@ -35,6 +35,10 @@ class DevBuf:
     def __init__(self, ctx: "Context", nbytes: int):
         self.ctx = ctx
         self.nbytes = nbytes
+        pooled = ctx._pool.get(nbytes) if ctx.pooling else None
+        if pooled:
+            self.ptr = pooled.pop()
+            return
         p = C.c_void_p()
         ctx._ck(ctx.lib.zk_dev_alloc(ctx.h, nbytes, C.byref(p)))
         self.ptr = p.value
@@ -44,7 +48,12 @@ class DevBuf:
 
     def free(self):
         if self.ptr:
-            self.ctx.lib.zk_dev_free(self.ctx.h, C.c_void_p(self.ptr))
+            if self.ctx.pooling and self.ctx.h:
+                # all work of a context is ordered on its stream (the MSM entry points synchronise before they return),
+                # so a buffer handed to a later call is only touched after every earlier kernel that used it
+                self.ctx._pool.setdefault(self.nbytes, []).append(self.ptr)
+            else:
+                self.ctx.lib.zk_dev_free(self.ctx.h, C.c_void_p(self.ptr))
             self.ptr = None
 
     def __del__(self):
@@ -65,9 +74,18 @@ class Context:
             raise ZkError("zk_ctx_create failed (rc=%d): no usable HIP device %d -- this library has no CPU path" % (rc, device))
         self.h = h
         self.device, self.party_id, self.n_parties = device, party_id, n_parties
+        self.pooling = False        # keep freed DevBufs for same-size reuse (no hipMalloc / hipFree on a proving path)
+        self._pool = {}
+
+    def drop_pool(self):
+        for ptrs in self._pool.values():
+            for ptr in ptrs:
+                self.lib.zk_dev_free(self.h, C.c_void_p(ptr))
+        self._pool = {}
 
     def close(self):
         if self.h:
+            self.drop_pool()
             self.lib.zk_ctx_destroy(self.h)
             self.h = None
 

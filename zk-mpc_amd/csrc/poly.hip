@@ -78,14 +78,35 @@ __global__ void __launch_bounds__(256) k_chunk_fill(const void* c, size_t n, FrK
     }
 }
 
-// q_j = sum_{k>=1} c[j + k N]  (j < nq) ;  r_j = sum_{k>=0} c[j + k N]  (j < N)
-__global__ void __launch_bounds__(256) k_div_vanishing(const void* c, size_t n, size_t N, void* q, size_t nq, void* r) {
-    const size_t total = nq > N ? nq : N;
-    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+// Division by X^N - 1: with the coefficients viewed as an m x N row-major matrix (row k = c[kN .. kN+N-1]) the quotient
+// is the column-wise exclusive suffix sum, q[k][j] = sum_{k' > k} c[k'][j], and the remainder is r[j] = c[0][j] + q[0][j].
+// Rows are cut into G groups of R; one thread owns one (group, column), so the work is O(n) for every N (a tiny N, like
+// the |X| = 2 of Marlin's w(X) / v_X, included).
+__global__ void __launch_bounds__(256) k_divv_sums(const void* c, size_t n, size_t N, size_t R, size_t G, void* sums) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < G * N; t += (size_t)gridDim.x * blockDim.x) {
+        size_t g = t / N, j = t - g * N;
         Fr acc = fp_zero<FrParams>();
-        for (size_t i = j + N; i < n; i += N) acc = fr_add(acc, fr_load(c, i));
-        if (j < nq) fr_store(q, j, acc);
-        if (j < N) fr_store(r, j, j < n ? fr_add(acc, fr_load(c, j)) : acc);
+        for (size_t r = 0; r < R; r++) {
+            size_t i = (g * R + r) * N + j;
+            if (i < n) acc = fr_add(acc, fr_load(c, i));
+        }
+        fr_store(sums, t, acc);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_divv_fill(const void* c, size_t n, size_t N, size_t R, size_t G, const void* sums, void* q,
+                                                   size_t nq, void* rem) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < G * N; t += (size_t)gridDim.x * blockDim.x) {
+        size_t g = t / N, j = t - g * N;
+        Fr acc = fp_zero<FrParams>();
+        for (size_t g2 = g + 1; g2 < G; g2++) acc = fr_add(acc, fr_load(sums, g2 * N + j));
+        for (size_t r = R; r-- > 0;) {
+            size_t row = g * R + r, i = row * N + j;
+            if (i < nq) fr_store(q, i, acc);
+            Fr x = i < n ? fr_load(c, i) : fp_zero<FrParams>();
+            if (row == 0) fr_store(rem, j, fr_add(acc, x));
+            acc = fr_add(acc, x);
+        }
     }
 }
 
@@ -208,7 +229,21 @@ extern "C" int zk_poly_divide_by_vanishing_dev(zk_ctx* ctx, const void* coeffs_d
     const size_t N = (size_t)1 << log_domain;
     const size_t nq = n > N ? n - N : 0;
     if (nq && !q_dev) return ZK_ERR_ARG;
-    hipLaunchKernelGGL(k_div_vanishing, zk_grid(nq > N ? nq : N, 256), 256, 0, ctx->stream, coeffs_dev, n, N, q_dev, nq, r_dev);
+    if (coeffs_dev == q_dev || coeffs_dev == r_dev) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_poly_divide_by_vanishing_dev: outputs must not alias the input");
+    size_t m = (n + N - 1) / N;
+    if (m == 0) m = 1;
+    size_t G = 65536 / N;
+    if (G < 1) G = 1;
+    if (G > 1024) G = 1024;
+    if (G > m) G = m;
+    const size_t R = (m + G - 1) / G;
+    G = (m + R - 1) / R;
+    void* sums = nullptr;
+    if (G > 1) {
+        ZK_TRY(zk_scratch(ctx, "poly_divv_sums", G * N * 32, &sums));
+        hipLaunchKernelGGL(k_divv_sums, zk_grid(G * N, 256), 256, 0, ctx->stream, coeffs_dev, n, N, R, G, sums);
+    }
+    hipLaunchKernelGGL(k_divv_fill, zk_grid(G * N, 256), 256, 0, ctx->stream, coeffs_dev, n, N, R, G, (const void*)sums, q_dev, nq, r_dev);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }

@@ -241,6 +241,19 @@ class Index:
             tr.append((np.cumsum(rp).astype(np.uint32), m.row_of_entry()[order].astype(np.uint32), m.coeff[order]))
         self.r1cs_t = ctx.r1cs_upload(1, H - 1, *tr)
 
+    def w_evals_index(self):
+        """Index maps of prover.rs:343-353: position k of H takes witness k - k/ratio - 1 (zero beyond the witness) minus
+        x_evals[k], and is zero on the sub-domain X.  Built once per index."""
+        if getattr(self, "_w_idx", None) is None:
+            n, ratio = self.dom_h.size, self.dom_h.size // self.dom_x.size
+            k = np.arange(n, dtype=np.int64)
+            wi = k - k // ratio - 1
+            on_x = (k % ratio) == 0
+            idx_w = np.where(on_x | (wi >= self.num_witness), int(SENTINEL), wi + self.num_instance).astype(np.uint32)
+            idx_x = np.where(on_x, int(SENTINEL), k).astype(np.uint32)
+            self._w_idx = (self.ctx.upload(idx_w), self.ctx.upload(idx_x))
+        return self._w_idx
+
     def polynomials(self):
         out = {}
         for m in "abc":
@@ -278,27 +291,26 @@ def _blind_with_vanishing(ctx, poly: DevPoly, n: int, r_dev: int) -> DevPoly:
     return DevPoly(out, n + 1)
 
 
-def prover_first_round(st: ProverState, randomness_mont: np.ndarray):
-    """prover.rs:311-404.  randomness_mont: 3 + mask_poly_degree + 1 field elements (Montgomery limbs) in the order the
-    reference draws them: w, z_a, z_b blinders, then the mask polynomial's coefficients."""
+def prover_first_round(st: ProverState, randomness):
+    """prover.rs:311-404.  randomness: 3 + mask_poly_degree + 1 field elements in the order the reference draws them
+    (w, z_a, z_b blinders, then the mask polynomial's coefficients), as Montgomery limbs (n, 4) on the host or as a
+    DevBuf already holding them."""
     ix = st.index
     ctx, H, X = ix.ctx, ix.dom_h, ix.dom_x
     n = H.size
     md = mask_poly_degree(ix)
-    assert randomness_mont.shape == (3 + md + 1, 4)
-    rnd = ctx.upload(randomness_mont)
+    if isinstance(randomness, DevBuf):
+        assert randomness.nbytes >= (3 + md + 1) * 32
+        rnd = randomness
+    else:
+        assert randomness.shape == (3 + md + 1, 4)
+        rnd = ctx.upload(randomness)
     # x(X): interpolation of the formatted input over X, then its evaluations over H
     xb = ctx.alloc(X.size * 32)
     ctx.memcpy_d2d(xb.ptr, st.z.ptr, X.size * 32)
     st.x_poly = X.ifft_in_place(ctx, xb)
     x_evals = H.fft(ctx, st.x_poly)
-    ratio = n // X.size
-    k = np.arange(n, dtype=np.int64)
-    wi = k - k // ratio - 1
-    on_x = (k % ratio) == 0
-    idx_w = np.where(on_x | (wi >= ix.num_witness), int(SENTINEL), wi + ix.num_instance).astype(np.uint32)
-    idx_x = np.where(on_x, int(SENTINEL), k).astype(np.uint32)
-    d_iw, d_ix = ctx.upload(idx_w), ctx.upload(idx_x)
+    d_iw, d_ix = ix.w_evals_index()
     w_evals, tmp = ctx.alloc(n * 32), ctx.alloc(n * 32)
     ctx.fr_gather_dev(st.z.ptr, d_iw.ptr, n, w_evals.ptr)
     ctx.fr_gather_dev(x_evals.ptr, d_ix.ptr, n, tmp.ptr)
@@ -420,6 +432,47 @@ def prover_third_round(st: ProverState, beta: int):
         raise ValueError("inner sum-check: a - b f is not divisible by v_K")
     ctx.sync()
     return {"g_2": g_2, "h_2": DevPoly(hq, total - K.size)}
+
+
+def linear_combination(ctx: Context, polys, coeffs) -> DevPoly:
+    """sum_i coeffs[i] * polys[i] (the combined polynomial of a batched opening, poly-commit/src/lib.rs batch_open)."""
+    n = max(p.n for p in polys)
+    out, tmp = ctx.alloc(n * 32), ctx.alloc(n * 32)
+    ctx.dev_zero(out.ptr, n * 32)
+    for p, k in zip(polys, coeffs):
+        ctx.fr_vec_scale_dev(p.ptr, HostField.m(k), tmp.ptr, p.n)
+        ctx.fr_vec_op_dev(_lib.OP_ADD, out.ptr, tmp.ptr, out.ptr, p.n)
+    return DevPoly(out, n)
+
+
+def commit(ctx: Context, powers_g, polys: dict) -> dict:
+    """PC::commit without hiding (kzg10/mod.rs:142-205): one G1 MSM per polynomial."""
+    return {label: ctx.kzg_commit_dev(powers_g, p.ptr, p.n) for label, p in polys.items()}
+
+
+def batch_open(ctx: Context, powers_g, polys, point: int, opening_challenge: int):
+    """One KZG10 witness for several polynomials at one point: p = sum_i xi^i p_i, w = commit((p - p(z)) / (X - z))
+    (kzg10/mod.rs:212-293 applied to the combination, as marlin_pc::batch_open does per query point)."""
+    F = HostField(ctx)
+    ks, k = [], 1
+    for _ in polys:
+        ks.append(k)
+        k = F.mul(k, opening_challenge)
+    comb = linear_combination(ctx, polys, ks)
+    w, _ = ctx.kzg_open_dev(powers_g, comb.ptr, comb.n, HostField.m(point))
+    return w
+
+
+def mul_chain_system(ctx: Context, n: int):
+    """The SURVEY 8(d) mul-chain R1CS (w_i w_{i+1} = w_{i+2}, public input = the last product) already in Marlin's
+    padded square form: 2 instance variables (a power of two), n + 1 witnesses, n constraints plus 3 empty rows."""
+    def idx(j):
+        return np.where(j <= n, 2 + j, 1)
+    i = np.arange(n, dtype=np.int64)
+    rp = np.concatenate([np.arange(n + 1, dtype=np.int64), np.full(3, n, dtype=np.int64)])
+    ones = np.tile(HostField.m(1), (n, 1))
+    mk = lambda col: Csr(rp, col, ones)
+    return 2, n + 1, mk(idx(i)), mk(idx(i + 1)), mk(idx(i + 2))
 
 
 def download_poly(ctx: Context, p: DevPoly) -> list:
