@@ -121,6 +121,16 @@ int zk_fixed_base_g2_dev(zk_ctx* ctx, const zk_fr* gen_k_host, const void* scala
 int zk_bases_download_g1(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, zk_g1_affine* out_host);
 int zk_bases_download_g2(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, zk_g2_affine* out_host);
 
+/* ---- arkworks CanonicalSerialize of point tables ----
+ * Bytes as GroupAffine::serialize (compressed: x with bit 7 of the last byte = y > -y, bit 6 = infinity) or
+ * serialize_uncompressed (x | y, infinity = (0, 1) with bit 6 of the last byte) write them
+ * (ec/src/models/short_weierstrass_jacobian.rs:847-883); n points back to back, no length prefix. */
+size_t zk_point_serialized_size(int group, int compressed);      /* 48 / 96 (G1), 96 / 192 (G2) */
+int zk_bases_serialize(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, int compressed, uint8_t* out_host);
+/* GroupAffine::deserialize_unchecked (:930-942) on n uncompressed points, plus an on-curve check (error instead of
+ * a silently wrong table); no subgroup check. */
+int zk_bases_deserialize_uncompressed(zk_ctx* ctx, int group, const uint8_t* bytes_host, size_t n, zk_bases** out);
+
 /* ---- host-side group helpers (O(1) work per proof; rows a10, a12) ------------------------ */
 int zk_g1_add(const zk_g1_projective* a, const zk_g1_projective* b, zk_g1_projective* out);
 int zk_g2_add(const zk_g2_projective* a, const zk_g2_projective* b, zk_g2_projective* out);

@@ -317,6 +317,38 @@ def g2_serialize(P) -> bytes:
     return fq_serialize(x[0]) + fq_serialize(x[1], SW_POSITIVE_Y if _fq2_gt_neg(P[1]) else 0)
 
 
+def g1_serialize_uncompressed(P) -> bytes:
+    """x || y-with-flags, 96 B (short_weierstrass_jacobian.rs:867-877); infinity is (0, 1) with the infinity bit."""
+    if P is None:
+        return fq_serialize(0) + fq_serialize(1, SW_INFINITY)
+    return fq_serialize(P[0]) + fq_serialize(P[1])
+
+
+def g2_serialize_uncompressed(P) -> bytes:
+    if P is None:
+        return fq_serialize(0) + fq_serialize(0) + fq_serialize(1) + fq_serialize(0, SW_INFINITY)
+    (x0, x1), (y0, y1) = P
+    return fq_serialize(x0) + fq_serialize(x1) + fq_serialize(y0) + fq_serialize(y1)
+
+
+def _vec(points, ser) -> bytes:
+    """Vec<T>: u64 LE length, then the items (serialize/src/lib.rs:263-272)."""
+    return len(points).to_bytes(8, "little") + b"".join(ser(p) for p in points)
+
+
+def vk_serialize(pk, compressed=True) -> bytes:
+    """VerifyingKey (arkworks/groth16/src/data_structures.rs:43-58): alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1."""
+    s1, s2 = (g1_serialize, g2_serialize) if compressed else (g1_serialize_uncompressed, g2_serialize_uncompressed)
+    return s1(pk.alpha_g1) + s2(pk.beta_g2) + s2(pk.gamma_g2) + s2(pk.delta_g2) + _vec(pk.gamma_abc_g1, s1)
+
+
+def pk_serialize(pk, compressed=True) -> bytes:
+    """ProvingKey (data_structures.rs:133-151): vk, beta_g1, delta_g1, a_query, b_g1_query, b_g2_query, h_query, l_query."""
+    s1, s2 = (g1_serialize, g2_serialize) if compressed else (g1_serialize_uncompressed, g2_serialize_uncompressed)
+    return (vk_serialize(pk, compressed) + s1(pk.beta_g1) + s1(pk.delta_g1) + _vec(pk.a_query, s1) + _vec(pk.b_g1_query, s1)
+            + _vec(pk.b_g2_query, s2) + _vec(pk.h_query, s1) + _vec(pk.l_query, s1))
+
+
 def proof_serialize(A, B, C) -> bytes:
     """a || b || c = 192 B (arkworks/groth16/src/data_structures.rs:10-18)."""
     return g1_serialize(A) + g2_serialize(B) + g1_serialize(C)

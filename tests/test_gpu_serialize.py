@@ -1,0 +1,67 @@
+"""GPU parity: arkworks CanonicalSerialize of point tables and Groth16 keys against the oracle."""
+import numpy as np
+import pytest
+
+import zkref as O
+import zk_mpc_amd.convert as cv
+from zk_mpc_amd import serialize as S
+from helpers import mont1
+
+pytestmark = pytest.mark.gpu
+
+
+def test_point_tables_both_forms(ctx):
+    rng = O.Prng(950)
+    p1 = [O.g1_mul(O.G1_GEN, rng.fr()) for _ in range(9)] + [None]
+    p1 += [O.g1_neg(p1[0])]                                    # same x, other sign bit
+    p2 = [O.g2_mul(O.G2_GEN, rng.fr()) for _ in range(5)] + [None]
+    p2 += [O.g2_neg(p2[0])]
+    b1 = ctx.bases_upload(cv.g1_affine_to_array(p1), 1)
+    b2 = ctx.bases_upload(cv.g2_affine_to_array(p2), 2)
+    assert b1.serialize(True) == b"".join(O.g1_serialize(p) for p in p1)
+    assert b1.serialize(False) == b"".join(O.g1_serialize_uncompressed(p) for p in p1)
+    assert b2.serialize(True) == b"".join(O.g2_serialize(p) for p in p2)
+    assert b2.serialize(False) == b"".join(O.g2_serialize_uncompressed(p) for p in p2)
+    assert b1.serialize(True, offset=3, n=2) == b"".join(O.g1_serialize(p) for p in p1[3:5])
+    # uncompressed round trip through the device
+    r1 = ctx.bases_deserialize_uncompressed(b1.serialize(False), len(p1), 1)
+    r2 = ctx.bases_deserialize_uncompressed(b2.serialize(False), len(p2), 2)
+    assert cv.g1_array_to_affine(r1.download()) == p1
+    assert cv.g2_array_to_affine(r2.download()) == p2
+
+
+def test_deserialize_rejects_garbage(ctx):
+    rng = O.Prng(951)
+    good = O.g1_serialize_uncompressed(O.g1_mul(O.G1_GEN, rng.fr()))
+    bad = bytearray(good)
+    bad[0] ^= 1                                                 # x changed: no longer on the curve
+    with pytest.raises(Exception, match="not on the curve"):
+        ctx.bases_deserialize_uncompressed(bytes(bad), 1, 1)
+    flagged = bytearray(good)
+    flagged[95] |= 0x80                                         # sign flag has no place in the uncompressed form
+    with pytest.raises(Exception, match="flag"):
+        ctx.bases_deserialize_uncompressed(bytes(flagged), 1, 1)
+
+
+def test_groth16_keys_wire_format(ctx):
+    """Keys of the device's own setup serialise to the oracle's bytes; a key read back from its uncompressed bytes proves
+    the same proof."""
+    rng = O.Prng(952)
+    n = 20
+    r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
+    td = O.Trapdoor(*[rng.fr() for _ in range(7)])
+    opk = O.ProvingKey(O.ProvingKeyScalars(r1cs, td))
+    dr = ctx.r1cs_mul_chain(n)
+    dpk = ctx.groth16_setup(dr, *[mont1(v) for v in (td.alpha, td.beta, td.gamma, td.delta, td.tau, td.g1_k, td.g2_k)])
+    for compressed in (True, False):
+        assert S.verifying_key_bytes(ctx, dpk, compressed) == O.vk_serialize(opk, compressed)
+        assert S.proving_key_bytes(ctx, dpk, compressed) == O.pk_serialize(opk, compressed)
+    pk2, gamma_g2, gamma_abc = S.proving_key_from_bytes(ctx, O.pk_serialize(opk, False))
+    assert cv.g2_array_to_affine(gamma_g2.reshape(1, 24)) == [opk.gamma_g2]
+    assert cv.g1_array_to_affine(gamma_abc) == opk.gamma_abc_g1
+    r, s = rng.fr(), rng.fr()
+    zm = cv.fr_to_mont(z)
+    proof = ctx.create_proof(pk2, dr, zm, mont1(r), mont1(s))
+    assert proof == ctx.create_proof(dpk, dr, zm, mont1(r), mont1(s))
+    A, B, Cc = O.create_proof(r1cs, opk, z, r, s)
+    assert proof == O.proof_serialize(A, B, Cc)

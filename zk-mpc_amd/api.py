@@ -185,6 +185,13 @@ class Context:
         self._ck(fn(self.h, _ptr(arr), arr.shape[0], C.byref(h)))
         return Bases(self, h, group)
 
+    def bases_deserialize_uncompressed(self, data: bytes, n: int, group: int) -> "Bases":
+        buf = np.frombuffer(data, dtype=np.uint8)
+        assert buf.size == n * self.lib.zk_point_serialized_size(group, 0)
+        out = C.c_void_p()
+        self._ck(self.lib.zk_bases_deserialize_uncompressed(self.h, group, _ptr(np.ascontiguousarray(buf)) if n else None, n, C.byref(out)))
+        return Bases(self, out, group)
+
     def fixed_base(self, scalars_dev, n: int, group: int, gen_k_mont4) -> "Bases":
         h = C.c_void_p()
         k = _fr_struct(gen_k_mont4)
@@ -484,8 +491,8 @@ class Context:
 
 
 class Bases:
-    def __init__(self, ctx: Context, h, group: int):
-        self.ctx, self.h, self.group = ctx, h, group
+    def __init__(self, ctx: Context, h, group: int, owned: bool = True):
+        self.ctx, self.h, self.group, self.owned = ctx, h, group, owned
 
     def __len__(self):
         return self.ctx.lib.zk_bases_len(self.h)
@@ -501,10 +508,18 @@ class Bases:
         self.ctx._ck(fn(self.ctx.h, self.h, offset, n, _ptr(out)))
         return out
 
+    def serialize(self, compressed: bool = True, offset: int = 0, n: int = None) -> bytes:
+        """The points as GroupAffine::serialize / serialize_uncompressed write them, back to back."""
+        n = len(self) - offset if n is None else n
+        per = self.ctx.lib.zk_point_serialized_size(self.group, int(compressed))
+        out = np.zeros(max(n * per, 1), dtype=np.uint8)
+        self.ctx._ck(self.ctx.lib.zk_bases_serialize(self.ctx.h, self.h, offset, n, int(compressed), _ptr(out)))
+        return out[: n * per].tobytes()
+
     def free(self):
-        if self.h:
+        if self.h and self.owned:
             self.ctx.lib.zk_bases_free(self.ctx.h, self.h)
-            self.h = None
+        self.h = None
 
 
 class R1cs:
@@ -541,6 +556,12 @@ class ProvingKey:
             out = np.zeros((n, 12), dtype=np.uint64)
             self.ctx._ck(self.ctx.lib.zk_pk_download_g1(self.ctx.h, self.h, which, offset, n, _ptr(out)))
         return out
+
+    def query_bases(self, name: str) -> "Bases":
+        """Borrowed handle to one query table (valid while the key lives)."""
+        which = self.QUERIES[name]
+        h = self.ctx.lib.zk_pk_query_bases(self.h, which)
+        return Bases(self.ctx, C.c_void_p(h), 2 if which == 2 else 1, owned=False)
 
     def vk_g1(self, which: int) -> np.ndarray:
         out = np.zeros(12, dtype=np.uint64)
