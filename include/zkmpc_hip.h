@@ -131,6 +131,12 @@ int zk_bases_serialize(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, 
  * a silently wrong table); no subgroup check. */
 int zk_bases_deserialize_uncompressed(zk_ctx* ctx, int group, const uint8_t* bytes_host, size_t n, zk_bases** out);
 
+/* n_jobs independent MSMs pipelined over the library's sort / accumulate streams (one job sorts while the previous one
+ * accumulates).  outs[k] receives a zk_g1_projective or zk_g2_projective according to bases[k]'s group; base_offsets may
+ * be NULL.  Same result as n_jobs calls of zk_msm_g1_dev / zk_msm_g2_dev. */
+int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* const* bases, const size_t* base_offsets,
+                     const void* const* scalars_dev, const size_t* lens, void* const* outs);
+
 /* ---- host-side group helpers (O(1) work per proof; rows a10, a12) ------------------------ */
 int zk_g1_add(const zk_g1_projective* a, const zk_g1_projective* b, zk_g1_projective* out);
 int zk_g2_add(const zk_g2_projective* a, const zk_g2_projective* b, zk_g2_projective* out);

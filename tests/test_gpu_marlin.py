@@ -104,3 +104,15 @@ def test_round_polynomials_commit_and_open_with_kzg10(ctx):
         z = ch[point]
         w, _ = ctx.kzg_open_dev(pg, p.ptr, p.n, mont1(z))
         assert O.kzg_check(pp, comm, z, O.poly_evaluate(coeffs, z), cv.g1_projective_to_affine(w)), label
+    # the round's commitments as one pipelined batch, and a batched opening of several polynomials at one point
+    labels = ["w", "z_a", "z_b", "mask_poly"]
+    comms = DM.commit(ctx, pg, {l: polys[l] for l in labels})
+    for l in labels:
+        assert cv.g1_projective_to_affine(comms[l]) == O.kzg_commit(pp, DM.download_poly(ctx, polys[l])), l
+    xi = rng.fr()
+    (w_beta,) = DM.batch_open(ctx, pg, [([polys[l] for l in labels], ch["beta"])], xi)
+    comb = []
+    for i, l in enumerate(labels):
+        comb = M.padd(comb, M.pscale(DM.download_poly(ctx, polys[l]), pow(xi, i, O.R_MOD)))
+    c_comb = O.kzg_commit(pp, comb)
+    assert O.kzg_check(pp, c_comb, ch["beta"], O.poly_evaluate(comb, ch["beta"]), cv.g1_projective_to_affine(w_beta))

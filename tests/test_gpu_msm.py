@@ -4,6 +4,7 @@ import pytest
 
 import zkref as O
 import zk_mpc_amd.convert as cv
+from helpers import mont1
 
 pytestmark = pytest.mark.gpu
 
@@ -204,3 +205,21 @@ def test_groth16_precomputed_key_matches_plain(ctx):
     cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))
     assert p1 == OC.groth16_predict(cr, np.stack(td), zarr, OC.witness_map(cr, zarr), rr, ss)
     pk0.free(); pk1.free()
+
+
+def test_msm_batch_pipeline(ctx):
+    """zk_msm_batch_dev: more jobs than scratch slots, both groups, an empty job, offsets; equal to the single calls."""
+    rng = O.Prng(4242)
+    n = 300
+    ks = [rng.fr() for _ in range(n)]
+    sc = ctx.upload(cv.fr_to_mont(ks))
+    b1 = ctx.fixed_base(sc.ptr, n, 1, mont1(1))
+    b2 = ctx.fixed_base(sc.ptr, 64, 2, mont1(1))
+    vecs = [ctx.upload(cv.fr_to_mont([rng.fr() for _ in range(n)])) for _ in range(4)]
+    jobs = [(b1, 0, vecs[0].ptr, n), (b2, 0, vecs[1].ptr, 64), (b1, 5, vecs[2].ptr, 100), (b1, 0, vecs[3].ptr, 0),
+            (b1, 0, vecs[3].ptr, n), (b2, 3, vecs[0].ptr, 61), (b1, 0, vecs[1].ptr, 1), (b1, 290, vecs[2].ptr, 10)]
+    outs = ctx.msm_batch_dev(jobs)
+    for (b, off, s, m), got in zip(jobs, outs):
+        want = ctx.msm_dev(b, off, s, m)
+        to_aff = cv.g1_projective_to_affine if b.group == 1 else cv.g2_projective_to_affine
+        assert to_aff(got) == to_aff(want)

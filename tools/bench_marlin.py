@@ -78,8 +78,7 @@ def main():
             at_beta = [polys[l] for l in ("g_1", "z_b", "t", "mask_poly", "z_a", "w", "h_1")]
             ixp = index.polynomials()
             at_gamma = [polys["g_2"], polys["h_2"]] + [ixp[l] for l in sorted(ixp)]
-            w_beta = DM.batch_open(ctx, powers_g, at_beta, ch["beta"], ch["xi"])
-            w_gamma = DM.batch_open(ctx, powers_g, at_gamma, ch["gamma"], ch["xi"])
+            w_beta, w_gamma = DM.batch_open(ctx, powers_g, [(at_beta, ch["beta"]), (at_gamma, ch["gamma"])], ch["xi"])
             lap("open")
             return comms, evals, w_beta, w_gamma
 

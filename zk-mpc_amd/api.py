@@ -206,6 +206,18 @@ class Context:
         return out
 
     # ---- dense polynomials / KZG10 (names follow DensePolynomial / KZG10 in the reference) ----
+    def msm_batch_dev(self, jobs):
+        """jobs: list of (Bases, base_offset, scalars_dev, n).  Returns one projective array per job (18 or 36 u64)."""
+        k = len(jobs)
+        bases = (C.c_void_p * k)(*[j[0].h for j in jobs])
+        offs = (C.c_size_t * k)(*[j[1] for j in jobs])
+        scal = (C.c_void_p * k)(*[int(j[2]) for j in jobs])
+        lens = (C.c_size_t * k)(*[j[3] for j in jobs])
+        outs = [np.zeros(18 if j[0].group == 1 else 36, dtype=np.uint64) for j in jobs]
+        outp = (C.c_void_p * k)(*[o.ctypes.data for o in outs])
+        self._ck(self.lib.zk_msm_batch_dev(self.h, k, bases, offs, scal, lens, outp))
+        return outs
+
     def fr_powers_dev(self, base4, start4, n: int, out):
         b, s_ = _fr_struct(base4), _fr_struct(start4)
         self._ck(self.lib.zk_fr_powers_dev(self.h, C.byref(b), C.byref(s_), n, C.c_void_p(int(out))))

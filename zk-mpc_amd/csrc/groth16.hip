@@ -533,6 +533,51 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
 
 }  // namespace
 
+// Several independent MSMs as a software pipeline over the sort / accumulate streams: job k+1 is sorted while job k
+// accumulates, reduces follow in job order, three scratch slots rotate.  Used for the commitments of one Marlin round
+// (lib.rs:171-247: PC::commit over the round's oracles) and for the two MSMs of SpdzGroupShare::multi_scale_pub_group
+// (share/spdz.rs:482-488).  Outputs are Jacobian points (G1 or G2 according to each job's table).
+extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* const* bases, const size_t* base_offsets,
+                                const void* const* scalars_dev, const size_t* lens, void* const* outs) {
+    if (!ctx || (n_jobs && (!bases || !scalars_dev || !lens || !outs))) return ZK_ERR_ARG;
+    for (size_t k = 0; k < n_jobs; k++) {
+        if (!bases[k] || !outs[k] || (lens[k] && !scalars_dev[k])) return ZK_ERR_ARG;
+        const size_t off = base_offsets ? base_offsets[k] : 0;
+        if (off + lens[k] > bases[k]->n) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_msm_batch_dev: a job reads past its base table");
+    }
+    if (n_jobs == 0) return ZK_OK;
+    ZK_TRY(ensure_aux(ctx, 1));
+    constexpr size_t SLOTS = 3;
+    hipStream_t s_sort = ctx->aux[0], s_acc = ctx->acc_stream;
+    hipEvent_t e0;
+    ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    ZK_HIP(ctx, hipEventRecord(e0, ctx->stream));        // the scalars were produced on the context stream
+    ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e0, 0));
+    ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e0, 0));
+    std::vector<ZkMsmJob> jobs(n_jobs);
+    size_t finished = 0;
+    int rc = ZK_OK;
+    auto start = [&](size_t k) -> int {
+        while (k >= finished + SLOTS) {                  // the slot's previous user must have delivered its result
+            ZK_TRY(zk_msm_finish(ctx, &jobs[finished], outs[finished]));
+            finished++;
+        }
+        ZK_TRY(zk_msm_prepare(ctx, &jobs[k], bases[k], base_offsets ? base_offsets[k] : 0, scalars_dev[k], lens[k], 1 + (int)(k % SLOTS)));
+        return zk_msm_enqueue_sort(ctx, &jobs[k], s_sort, nullptr);
+    };
+    rc = start(0);
+    for (size_t k = 0; k < n_jobs && rc == ZK_OK; k++) {
+        if (k + 1 < n_jobs) rc = start(k + 1);
+        if (rc == ZK_OK) rc = zk_msm_enqueue_accum(ctx, &jobs[k], s_acc);
+        if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, &jobs[k], s_sort);
+    }
+    for (; finished < n_jobs && rc == ZK_OK; finished++) rc = zk_msm_finish(ctx, &jobs[finished], outs[finished]);
+    (void)hipStreamSynchronize(s_sort);
+    (void)hipStreamSynchronize(s_acc);
+    (void)hipEventDestroy(e0);
+    return rc;
+}
+
 extern "C" int zk_groth16_msms_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const void* h,
                                    zk_g1_projective out_g1[4], zk_g2_projective* out_g2) {
     if (!ctx || !pk || !r || !z || !h || !out_g1 || !out_g2) return ZK_ERR_ARG;

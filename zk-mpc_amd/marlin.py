@@ -447,20 +447,28 @@ def linear_combination(ctx: Context, polys, coeffs) -> DevPoly:
 
 def commit(ctx: Context, powers_g, polys: dict) -> dict:
     """PC::commit without hiding (kzg10/mod.rs:142-205): one G1 MSM per polynomial."""
-    return {label: ctx.kzg_commit_dev(powers_g, p.ptr, p.n) for label, p in polys.items()}
+    labels = list(polys)
+    outs = ctx.msm_batch_dev([(powers_g, 0, polys[l].ptr, polys[l].n) for l in labels])
+    return dict(zip(labels, outs))
 
 
-def batch_open(ctx: Context, powers_g, polys, point: int, opening_challenge: int):
-    """One KZG10 witness for several polynomials at one point: p = sum_i xi^i p_i, w = commit((p - p(z)) / (X - z))
-    (kzg10/mod.rs:212-293 applied to the combination, as marlin_pc::batch_open does per query point)."""
+def batch_open(ctx: Context, powers_g, queries, opening_challenge: int):
+    """KZG10 witnesses for several (polynomials, point) queries: per query p = sum_i xi^i p_i and
+    w = commit((p - p(z)) / (X - z)) (kzg10/mod.rs:212-293 applied to the combination, as marlin_pc::batch_open does per
+    query point); the witness MSMs of all queries run as one pipelined batch.  queries: [(polys, point), ...]."""
     F = HostField(ctx)
-    ks, k = [], 1
-    for _ in polys:
-        ks.append(k)
-        k = F.mul(k, opening_challenge)
-    comb = linear_combination(ctx, polys, ks)
-    w, _ = ctx.kzg_open_dev(powers_g, comb.ptr, comb.n, HostField.m(point))
-    return w
+    jobs, keep = [], []
+    for polys, point in queries:
+        ks, k = [], 1
+        for _ in polys:
+            ks.append(k)
+            k = F.mul(k, opening_challenge)
+        comb = linear_combination(ctx, polys, ks)
+        q = ctx.alloc(max(comb.n - 1, 1) * 32)
+        ctx.poly_divide_by_linear_dev(comb.ptr, comb.n, HostField.m(point), q.ptr)
+        keep += [comb, q]
+        jobs.append((powers_g, 0, q.ptr, comb.n - 1))
+    return ctx.msm_batch_dev(jobs)
 
 
 def mul_chain_system(ctx: Context, n: int):
