@@ -172,3 +172,72 @@ def test_distnet_nccl_single_rank():
     finally:
         ctx.close()
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_parties,n", [(2, 6), (3, 13), (3, 500)])
+def test_collaborative_marlin(n_parties, n):
+    """Collaborative Marlin over additive shares (BASELINE config 5 shape at test size): revealed commitments, evaluations
+    and opening witnesses equal the single-prover run on the summed witness and summed randomness; the opened evaluations
+    satisfy the verifier's sum-check equations."""
+    import marlin_ref as M
+    from zk_mpc_amd import marlin as DM
+    rng = O.Prng(1100 + n)
+    r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
+    sq, zz = M.pad_and_square(r1cs, z)
+    H = M.next_pow2(sq.num_constraints)
+    n_rnd = 3 + 3 * H
+    rnd = [rng.fr() for _ in range(n_rnd)]
+    zs = additive_shares(zz, n_parties, rng)
+    rs = additive_shares(rnd, n_parties, rng)
+    chal = {1: {k: rng.fr() for k in ("alpha", "eta_a", "eta_b", "eta_c")}, 2: {"beta": rng.fr()}, 3: {"gamma": rng.fr(), "xi": rng.fr()}}
+    beta_srs = rng.fr()
+    a, b, c = DM.Csr.from_rows(sq.a), DM.Csr.from_rows(sq.b), DM.Csr.from_rows(sq.c)
+
+    def setup(ctx):
+        index = DM.Index(ctx, sq.num_instance, sq.num_witness, a, b, c)
+        deg = 3 * max(index.dom_h.size, index.dom_k.size) + 2
+        pw = ctx.alloc(deg * 32)
+        ctx.fr_powers_dev(mont1(beta_srs), mont1(1), deg, pw.ptr)
+        return index, ctx.fixed_base(pw.ptr, deg, 1, mont1(1))
+
+    seen = [[] for _ in range(n_parties)]
+
+    def fn(p, ctx, net):
+        party = mpc.Party(ctx, net=net)
+        index, powers_g = setup(ctx)
+        def challenge_fn(rnd_no, comms):
+            seen[p].append({l: cv.g1_projective_to_affine(c) for l, c in comms.items()})
+            return chal[rnd_no]
+        out = party.marlin_prove_shared(index, powers_g, ctx.upload(cv.fr_to_mont(zs[p])), cv.fr_to_mont(rs[p]), challenge_fn)
+        return ({l: cv.g1_projective_to_affine(c) for l, c in out["commitments"].items()},
+                {l: cv.fr_from_mont(np.asarray(v).reshape(1, 4))[0] for l, v in out["evaluations"].items()},
+                cv.g1_projective_to_affine(out["w_beta"]), cv.g1_projective_to_affine(out["w_gamma"]))
+
+    res = run_parties(n_parties, fn)
+    assert all(r == res[0] for r in res)
+    # single prover on the summed inputs
+    ctx = Z.Context(0)
+    try:
+        index, powers_g = setup(ctx)
+        st = DM.prover_init(index, ctx.upload(cv.fr_to_mont(zz)))
+        polys = dict(DM.prover_first_round(st, cv.fr_to_mont(rnd)))
+        c1 = chal[1]
+        polys.update(DM.prover_second_round(st, c1["alpha"], c1["eta_a"], c1["eta_b"], c1["eta_c"]))
+        polys.update(DM.prover_third_round(st, chal[2]["beta"]))
+        comms = {l: cv.g1_projective_to_affine(v) for l, v in DM.commit(ctx, powers_g, polys).items()}
+        beta, gamma, xi = chal[2]["beta"], chal[3]["gamma"], chal[3]["xi"]
+        ev = lambda l, pt: cv.fr_from_mont(ctx.poly_evaluate_dev(polys[l].ptr, polys[l].n, mont1(pt)).reshape(1, 4))[0]
+        evals = {"g_1": ev("g_1", beta), "z_b": ev("z_b", beta), "t": ev("t", beta), "g_2": ev("g_2", gamma)}
+        ixp = index.polynomials()
+        wb, wg = DM.batch_open(ctx, powers_g, [([polys[l] for l in ("g_1", "z_b", "t", "mask_poly", "z_a", "w", "h_1")], beta),
+                                               ([polys["g_2"], polys["h_2"]] + [ixp[l] for l in sorted(ixp)], gamma)], xi)
+        assert res[0] == (comms, evals, cv.g1_projective_to_affine(wb), cv.g1_projective_to_affine(wg))
+        # the sum-check equations on the device's polynomials (pins the single-prover side as in test_gpu_marlin.py)
+        allp = {**ixp, **polys}
+        evf = lambda l, pt: cv.fr_from_mont(ctx.poly_evaluate_dev(allp[l].ptr, allp[l].n, mont1(pt)).reshape(1, 4))[0]
+        info = M.IndexInfo(index.num_constraints, index.num_non_zero, index.num_instance)
+        assert M.sumcheck_equations(info, zz[1:r1cs.num_instance], evf, c1["alpha"], c1["eta_a"], c1["eta_b"], c1["eta_c"], beta, gamma) == (0, 0)
+    finally:
+        ctx.close()
+    # every party saw the same revealed commitments before each challenge
+    assert all(s == seen[0] for s in seen)

@@ -266,10 +266,14 @@ class ProverState:
     pass
 
 
-def prover_init(index: Index, assignment_dev: DevBuf) -> ProverState:
-    """prover.rs:216-309: z_A = A z, z_B = B z.  assignment_dev: the full (padded) assignment, instance first."""
+def prover_init(index: Index, assignment_dev: DevBuf, shared: bool = False) -> ProverState:
+    """prover.rs:216-309: z_A = A z, z_B = B z.  assignment_dev: the full (padded) assignment, instance first.
+    shared: the assignment (and later the randomness) is this party's additive share; every step of the rounds is linear
+    in it except the product z_A * z_B of round 2, which then goes through the caller's Beaver multiplication, and the
+    zero tests, which go through the caller's open."""
     ctx, H = index.ctx, index.dom_h.size
     st = ProverState()
+    st.shared = shared
     st.index, st.z = index, assignment_dev
     st.z_a, st.z_b = ctx.alloc(H * 32), ctx.alloc(H * 32)
     ctx.r1cs_matvec_dev(index.r1cs, 0, assignment_dev.ptr, st.z_a.ptr, H)
@@ -318,7 +322,7 @@ def prover_first_round(st: ProverState, randomness):
     w_h = _blind_with_vanishing(ctx, H.ifft_in_place(ctx, w_evals), n, rnd.ptr)
     wq, wr = ctx.alloc(max(n + 1 - X.size, 1) * 32), ctx.alloc(X.size * 32)
     ctx.poly_divide_by_vanishing_dev(w_h.ptr, n + 1, X.log, wq.ptr, wr.ptr)
-    if not ctx.fr_vec_is_zero_dev(wr.ptr, X.size):
+    if not st.shared and not ctx.fr_vec_is_zero_dev(wr.ptr, X.size):
         raise ValueError("w polynomial is not divisible by v_X")      # assert!(remainder.is_zero()), prover.rs:360
     st.w_poly = DevPoly(wq, n + 1 - X.size)
     za, zb = ctx.alloc(n * 32), ctx.alloc(n * 32)
@@ -336,22 +340,18 @@ def prover_first_round(st: ProverState, randomness):
     return {"w": st.w_poly, "z_a": st.z_a_poly, "z_b": st.z_b_poly, "mask_poly": st.mask_poly}
 
 
-def prover_second_round(st: ProverState, alpha: int, eta_a: int, eta_b: int, eta_c: int):
-    """prover.rs:438-565."""
+def prover_second_round(st: ProverState, alpha: int, eta_a: int, eta_b: int, eta_c: int, batch_mul=None, open_is_zero=None):
+    """prover.rs:438-565.  batch_mul(x_dev, y_dev, out_dev, n): element-wise product of two vectors of the prover's own
+    values (default: the local product; over shares: FieldShare::batch_mul, as `DensePolynomial::mul` on MpcField does
+    through batch_product_in_place).  open_is_zero(v_dev, n): whether the (shared) vector opens to zero."""
     ix = st.index
     ctx, H, X, F = ix.ctx, ix.dom_h, ix.dom_x, ix.dom_h.F
     n = H.size
     m = HostField.m
-    # summed_z_m = eta_c z_a z_b + eta_a z_a + eta_b z_b
-    zc = ctx.alloc((2 * n + 1) * 32)
-    ctx.poly_mul_dev(st.z_a_poly.ptr, n + 1, st.z_b_poly.ptr, n + 1, zc.ptr)
-    ctx.fr_vec_scale_dev(zc.ptr, m(eta_c), zc.ptr, 2 * n + 1)
-    tmp = ctx.alloc((n + 1) * 32)
-    ctx.fr_vec_scale_dev(st.z_a_poly.ptr, m(eta_a), tmp.ptr, n + 1)
-    ctx.fr_vec_op_dev(_lib.OP_ADD, zc.ptr, tmp.ptr, zc.ptr, n + 1)
-    ctx.fr_vec_scale_dev(st.z_b_poly.ptr, m(eta_b), tmp.ptr, n + 1)
-    ctx.fr_vec_op_dev(_lib.OP_ADD, zc.ptr, tmp.ptr, zc.ptr, n + 1)
-    summed = DevPoly(zc, 2 * n + 1)
+    if batch_mul is None:
+        batch_mul = lambda x, y, out, k: ctx.fr_vec_op_dev(_lib.OP_MUL, x, y, out, k)
+    if open_is_zero is None:
+        open_is_zero = lambda v, k: ctx.fr_vec_is_zero_dev(v, k)
     # r(alpha, X) on H: v_H(alpha) / (alpha - h)   (mod.rs:352-360)
     v_h_alpha = H.evaluate_vanishing_polynomial(alpha)
     ra = ctx.alloc(n * 32)
@@ -378,18 +378,26 @@ def prover_second_round(st: ProverState, alpha: int, eta_a: int, eta_b: int, eta
     ctx.fr_vec_op_dev(_lib.OP_SUB, zp.ptr, st.w_poly.ptr, zp.ptr, nw)
     ctx.fr_vec_op_dev(_lib.OP_ADD, zp.ptr, st.x_poly.ptr, zp.ptr, X.size)
     z_poly = DevPoly(zp, n + 1)
-    # q_1 = mask + r_alpha * summed - t * z over one multiplication domain (prover.rs:520-545)
-    mul = Domain(ctx, max(st.mask_poly.n, n + summed.n, n + z_poly.n))
-    e_r, e_s = mul.fft(ctx, r_alpha_poly), mul.fft(ctx, summed)
-    e_z, e_t = mul.fft(ctx, z_poly), mul.fft(ctx, st.t_poly)
-    ctx.fr_vec_op_dev(_lib.OP_MUL, e_r.ptr, e_s.ptr, e_r.ptr, mul.size)
+    # q_1 = mask + r_alpha * (eta_c z_a z_b + eta_a z_a + eta_b z_b) - t * z over one multiplication domain
+    # (prover.rs:458-545; summed_z_m has 2n + 1 coefficients, so the domain is the 4n one the reference picks)
+    mul = Domain(ctx, max(st.mask_poly.n, n + 2 * n + 1, n + z_poly.n))
+    e_a, e_b = mul.fft(ctx, st.z_a_poly), mul.fft(ctx, st.z_b_poly)
+    e_s = ctx.alloc(mul.size * 32)
+    batch_mul(e_a.ptr, e_b.ptr, e_s.ptr, mul.size)                    # z_c = z_a z_b: the one product of two witness vectors
+    ctx.fr_vec_scale_dev(e_s.ptr, m(eta_c), e_s.ptr, mul.size)
+    ctx.fr_vec_scale_dev(e_a.ptr, m(eta_a), e_a.ptr, mul.size)
+    ctx.fr_vec_op_dev(_lib.OP_ADD, e_s.ptr, e_a.ptr, e_s.ptr, mul.size)
+    ctx.fr_vec_scale_dev(e_b.ptr, m(eta_b), e_b.ptr, mul.size)
+    ctx.fr_vec_op_dev(_lib.OP_ADD, e_s.ptr, e_b.ptr, e_s.ptr, mul.size)
+    e_r, e_z, e_t = mul.fft(ctx, r_alpha_poly), mul.fft(ctx, z_poly), mul.fft(ctx, st.t_poly)
+    ctx.fr_vec_op_dev(_lib.OP_MUL, e_r.ptr, e_s.ptr, e_r.ptr, mul.size)      # public * own value: local
     ctx.fr_vec_op_dev(_lib.OP_MUL, e_z.ptr, e_t.ptr, e_z.ptr, mul.size)
     ctx.fr_vec_op_dev(_lib.OP_SUB, e_r.ptr, e_z.ptr, e_r.ptr, mul.size)
     q1 = mul.ifft_in_place(ctx, e_r)
     ctx.fr_vec_op_dev(_lib.OP_ADD, q1.ptr, st.mask_poly.ptr, q1.ptr, st.mask_poly.n)
     hq, hr = ctx.alloc((mul.size - n) * 32), ctx.alloc(n * 32)
     ctx.poly_divide_by_vanishing_dev(q1.ptr, mul.size, H.log, hq.ptr, hr.ptr)
-    if not ctx.fr_vec_is_zero_dev(hr.ptr, 1):
+    if not open_is_zero(hr.ptr, 1):
         raise ValueError("outer sum-check: the sum over H is not zero (unsatisfied constraint system)")
     st.first_msg = (alpha, eta_a, eta_b, eta_c)
     g_1 = DevPoly(hr, n - 1, 1)
@@ -436,10 +444,12 @@ def prover_third_round(st: ProverState, beta: int):
 
 def linear_combination(ctx: Context, polys, coeffs) -> DevPoly:
     """sum_i coeffs[i] * polys[i] (the combined polynomial of a batched opening, poly-commit/src/lib.rs batch_open)."""
-    n = max(p.n for p in polys)
+    n = max(p.n for p in polys if p is not None)
     out, tmp = ctx.alloc(n * 32), ctx.alloc(n * 32)
     ctx.dev_zero(out.ptr, n * 32)
     for p, k in zip(polys, coeffs):
+        if p is None:            # a public polynomial on a non-leading party: its term belongs to the leader's share
+            continue
         ctx.fr_vec_scale_dev(p.ptr, HostField.m(k), tmp.ptr, p.n)
         ctx.fr_vec_op_dev(_lib.OP_ADD, out.ptr, tmp.ptr, out.ptr, p.n)
     return DevPoly(out, n)

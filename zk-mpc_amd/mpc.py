@@ -389,6 +389,59 @@ class Party:
         return be.g1_serialize(A) + be.g2_serialize(B) + be.g1_serialize(C)
 
 
+    # ---- collaborative Marlin (AHP rounds over additive shares) ----
+    SHARED_POLYS = ("w", "z_a", "z_b", "mask_poly", "g_1", "h_1")     # the witness-dependent oracles; t, g_2, h_2 are public
+
+    def marlin_prove_shared(self, index, powers_g, z_share, randomness_share, challenge_fn, triple_fn=None) -> dict:
+        """Marlin::prove (arkworks/marlin/src/lib.rs:152-319) with F = MpcField over additive shares, on this party's GPU.
+
+        Every step of the AHP rounds is linear in the witness except z_A * z_B in round 2 (`DensePolynomial::mul` on
+        MpcField = FieldShare::batch_mul: one Beaver product of two vectors over the 4|H| multiplication domain); round 3
+        involves public values only.  Commitments / evaluations / opening witnesses of witness-dependent polynomials are
+        computed on the shares and revealed (`first_comms.publicize()`, `evaluations.publicize()` in the reference).
+
+        z_share: this party's share of the padded assignment (device vector, instance part shared like the rest);
+        randomness_share: this party's share of the prover's randomness (3 + 3|H| elements);
+        challenge_fn(round, revealed_commitments) -> dict of challenges (the Fiat-Shamir transcript stays with the caller);
+        triple_fn(n) -> (tx, ty, tz) device vectors, or None for the reference's DummyFieldTripleSource."""
+        from . import marlin as DM
+        be = self.be
+        ctx = be.ctx
+        m = DM.HostField.m
+
+        def reveal_some(comms):
+            return {l: (self.reveal_g1(c) if l in self.SHARED_POLYS else c) for l, c in comms.items()}
+
+        def open_is_zero(v, n):
+            tmp = be.vec("marlin_open", n)
+            be.open_vec(v, tmp, n)
+            return be.is_zero_vec(tmp, n)
+
+        def batch_mul(x, y, out, n):
+            self.beaver_batch_mul(x, y, out, n, triple_fn(n) if triple_fn else None)
+
+        st = DM.prover_init(index, z_share, shared=True)
+        r1 = DM.prover_first_round(st, randomness_share)
+        comms = reveal_some(DM.commit(ctx, powers_g, r1))
+        ch = dict(challenge_fn(1, comms))
+        r2 = DM.prover_second_round(st, ch["alpha"], ch["eta_a"], ch["eta_b"], ch["eta_c"], batch_mul=batch_mul, open_is_zero=open_is_zero)
+        comms.update(reveal_some(DM.commit(ctx, powers_g, r2)))
+        ch.update(challenge_fn(2, comms))
+        r3 = DM.prover_third_round(st, ch["beta"])
+        comms.update(DM.commit(ctx, powers_g, r3))
+        ch.update(challenge_fn(3, comms))
+        polys = {**r1, **r2, **r3}
+        ev = lambda l, pt: ctx.poly_evaluate_dev(polys[l].ptr, polys[l].n, m(pt))
+        evals = {"g_1": self._open_fr(ev("g_1", ch["beta"])), "z_b": self._open_fr(ev("z_b", ch["beta"])),
+                 "t": ev("t", ch["beta"]), "g_2": ev("g_2", ch["gamma"])}
+        mine = lambda l: polys[l] if (l in self.SHARED_POLYS or self.leader) else None
+        at_beta = [mine(l) for l in ("g_1", "z_b", "t", "mask_poly", "z_a", "w", "h_1")]
+        ixp = index.polynomials()
+        at_gamma = [polys["g_2"], polys["h_2"]] + [ixp[l] for l in sorted(ixp)]
+        w_beta, w_gamma = DM.batch_open(ctx, powers_g, [(at_beta, ch["beta"]), (at_gamma, ch["gamma"])], ch["xi"])
+        return {"commitments": comms, "evaluations": evals, "w_beta": self.reveal_g1(w_beta), "w_gamma": w_gamma, "challenges": ch}
+
+
 # ------------------------------------------------------------------------------------------------
 # SPDZ (malicious-majority backend): every share carries a MAC share; opens are MAC-checked
 # ------------------------------------------------------------------------------------------------
