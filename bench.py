@@ -79,7 +79,93 @@ def pk_bases(ctx, pk, which):
     import ctypes as C
     from zk_mpc_amd.api import Bases
     h = C.c_void_p(ctx.lib.zk_pk_query_bases(pk.h, {"a": 0, "b_g1": 1, "b_g2": 2, "h": 3, "l": 4}[which]))
-    return Bases(ctx, h, 2 if which == "b_g2" else 1)
+    return Bases(ctx, h, 2 if which == "b_g2" else 1, owned=False)
+
+
+def other_workloads(ctx, log_h=20):
+    """Rows a14 / a15 beside the headline metric (not part of `value`): Marlin AHP prover + KZG10 commitments / openings on
+    the same mul-chain family (BASELINE config 4 shape), and the SHE ciphertext product.  Same code as
+    tools/bench_marlin.py / tools/bench_she.py, fewer repetitions."""
+    import numpy as np
+    from zk_mpc_amd import marlin as DM
+    out = {}
+    rng = np.random.default_rng(11)
+    m = DM.HostField.m
+
+    def rand_fr(k):
+        a = rng.integers(0, 1 << 63, size=(k, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+    try:
+        n = (1 << log_h) - 3
+        ni, nw, a, b, c = DM.mul_chain_system(ctx, n)
+        index = DM.Index(ctx, ni, nw, a, b, c)
+        H = index.dom_h.size
+        deg = 3 * max(H, index.dom_k.size) + 2
+        pw = ctx.alloc(deg * 32)
+        ctx.fr_powers_dev(m(0x1234567), m(1), deg, pw.ptr)
+        powers_g = ctx.fixed_base(pw.ptr, deg, 1, m(1))
+        z = ctx.mul_chain_assignment_dev(n, m(3), m(5))
+        rnd = ctx.upload(rand_fr(3 + 3 * H))
+        ch = {k: int(rng.integers(2, 1 << 62)) for k in ("alpha", "eta_a", "eta_b", "eta_c", "beta", "gamma", "xi")}
+        ctx.pooling = True
+
+        def prove():
+            st = DM.prover_init(index, z)
+            polys = dict(DM.prover_first_round(st, rnd))
+            comms = DM.commit(ctx, powers_g, polys)
+            r2 = DM.prover_second_round(st, ch["alpha"], ch["eta_a"], ch["eta_b"], ch["eta_c"])
+            comms.update(DM.commit(ctx, powers_g, r2))
+            r3 = DM.prover_third_round(st, ch["beta"])
+            comms.update(DM.commit(ctx, powers_g, r3))
+            polys.update(r2)
+            polys.update(r3)
+            for l, pt in (("g_1", "beta"), ("z_b", "beta"), ("t", "beta"), ("g_2", "gamma")):
+                ctx.poly_evaluate_dev(polys[l].ptr, polys[l].n, m(ch[pt]))
+            ixp = index.polynomials()
+            DM.batch_open(ctx, powers_g, [([polys[l] for l in ("g_1", "z_b", "t", "mask_poly", "z_a", "w", "h_1")], ch["beta"]),
+                                          ([polys["g_2"], polys["h_2"]] + [ixp[l] for l in sorted(ixp)], ch["gamma"])], ch["xi"])
+        prove()
+        ctx.sync()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            prove()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        ctx.pooling = False
+        ctx.drop_pool()
+        out["marlin"] = {"workload": "Marlin AHP prover + 9 KZG10 commitments + 2 batched openings, mul-chain R1CS, |H| = |K| = 2^%d, "
+                                     "index and SRS resident, challenges supplied by the caller" % log_h,
+                         "constraints": n, "ms_per_proof": round(dt * 1e3, 2), "constraints_per_s": round(n / dt, 1)}
+        del index, powers_g, pw, z, rnd
+    except Exception as e:  # the headline line must not depend on this leg
+        ctx.pooling = False
+        out["marlin"] = {"error": repr(e)}
+    try:
+        N, batch = 1024, 2048
+
+        def rnd753(k):
+            a = rng.integers(0, 1 << 63, size=(k, 12), dtype=np.uint64)
+            a[:, 11] &= np.uint64((1 << 46) - 1)
+            return a
+        x, y = ctx.upload(rnd753(batch * 3 * N)), ctx.upload(rnd753(batch * 3 * N))
+        o = ctx.alloc(batch * 3 * N * 96)
+        ctx.ciphertext_mul_dev(x.ptr, y.ptr, o.ptr, N, batch)
+        ctx.sync()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            ctx.ciphertext_mul_dev(x.ptr, y.ptr, o.ptr, N, batch)
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / reps
+        mmuls = (7 * (N // 2) * 10 + 7 * N) * batch
+        out["she"] = {"workload": "Ciphertext::mul in F_q[X]/(X^N+1), q = MNT4-753 base prime, N = %d, batch %d" % (N, batch),
+                      "products_per_s": round(batch / dt, 1), "fq753_modmul_per_s": round(mmuls / dt, 1),
+                      "frac_of_int_mad_peak": round(mmuls / dt * 2 * 26 * 26 / INT_MAD_PEAK, 3)}
+    except Exception as e:
+        out["she"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -91,6 +177,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-mpc", action="store_true", help="run the collaborative code path even with one rank (1-party: exercises transport + share plumbing)")
     ap.add_argument("--cpu-sample-log", type=int, default=16)
+    ap.add_argument("--no-extras", action="store_true", help="skip the Marlin / SHE side measurements")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE JSON line: libraries (RCCL prints a version banner on stdout at communicator
@@ -232,6 +319,8 @@ def main():
                 ctx.sync()
                 msm[name] = round(m * reps / (time.perf_counter() - t1) / 1e6, 1)
             out["msm_mscalar_per_s"] = dict(msm, n=n, note="single MSM per call incl. host round trip, bases resident")
+        if dist is None and not args.no_extras:
+            out["other_workloads"] = other_workloads(ctx, min(args.log_constraints, 20))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(ctx, td, args.cpu_sample_log, os.cpu_count() or 1)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
