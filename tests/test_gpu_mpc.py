@@ -241,3 +241,56 @@ def test_collaborative_marlin(n_parties, n):
         ctx.close()
     # every party saw the same revealed commitments before each challenge
     assert all(s == seen[0] for s in seen)
+
+
+@pytest.mark.parametrize("n_parties,n", [(2, 6), (3, 40)])
+def test_collaborative_marlin_spdz(n_parties, n):
+    """Marlin over SPDZ shares (two lanes, MAC-checked opens): the same revealed outputs as the additive run above on the
+    same inputs, and a corrupted MAC share of the witness is detected."""
+    import marlin_ref as M
+    from zk_mpc_amd import marlin as DM
+    rng = O.Prng(1200 + n)
+    r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
+    sq, zz = M.pad_and_square(r1cs, z)
+    H = M.next_pow2(sq.num_constraints)
+    rnd = [rng.fr() for _ in range(3 + 3 * H)]
+    zs, zm = additive_shares(zz, n_parties, rng), additive_shares(zz, n_parties, rng)       # key alpha = 1: mac shares sum to z
+    rs, rm = additive_shares(rnd, n_parties, rng), additive_shares(rnd, n_parties, rng)
+    chal = {1: {k: rng.fr() for k in ("alpha", "eta_a", "eta_b", "eta_c")}, 2: {"beta": rng.fr()}, 3: {"gamma": rng.fr(), "xi": rng.fr()}}
+    beta_srs = rng.fr()
+    a, b, c = DM.Csr.from_rows(sq.a), DM.Csr.from_rows(sq.b), DM.Csr.from_rows(sq.c)
+
+    def setup(ctx):
+        index = DM.Index(ctx, sq.num_instance, sq.num_witness, a, b, c)
+        deg = 3 * max(index.dom_h.size, index.dom_k.size) + 2
+        pw = ctx.alloc(deg * 32)
+        ctx.fr_powers_dev(mont1(beta_srs), mont1(1), deg, pw.ptr)
+        return index, ctx.fixed_base(pw.ptr, deg, 1, mont1(1))
+
+    def flat(out):
+        return ({l: cv.g1_projective_to_affine(c) for l, c in out["commitments"].items()},
+                {l: cv.fr_from_mont(np.asarray(v).reshape(1, 4))[0] for l, v in out["evaluations"].items()},
+                cv.g1_projective_to_affine(out["w_beta"]), cv.g1_projective_to_affine(out["w_gamma"]))
+
+    def fn(p, ctx, net):
+        party = mpc.SpdzParty(ctx, net=net)
+        index, powers_g = setup(ctx)
+        up = lambda v: ctx.upload(cv.fr_to_mont(v))
+        spdz = flat(party.marlin_prove_shared_spdz(index, powers_g, (up(zs[p]), up(zm[p])), (cv.fr_to_mont(rs[p]), cv.fr_to_mont(rm[p])),
+                                                   lambda k, comms: chal[k]))
+        additive = flat(party.marlin_prove_shared(index, powers_g, up(zs[p]), cv.fr_to_mont(rs[p]), lambda k, comms: chal[k]))
+        bad = cv.fr_to_mont(zm[p])
+        if p == n_parties - 1:
+            bad[3, 0] ^= np.uint64(1)
+        try:
+            party.marlin_prove_shared_spdz(index, powers_g, (up(zs[p]), ctx.upload(bad)), (cv.fr_to_mont(rs[p]), cv.fr_to_mont(rm[p])),
+                                           lambda k, comms: chal[k])
+            caught = False
+        except mpc.MacCheckError:
+            caught = True
+        return spdz, additive, caught
+
+    res = run_parties(n_parties, fn)
+    assert all(r[0] == res[0][0] for r in res)
+    assert res[0][0] == res[0][1]           # SPDZ run == additive run (which test_collaborative_marlin ties to the single prover)
+    assert all(r[2] for r in res)

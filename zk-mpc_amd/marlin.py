@@ -344,14 +344,33 @@ def prover_second_round(st: ProverState, alpha: int, eta_a: int, eta_b: int, eta
     """prover.rs:438-565.  batch_mul(x_dev, y_dev, out_dev, n): element-wise product of two vectors of the prover's own
     values (default: the local product; over shares: FieldShare::batch_mul, as `DensePolynomial::mul` on MpcField does
     through batch_product_in_place).  open_is_zero(v_dev, n): whether the (shared) vector opens to zero."""
-    ix = st.index
-    ctx, H, X, F = ix.ctx, ix.dom_h, ix.dom_x, ix.dom_h.F
-    n = H.size
-    m = HostField.m
+    ctx = st.index.ctx
     if batch_mul is None:
         batch_mul = lambda x, y, out, k: ctx.fr_vec_op_dev(_lib.OP_MUL, x, y, out, k)
     if open_is_zero is None:
         open_is_zero = lambda v, k: ctx.fr_vec_is_zero_dev(v, k)
+    steps = second_round_steps(st, alpha, eta_a, eta_b, eta_c)
+    req = next(steps)
+    try:
+        while True:
+            if req[0] == "mul":
+                batch_mul(*req[1:])
+                req = steps.send(None)
+            else:
+                req = steps.send(open_is_zero(*req[1:]))
+    except StopIteration as done:
+        return done.value
+
+
+def second_round_steps(st: ProverState, alpha: int, eta_a: int, eta_b: int, eta_c: int):
+    """The second round as a generator that hands the two witness-dependent operations to its driver:
+    yields ("mul", x_dev, y_dev, out_dev, n) for z_A * z_B on the multiplication domain, then ("zero", v_dev, n) and
+    expects the answer (bool) to be sent back; returns the round's oracles.  Lets a SPDZ prover advance its share lane and
+    its MAC lane in lock-step around one joint Beaver multiplication."""
+    ix = st.index
+    ctx, H, X, F = ix.ctx, ix.dom_h, ix.dom_x, ix.dom_h.F
+    n = H.size
+    m = HostField.m
     # r(alpha, X) on H: v_H(alpha) / (alpha - h)   (mod.rs:352-360)
     v_h_alpha = H.evaluate_vanishing_polynomial(alpha)
     ra = ctx.alloc(n * 32)
@@ -383,7 +402,7 @@ def prover_second_round(st: ProverState, alpha: int, eta_a: int, eta_b: int, eta
     mul = Domain(ctx, max(st.mask_poly.n, n + 2 * n + 1, n + z_poly.n))
     e_a, e_b = mul.fft(ctx, st.z_a_poly), mul.fft(ctx, st.z_b_poly)
     e_s = ctx.alloc(mul.size * 32)
-    batch_mul(e_a.ptr, e_b.ptr, e_s.ptr, mul.size)                    # z_c = z_a z_b: the one product of two witness vectors
+    yield ("mul", e_a.ptr, e_b.ptr, e_s.ptr, mul.size)                # z_c = z_a z_b: the one product of two witness vectors
     ctx.fr_vec_scale_dev(e_s.ptr, m(eta_c), e_s.ptr, mul.size)
     ctx.fr_vec_scale_dev(e_a.ptr, m(eta_a), e_a.ptr, mul.size)
     ctx.fr_vec_op_dev(_lib.OP_ADD, e_s.ptr, e_a.ptr, e_s.ptr, mul.size)
@@ -397,7 +416,7 @@ def prover_second_round(st: ProverState, alpha: int, eta_a: int, eta_b: int, eta
     ctx.fr_vec_op_dev(_lib.OP_ADD, q1.ptr, st.mask_poly.ptr, q1.ptr, st.mask_poly.n)
     hq, hr = ctx.alloc((mul.size - n) * 32), ctx.alloc(n * 32)
     ctx.poly_divide_by_vanishing_dev(q1.ptr, mul.size, H.log, hq.ptr, hr.ptr)
-    if not open_is_zero(hr.ptr, 1):
+    if not (yield ("zero", hr.ptr, 1)):
         raise ValueError("outer sum-check: the sum over H is not zero (unsatisfied constraint system)")
     st.first_msg = (alpha, eta_a, eta_b, eta_c)
     g_1 = DevPoly(hr, n - 1, 1)

@@ -549,6 +549,62 @@ class SpdzParty(Party):
             out.append(t)
         return tuple(out)
 
+    def marlin_prove_shared_spdz(self, index, powers_g, z_share, randomness_share, challenge_fn, triple_fn=None) -> dict:
+        """Marlin::prove over SPDZ shares (the `malicious` feature, BASELINE config 5 shape): the AHP rounds run on the
+        share lane and on the MAC lane; the two lanes meet in the one Beaver multiplication of round 2 (SPDZ batch_mul:
+        both opens MAC-checked) and in the MAC-checked opens of commitments, evaluations and the opening witness.
+        z_share, randomness_share: (sh, mac) pairs; triple_fn(n) -> ((tx_sh, tx_mac), (ty..), (tz..)) or None (dummy)."""
+        from . import marlin as DM
+        be = self.be
+        ctx = be.ctx
+        m = DM.HostField.m
+        lanes = (0, 1)
+        shared = Party.SHARED_POLYS
+
+        def commit_open(polys2):
+            c = [DM.commit(ctx, powers_g, polys2[lane]) for lane in lanes]
+            return {l: (self.spdz_open_g1((c[0][l], c[1][l])) if l in shared else c[0][l]) for l in c[0]}
+
+        st = [DM.prover_init(index, z_share[lane], shared=True) for lane in lanes]
+        r1 = [DM.prover_first_round(st[lane], randomness_share[lane]) for lane in lanes]
+        comms = commit_open(r1)
+        ch = dict(challenge_fn(1, comms))
+        steps = [DM.second_round_steps(st[lane], ch["alpha"], ch["eta_a"], ch["eta_b"], ch["eta_c"]) for lane in lanes]
+        req = [next(g) for g in steps]                                   # both lanes stop at z_A * z_B
+        n_mul = req[0][4]
+        self.spdz_beaver_batch_mul((req[0][1], req[1][1]), (req[0][2], req[1][2]), (req[0][3], req[1][3]), n_mul,
+                                   triple_fn(n_mul) if triple_fn else None)
+        req = [g.send(None) for g in steps]                              # ... and at the zero test of the sum over H
+        opened = be.vec("marlin_open", req[0][2])
+        self.spdz_open_vec((req[0][1], req[1][1]), opened, req[0][2])
+        ok = be.is_zero_vec(opened, req[0][2])
+        r2 = []
+        for g in steps:
+            try:
+                g.send(ok)
+                raise RuntimeError("second round did not finish")
+            except StopIteration as done:
+                r2.append(done.value)
+        comms.update(commit_open(r2))
+        ch.update(challenge_fn(2, comms))
+        r3 = DM.prover_third_round(st[0], ch["beta"])                    # public values only: one lane suffices
+        comms.update(DM.commit(ctx, powers_g, r3))
+        ch.update(challenge_fn(3, comms))
+        polys = [{**r1[lane], **r2[lane], **r3} for lane in lanes]
+        ev = lambda lane, l, pt: ctx.poly_evaluate_dev(polys[lane][l].ptr, polys[lane][l].n, m(pt))
+        evals = {l: self.spdz_open_fr((ev(0, l, ch["beta"]), ev(1, l, ch["beta"]))) for l in ("g_1", "z_b")}
+        evals["t"], evals["g_2"] = ev(0, "t", ch["beta"]), ev(0, "g_2", ch["gamma"])
+        # public polynomials enter a shared combination through shift(): on the leader, in both lanes (mac_share = 1 there)
+        mine = lambda lane, l: polys[lane][l] if (l in shared or self.leader) else None
+        ixp = index.polynomials()
+        at_gamma = [polys[0]["g_2"], polys[0]["h_2"]] + [ixp[l] for l in sorted(ixp)]
+        w = []
+        for lane in lanes:
+            at_beta = [mine(lane, l) for l in ("g_1", "z_b", "t", "mask_poly", "z_a", "w", "h_1")]
+            w.append(DM.batch_open(ctx, powers_g, [(at_beta, ch["beta"])] + ([(at_gamma, ch["gamma"])] if lane == 0 else []), ch["xi"]))
+        return {"commitments": comms, "evaluations": evals, "w_beta": self.spdz_open_g1((w[0][0], w[1][0])), "w_gamma": w[0][1],
+                "challenges": ch}
+
     def create_proof_shared_spdz(self, pk, r1cs, z_share, r_share, s_share, triple=None) -> bytes:
         """create_proof with E = MpcPairingEngine<_, SpdzPairingShare> (the `malicious` feature).
         z_share = (sh, mac) device vectors; r_share, s_share = (sh, mac) scalars."""
