@@ -103,10 +103,13 @@ int zk_msm_g2(zk_ctx* ctx, const zk_g2_affine* bases_host, size_t n_bases,
 int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* bases_host, size_t n, zk_bases** out);
 int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* bases_host, size_t n, zk_bases** out);
 int zk_bases_free(zk_ctx* ctx, zk_bases* b);
-/* Trade HBM for work on a resident table: store 2^(16w)*base_i for w < 16 (16x the memory) so that all
- * windows of later MSMs share one bucket set.  No-op for tables under 4096 points.  zk_pk_upload /
- * zk_groth16_setup apply it to the proving-key queries only when ZK_PRECOMP=1 (measured: no gain at 2^20). */
+/* Trade HBM for work on a resident table: store 2^(c w) * base_i for w < ceil(255 / c), c ~ log2(n) capped at 20
+ * (13x the memory at 2^20), so that all digits of later MSMs share ONE bucket set and a scalar has 13 digits instead
+ * of 16.  No-op for tables under 4096 points.  zk_pk_upload / zk_groth16_setup apply it to proving-key queries of
+ * >= 2^16 points unless ZK_PRECOMP=0 (measured at 2^20: 35.9 -> 32.4 ms per proof). */
 int zk_bases_precompute(zk_ctx* ctx, zk_bases* b);
+/* Window width of the table's precomputed multiples (0: none): MSMs over it use ceil(255 / c) digits per scalar. */
+uint32_t zk_bases_window_bits(const zk_bases* b);
 size_t zk_bases_len(const zk_bases* b);
 /* out = sum_{i<n} scalars[i] * bases[base_offset + i]; scalars_dev: n Montgomery zk_fr on device. */
 int zk_msm_g1_dev(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev,

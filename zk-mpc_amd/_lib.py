@@ -98,6 +98,7 @@ PROTOTYPES = {
     "zk_bases_free": (_I, [_P, _P]),
     "zk_bases_precompute": (_I, [_P, _P]),
     "zk_bases_len": (_SZ, [_P]),
+    "zk_bases_window_bits": (_U32, [_P]),
     "zk_msm_g1_dev": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
     "zk_msm_g2_dev": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
     "zk_fixed_base_g1_dev": (_I, [_P, _P, _P, _SZ, C.POINTER(_P)]),

@@ -164,23 +164,47 @@ extern "C" int zk_fixed_base_g2_dev(zk_ctx* ctx, const zk_fr* gen_k, const void*
     return fixed_base_run<G2Field>(ctx, g2_generator(), gen_k, scalars, n, 2, out);
 }
 
-// Window multiples 2^(16 w) * base_i for w < 16, for proving-key queries that stay resident (288 GB of HBM:
-// a 2^20-point G1 query grows from 96 MiB to 1.5 GiB).  Setup-time cost ~16 doublings + one batched
-// normalisation per stored point.  Disabled with ZK_PRECOMP=0.
+// Window multiples 2^(c w) * base_i, w < W = ceil(255 / c), for tables that stay resident (proving-key queries, an SRS).
+// With them all W digits of a scalar drop into ONE bucket set, so the window can be as wide as c ~ log2(n) -- W falls
+// from 16 to 13 at n = 2^20 (19 % fewer mixed additions) while the bucket count stays ~ n/2 -- and only one set of
+// buckets is reduced.  288 GB of HBM is what pays for it: a 2^20-point G1 query grows from 96 MiB to 1.2 GiB.
+// Measured at n = 2^20 (whole Groth16 proof): 35.9 ms without, 32.1 ms with c = 20.  c = 16 tables (the first attempt)
+// did not pay: same number of additions, 16x the gather footprint.
+// The top window must keep >= 10 significant bits: 255 - c (W - 1) of only 3 bits (c = 18, 21) sends every point into
+// <= 8 buckets and the sort's atomics serialise (65 ms instead of 32).
+static uint32_t precompute_window_bits(size_t n) {
+    static const int env_c = getenv("ZK_PRECOMP_C") ? atoi(getenv("ZK_PRECOMP_C")) : 0;   // experiments
+    if (env_c >= 8 && env_c <= 24) return (uint32_t)env_c;
+    uint32_t lg = 0;                                   // round(log2 n): a 2^20 - 1 point query is a 2^20 one
+    while (((size_t)3 << lg) <= 2 * n) lg++;
+    int c0 = (int)lg - 1;      // measured on whole proofs: 2^16 -> 15, 2^18 -> 16/17, 2^20..2^22 -> 20 (22 loses: 4x the buckets)
+    if (c0 < 13) c0 = 13;
+    if (c0 > 20) c0 = 20;
+    const int tries[6] = {0, -1, 1, -2, 2, -3};
+    for (int t : tries) {
+        int c = c0 + t;
+        if (c < 12 || c > 20) continue;
+        int W = (255 + c - 1) / c;
+        if (255 - c * (W - 1) >= 10) return (uint32_t)c;
+    }
+    return 16;
+}
+
 static int precompute_enabled_by_default() {
     const char* e = getenv("ZK_PRECOMP");
-    return e && atoi(e) != 0;
+    return !e || atoi(e) != 0;
 }
-int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b) { return precompute_enabled_by_default() ? zk_bases_precompute(ctx, b) : ZK_OK; }
+// Resident proving-key queries get their window multiples at upload / setup time (ZK_PRECOMP=0 turns it off).
+int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b) {
+    return (precompute_enabled_by_default() && b && b->n >= ((size_t)1 << 16)) ? zk_bases_precompute(ctx, b) : ZK_OK;
+}
+
+extern "C" uint32_t zk_bases_window_bits(const zk_bases* b) { return b ? b->c_pre : 0; }
 
 extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b) {
     if (!ctx) return ZK_ERR_ARG;
     if (!b || b->pre || b->n < 4096) return ZK_OK;
-    // Off by default: measured on MI355X at n = 2^20 it does not pay (37.1 vs 36.0 ms per proof): the 16x larger
-    // table no longer sits in the 256 MiB Infinity Cache, and k_accum's gathers slow down by more than the
-    // bucket-reduce work that is saved.  ZK_PRECOMP=1 enables it; explicit zk_bases_precompute calls always run.
-    (void)0;
-    const uint32_t c = 16, W = 16;
+    const uint32_t c = precompute_window_bits(b->n), W = (255 + c - 1) / c;
     if (b->group == 1) return precompute_t<G1Field>(ctx, b, c, W);
     return precompute_t<G2Field>(ctx, b, c, W);
 }

@@ -184,6 +184,83 @@ k_scan(const uint32_t* counts, uint32_t* offs, uint32_t* seg_local, uint32_t* wi
     }
 }
 
+// The same scan for a big bucket set (merged mode: one window of 2^19 buckets), over several blocks: chunk totals,
+// a scan of the totals, then the scan inside each chunk.  One 1024-thread block walking 2^19 counters alone took
+// 1.2 ms, on the critical path in front of the first accumulate kernel.
+constexpr uint32_t SCAN_CHUNK = 8192;   // 1024 threads x 8 consecutive counters
+
+__device__ __forceinline__ uint32_t segs_of(uint32_t c, uint32_t seg) { return c ? (c + seg - 1) / seg : 1; }
+
+// block-wide inclusive scan of one value pair per thread (1024 threads)
+__device__ __forceinline__ void block_scan2(uint32_t* part, uint32_t* part2, uint32_t tid) {
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = tid >= d ? part[tid - d] : 0, v2 = tid >= d ? part2[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        part2[tid] += v2;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan_sums(const uint32_t* counts, uint32_t NB, uint32_t seg, uint32_t nchunks, uint32_t* sums) {
+    __shared__ uint32_t part[1024], part2[1024];
+    const uint32_t w = blockIdx.x / nchunks, ch = blockIdx.x % nchunks, tid = threadIdx.x;
+    uint32_t s = 0, s2 = 0;
+    for (uint32_t k = 0; k < 8; k++) {
+        uint32_t b = ch * SCAN_CHUNK + k * 1024 + tid;           // totals only: any order, so read coalesced
+        if (b < NB) { uint32_t c = counts[(size_t)w * NB + b]; s += c; s2 += segs_of(c, seg); }
+    }
+    part[tid] = s;
+    part2[tid] = s2;
+    block_scan2(part, part2, tid);
+    if (tid == 1023) { sums[2 * blockIdx.x] = part[1023]; sums[2 * blockIdx.x + 1] = part2[1023]; }
+}
+
+// one block per window: exclusive scan of the chunk totals in place (nchunks <= 1024)
+__global__ void __launch_bounds__(1024) k_scan_tops(uint32_t* sums, uint32_t nchunks) {
+    __shared__ uint32_t part[1024], part2[1024];
+    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    uint32_t v = tid < nchunks ? sums[2 * ((size_t)w * nchunks + tid)] : 0, v2 = tid < nchunks ? sums[2 * ((size_t)w * nchunks + tid) + 1] : 0;
+    part[tid] = v;
+    part2[tid] = v2;
+    block_scan2(part, part2, tid);
+    if (tid < nchunks) { sums[2 * ((size_t)w * nchunks + tid)] = part[tid] - v; sums[2 * ((size_t)w * nchunks + tid) + 1] = part2[tid] - v2; }
+}
+
+__global__ void __launch_bounds__(1024)
+k_scan_fill(const uint32_t* counts, const uint32_t* sums, uint32_t* offs, uint32_t* seg_local, uint32_t* win_segs, uint32_t NB,
+            uint32_t seg, uint32_t nchunks) {
+    __shared__ uint32_t part[1024], part2[1024];
+    const uint32_t w = blockIdx.x / nchunks, ch = blockIdx.x % nchunks, tid = threadIdx.x;
+    const uint32_t lo = ch * SCAN_CHUNK + tid * 8;
+    uint32_t c[8], s = 0, s2 = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        c[k] = lo + k < NB ? counts[(size_t)w * NB + lo + k] : 0;
+        s += c[k];
+        s2 += lo + k < NB ? segs_of(c[k], seg) : 0;
+    }
+    part[tid] = s;
+    part2[tid] = s2;
+    block_scan2(part, part2, tid);
+    uint32_t run = sums[2 * blockIdx.x] + part[tid] - s, run2 = sums[2 * blockIdx.x + 1] + part2[tid] - s2;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) {
+        if (lo + k < NB) {
+            offs[(size_t)w * (NB + 1) + lo + k] = run;
+            seg_local[(size_t)w * NB + lo + k] = run2;
+            run += c[k];
+            run2 += segs_of(c[k], seg);
+        }
+    }
+    if (ch == nchunks - 1 && tid == 1023) {
+        offs[(size_t)w * (NB + 1) + NB] = sums[2 * blockIdx.x] + part[1023];
+        win_segs[w] = sums[2 * blockIdx.x + 1] + part2[1023];
+    }
+}
+
 // ctr[0] = heavy buckets, ctr[1] = heavy segments, ctr[2] = total segments; hist[len] = #segments of that length
 __global__ void __launch_bounds__(256)
 k_build_segs(const uint32_t* offs, const uint32_t* seg_local, const uint32_t* win_segs, size_t n, uint32_t W, uint32_t NB,
@@ -384,14 +461,16 @@ k_reduce(const uint32_t* S_in, const uint32_t* W_in, uint32_t* S_out, uint32_t* 
 // strided serial adds, then an LDS tree.  Depth ~ T/256 + 8 additions instead of ~24 per extra chunk level.
 template <class F>
 __global__ void __launch_bounds__(256)
-k_bitsum(const uint32_t* S_in, const uint32_t* W_in, uint32_t* out, uint32_t T, uint32_t nbits) {
+k_bitsum(const uint32_t* S_in, const uint32_t* W_in, uint32_t* out, uint32_t T, uint32_t nbits, uint32_t nout) {
     constexpr int XW = 4 * F::WORDS;
     extern __shared__ uint32_t lds[];  // 256 * XW words
-    const uint32_t w = blockIdx.x / (nbits + 1), j = blockIdx.x % (nbits + 1);
+    const uint32_t w = blockIdx.x / nout, j = blockIdx.x % nout;   // nout = nbits + 1, or nbits + 2 with the plain sum of S
     const uint32_t tid = threadIdx.x;
     XYZZ<F> acc = xyzz_inf<F>();
     if (j == nbits) {
         for (uint32_t t = tid; t < T; t += 256) acc = xyzz_add<F>(acc, xyzz_load16<F>(W_in, (size_t)w * T + t));
+    } else if (j == nbits + 1) {
+        for (uint32_t t = tid; t < T; t += 256) acc = xyzz_add<F>(acc, xyzz_load16<F>(S_in, (size_t)w * T + t));
     } else {
         for (uint32_t t = tid; t < T; t += 256)
             if ((t >> j) & 1) acc = xyzz_add<F>(acc, xyzz_load16<F>(S_in, (size_t)w * T + t));
@@ -470,7 +549,12 @@ int msm_prepare_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base
     uint32_t seg = 32;
     while (seg < per_lane && seg < 4096) seg <<= 1;
     job->seg = seg;
-    job->T1 = (p.NB + (1u << REDUCE_K_LOG) - 1) >> REDUCE_K_LOG;
+    // Reduce phase geometry.  A merged bucket set of 2^(c-1) > 2^15 buckets is cut into "virtual windows" of 2^15:
+    // sum_b b B_b = sum_v [ R_v + v 2^15 S_v ] with R_v the ordinary window sum of slice v and S_v its plain sum, so the
+    // kernels keep the grid shapes they have for 16 real windows (one slice per block row) instead of one long chain.
+    job->RNB = (merged && p.NB > 32768u) ? 32768u : p.NB;
+    job->Rw = job->Wb * (p.NB / job->RNB);
+    job->T1 = (job->RNB + (1u << REDUCE_K_LOG) - 1) >> REDUCE_K_LOG;
     uint32_t nbits = 0;
     while ((1u << nbits) < job->T1) nbits++;
     job->nbits = nbits;
@@ -500,9 +584,9 @@ int msm_bufs_t(zk_ctx* ctx, ZkMsmJob* job, MsmBufs<F>& b, bool need_sort) {
         ZK_TRY(zk_scratch(ctx, slotname("msm_order"), job->max_segs * 4, (void**)&b.order));
     }
     ZK_TRY(zk_scratch(ctx, slotname("msm_sums"), (nbuck + max_heavy_segs) * XW * 4, (void**)&b.sums));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_lvS"), Wb * job->T1 * XW * 4, (void**)&b.lvS));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_lvW"), Wb * job->T1 * XW * 4, (void**)&b.lvW));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_bits"), Wb * (job->nbits + 1) * XW * 4, (void**)&b.bits));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_lvS"), (size_t)job->Rw * job->T1 * XW * 4, (void**)&b.lvS));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_lvW"), (size_t)job->Rw * job->T1 * XW * 4, (void**)&b.lvW));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_bits"), (size_t)job->Rw * (job->nbits + 2) * XW * 4, (void**)&b.bits));
     return ZK_OK;
 }
 
@@ -542,7 +626,19 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     ZK_HIP(ctx, hipMemsetAsync(b.counts, 0, nbuck * 4, st));
     ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 4 + 3 * (size_t)(seg + 1)) * 4, st));
     hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, b.counts, merged);
-    hipLaunchKernelGGL(k_scan, Wb, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NB, seg);
+    if (NB <= 65536) {
+        hipLaunchKernelGGL(k_scan, Wb, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NB, seg);
+    } else {
+        const uint32_t nchunks = (uint32_t)((NB + SCAN_CHUNK - 1) / SCAN_CHUNK);
+        uint32_t* sums;
+        char nm2[64];
+        snprintf(nm2, sizeof nm2, "msm_scan_sums.%d", job->slot);
+        ZK_TRY(zk_scratch(ctx, nm2, (size_t)Wb * nchunks * 8, (void**)&sums));
+        hipLaunchKernelGGL(k_scan_sums, Wb * nchunks, 1024, 0, st, b.counts, (uint32_t)NB, seg, nchunks, sums);
+        hipLaunchKernelGGL(k_scan_tops, Wb, 1024, 0, st, sums, nchunks);
+        hipLaunchKernelGGL(k_scan_fill, Wb * nchunks, 1024, 0, st, b.counts, (const uint32_t*)sums, b.offs, b.seg_local, win_segs, (uint32_t)NB,
+                           seg, nchunks);
+    }
     hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted, merged,
                        job->n_tab, job->tab_off);
     hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
@@ -594,26 +690,27 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     tm->begin(g1 ? "msm_g1.reduce" : "msm_g2.reduce");
     hipLaunchKernelGGL(k_fold_light<F>, (unsigned)std::min<size_t>((job->max_heavy + 63) / 64, 512), 64, 0, st,
                        (const HeavyDesc*)job->heavy, job->ctr, b.sums);
-    hipLaunchKernelGGL(k_fold_heavy<F>, (unsigned)std::min<size_t>(job->max_heavy, 64), 64, 64 * XW * 4, st,
+    hipLaunchKernelGGL(k_fold_heavy<F>, (unsigned)std::min<size_t>(job->max_heavy, 1024), 64, 64 * XW * 4, st,
                        (const HeavyDesc*)job->heavy, job->ctr, b.sums);
-    const size_t threads = (size_t)job->Wb * job->T1;
-    hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, b.sums, nullptr, b.lvS, b.lvW, job->NB, job->T1,
-                       (uint32_t)REDUCE_K_LOG, job->Wb, 1, 0);
+    const size_t threads = (size_t)job->Rw * job->T1;
+    const uint32_t nout = job->nbits + (job->Rw > job->Wb ? 2u : 1u);
+    hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, b.sums, nullptr, b.lvS, b.lvW, job->RNB, job->T1,
+                       (uint32_t)REDUCE_K_LOG, job->Rw, 1, 0);
     if (256 * XW * 4 > 64 * 1024)
         ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_bitsum<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * XW * 4)));
-    hipLaunchKernelGGL(k_bitsum<F>, job->Wb * (job->nbits + 1), 256, 256 * XW * 4, st, b.lvS, b.lvW, b.bits, job->T1, job->nbits);
+    hipLaunchKernelGGL(k_bitsum<F>, job->Rw * nout, 256, 256 * XW * 4, st, b.lvS, b.lvW, b.bits, job->T1, job->nbits, nout);
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
     // pinned destination: a pageable one would make the "async" copy block the host until this job is done
     auto& pin = ctx->pinned[job->slot];
-    const size_t bytes = (size_t)64 * 17 * XW * 4;
+    const size_t bytes = std::max<size_t>((size_t)64 * 17, (size_t)job->Rw * nout) * XW * 4;
     if (pin.bytes < bytes) {
         if (pin.p) (void)hipHostFree(pin.p);
         ZK_HIP(ctx, hipHostMalloc(&pin.p, bytes, hipHostMallocDefault));
         pin.bytes = bytes;
     }
     job->hw = (uint32_t*)pin.p;
-    ZK_HIP(ctx, hipMemcpyAsync(job->hw, b.bits, (size_t)job->Wb * (job->nbits + 1) * XW * 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(ctx, hipMemcpyAsync(job->hw, b.bits, (size_t)job->Rw * nout * XW * 4, hipMemcpyDeviceToHost, st));
     return ZK_OK;
 }
 
@@ -629,19 +726,36 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
     // window sum = W-part + sum_j 2^j * bit-sum_j ; then Horner over windows, most significant first
     // (variable_base.rs:94-105).  All in the 64-bit host field.
     using H = typename Host64Of<F>::type;
-    const uint32_t nb1 = job->nbits + 1;
-    XYZZ<H> total = xyzz_inf<H>();
-    for (int w = (int)job->Wb - 1; w >= 0; w--) {
-        const uint32_t cw = (uint32_t)(job->off[w + 1] - job->off[w]);   // 2^cw * (sum of the higher windows) + this window
-        for (uint32_t k = 0; k < cw; k++) total = xyzz_dbl<H>(total);
-        const uint32_t* base = job->hw + (size_t)w * nb1 * XW;
+    const bool sliced = job->Rw > job->Wb;              // merged bucket set cut into virtual windows (msm_prepare_t)
+    const uint32_t nout = job->nbits + (sliced ? 2u : 1u);
+    auto window_sum = [&](uint32_t w) {
+        const uint32_t* base = job->hw + (size_t)w * nout * XW;
         XYZZ<H> ws = xyzz_inf<H>();
         for (int j = (int)job->nbits - 1; j >= 0; j--) {
             ws = xyzz_dbl<H>(ws);
             ws = xyzz_add<H>(ws, xyzz_to_host64<F>(xyzz_load<F>(base + (size_t)j * XW)));
         }
-        ws = xyzz_add<H>(ws, xyzz_to_host64<F>(xyzz_load<F>(base + (size_t)job->nbits * XW)));
-        total = xyzz_add<H>(total, ws);
+        return xyzz_add<H>(ws, xyzz_to_host64<F>(xyzz_load<F>(base + (size_t)job->nbits * XW)));
+    };
+    XYZZ<H> total = xyzz_inf<H>();
+    if (sliced) {
+        // total = sum_v R_v + 2^15 sum_v v S_v; the device's plain sums are 2^K sum S (k_reduce pre-multiplies by the chunk size)
+        XYZZ<H> run = xyzz_inf<H>(), vs = xyzz_inf<H>();
+        for (uint32_t v = job->Rw; v-- > 0;) {
+            total = xyzz_add<H>(total, window_sum(v));
+            if (v > 0) {
+                run = xyzz_add<H>(run, xyzz_to_host64<F>(xyzz_load<F>(job->hw + ((size_t)v * nout + job->nbits + 1) * XW)));
+                vs = xyzz_add<H>(vs, run);
+            }
+        }
+        for (uint32_t k = REDUCE_K_LOG; k < 15; k++) vs = xyzz_dbl<H>(vs);
+        total = xyzz_add<H>(total, vs);
+    } else {
+        for (int w = (int)job->Wb - 1; w >= 0; w--) {
+            const uint32_t cw = (uint32_t)(job->off[w + 1] - job->off[w]);   // 2^cw * (sum of the higher windows) + this window
+            for (uint32_t k = 0; k < cw; k++) total = xyzz_dbl<H>(total);
+            total = xyzz_add<H>(total, window_sum((uint32_t)w));
+        }
     }
     host64_write_projective<H>(xyzz_to_affine<H>(total), (uint64_t*)out_host);
     return ZK_OK;
