@@ -64,6 +64,8 @@ struct zk_ctx {
         if (_r != ZK_OK) return _r;     \
     } while (0)
 
+hipError_t zk_stream_create(hipStream_t* st, bool high_priority);   // core.hip
+
 // Returns a device buffer of at least `bytes` bound to `name`; contents are unspecified.
 int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out);
 

@@ -457,10 +457,10 @@ namespace {
 int ensure_aux(zk_ctx* ctx, size_t k) {
     while (ctx->aux.size() < k) {
         hipStream_t st;
-        ZK_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        ZK_HIP(ctx, zk_stream_create(&st, true));
         ctx->aux.push_back(st);
     }
-    if (!ctx->acc_stream) ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->acc_stream, hipStreamNonBlocking));
+    if (!ctx->acc_stream) ZK_HIP(ctx, zk_stream_create(&ctx->acc_stream, false));
     return ZK_OK;
 }
 
@@ -505,7 +505,8 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &jobs[4], pk->h, 0, h, std::min(pk->h->n, D), 5);   // :106
     if (rc == ZK_OK) {
         ZK_HIP(ctx, hipEventRecord(e1, ctx->stream));
-        ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e1, 0));
+        static const bool gate = !(getenv("ZK_WM_GATE") && atoi(getenv("ZK_WM_GATE")) == 0);
+        if (gate) ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e1, 0));
         rc = zk_msm_enqueue_sort(ctx, &jobs[4], ctx->stream, nullptr);
     }
     // L's sort after the witness map (it is not needed before the fourth accumulate kernel)
