@@ -270,7 +270,7 @@ def main():
             c = ctx.lib.zk_bases_window_bits(pk_bases(ctx, pk, "a").h) or max(4, min(16, n_msm.bit_length() - 1 - 4))
             W = (255 + c - 1) // c                # digits per scalar (13 with the key's precomputed window multiples, c = 20)
             madds = n_msm * W                     # mixed additions in the accumulate kernel
-            mads = madds * (8 * 325 + 2 * 260)    # 8M + 2S, v_mad_u64_u32 per Fq mul / sqr (13x29-bit limbs)
+            mads = madds * (6 * 325 + 494 + 2 * 260)   # 8M + 2S with R(Q - X3) - Y1 PPP as one fused double product (494 mads)
             traffic = None
             try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), not measured live
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))

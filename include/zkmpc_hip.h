@@ -160,6 +160,7 @@ int zk_fr_mul(const zk_fr* a, const zk_fr* b, zk_fr* out);
 int zk_fq_add(const zk_fq* a, const zk_fq* b, zk_fq* out);
 int zk_fq_sub(const zk_fq* a, const zk_fq* b, zk_fq* out);
 int zk_fq_mul(const zk_fq* a, const zk_fq* b, zk_fq* out);
+int zk_fq_mul2(const zk_fq* a, const zk_fq* b, const zk_fq* c, const zk_fq* d, zk_fq* out);   /* a b + c d, the fused double product of the Fq2 multiplication */
 int zk_fr_inverse(const zk_fr* a, zk_fr* out);                    /* Field::inverse (macros.rs:389-443); error on zero */
 int zk_fr_pow(const zk_fr* a, uint64_t e, zk_fr* out);           /* Field::pow */
 int zk_fr_from_canonical(const uint64_t canon[4], zk_fr* out);   /* from_repr, macros.rs:464-474 */

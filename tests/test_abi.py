@@ -118,3 +118,33 @@ def test_field_add_sub_boundaries():
         for x in vals[::2]:
             for y in vals[::5]:
                 assert from_m(run(mul, to_m(x), to_m(y), nl)) == (x * y) % mod
+
+
+def test_fused_double_product_boundaries():
+    """fp_mul2 (a b + c d with one Montgomery reduction, the core of the Fq2 product) leaves up to 2.68 p before its two
+    conditional subtractions: operands next to p drive it through every range ([0,p), [p,2p), [2p,2.68p))."""
+    import ctypes as C
+    lib = Z.load()
+    q = O.Q_MOD
+    to_m = lambda v: np.ascontiguousarray(cv._ints_to_limbs([cv.fq_to_mont_int(v)], 6)[0])
+    from_m = lambda a: cv.fq_from_mont_int(cv._limbs_to_ints(a.reshape(1, 6))[0])
+    RI = 1 << (29 * 13)
+    R = (1 << 384) % q
+    rng = O.Prng(123)
+    seen = set()
+    # residues (the limbs the kernel sees are x * 2^384 mod q) crafted next to q and across the range
+    raws = [q - 1, q - 2, q - 1 - (rng.u64() & 0xFFFF), q // 2, 1, 0] + [rng.fq() for _ in range(6)] + [q - 1 - rng.u64() for _ in range(6)]
+    vals = [(x * pow(R, -1, q)) % q for x in raws]
+    for a in vals:
+        for b in vals[::2]:
+            for c in vals[::3]:
+                d = vals[(vals.index(a) + 5) % len(vals)]
+                out = np.zeros(6, dtype=np.uint64)
+                args = [to_m(v) for v in (a, b, c, d)]
+                assert lib.zk_fq_mul2(*[x.ctypes.data_as(C.c_void_p) for x in args], out.ctypes.data_as(C.c_void_p)) == 0
+                assert from_m(out) == (a * b + c * d) % q
+                ra, rb, rc, rd = [(v * R) % q for v in (a, b, c, d)]
+                t = ra * rb + rc * rd
+                pre = (t + ((-t * pow(q, -1, RI)) % RI) * q) // RI
+                seen.add(min(pre // q, 2))
+    assert seen == {0, 1, 2}

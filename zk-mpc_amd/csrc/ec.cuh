@@ -100,7 +100,7 @@ ZK_HD XYZZ<F> xyzz_madd(const XYZZ<F>& acc, const Affine<F>& q) {
     T ppp = F::mul(p, pp);
     T qq = F::mul(acc.x, pp);
     T x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
-    T y3 = F::sub(F::mul(r, F::sub(qq, x3)), F::mul(acc.y, ppp));
+    T y3 = F::mulsub(r, F::sub(qq, x3), acc.y, ppp);
     return XYZZ<F>{x3, y3, F::mul(acc.zz, pp), F::mul(acc.zzz, ppp)};
 }
 
@@ -124,7 +124,7 @@ ZK_HD XYZZ<F> xyzz_add(const XYZZ<F>& a, const XYZZ<F>& b) {
     T ppp = F::mul(p, pp);
     T qq = F::mul(u1, pp);
     T x3 = F::sub(F::sub(F::sqr(r), ppp), F::dbl(qq));
-    T y3 = F::sub(F::mul(r, F::sub(qq, x3)), F::mul(s1, ppp));
+    T y3 = F::mulsub(r, F::sub(qq, x3), s1, ppp);
     return XYZZ<F>{x3, y3, F::mul(F::mul(a.zz, b.zz), pp), F::mul(F::mul(a.zzz, b.zzz), ppp)};
 }
 

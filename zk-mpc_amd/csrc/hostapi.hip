@@ -134,6 +134,14 @@ extern "C" int zk_fq_sub(const zk_fq* a, const zk_fq* b, zk_fq* out) {
     host_store_ext<FqParams>(out->l, fp_sub<FqParams>(host_load_ext<FqParams>(a->l), host_load_ext<FqParams>(b->l)));
     return ZK_OK;
 }
+// a b + c d through the fused double product the Fq2 multiplication uses (fp29.cuh::fp_mul2), for boundary tests
+extern "C" int zk_fq_mul2(const zk_fq* a, const zk_fq* b, const zk_fq* c, const zk_fq* d, zk_fq* out) {
+    if (!a || !b || !c || !d || !out) return ZK_ERR_ARG;
+    Fq t = fp_mul2<FqParams>(host_load_ext<FqParams>(a->l), host_load_ext<FqParams>(b->l), host_load_ext<FqParams>(c->l),
+                             host_load_ext<FqParams>(d->l));
+    host_store_ext<FqParams>(out->l, fp_mul<FqParams>(t, fp_const<FqParams>(FqParams::EXT_TO_INT)));
+    return ZK_OK;
+}
 extern "C" int zk_fq_mul(const zk_fq* a, const zk_fq* b, zk_fq* out) {
     if (!a || !b || !out) return ZK_ERR_ARG;
     Fq t = fp_mul<FqParams>(host_load_ext<FqParams>(a->l), host_load_ext<FqParams>(b->l));

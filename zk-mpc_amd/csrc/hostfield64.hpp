@@ -90,6 +90,7 @@ struct Fq64Field {
         return o;
     }
     static T sqr(const T& a) { return mul(a, a); }
+    static T mulsub(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
     static T inv(const T& a) {  // a^(p-2)
         uint64_t e[6];
         for (int i = 0; i < 6; i++) e[i] = host64::P[i];
@@ -143,6 +144,7 @@ struct Fq264Field {
         return T{B::sub(v0, mul5(v1)), B::sub(B::sub(s, v0), v1)};
     }
     static T sqr(const T& a) { return mul(a, a); }
+    static T mulsub(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }
     static T inv(const T& a) {
         Fq64 n = B::add(B::sqr(a.c0), mul5(B::sqr(a.c1)));
         Fq64 ni = B::inv(n);
