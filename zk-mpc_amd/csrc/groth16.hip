@@ -17,6 +17,7 @@
 #include "hostfield64.hpp"
 #include "internal.hpp"
 #include <chrono>
+#include <functional>
 #include <future>
 #include <vector>
 
@@ -472,7 +473,7 @@ int ensure_aux(zk_ctx* ctx, size_t k) {
 //   accum      : the five accumulate kernels back to back, B-in-G2 first (longest reduce), H last;
 //                the first one is gated on the witness map, which would otherwise be starved 15x beside it
 int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const void* h_in, void* h_scratch,
-             zk_g1_projective out_g1[4], zk_g2_projective* out_g2) {
+             zk_g1_projective out_g1[4], zk_g2_projective* out_g2, const std::function<void()>& after_abc = nullptr) {
     const size_t D = (size_t)1 << r->log_d;
     const size_t nvars = (r->ni - 1) + r->nw;
     const char* zb = (const char*)z;
@@ -523,6 +524,7 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[0], out_g2);
     if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[1], &out_g1[2]);
     if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[2], &out_g1[3]);
+    if (rc == ZK_OK && after_abc) after_abc();      // A, B1, B2 are in: the caller's host work overlaps the L and H jobs
     if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[3], &out_g1[1]);
     if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[4], &out_g1[0]);
     (void)hipStreamSynchronize(s_sort);
@@ -596,10 +598,9 @@ extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs*
     ZK_TRY(zk_scratch(ctx, "prove_h", D * 32, &h));
     zk_g1_projective m1[4];
     zk_g2_projective m2;
-    ZK_TRY(run_msms(ctx, pk, r, z, nullptr, h, m1, &m2));
 
-    // ---- O(1) tail on the host, 64-bit limbs, three independent chains on three threads ----
-    const auto t_tail = std::chrono::steady_clock::now();
+    // ---- O(1) tail on the host, 64-bit limbs.  Everything that depends only on the A, B-in-G1 and B-in-G2 sums (and on
+    // r, s, the key) starts as soon as those three jobs have delivered, while the GPU still works on L and H ----
     using H1 = Fq64Field;
     using H2 = Fq264Field;
     using X1 = XYZZ<H1>;
@@ -607,35 +608,45 @@ extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs*
     uint32_t rw[8], sw[8];
     fr_abi_to_canon_words(r_->l, rw);
     fr_abi_to_canon_words(s_->l, sw);
-    const X1 h_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[0]);
-    const X1 l_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[1]);
-    const X1 a_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[2]);
-    const X1 b1_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[3]);
-    const X2 b2_acc = host64_proj_from_abi<H2>((const uint64_t*)&m2);
     const X1 delta1 = xyzz_from_affine<H1>(aff_to_host64<G1Field>(pk->delta_g1));
     const X2 delta2 = xyzz_from_affine<H2>(aff_to_host64<G2Field>(pk->delta_g2));
     const Affine<H1> a0 = aff_to_host64<G1Field>(pk->a0), alpha = aff_to_host64<G1Field>(pk->alpha_g1);
     const Affine<H1> b0 = aff_to_host64<G1Field>(pk->b0_g1), beta1 = aff_to_host64<G1Field>(pk->beta_g1);
     const Affine<H2> b02 = aff_to_host64<G2Field>(pk->b0_g2), beta2 = aff_to_host64<G2Field>(pk->beta_g2);
-
-    // calculate_coeff (src/groth16.rs:185-201): initial + query[0] + acc + vk_param
     X1 g_a, s_g_a, r_s_delta, r_g1_b;
-    auto chain_a = std::async(std::launch::async, [&] {
-        const X1 r_g1 = host64_scalar_mul<H1>(delta1, rw);
-        r_s_delta = host64_scalar_mul<H1>(r_g1, sw);                                                     // :115
-        g_a = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(r_g1, a0), a_acc), alpha);
-        s_g_a = host64_scalar_mul<H1>(g_a, sw);                                                           // :140
-    });
-    auto chain_b = std::async(std::launch::async, [&] {
-        const X1 s_g1 = host64_scalar_mul<H1>(delta1, sw);
-        const X1 g1_b = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(s_g1, b0), b1_acc), beta1);
-        r_g1_b = host64_scalar_mul<H1>(g1_b, rw);                                                         // :161
-    });
-    const X2 s_g2 = host64_scalar_mul<H2>(delta2, sw);
-    const X2 g2_b = xyzz_madd<H2>(xyzz_add<H2>(xyzz_madd<H2>(s_g2, b02), b2_acc), beta2);
-    const Affine<H2> b_aff = xyzz_to_affine<H2>(g2_b);
-    chain_a.get();
-    chain_b.get();
+    Affine<H2> b_aff;
+    std::future<void> chain_a, chain_b, chain_g2;
+    std::chrono::steady_clock::time_point t_tail;
+    auto after_abc = [&]() {
+        const X1 a_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[2]);
+        const X1 b1_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[3]);
+        const X2 b2_acc = host64_proj_from_abi<H2>((const uint64_t*)&m2);
+        // calculate_coeff (src/groth16.rs:185-201): initial + query[0] + acc + vk_param
+        chain_a = std::async(std::launch::async, [&, a_acc] {
+            const X1 r_g1 = host64_scalar_mul<H1>(delta1, rw);
+            r_s_delta = host64_scalar_mul<H1>(r_g1, sw);                                                     // :115
+            g_a = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(r_g1, a0), a_acc), alpha);
+            s_g_a = host64_scalar_mul<H1>(g_a, sw);                                                           // :140
+        });
+        chain_b = std::async(std::launch::async, [&, b1_acc] {
+            const X1 s_g1 = host64_scalar_mul<H1>(delta1, sw);
+            const X1 g1_b = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(s_g1, b0), b1_acc), beta1);
+            r_g1_b = host64_scalar_mul<H1>(g1_b, rw);                                                         // :161
+        });
+        chain_g2 = std::async(std::launch::async, [&, b2_acc] {
+            const X2 s_g2 = host64_scalar_mul<H2>(delta2, sw);
+            const X2 g2_b = xyzz_madd<H2>(xyzz_add<H2>(xyzz_madd<H2>(s_g2, b02), b2_acc), beta2);
+            b_aff = xyzz_to_affine<H2>(g2_b);
+        });
+    };
+    int rc_msm = run_msms(ctx, pk, r, z, nullptr, h, m1, &m2, after_abc);
+    t_tail = std::chrono::steady_clock::now();      // what is left of the host work once the GPU is done
+    if (chain_a.valid()) chain_a.get();
+    if (chain_b.valid()) chain_b.get();
+    if (chain_g2.valid()) chain_g2.get();
+    ZK_TRY(rc_msm);
+    const X1 h_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[0]);
+    const X1 l_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[1]);
     X1 g_c = xyzz_add<H1>(s_g_a, r_g1_b);                                                                 // :169-174
     g_c = xyzz_add<H1>(g_c, xyzz_neg<H1>(r_s_delta));
     g_c = xyzz_add<H1>(g_c, l_acc);

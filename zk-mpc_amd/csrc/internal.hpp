@@ -58,6 +58,7 @@ struct ZkMsmJob {
     hipStream_t stream = nullptr;     // the stream the reduce phase (and the copy to hw) is on
     hipEvent_t sort_done = nullptr;   // recorded once sorted/desc/order are final
     hipEvent_t accum_done = nullptr;  // recorded after the accumulate kernel
+    hipEvent_t reduce_done = nullptr; // recorded after the copy of the partial sums to the host: what finish() waits for
     uint32_t* hw = nullptr;           // partial window sums (XYZZ, internal form) in pinned host memory
     // the sort products, so that a later job over the same scalar vector can reuse them
     uint32_t *sorted = nullptr, *order = nullptr, *ctr = nullptr;

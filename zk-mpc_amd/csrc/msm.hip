@@ -711,6 +711,9 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     }
     job->hw = (uint32_t*)pin.p;
     ZK_HIP(ctx, hipMemcpyAsync(job->hw, b.bits, (size_t)job->Rw * nout * XW * 4, hipMemcpyDeviceToHost, st));
+    // finish() waits for this event, not for the stream: later jobs' reduce phases may be queued behind on the same stream
+    ZK_HIP(ctx, hipEventCreateWithFlags(&job->reduce_done, hipEventDisableTiming));
+    ZK_HIP(ctx, hipEventRecord(job->reduce_done, st));
     return ZK_OK;
 }
 
@@ -721,7 +724,8 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
         host_write_projective<F>(aff_inf<F>(), (uint64_t*)out_host);
         return ZK_OK;
     }
-    ZK_HIP(ctx, hipStreamSynchronize(job->stream));
+    if (job->reduce_done) ZK_HIP(ctx, hipEventSynchronize(job->reduce_done));
+    else ZK_HIP(ctx, hipStreamSynchronize(job->stream));
     for (auto* t : job->timers) t->resolve();
     // window sum = W-part + sum_j 2^j * bit-sum_j ; then Horner over windows, most significant first
     // (variable_base.rs:94-105).  All in the 64-bit host field.
@@ -861,6 +865,7 @@ ZkMsmJob::~ZkMsmJob() {
     for (auto* t : timers) delete t;
     if (accum_done) (void)hipEventDestroy(accum_done);
     if (sort_done) (void)hipEventDestroy(sort_done);
+    if (reduce_done) (void)hipEventDestroy(reduce_done);
 }
 
 int zk_msm_prepare(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n, int slot) {
