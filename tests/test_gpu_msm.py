@@ -138,17 +138,23 @@ def test_msm_large_discrete_log_check(ctx, log_n):
         for j in range(4):
             tot += int(pr[:, j].astype(object).sum()) << (64 * j)
         e = cv.fr_from_mont(cv.fr_raw([tot % O.R_MOD]))[0]
-        if group == 1:
-            assert cv.g1_projective_to_affine(out) == O.g1_mul(O.G1_GEN, e)
-        else:
-            assert cv.g2_projective_to_affine(out) == O.g2_mul(O.G2_GEN, e)
+        to_aff = cv.g1_projective_to_affine if group == 1 else cv.g2_projective_to_affine
+        want = O.g1_mul(O.G1_GEN, e) if group == 1 else O.g2_mul(O.G2_GEN, e)
+        assert to_aff(out) == want
+        # the same table with window multiples: one bucket set of 2^(c-1) buckets, cut into 2^15-bucket slices for the
+        # reduce when c > 16 (2^20 points: c = 20, 16 slices; 2^18 points: c = 17, 2 slices)
+        bases.precompute()
+        c = ctx.lib.zk_bases_window_bits(bases.h)
+        assert c >= (17 if m >= (1 << 18) else 13)
+        assert to_aff(ctx.msm_dev(bases, 0, ds.ptr, m)) == want
+        assert to_aff(ctx.msm_dev(bases, 3, ds.ptr, m - 3)) == to_aff(ctx.msm_dev(bases, 3, ds.ptr, m - 3))
         bases.free()
         prod.free()
 
 
 @pytest.mark.parametrize("group,n", [(1, 5000), (1, 1 << 16), (2, 6000)])
 def test_msm_precomputed_window_multiples(ctx, group, n):
-    """Resident bases with precomputed 2^(16w) multiples (one bucket set for all windows): random scalars,
+    """Resident bases with precomputed 2^(c w) multiples (one bucket set for all windows): random scalars,
     witness-like 0/1-heavy scalars, all-equal scalars (every point in one bucket per window), extreme scalars and
     an offset sub-range must give the same group element as the discrete-log identity."""
     rs = np.random.RandomState(group * 100 + (n & 0xff))
@@ -181,26 +187,29 @@ def test_msm_precomputed_window_multiples(ctx, group, n):
     bases.free()
 
 
-def test_groth16_precomputed_key_matches_plain(ctx):
-    """The same proof bytes with and without the precomputed proving-key tables (n >= 4096 enables them)."""
+@pytest.mark.parametrize("n", [(1 << 16) + 100, (1 << 18) - 2])
+def test_groth16_precomputed_key_matches_plain(ctx, n):
+    """The same proof bytes with the proving key's window multiples (default for queries of >= 2^16 points; 2^18: c = 17,
+    sliced reduce) and without them (ZK_PRECOMP=0), both equal to the known-trapdoor prediction of the C oracle."""
     import os
-    n = 4500
-    rng = O.Prng(4500)
+    import zkref_c as OC
+    rng = O.Prng(n)
     mont = lambda v: cv.fr_to_mont([v])[0]
     td = [mont(rng.fr()) for _ in range(7)]
     w0, w1, rr, ss = mont(rng.fr()), mont(rng.fr()), mont(rng.fr()), mont(rng.fr())
     dr = ctx.r1cs_mul_chain(n)
     dz = ctx.mul_chain_assignment_dev(n, w0, w1)
-    pk0 = ctx.groth16_setup(dr, *td)
-    p0 = ctx.create_proof_dev(pk0, dr, dz.ptr, rr, ss)
-    os.environ["ZK_PRECOMP"] = "1"
+    os.environ["ZK_PRECOMP"] = "0"
     try:
-        pk1 = ctx.groth16_setup(dr, *td)
+        pk0 = ctx.groth16_setup(dr, *td)
     finally:
         del os.environ["ZK_PRECOMP"]
+    pk1 = ctx.groth16_setup(dr, *td)
+    assert ctx.lib.zk_bases_window_bits(pk0.query_bases("a_query").h) == 0
+    assert ctx.lib.zk_bases_window_bits(pk1.query_bases("a_query").h) >= 15
+    p0 = ctx.create_proof_dev(pk0, dr, dz.ptr, rr, ss)
     p1 = ctx.create_proof_dev(pk1, dr, dz.ptr, rr, ss)
     assert p0 == p1
-    import zkref_c as OC
     zarr = ctx.download(dz, (n + 3, 4))
     cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))
     assert p1 == OC.groth16_predict(cr, np.stack(td), zarr, OC.witness_map(cr, zarr), rr, ss)
