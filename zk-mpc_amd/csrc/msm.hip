@@ -28,6 +28,7 @@
 #include "hostfield64.hpp"
 #include "internal.hpp"
 #include <algorithm>
+#include <future>
 #include <vector>
 
 using namespace zk;
@@ -141,7 +142,7 @@ k_scatter(const uint32_t* dig, size_t n, uint32_t W, uint32_t NB, const uint32_t
 // ---- segments -------------------------------------------------------------------------------
 // A bucket with cnt points is cut into max(1, ceil(cnt / SEG)) segments.  Single-segment buckets
 // write their sum straight to sums[key]; the segments of a split ("heavy") bucket write partial
-// sums to sums[n_keys + ...] and k_fold_heavy adds them up.  SEG is ~4x the mean bucket size, so
+// sums to sums[n_keys + ...] and k_fold adds them up.  SEG is ~4x the mean bucket size, so
 // for uniformly random scalars no bucket is split; splitting is what keeps 0/1-heavy witness
 // vectors, repeated scalars and a nearly empty top window from serialising on one thread.
 struct SegDesc { uint32_t start, len, dst; };
@@ -390,30 +391,28 @@ __device__ __forceinline__ XYZZ<F> lds_get_xyzz(const uint32_t* lds, uint32_t t)
     return xyzz_load<F>(w);
 }
 
-// Split buckets with few segments: one thread per bucket adds them up serially.
+// Split buckets are folded back into one sum per bucket by ONE launch (every launch of a reduce chain waits for a free
+// slot beside the running accumulate kernel, so fewer launches is a shorter chain): the first `light_blocks` blocks take
+// buckets with few segments, one thread per bucket adding them up serially; the remaining blocks take the very heavy
+// ones (repeated scalars, 0/1 witnesses), one 64-lane block per bucket: strided partial sums, then an LDS tree.
 template <class F>
 __global__ void __launch_bounds__(64)
-k_fold_light(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums) {
-    const uint32_t nheavy = ctr[0];
-    for (uint32_t hb = blockIdx.x * blockDim.x + threadIdx.x; hb < nheavy; hb += gridDim.x * blockDim.x) {
-        const HeavyDesc h = heavy[hb];
-        if (h.nseg > 32) continue;
-        XYZZ<F> acc = xyzz_load16<F>(sums, (size_t)h.first);
-        for (uint32_t j = 1; j < h.nseg; j++) acc = xyzz_add<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
-        xyzz_store16<F>(sums, h.key, acc);
-    }
-}
-
-// Split buckets with many segments (very heavy: repeated scalars, 0/1 witnesses): one 64-lane block per
-// bucket; lanes add strided partial sums, then an LDS tree.
-template <class F>
-__global__ void __launch_bounds__(64)
-k_fold_heavy(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums) {
+k_fold(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint32_t light_blocks) {
     constexpr int XW = 4 * F::WORDS;
-    extern __shared__ uint32_t lds[];  // 64 * XW words
+    extern __shared__ uint32_t lds[];  // 64 * XW words (heavy blocks only)
     const uint32_t nheavy = ctr[0];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t hb = blockIdx.x; hb < nheavy; hb += gridDim.x) {
+    if (blockIdx.x < light_blocks) {
+        for (uint32_t hb = blockIdx.x * 64 + tid; hb < nheavy; hb += light_blocks * 64) {
+            const HeavyDesc h = heavy[hb];
+            if (h.nseg > 32) continue;
+            XYZZ<F> acc = xyzz_load16<F>(sums, (size_t)h.first);
+            for (uint32_t j = 1; j < h.nseg; j++) acc = xyzz_add<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
+            xyzz_store16<F>(sums, h.key, acc);
+        }
+        return;
+    }
+    for (uint32_t hb = blockIdx.x - light_blocks; hb < nheavy; hb += gridDim.x - light_blocks) {
         const HeavyDesc h = heavy[hb];
         if (h.nseg <= 32) continue;
         XYZZ<F> acc = xyzz_inf<F>();
@@ -688,10 +687,10 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
     job->timers.push_back(tm);
     tm->begin(g1 ? "msm_g1.reduce" : "msm_g2.reduce");
-    hipLaunchKernelGGL(k_fold_light<F>, (unsigned)std::min<size_t>((job->max_heavy + 63) / 64, 512), 64, 0, st,
-                       (const HeavyDesc*)job->heavy, job->ctr, b.sums);
-    hipLaunchKernelGGL(k_fold_heavy<F>, (unsigned)std::min<size_t>(job->max_heavy, 1024), 64, 64 * XW * 4, st,
-                       (const HeavyDesc*)job->heavy, job->ctr, b.sums);
+    const unsigned light_blocks = (unsigned)std::min<size_t>((job->max_heavy + 63) / 64, 512);
+    const unsigned heavy_blocks = (unsigned)std::min<size_t>(job->max_heavy, 1024);
+    hipLaunchKernelGGL(k_fold<F>, light_blocks + heavy_blocks, 64, 64 * XW * 4, st, (const HeavyDesc*)job->heavy, job->ctr, b.sums,
+                       light_blocks);
     const size_t threads = (size_t)job->Rw * job->T1;
     const uint32_t nout = job->nbits + (job->Rw > job->Wb ? 2u : 1u);
     hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, b.sums, nullptr, b.lvS, b.lvW, job->RNB, job->T1,
@@ -742,11 +741,23 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
         return xyzz_add<H>(ws, xyzz_to_host64<F>(xyzz_load<F>(base + (size_t)job->nbits * XW)));
     };
     XYZZ<H> total = xyzz_inf<H>();
+    // the per-window Horner chains (13 doublings + 13 additions each, ~0.8 ms in all for 16 windows on one core) are
+    // independent: four host threads take them, because the last job's finish sits on the proof's critical path
+    const uint32_t nwin = sliced ? job->Rw : job->Wb;
+    std::vector<XYZZ<H>> wsum(nwin);
+    {
+        const uint32_t nthreads = nwin >= 8 ? 4u : 1u;
+        std::vector<std::future<void>> tasks;
+        for (uint32_t t = 1; t < nthreads; t++)
+            tasks.push_back(std::async(std::launch::async, [&, t] { for (uint32_t w = t; w < nwin; w += nthreads) wsum[w] = window_sum(w); }));
+        for (uint32_t w = 0; w < nwin; w += nthreads) wsum[w] = window_sum(w);
+        for (auto& f : tasks) f.get();
+    }
     if (sliced) {
         // total = sum_v R_v + 2^15 sum_v v S_v; the device's plain sums are 2^K sum S (k_reduce pre-multiplies by the chunk size)
         XYZZ<H> run = xyzz_inf<H>(), vs = xyzz_inf<H>();
         for (uint32_t v = job->Rw; v-- > 0;) {
-            total = xyzz_add<H>(total, window_sum(v));
+            total = xyzz_add<H>(total, wsum[v]);
             if (v > 0) {
                 run = xyzz_add<H>(run, xyzz_to_host64<F>(xyzz_load<F>(job->hw + ((size_t)v * nout + job->nbits + 1) * XW)));
                 vs = xyzz_add<H>(vs, run);
@@ -758,7 +769,7 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
         for (int w = (int)job->Wb - 1; w >= 0; w--) {
             const uint32_t cw = (uint32_t)(job->off[w + 1] - job->off[w]);   // 2^cw * (sum of the higher windows) + this window
             for (uint32_t k = 0; k < cw; k++) total = xyzz_dbl<H>(total);
-            total = xyzz_add<H>(total, window_sum((uint32_t)w));
+            total = xyzz_add<H>(total, wsum[(uint32_t)w]);
         }
     }
     host64_write_projective<H>(xyzz_to_affine<H>(total), (uint64_t*)out_host);
