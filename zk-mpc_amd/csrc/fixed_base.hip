@@ -204,7 +204,10 @@ extern "C" uint32_t zk_bases_window_bits(const zk_bases* b) { return b ? b->c_pr
 extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b) {
     if (!ctx) return ZK_ERR_ARG;
     if (!b || b->pre || b->n < 4096) return ZK_OK;
-    const uint32_t c = precompute_window_bits(b->n), W = (255 + c - 1) / c;
+    uint32_t c = precompute_window_bits(b->n);
+    static const int env_c2 = getenv("ZK_PRECOMP_C_G2") ? atoi(getenv("ZK_PRECOMP_C_G2")) : 0;   // experiments
+    if (b->group == 2 && env_c2 >= 8 && env_c2 <= 24) c = (uint32_t)env_c2;
+    const uint32_t W = (255 + c - 1) / c;
     if (b->group == 1) return precompute_t<G1Field>(ctx, b, c, W);
     return precompute_t<G2Field>(ctx, b, c, W);
 }
