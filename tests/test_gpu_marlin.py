@@ -116,3 +116,46 @@ def test_round_polynomials_commit_and_open_with_kzg10(ctx):
         comb = M.padd(comb, M.pscale(DM.download_poly(ctx, polys[l]), pow(xi, i, O.R_MOD)))
     c_comb = O.kzg_commit(pp, comb)
     assert O.kzg_check(pp, c_comb, ch["beta"], O.poly_evaluate(comb, ch["beta"]), cv.g1_projective_to_affine(w_beta))
+
+
+def test_marlin_pc_commit_with_bounds_and_hiding(ctx):
+    """MarlinKZG10::commit on the round oracles: hiding commitments (w, z_a, z_b, g_1) and the shifted commitments of the
+    degree-bounded oracles (g_1: |H| - 2, g_2: |K| - 2) equal the oracle's MSMs over the (shifted) powers."""
+    n = 6
+    rng, r1cs, sq, zz, dix = build(ctx, n, 840)
+    md = 3 * dix.dom_h.size - 1
+    rnd = [rng.fr() for _ in range(3 + md + 1)]
+    ch = {k: rng.fr() for k in ("alpha", "eta_a", "eta_b", "eta_c", "beta", "gamma")}
+    polys, _ = run_device(ctx, dix, zz, rnd, ch)
+    prover = {l: polys[l] for l in ("w", "z_a", "z_b", "mask_poly", "t", "g_1", "h_1", "g_2", "h_2")}
+    max_deg = max(p.n for p in prover.values()) + 3
+    pp = O.KzgParams(max_deg, rng.fr(), g_k=rng.fr(), gg_k=rng.fr(), h_k=rng.fr())
+    pg = ctx.bases_upload(cv.g1_affine_to_array(pp.powers_of_g), 1)
+    pgg = ctx.bases_upload(cv.g1_affine_to_array(pp.powers_of_gamma_g), 1)
+    bounds = DM.oracle_bounds(dix)
+    blinds_h, blinds_d = {}, {}
+    for label, (bound, hiding) in bounds.items():
+        if hiding is not None:
+            b0 = [rng.fr() for _ in range(hiding + 1)]
+            b1 = [rng.fr() for _ in range(hiding + 1)] if bound is not None else None
+            blinds_h[label] = (b0, b1)
+            up = lambda v: DM.DevPoly(ctx.upload(cv.fr_to_mont(v)), len(v))
+            blinds_d[label] = (up(b0), up(b1) if b1 else None)
+    got = DM.commit_marlin_pc(ctx, pg, pgg, prover, bounds, blinds_d)
+    for label, p in prover.items():
+        coeffs = DM.download_poly(ctx, p)
+        bound, hiding = bounds[label]
+        want = O.msm_naive(pp.powers_of_g, coeffs, O.FqOps)
+        if hiding is not None:
+            want = O.g1_add(want, O.msm_naive(pp.powers_of_gamma_g, blinds_h[label][0], O.FqOps))
+        assert cv.g1_projective_to_affine(got[label]["comm"]) == want, label
+        if bound is None:
+            assert got[label]["shifted_comm"] is None
+        else:
+            ws = O.msm_naive(pp.powers_of_g[max_deg - bound:], coeffs, O.FqOps)
+            if hiding is not None:
+                ws = O.g1_add(ws, O.msm_naive(pp.powers_of_gamma_g, blinds_h[label][1], O.FqOps))
+            assert cv.g1_projective_to_affine(got[label]["shifted_comm"]) == ws, label
+    # a polynomial above its bound is refused
+    with pytest.raises(ValueError, match="exceeds its bound"):
+        DM.commit_marlin_pc(ctx, pg, pgg, {"g_2": prover["h_2"]}, {"g_2": (1, None)})

@@ -137,6 +137,10 @@ int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W) {
     uint32_t *xy, *scr;
     ZK_TRY(zk_scratch(ctx, "fb_xyzz", n * 4 * F::WORDS * 4, (void**)&xy));
     ZK_TRY(zk_scratch(ctx, "fb_scr", n * F::WORDS * 4, (void**)&scr));
+    // the table is a trade of memory for work, never a reason to run out of memory later: it may take at most a third of
+    // what is free now (a 2^24-point G2 query would ask for 40 GB)
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || (size_t)W * n * PW * 4 > mem_free / 3) return ZK_OK;
     if (hipMalloc((void**)&b->pre, (size_t)W * n * PW * 4) != hipSuccess) {
         b->pre = nullptr;
         (void)hipGetLastError();

@@ -481,6 +481,44 @@ def commit(ctx: Context, powers_g, polys: dict) -> dict:
     return dict(zip(labels, outs))
 
 
+# degree bounds and hiding bounds of the prover's oracles as the reference labels them
+# (LabeledPolynomial::new(label, poly, degree_bound, hiding_bound), prover.rs:383-387,548-552,708-711)
+def oracle_bounds(index: "Index") -> dict:
+    H, K = index.dom_h.size, index.dom_k.size
+    return {"w": (None, 1), "z_a": (None, 1), "z_b": (None, 1), "mask_poly": (None, None), "t": (None, None),
+            "g_1": (H - 2, 1), "h_1": (None, None), "g_2": (K - 2, None), "h_2": (None, None)}
+
+
+def commit_marlin_pc(ctx: Context, powers_g, powers_gamma_g, polys: dict, bounds: dict, blinds: dict = None) -> dict:
+    """MarlinKZG10::commit (poly-commit/src/marlin/marlin_pc/mod.rs:172-243): per polynomial the KZG10 commitment, with
+    hiding (plus MSM(powers_of_gamma_g, blinding polynomial), kzg10/mod.rs:171-199) where the oracle has a hiding bound,
+    and for an oracle with degree bound d a second commitment to the same coefficients over the SHIFTED powers
+    powers_of_g[max_degree - d ..] (marlin_pc/data_structures.rs shifted_powers), which is what enforces deg <= d.
+    bounds: label -> (degree_bound or None, hiding_bound or None); blinds: label -> (blinding DevPoly, shifted blinding
+    DevPoly or None), supplied by the caller's rng.  All MSMs of the call run as one pipelined batch.
+    Returns label -> {"comm": G1, "shifted_comm": G1 or None}."""
+    max_degree = len(powers_g) - 1
+    jobs, slots = [], []
+    for label, p in polys.items():
+        bound, hiding = bounds.get(label, (None, None))
+        jobs.append((powers_g, 0, p.ptr, p.n)); slots.append((label, "comm"))
+        if hiding is not None and blinds and label in blinds:
+            bl = blinds[label][0]
+            jobs.append((powers_gamma_g, 0, bl.ptr, bl.n)); slots.append((label, "comm"))
+        if bound is not None:
+            if p.n - 1 > bound:
+                raise ValueError("%s: degree exceeds its bound" % label)
+            jobs.append((powers_g, max_degree - bound, p.ptr, p.n)); slots.append((label, "shifted_comm"))
+            if hiding is not None and blinds and label in blinds and blinds[label][1] is not None:
+                bl = blinds[label][1]
+                jobs.append((powers_gamma_g, 0, bl.ptr, bl.n)); slots.append((label, "shifted_comm"))
+    outs = ctx.msm_batch_dev(jobs)
+    res = {label: {"comm": None, "shifted_comm": None} for label in polys}
+    for (label, which), pt in zip(slots, outs):
+        res[label][which] = pt if res[label][which] is None else ctx.g1_add(res[label][which], pt)
+    return res
+
+
 def batch_open(ctx: Context, powers_g, queries, opening_challenge: int):
     """KZG10 witnesses for several (polynomials, point) queries: per query p = sum_i xi^i p_i and
     w = commit((p - p(z)) / (X - z)) (kzg10/mod.rs:212-293 applied to the combination, as marlin_pc::batch_open does per
