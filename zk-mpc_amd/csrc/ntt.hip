@@ -87,9 +87,15 @@ __device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t E, uint32_t li
 }
 
 // One DIF pass.  Tile = C columns x M points; column id = block * S + l.
+// FINAL (last pass, logS == 0): the element lands directly at its bit-reversed position in `out` (a different buffer:
+// the scattered stores would otherwise overwrite tiles that have not been read yet), multiplied by the post-scale
+// (POST 1: constant k = 1/N; POST 2: table post[dst] = g^-dst / N) -- this replaces a separate permutation pass
+// (72 us at 2^20, seven times per witness map).
+template <int POST>
 __global__ void __launch_bounds__(1024)
-k_ntt_pass(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, const uint32_t* __restrict__ pre,
-           uint32_t log_n, uint32_t logS, uint32_t logM, uint32_t logC, int inverse) {
+k_ntt_pass(const uint32_t* data, uint32_t* out, const uint32_t* __restrict__ tw,
+           const uint32_t* __restrict__ pre, uint32_t log_n, uint32_t logS, uint32_t logM, uint32_t logC, int inverse,
+           int final_rev, FrK post_k, const uint32_t* __restrict__ post) {
     extern __shared__ uint32_t lds[];
     const uint32_t M = 1u << logM, C = 1u << logC, E = M * C;
     const uint32_t N1 = (1u << log_n) - 1;
@@ -147,7 +153,13 @@ k_ntt_pass(uint32_t* __restrict__ data, const uint32_t* __restrict__ tw, const u
                 v = fr_mul(v, fr_load(tw, ex));
             }
         }
-        fr_store(data, idx, v);
+        uint32_t dst = idx;
+        if (final_rev) {
+            dst = __brev(idx) >> (32 - log_n);
+            if (POST == 1) v = fr_mul(v, frk(post_k));
+            if (POST == 2) v = fr_mul(v, fr_load(post, dst));
+        }
+        fr_store(out, dst, v);
     }
 }
 
@@ -238,11 +250,34 @@ int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset
     zk_domain* d;
     ZK_TRY(get_domain(ctx, log_n, coset != 0, &d));
     uint32_t* data = (uint32_t*)buf;
+    FrK zero{};
+    const int post_mode = !inverse ? 0 : (!coset ? 1 : 2);
+    const FrK post_k = post_mode == 1 ? to_frk(d->size_inv) : zero;
+    const uint32_t* post_tab = post_mode == 2 ? d->icos : nullptr;
+    auto launch = [&](const uint32_t* src, uint32_t* dst, uint32_t tiles, uint32_t nt, uint32_t E, const uint32_t* pre, uint32_t logS,
+                      uint32_t logM, uint32_t logC, int final_rev) {
+        if (post_mode == 0)
+            hipLaunchKernelGGL(k_ntt_pass<0>, tiles, nt, E * 36, ctx->stream, src, dst, d->tw, pre, log_n, logS, logM, logC, inverse, final_rev, post_k, post_tab);
+        else if (post_mode == 1)
+            hipLaunchKernelGGL(k_ntt_pass<1>, tiles, nt, E * 36, ctx->stream, src, dst, d->tw, pre, log_n, logS, logM, logC, inverse, final_rev, post_k, post_tab);
+        else
+            hipLaunchKernelGGL(k_ntt_pass<2>, tiles, nt, E * 36, ctx->stream, src, dst, d->tw, pre, log_n, logS, logM, logC, inverse, final_rev, post_k, post_tab);
+    };
+    bool permuted = false;      // the last pass already wrote the natural order (and the post-scale)
     if (log_n > 0) {
         uint32_t passes = (log_n + LOGM_MAX - 1) / LOGM_MAX;
         uint32_t base = log_n / passes, extra = log_n % passes;
         uint32_t remaining = log_n;
-        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELEMS * 36));
+        if (!ctx->flags["ntt_lds"]) {
+            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<0>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELEMS * 36));
+            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELEMS * 36));
+            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_ntt_pass<2>, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_ELEMS * 36));
+            ctx->flags["ntt_lds"] = 1;
+        }
+        // with two or more passes the first one writes a scratch buffer and the last one scatters from it back into the
+        // caller's buffer in natural order; a single-pass transform (N <= 2^LOGM_MAX) keeps the separate permutation
+        uint32_t* tmp = nullptr;
+        if (passes >= 2) ZK_TRY(zk_scratch(ctx, "ntt_tmp", ((size_t)1 << log_n) * 32, (void**)&tmp));
         for (uint32_t p = 0; p < passes; p++) {
             uint32_t logM = base + (p < extra ? 1 : 0);
             uint32_t logS = remaining - logM;
@@ -252,23 +287,26 @@ int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset
             uint32_t nt = E / 2 > 1024 ? 1024 : (E / 2 < 64 ? 64 : E / 2);
             uint32_t tiles = 1u << (log_n - logE);
             const uint32_t* pre = (p == 0 && coset && !inverse) ? d->cos : nullptr;
-            hipLaunchKernelGGL(k_ntt_pass, tiles, nt, E * 36, ctx->stream, data, d->tw, pre, log_n, logS, logM, logC, inverse);
+            const uint32_t* src = (tmp && p > 0) ? tmp : data;
+            const bool last = p + 1 == passes;
+            uint32_t* dst = tmp ? (last ? data : tmp) : data;
+            launch(src, dst, tiles, nt, E, pre, logS, logM, logC, (tmp && last) ? 1 : 0);
             ZK_HIP(ctx, hipGetLastError());
             remaining = logS;
         }
-    } else if (coset && !inverse) {
-        // N = 1: g^0 = 1, nothing to do
+        permuted = tmp != nullptr;
     }
-    unsigned g = zk_grid((size_t)1 << log_n, 256);
-    FrK zero{};
-    if (!inverse) {
-        if (log_n > 1) hipLaunchKernelGGL(k_bitrev_scale<0>, g, 256, 0, ctx->stream, data, log_n, zero, nullptr);
-    } else if (!coset) {
-        hipLaunchKernelGGL(k_bitrev_scale<1>, g, 256, 0, ctx->stream, data, log_n, to_frk(d->size_inv), nullptr);
-    } else {
-        hipLaunchKernelGGL(k_bitrev_scale<2>, g, 256, 0, ctx->stream, data, log_n, zero, d->icos);
+    if (!permuted) {
+        unsigned g = zk_grid((size_t)1 << log_n, 256);
+        if (!inverse) {
+            if (log_n > 1) hipLaunchKernelGGL(k_bitrev_scale<0>, g, 256, 0, ctx->stream, data, log_n, zero, nullptr);
+        } else if (!coset) {
+            hipLaunchKernelGGL(k_bitrev_scale<1>, g, 256, 0, ctx->stream, data, log_n, to_frk(d->size_inv), nullptr);
+        } else {
+            hipLaunchKernelGGL(k_bitrev_scale<2>, g, 256, 0, ctx->stream, data, log_n, zero, d->icos);
+        }
+        ZK_HIP(ctx, hipGetLastError());
     }
-    ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }
 
