@@ -169,6 +169,17 @@ def test_distnet_nccl_single_rank():
         out = party.be.vec("t_out", 64)
         party.be.open_vec(a.ptr, out, 64)
         assert np.array_equal(ctx.download(out, (64, 4)), ctx.download(a, (64, 4)))
+        # ... and through the all-to-all + all-gather pattern used for three or more parties (RCCL all_to_all_single)
+        os.environ["ZK_OPEN"] = "a2a"
+        try:
+            for m in (64, 61, 1):
+                ctx.dev_zero(out, 64 * 32)
+                party.be.open_vec(a.ptr, out, m)
+                assert np.array_equal(ctx.download(out, (m, 4)), ctx.download(a, (m, 4)))
+            proof2 = party.create_proof_shared(pk, dr, zshare, rs[0], rs[1])
+            assert proof2 == proof
+        finally:
+            del os.environ["ZK_OPEN"]
     finally:
         ctx.close()
         dist.destroy_process_group()

@@ -86,6 +86,35 @@ def _worker(rank, world, port, q):
         except mpc.MacCheckError:
             caught = True
         assert caught, "corrupted MAC share was not detected"
+        # (5) the vector open of the GPU transport path (DistNet.open_sum: all-to-all of slices, local sum, all-gather of the
+        # summed slices; all-gather-then-sum for 2 parties) on CPU tensors, incl. lengths that do not divide by the world size
+        import torch
+        import zkref_c as OC
+        bufs = {}
+
+        def buffer(name, nbytes):
+            if (name, nbytes) not in bufs:
+                bufs[(name, nbytes)] = torch.empty(nbytes // 8, dtype=torch.int64)
+            return bufs[(name, nbytes)]
+
+        def sum_parties(gathered, n_parts, m, dst):
+            a = gathered.numpy().view(np.uint64)[: n_parts * m * 4].reshape(n_parts, m, 4)
+            acc = a[0]
+            for part in a[1:]:
+                acc = OC.fr_vec_op(1, np.ascontiguousarray(acc), np.ascontiguousarray(part))
+            dst[: m * 4] = torch.from_numpy(np.ascontiguousarray(acc).view(np.int64).reshape(-1))
+        for n_open in (1, 16, 17, 100):
+            vals = [[rng.fr() for _ in range(n_open)] for _ in range(world)]
+            mine = torch.from_numpy(cv.fr_to_mont(vals[rank]).view(np.int64).reshape(-1).copy())
+            want_sum = [sum(c) % O.R_MOD for c in zip(*vals)]
+            for mode in ("a2a", "allgather", None):
+                if mode:
+                    os.environ["ZK_OPEN"] = mode
+                else:
+                    os.environ.pop("ZK_OPEN", None)
+                res = net.open_sum(mine, n_open, sum_parties, buffer)
+                got = cv.fr_from_mont(res.numpy().view(np.uint64).reshape(-1, 4)[:n_open])
+                assert got == want_sum, "open_sum(%s) wrong for n=%d" % (mode, n_open)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback

@@ -26,6 +26,7 @@ The protocol code below is written against two small interfaces:
 """
 from __future__ import annotations
 
+import os
 import threading
 
 import numpy as np
@@ -58,6 +59,44 @@ class DistNet:
     def all_gather(self, send_tensor, recv_tensor):
         """recv = concat over parties (ordered by party id) of send  (MpcNet::broadcast_bytes)."""
         self.dist.all_gather_into_tensor(recv_tensor, send_tensor)
+        if self.device.type == "cuda":
+            self.torch.cuda.current_stream().synchronize()
+
+    def open_sum(self, send, n: int, sum_parties, buffer):
+        """Every party learns the element-wise sum over parties of `send` (n field elements of 4 int64 words each): the
+        "open" of a share vector.  Reduce-scatter then all-gather over point-to-point links: party j receives slice j of
+        every party (all_to_all), sums its slice, and the summed slices are all-gathered -- 2 x 32 n bytes in per GPU
+        for any number of parties, where all-gather-then-sum moves P x 32 n (xGMI is point-to-point: 7 links per GPU,
+        so the all-to-all pattern is the native one).  With 2 parties both patterns move the same bytes and the
+        all-gather is one collective instead of two, so it is kept there.
+        sum_parties(gathered, n_parts, m, out): out[i] = sum_p gathered[p*m + i] mod r on the caller's arithmetic;
+        buffer(name, nbytes) -> int64 tensor that stays valid until the next call with the same name."""
+        N = self.n
+        words = 4 * n
+        if N < 3 and os.environ.get("ZK_OPEN") != "a2a" or os.environ.get("ZK_OPEN") == "allgather":
+            recv = buffer("open_recv", N * n * 32)
+            self.dist.all_gather_into_tensor(recv, send[:words])
+            out = buffer("open_out", n * 32)
+            self._sync()
+            sum_parties(recv, N, n, out)
+            return out
+        chunk = (n + N - 1) // N
+        if chunk * N != n:
+            padded = buffer("open_pad", N * chunk * 32)
+            padded[:words] = send[:words]
+            padded[words:] = 0
+            send = padded
+        recv = buffer("open_recv", N * chunk * 32)
+        self.dist.all_to_all_single(recv, send[:N * chunk * 4])          # recv[p] = slice `rank` of party p
+        part = buffer("open_part", chunk * 32)
+        self._sync()
+        sum_parties(recv, N, chunk, part)
+        full = buffer("open_full", N * chunk * 32)
+        self.dist.all_gather_into_tensor(full, part)
+        self._sync()
+        return full[:words]
+
+    def _sync(self):
         if self.device.type == "cuda":
             self.torch.cuda.current_stream().synchronize()
 
@@ -158,10 +197,17 @@ class GpuBackend:
                 sp = self.vec("xchg_send", n)
                 st = self._tensors[sp]
                 ctx.fr_vec_op_dev(1, v, self.const_vec(np.zeros(4, dtype=np.uint64), n), sp, n)
-            rp = self.vec("xchg_recv", net.n * n)
             ctx.sync()                           # the vector kernels ran on the context's stream
-            net.all_gather(st, self._tensors[rp])
-            ctx.fr_sum_parties_dev(rp, net.n, n, out)
+
+            def sum_parties(gathered, n_parts, m, dst):
+                ctx.fr_sum_parties_dev(gathered.data_ptr(), n_parts, m, dst.data_ptr())
+                ctx.sync()
+
+            def buffer(name, nbytes):
+                return self._tensors[self.vec(name, nbytes // 32)]
+            res = net.open_sum(st, n, sum_parties, buffer)
+            ctx.memcpy_d2d(out, res.data_ptr(), n * 32)
+            ctx.sync()
         else:  # LocalNet: parties share one process; stage through host memory
             mine = ctx.download(v, (n, 4))
             allv = net.exchange(mine)
