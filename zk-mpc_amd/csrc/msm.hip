@@ -346,8 +346,18 @@ k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t
 // per segment -- the kernel never has thousands of blocks queued in front of the small sort / reduce
 // kernels of the other in-flight MSMs (which were starved for milliseconds behind that queue).  The next
 // point is fetched while the current one is added.
+// Minimum waves per SIMD asked of the compiler for the accumulate kernel (1 = no constraint).  Left to the compiler it
+// takes 230 VGPRs for G1 (2 waves / SIMD) and the full 512 for G2 (1 wave / SIMD); forcing 3 / 2 waves makes it spill
+// (176 / 920 B of scratch per lane) and the proof gets slower (28.2 vs 26.3 ms): the kernel is issue-bound, not
+// latency-bound, so occupancy buys nothing here.
+#ifndef ZK_ACCUM_WAVES_G1
+#define ZK_ACCUM_WAVES_G1 1
+#endif
+#ifndef ZK_ACCUM_WAVES_G2
+#define ZK_ACCUM_WAVES_G2 1
+#endif
 template <class F>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (F::WORDS == 12 ? ZK_ACCUM_WAVES_G1 : ZK_ACCUM_WAVES_G2))
 k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
         const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums) {
     const uint32_t S = ctr[2];
