@@ -515,18 +515,26 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e1, 0));
         rc = zk_msm_enqueue_sort(ctx, &jobs[3], s_sort, nullptr);
     }
-    for (int k = 0; k < 5 && rc == ZK_OK; k++) rc = zk_msm_enqueue_accum(ctx, &jobs[k], s_acc);
+    // accumulate order (job numbers: 0 = B in G2, 1 = A, 2 = B in G1, 3 = L, 4 = H; H's scalars arrive last)
+    int ord[5] = {0, 1, 2, 3, 4};
+    if (const char* e = getenv("ZK_MSM_ORDER")) {
+        bool seen[5] = {false, false, false, false, false};
+        int tmp[5], cnt = 0;
+        for (; cnt < 5 && e[cnt] >= '0' && e[cnt] <= '4' && !seen[e[cnt] - '0']; cnt++) { tmp[cnt] = e[cnt] - '0'; seen[tmp[cnt]] = true; }
+        if (cnt == 5) for (int k = 0; k < 5; k++) ord[k] = tmp[k];
+    }
+    for (int k = 0; k < 5 && rc == ZK_OK; k++) rc = zk_msm_enqueue_accum(ctx, &jobs[ord[k]], s_acc);
     // B-in-G2's reduce chain (the long one) stays on the sort stream; the four G1 reduces go to the main stream, idle by
     // then, so that each runs right behind its own accumulate kernel instead of queueing behind the G2 chain (that
     // queueing left 4 x 0.7 ms of reduces after the last accumulate).
-    for (int k = 0; k < 5 && rc == ZK_OK; k++) rc = zk_msm_enqueue_reduce(ctx, &jobs[k], k == 0 ? s_red : ctx->stream);
+    for (int k = 0; k < 5 && rc == ZK_OK; k++) rc = zk_msm_enqueue_reduce(ctx, &jobs[ord[k]], ord[k] == 0 ? s_red : ctx->stream);
     // finish in completion order: the host-side Horner of an early job overlaps the GPU work of the later ones
-    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[0], out_g2);
-    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[1], &out_g1[2]);
-    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[2], &out_g1[3]);
-    if (rc == ZK_OK && after_abc) after_abc();      // A, B1, B2 are in: the caller's host work overlaps the L and H jobs
-    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[3], &out_g1[1]);
-    if (rc == ZK_OK) rc = zk_msm_finish(ctx, &jobs[4], &out_g1[0]);
+    void* outs[5] = {out_g2, &out_g1[2], &out_g1[3], &out_g1[1], &out_g1[0]};
+    int abc_left = 3;
+    for (int k = 0; k < 5 && rc == ZK_OK; k++) {
+        rc = zk_msm_finish(ctx, &jobs[ord[k]], outs[ord[k]]);
+        if (ord[k] <= 2 && --abc_left == 0 && rc == ZK_OK && after_abc) after_abc();   // A, B1, B2 are in: the caller's host work overlaps the rest
+    }
     (void)hipStreamSynchronize(s_sort);
     (void)hipStreamSynchronize(s_acc);
     (void)hipStreamSynchronize(s_red);
