@@ -51,6 +51,7 @@ struct ZkMsmJob {
     uint32_t c = 0, W = 0, NB = 0, seg = 0, T1 = 0, nbits = 0;
     uint16_t off[65] = {0};           // window w covers scalar bits [off[w], off[w+1])
     uint32_t Wb = 0;                  // bucket sets: W, or 1 when the bases carry precomputed window multiples
+    uint32_t levels = 1, T2 = 0;      // chunked running-sum levels before the bit-decomposition sums (2 for G2: its additions are 4x dearer)
     uint32_t Rw = 0, RNB = 0;         // the reduce phase sees Rw windows of RNB buckets (merged mode: one big set cut into 2^15-bucket windows)
     uint32_t n_tab = 0, tab_off = 0;  // merged mode: table stride and offset of this MSM's first base
     const uint32_t* bases_dev = nullptr;

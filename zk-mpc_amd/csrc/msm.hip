@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(256) k_bases_export(const uint32_t* in, uint32
 // and reduce phases of the neighbouring jobs run beside them on other streams.
 template <class F>
 struct MsmBufs {
-    uint32_t *dig, *sorted, *counts, *offs, *seg_local, *small, *order, *sums, *lvS, *lvW, *bits;
+    uint32_t *dig, *sorted, *counts, *offs, *seg_local, *small, *order, *sums, *lvS, *lvW, *lvS2, *lvW2, *bits;
     SegDesc* desc;
     HeavyDesc* heavy;
 };
@@ -564,8 +564,13 @@ int msm_prepare_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base
     job->RNB = (merged && p.NB > 32768u) ? 32768u : p.NB;
     job->Rw = job->Wb * (p.NB / job->RNB);
     job->T1 = (job->RNB + (1u << REDUCE_K_LOG) - 1) >> REDUCE_K_LOG;
+    // G2: a second chunk level (8 -> 64 buckets per element) before the bit-decomposition sums: 2*T1 additions instead of
+    // ~nbits*T1/2 + 2*T1 in the LDS-tree kernel, which is the part of the G2 reduce chain that co-runs with (and slows)
+    // the G1 accumulate kernels; G1 keeps one level (one launch less in a chain whose launches each wait for a slot)
+    job->levels = (F::WORDS == 24 && job->T1 >= 512) ? 2u : 1u;
+    job->T2 = job->levels == 2 ? (job->T1 + (1u << REDUCE_K_LOG) - 1) >> REDUCE_K_LOG : job->T1;
     uint32_t nbits = 0;
-    while ((1u << nbits) < job->T1) nbits++;
+    while ((1u << nbits) < job->T2) nbits++;
     job->nbits = nbits;
     return ZK_OK;
 }
@@ -596,6 +601,11 @@ int msm_bufs_t(zk_ctx* ctx, ZkMsmJob* job, MsmBufs<F>& b, bool need_sort) {
     ZK_TRY(zk_scratch(ctx, slotname("msm_lvS"), (size_t)job->Rw * job->T1 * XW * 4, (void**)&b.lvS));
     ZK_TRY(zk_scratch(ctx, slotname("msm_lvW"), (size_t)job->Rw * job->T1 * XW * 4, (void**)&b.lvW));
     ZK_TRY(zk_scratch(ctx, slotname("msm_bits"), (size_t)job->Rw * (job->nbits + 2) * XW * 4, (void**)&b.bits));
+    b.lvS2 = b.lvW2 = nullptr;
+    if (job->levels == 2) {
+        ZK_TRY(zk_scratch(ctx, slotname("msm_lvS2"), (size_t)job->Rw * job->T2 * XW * 4, (void**)&b.lvS2));
+        ZK_TRY(zk_scratch(ctx, slotname("msm_lvW2"), (size_t)job->Rw * job->T2 * XW * 4, (void**)&b.lvW2));
+    }
     return ZK_OK;
 }
 
@@ -707,7 +717,15 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
                        (uint32_t)REDUCE_K_LOG, job->Rw, 1, 0);
     if (256 * XW * 4 > 64 * 1024)
         ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_bitsum<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * XW * 4)));
-    hipLaunchKernelGGL(k_bitsum<F>, job->Rw * nout, 256, 256 * XW * 4, st, b.lvS, b.lvW, b.bits, job->T1, job->nbits, nout);
+    const uint32_t *topS = b.lvS, *topW = b.lvW;
+    if (job->levels == 2) {
+        const size_t threads2 = (size_t)job->Rw * job->T2;
+        hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads2 + 63) / 64), 64, 0, st, (const uint32_t*)b.lvS, (const uint32_t*)b.lvW, b.lvS2, b.lvW2,
+                           job->T1, job->T2, (uint32_t)REDUCE_K_LOG, job->Rw, 0, 0);
+        topS = b.lvS2;
+        topW = b.lvW2;
+    }
+    hipLaunchKernelGGL(k_bitsum<F>, job->Rw * nout, 256, 256 * XW * 4, st, topS, topW, b.bits, job->T2, job->nbits, nout);
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
     // pinned destination: a pageable one would make the "async" copy block the host until this job is done
@@ -773,7 +791,7 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
                 vs = xyzz_add<H>(vs, run);
             }
         }
-        for (uint32_t k = REDUCE_K_LOG; k < 15; k++) vs = xyzz_dbl<H>(vs);
+        for (uint32_t k = REDUCE_K_LOG * job->levels; k < 15; k++) vs = xyzz_dbl<H>(vs);   // the plain sums carry 2^(K levels)
         total = xyzz_add<H>(total, vs);
     } else {
         for (int w = (int)job->Wb - 1; w >= 0; w--) {
