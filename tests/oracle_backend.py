@@ -59,6 +59,28 @@ class OracleBackend:
     def add(self, a, b, out, n): self.store[out] = OC.fr_vec_op(1, self.store[a], self.store[b])
     def sub(self, a, b, out, n): self.store[out] = OC.fr_vec_op(2, self.store[a], self.store[b])
 
+    def king_share(self, values, n, seed):
+        """Test-side mirror of GpuBackend.king_share (numpy shares, the product's transport scatter)."""
+        import torch
+        net = self.net
+        parts = None
+        if net.is_leader():
+            rs = np.random.RandomState(seed & 0x7FFFFFFF)
+            last = np.array(self.store[values], copy=True)
+            parts = []
+            for _ in range(net.n - 1):
+                t = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+                t[:, 3] &= np.uint64((1 << 60) - 1)
+                last = OC.fr_vec_op(2, last, t)
+                parts.append(t)
+            parts.append(last)
+        if hasattr(net, "dist"):
+            tensors = [torch.from_numpy(np.ascontiguousarray(p).view(np.int64).reshape(-1).copy()) for p in parts] if parts else None
+            mine = net.scatter(tensors, n * 32).numpy().view(np.uint64).reshape(n, 4)
+        else:
+            mine = net.scatter(parts, n * 32)
+        return self.put("king_share_%d" % len(self.store), mine)
+
     def open_vec(self, v, out, n):
         parts = self.net.all_gather_small(self.store[v])
         acc = parts[0]

@@ -178,6 +178,9 @@ def test_distnet_nccl_single_rank():
                 assert np.array_equal(ctx.download(out, (m, 4)), ctx.download(a, (m, 4)))
             proof2 = party.create_proof_shared(pk, dr, zshare, rs[0], rs[1])
             assert proof2 == proof
+            # king_share through RCCL's scatter (one rank: the only share is the value itself)
+            ks = party.king_share_vec(a.ptr, 64, seed=3)
+            assert np.array_equal(ctx.download(ks, (64, 4)), ctx.download(a, (64, 4)))
         finally:
             del os.environ["ZK_OPEN"]
     finally:
@@ -305,3 +308,22 @@ def test_collaborative_marlin_spdz(n_parties, n):
     assert all(r[0] == res[0][0] for r in res)
     assert res[0][0] == res[0][1]           # SPDZ run == additive run (which test_collaborative_marlin ties to the single prover)
     assert all(r[2] for r in res)
+
+
+@pytest.mark.parametrize("n_parties", [2, 3])
+def test_king_share_vector(n_parties):
+    """Reveal::king_share on a device vector: the leader's N - 1 random shares plus the residual, scattered; the shares
+    sum to the secret and no single share equals it."""
+    rng = O.Prng(1300 + n_parties)
+    n = 777
+    secret = [rng.fr() for _ in range(n)]
+
+    def fn(p, ctx, net):
+        party = mpc.Party(ctx, net=net)
+        src = ctx.upload(cv.fr_to_mont(secret)) if p == 0 else None
+        mine = party.king_share_vec(src.ptr if src else None, n, seed=42)
+        return cv.fr_from_mont(ctx.download(mine, (n, 4)))
+
+    res = run_parties(n_parties, fn)
+    assert [sum(c) % O.R_MOD for c in zip(*res)] == secret
+    assert all(r != secret for r in res)

@@ -115,6 +115,13 @@ def _worker(rank, world, port, q):
                 res = net.open_sum(mine, n_open, sum_parties, buffer)
                 got = cv.fr_from_mont(res.numpy().view(np.uint64).reshape(-1, 4)[:n_open])
                 assert got == want_sum, "open_sum(%s) wrong for n=%d" % (mode, n_open)
+        # (6) king_share: the leader splits a vector and scatters the shares (transport scatter); they sum to the vector
+        secret = [rng.fr() for _ in range(23)]
+        S = be.put("secret", cv.fr_to_mont(secret)) if rank == 0 else None
+        mine = party.king_share_vec(S, 23, seed=5)
+        parts = [cv.fr_from_mont(a) for a in net.all_gather_small(be.store[mine])]
+        assert [sum(c) % O.R_MOD for c in zip(*parts)] == secret
+        assert parts[0] != secret or world == 1
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback

@@ -96,6 +96,15 @@ class DistNet:
         self._sync()
         return full[:words]
 
+    def scatter(self, parts, nbytes: int):
+        """The leader ("king") hands parts[p] to party p; everybody returns its own part
+        (MpcNet::worker_receive_or_leader_send_element, used by king_share: mpc-algebra/src/share/additive.rs:98-107).
+        parts: list of N int64 tensors of nbytes / 8 words on the leader, None elsewhere."""
+        recv = self.torch.empty(nbytes // 8, dtype=self.torch.int64, device=self.device)
+        self.dist.scatter(recv, scatter_list=[p.reshape(-1) for p in parts] if self.rank == 0 else None, src=0)
+        self._sync()
+        return recv
+
     def _sync(self):
         if self.device.type == "cuda":
             self.torch.cuda.current_stream().synchronize()
@@ -140,6 +149,10 @@ class LocalNet:
 
     def all_gather_small(self, arr):
         return self.exchange(np.array(arr, copy=True))
+
+    def scatter(self, parts, nbytes: int):
+        """parts: list of N arrays on the leader, None elsewhere; returns this party's part."""
+        return self.exchange(parts if self.rank == 0 else None)[0][self.rank]
 
     def barrier(self):
         self.sh.barrier.wait()
@@ -218,6 +231,39 @@ class GpuBackend:
 
     def beaver_combine(self, sx, oy, tx, ty, tz, out, n):
         self.ctx.beaver_combine_dev(sx, oy, out, n, triple=(tx, ty, tz))
+
+    def king_share(self, values, n, seed):
+        """AdditiveFieldShare::king_share over a vector: the leader draws N-1 random share vectors, sets the last to
+        values - sum, and scatters them (share/additive.rs:98-107); `values` is a device vector on the leader, ignored
+        elsewhere.  Returns this party's share (device vector)."""
+        import torch
+        ctx, net = self.ctx, self.net
+        N = net.n
+        parts = None
+        if net.is_leader():
+            dev = torch.device("cuda", ctx.device)
+            g = torch.Generator(device=dev)
+            g.manual_seed(int(seed))
+            parts = []
+            last = torch.empty(n * 4, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            ctx.memcpy_d2d(last.data_ptr(), values, n * 32)
+            for _ in range(N - 1):
+                t = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device=dev, generator=g)
+                t[:, 3] &= (1 << 60) - 1              # < 2^252 < r: a valid residue
+                torch.cuda.synchronize()
+                ctx.fr_vec_op_dev(2, last.data_ptr(), t.data_ptr(), last.data_ptr(), n)
+                parts.append(t.reshape(-1))
+            ctx.sync()
+            parts.append(last)
+        if isinstance(net, DistNet):
+            mine = net.scatter(parts, n * 32)
+            self._tensors[mine.data_ptr()] = mine
+            return mine.data_ptr()
+        host = [p.cpu().numpy().view(np.uint64).reshape(n, 4) for p in parts] if parts is not None else None
+        b = ctx.upload(net.scatter(host, n * 32))
+        self._bufs[("king_share", n, len(self._bufs))] = (b, b.ptr)
+        return b.ptr
 
     def is_zero_vec(self, v, n) -> bool:
         return self.ctx.fr_vec_is_zero_dev(v, n)
@@ -303,6 +349,11 @@ class Party:
             sh.append((int(v) - sum(sh)) % R_MOD)
             out.append(fr_to_mont([sh[self.net.rank]])[0])
         return out
+
+    def king_share_vec(self, values, n: int, seed: int = 0):
+        """Input distribution by the leader (Reveal::king_share / king_share_batch): see GpuBackend.king_share."""
+        self.bytes_sent += (self.net.n - 1) * n * 32 if self.leader else 0
+        return self.be.king_share(values, n, seed)
 
     def share_assignment_dev(self, z_dev, r1cs, seed: int):
         """This party's additive share of a full assignment that is resident on its own device
