@@ -133,6 +133,9 @@ int zk_bases_serialize(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, 
 /* GroupAffine::deserialize_unchecked (:930-942) on n uncompressed points, plus an on-curve check (error instead of
  * a silently wrong table); no subgroup check. */
 int zk_bases_deserialize_uncompressed(zk_ctx* ctx, int group, const uint8_t* bytes_host, size_t n, zk_bases** out);
+/* GroupAffine::deserialize (:888-905) on n compressed points: y from x by a square root in Fq / Fq2 (get_point_from_x,
+ * :110-125), sign from the flag; error if an x is not on the curve; no subgroup check. */
+int zk_bases_deserialize_compressed(zk_ctx* ctx, int group, const uint8_t* bytes_host, size_t n, zk_bases** out);
 
 /* n_jobs independent MSMs pipelined over the library's sort / accumulate streams (one job sorts while the previous one
  * accumulates).  outs[k] receives a zk_g1_projective or zk_g2_projective according to bases[k]'s group; base_offsets may

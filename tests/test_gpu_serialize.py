@@ -28,6 +28,11 @@ def test_point_tables_both_forms(ctx):
     r2 = ctx.bases_deserialize_uncompressed(b2.serialize(False), len(p2), 2)
     assert cv.g1_array_to_affine(r1.download()) == p1
     assert cv.g2_array_to_affine(r2.download()) == p2
+    # compressed round trip: one square root per point (Tonelli-Shanks in Fq, the norm method in Fq2), sign from the flag
+    c1 = ctx.bases_deserialize_compressed(b1.serialize(True), len(p1), 1)
+    c2 = ctx.bases_deserialize_compressed(b2.serialize(True), len(p2), 2)
+    assert cv.g1_array_to_affine(c1.download()) == p1
+    assert cv.g2_array_to_affine(c2.download()) == p2
 
 
 def test_deserialize_rejects_garbage(ctx):
@@ -37,6 +42,17 @@ def test_deserialize_rejects_garbage(ctx):
     bad[0] ^= 1                                                 # x changed: no longer on the curve
     with pytest.raises(Exception, match="not on the curve"):
         ctx.bases_deserialize_uncompressed(bytes(bad), 1, 1)
+    xs = bytearray(O.g1_serialize(O.g1_mul(O.G1_GEN, 5)))
+    for delta in range(1, 40):                                  # some x + delta has no y: x^3 + 1 is a non-residue
+        cand = bytearray(xs)
+        cand[0] = (cand[0] + delta) & 0xFF
+        x = int.from_bytes(bytes(cand[:47]) + bytes([cand[47] & 0x3F]), "little")
+        if pow((x ** 3 + 1) % O.Q_MOD, (O.Q_MOD - 1) // 2, O.Q_MOD) != 1:
+            with pytest.raises(Exception, match="not on the curve"):
+                ctx.bases_deserialize_compressed(bytes(cand), 1, 1)
+            break
+    else:
+        raise AssertionError("no non-residue found")
     flagged = bytearray(good)
     flagged[95] |= 0x80                                         # sign flag has no place in the uncompressed form
     with pytest.raises(Exception, match="flag"):
@@ -56,6 +72,7 @@ def test_groth16_keys_wire_format(ctx):
     for compressed in (True, False):
         assert S.verifying_key_bytes(ctx, dpk, compressed) == O.vk_serialize(opk, compressed)
         assert S.proving_key_bytes(ctx, dpk, compressed) == O.pk_serialize(opk, compressed)
+    pk3, _, _ = S.proving_key_from_bytes(ctx, O.pk_serialize(opk, True), compressed=True)
     pk2, gamma_g2, gamma_abc = S.proving_key_from_bytes(ctx, O.pk_serialize(opk, False))
     assert cv.g2_array_to_affine(gamma_g2.reshape(1, 24)) == [opk.gamma_g2]
     assert cv.g1_array_to_affine(gamma_abc) == opk.gamma_abc_g1
@@ -63,5 +80,6 @@ def test_groth16_keys_wire_format(ctx):
     zm = cv.fr_to_mont(z)
     proof = ctx.create_proof(pk2, dr, zm, mont1(r), mont1(s))
     assert proof == ctx.create_proof(dpk, dr, zm, mont1(r), mont1(s))
+    assert proof == ctx.create_proof(pk3, dr, zm, mont1(r), mont1(s))
     A, B, Cc = O.create_proof(r1cs, opk, z, r, s)
     assert proof == O.proof_serialize(A, B, Cc)

@@ -154,6 +154,7 @@ PROTOTYPES = {
     "zk_point_serialized_size": (_SZ, [_I, _I]),
     "zk_bases_serialize": (_I, [_P, _P, _SZ, _SZ, _I, _P]),
     "zk_bases_deserialize_uncompressed": (_I, [_P, _I, _P, _SZ, C.POINTER(_P)]),
+    "zk_bases_deserialize_compressed": (_I, [_P, _I, _P, _SZ, C.POINTER(_P)]),
     "zk_msm_batch_dev": (_I, [_P, _SZ, _P, _P, _P, _P, _P]),
     "zk_memcpy_d2d": (_I, [_P, _P, _P, _SZ]),
     "zk_dev_zero": (_I, [_P, _P, _SZ]),

@@ -186,10 +186,17 @@ class Context:
         return Bases(self, h, group)
 
     def bases_deserialize_uncompressed(self, data: bytes, n: int, group: int) -> "Bases":
+        return self._bases_deserialize(data, n, group, 0)
+
+    def bases_deserialize_compressed(self, data: bytes, n: int, group: int) -> "Bases":
+        return self._bases_deserialize(data, n, group, 1)
+
+    def _bases_deserialize(self, data: bytes, n: int, group: int, compressed: int) -> "Bases":
         buf = np.frombuffer(data, dtype=np.uint8)
-        assert buf.size == n * self.lib.zk_point_serialized_size(group, 0)
+        assert buf.size == n * self.lib.zk_point_serialized_size(group, compressed)
         out = C.c_void_p()
-        self._ck(self.lib.zk_bases_deserialize_uncompressed(self.h, group, _ptr(np.ascontiguousarray(buf)) if n else None, n, C.byref(out)))
+        fn = self.lib.zk_bases_deserialize_compressed if compressed else self.lib.zk_bases_deserialize_uncompressed
+        self._ck(fn(self.h, group, _ptr(np.ascontiguousarray(buf)) if n else None, n, C.byref(out)))
         return Bases(self, out, group)
 
     def fixed_base(self, scalars_dev, n: int, group: int, gen_k_mont4) -> "Bases":

@@ -3,6 +3,7 @@
 // Replaces (reference, relative to /root/reference/arkworks/algebra):
 //   ec/src/models/short_weierstrass_jacobian.rs:847-883   GroupAffine::{serialize, serialize_uncompressed}
 //   ec/src/models/short_weierstrass_jacobian.rs:930-942   GroupAffine::deserialize_unchecked
+//   ec/src/models/short_weierstrass_jacobian.rs:888-905,110-125   GroupAffine::deserialize / get_point_from_x (compressed form)
 //   ff/src/fields/macros.rs:3-55, serialize/src/flags.rs:61-139   field bytes + SWFlags (bit 7: y > -y, bit 6: infinity)
 //   ff/src/fields/models/quadratic_extension.rs:411-420,659-669   Fq2 ordering (c1 first) and layout (c0 | c1, flags on c1)
 // A proving key at 2^20 holds ~5 M points: one thread per point, HBM-bound (96-192 B in, 48-192 B out).
@@ -106,6 +107,92 @@ __global__ void __launch_bounds__(256) k_deserialize_uncompressed(const uint32_t
     }
 }
 
+// ---- square roots, for the compressed form (GroupAffine::get_point_from_x, short_weierstrass_jacobian.rs:110-125) ----
+// Which root comes out does not matter: the sign flag of the encoding selects between y and -y afterwards.
+// Fq: Tonelli-Shanks with q - 1 = 2^46 t (ff/src/fields/macros.rs sqrt_impl, eprint 2012/685 alg. 5); false = non-residue.
+__device__ bool fq_sqrt(const Fq& a, Fq* out) {
+    if (fp_is_zero<FqParams>(a)) { *out = a; return true; }
+    const Fq one = fp_one<FqParams>();
+    uint32_t e[FqParams::L];
+#pragma unroll
+    for (int i = 0; i < FqParams::L; i++) e[i] = FqParams::TS_T_MINUS1_DIV2[i];
+    Fq z = fp_const<FqParams>(FqParams::TS_ROOT);
+    Fq w = fp_pow_limbs<FqParams>(a, e, FqParams::L);       // a^((t-1)/2)
+    Fq x = fp_mul<FqParams>(w, a);                            // a^((t+1)/2)
+    Fq b = fp_mul<FqParams>(x, w);                            // a^t
+    uint32_t v = FQ_TWO_ADICITY;
+    while (!fp_eq<FqParams>(b, one)) {
+        uint32_t k = 0;
+        Fq b2k = b;
+        while (!fp_eq<FqParams>(b2k, one)) {
+            b2k = fp_sqr<FqParams>(b2k);
+            if (++k == v) return false;
+        }
+        Fq ww = z;
+        for (uint32_t i = 0; i + k + 1 < v; i++) ww = fp_sqr<FqParams>(ww);
+        z = fp_sqr<FqParams>(ww);
+        b = fp_mul<FqParams>(b, z);
+        x = fp_mul<FqParams>(x, ww);
+        v = k;
+    }
+    *out = x;
+    return fp_eq<FqParams>(fp_sqr<FqParams>(x), a);
+}
+// Fq2 = Fq[u]/(u^2 + 5): through the norm (ff/src/fields/models/quadratic_extension.rs sqrt).
+__device__ bool fq2_sqrt(const Fq2& a, Fq2* out) {
+    using B = FqField;
+    Fq r;
+    if (B::is_zero(a.c1)) {
+        if (fq_sqrt(a.c0, &r)) { *out = Fq2{r, B::zero()}; return true; }
+        if (!fq_sqrt(B::mul(a.c0, fp_const<FqParams>(FqParams::G2_B_C1)), &r)) return false;   // c0 / (-5) = s^2  =>  (s u)^2 = c0
+        *out = Fq2{B::zero(), r};
+        return true;
+    }
+    Fq norm = B::add(B::sqr(a.c0), Fq2Field::mul5(B::sqr(a.c1)));
+    Fq alpha;
+    if (!fq_sqrt(norm, &alpha)) return false;
+    const Fq inv2 = fp_const<FqParams>(FqParams::INV2);
+    Fq delta = B::mul(B::add(alpha, a.c0), inv2);
+    Fq c0;
+    if (!fq_sqrt(delta, &c0)) {
+        delta = B::sub(delta, alpha);
+        if (!fq_sqrt(delta, &c0)) return false;
+    }
+    Fq2 y{c0, B::mul(B::mul(a.c1, inv2), B::inv(c0))};
+    *out = y;
+    return Fq2Field::eq(Fq2Field::sqr(y), a);
+}
+__device__ __forceinline__ bool field_sqrt(const Fq& a, Fq* out) { return fq_sqrt(a, out); }
+__device__ __forceinline__ bool field_sqrt(const Fq2& a, Fq2* out) { return fq2_sqrt(a, out); }
+
+// Compressed points (GroupAffine::deserialize, :888-905 without the subgroup check): x with the flags in its last byte.
+template <class F>
+__global__ void __launch_bounds__(64) k_deserialize_compressed(const uint32_t* in, size_t n, uint32_t* bases, uint32_t* bad) {
+    constexpr int FW = Ser<F>::FW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t w[FW];
+#pragma unroll
+        for (int k = 0; k < FW; k++) w[k] = in[i * FW + k];
+        const uint32_t flags = w[FW - 1] & (FLAG_POSITIVE | FLAG_INFINITY);
+        w[FW - 1] &= ~(FLAG_POSITIVE | FLAG_INFINITY);
+        Affine<F> p;
+        p.x = F::zero();
+        p.y = F::zero();
+        if (!(flags & FLAG_INFINITY)) {
+            p.x = Ser<F>::from_words(w);
+            typename F::T y, rhs = F::add(F::mul(F::sqr(p.x), p.x), curve_b<F>());
+            if (!field_sqrt(rhs, &y)) {
+                atomicOr(bad, 1u);                       // x is not the abscissa of a curve point
+                p.x = F::zero();
+            } else {
+                const bool positive = (flags & FLAG_POSITIVE) != 0;
+                p.y = (Ser<F>::gt_neg(y) != positive) ? F::neg(y) : y;
+            }
+        }
+        aff_store16<F>(bases, i, p);
+    }
+}
+
 template <class F>
 int serialize_t(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, int compressed, uint8_t* out) {
     if (offset + n > b->n) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_bases_serialize: range out of bounds");
@@ -123,11 +210,11 @@ int serialize_t(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, int com
 }
 
 template <class F>
-int deserialize_t(zk_ctx* ctx, int group, const uint8_t* bytes, size_t n, zk_bases** out) {
+int deserialize_t(zk_ctx* ctx, int group, const uint8_t* bytes, size_t n, int compressed, zk_bases** out) {
     zk_bases* b = new zk_bases();
     b->group = group;
     b->n = n;
-    const size_t in_bytes = n * (size_t)Ser<F>::FW * 8, dev_bytes = n * 2 * F::WORDS * 4;
+    const size_t in_bytes = n * (size_t)Ser<F>::FW * (compressed ? 4 : 8), dev_bytes = n * 2 * F::WORDS * 4;
     if (n) {
         char* stage;
         ZK_TRY(zk_scratch(ctx, "ser_stage", in_bytes + 16, (void**)&stage));
@@ -136,7 +223,10 @@ int deserialize_t(zk_ctx* ctx, int group, const uint8_t* bytes, size_t n, zk_bas
         uint32_t* bad = (uint32_t*)(stage + in_bytes);
         ZK_HIP(ctx, hipMemcpyAsync(stage, bytes, in_bytes, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(ctx, hipMemsetAsync(bad, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(k_deserialize_uncompressed<F>, zk_grid(n, 256), 256, 0, ctx->stream, (const uint32_t*)stage, n, b->dev, bad);
+        if (compressed)
+            hipLaunchKernelGGL(k_deserialize_compressed<F>, zk_grid(n, 64, 1 << 16), 64, 0, ctx->stream, (const uint32_t*)stage, n, b->dev, bad);
+        else
+            hipLaunchKernelGGL(k_deserialize_uncompressed<F>, zk_grid(n, 256), 256, 0, ctx->stream, (const uint32_t*)stage, n, b->dev, bad);
         ZK_HIP(ctx, hipGetLastError());
         uint32_t h = 0;
         ZK_HIP(ctx, hipMemcpyAsync(&h, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -166,5 +256,10 @@ extern "C" int zk_bases_serialize(zk_ctx* ctx, const zk_bases* b, size_t offset,
 
 extern "C" int zk_bases_deserialize_uncompressed(zk_ctx* ctx, int group, const uint8_t* bytes_host, size_t n, zk_bases** out) {
     if (!ctx || !out || (n && !bytes_host) || (group != 1 && group != 2)) return ZK_ERR_ARG;
-    return group == 2 ? deserialize_t<G2Field>(ctx, group, bytes_host, n, out) : deserialize_t<G1Field>(ctx, group, bytes_host, n, out);
+    return group == 2 ? deserialize_t<G2Field>(ctx, group, bytes_host, n, 0, out) : deserialize_t<G1Field>(ctx, group, bytes_host, n, 0, out);
+}
+
+extern "C" int zk_bases_deserialize_compressed(zk_ctx* ctx, int group, const uint8_t* bytes_host, size_t n, zk_bases** out) {
+    if (!ctx || !out || (n && !bytes_host) || (group != 1 && group != 2)) return ZK_ERR_ARG;
+    return group == 2 ? deserialize_t<G2Field>(ctx, group, bytes_host, n, 1, out) : deserialize_t<G1Field>(ctx, group, bytes_host, n, 1, out);
 }

@@ -55,15 +55,15 @@ class _Reader:
         return int.from_bytes(self.take(8), "little")
 
 
-def proving_key_from_bytes(ctx: Context, data: bytes):
-    """Load a ProvingKey written with `serialize_uncompressed` (the form meant for trusted local storage; the
-    compressed form needs a square root per point and is not read here).  Returns (ProvingKey, gamma_g2, gamma_abc_g1):
-    the prover does not use the last two, the verifier does."""
+def proving_key_from_bytes(ctx: Context, data: bytes, compressed: bool = False):
+    """Load a ProvingKey written with `serialize_uncompressed` or, with compressed=True, with `serialize` (one square
+    root per point on the device).  Returns (ProvingKey, gamma_g2, gamma_abc_g1): the prover does not use the last two,
+    the verifier does."""
     r = _Reader(data)
 
     def pts(n: int, group: int) -> np.ndarray:
-        raw = r.take(n * (96 if group == 1 else 192))
-        b = ctx.bases_deserialize_uncompressed(raw, n, group)
+        raw = r.take(n * (48 if group == 1 else 96) * (1 if compressed else 2))
+        b = (ctx.bases_deserialize_compressed if compressed else ctx.bases_deserialize_uncompressed)(raw, n, group)
         try:
             return b.download()
         finally:
