@@ -232,3 +232,27 @@ def test_msm_batch_pipeline(ctx):
         want = ctx.msm_dev(b, off, s, m)
         to_aff = cv.g1_projective_to_affine if b.group == 1 else cv.g2_projective_to_affine
         assert to_aff(got) == to_aff(want)
+
+
+def test_msm_batch_over_window_multiples_with_offsets(ctx):
+    """Pipelined batch over ONE resident table that carries window multiples (2^18 points: c = 17, sliced reduce), jobs
+    with base offsets (the shifted powers of a degree-bounded KZG commitment) and different lengths: same group elements
+    as the plain table gives."""
+    n = 1 << 18
+    rs = np.random.RandomState(99)
+
+    def rand_mont(m):
+        a = rs.randint(0, 1 << 62, size=(m, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+    dk = ctx.upload(rand_mont(n))
+    plain = ctx.fixed_base(dk.ptr, n, 1, mont1(1))
+    pre = ctx.fixed_base(dk.ptr, n, 1, mont1(1))
+    pre.precompute()
+    assert ctx.lib.zk_bases_window_bits(pre.h) == 17 and ctx.lib.zk_bases_window_bits(plain.h) == 0
+    vecs = [ctx.upload(rand_mont(n)) for _ in range(3)]
+    spec = [(0, n, 0), (1000, n - 1000, 1), (5, 70000, 2), (n - 4096, 4096, 0), (12345, 1, 1)]
+    got = ctx.msm_batch_dev([(pre, off, vecs[v].ptr, m) for off, m, v in spec])
+    want = ctx.msm_batch_dev([(plain, off, vecs[v].ptr, m) for off, m, v in spec])
+    for g, w in zip(got, want):
+        assert cv.g1_projective_to_affine(g) == cv.g1_projective_to_affine(w)
