@@ -303,6 +303,19 @@ int zk_she_encode_dev(zk_ctx* ctx, const void* plain_fr_dev, void* out_dev, size
 /* Encodedtext::decode (src/she/encodedtext.rs:24-52): batch x N Fq coefficients -> batch x N Fr slots. */
 int zk_she_decode_dev(zk_ctx* ctx, const void* enc_dev, void* out_fr_dev, size_t n, size_t batch);
 
+/* ---- transport of the vector opens inside the library (row a13): RCCL over xGMI, one communicator per context ----
+ * The leader calls zk_comm_unique_id and ships the 128 bytes to the other parties over the channel it already has (the
+ * reference's TCP mesh); then every party calls zk_comm_init(ctx, id, party_id, n_parties).  RCCL is dlopen'ed on first
+ * use (ZK_RCCL_LIB overrides the library name). */
+int zk_comm_unique_id(uint8_t out[128]);
+int zk_comm_init(zk_ctx* ctx, const uint8_t id[128], int rank, int n_parties);
+int zk_comm_destroy(zk_ctx* ctx);             /* also done by zk_ctx_destroy */
+/* AdditiveFieldShare::batch_open on a device vector (mpc-algebra/src/share/additive.rs:124-131 over
+ * MpcSerNet::broadcast, channel.rs:12-28): out[i] = sum over parties of v[i] mod r, on every party; out may alias v.
+ * Three or more parties: all-to-all of slices, local sum, all-gather of the summed slices (2 x 32 n bytes in per GPU);
+ * two: one all-gather and a local sum.  Asynchronous on the context stream. */
+int zk_open_sum_fr_dev(zk_ctx* ctx, const void* v_dev, size_t n, void* out_dev);
+
 /* ---- share algebra on device vectors (rows a11, a13) ------------------------------------- */
 /* out[i] = sum_p gathered[p*n + i] mod r: the receive side of AdditiveFieldShare::batch_open
  * (mpc-algebra/src/share/additive.rs:124-131) after an all-gather of the parties' vectors. */

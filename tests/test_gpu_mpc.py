@@ -178,6 +178,15 @@ def test_distnet_nccl_single_rank():
                 assert np.array_equal(ctx.download(out, (m, 4)), ctx.download(a, (m, 4)))
             proof2 = party.create_proof_shared(pk, dr, zshare, rs[0], rs[1])
             assert proof2 == proof
+            # the same proof with the opens on the library's own RCCL communicator (ZK_TRANSPORT=native)
+            os.environ["ZK_TRANSPORT"] = "native"
+            try:
+                party_n = mpc.Party(ctx, dist)
+                assert party_n.be.native_open
+                assert party_n.create_proof_shared(pk, dr, zshare, rs[0], rs[1]) == proof
+            finally:
+                del os.environ["ZK_TRANSPORT"]
+                ctx.comm_destroy()
             # king_share through RCCL's scatter (one rank: the only share is the value itself)
             ks = party.king_share_vec(a.ptr, 64, seed=3)
             assert np.array_equal(ctx.download(ks, (64, 4)), ctx.download(a, (64, 4)))
@@ -327,3 +336,35 @@ def test_king_share_vector(n_parties):
     res = run_parties(n_parties, fn)
     assert [sum(c) % O.R_MOD for c in zip(*res)] == secret
     assert all(r != secret for r in res)
+
+
+def test_native_rccl_open_single_rank(ctx):
+    """The library's own transport (comm.hip: RCCL dlopen'ed, communicator from a unique id) with one rank: both open
+    patterns return the vector itself, in place and out of place, for lengths with and without padding."""
+    import os
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.comm_init(uid, 0, 1)
+    try:
+        rng = O.Prng(1400)
+        vals = [rng.fr() for _ in range(1000)]
+        v = ctx.upload(cv.fr_to_mont(vals))
+        out = ctx.alloc(1000 * 32)
+        for mode in ("allgather", "a2a", None):
+            if mode:
+                os.environ["ZK_OPEN"] = mode
+            else:
+                os.environ.pop("ZK_OPEN", None)
+            for m in (1000, 999, 1):
+                ctx.dev_zero(out.ptr, 1000 * 32)
+                ctx.open_sum_fr_dev(v.ptr, m, out.ptr)
+                assert cv.fr_from_mont(ctx.download(out, (m, 4))) == vals[:m]
+        os.environ.pop("ZK_OPEN", None)
+        w = ctx.upload(cv.fr_to_mont(vals))
+        ctx.open_sum_fr_dev(w.ptr, 1000, w.ptr)           # in place
+        assert cv.fr_from_mont(ctx.download(w, (1000, 4))) == vals
+        with pytest.raises(Exception, match="already has a communicator"):
+            ctx.comm_init(uid, 0, 1)
+    finally:
+        os.environ.pop("ZK_OPEN", None)
+        ctx.comm_destroy()

@@ -156,6 +156,10 @@ PROTOTYPES = {
     "zk_bases_deserialize_uncompressed": (_I, [_P, _I, _P, _SZ, C.POINTER(_P)]),
     "zk_bases_deserialize_compressed": (_I, [_P, _I, _P, _SZ, C.POINTER(_P)]),
     "zk_msm_batch_dev": (_I, [_P, _SZ, _P, _P, _P, _P, _P]),
+    "zk_comm_unique_id": (_I, [_P]),
+    "zk_comm_init": (_I, [_P, _P, _I, _I]),
+    "zk_comm_destroy": (_I, [_P]),
+    "zk_open_sum_fr_dev": (_I, [_P, _P, _SZ, _P]),
     "zk_memcpy_d2d": (_I, [_P, _P, _P, _SZ]),
     "zk_dev_zero": (_I, [_P, _P, _SZ]),
     "zk_fr_inverse": (_I, [_P, _P]),

@@ -346,6 +346,23 @@ class Context:
     def encodedtext_decode_dev(self, enc, out_fr, n: int, batch: int = 1):
         self._ck(self.lib.zk_she_decode_dev(self.h, C.c_void_p(int(enc)), C.c_void_p(int(out_fr)), n, batch))
 
+    # ---- native transport (RCCL inside the library) ----
+    def comm_unique_id(self) -> bytes:
+        out = np.zeros(128, dtype=np.uint8)
+        self._ck(self.lib.zk_comm_unique_id(_ptr(out)))
+        return out.tobytes()
+
+    def comm_init(self, unique_id: bytes, rank: int, n_parties: int):
+        buf = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        assert buf.size == 128
+        self._ck(self.lib.zk_comm_init(self.h, _ptr(buf), rank, n_parties))
+
+    def comm_destroy(self):
+        self._ck(self.lib.zk_comm_destroy(self.h))
+
+    def open_sum_fr_dev(self, v, n: int, out):
+        self._ck(self.lib.zk_open_sum_fr_dev(self.h, C.c_void_p(int(v)), n, C.c_void_p(int(out))))
+
     # ---- share algebra ----
     def fr_sum_parties_dev(self, gathered, n_parties: int, n: int, out):
         self._ck(self.lib.zk_fr_sum_parties_dev(self.h, C.c_void_p(int(gathered)), n_parties, n, C.c_void_p(int(out))))

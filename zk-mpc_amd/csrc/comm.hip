@@ -1,0 +1,154 @@
+// comm.hip -- the transport of the share-vector open inside the library: RCCL over xGMI, one communicator per context.
+//
+// Replaces (reference): MpcSerNet::broadcast over MPCNetConnection::broadcast_bytes for the vector opens of
+// AdditiveFieldShare::batch_open (mpc-algebra/src/channel.rs:12-28, mpc-net/src/multi.rs:469-525,
+// mpc-algebra/src/share/additive.rs:124-131): every party ends up with sum_p v_p mod r.
+// A host in the reference's language needs nothing but this C ABI: the leader obtains a 128-byte id
+// (zk_comm_unique_id), ships it to the other parties over the TCP mesh it already has, every party calls
+// zk_comm_init, and the opens run GPU to GPU.
+//
+// Pattern (same as mpc.py::DistNet.open_sum): for P >= 3 an all-to-all of slices (grouped send / recv), a local sum of
+// the P slices, an all-gather of the summed slices: 2 x 32 n bytes in per GPU for any P; for P <= 2 one all-gather and a
+// local sum.  RCCL is loaded with dlopen on first use, so the library carries no link-time dependency on it (a process
+// that also hosts PyTorch already has a copy mapped).
+#include "../../include/zkmpc_hip.h"
+#include "ctx.hpp"
+#include "internal.hpp"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl* rccl(std::string* err) {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {getenv("ZK_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* nm : names) {
+            if (!nm) continue;
+            if ((r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+        }
+        if (r.lib) {
+#define ZK_SYM(f) *(void**)(&r.f) = dlsym(r.lib, "nccl" #f)
+            ZK_SYM(GetUniqueId); ZK_SYM(CommInitRank); ZK_SYM(CommDestroy); ZK_SYM(AllGather); ZK_SYM(Send); ZK_SYM(Recv);
+            ZK_SYM(GroupStart); ZK_SYM(GroupEnd); ZK_SYM(GetErrorString);
+#undef ZK_SYM
+        }
+    }
+    if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd) {
+        if (err) *err = "RCCL not available (dlopen librccl.so failed or symbols missing; set ZK_RCCL_LIB)";
+        return nullptr;
+    }
+    return &r;
+}
+
+struct Comm { ncclComm_t comm = nullptr; int rank = 0, n = 1; };
+
+#define ZK_NCCL(ctx, R, expr)                                                                   \
+    do {                                                                                          \
+        ncclResult_t _e = (expr);                                                                 \
+        if (_e != ncclSuccess) {                                                                  \
+            (ctx)->last_error = std::string(#expr " -> ") + ((R)->GetErrorString ? (R)->GetErrorString(_e) : "rccl error"); \
+            return ZK_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+}  // namespace
+
+extern "C" int zk_comm_unique_id(uint8_t out[128]) {
+    if (!out) return ZK_ERR_ARG;
+    Rccl* R = rccl(nullptr);
+    if (!R) return ZK_ERR_STATE;
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) return ZK_ERR_HIP;
+    static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
+    memcpy(out, &id, 128);
+    return ZK_OK;
+}
+
+extern "C" int zk_comm_init(zk_ctx* ctx, const uint8_t id_bytes[128], int rank, int n_parties) {
+    if (!ctx || !id_bytes || n_parties < 1 || rank < 0 || rank >= n_parties) return ZK_ERR_ARG;
+    if (ctx->comm) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_comm_init: this context already has a communicator");
+    Rccl* R = rccl(&ctx->last_error);
+    if (!R) return ZK_ERR_STATE;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, 128);
+    Comm* c = new Comm();
+    c->rank = rank;
+    c->n = n_parties;
+    ncclResult_t e = R->CommInitRank(&c->comm, n_parties, id, rank);
+    if (e != ncclSuccess) {
+        delete c;
+        ctx->last_error = std::string("ncclCommInitRank -> ") + (R->GetErrorString ? R->GetErrorString(e) : "rccl error");
+        return ZK_ERR_HIP;
+    }
+    ctx->comm = c;
+    return ZK_OK;
+}
+
+extern "C" int zk_comm_destroy(zk_ctx* ctx) {
+    if (!ctx) return ZK_ERR_ARG;
+    if (!ctx->comm) return ZK_OK;
+    Comm* c = (Comm*)ctx->comm;
+    Rccl* R = rccl(nullptr);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (R && R->CommDestroy && c->comm) (void)R->CommDestroy(c->comm);
+    delete c;
+    ctx->comm = nullptr;
+    return ZK_OK;
+}
+
+// out[i] = sum over parties of v[i] mod r, on every party (v, out: n field elements on the device; out may alias v)
+extern "C" int zk_open_sum_fr_dev(zk_ctx* ctx, const void* v_dev, size_t n, void* out_dev) {
+    if (!ctx || (n && (!v_dev || !out_dev))) return ZK_ERR_ARG;
+    if (!ctx->comm) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_open_sum_fr_dev: no communicator (zk_comm_init)");
+    if (n == 0) return ZK_OK;
+    Comm* c = (Comm*)ctx->comm;
+    Rccl* R = rccl(&ctx->last_error);
+    if (!R) return ZK_ERR_STATE;
+    const int P = c->n;
+    hipStream_t st = ctx->stream;
+    const char* mode = getenv("ZK_OPEN");
+    const bool a2a = mode ? strcmp(mode, "a2a") == 0 : P >= 3;
+    if (!a2a) {
+        void* recv;
+        ZK_TRY(zk_scratch(ctx, "open_recv", (size_t)P * n * 32, &recv));
+        ZK_NCCL(ctx, R, R->AllGather(v_dev, recv, n * 4, ncclUint64, c->comm, st));
+        return zk_fr_sum_parties_dev(ctx, recv, (size_t)P, n, out_dev);
+    }
+    const size_t chunk = (n + P - 1) / P;
+    char *send, *recv, *part, *full;
+    ZK_TRY(zk_scratch(ctx, "open_pad", (size_t)P * chunk * 32, (void**)&send));
+    ZK_TRY(zk_scratch(ctx, "open_recv", (size_t)P * chunk * 32, (void**)&recv));
+    ZK_TRY(zk_scratch(ctx, "open_part", chunk * 32, (void**)&part));
+    ZK_TRY(zk_scratch(ctx, "open_full", (size_t)P * chunk * 32, (void**)&full));
+    ZK_HIP(ctx, hipMemcpyAsync(send, v_dev, n * 32, hipMemcpyDeviceToDevice, st));
+    if ((size_t)P * chunk > n) ZK_HIP(ctx, hipMemsetAsync(send + n * 32, 0, ((size_t)P * chunk - n) * 32, st));
+    ZK_NCCL(ctx, R, R->GroupStart());
+    for (int p = 0; p < P; p++) {
+        ZK_NCCL(ctx, R, R->Send(send + (size_t)p * chunk * 32, chunk * 4, ncclUint64, p, c->comm, st));     // slice p goes to party p
+        ZK_NCCL(ctx, R, R->Recv(recv + (size_t)p * chunk * 32, chunk * 4, ncclUint64, p, c->comm, st));     // my slice of party p
+    }
+    ZK_NCCL(ctx, R, R->GroupEnd());
+    ZK_TRY(zk_fr_sum_parties_dev(ctx, recv, (size_t)P, chunk, part));
+    ZK_NCCL(ctx, R, R->AllGather(part, full, chunk * 4, ncclUint64, c->comm, st));
+    ZK_HIP(ctx, hipMemcpyAsync(out_dev, full, n * 32, hipMemcpyDeviceToDevice, st));
+    return ZK_OK;
+}

@@ -42,6 +42,7 @@ extern "C" int zk_ctx_destroy(zk_ctx* ctx) {
     if (!ctx) return ZK_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)zk_comm_destroy(ctx);
     for (auto& kv : ctx->slots)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto& kv : ctx->pinned)

@@ -34,6 +34,7 @@ struct zk_ctx {
     std::map<int, Slot> pinned;     // pinned host staging per MSM slot
     std::map<uint32_t, zk_domain*> domains;  // keyed by log2(size)
     std::map<std::string, int> flags;         // one-time per-context setup markers
+    void* comm = nullptr;                     // RCCL communicator of this party (comm.hip), created by zk_comm_init
     std::mutex mu;
     // timing of the most recent instrumented call (ms), filled when ZK_PROFILE env or explicit request
     struct Timer { float ms = 0; int count = 0; };

@@ -204,6 +204,10 @@ class GpuBackend:
     def open_vec(self, v, out, n):
         """out = sum over parties of v (AdditiveFieldShare::batch_open)."""
         net, ctx = self.net, self.ctx
+        if getattr(self, "native_open", False):
+            ctx.open_sum_fr_dev(v, n, out)       # zk_open_sum_fr_dev: RCCL inside the library, on the context's stream
+            ctx.sync()
+            return
         if isinstance(net, DistNet):
             st = self._tensors.get(v)
             if st is None:                       # not one of our tensors: stage it
@@ -330,6 +334,14 @@ class Party:
         self.net = net
         self.be = backend if backend is not None else GpuBackend(ctx, net)
         self.ctx = ctx
+        # ZK_TRANSPORT=native: the share-vector opens go through the library's own RCCL communicator (comm.hip) instead of
+        # torch.distributed; the 128-byte id travels over the existing process group, as it would over the reference's
+        # TCP mesh.  Small opens (points, scalars) stay on the process group.
+        if os.environ.get("ZK_TRANSPORT") == "native" and isinstance(net, DistNet) and backend is None:
+            box = [ctx.comm_unique_id() if net.is_leader() else None]
+            net.dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(box[0], net.rank, net.n)
+            self.be.native_open = True
         self._pk_cache = {}
         self.bytes_sent = 0   # payload bytes this party contributed to opens (cf. mpc-net/src/multi.rs:527-536)
 
