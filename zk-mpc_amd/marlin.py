@@ -441,20 +441,30 @@ def prover_third_round(st: ProverState, beta: int):
     g_2 = f.slice(1, K.size - 1)
     a_ev, b_ev = ctx.alloc(B.size * 32), ctx.alloc(B.size * 32)
     ctx.marlin_round3_ab_evals_dev(on_b, B.size, m(alpha), m(beta), etas, m(vv), a_ev.ptr, b_ev.ptr)
-    a_poly, b_poly = B.ifft_in_place(ctx, a_ev), B.ifft_in_place(ctx, b_ev)
-    # h_2 = (a - b f) / v_K ; deg b <= 3(|K| - 1), so only that many coefficients enter the product
-    nb = min(B.size, 3 * K.size - 2)
-    nbf = nb + K.size - 1
-    bf = ctx.alloc(max(nbf, B.size) * 32)
-    ctx.dev_zero(bf.ptr, max(nbf, B.size) * 32)
-    ctx.poly_mul_dev(b_poly.ptr, nb, f.ptr, K.size, bf.ptr)
-    ctx.fr_vec_scale_dev(bf.ptr, m(R_MOD - 1), bf.ptr, nbf)
-    ctx.fr_vec_op_dev(_lib.OP_ADD, bf.ptr, a_poly.ptr, bf.ptr, B.size)
-    total = max(nbf, B.size)
-    if total <= K.size:
-        raise ValueError("degenerate K domain")
+    # h_2 = (a - b f) / v_K.  a and b are only ever needed through a - b f, whose degree (<= 4|K| - 4) is below |B|: the
+    # product is taken on B itself, where a and b already live as evaluations (the reference interpolates both and
+    # multiplies the polynomials, prover.rs:680-698: five transforms of size |B| instead of two)
+    if B.size >= 4 * K.size - 3:
+        f_on_b = B.fft(ctx, f)
+        ctx.fr_vec_op_dev(_lib.OP_MUL, b_ev.ptr, f_on_b.ptr, b_ev.ptr, B.size)
+        ctx.fr_vec_op_dev(_lib.OP_SUB, a_ev.ptr, b_ev.ptr, a_ev.ptr, B.size)
+        diff = B.ifft_in_place(ctx, a_ev)
+        total = B.size
+    else:
+        # tiny K (|K| = 2: |B| = 4 < 4|K| - 3): the product does not fit B; the reference's way
+        a_poly, b_poly = B.ifft_in_place(ctx, a_ev), B.ifft_in_place(ctx, b_ev)
+        nb = min(B.size, 3 * K.size - 2)
+        total = max(nb + K.size - 1, B.size)
+        if total <= K.size:
+            raise ValueError("degenerate K domain")
+        bf = ctx.alloc(total * 32)
+        ctx.dev_zero(bf.ptr, total * 32)
+        ctx.poly_mul_dev(b_poly.ptr, nb, f.ptr, K.size, bf.ptr)
+        ctx.fr_vec_scale_dev(bf.ptr, m(R_MOD - 1), bf.ptr, nb + K.size - 1)
+        ctx.fr_vec_op_dev(_lib.OP_ADD, bf.ptr, a_poly.ptr, bf.ptr, B.size)
+        diff = DevPoly(bf, total)
     hq, hr = ctx.alloc((total - K.size) * 32), ctx.alloc(K.size * 32)
-    ctx.poly_divide_by_vanishing_dev(bf.ptr, total, K.log, hq.ptr, hr.ptr)
+    ctx.poly_divide_by_vanishing_dev(diff.ptr, total, K.log, hq.ptr, hr.ptr)
     if not ctx.fr_vec_is_zero_dev(hr.ptr, K.size):
         raise ValueError("inner sum-check: a - b f is not divisible by v_K")
     ctx.sync()
