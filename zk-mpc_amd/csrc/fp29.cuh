@@ -214,6 +214,29 @@ ZK_HD Fp<P> fp_mul2(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>&
     return fp_reduce_once<P>(t2);      // now < 2p
 }
 
+// -5 a mod p in ONE carry pass, almost reduced: returns V = k p - 5 a with k = floor(upper estimate of 5 a / p) + 1, so
+// V = -5 a (mod p) and 0 < V <= p (1 + 3e-8); all limbs < 2^29 (p (1 + 3e-8) < 2^(29 L) for BLS12-377's q = 0.84 * 2^377).
+// The estimate uses the top limb only: y = (a_top + 1) * ceil(5 * 2^58 / p_top) / 2^58 >= 5 a / p, too large by < 3e-8.
+// V is meant as the c operand of fp_mul2 (whose pre-subtraction bound 2.68 p has room for it) in the Fq2 product with
+// non-residue -5: the exact neg(mul5(a)) was three additions and a subtraction, each with its conditional reduction
+// (~420 instructions, a sixth of a G2 mixed addition); this is ~55.
+template <class P>
+ZK_HD Fp<P> fp_neg5_almost(const Fp<P>& a) {
+    constexpr int L = P::L;
+    constexpr uint64_t M = ((5ull << 58) + P::P[L - 1] - 1) / P::P[L - 1];
+    static_assert(M < (1ull << 32), "reciprocal must fit 32 bits");
+    const uint32_t k = (uint32_t)(((uint64_t)(a.l[L - 1] + 1u) * (uint32_t)M) >> 58) + 1u;
+    Fp<P> r;
+    int64_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        int64_t s = (int64_t)((uint64_t)k * P::P[i]) + cy;
+        s += (int64_t)(int32_t)a.l[i] * (int64_t)(-5);
+        if (i < L - 1) { r.l[i] = (uint32_t)s & MASK29; cy = s >> 29; } else { r.l[i] = (uint32_t)s; }
+    }
+    return r;
+}
+
 // Montgomery square: cross products taken once against the doubled operand.
 template <class P>
 ZK_HD Fp<P> fp_sqr(const Fp<P>& a) {
@@ -368,12 +391,12 @@ struct Fq2Field {
     static ZK_HD T mul(const T& a, const T& b) {
         // nonresidue -5: c0 = a0 b0 + (-5 a1) b1 ; c1 = a0 b1 + a1 b0, each a fused double product with one reduction
         // (same 1 014 mads as Karatsuba's three products, 4 instead of 8 field add/sub)
-        Fq m5a1 = B::neg(mul5(a.c1));
+        Fq m5a1 = fp_neg5_almost<FqParams>(a.c1);
         return T{fp_mul2<FqParams>(a.c0, b.c0, m5a1, b.c1), fp_mul2<FqParams>(a.c0, b.c1, a.c1, b.c0)};
     }
     static ZK_HD T sqr(const T& a) {
         // c0 = a0^2 - 5 a1^2 (fused) ; c1 = 2 a0 a1
-        Fq m5a1 = B::neg(mul5(a.c1));
+        Fq m5a1 = fp_neg5_almost<FqParams>(a.c1);
         return T{fp_mul2<FqParams>(a.c0, a.c0, m5a1, a.c1), B::dbl(B::mul(a.c0, a.c1))};
     }
     static ZK_HD T mulsub(const T& a, const T& b, const T& c, const T& d) { return sub(mul(a, b), mul(c, d)); }

@@ -17,6 +17,7 @@
 #include "hostfield64.hpp"
 #include "internal.hpp"
 #include <chrono>
+#include <cstring>
 #include <functional>
 #include <future>
 #include <vector>
@@ -39,6 +40,10 @@ struct zk_r1cs {
 
 struct zk_pk {
     zk_bases *a = nullptr, *b_g1 = nullptr, *b_g2 = nullptr, *h = nullptr, *l = nullptr, *gamma_abc = nullptr;
+    // l_query behind as many points at infinity as a_query has entries for the instance (l_pad[ni + j] = l[j]), so that the
+    // L job indexes its table by the position in z like A and B do and reuses their sort of z[1..]; the instance part adds
+    // infinity, which the complete addition skips.  Only the prover's pipeline reads it.
+    zk_bases* l_pad = nullptr;
     Affine<G1Field> alpha_g1, beta_g1, delta_g1, a0, b0_g1;
     Affine<G2Field> beta_g2, delta_g2, gamma_g2, b0_g2;
 };
@@ -292,9 +297,25 @@ extern "C" int zk_groth16_witness_map_dev(zk_ctx* ctx, const zk_r1cs* r, const v
 
 // ---- proving key -----------------------------------------------------------------------------
 
+// see zk_pk::l_pad.  ZK_L_SHARE=0 keeps the L job on its own table and its own sort.
+static int pk_make_l_pad(zk_ctx* ctx, zk_pk* pk) {
+    static const bool on = !(getenv("ZK_L_SHARE") && atoi(getenv("ZK_L_SHARE")) == 0);
+    if (!on || !pk->a || !pk->l || pk->l->n == 0 || pk->a->n <= pk->l->n) return ZK_OK;
+    const size_t n = pk->a->n, front = n - pk->l->n, PW = 2 * G1Field::WORDS * 4;
+    zk_bases* b = new zk_bases();
+    b->group = 1;
+    b->n = n;
+    if (hipMalloc((void**)&b->dev, n * PW) != hipSuccess) { delete b; (void)hipGetLastError(); return ZK_OK; }   // no memory: L keeps its own sort
+    pk->l_pad = b;
+    ZK_HIP(ctx, hipMemsetAsync(b->dev, 0, front * PW, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync((char*)b->dev + front * PW, pk->l->dev, pk->l->n * PW, hipMemcpyDeviceToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return zk_bases_precompute_auto(ctx, b);
+}
+
 extern "C" int zk_pk_free(zk_ctx* ctx, zk_pk* pk) {
     if (!pk) return ZK_OK;
-    zk_bases* all[6] = {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l, pk->gamma_abc};
+    zk_bases* all[7] = {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l, pk->gamma_abc, pk->l_pad};
     for (auto* b : all) zk_bases_free(ctx, b);
     delete pk;
     return ZK_OK;
@@ -310,6 +331,7 @@ extern "C" int zk_pk_upload(zk_ctx* ctx, const zk_pk_host* h, zk_pk** out) {
     if (rc == ZK_OK) rc = zk_bases_upload_g1(ctx, h->l_query, h->l_len, &pk->l);
     for (zk_bases* q : {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l})
         if (rc == ZK_OK) rc = zk_bases_precompute_auto(ctx, q);
+    if (rc == ZK_OK) rc = pk_make_l_pad(ctx, pk);
     if (rc != ZK_OK) { zk_pk_free(ctx, pk); return rc; }
     pk->alpha_g1 = host_aff_from_abi<G1Field>((const uint64_t*)&h->alpha_g1);
     pk->beta_g1 = host_aff_from_abi<G1Field>((const uint64_t*)&h->beta_g1);
@@ -432,6 +454,7 @@ extern "C" int zk_groth16_setup(zk_ctx* ctx, const zk_r1cs* r, const zk_fr* alph
     if (rc == ZK_OK) rc = zk_fixed_base_g1_dev(ctx, g1_k, dev, gamma_abc.size(), &pk->gamma_abc);
     for (zk_bases* q : {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l})
         if (rc == ZK_OK) rc = zk_bases_precompute_auto(ctx, q);
+    if (rc == ZK_OK) rc = pk_make_l_pad(ctx, pk);
     if (rc != ZK_OK) { zk_pk_free(ctx, pk); return rc; }
 
     const Fr k1 = ld(g1_k), k2 = ld(g2_k);
@@ -490,10 +513,15 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     int rc = zk_msm_prepare(ctx, &jobs[0], pk->b_g2, 1, zb + 32, nvars, 1);                       // src/groth16.rs:160 (query[1..])
     if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &jobs[1], pk->a, 1, zb + 32, nvars, 2);              // :137
     if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &jobs[2], pk->b_g1, 1, zb + 32, nvars, 3);           // :148
-    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &jobs[3], pk->l, 0, zb + r->ni * 32, r->nw, 4);      // :110
+    // :110: aux_assignment against l_query; over the padded table the same sum reads z[1..] (the instance meets infinity)
+    const bool l_shared = pk->l_pad && pk->l_pad->n == nvars + 1 && (pk->l_pad->pre != nullptr) == (pk->a->pre != nullptr) &&
+                          pk->l_pad->c_pre == pk->a->c_pre;
+    if (rc == ZK_OK) rc = l_shared ? zk_msm_prepare(ctx, &jobs[3], pk->l_pad, 1, zb + 32, nvars, 4)
+                                   : zk_msm_prepare(ctx, &jobs[3], pk->l, 0, zb + r->ni * 32, r->nw, 4);
     if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[0], s_sort, nullptr);
     if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[1], s_sort, &jobs[0]);
     if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[2], s_sort, &jobs[0]);
+    if (rc == ZK_OK && l_shared) rc = zk_msm_enqueue_sort(ctx, &jobs[3], s_sort, &jobs[0]);
     const void* h = h_in;
     ZkPhaseTimer tm(ctx);
     if (rc == ZK_OK && !h_in) {
@@ -511,7 +539,7 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         rc = zk_msm_enqueue_sort(ctx, &jobs[4], ctx->stream, nullptr);
     }
     // L's sort after the witness map (it is not needed before the fourth accumulate kernel)
-    if (rc == ZK_OK) {
+    if (rc == ZK_OK && !l_shared) {
         ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e1, 0));
         rc = zk_msm_enqueue_sort(ctx, &jobs[3], s_sort, nullptr);
     }
@@ -571,6 +599,7 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
     std::vector<ZkMsmJob> jobs(n_jobs);
     size_t finished = 0;
     int rc = ZK_OK;
+    static const bool red_on_main = !(getenv("ZK_BATCH_REDUCE_STREAM") && !strcmp(getenv("ZK_BATCH_REDUCE_STREAM"), "sort"));
     auto start = [&](size_t k) -> int {
         while (k >= finished + SLOTS) {                  // the slot's previous user must have delivered its result
             ZK_TRY(zk_msm_finish(ctx, &jobs[finished], outs[finished]));
@@ -583,7 +612,11 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
     for (size_t k = 0; k < n_jobs && rc == ZK_OK; k++) {
         if (k + 1 < n_jobs) rc = start(k + 1);
         if (rc == ZK_OK) rc = zk_msm_enqueue_accum(ctx, &jobs[k], s_acc);
-        if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, &jobs[k], s_sort);
+        // reduces on the context stream (idle here), not behind the sorts: on the sort stream the sort of job k+2 queued
+        // behind the reduce of job k, i.e. behind the accumulate of job k, and the accumulate stream then waited for it
+        // (period = reduce + sort beside a running accumulate ~ 4 ms per 2^20-scalar job instead of the accumulate's 2.1 ms).
+        // ZK_BATCH_REDUCE_STREAM=sort restores the old placement.
+        if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, &jobs[k], red_on_main ? ctx->stream : s_sort);
     }
     for (; finished < n_jobs && rc == ZK_OK; finished++) rc = zk_msm_finish(ctx, &jobs[finished], outs[finished]);
     (void)hipStreamSynchronize(s_sort);

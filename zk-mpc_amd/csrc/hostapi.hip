@@ -142,6 +142,15 @@ extern "C" int zk_fq_mul2(const zk_fq* a, const zk_fq* b, const zk_fq* c, const 
     host_store_ext<FqParams>(out->l, fp_mul<FqParams>(t, fp_const<FqParams>(FqParams::EXT_TO_INT)));
     return ZK_OK;
 }
+// raw limbs (29-bit, 13 words) of fp_neg5_almost on the raw limbs of a: V = k p - 5 a, for range tests
+extern "C" int zk_fq_neg5_almost_raw(const uint32_t a13[13], uint32_t out13[13]) {
+    if (!a13 || !out13) return ZK_ERR_ARG;
+    Fq a;
+    for (int i = 0; i < 13; i++) a.l[i] = a13[i];
+    Fq v = fp_neg5_almost<FqParams>(a);
+    for (int i = 0; i < 13; i++) out13[i] = v.l[i];
+    return ZK_OK;
+}
 extern "C" int zk_fq_mul(const zk_fq* a, const zk_fq* b, zk_fq* out) {
     if (!a || !b || !out) return ZK_ERR_ARG;
     Fq t = fp_mul<FqParams>(host_load_ext<FqParams>(a->l), host_load_ext<FqParams>(b->l));

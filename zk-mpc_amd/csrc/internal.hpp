@@ -74,3 +74,7 @@ int zk_msm_enqueue_sort(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJ
 int zk_msm_enqueue_accum(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st);
 int zk_msm_enqueue_reduce(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st);
 int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out_host_projective);
+
+// msm_g2pair.hip: the G2 accumulate kernel with two lanes per point addition
+void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bases, const uint32_t* sorted, const void* desc,
+                            const uint32_t* order, const uint32_t* ctr, uint32_t* sums);

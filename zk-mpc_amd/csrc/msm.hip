@@ -686,8 +686,13 @@ int msm_enqueue_accum_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     static const int bpc = getenv("ZK_ACCUM_BPC") ? atoi(getenv("ZK_ACCUM_BPC")) : 0;
     const size_t full_grid = (job->max_segs + 255) / 256;
     const unsigned accum_blocks = (unsigned)(bpc > 0 ? std::min<size_t>(full_grid, (size_t)ctx->n_cu * bpc) : full_grid);
-    hipLaunchKernelGGL(k_accum<F>, accum_blocks, 256, 0, st, job->bases_dev, job->sorted,
-                       (const SegDesc*)job->desc, job->order, job->ctr, b.sums);
+    // G2: two lanes per addition (msm_g2pair.hip) unless ZK_G2_PAIR=0 asks for the one-lane kernel
+    static const bool g2pair = !(getenv("ZK_G2_PAIR") && atoi(getenv("ZK_G2_PAIR")) == 0);
+    if (!g1 && g2pair)
+        zk_launch_accum_g2pair(st, job->max_segs, job->bases_dev, job->sorted, job->desc, job->order, job->ctr, b.sums);
+    else
+        hipLaunchKernelGGL(k_accum<F>, accum_blocks, 256, 0, st, job->bases_dev, job->sorted,
+                           (const SegDesc*)job->desc, job->order, job->ctr, b.sums);
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
     ZK_HIP(ctx, hipEventCreateWithFlags(&job->accum_done, hipEventDisableTiming));

@@ -1,0 +1,173 @@
+// msm_g2pair.hip -- G2 bucket accumulation with TWO lanes per point addition (gfx950).
+//
+// Same job as k_accum<Fq2Field> of msm.hip (the inner loop of VariableBaseMSM::multi_scalar_mul,
+// arkworks/algebra/ec/src/msm/variable_base.rs:47-76, for G2Affine of bls12_377/src/curves/g2.rs), same
+// inputs and the same group element out; only the mapping of the arithmetic onto lanes differs.
+//
+// Why: the one-lane-per-addition G2 kernel needs the whole register file (256 VGPR + 217 AGPR: one wave per
+// SIMD, nothing to issue while a gather or a dependent mad is in flight) and its loop body is ~110 KB of code,
+// more than the instruction cache.  Here the even lane of a pair holds the c0 component of every Fq2 value and
+// the odd lane the c1 component (Fq2 = Fq[u]/(u^2 + 5), ff/src/fields/models/quadratic_extension.rs:632-643):
+//   * add / sub / neg / dbl are component-wise: no communication;
+//   * a product (a0 + a1 u)(b0 + b1 u) is ONE fused double product per lane (fp29.cuh::fp_mul2):
+//       even: a0 b0 + (-5 a1) b1      odd: a1 b0 + a0 b1
+//     the partner's limbs arrive by DPP quad_perm [1,0,3,2] (13 v_mov_dpp per operand, no LDS);
+//   * zero tests OR the limbs and exchange one word.
+// Per lane this is half the live state (two waves per SIMD) and half the code (the loop body fits the instruction cache);
+// the total number of v_mad_u64_u32 per addition is unchanged (10 x 1 014; squarings cost a product here).
+// A pair shares its control flow (all branch conditions are pair-wide), so the partner lane is always active.
+#include "devutil.cuh"
+#include "internal.hpp"
+#include <stdlib.h>
+
+using namespace zk;
+
+namespace {
+
+struct SegDesc { uint32_t start, len, dst; };   // msm.hip
+
+using B = FqField;
+constexpr int L = FqParams::L;
+constexpr int FW = FqParams::W;   // packed words per Fq: 12
+
+__device__ __forceinline__ uint32_t dpp_swap1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+__device__ __forceinline__ Fq xchg(const Fq& a) {
+    Fq r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = dpp_swap1(a.l[i]);
+    return r;
+}
+__device__ __forceinline__ Fq sel(bool c, const Fq& a, const Fq& b) { return B::select(c, a, b); }
+
+// pair-wide "both components are zero" of the OR of some limbs
+__device__ __forceinline__ bool pair_zero(uint32_t o) { return (o | dpp_swap1(o)) == 0; }
+__device__ __forceinline__ uint32_t limbs_or(const Fq& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) o |= a.l[i];
+    return o;
+}
+
+// A left operand made ready for products: a = own component, r = what the partner contributes
+// (even lane: -5 * a1, odd lane: a0).  Prepared once per distinct left operand.
+struct Left { Fq a, r; };
+
+__device__ __forceinline__ Left prep(const Fq& a, bool odd) {
+    Fq m5 = fp_neg5_almost<FqParams>(a);   // -5 a, almost reduced: only ever the c operand of fp_mul2
+    return Left{a, xchg(sel(odd, m5, a))};
+}
+__device__ __forceinline__ Fq mulp(const Left& A, const Fq& b, bool odd) {
+    Fq ob = xchg(b);
+    return fp_mul2<FqParams>(A.a, sel(odd, ob, b), A.r, sel(odd, b, ob));
+}
+
+struct AffP { Fq x, y; };
+struct XyzzP { Fq x, y, zz, zzz; };
+
+__device__ __forceinline__ Fq one_p(bool odd) { return sel(odd, B::zero(), B::one()); }
+
+// 2 * (x, y), affine and not infinity ("mdbl-2008-s-1", a = 0); rare path (a bucket receiving the same point twice)
+__device__ __forceinline__ XyzzP dbl_affine_p(const AffP& q, bool odd) {
+    Fq u = B::dbl(q.y);
+    if (pair_zero(limbs_or(u))) return XyzzP{B::zero(), B::zero(), B::zero(), B::zero()};
+    Left U = prep(u, odd);
+    Fq v = mulp(U, u, odd);
+    Fq w = mulp(U, v, odd);
+    Left X = prep(q.x, odd);
+    Fq s = mulp(X, v, odd);
+    Fq xx = mulp(X, q.x, odd);
+    Fq m = B::add(B::dbl(xx), xx);
+    Left M = prep(m, odd);
+    Fq x3 = B::sub(mulp(M, m, odd), B::dbl(s));
+    Fq y3 = B::sub(mulp(M, B::sub(s, x3), odd), mulp(prep(w, odd), q.y, odd));
+    return XyzzP{x3, y3, v, w};
+}
+
+// acc + q ("madd-2008-s"), complete like ec.cuh::xyzz_madd
+__device__ __forceinline__ XyzzP madd_p(const XyzzP& acc, const AffP& q, bool odd) {
+    if (pair_zero(limbs_or(q.x) | limbs_or(q.y))) return acc;
+    if (pair_zero(limbs_or(acc.zz))) return XyzzP{q.x, q.y, one_p(odd), one_p(odd)};
+    Fq u2 = mulp(prep(q.x, odd), acc.zz, odd);
+    Fq s2 = mulp(prep(q.y, odd), acc.zzz, odd);
+    Fq p = B::sub(u2, acc.x);
+    Fq r = B::sub(s2, acc.y);
+    if (pair_zero(limbs_or(p))) {
+        if (pair_zero(limbs_or(r))) return dbl_affine_p(q, odd);
+        return XyzzP{B::zero(), B::zero(), B::zero(), B::zero()};
+    }
+    Fq pp = mulp(prep(p, odd), p, odd);
+    Left PP = prep(pp, odd);
+    Fq ppp = mulp(PP, p, odd);
+    Fq qq = mulp(PP, acc.x, odd);
+    Left R = prep(r, odd);
+    Fq x3 = B::sub(B::sub(mulp(R, r, odd), ppp), B::dbl(qq));
+    Left PPP = prep(ppp, odd);
+    Fq y3 = B::sub(mulp(R, B::sub(qq, x3), odd), mulp(PPP, acc.y, odd));
+    return XyzzP{x3, y3, mulp(PP, acc.zz, odd), mulp(PPP, acc.zzz, odd)};
+}
+
+__device__ __forceinline__ Fq fq_load16(const uint32_t* w) { return felt_load16<FqField>(w); }
+
+// this lane's components of affine point i: x.c[odd] at words [odd*12, +12), y.c[odd] at [24 + odd*12, +12)
+__device__ __forceinline__ AffP aff_load_p(const uint32_t* bases, size_t i, uint32_t odd) {
+    const uint32_t* w = bases + i * (4 * FW) + odd * FW;
+    return AffP{fq_load16(w), fq_load16(w + 2 * FW)};
+}
+
+// MODE 2: at most 256 registers, two waves per SIMD.  MODE 1: no constraint.  MODE 0: one wave per SIMD AND 192 registers
+// per lane left free (the clobber of a63 makes the kernel own 256 + 64 registers), so that kernels of other streams
+// (the witness map's transforms, the other jobs' sorts) find room on every SIMD beside it instead of waiting for
+// a block of this kernel to retire.
+template <int MODE>
+__global__ void __launch_bounds__(256, (MODE == 2 ? 2 : 1))
+k_accum_g2pair(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
+               const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums) {
+    if (MODE == 0) asm volatile("" ::: "a63");
+    const uint32_t S = ctr[2];
+    const uint32_t G = gridDim.x * (blockDim.x >> 1);
+    const uint32_t oddw = threadIdx.x & 1u;
+    const bool odd = oddw != 0;
+    for (uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 1; t < S; t += G) {
+        const SegDesc d = desc[order[t]];
+        XyzzP acc{B::zero(), B::zero(), B::zero(), B::zero()};
+        if (d.len) {
+            const uint32_t* srt = sorted + d.start;
+            uint32_t e = srt[0];
+            AffP p = aff_load_p(bases, e & 0x7fffffffu, oddw);
+            for (uint32_t k = 0; k < d.len; k++) {
+                AffP cur = p;
+                const uint32_t ce = e;
+                if (k + 1 < d.len) {
+                    e = srt[k + 1];
+                    p = aff_load_p(bases, e & 0x7fffffffu, oddw);
+                }
+                if (ce >> 31) cur.y = B::neg(cur.y);
+                acc = madd_p(acc, cur, odd);
+            }
+        }
+        // XYZZ over Fq2 in memory: x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1, 12 words each
+        uint32_t* w = sums + (size_t)d.dst * (8 * FW) + oddw * FW;
+        felt_store16<FqField>(w, acc.x);
+        felt_store16<FqField>(w + 2 * FW, acc.y);
+        felt_store16<FqField>(w + 4 * FW, acc.zz);
+        felt_store16<FqField>(w + 6 * FW, acc.zzz);
+    }
+}
+
+}  // namespace
+
+// One pair of lanes per segment: `segments` logical threads.  WAVES = 2 caps the kernel at 256 VGPRs (two waves per SIMD) at
+// the price of 24 spilled registers; ZK_G2PAIR_WAVES=1 selects the unconstrained build (279 registers, one wave) for comparison.
+void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bases, const uint32_t* sorted, const void* desc,
+                            const uint32_t* order, const uint32_t* ctr, uint32_t* sums) {
+    static const int waves = getenv("ZK_G2PAIR_WAVES") ? atoi(getenv("ZK_G2PAIR_WAVES")) : 2;
+    const unsigned blocks = (unsigned)((segments + 127) / 128);
+    if (waves == 0)
+        hipLaunchKernelGGL(k_accum_g2pair<0>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
+    else if (waves == 1)
+        hipLaunchKernelGGL(k_accum_g2pair<1>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
+    else
+        hipLaunchKernelGGL(k_accum_g2pair<2>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
+}
