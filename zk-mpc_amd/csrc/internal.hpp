@@ -78,3 +78,9 @@ int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out_host_projective);
 // msm_g2pair.hip: the G2 accumulate kernel with two lanes per point addition
 void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bases, const uint32_t* sorted, const void* desc,
                             const uint32_t* order, const uint32_t* ctr, uint32_t* sums);
+struct ZkG2PairReduce {   // the arguments of msm.hip's reduce chain
+    const void* heavy; const uint32_t* ctr;
+    uint32_t *sums, *lvS, *lvW, *lvS2, *lvW2, *bits;
+    uint32_t RNB, T1, T2, Rw, levels, nbits, nout, klog, light_blocks, heavy_blocks;
+};
+int zk_launch_reduce_g2pair(hipStream_t st, const ZkG2PairReduce& a);

@@ -714,10 +714,17 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     tm->begin(g1 ? "msm_g1.reduce" : "msm_g2.reduce");
     const unsigned light_blocks = (unsigned)std::min<size_t>((job->max_heavy + 63) / 64, 512);
     const unsigned heavy_blocks = (unsigned)std::min<size_t>(job->max_heavy, 1024);
+    const uint32_t nout = job->nbits + (job->Rw > job->Wb ? 2u : 1u);
+    static const bool g2pair_red = !(getenv("ZK_G2_PAIR_REDUCE") && atoi(getenv("ZK_G2_PAIR_REDUCE")) == 0);
+        if (!g1 && g2pair_red) {
+        // G2: the same chain on lane pairs (msm_g2pair.hip)
+        ZkG2PairReduce a{job->heavy, job->ctr, b.sums, b.lvS, b.lvW, b.lvS2, b.lvW2, b.bits, job->RNB, job->T1, job->T2, job->Rw,
+                         job->levels, job->nbits, nout, (uint32_t)REDUCE_K_LOG, 2 * light_blocks, heavy_blocks};
+        ZK_TRY(zk_launch_reduce_g2pair(st, a));
+    } else {
     hipLaunchKernelGGL(k_fold<F>, light_blocks + heavy_blocks, 64, 64 * XW * 4, st, (const HeavyDesc*)job->heavy, job->ctr, b.sums,
                        light_blocks);
     const size_t threads = (size_t)job->Rw * job->T1;
-    const uint32_t nout = job->nbits + (job->Rw > job->Wb ? 2u : 1u);
     hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, b.sums, nullptr, b.lvS, b.lvW, job->RNB, job->T1,
                        (uint32_t)REDUCE_K_LOG, job->Rw, 1, 0);
     if (256 * XW * 4 > 64 * 1024)
@@ -731,6 +738,7 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
         topW = b.lvW2;
     }
     hipLaunchKernelGGL(k_bitsum<F>, job->Rw * nout, 256, 256 * XW * 4, st, topS, topW, b.bits, job->T2, job->nbits, nout);
+    }
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
     // pinned destination: a pageable one would make the "async" copy block the host until this job is done

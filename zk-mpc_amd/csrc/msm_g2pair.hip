@@ -17,6 +17,7 @@
 // the total number of v_mad_u64_u32 per addition is unchanged (10 x 1 014; squarings cost a product here).
 // A pair shares its control flow (all branch conditions are pair-wide), so the partner lane is always active.
 #include "devutil.cuh"
+#include "../../include/zkmpc_hip.h"
 #include "internal.hpp"
 #include <stdlib.h>
 
@@ -156,6 +157,141 @@ k_accum_g2pair(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ 
     }
 }
 
+
+// ---- the reduce phase (fold / chunked running sums / bit-decomposition sums of msm.hip) on lane pairs --------------------
+// The one-lane G2 versions need 489-512 registers (k_reduce spills 692 B per lane) and, one wave per SIMD with 2^16
+// threads per level, leave most of the chip idle; on pairs they fit 256 registers and have twice the waves.
+// The curve formulas are ec.cuh's, instantiated with a field whose element is this lane's component.
+struct Fq2PairField {
+    using T = Fq;
+    static constexpr int WORDS = FqParams::W;   // words per LANE per element
+    static __device__ __forceinline__ bool odd() { return (threadIdx.x & 1u) != 0; }
+    static __device__ __forceinline__ T zero() { return B::zero(); }
+    static __device__ __forceinline__ T one() { return one_p(odd()); }
+    static __device__ __forceinline__ T add(const T& a, const T& b) { return B::add(a, b); }
+    static __device__ __forceinline__ T sub(const T& a, const T& b) { return B::sub(a, b); }
+    static __device__ __forceinline__ T dbl(const T& a) { return B::dbl(a); }
+    static __device__ __forceinline__ T neg(const T& a) { return B::neg(a); }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) { return mulp(prep(a, odd()), b, odd()); }
+    static __device__ __forceinline__ T sqr(const T& a) { return mul(a, a); }
+    static __device__ __forceinline__ T mulsub(const T& a, const T& b, const T& c, const T& d) { return B::sub(mul(a, b), mul(c, d)); }
+    static __device__ __forceinline__ bool is_zero(const T& a) { return pair_zero(limbs_or(a)); }
+    static __device__ __forceinline__ T load(const uint32_t* w) { return B::load(w); }
+    static __device__ __forceinline__ void store(uint32_t* w, const T& a) { B::store(w, a); }
+};
+using FP = Fq2PairField;
+using XP = XYZZ<FP>;
+
+// XYZZ over Fq2 in memory: x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1 (12 words each); a lane touches its four
+__device__ __forceinline__ XP xyzz_load_pair(const uint32_t* base, size_t i, uint32_t odd) {
+    const uint32_t* w = base + i * (8 * FW) + odd * FW;
+    return XP{fq_load16(w), fq_load16(w + 2 * FW), fq_load16(w + 4 * FW), fq_load16(w + 6 * FW)};
+}
+__device__ __forceinline__ void xyzz_store_pair(uint32_t* base, size_t i, uint32_t odd, const XP& p) {
+    uint32_t* w = base + i * (8 * FW) + odd * FW;
+    felt_store16<FqField>(w, p.x);
+    felt_store16<FqField>(w + 2 * FW, p.y);
+    felt_store16<FqField>(w + 4 * FW, p.zz);
+    felt_store16<FqField>(w + 6 * FW, p.zzz);
+}
+// LDS staging of this lane's half of a point, word-major over the NT physical lanes (conflict-free)
+template <int NT>
+__device__ __forceinline__ void lds_put_pair(uint32_t* lds, uint32_t tid, const XP& p) {
+    uint32_t w[4 * FW];
+    xyzz_store<FP>(w, p);
+#pragma unroll
+    for (int k = 0; k < 4 * FW; k++) lds[k * NT + tid] = w[k];
+}
+template <int NT>
+__device__ __forceinline__ XP lds_get_pair(const uint32_t* lds, uint32_t tid) {
+    uint32_t w[4 * FW];
+#pragma unroll
+    for (int k = 0; k < 4 * FW; k++) w[k] = lds[k * NT + tid];
+    return xyzz_load<FP>(w);
+}
+
+struct HeavyDesc { uint32_t key, first, nseg; };   // msm.hip
+
+// msm.hip::k_fold on pairs: 32 buckets (light part) or one bucket (heavy part) per 64-lane block
+__global__ void __launch_bounds__(64)
+k_fold_g2pair(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint32_t light_blocks) {
+    extern __shared__ uint32_t lds[];  // 64 * 48 words (heavy blocks only)
+    const uint32_t nheavy = ctr[0];
+    const uint32_t tid = threadIdx.x, lt = tid >> 1, odd = tid & 1u;
+    if (blockIdx.x < light_blocks) {
+        for (uint32_t hb = blockIdx.x * 32 + lt; hb < nheavy; hb += light_blocks * 32) {
+            const HeavyDesc h = heavy[hb];
+            if (h.nseg > 32) continue;
+            XP acc = xyzz_load_pair(sums, (size_t)h.first, odd);
+            for (uint32_t j = 1; j < h.nseg; j++) acc = xyzz_add<FP>(acc, xyzz_load_pair(sums, (size_t)h.first + j, odd));
+            xyzz_store_pair(sums, h.key, odd, acc);
+        }
+        return;
+    }
+    for (uint32_t hb = blockIdx.x - light_blocks; hb < nheavy; hb += gridDim.x - light_blocks) {
+        const HeavyDesc h = heavy[hb];
+        if (h.nseg <= 32) continue;
+        XP acc = xyzz_inf<FP>();
+        for (uint32_t j = lt; j < h.nseg; j += 32) acc = xyzz_add<FP>(acc, xyzz_load_pair(sums, (size_t)h.first + j, odd));
+        lds_put_pair<64>(lds, tid, acc);
+        __syncthreads();
+        for (uint32_t d = 16; d >= 1; d >>= 1) {
+            if (lt < d) lds_put_pair<64>(lds, tid, xyzz_add<FP>(lds_get_pair<64>(lds, tid), lds_get_pair<64>(lds, tid + 2 * d)));
+            __syncthreads();
+        }
+        if (lt == 0) xyzz_store_pair(sums, h.key, odd, lds_get_pair<64>(lds, tid));
+        __syncthreads();
+    }
+}
+
+// msm.hip::k_reduce on pairs (one chunk of 2^klog elements per pair)
+__global__ void __launch_bounds__(64)
+k_reduce_g2pair(const uint32_t* S_in, const uint32_t* W_in, uint32_t* S_out, uint32_t* W_out, uint32_t T_in, uint32_t T_out,
+                uint32_t klog, uint32_t n_windows, int one_based, int last) {
+    const size_t t = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 1;
+    const uint32_t odd = threadIdx.x & 1u;
+    if (t >= (size_t)n_windows * T_out) return;
+    const uint32_t w = (uint32_t)(t / T_out), c = (uint32_t)(t - (size_t)w * T_out);
+    const uint32_t lo = c << klog, hi = min(lo + (1u << klog), T_in);
+    XP running = xyzz_inf<FP>(), acc = xyzz_inf<FP>(), wsum = xyzz_inf<FP>();
+    for (uint32_t k = hi; k-- > lo;) {
+        const size_t idx = (size_t)w * T_in + k;
+        if (W_in) wsum = xyzz_add<FP>(wsum, xyzz_load_pair(W_in, idx, odd));
+        running = xyzz_add<FP>(running, xyzz_load_pair(S_in, idx, odd));
+        if (k > lo || one_based) acc = xyzz_add<FP>(acc, running);
+    }
+    acc = xyzz_add<FP>(acc, wsum);
+    xyzz_store_pair(W_out, t, odd, acc);
+    if (!last) {
+        for (uint32_t k = 0; k < klog; k++) running = xyzz_dbl<FP>(running);
+        xyzz_store_pair(S_out, t, odd, running);
+    }
+}
+
+// msm.hip::k_bitsum on pairs: 512 lanes = 256 pairs per block (96 KiB of LDS for the tree)
+__global__ void __launch_bounds__(512)
+k_bitsum_g2pair(const uint32_t* S_in, const uint32_t* W_in, uint32_t* out, uint32_t T, uint32_t nbits, uint32_t nout) {
+    extern __shared__ uint32_t lds[];  // 512 * 48 words
+    const uint32_t w = blockIdx.x / nout, j = blockIdx.x % nout;
+    const uint32_t tid = threadIdx.x, lt = tid >> 1, odd = tid & 1u;
+    XP acc = xyzz_inf<FP>();
+    if (j == nbits) {
+        for (uint32_t t = lt; t < T; t += 256) acc = xyzz_add<FP>(acc, xyzz_load_pair(W_in, (size_t)w * T + t, odd));
+    } else if (j == nbits + 1) {
+        for (uint32_t t = lt; t < T; t += 256) acc = xyzz_add<FP>(acc, xyzz_load_pair(S_in, (size_t)w * T + t, odd));
+    } else {
+        for (uint32_t t = lt; t < T; t += 256)
+            if ((t >> j) & 1) acc = xyzz_add<FP>(acc, xyzz_load_pair(S_in, (size_t)w * T + t, odd));
+    }
+    lds_put_pair<512>(lds, tid, acc);
+    __syncthreads();
+    for (uint32_t d = 128; d >= 1; d >>= 1) {
+        if (lt < d) lds_put_pair<512>(lds, tid, xyzz_add<FP>(lds_get_pair<512>(lds, tid), lds_get_pair<512>(lds, tid + 2 * d)));
+        __syncthreads();
+    }
+    if (lt == 0) xyzz_store_pair(out, blockIdx.x, odd, lds_get_pair<512>(lds, tid));
+}
+
 }  // namespace
 
 // One pair of lanes per segment: `segments` logical threads.  WAVES = 2 caps the kernel at 256 VGPRs (two waves per SIMD) at
@@ -170,4 +306,29 @@ void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bas
         hipLaunchKernelGGL(k_accum_g2pair<1>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
     else
         hipLaunchKernelGGL(k_accum_g2pair<2>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
+}
+
+// The G2 reduce chain of msm.hip::msm_enqueue_reduce_t, same buffers and geometry, on lane pairs.
+int zk_launch_reduce_g2pair(hipStream_t st, const ZkG2PairReduce& a) {
+    hipLaunchKernelGGL(k_fold_g2pair, a.light_blocks + a.heavy_blocks, 64, 64 * 4 * FW * 4, st, (const HeavyDesc*)a.heavy, a.ctr, a.sums,
+                       a.light_blocks);
+    const size_t threads = (size_t)a.Rw * a.T1;
+    hipLaunchKernelGGL(k_reduce_g2pair, (unsigned)((2 * threads + 63) / 64), 64, 0, st, (const uint32_t*)a.sums, (const uint32_t*)nullptr,
+                       a.lvS, a.lvW, a.RNB, a.T1, a.klog, a.Rw, 1, 0);
+    const uint32_t *topS = a.lvS, *topW = a.lvW;
+    if (a.levels == 2) {
+        const size_t threads2 = (size_t)a.Rw * a.T2;
+        hipLaunchKernelGGL(k_reduce_g2pair, (unsigned)((2 * threads2 + 63) / 64), 64, 0, st, (const uint32_t*)a.lvS, (const uint32_t*)a.lvW,
+                           a.lvS2, a.lvW2, a.T1, a.T2, a.klog, a.Rw, 0, 0);
+        topS = a.lvS2;
+        topW = a.lvW2;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_bitsum_g2pair, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 4 * FW * 4) != hipSuccess)
+            return ZK_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_bitsum_g2pair, a.Rw * a.nout, 512, 512 * 4 * FW * 4, st, topS, topW, a.bits, a.T2, a.nbits, a.nout);
+    return ZK_OK;
 }
