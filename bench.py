@@ -247,7 +247,7 @@ def main():
         step()
     for _ in range(args.warmup):
         proof = step()
-    ctx.set_profiling(True)
+    ctx.set_profiling(not os.environ.get('BENCH_NO_PHASES'))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -148,3 +148,27 @@ def test_fused_double_product_boundaries():
                 pre = (t + ((-t * pow(q, -1, RI)) % RI) * q) // RI
                 seen.add(min(pre // q, 2))
     assert seen == {0, 1, 2}
+
+
+def test_neg5_almost_range_and_congruence():
+    """fp_neg5_almost (the -5 a1 operand of the Fq2 product, one carry pass): V = k q - 5 a with 0 < V <= q (1 + 2^-24),
+    every limb below 2^29, for values at the quotient boundaries j q / 5, at the top-limb boundaries and at random."""
+    import ctypes as C, random
+    lib = Z.load()
+    q = O.Q_MOD
+    limbs = lambda v: np.array([(v >> (29 * i)) & ((1 << 29) - 1) for i in range(13)], dtype=np.uint32)
+    val = lambda a: sum(int(x) << (29 * i) for i, x in enumerate(a))
+    rnd = random.Random(5)
+    ptop = q >> 348
+    cases = [0, 1, 2, q - 1, q - 2, ptop << 348, (ptop << 348) - 1, (ptop - 1) << 348, (1 << 348) - 1, 1 << 348]
+    for j in range(1, 6):
+        t = ((j * q) // 5) >> 348
+        cases += [v for v in [(j * q) // 5 + d for d in range(-3, 4)] if 0 <= v < q]
+        cases += [v for v in [((t + dt) << 348) + low for dt in (-1, 0, 1) for low in (0, (1 << 348) - 1)] if 0 <= v < q]
+    cases += [rnd.randrange(q) for _ in range(3000)]
+    for a in cases:
+        out = np.zeros(13, dtype=np.uint32)
+        assert lib.zk_fq_neg5_almost_raw(limbs(a).ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+        assert all(int(x) < (1 << 29) for x in out)
+        v = val(out)
+        assert (v + 5 * a) % q == 0 and 0 < v <= q + (q >> 24)

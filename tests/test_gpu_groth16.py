@@ -147,3 +147,38 @@ def test_mul_chain_device_builder(ctx, n):
     r, s = rng.fr(), rng.fr()
     proof = ctx.create_proof_dev(pk, dr, dz.ptr, cv.fr_to_mont([r])[0], cv.fr_to_mont([s])[0])
     assert proof == O.proof_serialize(*O.predict_proof(r1cs, pks, z, r, s))
+
+
+def test_many_public_inputs_with_window_multiples(ctx):
+    """5 instance variables, 2^16 + 300 constraints: the proving key carries window multiples and the L job reads the
+    padded l_query through the sort shared with A / B (the instance part meets points at infinity).  Proof bytes equal
+    the C oracle's known-trapdoor prediction."""
+    import zkref_c as OC
+    rng = O.Prng(909)
+    ni, nc = 5, (1 << 16) + 300
+    nw = nc + 1
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    r = O.R_MOD
+    xs = [rng.fr() for _ in range(ni - 1)]
+    w = [rng.fr()]
+    for i in range(nc):                                  # (w_i + x_{i mod 4}) * w_i = w_{i+1}
+        w.append((w[i] + xs[i % 4]) * w[i] % r)
+    z = [1] + xs + w
+    one = mont(1)
+    i = np.arange(nc, dtype=np.int64)
+    rp1 = np.arange(nc + 1, dtype=np.uint32)
+    rp2 = (2 * np.arange(nc + 1)).astype(np.uint32)
+    a_col = np.stack([1 + (i % 4), ni + i], axis=1).reshape(-1).astype(np.uint32)
+    A = (rp2, a_col, np.tile(one, (2 * nc, 1)))
+    B = (rp1, (ni + i).astype(np.uint32), np.tile(one, (nc, 1)))
+    Cm = (rp1, (ni + i + 1).astype(np.uint32), np.tile(one, (nc, 1)))
+    dr = ctx.r1cs_upload(ni, nw, A, B, Cm)
+    td = [mont(rng.fr()) for _ in range(7)]
+    rr, ss = mont(rng.fr()), mont(rng.fr())
+    pk = ctx.groth16_setup(dr, *td)
+    assert ctx.lib.zk_bases_window_bits(pk.query_bases("a_query").h) >= 15
+    zarr = cv.fr_to_mont(z)
+    proof = ctx.create_proof(pk, dr, zarr, rr, ss)
+    cr = OC.R1cs(ni, nw, A, B, Cm)
+    assert proof == OC.groth16_predict(cr, np.stack(td), zarr, OC.witness_map(cr, zarr), rr, ss)
+    pk.free()

@@ -43,7 +43,7 @@ struct ZkPhaseTimer {
     ~ZkPhaseTimer();
     void begin(const char* name);
     void end();
-    void resolve();  // synchronises the stream and accumulates into ctx->timers
+    void resolve();  // waits for the recorded end events (not for the stream) and accumulates into ctx->timers
 };
 
 // An MSM in flight (msm.hip): prepare -> enqueue_sort -> enqueue_accum -> enqueue_reduce -> finish.

@@ -188,14 +188,15 @@ k_scan(const uint32_t* counts, uint32_t* offs, uint32_t* seg_local, uint32_t* wi
 // The same scan for a big bucket set (merged mode: one window of 2^19 buckets), over several blocks: chunk totals,
 // a scan of the totals, then the scan inside each chunk.  One 1024-thread block walking 2^19 counters alone took
 // 1.2 ms, on the critical path in front of the first accumulate kernel.
-constexpr uint32_t SCAN_CHUNK = 8192;   // 1024 threads x 8 consecutive counters
+constexpr uint32_t SCAN_T = 512;                 // threads per block of the multi-block scan
+constexpr uint32_t SCAN_CHUNK = SCAN_T * 8;      // 8 consecutive counters per thread
 
 __device__ __forceinline__ uint32_t segs_of(uint32_t c, uint32_t seg) { return c ? (c + seg - 1) / seg : 1; }
 
-// block-wide inclusive scan of one value pair per thread (1024 threads)
+// block-wide inclusive scan of one value pair per thread (SCAN_T threads)
 __device__ __forceinline__ void block_scan2(uint32_t* part, uint32_t* part2, uint32_t tid) {
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
+    for (uint32_t d = 1; d < SCAN_T; d <<= 1) {
         uint32_t v = tid >= d ? part[tid - d] : 0, v2 = tid >= d ? part2[tid - d] : 0;
         __syncthreads();
         part[tid] += v;
@@ -204,24 +205,24 @@ __device__ __forceinline__ void block_scan2(uint32_t* part, uint32_t* part2, uin
     }
 }
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(SCAN_T)
 k_scan_sums(const uint32_t* counts, uint32_t NB, uint32_t seg, uint32_t nchunks, uint32_t* sums) {
-    __shared__ uint32_t part[1024], part2[1024];
+    __shared__ uint32_t part[SCAN_T], part2[SCAN_T];
     const uint32_t w = blockIdx.x / nchunks, ch = blockIdx.x % nchunks, tid = threadIdx.x;
     uint32_t s = 0, s2 = 0;
     for (uint32_t k = 0; k < 8; k++) {
-        uint32_t b = ch * SCAN_CHUNK + k * 1024 + tid;           // totals only: any order, so read coalesced
+        uint32_t b = ch * SCAN_CHUNK + k * SCAN_T + tid;           // totals only: any order, so read coalesced
         if (b < NB) { uint32_t c = counts[(size_t)w * NB + b]; s += c; s2 += segs_of(c, seg); }
     }
     part[tid] = s;
     part2[tid] = s2;
     block_scan2(part, part2, tid);
-    if (tid == 1023) { sums[2 * blockIdx.x] = part[1023]; sums[2 * blockIdx.x + 1] = part2[1023]; }
+    if (tid == SCAN_T - 1) { sums[2 * blockIdx.x] = part[SCAN_T - 1]; sums[2 * blockIdx.x + 1] = part2[SCAN_T - 1]; }
 }
 
-// one block per window: exclusive scan of the chunk totals in place (nchunks <= 1024)
-__global__ void __launch_bounds__(1024) k_scan_tops(uint32_t* sums, uint32_t nchunks) {
-    __shared__ uint32_t part[1024], part2[1024];
+// one block per window: exclusive scan of the chunk totals in place (nchunks <= SCAN_T)
+__global__ void __launch_bounds__(SCAN_T) k_scan_tops(uint32_t* sums, uint32_t nchunks) {
+    __shared__ uint32_t part[SCAN_T], part2[SCAN_T];
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
     uint32_t v = tid < nchunks ? sums[2 * ((size_t)w * nchunks + tid)] : 0, v2 = tid < nchunks ? sums[2 * ((size_t)w * nchunks + tid) + 1] : 0;
     part[tid] = v;
@@ -230,10 +231,10 @@ __global__ void __launch_bounds__(1024) k_scan_tops(uint32_t* sums, uint32_t nch
     if (tid < nchunks) { sums[2 * ((size_t)w * nchunks + tid)] = part[tid] - v; sums[2 * ((size_t)w * nchunks + tid) + 1] = part2[tid] - v2; }
 }
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(SCAN_T)
 k_scan_fill(const uint32_t* counts, const uint32_t* sums, uint32_t* offs, uint32_t* seg_local, uint32_t* win_segs, uint32_t NB,
             uint32_t seg, uint32_t nchunks) {
-    __shared__ uint32_t part[1024], part2[1024];
+    __shared__ uint32_t part[SCAN_T], part2[SCAN_T];
     const uint32_t w = blockIdx.x / nchunks, ch = blockIdx.x % nchunks, tid = threadIdx.x;
     const uint32_t lo = ch * SCAN_CHUNK + tid * 8;
     uint32_t c[8], s = 0, s2 = 0;
@@ -256,9 +257,9 @@ k_scan_fill(const uint32_t* counts, const uint32_t* sums, uint32_t* offs, uint32
             run2 += segs_of(c[k], seg);
         }
     }
-    if (ch == nchunks - 1 && tid == 1023) {
-        offs[(size_t)w * (NB + 1) + NB] = sums[2 * blockIdx.x] + part[1023];
-        win_segs[w] = sums[2 * blockIdx.x + 1] + part2[1023];
+    if (ch == nchunks - 1 && tid == SCAN_T - 1) {
+        offs[(size_t)w * (NB + 1) + NB] = sums[2 * blockIdx.x] + part[SCAN_T - 1];
+        win_segs[w] = sums[2 * blockIdx.x + 1] + part2[SCAN_T - 1];
     }
 }
 
@@ -298,16 +299,16 @@ k_build_segs(const uint32_t* offs, const uint32_t* seg_local, const uint32_t* wi
 }
 
 // bin_start[len] for a DESCENDING order by length (longest segments first); one block.
-__global__ void __launch_bounds__(1024) k_len_scan(const uint32_t* hist, uint32_t* bin_start, uint32_t* bin_cursor, uint32_t seg) {
-    __shared__ uint32_t part[1024];
+__global__ void __launch_bounds__(512) k_len_scan(const uint32_t* hist, uint32_t* bin_start, uint32_t* bin_cursor, uint32_t seg) {
+    __shared__ uint32_t part[512];
     const uint32_t tid = threadIdx.x, nb = seg + 1;
-    const uint32_t per = (nb + 1023) / 1024;
+    const uint32_t per = (nb + 511) / 512;
     // position p = seg - len  (p = 0 is the longest)
     uint32_t lo = tid * per, hi = min(lo + per, nb), s = 0;
     for (uint32_t p = lo; p < hi; p++) s += hist[seg - p];
     part[tid] = s;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
+    for (uint32_t d = 1; d < 512; d <<= 1) {
         uint32_t v = tid >= d ? part[tid - d] : 0;
         __syncthreads();
         part[tid] += v;
@@ -346,10 +347,12 @@ k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t
 // per segment -- the kernel never has thousands of blocks queued in front of the small sort / reduce
 // kernels of the other in-flight MSMs (which were starved for milliseconds behind that queue).  The next
 // point is fetched while the current one is added.
-// Minimum waves per SIMD asked of the compiler for the accumulate kernel (1 = no constraint).  Left to the compiler it
-// takes 230 VGPRs for G1 (2 waves / SIMD) and the full 512 for G2 (1 wave / SIMD); forcing 3 / 2 waves makes it spill
-// (176 / 920 B of scratch per lane) and the proof gets slower (28.2 vs 26.3 ms): the kernel is issue-bound, not
-// latency-bound, so occupancy buys nothing here.
+// G1 only (G2 runs on lane pairs: msm_g2pair.hip).  Left to the compiler the kernel takes 230 VGPRs = 2 waves / SIMD; forcing
+// 3 waves makes it spill (176 B of scratch per lane) and the proof slower: the kernel is issue-bound, not latency-bound.
+// Holding it to 224 registers (amdgpu_num_vgpr(112): counted in pairs on gfx90a+) so that two resident waves leave 64 free
+// registers per SIMD lane for the sort kernels of the next job (k_digits needs 56, k_build_segs 64; scans in 512-thread
+// blocks) was measured too: no change for Groth16 (23.7 ms) or Marlin (86.7 ms) -- the co-running sorts are not waiting
+// for registers.
 #ifndef ZK_ACCUM_WAVES_G1
 #define ZK_ACCUM_WAVES_G1 1
 #endif
@@ -649,20 +652,21 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
         hipLaunchKernelGGL(k_scan, Wb, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NB, seg);
     } else {
         const uint32_t nchunks = (uint32_t)((NB + SCAN_CHUNK - 1) / SCAN_CHUNK);
+        if (nchunks > SCAN_T) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: bucket set too large for the two-level scan");
         uint32_t* sums;
         char nm2[64];
         snprintf(nm2, sizeof nm2, "msm_scan_sums.%d", job->slot);
         ZK_TRY(zk_scratch(ctx, nm2, (size_t)Wb * nchunks * 8, (void**)&sums));
-        hipLaunchKernelGGL(k_scan_sums, Wb * nchunks, 1024, 0, st, b.counts, (uint32_t)NB, seg, nchunks, sums);
-        hipLaunchKernelGGL(k_scan_tops, Wb, 1024, 0, st, sums, nchunks);
-        hipLaunchKernelGGL(k_scan_fill, Wb * nchunks, 1024, 0, st, b.counts, (const uint32_t*)sums, b.offs, b.seg_local, win_segs, (uint32_t)NB,
+        hipLaunchKernelGGL(k_scan_sums, Wb * nchunks, SCAN_T, 0, st, b.counts, (uint32_t)NB, seg, nchunks, sums);
+        hipLaunchKernelGGL(k_scan_tops, Wb, SCAN_T, 0, st, sums, nchunks);
+        hipLaunchKernelGGL(k_scan_fill, Wb * nchunks, SCAN_T, 0, st, b.counts, (const uint32_t*)sums, b.offs, b.seg_local, win_segs, (uint32_t)NB,
                            seg, nchunks);
     }
     hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted, merged,
                        job->n_tab, job->tab_off);
     hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
                        merged ? (size_t)0 : n, Wb, NB, seg, b.desc, b.heavy, ctr, hist);
-    hipLaunchKernelGGL(k_len_scan, 1, 1024, 0, st, hist, bin_start, bin_cursor, seg);
+    hipLaunchKernelGGL(k_len_scan, 1, 512, 0, st, hist, bin_start, bin_cursor, seg);
     hipLaunchKernelGGL(k_order, 512, 256, (seg + 1) * 4, st, b.desc, ctr, bin_cursor, seg, b.order);
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
@@ -686,13 +690,12 @@ int msm_enqueue_accum_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     static const int bpc = getenv("ZK_ACCUM_BPC") ? atoi(getenv("ZK_ACCUM_BPC")) : 0;
     const size_t full_grid = (job->max_segs + 255) / 256;
     const unsigned accum_blocks = (unsigned)(bpc > 0 ? std::min<size_t>(full_grid, (size_t)ctx->n_cu * bpc) : full_grid);
-    // G2: two lanes per addition (msm_g2pair.hip) unless ZK_G2_PAIR=0 asks for the one-lane kernel
-    static const bool g2pair = !(getenv("ZK_G2_PAIR") && atoi(getenv("ZK_G2_PAIR")) == 0);
-    if (!g1 && g2pair)
-        zk_launch_accum_g2pair(st, job->max_segs, job->bases_dev, job->sorted, job->desc, job->order, job->ctr, b.sums);
-    else
+    // G2 runs on lane pairs (msm_g2pair.hip): the one-lane-per-addition form needs the whole register file and is slower
+    if constexpr (F::WORDS == 12)
         hipLaunchKernelGGL(k_accum<F>, accum_blocks, 256, 0, st, job->bases_dev, job->sorted,
                            (const SegDesc*)job->desc, job->order, job->ctr, b.sums);
+    else
+        zk_launch_accum_g2pair(st, job->max_segs, job->bases_dev, job->sorted, job->desc, job->order, job->ctr, b.sums);
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
     ZK_HIP(ctx, hipEventCreateWithFlags(&job->accum_done, hipEventDisableTiming));
@@ -715,29 +718,26 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     const unsigned light_blocks = (unsigned)std::min<size_t>((job->max_heavy + 63) / 64, 512);
     const unsigned heavy_blocks = (unsigned)std::min<size_t>(job->max_heavy, 1024);
     const uint32_t nout = job->nbits + (job->Rw > job->Wb ? 2u : 1u);
-    static const bool g2pair_red = !(getenv("ZK_G2_PAIR_REDUCE") && atoi(getenv("ZK_G2_PAIR_REDUCE")) == 0);
-        if (!g1 && g2pair_red) {
+    if constexpr (F::WORDS != 12) {
         // G2: the same chain on lane pairs (msm_g2pair.hip)
         ZkG2PairReduce a{job->heavy, job->ctr, b.sums, b.lvS, b.lvW, b.lvS2, b.lvW2, b.bits, job->RNB, job->T1, job->T2, job->Rw,
                          job->levels, job->nbits, nout, (uint32_t)REDUCE_K_LOG, 2 * light_blocks, heavy_blocks};
         ZK_TRY(zk_launch_reduce_g2pair(st, a));
     } else {
-    hipLaunchKernelGGL(k_fold<F>, light_blocks + heavy_blocks, 64, 64 * XW * 4, st, (const HeavyDesc*)job->heavy, job->ctr, b.sums,
-                       light_blocks);
-    const size_t threads = (size_t)job->Rw * job->T1;
-    hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, b.sums, nullptr, b.lvS, b.lvW, job->RNB, job->T1,
-                       (uint32_t)REDUCE_K_LOG, job->Rw, 1, 0);
-    if (256 * XW * 4 > 64 * 1024)
-        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_bitsum<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * XW * 4)));
-    const uint32_t *topS = b.lvS, *topW = b.lvW;
-    if (job->levels == 2) {
-        const size_t threads2 = (size_t)job->Rw * job->T2;
-        hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads2 + 63) / 64), 64, 0, st, (const uint32_t*)b.lvS, (const uint32_t*)b.lvW, b.lvS2, b.lvW2,
-                           job->T1, job->T2, (uint32_t)REDUCE_K_LOG, job->Rw, 0, 0);
-        topS = b.lvS2;
-        topW = b.lvW2;
-    }
-    hipLaunchKernelGGL(k_bitsum<F>, job->Rw * nout, 256, 256 * XW * 4, st, topS, topW, b.bits, job->T2, job->nbits, nout);
+        hipLaunchKernelGGL(k_fold<F>, light_blocks + heavy_blocks, 64, 64 * XW * 4, st, (const HeavyDesc*)job->heavy, job->ctr, b.sums,
+                           light_blocks);
+        const size_t threads = (size_t)job->Rw * job->T1;
+        hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, b.sums, nullptr, b.lvS, b.lvW, job->RNB, job->T1,
+                           (uint32_t)REDUCE_K_LOG, job->Rw, 1, 0);
+        const uint32_t *topS = b.lvS, *topW = b.lvW;
+        if (job->levels == 2) {
+            const size_t threads2 = (size_t)job->Rw * job->T2;
+            hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads2 + 63) / 64), 64, 0, st, (const uint32_t*)b.lvS, (const uint32_t*)b.lvW, b.lvS2,
+                               b.lvW2, job->T1, job->T2, (uint32_t)REDUCE_K_LOG, job->Rw, 0, 0);
+            topS = b.lvS2;
+            topW = b.lvW2;
+        }
+        hipLaunchKernelGGL(k_bitsum<F>, job->Rw * nout, 256, 256 * XW * 4, st, topS, topW, b.bits, job->T2, job->nbits, nout);   // 48 KiB of LDS
     }
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
@@ -903,10 +903,13 @@ void ZkPhaseTimer::end() {
 void ZkPhaseTimer::resolve() {
     if (!enabled || resolved) return;
     resolved = true;
-    (void)hipStreamSynchronize(stream);
+    // wait for each phase's own end event, never for the stream: the accumulate stream holds the kernels of ALL in-flight
+    // jobs, and synchronising it from the first job's finish() made the host wait for the whole proof (the host-side
+    // chains of create_proof then started after the GPU had gone idle: +1.1 ms per proof with the timers on)
     for (auto& e : ev) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, e.second.first, e.second.second) == hipSuccess) {
+        if (hipEventSynchronize(e.second.second) == hipSuccess &&
+            hipEventElapsedTime(&ms, e.second.first, e.second.second) == hipSuccess) {
             ctx->timers[e.first].ms += ms;
             ctx->timers[e.first].count += 1;
         }
