@@ -247,7 +247,7 @@ def main():
         step()
     for _ in range(args.warmup):
         proof = step()
-    ctx.set_profiling(not os.environ.get('BENCH_NO_PHASES'))
+    ctx.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -292,6 +292,15 @@ def main():
                     "note": "kernel is integer-ALU bound, not HBM bound (SURVEY 8d); see int_alu",
                     "int_alu": {"achieved": round(mads / avg_s / 1e12, 3), "peak": round(INT_MAD_PEAK / 1e12, 2),
                                 "unit": "T v_mad_u64_u32 lane-ops/s", "frac": round(mads / avg_s / INT_MAD_PEAK, 4)}}
+            # the single longest kernel: the G2 accumulate on lane pairs (one launch per proof); every one of its 10 Fq2
+            # products per mixed addition is two fused double products of 507 mads
+            g2_ms, g2_cnt = timers.get("msm_g2.accum", (0.0, 0))
+            if g2_cnt:
+                g2_s = g2_ms / g2_cnt * 1e-3
+                roof["g2_accum"] = {"kernel": "k_accum_g2pair (B-in-G2 bucket accumulation, two lanes per addition)",
+                                    "avg_launch_ms": round(g2_s * 1e3, 3), "launches": g2_cnt,
+                                    "int_alu": {"achieved": round(madds * 10 * 1014 / g2_s / 1e12, 3), "peak": round(INT_MAD_PEAK / 1e12, 2),
+                                                "unit": "T v_mad_u64_u32 lane-ops/s", "frac": round(madds * 10 * 1014 / g2_s / INT_MAD_PEAK, 4)}}
         out = {
             "metric": "R1CS constraints/sec (prove), Groth16 BLS12-377",
             "value": round(per_proof * world, 1),

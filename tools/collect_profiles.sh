@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-end evidence, run on the GPU box from the repo root:  bash tools/collect_profiles.sh <tag>
+# Writes under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
+set -u
+T=${1:-r1}
+O=gpurun_out
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python3 bench.py > $O/${T}_bench_n1.json 2> $O/${T}_bench_n1.err
+rocprofv3 --kernel-trace --stats -d $O/${T}_trace -o t --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/${T}_trace.log 2>&1
+python3 tools/trace_timeline.py $O/${T}_trace/t_kernel_trace.csv 100 -8 > $O/${T}_timeline.txt 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${T}_pmc_fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${T}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${T}_pmc_write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${T}_pmc_write.log 2>&1
+python3 tools/pmc_traffic.py $O/${T}_pmc_fetch $O/${T}_pmc_write $O/${T}_pmc_traffic.json "bench.py --steps 3 --warmup 1, 2^20 Groth16 proofs." > $O/${T}_pmc_traffic.txt 2>&1
+python3 tools/bench_marlin.py --logs 16,18,20,21,22 > $O/${T}_marlin_bench.jsonl 2> $O/${T}_marlin_bench.err
+rocprofv3 --kernel-trace --stats -d $O/${T}_marlin_trace -o m --output-format csv -- python3 tools/bench_marlin.py --logs 20 --reps 3 > $O/${T}_marlin_trace.log 2>&1
+python3 tools/bench_msm.py 24 > $O/${T}_micro_msm_ntt.json 2> $O/${T}_micro.err
+python3 tools/bench_she.py > $O/${T}_she_bench.jsonl 2> $O/${T}_she.err
+ls $O | grep "^${T}_"

@@ -555,7 +555,12 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     // B-in-G2's reduce chain (the long one) stays on the sort stream; the four G1 reduces go to the main stream, idle by
     // then, so that each runs right behind its own accumulate kernel instead of queueing behind the G2 chain (that
     // queueing left 4 x 0.7 ms of reduces after the last accumulate).
-    for (int k = 0; k < 5 && rc == ZK_OK; k++) rc = zk_msm_enqueue_reduce(ctx, &jobs[ord[k]], ord[k] == 0 ? s_red : ctx->stream);
+    // The last two reduce chains alternate between the two streams (the sort stream is idle again once the G2 chain is
+    // through): on one stream the last job's chain queued behind its predecessor's, which was still waiting for slots
+    // beside the last accumulate kernel, and ~0.6 ms of it ran after the GPU had otherwise gone idle.
+    static const int alt = getenv("ZK_REDUCE_ALT") ? atoi(getenv("ZK_REDUCE_ALT")) : 2;   // 0: all on main, 1: last on sort, 2: every other one
+    for (int k = 0; k < 5 && rc == ZK_OK; k++)
+        rc = zk_msm_enqueue_reduce(ctx, &jobs[ord[k]], (ord[k] == 0 || (alt == 1 && k == 4) || (alt == 2 && (k & 1) == 0)) ? s_red : ctx->stream);
     // finish in completion order: the host-side Horner of an early job overlaps the GPU work of the later ones
     void* outs[5] = {out_g2, &out_g1[2], &out_g1[3], &out_g1[1], &out_g1[0]};
     int abc_left = 3;
