@@ -444,8 +444,11 @@ k_fold(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint32_t lig
 // One reduction level (see file header).  Elements per window: T_in; chunk = 2^klog elements.
 // in : S_in[w*T_in + t], optional W_in[w*T_in + t]
 // out: S_out[w*T_out + c] = 2^klog * sum S ; W_out[w*T_out + c] = sum W + sum (t - lo (+1)) S_t
+// At most 256 registers (it would take 322): a wave of this kernel then shares a SIMD with one accumulate wave
+// (232 + 256 <= 512).  With 322 it had the SIMD to itself while running a latency-bound chain of 16 dependent additions,
+// and the accumulate kernel beside it lost the SIMD for that time.
 template <class F>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)
 k_reduce(const uint32_t* S_in, const uint32_t* W_in, uint32_t* S_out, uint32_t* W_out, uint32_t T_in,
          uint32_t T_out, uint32_t klog, uint32_t n_windows, int one_based, int last) {
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;

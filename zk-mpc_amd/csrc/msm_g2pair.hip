@@ -245,7 +245,7 @@ k_fold_g2pair(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint3
 }
 
 // msm.hip::k_reduce on pairs (one chunk of 2^klog elements per pair)
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)   // <= 256 registers: shares a SIMD with an accumulate wave (msm.hip::k_reduce)
 k_reduce_g2pair(const uint32_t* S_in, const uint32_t* W_in, uint32_t* S_out, uint32_t* W_out, uint32_t T_in, uint32_t T_out,
                 uint32_t klog, uint32_t n_windows, int one_based, int last) {
     const size_t t = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 1;
