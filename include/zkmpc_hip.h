@@ -230,6 +230,11 @@ int zk_groth16_witness_map_post_dev(zk_ctx* ctx, const zk_r1cs* r1cs, void* ab_d
 /* The five MSMs of create_proof (src/groth16.rs:106,110,137,148,160) on a resident key:
  * out = [h_acc, l_aux_acc, a_acc, b_g1_acc] and b_g2_acc; z_dev as above, h_dev from witness_map.
  * (For shares these are the party-local MSMs of multi_scale_pub_group, share/additive.rs:517-520.) */
+/* Optional: enqueue the sort of z[1..] that four of those MSMs share, ahead of zk_groth16_msms_dev on the same z_dev
+ * (asynchronous; z_dev must stay unchanged).  The collaborative prover calls it before the Beaver open of
+ * mpc-algebra/src/share/field.rs:97-129 so that the sort runs during the exchange.  Dropped if another MSM batch or a
+ * different z_dev comes first. */
+int zk_groth16_msms_presort_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const void* z_dev);
 int zk_groth16_msms_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const void* z_dev,
                         const void* h_dev, zk_g1_projective out_g1[4], zk_g2_projective* out_g2);
 /* create_proof (src/groth16.rs:68-183 / arkworks/groth16/src/prover.rs:44-153) for a plain

@@ -115,6 +115,9 @@ class OracleBackend:
         d = OC.fr_vec_op(0, d, np.tile(cv.fr_to_mont([zinv])[0], (self.dom.size, 1)))
         self.store[ab] = OC.fft(d, self.dom.log_size, 1, 1)
 
+    def msms_presort(self, pk, r1cs, z):
+        pass                                   # a scheduling hint of the device backend
+
     def msms(self, pk: OraclePk, r1cs, z, h):
         zz, hh = self.store[z], self.store[h]
         ni = self.r1cs.num_instance

@@ -47,6 +47,7 @@ extern "C" int zk_ctx_destroy(zk_ctx* ctx) {
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto& kv : ctx->pinned)
         if (kv.second.p) (void)hipHostFree(kv.second.p);
+    zk_presort_free(ctx);
     zk_domains_free(ctx);
     for (auto st : ctx->aux) (void)hipStreamDestroy(st);
     if (ctx->acc_stream) (void)hipStreamDestroy(ctx->acc_stream);

@@ -35,6 +35,7 @@ struct zk_ctx {
     std::map<uint32_t, zk_domain*> domains;  // keyed by log2(size)
     std::map<std::string, int> flags;         // one-time per-context setup markers
     void* comm = nullptr;                     // RCCL communicator of this party (comm.hip), created by zk_comm_init
+    void* presort = nullptr;                  // groth16.hip: a sort of z[1..] enqueued ahead of zk_groth16_msms_dev (ZkPresort)
     std::mutex mu;
     // timing of the most recent instrumented call (ms), filled when ZK_PROFILE env or explicit request
     struct Timer { float ms = 0; int count = 0; };

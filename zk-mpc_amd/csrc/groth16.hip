@@ -20,6 +20,7 @@
 #include <cstring>
 #include <functional>
 #include <future>
+#include <memory>
 #include <vector>
 
 using namespace zk;
@@ -476,6 +477,22 @@ extern "C" int zk_groth16_setup(zk_ctx* ctx, const zk_r1cs* r, const zk_fr* alph
 
 // ---- prover ----------------------------------------------------------------------------------
 
+// A sort of z[1..] (shared by the B-in-G2 / A / B-in-G1 / L jobs) enqueued ahead of the MSMs: the collaborative prover
+// calls zk_groth16_msms_presort_dev right after the local half of the witness map, so the sort runs under the Beaver open
+// (network time) instead of in front of the first accumulate kernel.  Owned by the context until run_msms takes it over.
+struct ZkPresort {
+    ZkMsmJob job;
+    const zk_pk* pk = nullptr;
+    const void* z = nullptr;
+};
+void zk_presort_free(zk_ctx* ctx) {
+    if (!ctx || !ctx->presort) return;
+    ZkPresort* p = (ZkPresort*)ctx->presort;
+    ctx->presort = nullptr;
+    if (ctx->aux.size()) (void)hipStreamSynchronize(ctx->aux[0]);   // its kernels write the job's scratch slot
+    delete p;
+}
+
 namespace {
 
 int ensure_aux(zk_ctx* ctx, size_t k) {
@@ -509,19 +526,27 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     ZK_HIP(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventRecord(e0, ctx->stream));
     ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e0, 0));
-    ZkMsmJob jobs[5];  // 0: B in G2, 1: A, 2: B in G1, 3: L, 4: H
-    int rc = zk_msm_prepare(ctx, &jobs[0], pk->b_g2, 1, zb + 32, nvars, 1);                       // src/groth16.rs:160 (query[1..])
-    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &jobs[1], pk->a, 1, zb + 32, nvars, 2);              // :137
-    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &jobs[2], pk->b_g1, 1, zb + 32, nvars, 3);           // :148
+    ZkMsmJob own[5];  // 0: B in G2, 1: A, 2: B in G1, 3: L, 4: H
+    ZkMsmJob* J[5] = {&own[0], &own[1], &own[2], &own[3], &own[4]};
+    // the sort of z[1..] may already be running (zk_groth16_msms_presort_dev, enqueued by the collaborative prover before
+    // its Beaver open): take it over as job 0's
+    ZkPresort* pre = (ZkPresort*)ctx->presort;
+    ctx->presort = nullptr;
+    std::unique_ptr<ZkPresort> pre_owner(pre);
+    const bool presorted = pre && pre->pk == pk && pre->z == z && pre->job.n == nvars;
+    if (presorted) J[0] = &pre->job;
+    int rc = presorted ? ZK_OK : zk_msm_prepare(ctx, J[0], pk->b_g2, 1, zb + 32, nvars, 1);                 // src/groth16.rs:160 (query[1..])
+    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, J[1], pk->a, 1, zb + 32, nvars, 2);              // :137
+    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, J[2], pk->b_g1, 1, zb + 32, nvars, 3);           // :148
     // :110: aux_assignment against l_query; over the padded table the same sum reads z[1..] (the instance meets infinity)
     const bool l_shared = pk->l_pad && pk->l_pad->n == nvars + 1 && (pk->l_pad->pre != nullptr) == (pk->a->pre != nullptr) &&
                           pk->l_pad->c_pre == pk->a->c_pre;
-    if (rc == ZK_OK) rc = l_shared ? zk_msm_prepare(ctx, &jobs[3], pk->l_pad, 1, zb + 32, nvars, 4)
-                                   : zk_msm_prepare(ctx, &jobs[3], pk->l, 0, zb + r->ni * 32, r->nw, 4);
-    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[0], s_sort, nullptr);
-    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[1], s_sort, &jobs[0]);
-    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[2], s_sort, &jobs[0]);
-    if (rc == ZK_OK && l_shared) rc = zk_msm_enqueue_sort(ctx, &jobs[3], s_sort, &jobs[0]);
+    if (rc == ZK_OK) rc = l_shared ? zk_msm_prepare(ctx, J[3], pk->l_pad, 1, zb + 32, nvars, 4)
+                                   : zk_msm_prepare(ctx, J[3], pk->l, 0, zb + r->ni * 32, r->nw, 4);
+    if (rc == ZK_OK && !presorted) rc = zk_msm_enqueue_sort(ctx, J[0], s_sort, nullptr);
+    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, J[1], s_sort, J[0]);
+    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, J[2], s_sort, J[0]);
+    if (rc == ZK_OK && l_shared) rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, J[0]);
     const void* h = h_in;
     ZkPhaseTimer tm(ctx);
     if (rc == ZK_OK && !h_in) {
@@ -531,17 +556,17 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         h = h_scratch;
     }
     // h_acc: min(len) rule (variable_base.rs:15-17): h_query has D-1 entries, h has D
-    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &jobs[4], pk->h, 0, h, std::min(pk->h->n, D), 5);   // :106
+    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, J[4], pk->h, 0, h, std::min(pk->h->n, D), 5);   // :106
     if (rc == ZK_OK) {
         ZK_HIP(ctx, hipEventRecord(e1, ctx->stream));
         static const bool gate = !(getenv("ZK_WM_GATE") && atoi(getenv("ZK_WM_GATE")) == 0);
         if (gate) ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e1, 0));
-        rc = zk_msm_enqueue_sort(ctx, &jobs[4], ctx->stream, nullptr);
+        rc = zk_msm_enqueue_sort(ctx, J[4], ctx->stream, nullptr);
     }
     // L's sort after the witness map (it is not needed before the fourth accumulate kernel)
     if (rc == ZK_OK && !l_shared) {
         ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e1, 0));
-        rc = zk_msm_enqueue_sort(ctx, &jobs[3], s_sort, nullptr);
+        rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, nullptr);
     }
     // accumulate order (job numbers: 0 = B in G2, 1 = A, 2 = B in G1, 3 = L, 4 = H; H's scalars arrive last)
     int ord[5] = {0, 1, 2, 3, 4};
@@ -551,7 +576,7 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         for (; cnt < 5 && e[cnt] >= '0' && e[cnt] <= '4' && !seen[e[cnt] - '0']; cnt++) { tmp[cnt] = e[cnt] - '0'; seen[tmp[cnt]] = true; }
         if (cnt == 5) for (int k = 0; k < 5; k++) ord[k] = tmp[k];
     }
-    for (int k = 0; k < 5 && rc == ZK_OK; k++) rc = zk_msm_enqueue_accum(ctx, &jobs[ord[k]], s_acc);
+    for (int k = 0; k < 5 && rc == ZK_OK; k++) rc = zk_msm_enqueue_accum(ctx, J[ord[k]], s_acc);
     // B-in-G2's reduce chain (the long one) stays on the sort stream; the four G1 reduces go to the main stream, idle by
     // then, so that each runs right behind its own accumulate kernel instead of queueing behind the G2 chain (that
     // queueing left 4 x 0.7 ms of reduces after the last accumulate).
@@ -560,12 +585,12 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     // beside the last accumulate kernel, and ~0.6 ms of it ran after the GPU had otherwise gone idle.
     static const int alt = getenv("ZK_REDUCE_ALT") ? atoi(getenv("ZK_REDUCE_ALT")) : 2;   // 0: all on main, 1: last on sort, 2: every other one
     for (int k = 0; k < 5 && rc == ZK_OK; k++)
-        rc = zk_msm_enqueue_reduce(ctx, &jobs[ord[k]], (ord[k] == 0 || (alt == 1 && k == 4) || (alt == 2 && (k & 1) == 0)) ? s_red : ctx->stream);
+        rc = zk_msm_enqueue_reduce(ctx, J[ord[k]], (ord[k] == 0 || (alt == 1 && k == 4) || (alt == 2 && (k & 1) == 0)) ? s_red : ctx->stream);
     // finish in completion order: the host-side Horner of an early job overlaps the GPU work of the later ones
     void* outs[5] = {out_g2, &out_g1[2], &out_g1[3], &out_g1[1], &out_g1[0]};
     int abc_left = 3;
     for (int k = 0; k < 5 && rc == ZK_OK; k++) {
-        rc = zk_msm_finish(ctx, &jobs[ord[k]], outs[ord[k]]);
+        rc = zk_msm_finish(ctx, J[ord[k]], outs[ord[k]]);
         if (ord[k] <= 2 && --abc_left == 0 && rc == ZK_OK && after_abc) after_abc();   // A, B1, B2 are in: the caller's host work overlaps the rest
     }
     (void)hipStreamSynchronize(s_sort);
@@ -593,6 +618,7 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
         if (off + lens[k] > bases[k]->n) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_msm_batch_dev: a job reads past its base table");
     }
     if (n_jobs == 0) return ZK_OK;
+    zk_presort_free(ctx);            // the batch rotates over the same scratch slots
     ZK_TRY(ensure_aux(ctx, 1));
     constexpr size_t SLOTS = 3;
     hipStream_t s_sort = ctx->aux[0], s_acc = ctx->acc_stream;
@@ -628,6 +654,26 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
     (void)hipStreamSynchronize(s_acc);
     (void)hipEventDestroy(e0);
     return rc;
+}
+
+extern "C" int zk_groth16_msms_presort_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z) {
+    if (!ctx || !pk || !r || !z) return ZK_ERR_ARG;
+    zk_presort_free(ctx);
+    const size_t nvars = (r->ni - 1) + r->nw;
+    if (pk->b_g2->n != nvars + 1) ZK_FAIL(ctx, ZK_ERR_ARG, "groth16: proving key does not match the constraint system");
+    ZK_TRY(ensure_aux(ctx, 1));
+    hipEvent_t e0;
+    ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    ZK_HIP(ctx, hipEventRecord(e0, ctx->stream));          // z was produced on the context stream
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->aux[0], e0, 0));
+    (void)hipEventDestroy(e0);
+    std::unique_ptr<ZkPresort> p(new ZkPresort());
+    p->pk = pk;
+    p->z = z;
+    ZK_TRY(zk_msm_prepare(ctx, &p->job, pk->b_g2, 1, (const char*)z + 32, nvars, 1));
+    ZK_TRY(zk_msm_enqueue_sort(ctx, &p->job, ctx->aux[0], nullptr));
+    ctx->presort = p.release();
+    return ZK_OK;
 }
 
 extern "C" int zk_groth16_msms_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const void* h,

@@ -6,6 +6,7 @@
 
 // ntt.hip
 void zk_domains_free(zk_ctx* ctx);
+void zk_presort_free(zk_ctx* ctx);   // groth16.hip: drop a pending zk_groth16_msms_presort_dev
 extern "C" int zk_comm_destroy(zk_ctx* ctx);
 extern "C" int zk_fr_sum_parties_dev(zk_ctx* ctx, const void* gathered_dev, size_t n_parties, size_t n, void* out_dev);
 int zk_ntt_launch(zk_ctx* ctx, void* buf_dev, uint32_t log_n, int inverse, int coset);

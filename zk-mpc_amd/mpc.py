@@ -282,6 +282,9 @@ class GpuBackend:
     def witness_map_post(self, r1cs, ab, c):
         self.ctx.witness_map_post_dev(r1cs, ab, c)
 
+    def msms_presort(self, pk, r1cs, z):
+        self.ctx.groth16_msms_presort_dev(pk, r1cs, z)
+
     def msms(self, pk, r1cs, z, h):
         return self.ctx.groth16_msms_dev(pk, r1cs, z, h)
 
@@ -471,6 +474,7 @@ class Party:
         D = be.domain_size(r1cs)
         a, b, c = be.vec("wm_a", D), be.vec("wm_b", D), be.vec("wm_c", D)
         be.witness_map_pre(r1cs, z_share, a, b, c)                 # local: linear in the shares
+        be.msms_presort(pk, r1cs, z_share)                         # the MSMs' shared sort of z runs under the open below
         self.beaver_batch_mul(a, b, a, D, triple)                  # the one shared x shared vector product (:285)
         be.witness_map_post(r1cs, a, c)                            # h shares in `a`
         g1, g2 = be.msms(pk, r1cs, z_share, a)                     # party-local MSMs (multi_scale_pub_group)
