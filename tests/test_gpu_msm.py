@@ -87,6 +87,21 @@ def test_msm_witness_like_scalars(ctx):
     assert run_g1(ctx, bases, scalars) == O.msm_naive(bases, scalars, O.FqOps)
 
 
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_very_heavy_bucket(ctx, group):
+    """Thousands of unit scalars: one bucket is cut into more than 32 segments, which the fold kernels add up with a
+    whole block per bucket (k_fold / k_fold_g2pair, heavy part); a few buckets of 2 .. 32 segments take the light part."""
+    rng = O.Prng(59 + group)
+    n = 3000
+    if group == 1:
+        pts, run, ops = g1_points(rng, 25), run_g1, O.FqOps
+    else:
+        pts, run, ops = g2_points(rng, 25), run_g2, O.Fq2Ops
+    bases = pts * (n // 25)
+    scalars = [rng.fr() if i % 97 == 0 else (3 if i % 5 == 0 else 1) for i in range(n)]
+    assert run(ctx, bases, scalars) == O.msm_naive(bases, scalars, ops)
+
+
 def test_fixed_base_and_resident_msm(ctx):
     """zk_fixed_base_* (setup-side) against k_i * G, then a resident-bases MSM with an offset."""
     rng = O.Prng(58)

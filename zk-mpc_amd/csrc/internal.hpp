@@ -76,6 +76,11 @@ int zk_msm_enqueue_accum(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st);
 int zk_msm_enqueue_reduce(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st);
 int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out_host_projective);
 
+// msm_sort.hip: rocPRIM radix sort of (bucket, table index) pairs for the merged bucket set
+size_t zk_sort_pairs_temp_bytes(size_t n, unsigned key_bits);
+int zk_sort_pairs(hipStream_t st, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                  const uint32_t* vals_in, uint32_t* vals_out, size_t n, unsigned key_bits);
+
 // msm_g2pair.hip: the G2 accumulate kernel with two lanes per point addition
 void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bases, const uint32_t* sorted, const void* desc,
                             const uint32_t* order, const uint32_t* ctr, uint32_t* sums);

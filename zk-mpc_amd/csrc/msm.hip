@@ -139,6 +139,59 @@ k_scatter(const uint32_t* dig, size_t n, uint32_t W, uint32_t NB, const uint32_t
     }
 }
 
+// ---- merged bucket set: sort by key instead of counting with atomics (msm_sort.hip) ----------------------------
+// key[w*n + i] = |d| - 1 (the bucket), or NB for a zero digit (sorts behind every bucket and is never read);
+// val[w*n + i] = table index | sign, the entry k_accum reads.
+__global__ void __launch_bounds__(256)
+k_digit_keys(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, uint32_t* key, uint32_t* val,
+             uint32_t n_tab, uint32_t tab_off) {
+    __shared__ uint32_t kw[9][256];
+    const uint32_t tid = threadIdx.x;
+    for (size_t i0 = blockIdx.x * (size_t)256; i0 < n; i0 += (size_t)gridDim.x * 256) {
+        size_t i = i0 + tid;
+        if (i < n) {
+            Fr s = fp_ext_to_canon<FrParams>(fr_load(scalars, i));
+            uint32_t w8[8];
+            fp_pack<FrParams>(w8, s);
+            uint32_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                uint64_t t = (uint64_t)(k < 8 ? w8[k] : 0u) + bias.w[k] + carry;
+                kw[k][tid] = (uint32_t)t;
+                carry = (uint32_t)(t >> 32);
+            }
+            for (uint32_t w = 0; w < W; w++) {
+                const uint32_t bit = wo.off[w], cw = wo.off[w + 1] - bit;
+                const uint32_t half = 1u << (cw - 1), mask = (1u << cw) - 1;
+                const uint32_t wi = bit >> 5, sh = bit & 31;
+                uint64_t two = kw[wi][tid];
+                if (wi + 1 < 9) two |= (uint64_t)kw[wi + 1][tid] << 32;
+                int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (int32_t)half;
+                uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+                key[(size_t)w * n + i] = mag ? mag - 1 : NB;
+                val[(size_t)w * n + i] = (uint32_t)(w * n_tab + tab_off + i) | (d < 0 ? 0x80000000u : 0u);
+            }
+        }
+    }
+}
+
+// offs[b] = first position of bucket b in the sorted keys, for every b <= NB (empty buckets get the next bucket's start;
+// offs[NB] = number of non-zero digits).  A thread at the first element of a run fills the offsets of its own bucket and of
+// the empty buckets just below it; the last thread fills what lies above the last key.
+__global__ void __launch_bounds__(256)
+k_offs_from_sorted(const uint32_t* __restrict__ skey, size_t total, uint32_t NB, uint32_t* __restrict__ offs) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t k = skey[t];
+        const uint32_t lo = t ? skey[t - 1] + 1 : 0u;          // keys are <= NB, so no wrap
+        for (uint32_t b = lo; b <= k; b++) offs[b] = (uint32_t)t;
+        if (t == total - 1)
+            for (uint32_t b = k + 1; b <= NB; b++) offs[b] = (uint32_t)total;
+    }
+}
+__global__ void __launch_bounds__(256) k_counts_from_offs(const uint32_t* __restrict__ offs, uint32_t NB, uint32_t* __restrict__ counts) {
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < NB; b += gridDim.x * blockDim.x) counts[b] = offs[b + 1] - offs[b];
+}
+
 // ---- segments -------------------------------------------------------------------------------
 // A bucket with cnt points is cut into max(1, ceil(cnt / SEG)) segments.  Single-segment buckets
 // write their sum straight to sums[key]; the segments of a split ("heavy") bucket write partial
@@ -648,25 +701,54 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
     job->timers.push_back(tm);
     tm->begin(g1 ? "msm_g1.sort" : "msm_g2.sort");
-    ZK_HIP(ctx, hipMemsetAsync(b.counts, 0, nbuck * 4, st));
     ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 4 + 3 * (size_t)(seg + 1)) * 4, st));
-    hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, b.counts, merged);
-    if (NB <= 65536) {
-        hipLaunchKernelGGL(k_scan, Wb, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NB, seg);
-    } else {
-        const uint32_t nchunks = (uint32_t)((NB + SCAN_CHUNK - 1) / SCAN_CHUNK);
-        if (nchunks > SCAN_T) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: bucket set too large for the two-level scan");
-        uint32_t* sums;
+    // merged bucket set: radix sort of (bucket, entry) pairs, no global atomics (msm_sort.hip); ZK_SORT_ATOMIC=1 keeps the
+    // counting sort.  Per-window bucket sets (tables without window multiples) always take the counting sort.
+    static const bool radix = !(getenv("ZK_SORT_ATOMIC") && atoi(getenv("ZK_SORT_ATOMIC")) != 0);
+    const bool use_radix = merged && radix;
+    auto scans = [&]() -> int {
+        if (NB <= 65536) {
+            hipLaunchKernelGGL(k_scan, Wb, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NB, seg);
+        } else {
+            const uint32_t nchunks = (uint32_t)((NB + SCAN_CHUNK - 1) / SCAN_CHUNK);
+            if (nchunks > SCAN_T) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: bucket set too large for the two-level scan");
+            uint32_t* sums;
+            char nm2[64];
+            snprintf(nm2, sizeof nm2, "msm_scan_sums.%d", job->slot);
+            ZK_TRY(zk_scratch(ctx, nm2, (size_t)Wb * nchunks * 8, (void**)&sums));
+            hipLaunchKernelGGL(k_scan_sums, Wb * nchunks, SCAN_T, 0, st, b.counts, (uint32_t)NB, seg, nchunks, sums);
+            hipLaunchKernelGGL(k_scan_tops, Wb, SCAN_T, 0, st, sums, nchunks);
+            hipLaunchKernelGGL(k_scan_fill, Wb * nchunks, SCAN_T, 0, st, b.counts, (const uint32_t*)sums, b.offs, b.seg_local, win_segs,
+                               (uint32_t)NB, seg, nchunks);
+        }
+        return ZK_OK;
+    };
+    if (use_radix) {
+        const size_t total = (size_t)W * n;
+        const unsigned key_bits = job->c;                      // keys are in [0, NB], NB = 2^(c-1)
+        uint32_t *vals, *skey;
+        void* tmp;
         char nm2[64];
-        snprintf(nm2, sizeof nm2, "msm_scan_sums.%d", job->slot);
-        ZK_TRY(zk_scratch(ctx, nm2, (size_t)Wb * nchunks * 8, (void**)&sums));
-        hipLaunchKernelGGL(k_scan_sums, Wb * nchunks, SCAN_T, 0, st, b.counts, (uint32_t)NB, seg, nchunks, sums);
-        hipLaunchKernelGGL(k_scan_tops, Wb, SCAN_T, 0, st, sums, nchunks);
-        hipLaunchKernelGGL(k_scan_fill, Wb * nchunks, SCAN_T, 0, st, b.counts, (const uint32_t*)sums, b.offs, b.seg_local, win_segs, (uint32_t)NB,
-                           seg, nchunks);
+        snprintf(nm2, sizeof nm2, "msm_vals.%d", job->slot);
+        ZK_TRY(zk_scratch(ctx, nm2, total * 4, (void**)&vals));
+        snprintf(nm2, sizeof nm2, "msm_skey.%d", job->slot);
+        ZK_TRY(zk_scratch(ctx, nm2, total * 4, (void**)&skey));
+        const size_t tmp_bytes = zk_sort_pairs_temp_bytes(total, key_bits);
+        snprintf(nm2, sizeof nm2, "msm_sorttmp.%d", job->slot);
+        ZK_TRY(zk_scratch(ctx, nm2, tmp_bytes, &tmp));
+        hipLaunchKernelGGL(k_digit_keys, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, vals, job->n_tab, job->tab_off);
+        if (zk_sort_pairs(st, tmp, tmp_bytes, b.dig, skey, vals, b.sorted, total, key_bits) != 0)
+            ZK_FAIL(ctx, ZK_ERR_HIP, "msm: radix sort failed");
+        hipLaunchKernelGGL(k_offs_from_sorted, zk_grid(total, 256), 256, 0, st, (const uint32_t*)skey, total, NB, b.offs);
+        hipLaunchKernelGGL(k_counts_from_offs, zk_grid(NB, 256), 256, 0, st, (const uint32_t*)b.offs, NB, b.counts);
+        ZK_TRY(scans());                                       // rewrites offs (same values) and produces the segment counts
+    } else {
+        ZK_HIP(ctx, hipMemsetAsync(b.counts, 0, nbuck * 4, st));
+        hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, b.counts, merged);
+        ZK_TRY(scans());
+        hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted, merged,
+                           job->n_tab, job->tab_off);
     }
-    hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted, merged,
-                       job->n_tab, job->tab_off);
     hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
                        merged ? (size_t)0 : n, Wb, NB, seg, b.desc, b.heavy, ctr, hist);
     hipLaunchKernelGGL(k_len_scan, 1, 512, 0, st, hist, bin_start, bin_cursor, seg);
