@@ -561,6 +561,8 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         ZK_HIP(ctx, hipEventRecord(e1, ctx->stream));
         static const bool gate = !(getenv("ZK_WM_GATE") && atoi(getenv("ZK_WM_GATE")) == 0);
         if (gate) ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e1, 0));
+        static const bool h_counting = getenv("ZK_H_SORT_ATOMIC") && atoi(getenv("ZK_H_SORT_ATOMIC")) != 0;
+        J[4]->counting_sort = h_counting ? 1 : 0;
         rc = zk_msm_enqueue_sort(ctx, J[4], ctx->stream, nullptr);
     }
     // L's sort after the witness map (it is not needed before the fourth accumulate kernel)

@@ -14,6 +14,9 @@
 //   3. k_scatter  : counting sort of (point index, sign) by bucket.  Order inside a bucket is
 //                   whatever the atomics give: the group is commutative and the result is reduced
 //                   to its canonical affine form, so the output bits do not depend on it.
+//   1-3 for a table with window multiples (ONE bucket set for all digits): k_digit_keys writes (bucket, entry)
+//                   pairs, rocPRIM's radix sort orders them (msm_sort.hip), k_offs_from_sorted reads the
+//                   bucket boundaries off the sorted keys -- no global atomics at all.
 //   4. k_accum    : one thread per bucket: gather its points (96 B / 192 B random reads), mixed
 //                   XYZZ additions (8M+2S in Fq / Fq2).  This is the dominant kernel; it is bound by
 //                   the integer ALU (v_mad_u64_u32), not by HBM.
@@ -705,7 +708,7 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     // merged bucket set: radix sort of (bucket, entry) pairs, no global atomics (msm_sort.hip); ZK_SORT_ATOMIC=1 keeps the
     // counting sort.  Per-window bucket sets (tables without window multiples) always take the counting sort.
     static const bool radix = !(getenv("ZK_SORT_ATOMIC") && atoi(getenv("ZK_SORT_ATOMIC")) != 0);
-    const bool use_radix = merged && radix;
+    const bool use_radix = merged && radix && !job->counting_sort;
     auto scans = [&]() -> int {
         if (NB <= 65536) {
             hipLaunchKernelGGL(k_scan, Wb, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NB, seg);
