@@ -142,12 +142,14 @@ k_scatter(const uint32_t* dig, size_t n, uint32_t W, uint32_t NB, const uint32_t
     }
 }
 
-// ---- merged bucket set: sort by key instead of counting with atomics (msm_sort.hip) ----------------------------
-// key[w*n + i] = |d| - 1 (the bucket), or NB for a zero digit (sorts behind every bucket and is never read);
-// val[w*n + i] = table index | sign, the entry k_accum reads.
+// ---- sort by key instead of counting with atomics (msm_sort.hip) ------------------------------------------------
+// key[w*n + i] = the bucket of digit w of scalar i, or `none` for a zero digit (sorts behind every bucket and is never
+// read); val[w*n + i] = entry | sign, what k_accum reads.
+// merged: one bucket set, the entry is the table index of the window multiple.  Otherwise window w owns the buckets
+// [w*NB, (w+1)*NB) and the entry is the index of the base; `none` (the key of a zero digit) is the total bucket count.
 __global__ void __launch_bounds__(256)
 k_digit_keys(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, uint32_t* key, uint32_t* val,
-             uint32_t n_tab, uint32_t tab_off) {
+             int merged, uint32_t none, uint32_t n_tab, uint32_t tab_off) {
     __shared__ uint32_t kw[9][256];
     const uint32_t tid = threadIdx.x;
     for (size_t i0 = blockIdx.x * (size_t)256; i0 < n; i0 += (size_t)gridDim.x * 256) {
@@ -171,8 +173,8 @@ k_digit_keys(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, 
                 if (wi + 1 < 9) two |= (uint64_t)kw[wi + 1][tid] << 32;
                 int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (int32_t)half;
                 uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-                key[(size_t)w * n + i] = mag ? mag - 1 : NB;
-                val[(size_t)w * n + i] = (uint32_t)(w * n_tab + tab_off + i) | (d < 0 ? 0x80000000u : 0u);
+                key[(size_t)w * n + i] = mag ? (merged ? 0u : w * NB) + mag - 1 : none;
+                val[(size_t)w * n + i] = (merged ? (uint32_t)(w * n_tab + tab_off + i) : (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
             }
         }
     }
@@ -708,27 +710,32 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     // merged bucket set: radix sort of (bucket, entry) pairs, no global atomics (msm_sort.hip); ZK_SORT_ATOMIC=1 keeps the
     // counting sort.  Per-window bucket sets (tables without window multiples) always take the counting sort.
     static const bool radix = !(getenv("ZK_SORT_ATOMIC") && atoi(getenv("ZK_SORT_ATOMIC")) != 0);
-    const bool use_radix = merged && radix && !job->counting_sort;
-    auto scans = [&]() -> int {
-        if (NB <= 65536) {
-            hipLaunchKernelGGL(k_scan, Wb, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NB, seg);
+    // Radix sort of (bucket, entry) pairs, no global atomics (msm_sort.hip), for every MSM with at least 2^16 digits; the sort
+    // then sees ONE set of Wb*NB buckets (bucket ids w*NB + b, as the reduce phase numbers them).  Small MSMs keep the
+    // counting sort with per-window offsets.  ZK_SORT_ATOMIC=1 forces the counting sort.
+    const bool use_radix = radix && !job->counting_sort && (size_t)W * n >= 65536;
+    auto scans = [&](uint32_t Wx, uint32_t NBx) -> int {
+        if (NBx <= 65536) {
+            hipLaunchKernelGGL(k_scan, Wx, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NBx, seg);
         } else {
-            const uint32_t nchunks = (uint32_t)((NB + SCAN_CHUNK - 1) / SCAN_CHUNK);
+            const uint32_t nchunks = (uint32_t)((NBx + SCAN_CHUNK - 1) / SCAN_CHUNK);
             if (nchunks > SCAN_T) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: bucket set too large for the two-level scan");
             uint32_t* sums;
             char nm2[64];
             snprintf(nm2, sizeof nm2, "msm_scan_sums.%d", job->slot);
-            ZK_TRY(zk_scratch(ctx, nm2, (size_t)Wb * nchunks * 8, (void**)&sums));
-            hipLaunchKernelGGL(k_scan_sums, Wb * nchunks, SCAN_T, 0, st, b.counts, (uint32_t)NB, seg, nchunks, sums);
-            hipLaunchKernelGGL(k_scan_tops, Wb, SCAN_T, 0, st, sums, nchunks);
-            hipLaunchKernelGGL(k_scan_fill, Wb * nchunks, SCAN_T, 0, st, b.counts, (const uint32_t*)sums, b.offs, b.seg_local, win_segs,
-                               (uint32_t)NB, seg, nchunks);
+            ZK_TRY(zk_scratch(ctx, nm2, (size_t)Wx * nchunks * 8, (void**)&sums));
+            hipLaunchKernelGGL(k_scan_sums, Wx * nchunks, SCAN_T, 0, st, b.counts, NBx, seg, nchunks, sums);
+            hipLaunchKernelGGL(k_scan_tops, Wx, SCAN_T, 0, st, sums, nchunks);
+            hipLaunchKernelGGL(k_scan_fill, Wx * nchunks, SCAN_T, 0, st, b.counts, (const uint32_t*)sums, b.offs, b.seg_local, win_segs,
+                               NBx, seg, nchunks);
         }
         return ZK_OK;
     };
     if (use_radix) {
         const size_t total = (size_t)W * n;
-        const unsigned key_bits = job->c;                      // keys are in [0, NB], NB = 2^(c-1)
+        const uint32_t NBt = (uint32_t)nbuck;                  // all buckets as one set; a zero digit gets the key NBt
+        unsigned key_bits = 1;
+        while (((uint64_t)1 << key_bits) <= NBt) key_bits++;
         uint32_t *vals, *skey;
         void* tmp;
         char nm2[64];
@@ -739,21 +746,24 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
         const size_t tmp_bytes = zk_sort_pairs_temp_bytes(total, key_bits);
         snprintf(nm2, sizeof nm2, "msm_sorttmp.%d", job->slot);
         ZK_TRY(zk_scratch(ctx, nm2, tmp_bytes, &tmp));
-        hipLaunchKernelGGL(k_digit_keys, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, vals, job->n_tab, job->tab_off);
+        hipLaunchKernelGGL(k_digit_keys, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, vals, merged, NBt,
+                           job->n_tab, job->tab_off);
         if (zk_sort_pairs(st, tmp, tmp_bytes, b.dig, skey, vals, b.sorted, total, key_bits) != 0)
             ZK_FAIL(ctx, ZK_ERR_HIP, "msm: radix sort failed");
-        hipLaunchKernelGGL(k_offs_from_sorted, zk_grid(total, 256), 256, 0, st, (const uint32_t*)skey, total, NB, b.offs);
-        hipLaunchKernelGGL(k_counts_from_offs, zk_grid(NB, 256), 256, 0, st, (const uint32_t*)b.offs, NB, b.counts);
-        ZK_TRY(scans());                                       // rewrites offs (same values) and produces the segment counts
+        hipLaunchKernelGGL(k_offs_from_sorted, zk_grid(total, 256), 256, 0, st, (const uint32_t*)skey, total, NBt, b.offs);
+        hipLaunchKernelGGL(k_counts_from_offs, zk_grid(NBt, 256), 256, 0, st, (const uint32_t*)b.offs, NBt, b.counts);
+        ZK_TRY(scans(1, NBt));                                 // rewrites offs (same values) and produces the segment counts
+        hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
+                           (size_t)0, 1u, NBt, seg, b.desc, b.heavy, ctr, hist);
     } else {
         ZK_HIP(ctx, hipMemsetAsync(b.counts, 0, nbuck * 4, st));
         hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, b.counts, merged);
-        ZK_TRY(scans());
+        ZK_TRY(scans(Wb, NB));
         hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted, merged,
                            job->n_tab, job->tab_off);
+        hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
+                           merged ? (size_t)0 : n, Wb, NB, seg, b.desc, b.heavy, ctr, hist);
     }
-    hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
-                       merged ? (size_t)0 : n, Wb, NB, seg, b.desc, b.heavy, ctr, hist);
     hipLaunchKernelGGL(k_len_scan, 1, 512, 0, st, hist, bin_start, bin_cursor, seg);
     hipLaunchKernelGGL(k_order, 512, 256, (seg + 1) * 4, st, b.desc, ctr, bin_cursor, seg, b.order);
     ZK_HIP(ctx, hipGetLastError());

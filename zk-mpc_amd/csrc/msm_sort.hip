@@ -1,10 +1,10 @@
-// msm_sort.hip -- the key sort of the MSM's bucket sort (merged bucket set: resident tables with window multiples).
+// msm_sort.hip -- the key sort of the MSM's bucket sort.
 //
 // Step of VariableBaseMSM::multi_scalar_mul (arkworks/algebra/ec/src/msm/variable_base.rs:47-76: "for each scalar, add the
 // base to bucket[digit - 1]") restated as a sort of (bucket, table index) pairs, so that one lane can own one bucket.
 //
 // msm.hip's counting sort (histogram with one atomicAdd per digit, scatter with one returning atomicSub per digit) is kept
-// for per-window bucket sets.  For the merged set (13 digits per scalar into 2^19 buckets at n = 2^20: 13.6 M pairs) its
+// for small MSMs.  For a 2^20-scalar MSM over a table with window multiples (13 digits per scalar into 2^19 buckets at n = 2^20: 13.6 M pairs) its
 // 27 M device-scope atomics execute at the memory side, take 1.26 ms and slow whatever runs beside them (the witness map's
 // first transform pass: 0.6 ms instead of 0.09).  rocPRIM's LSD radix sort (block-local LDS ranking, no global atomics)
 // sorts the same pairs on c key bits in 0.40 ms (tools/ubench_radix.hip: 34 G pairs/s).  This file only wraps that call:
