@@ -230,6 +230,11 @@ int zk_groth16_witness_map_post_dev(zk_ctx* ctx, const zk_r1cs* r1cs, void* ab_d
 /* The five MSMs of create_proof (src/groth16.rs:106,110,137,148,160) on a resident key:
  * out = [h_acc, l_aux_acc, a_acc, b_g1_acc] and b_g2_acc; z_dev as above, h_dev from witness_map.
  * (For shares these are the party-local MSMs of multi_scale_pub_group, share/additive.rs:517-520.) */
+/* Optional, for a prover that works through a queue of assignments (same key, same constraint system): announce the
+ * assignment of the NEXT zk_groth16_prove_dev call.  The proof in between then enqueues that proof's front (sort of z,
+ * witness map, sort of h) behind its own kernels, where it runs under the reduce tail and the host time between two
+ * proofs.  z_next_dev must stay unchanged until that proof is done; NULL withdraws; a different next call simply drops it. */
+int zk_groth16_hint_next_dev(zk_ctx* ctx, const void* z_next_dev);
 /* Optional: enqueue the sort of z[1..] that four of those MSMs share, ahead of zk_groth16_msms_dev on the same z_dev
  * (asynchronous; z_dev must stay unchanged).  The collaborative prover calls it before the Beaver open of
  * mpc-algebra/src/share/field.rs:97-129 so that the sort runs during the exchange.  Dropped if another MSM batch or a

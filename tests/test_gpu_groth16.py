@@ -182,3 +182,43 @@ def test_many_public_inputs_with_window_multiples(ctx):
     cr = OC.R1cs(ni, nw, A, B, Cm)
     assert proof == OC.groth16_predict(cr, np.stack(td), zarr, OC.witness_map(cr, zarr), rr, ss)
     pk.free()
+
+
+def test_hint_next_front_prefetch(ctx):
+    """zk_groth16_hint_next_dev: a proof enqueues the announced next proof's front (z-sort, witness map, H-sort) behind its
+    own kernels.  Proof bytes must not change: a queue of three different assignments proved with hints equals the same
+    queue without; a hint that does not come true (another assignment follows) is dropped; a hint followed by a batch MSM
+    on the same context is dropped too."""
+    n = (1 << 16) + 50
+    rng = O.Prng(4711)
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    td = [mont(rng.fr()) for _ in range(7)]
+    dr = ctx.r1cs_mul_chain(n)
+    pk = ctx.groth16_setup(dr, *td)
+    zs = [ctx.mul_chain_assignment_dev(n, mont(rng.fr()), mont(rng.fr())) for _ in range(3)]
+    rs = [(mont(rng.fr()), mont(rng.fr())) for _ in range(3)]
+    plain = [ctx.create_proof_dev(pk, dr, z.ptr, r, s) for z, (r, s) in zip(zs, rs)]
+    assert len(set(plain)) == 3
+    hinted = []
+    for k in range(3):
+        ctx.groth16_hint_next_dev(zs[k + 1].ptr if k + 1 < 3 else None)
+        hinted.append(ctx.create_proof_dev(pk, dr, zs[k].ptr, *rs[k]))
+    assert hinted == plain
+    # the announced assignment does not follow
+    ctx.groth16_hint_next_dev(zs[2].ptr)
+    assert ctx.create_proof_dev(pk, dr, zs[0].ptr, *rs[0]) == plain[0]
+    assert ctx.create_proof_dev(pk, dr, zs[1].ptr, *rs[1]) == plain[1]
+    # a front in flight and then other work on the MSM scratch
+    ctx.groth16_hint_next_dev(zs[1].ptr)
+    assert ctx.create_proof_dev(pk, dr, zs[0].ptr, *rs[0]) == plain[0]
+    q = pk.query_bases("a_query")
+    one = ctx.msm_batch_dev([(q, 1, zs[2].ptr + 32, n + 2)])[0]
+    assert cv.g1_projective_to_affine(one) == cv.g1_projective_to_affine(ctx.msm_dev(q, 1, zs[2].ptr + 32, n + 2))
+    assert ctx.create_proof_dev(pk, dr, zs[1].ptr, *rs[1]) == plain[1]
+    # steady state: the same assignment announced again and again
+    for _ in range(3):
+        ctx.groth16_hint_next_dev(zs[2].ptr)
+        assert ctx.create_proof_dev(pk, dr, zs[2].ptr, *rs[2]) == plain[2]
+    ctx.groth16_hint_next_dev(None)
+    assert ctx.create_proof_dev(pk, dr, zs[2].ptr, *rs[2]) == plain[2]
+    pk.free()

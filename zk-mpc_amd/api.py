@@ -503,6 +503,10 @@ class Context:
     def witness_map_post_dev(self, r1cs, ab, c):
         self._ck(self.lib.zk_groth16_witness_map_post_dev(self.h, r1cs.h, C.c_void_p(int(ab)), C.c_void_p(int(c))))
 
+    def groth16_hint_next_dev(self, z_next_dev):
+        """Announce the assignment of the next create_proof_dev call (same key and constraint system); None withdraws."""
+        self._ck(self.lib.zk_groth16_hint_next_dev(self.h, C.c_void_p(int(z_next_dev)) if z_next_dev else None))
+
     def groth16_msms_presort_dev(self, pk: "ProvingKey", r1cs: "R1cs", z_dev):
         """Enqueue the shared sort of z[1..] ahead of groth16_msms_dev on the same z_dev (asynchronous)."""
         self._ck(self.lib.zk_groth16_msms_presort_dev(self.h, pk.h, r1cs.h, C.c_void_p(int(z_dev))))

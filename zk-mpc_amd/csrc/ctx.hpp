@@ -36,6 +36,7 @@ struct zk_ctx {
     std::map<std::string, int> flags;         // one-time per-context setup markers
     void* comm = nullptr;                     // RCCL communicator of this party (comm.hip), created by zk_comm_init
     void* presort = nullptr;                  // groth16.hip: a sort of z[1..] enqueued ahead of zk_groth16_msms_dev (ZkPresort)
+    const void* next_z = nullptr;             // groth16.hip: zk_groth16_hint_next_dev
     std::mutex mu;
     // timing of the most recent instrumented call (ms), filled when ZK_PROFILE env or explicit request
     struct Timer { float ms = 0; int count = 0; };

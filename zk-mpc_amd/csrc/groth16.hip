@@ -484,12 +484,25 @@ struct ZkPresort {
     ZkMsmJob job;
     const zk_pk* pk = nullptr;
     const void* z = nullptr;
+    // the whole FRONT of the next local proof (zk_groth16_hint_next_dev): besides the sort of z also its witness map and
+    // the H job's sort, enqueued behind the current proof's last kernels so that they run under its reduce tail and the
+    // host time between two proofs
+    bool front = false;
+    const zk_r1cs* r = nullptr;
+    void* h = nullptr;                 // where the witness map put h
+    ZkMsmJob jobh;
+    hipEvent_t wm_done = nullptr;
+    ~ZkPresort() { if (wm_done) (void)hipEventDestroy(wm_done); }
 };
 void zk_presort_free(zk_ctx* ctx) {
     if (!ctx || !ctx->presort) return;
     ZkPresort* p = (ZkPresort*)ctx->presort;
     ctx->presort = nullptr;
     if (ctx->aux.size()) (void)hipStreamSynchronize(ctx->aux[0]);   // its kernels write the job's scratch slot
+    if (p->front) {                                                 // the front runs on the accumulate and context streams
+        if (ctx->acc_stream) (void)hipStreamSynchronize(ctx->acc_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     delete p;
 }
 
@@ -525,7 +538,6 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e0, 0));
     ZkMsmJob own[5];  // 0: B in G2, 1: A, 2: B in G1, 3: L, 4: H
     ZkMsmJob* J[5] = {&own[0], &own[1], &own[2], &own[3], &own[4]};
     // the sort of z[1..] may already be running (zk_groth16_msms_presort_dev, enqueued by the collaborative prover before
@@ -534,7 +546,18 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     ctx->presort = nullptr;
     std::unique_ptr<ZkPresort> pre_owner(pre);
     const bool presorted = pre && pre->pk == pk && pre->z == z && pre->job.n == nvars;
+    const bool fronted = presorted && pre->front && !h_in && pre->r == r && pre->h == h_scratch;
+    if (pre && !presorted) {                       // a front / sort for other inputs: let it drain before its scratch is reused
+        pre_owner.release();
+        ctx->presort = pre;
+        zk_presort_free(ctx);
+        pre = nullptr;
+    }
     if (presorted) J[0] = &pre->job;
+    if (fronted) J[4] = &pre->jobh;
+    // z was produced on the context stream.  (With a front that stream already carries this proof's witness map and H-sort:
+    // waiting for it here would hold the sort stream -- and the G2 reduce chain on it -- until the H-sort is through.)
+    if (!fronted) ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e0, 0));
     int rc = presorted ? ZK_OK : zk_msm_prepare(ctx, J[0], pk->b_g2, 1, zb + 32, nvars, 1);                 // src/groth16.rs:160 (query[1..])
     if (rc == ZK_OK) rc = zk_msm_prepare(ctx, J[1], pk->a, 1, zb + 32, nvars, 2);              // :137
     if (rc == ZK_OK) rc = zk_msm_prepare(ctx, J[2], pk->b_g1, 1, zb + 32, nvars, 3);           // :148
@@ -549,21 +572,27 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     if (rc == ZK_OK && l_shared) rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, J[0]);
     const void* h = h_in;
     ZkPhaseTimer tm(ctx);
-    if (rc == ZK_OK && !h_in) {
-        tm.begin("witness_map");
-        rc = zk_groth16_witness_map_dev(ctx, r, z, h_scratch);
-        tm.end();
+    static const bool gate = !(getenv("ZK_WM_GATE") && atoi(getenv("ZK_WM_GATE")) == 0);
+    static const bool h_counting = getenv("ZK_H_SORT_ATOMIC") && atoi(getenv("ZK_H_SORT_ATOMIC")) != 0;
+    if (fronted) {
+        // witness map and H's sort were enqueued with the previous proof (enqueue_front below)
         h = h_scratch;
-    }
-    // h_acc: min(len) rule (variable_base.rs:15-17): h_query has D-1 entries, h has D
-    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, J[4], pk->h, 0, h, std::min(pk->h->n, D), 5);   // :106
-    if (rc == ZK_OK) {
-        ZK_HIP(ctx, hipEventRecord(e1, ctx->stream));
-        static const bool gate = !(getenv("ZK_WM_GATE") && atoi(getenv("ZK_WM_GATE")) == 0);
-        if (gate) ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e1, 0));
-        static const bool h_counting = getenv("ZK_H_SORT_ATOMIC") && atoi(getenv("ZK_H_SORT_ATOMIC")) != 0;
-        J[4]->counting_sort = h_counting ? 1 : 0;
-        rc = zk_msm_enqueue_sort(ctx, J[4], ctx->stream, nullptr);
+        if (gate) ZK_HIP(ctx, hipStreamWaitEvent(s_acc, pre->wm_done, 0));
+    } else {
+        if (rc == ZK_OK && !h_in) {
+            tm.begin("witness_map");
+            rc = zk_groth16_witness_map_dev(ctx, r, z, h_scratch);
+            tm.end();
+            h = h_scratch;
+        }
+        // h_acc: min(len) rule (variable_base.rs:15-17): h_query has D-1 entries, h has D
+        if (rc == ZK_OK) rc = zk_msm_prepare(ctx, J[4], pk->h, 0, h, std::min(pk->h->n, D), 5);   // :106
+        if (rc == ZK_OK) {
+            ZK_HIP(ctx, hipEventRecord(e1, ctx->stream));
+            if (gate) ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e1, 0));
+            J[4]->counting_sort = h_counting ? 1 : 0;
+            rc = zk_msm_enqueue_sort(ctx, J[4], ctx->stream, nullptr);
+        }
     }
     // L's sort after the witness map (it is not needed before the fourth accumulate kernel)
     if (rc == ZK_OK && !l_shared) {
@@ -588,6 +617,34 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     static const int alt = getenv("ZK_REDUCE_ALT") ? atoi(getenv("ZK_REDUCE_ALT")) : 2;   // 0: all on main, 1: last on sort, 2: every other one
     for (int k = 0; k < 5 && rc == ZK_OK; k++)
         rc = zk_msm_enqueue_reduce(ctx, J[ord[k]], (ord[k] == 0 || (alt == 1 && k == 4) || (alt == 2 && (k & 1) == 0)) ? s_red : ctx->stream);
+    // The caller announced the next assignment (zk_groth16_hint_next_dev): enqueue that proof's front now, behind this
+    // proof's kernels.  Its z-sort goes on the accumulate stream (in order behind the five accumulate kernels, the readers of
+    // this proof's sort products; it also waits for the reduce chains, whose fold kernels read the segment tables), its
+    // witness map and H-sort on the context stream (behind this proof's H-sort and reduce chains; the H-sort also waits for
+    // the last accumulate kernel, the reader of the H job's sort products).  No buffer is doubled: stream order and these
+    // events keep every reader in front of the next writer.
+    bool front_enqueued = false;
+    if (rc == ZK_OK && ctx->next_z && !h_in && l_shared) {
+        const void* zn = ctx->next_z;
+        ctx->next_z = nullptr;
+        std::unique_ptr<ZkPresort> nf(new ZkPresort());
+        nf->pk = pk; nf->z = zn; nf->r = r; nf->h = h_scratch; nf->front = true;
+        for (int k = 0; k < 4; k++)
+            if (J[k]->reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(s_acc, J[k]->reduce_done, 0));
+        rc = zk_msm_prepare(ctx, &nf->job, pk->b_g2, 1, (const char*)zn + 32, nvars, 1);
+        if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &nf->job, s_acc, nullptr);
+        if (rc == ZK_OK) rc = zk_groth16_witness_map_dev(ctx, r, zn, h_scratch);
+        if (rc == ZK_OK) {
+            ZK_HIP(ctx, hipEventCreateWithFlags(&nf->wm_done, hipEventDisableTiming));
+            ZK_HIP(ctx, hipEventRecord(nf->wm_done, ctx->stream));
+            if (J[4]->accum_done) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, J[4]->accum_done, 0));
+            rc = zk_msm_prepare(ctx, &nf->jobh, pk->h, 0, h_scratch, std::min(pk->h->n, D), 5);
+            nf->jobh.counting_sort = h_counting ? 1 : 0;
+            if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &nf->jobh, ctx->stream, nullptr);
+        }
+        if (rc == ZK_OK) { ctx->presort = nf.release(); front_enqueued = true; }
+    }
+    ctx->next_z = nullptr;
     // finish in completion order: the host-side Horner of an early job overlaps the GPU work of the later ones
     void* outs[5] = {out_g2, &out_g1[2], &out_g1[3], &out_g1[1], &out_g1[0]};
     int abc_left = 3;
@@ -595,10 +652,12 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         rc = zk_msm_finish(ctx, J[ord[k]], outs[ord[k]]);
         if (ord[k] <= 2 && --abc_left == 0 && rc == ZK_OK && after_abc) after_abc();   // A, B1, B2 are in: the caller's host work overlaps the rest
     }
-    (void)hipStreamSynchronize(s_sort);
-    (void)hipStreamSynchronize(s_acc);
-    (void)hipStreamSynchronize(s_red);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (!front_enqueued) {                         // (with a front in flight the streams carry the next proof's kernels)
+        (void)hipStreamSynchronize(s_sort);
+        (void)hipStreamSynchronize(s_acc);
+        (void)hipStreamSynchronize(s_red);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     tm.resolve();
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -656,6 +715,14 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
     (void)hipStreamSynchronize(s_acc);
     (void)hipEventDestroy(e0);
     return rc;
+}
+
+// The next zk_groth16_prove_dev on this context will be for `z_next_dev` (same key, same constraint system): the proof
+// in between enqueues that proof's front (z-sort, witness map, H-sort) behind its own kernels.  Pass NULL to withdraw.
+extern "C" int zk_groth16_hint_next_dev(zk_ctx* ctx, const void* z_next_dev) {
+    if (!ctx) return ZK_ERR_ARG;
+    ctx->next_z = z_next_dev;
+    return ZK_OK;
 }
 
 extern "C" int zk_groth16_msms_presort_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z) {
