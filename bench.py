@@ -309,6 +309,21 @@ def main():
                     "note": "kernel is integer-ALU bound, not HBM bound (SURVEY 8d); see int_alu",
                     "int_alu": {"achieved": round(mads / avg_s / 1e12, 3), "peak": round(INT_MAD_PEAK / 1e12, 2),
                                 "unit": "T v_mad_u64_u32 lane-ops/s", "frac": round(mads / avg_s / INT_MAD_PEAK, 4)}}
+            try:  # VALU issue utilisation from the committed rocprofv3 PMC passes (tools/pmc_valu.py), not measured live
+                pv = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_valu.json")))["kernels"]
+                roof["valu_issue"] = {
+                    "note": "SQ_INSTS_VALU per launch / kernel duration (kernel alone on the chip, under counter collection) vs the "
+                            "measured integer issue peak of 32.16 T lane-ops/s = 0.5025 T wave-instructions/s: both accumulate "
+                            "kernels fill every VALU issue slot; what int_alu reports below 1 is the share of v_mad_u64_u32 in "
+                            "their instruction mix",
+                    "k_accum<G1>": {"wave_insts_per_launch": round(pv["k_accum<G1>"]["SQ_INSTS_VALU"]),
+                                    "frac_of_issue_peak": round(pv["k_accum<G1>"]["frac_of_int_issue_peak"], 4),
+                                    "mean_waves_per_cu": round(pv["k_accum<G1>"]["MeanOccupancyPerCU"], 2)},
+                    "k_accum_g2pair": {"wave_insts_per_launch": round(pv["k_accum_g2pair<2>"]["SQ_INSTS_VALU"]),
+                                       "frac_of_issue_peak": round(pv["k_accum_g2pair<2>"]["frac_of_int_issue_peak"], 4),
+                                       "mean_waves_per_cu": round(pv["k_accum_g2pair<2>"]["MeanOccupancyPerCU"], 2)}}
+            except Exception:
+                pass
             # the single longest kernel: the G2 accumulate on lane pairs (one launch per proof); every one of its 10 Fq2
             # products per mixed addition is two fused double products of 507 mads
             g2_ms, g2_cnt = timers.get("msm_g2.accum", (0.0, 0))
