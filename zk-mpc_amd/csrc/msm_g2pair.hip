@@ -13,8 +13,10 @@
 //       even: a0 b0 + (-5 a1) b1      odd: a1 b0 + a0 b1
 //     the partner's limbs arrive by DPP quad_perm [1,0,3,2] (13 v_mov_dpp per operand, no LDS);
 //   * zero tests OR the limbs and exchange one word.
-// Per lane this is half the live state (two waves per SIMD) and half the code (the loop body fits the instruction cache);
-// the total number of v_mad_u64_u32 per addition is unchanged (10 x 1 014; squarings cost a product here).
+// Per lane this is half the live state (256 registers: two waves per SIMD, no spills) and half the code; the number of
+// v_mad_u64_u32 per addition is about the same (10 x 1 014; a squaring costs a product here).  By the hardware counters the
+// kernel issues a VALU instruction in every cycle (profiles/r1_pmc_valu.json): 17 350 instructions per addition, 62 % of them
+// 64-bit multiply-adds.
 // A pair shares its control flow (all branch conditions are pair-wide), so the partner lane is always active.
 #include "devutil.cuh"
 #include "../../include/zkmpc_hip.h"
@@ -117,10 +119,10 @@ __device__ __forceinline__ AffP aff_load_p(const uint32_t* bases, size_t i, uint
     return AffP{fq_load16(w), fq_load16(w + 2 * FW)};
 }
 
-// MODE 2: at most 256 registers, two waves per SIMD.  MODE 1: no constraint.  MODE 0: one wave per SIMD AND 192 registers
-// per lane left free (the clobber of a63 makes the kernel own 256 + 64 registers), so that kernels of other streams
-// (the witness map's transforms, the other jobs' sorts) find room on every SIMD beside it instead of waiting for
-// a block of this kernel to retire.
+// MODE 2 (the product): 256 registers, two waves per SIMD, no spills.  MODE 0 (experiment, ZK_G2PAIR_WAVES=0): one wave per
+// SIMD AND 192 registers per lane left free -- the clobber of a63 makes the kernel own 256 + 64 registers -- so that kernels
+// of other streams find room on every SIMD beside it instead of waiting for a block of this kernel to retire; measured
+// slower (7.7 vs 7.2 ms alone, 21.3 vs 20.8 ms per proof).
 template <int MODE>
 __global__ void __launch_bounds__(256, (MODE == 2 ? 2 : 1))
 k_accum_g2pair(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
@@ -294,16 +296,13 @@ k_bitsum_g2pair(const uint32_t* S_in, const uint32_t* W_in, uint32_t* out, uint3
 
 }  // namespace
 
-// One pair of lanes per segment: `segments` logical threads.  WAVES = 2 caps the kernel at 256 VGPRs (two waves per SIMD) at
-// the price of 24 spilled registers; ZK_G2PAIR_WAVES=1 selects the unconstrained build (279 registers, one wave) for comparison.
+// One pair of lanes per segment: `segments` logical threads.
 void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bases, const uint32_t* sorted, const void* desc,
                             const uint32_t* order, const uint32_t* ctr, uint32_t* sums) {
     static const int waves = getenv("ZK_G2PAIR_WAVES") ? atoi(getenv("ZK_G2PAIR_WAVES")) : 2;
     const unsigned blocks = (unsigned)((segments + 127) / 128);
     if (waves == 0)
         hipLaunchKernelGGL(k_accum_g2pair<0>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
-    else if (waves == 1)
-        hipLaunchKernelGGL(k_accum_g2pair<1>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
     else
         hipLaunchKernelGGL(k_accum_g2pair<2>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
 }
