@@ -53,17 +53,20 @@ __device__ __forceinline__ uint32_t limbs_or(const Fq& a) {
     return o;
 }
 
-// A left operand made ready for products: a = own component, r = what the partner contributes
-// (even lane: -5 * a1, odd lane: a0).  Prepared once per distinct left operand.
-struct Left { Fq a, r; };
+// A left operand made ready for products, prepared once per distinct left operand: (p, q) such that the product with
+// b = (b0, b1) is p * (own b) + q * (partner's b) on BOTH lanes --
+//   even lane: p = a0, q = -5 a1  ->  a0 b0 + (-5 a1) b1        odd lane: p = a0, q = a1  ->  a0 b1 + a1 b0.
+// The lane-dependent selects are paid here, not in every product.
+struct Left { Fq p, q; };
 
 __device__ __forceinline__ Left prep(const Fq& a, bool odd) {
     Fq m5 = fp_neg5_almost<FqParams>(a);   // -5 a, almost reduced: only ever the c operand of fp_mul2
-    return Left{a, xchg(sel(odd, m5, a))};
+    Fq r = xchg(sel(odd, m5, a));          // even receives -5 a1, odd receives a0
+    return Left{sel(odd, r, a), sel(odd, a, r)};
 }
 __device__ __forceinline__ Fq mulp(const Left& A, const Fq& b, bool odd) {
-    Fq ob = xchg(b);
-    return fp_mul2<FqParams>(A.a, sel(odd, ob, b), A.r, sel(odd, b, ob));
+    (void)odd;
+    return fp_mul2<FqParams>(A.p, b, A.q, xchg(b));
 }
 
 struct AffP { Fq x, y; };
