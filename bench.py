@@ -14,6 +14,10 @@ N > 1: N-party collaborative prove (additive shares, honest backend), one party 
 
 A step = one proof.  Timing: W untimed proofs, then exactly K proofs bracketed by barrier +
 device synchronisation; max over ranks.  One JSON line on rank 0.
+
+Outside the timed region the run checks itself: the bytes of the timed proofs are compared with the oracle's known-trapdoor
+prediction (Fr arithmetic on the CPU + three scalar multiplications; `proof_matches_prediction`), for N > 1 the revealed
+proof against the prediction on the summed shares, identical on every rank.
 """
 from __future__ import annotations
 
@@ -31,6 +35,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INT_MAD_PEAK = 32.16e12  # v_mad_u64_u32 wave-lane instr/s measured on MI355X (tools/ubench_int.hip, gpurun_out/ubench_int.txt)
+# v_mad_u64_u32 per XYZZ mixed addition (8M + 2S): 6 products, 2 squarings, one fused double product R(Q - X3) - Y1 PPP
+MADS_PER_MADD_G1 = 6 * 325 + 494 + 2 * 260
+MADS_PER_MADD_G2 = 10 * 1014                      # per lane PAIR: every Fq2 product is two fused double products of 507
 
 
 def seeded_fr(seed: int):
@@ -40,7 +47,7 @@ def seeded_fr(seed: int):
     return int.from_bytes(h[:40], "little") % cv.R_MOD
 
 
-def cpu_baseline(ctx, td, sample_log: int, threads: int):
+def cpu_baseline(ctx, td, sample_log: int, threads: int, full_log: int = 20):
     """Time the oracle's C restatement of the reference prover (oracle/zkref.c: arkworks' CIOS field
     arithmetic, Jacobian formulas, Pippenger with c = ln(n)+2, in-order radix-2 FFT, src/groth16.rs
     pipeline) on a bounded sample of the same workload, on this host's cores.  The proving key is the
@@ -67,10 +74,18 @@ def cpu_baseline(ctx, td, sample_log: int, threads: int):
     for o in (z, ):
         o.free()
     pk.free(); r1cs.free()
+    c_ref = max(3, int(__import__("math").log(max(n, 2))) + 2)        # arkworks' window: ln(n) + 2 (msm/variable_base.rs:22-26)
+    windows = (253 + c_ref - 1) // c_ref
     return {"value": round(n / t_all, 1), "unit": "constraints/s", "cores": threads, "kind": "port",
-            "sample": "mul-chain prove, n=2^%d-2 constraints (bounded sample of the 2^20 workload), device's proving key; "
-                      "%.2f s on %d threads (witness map %.2f s, MSMs %.2f s); single thread (the reference's build: no rayon): "
-                      "%.2f s = %.0f constraints/s" % (sample_log, t_all, threads, ph[0], ph[1], t_one, n / t_one),
+            "sample": "mul-chain prove, n=2^%d-2 constraints (%s), device's proving key; %.2f s with %d threads requested "
+                      "(witness map %.2f s, MSMs %.2f s); single thread (the reference's actual build: no rayon feature): "
+                      "%.2f s = %.0f constraints/s" % (
+                          sample_log, "the benched configuration itself" if sample_log == full_log else
+                          "bounded sample of the 2^%d workload" % full_log, t_all, threads, ph[0], ph[1], t_one, n / t_one),
+            "effective_parallel_width": {"msm": min(threads, windows), "fft": min(threads, 32),
+                                         "note": "the port parallelises where arkworks' `parallel` feature does: over the %d Pippenger "
+                                                 "windows of an MSM (c = %d) and over butterfly chunks; the five MSMs run one after the "
+                                                 "other as in the reference" % (windows, c_ref)},
             "single_thread_value": round(n / t_one, 1), "proof_matches_device": bool(ok)}
 
 
@@ -169,6 +184,19 @@ def other_workloads(ctx, log_h=20):
     return out
 
 
+def predict_proof(ctx, n, zarr, td, r_, s_, threads):
+    """The oracle's known-trapdoor prediction of the 192 proof bytes for the mul-chain system (checker only: never in the
+    timed region).  Returns (bytes or None, note)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import zkref_c as OC
+    except Exception as e:
+        return None, "oracle unavailable: %s" % e
+    cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))
+    h = OC.witness_map(cr, zarr, threads)
+    return OC.groth16_predict(cr, np.stack(td), zarr, h, r_, s_), "ok"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,8 +206,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hint", action="store_true", help="do not announce the next assignment (isolated proofs)")
     ap.add_argument("--force-mpc", action="store_true", help="run the collaborative code path even with one rank (1-party: exercises transport + share plumbing)")
-    ap.add_argument("--cpu-sample-log", type=int, default=16)
+    ap.add_argument("--cpu-sample-log", type=int, default=None,
+                    help="log2 of the CPU baseline's constraint count (default: the benched configuration itself; 16 = bounded sample)")
     ap.add_argument("--no-extras", action="store_true", help="skip the Marlin / SHE side measurements")
+    ap.add_argument("--no-predict", action="store_true", help="skip the known-trapdoor check of the timed proofs (CPU, ~10 s per proof at 2^20)")
+    ap.add_argument("--queue", type=int, default=4, help="number of DIFFERENT assignments the timed proofs cycle through")
+    ap.add_argument("--natural-domain", action="store_true",
+                    help="n = 2^L constraints, so that the QAP domain is 2^(L+1) (the reference's natural sizing, src/groth16.rs:256-257)")
+    ap.add_argument("--spdz", action="store_true", help="N > 1: SPDZ (malicious) shares instead of additive ones")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE JSON line: libraries (RCCL prints a version banner on stdout at communicator
@@ -195,6 +229,7 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
 
+    import hashlib
     import torch
     import zk_mpc_amd as Z
     import zk_mpc_amd.convert as cv
@@ -210,7 +245,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    n = (1 << args.log_constraints) - 2      # + 2 instance variables -> domain 2^L exactly
+    n = (1 << args.log_constraints) - (0 if args.natural_domain else 2)      # + 2 instance variables -> domain 2^L exactly
     ctx = Z.Context(local_rank, rank, world)
     mont = lambda v: cv.fr_to_mont([v])[0]
     r1cs = ctx.r1cs_mul_chain(n)
@@ -219,25 +254,46 @@ def main():
     t0 = time.time()
     pk = ctx.groth16_setup(r1cs, *td)
     t_setup = time.time() - t0
-    z = ctx.mul_chain_assignment_dev(n, mont(seeded_fr(100)), mont(seeded_fr(101)))
-    r_, s_ = mont(seeded_fr(200)), mont(seeded_fr(201))
+    # a queue of DIFFERENT assignments (same circuit): the timed proofs cycle through them
+    Q = max(1, args.queue) if dist is None else 1
+    zs = [ctx.mul_chain_assignment_dev(n, mont(seeded_fr(100 + 10 * q)), mont(seeded_fr(101 + 10 * q))) for q in range(Q)]
+    rs = [(mont(seeded_fr(200 + 10 * q)), mont(seeded_fr(201 + 10 * q))) for q in range(Q)]
+    last_proof = {}                                   # assignment index -> bytes of its most recent proof
 
     if dist is None:
-        def step():
+        def step(i):
             # a prover working through a queue of assignments announces the next one: the proof then enqueues the next
             # proof's front (z-sort, witness map, H-sort) behind its own kernels (zk_groth16_hint_next_dev).  Every timed
             # proof still contains one full front: the one it runs for its successor.  --no-hint times isolated proofs.
+            q = i % Q
             if not args.no_hint:
-                ctx.groth16_hint_next_dev(z.ptr)
-            return ctx.create_proof_dev(pk, r1cs, z.ptr, r_, s_)
+                ctx.groth16_hint_next_dev(zs[(i + 1) % Q].ptr)
+            last_proof[q] = ctx.create_proof_dev(pk, r1cs, zs[q].ptr, *rs[q])
+            return last_proof[q]
     else:
         from zk_mpc_amd import mpc
-        party = mpc.Party(ctx, dist)
-        zshare = party.share_assignment_dev(z, r1cs, seed=1234)
-        rs = party.share_scalars([seeded_fr(200), seeded_fr(201)], seed=99)
+        party = (mpc.SpdzParty if args.spdz else mpc.Party)(ctx, dist)
+        r_plain, s_plain = seeded_fr(200), seeded_fr(201)
+        if args.spdz:
+            # SPDZ shares: (share, mac) lanes, MAC key alpha = 1 held by the leader (share/spdz.rs:31-37): the mac lane is an
+            # independent additive sharing of the same values
+            zshare = (party.share_assignment_dev(zs[0], r1cs, seed=1234), None)
+            keep0 = party._keep
+            zshare = (zshare[0], party.share_assignment_dev(zs[0], r1cs, seed=4321))
+            keep1 = party._keep
+            ra, rb = party.share_scalars([r_plain, s_plain], seed=99), party.share_scalars([r_plain, s_plain], seed=77)
+            rsh, ssh = (ra[0], rb[0]), (ra[1], rb[1])
 
-        def step():
-            return party.create_proof_shared(pk, r1cs, zshare, rs[0], rs[1])
+            def step(i):
+                last_proof[0] = party.create_proof_shared_spdz(pk, r1cs, zshare, rsh, ssh)
+                return last_proof[0]
+        else:
+            zshare = party.share_assignment_dev(zs[0], r1cs, seed=1234)
+            sc = party.share_scalars([r_plain, s_plain], seed=99)
+
+            def step(i):
+                last_proof[0] = party.create_proof_shared(pk, r1cs, zshare, sc[0], sc[1])
+                return last_proof[0]
 
     def barrier():
         if dist is not None:
@@ -249,38 +305,129 @@ def main():
     # priming, part of set-up like the key generation above: the first few proofs of a process pay one-off costs (pinned
     # staging buffers, scratch arenas growing to their final size, RCCL's lazy channel set-up: the 3rd collaborative proof
     # of a process takes 65 ms instead of 28) that must not land in the timed region when the caller asks for W < 3
+    it = 0
     for _ in range(4 if dist is not None else 2):
-        step()
+        step(it); it += 1
     for _ in range(args.warmup):
-        proof = step()
+        proof = step(it); it += 1
     ctx.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        proof = step()
+        proof = step(it); it += 1
     barrier()
     dt = time.perf_counter() - t0
     timers = ctx.timers()
     ctx.set_profiling(False)
     isolated_ms = None
-    if dist is None and not args.no_hint:
-        # the same proof without the announcement (latency of one isolated proof), outside the timed region
+    host_leg = None
+    if dist is None:
         ctx.groth16_hint_next_dev(None)
-        ctx.create_proof_dev(pk, r1cs, z.ptr, r_, s_)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            ctx.create_proof_dev(pk, r1cs, z.ptr, r_, s_)
-        barrier()
-        isolated_ms = (time.perf_counter() - t1) / 3 * 1e3
+        if not args.no_hint:
+            # the same proofs without the announcement (latency of one isolated proof), outside the timed region
+            ctx.create_proof_dev(pk, r1cs, zs[0].ptr, *rs[0])
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(3):
+                ctx.create_proof_dev(pk, r1cs, zs[i % Q].ptr, *rs[i % Q])
+            barrier()
+            isolated_ms = (time.perf_counter() - t1) / 3 * 1e3
+        # second leg, SURVEY 8(d)'s definition of t: "from witness vector on host to 192 proof bytes on host", through the
+        # host-slice entry point (zk_groth16_prove_queued; the assignments sit in page-locked host memory from zk_host_alloc)
+        try:
+            pinned = [ctx.host_alloc((n + 3) * 32) for _ in range(Q)]
+            hz = []
+            for q in range(Q):
+                a = pinned[q].array((n + 3, 4))
+                a[:] = ctx.download(zs[q], (n + 3, 4))
+                hz.append(a)
+            host_ok = True
+            for i in range(2):
+                p = ctx.create_proof_queued(pk, r1cs, hz[i % Q], *rs[i % Q], z_next_host=hz[(i + 1) % Q])
+                if (i % Q) in last_proof and p != last_proof[i % Q]:
+                    host_ok = False
+            barrier()
+            t1 = time.perf_counter()
+            Kh = max(args.steps, 4)
+            for i in range(2, 2 + Kh):
+                p = ctx.create_proof_queued(pk, r1cs, hz[i % Q], *rs[i % Q], z_next_host=hz[(i + 1) % Q])
+                if (i % Q) in last_proof and p != last_proof[i % Q]:
+                    host_ok = False
+            barrier()
+            th = (time.perf_counter() - t1) / Kh
+            # one isolated host proof (no announcement): upload + proof + bytes back
+            ctx.create_proof_queued(pk, r1cs, hz[0], *rs[0])
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(3):
+                ctx.create_proof_queued(pk, r1cs, hz[i % Q], *rs[i % Q])
+            barrier()
+            th_iso = (time.perf_counter() - t1) / 3
+            host_leg = {"entry_point": "zk_groth16_prove_queued (host assignment in page-locked memory -> 192 proof bytes on the host; "
+                                       "the next assignment announced and uploaded on a copy stream under the current proof)",
+                        "ms_per_proof": round(th * 1e3, 3), "constraints_per_s": round(n / th, 1),
+                        "isolated_ms_per_proof": round(th_iso * 1e3, 3), "isolated_constraints_per_s": round(n / th_iso, 1),
+                        "proofs_equal_device_leg": bool(host_ok), "steps": Kh}
+            for pb in pinned:
+                pb.free()
+        except Exception as e:          # the headline line must not depend on this leg
+            host_leg = {"error": repr(e)}
+    open_probe = None
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank must hold the same revealed proof
+        hsh = np.frombuffer(hashlib.sha256(proof).digest()[:8], dtype=np.uint64).copy()
+        allh = party.net.all_gather_small(hsh)
+        same_on_all_ranks = all(int(x[0]) == int(hsh[0]) for x in allh)
+        # cost of one share-vector open (the data-path collective) on its own: D elements, outside the timed region
+        try:
+            be = party.be
+            va, vo = be.vec("probe_a", D), be.vec("probe_o", D)
+            ctx.dev_zero(va, D * 32)
+            be.open_vec(va, vo, D)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                be.open_vec(va, vo, D)
+            barrier()
+            t_open = (time.perf_counter() - t1) / 5
+            pattern = "all-gather + sum" if world < 3 else "all-to-all of slices + sum + all-gather of the summed slices"
+            in_bytes = (world - 1) * D * 32 if world < 3 else 2 * (world - 1) * ((D + world - 1) // world) * 32
+            open_probe = {"elements": D, "ms": round(t_open * 1e3, 3), "pattern": pattern, "bytes_in_per_gpu": in_bytes,
+                          "gb_per_s_in_per_gpu": round(in_bytes / t_open / 1e9, 2) if t_open > 0 else None,
+                          "opens_per_proof": 4 if args.spdz else 2}
+        except Exception as e:
+            open_probe = {"error": repr(e)}
 
     if rank == 0:
         K = args.steps
         per_proof = n * K / dt
+        # ---- self-check: the timed proofs against the known-trapdoor prediction (CPU, outside the timed region) ----
+        pred = {"checked": 0}
+        if not args.no_predict:
+            try:
+                threads = os.cpu_count() or 1
+                ok = True
+                t1 = time.time()
+                check = sorted(last_proof)[-2:] if dist is None else [0]
+                for q in check:
+                    zarr = ctx.download(zs[q], (n + 3, 4))
+                    r_q, s_q = (rs[q] if dist is None else (mont(seeded_fr(200)), mont(seeded_fr(201))))
+                    want, note = predict_proof(ctx, n, zarr, td, r_q, s_q, threads)
+                    if want is None:
+                        pred = {"checked": 0, "note": note}
+                        ok = None
+                        break
+                    ok = ok and (want == last_proof[q])
+                    pred["checked"] += 1
+                pred["ok"] = ok
+                pred["seconds"] = round(time.time() - t1, 1)
+                pred["what"] = ("bytes of the last proof of %d different assignments of the timed queue" % len(check)) if dist is None else \
+                               "revealed %d-party proof vs the prediction for z = sum of the shares, r = sum r_i, s = sum s_i" % world
+            except Exception as e:
+                pred = {"checked": 0, "ok": None, "error": repr(e)}
         # dominant kernel: G1 bucket accumulation (k_accum<G1>), 4 launches per proof.
         acc_ms, acc_cnt = timers.get("msm_g1.accum", (0.0, 0))
         roof = None
@@ -292,47 +439,47 @@ def main():
             c = ctx.lib.zk_bases_window_bits(pk_bases(ctx, pk, "a").h) or max(4, min(16, n_msm.bit_length() - 1 - 4))
             W = (255 + c - 1) // c                # digits per scalar (13 with the key's precomputed window multiples, c = 20)
             madds = n_msm * W                     # mixed additions in the accumulate kernel
-            mads = madds * (6 * 325 + 494 + 2 * 260)   # 8M + 2S with R(Q - X3) - Y1 PPP as one fused double product (494 mads)
-            traffic = None
+            mads_per_madd = MADS_PER_MADD_G1
+            mads = madds * mads_per_madd
+            traffic, traffic_src = None, None
             try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), not measured live
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-                if args.log_constraints == 20:
-                    traffic = pmc["kernels"]["k_accum<G1>"]["hbm_bytes"]
+                for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+                    pth = os.path.join(ROOT, "profiles", f)
+                    if os.path.exists(pth) and args.log_constraints == 20 and not args.natural_domain:
+                        traffic = json.load(open(pth))["kernels"]["k_accum<G1>"]["hbm_bytes"]
+                        traffic_src = "profiles/" + f
+                        break
             except Exception:
                 pass
             roof = {"bound": "hbm", "kernel": "k_accum<G1> (MSM bucket accumulation)", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_note": "bytes/launch, 2*FETCH_SIZE+WRITE_SIZE from profiles/r1_pmc_traffic.json; ~29x the 128 B/term "
-                                    "algorithmic figure because the bucket method re-reads every base once per window (16x) in "
-                                    "128-B lines (96-B points); the kernel is ALU-bound at ~1.2 TB/s of gather traffic",
+                    "traffic_source": traffic_src,
+                    "traffic_note": "bytes/launch, 2*FETCH_SIZE+WRITE_SIZE from a SEPARATE rocprofv3 --pmc run committed under profiles/ "
+                                    "(not measured in this run); ~25x the 128 B/term algorithmic figure because the bucket method "
+                                    "reads every base once per digit (13x) in 128-B lines (96-B points); the kernel is ALU-bound",
                     "avg_launch_ms": round(avg_s * 1e3, 3), "launches": acc_cnt,
                     "note": "kernel is integer-ALU bound, not HBM bound (SURVEY 8d); see int_alu",
                     "int_alu": {"achieved": round(mads / avg_s / 1e12, 3), "peak": round(INT_MAD_PEAK / 1e12, 2),
-                                "unit": "T v_mad_u64_u32 lane-ops/s", "frac": round(mads / avg_s / INT_MAD_PEAK, 4)}}
-            try:  # VALU issue utilisation from the committed rocprofv3 PMC passes (tools/pmc_valu.py), not measured live
-                pv = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_valu.json")))["kernels"]
-                roof["valu_issue"] = {
-                    "note": "SQ_INSTS_VALU per launch / kernel duration (kernel alone on the chip, under counter collection) vs the "
-                            "measured integer issue peak of 32.16 T lane-ops/s = 0.5025 T wave-instructions/s: both accumulate "
-                            "kernels fill every VALU issue slot; what int_alu reports below 1 is the share of v_mad_u64_u32 in "
-                            "their instruction mix",
-                    "k_accum<G1>": {"wave_insts_per_launch": round(pv["k_accum<G1>"]["SQ_INSTS_VALU"]),
-                                    "frac_of_issue_peak": round(pv["k_accum<G1>"]["frac_of_int_issue_peak"], 4),
-                                    "mean_waves_per_cu": round(pv["k_accum<G1>"]["MeanOccupancyPerCU"], 2)},
-                    "k_accum_g2pair": {"wave_insts_per_launch": round(pv["k_accum_g2pair<2>"]["SQ_INSTS_VALU"]),
-                                       "frac_of_issue_peak": round(pv["k_accum_g2pair<2>"]["frac_of_int_issue_peak"], 4),
-                                       "mean_waves_per_cu": round(pv["k_accum_g2pair<2>"]["MeanOccupancyPerCU"], 2)}}
+                                "unit": "T v_mad_u64_u32 lane-ops/s", "frac": round(mads / avg_s / INT_MAD_PEAK, 4),
+                                "mads_per_mixed_add": mads_per_madd}}
+            try:  # instruction mix of the kernel's main path (static, from the ISA: tools/isa_hist.py) -> mix-weighted ceiling
+                ih = json.load(open(os.path.join(ROOT, "profiles", "r2_isa_k_accum_g1.json")))
+                roof["int_alu"]["mix_weighted_ceiling"] = {
+                    "source": "profiles/r2_isa_k_accum_g1.json (tools/isa_hist.py over hipcc -S; priced with profiles/r1_ubench_int.txt: "
+                              "v_mad_u64_u32 and the other ~35 T/s classes = 1 issue slot, the ~67 T/s classes = 0.5)",
+                    "mad_share_of_issue_slots": round(ih["main_path"]["mix_ceiling"], 4)}
             except Exception:
                 pass
             # the single longest kernel: the G2 accumulate on lane pairs (one launch per proof); every one of its 10 Fq2
-            # products per mixed addition is two fused double products of 507 mads
+            # products per mixed addition is two fused double products
             g2_ms, g2_cnt = timers.get("msm_g2.accum", (0.0, 0))
             if g2_cnt:
                 g2_s = g2_ms / g2_cnt * 1e-3
                 roof["g2_accum"] = {"kernel": "k_accum_g2pair (B-in-G2 bucket accumulation, two lanes per addition)",
                                     "avg_launch_ms": round(g2_s * 1e3, 3), "launches": g2_cnt,
-                                    "int_alu": {"achieved": round(madds * 10 * 1014 / g2_s / 1e12, 3), "peak": round(INT_MAD_PEAK / 1e12, 2),
-                                                "unit": "T v_mad_u64_u32 lane-ops/s", "frac": round(madds * 10 * 1014 / g2_s / INT_MAD_PEAK, 4)}}
+                                    "int_alu": {"achieved": round(madds * MADS_PER_MADD_G2 / g2_s / 1e12, 3), "peak": round(INT_MAD_PEAK / 1e12, 2),
+                                                "unit": "T v_mad_u64_u32 lane-ops/s", "frac": round(madds * MADS_PER_MADD_G2 / g2_s / INT_MAD_PEAK, 4)}}
+        share_kind = "SPDZ (share + MAC lanes, MAC-checked opens)" if args.spdz else "additive-share"
         out = {
             "metric": "R1CS constraints/sec (prove), Groth16 BLS12-377",
             "value": round(per_proof * world, 1),
@@ -341,39 +488,50 @@ def main():
             "ms_per_step": round(dt / K * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x13 (29-bit limbs, int64 accumulate)", "data": "synthetic",
-            "config": {"workload": "mul-chain R1CS, n=2^%d-2 constraints, QAP domain 2^%d, %s" % (
-                args.log_constraints, r1cs.domain_log,
-                "local prove" if dist is None else "%d-party additive-share collaborative prove" % world),
+            "config": {"workload": "mul-chain R1CS, n=2^%d%s constraints, QAP domain 2^%d, %s" % (
+                args.log_constraints, "" if args.natural_domain else "-2", r1cs.domain_log,
+                "local prove" if dist is None else "%d-party %s collaborative prove" % (world, share_kind)),
                 "constraints": n, "parties": world,
                 "queue": ("isolated proofs" if (dist is not None or args.no_hint) else
-                          "proofs back to back, the next assignment announced (zk_groth16_hint_next_dev): each timed proof "
-                          "also runs the front of its successor")},
+                          "proofs back to back over a queue of %d DIFFERENT assignments, the next one announced "
+                          "(zk_groth16_hint_next_dev): each timed proof also runs the front of its successor" % Q)},
             "proof_constraints_per_s": round(per_proof, 1),
+            "proof_matches_prediction": pred.get("ok"),
+            "prediction_check": pred,
             "isolated_proof_ms": None if isolated_ms is None else round(isolated_ms, 3),
+            "host_witness_leg": host_leg,
             "phases_ms_per_proof": {k: round(v[0] / K, 3) for k, v in sorted(timers.items())},
             "setup_s": round(t_setup, 2),
-            "proof_sha": __import__("hashlib").sha256(proof).hexdigest()[:16],
+            "proof_sha": hashlib.sha256(proof).hexdigest()[:16],
             "roofline": roof,
         }
+        if dist is not None:
+            out["value_note"] = ("weak scaling: every party runs the full-size prover on its shares, value = parties x constraints x "
+                                 "proofs / time (constraint-shares/s); proof_constraints_per_s is the per-proof rate the north star's "
+                                 "'3-party within 2x of 1-GPU' is about")
+            out["same_proof_on_all_ranks"] = bool(same_on_all_ranks)
+            out["open_probe"] = open_probe
+            out["bytes_sent_per_party"] = int(party.bytes_sent)
         if dist is None:
             # second half of the headline metric: standalone variable-base MSM throughput (resident bases = the
             # proving key's A / B-in-G2 queries, scalars = the assignment already in HBM), outside the timed region
             msm = {}
             for name, q, grp in (("g1", pk_bases(ctx, pk, "a"), 1), ("g2", pk_bases(ctx, pk, "b_g2"), 2)):
                 m = n                       # terms
-                ctx.msm_dev(q, 1, z.ptr + 32, m)
+                ctx.msm_dev(q, 1, zs[0].ptr + 32, m)
                 ctx.sync()
                 t1 = time.perf_counter()
                 reps = 5
                 for _ in range(reps):
-                    ctx.msm_dev(q, 1, z.ptr + 32, m)
+                    ctx.msm_dev(q, 1, zs[0].ptr + 32, m)
                 ctx.sync()
                 msm[name] = round(m * reps / (time.perf_counter() - t1) / 1e6, 1)
             out["msm_mscalar_per_s"] = dict(msm, n=n, note="single MSM per call incl. host round trip, bases resident")
         if dist is None and not args.no_extras:
             out["other_workloads"] = other_workloads(ctx, min(args.log_constraints, 20))
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(ctx, td, args.cpu_sample_log, os.cpu_count() or 1)
+            sample_log = args.cpu_sample_log if args.cpu_sample_log is not None else args.log_constraints
+            out["cpu_baseline"] = cpu_baseline(ctx, td, sample_log, os.cpu_count() or 1, args.log_constraints)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()

@@ -60,6 +60,9 @@ int zk_version(void);
 
 int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** dev_out);
 int zk_dev_free(zk_ctx* ctx, void* dev);
+/* Page-locked host memory for buffers that cross the boundary on the proving path (assignment vectors). */
+int zk_host_alloc(zk_ctx* ctx, size_t bytes, void** host_out);
+int zk_host_free(zk_ctx* ctx, void* host);
 int zk_memcpy_h2d(zk_ctx* ctx, void* dev, const void* host, size_t bytes);
 int zk_memcpy_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes);
 int zk_memcpy_d2d(zk_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);   /* asynchronous on the context stream */
@@ -246,9 +249,16 @@ int zk_groth16_msms_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const
  * (non-shared) assignment resident on the device; proof = a||b||c compressed, 192 bytes. */
 int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const void* z_dev,
                          const zk_fr* r, const zk_fr* s, uint8_t proof_out[192]);
-/* Same with the assignment in host memory (instance then witness). */
+/* Same with the assignment in host memory (instance then witness): SURVEY 8(d)'s "witness vector on host to 192 proof
+ * bytes on host". */
 int zk_groth16_prove(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const zk_fr* z_host,
                      const zk_fr* r, const zk_fr* s, uint8_t proof_out[192]);
+/* The same for a prover that works through a queue of host assignments: z_next_host (or NULL) is the assignment of the
+ * NEXT call.  It is uploaded at once on a copy stream (two device slots alternate) and this proof enqueues its front as
+ * zk_groth16_hint_next_dev does; the next call, naming that buffer (matched by address: it must stay unchanged in between),
+ * copies nothing.  Page-locked buffers (zk_host_alloc) make the upload asynchronous. */
+int zk_groth16_prove_queued(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const zk_fr* z_host,
+                            const zk_fr* r, const zk_fr* s, const zk_fr* z_next_host, uint8_t proof_out[192]);
 
 /* ---- dense polynomials over Fr and KZG10 (row a14: the data-parallel pieces of the Marlin / poly-commit path) ---- */
 /* out[i] = start * base^i, i < n (device vector). */
@@ -321,6 +331,10 @@ int zk_she_decode_dev(zk_ctx* ctx, const void* enc_dev, void* out_fr_dev, size_t
 int zk_comm_unique_id(uint8_t out[128]);
 int zk_comm_init(zk_ctx* ctx, const uint8_t id[128], int rank, int n_parties);
 int zk_comm_destroy(zk_ctx* ctx);             /* also done by zk_ctx_destroy */
+/* Exchange pattern of zk_open_sum_fr_dev: 0 = by party count (default), 1 = all-gather + sum, 2 = all-to-all of slices +
+ * sum + all-gather.  A property of the communicator: every party must make the same call (it is not read from the
+ * environment, where parties could disagree and wait for each other in different collectives). */
+int zk_comm_set_open_pattern(zk_ctx* ctx, int pattern);
 /* AdditiveFieldShare::batch_open on a device vector (mpc-algebra/src/share/additive.rs:124-131 over
  * MpcSerNet::broadcast, channel.rs:12-28): out[i] = sum over parties of v[i] mod r, on every party; out may alias v.
  * Three or more parties: all-to-all of slices, local sum, all-gather of the summed slices (2 x 32 n bytes in per GPU);
@@ -341,6 +355,34 @@ int zk_beaver_combine_dev(zk_ctx* ctx, const void* sx_open_dev, const void* oy_o
 /* *is_zero = 1 iff every element of the device vector is 0: the MAC check of SpdzFieldShare::batch_open
  * (assert!(sum.is_zero()) per element, mpc-algebra/src/share/spdz.rs:188-195) as one reduction. */
 int zk_fr_vec_is_zero_dev(zk_ctx* ctx, const void* v_dev, size_t n, int* is_zero);
+
+/* ---- randomness (rows a11 / a13: share sampling; f.1: the Fiat-Shamir generator of Marlin) ------------------------- */
+/* out[i] = F::rand(rng), i < n, on the device: the N - 1 uniform share vectors of AdditiveFieldShare::king_share
+ * (mpc-algebra/src/share/additive.rs:98-107; ff/src/fields/arithmetic.rs:200-219).  Element i is ChaCha20(key, block i,
+ * stream_id) -- 512 bits -- reduced mod r.  key32 = NULL draws the key from the operating system's CSPRNG (getrandom);
+ * a caller-supplied 32-byte key makes the vector reproducible (tests).  Asynchronous on the context stream. */
+int zk_fr_random_dev(zk_ctx* ctx, const uint8_t* key32, uint64_t stream_id, void* out_dev, size_t n);
+/* Byte-exact host generators.  zk_rng is rand_chacha's ChaChaRng behind rand_core's BlockRng word stream.
+ *   zk_fsrng_new / zk_fsrng_absorb   FiatShamirRng::<Blake2s>::{from_seed, absorb} (arkworks/marlin/src/rng.rs:44-67) on the
+ *                                    bytes the reference's to_bytes! produces (the caller serialises)
+ *   zk_rng_from_seed(seed, rounds)   ChaChaRng::from_seed (20) or rand 0.8.5's StdRng::from_seed (12: ark_std::test_rng,
+ *                                    arkworks/std/src/rand_helper.rs:31-39)
+ *   zk_rng_next_fr                   Fr::rand: 4 x next_u64, top 3 bits cleared, rejected unless < r; the words are the
+ *                                    element's Montgomery form (ff/src/fields/arithmetic.rs:200-219)
+ *   zk_rng_next_u128                 u128::rand (marlin/src/lib.rs:300: the opening challenge), low half in out[0] */
+typedef struct zk_rng zk_rng;
+int zk_fsrng_new(const uint8_t* seed_bytes, size_t len, zk_rng** out);
+int zk_fsrng_absorb(zk_rng* rng, const uint8_t* bytes, size_t len);
+int zk_rng_from_seed(const uint8_t seed[32], int rounds, zk_rng** out);
+int zk_rng_free(zk_rng* rng);
+int zk_rng_next_u64(zk_rng* rng, uint64_t* out);
+int zk_rng_next_u128(zk_rng* rng, uint64_t out[2]);
+int zk_rng_next_fr(zk_rng* rng, zk_fr* out);
+int zk_rng_fill_bytes(zk_rng* rng, uint8_t* out, size_t n);
+/* Blake2s-256 (RFC 7693; the digest of FiatShamirRng) and the ChaCha block function (RFC 8439 2.3; words 12..15 of the
+ * state are passed in: (counter lo, counter hi, stream lo, stream hi) for rand_chacha, (counter, nonce[3]) for the RFC). */
+int zk_blake2s(const uint8_t* data, size_t len, uint8_t out[32]);
+int zk_chacha_block(const uint8_t key[32], const uint32_t words12_15[4], int rounds, uint8_t out[64]);
 
 /* ---- instrumentation -------------------------------------------------------------------- */
 /* zk_set_profiling(ctx, 1): bracket every phase (witness map, MSM sort / accumulate / reduce) with

@@ -59,13 +59,13 @@ class OracleBackend:
     def add(self, a, b, out, n): self.store[out] = OC.fr_vec_op(1, self.store[a], self.store[b])
     def sub(self, a, b, out, n): self.store[out] = OC.fr_vec_op(2, self.store[a], self.store[b])
 
-    def king_share(self, values, n, seed):
+    def king_share(self, values, n, key32=None):
         """Test-side mirror of GpuBackend.king_share (numpy shares, the product's transport scatter)."""
         import torch
         net = self.net
         parts = None
         if net.is_leader():
-            rs = np.random.RandomState(seed & 0x7FFFFFFF)
+            rs = np.random.RandomState(int.from_bytes((key32 or b'\x05' * 32)[:4], 'little') & 0x7FFFFFFF)
             last = np.array(self.store[values], copy=True)
             parts = []
             for _ in range(net.n - 1):

@@ -222,3 +222,134 @@ def test_hint_next_front_prefetch(ctx):
     ctx.groth16_hint_next_dev(None)
     assert ctx.create_proof_dev(pk, dr, zs[2].ptr, *rs[2]) == plain[2]
     pk.free()
+
+
+@pytest.mark.parametrize("n,label", [((1 << 20) - 2, "D=2^20 (BASELINE config 2, the benched shape)"),
+                                     (1 << 20, "D=2^21 (the reference's natural sizing, src/groth16.rs:256-257)")])
+def test_headline_size_matches_known_trapdoor_prediction(ctx, n, label):
+    """The benched configuration itself: mul-chain Groth16 at n = 2^20 - 2 (domain 2^20) and n = 2^20 (domain 2^21), key with
+    window multiples (c = 20: G2 accumulate / reduce on lane pairs with 16 virtual windows), proof bytes against the C
+    oracle's known-trapdoor prediction (Fr arithmetic on the CPU + three scalar multiplications) -- for isolated proofs,
+    for a queue with the next assignment announced (zk_groth16_hint_next_dev) and through the host-slice entry point."""
+    import zkref_c as OC
+    rng = O.Prng(20200 + (n & 3))
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    td = [mont(rng.fr()) for _ in range(7)]
+    dr = ctx.r1cs_mul_chain(n)
+    assert dr.domain_log == (20 if n < (1 << 20) - 1 else 21)
+    pk = ctx.groth16_setup(dr, *td)
+    assert ctx.lib.zk_bases_window_bits(pk.query_bases("b_g2_query").h) == 20
+    zs = [ctx.mul_chain_assignment_dev(n, mont(rng.fr()), mont(rng.fr())) for _ in range(2)]
+    rs = [(mont(rng.fr()), mont(rng.fr())) for _ in range(2)]
+    cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))
+    want = []
+    zarrs = []
+    for z, (r, s) in zip(zs, rs):
+        zarr = ctx.download(z, (n + 3, 4))
+        zarrs.append(zarr)
+        want.append(OC.groth16_predict(cr, np.stack(td), zarr, OC.witness_map(cr, zarr, OC.num_threads()), r, s))
+    assert want[0] != want[1]
+    assert [ctx.create_proof_dev(pk, dr, z.ptr, r, s) for z, (r, s) in zip(zs, rs)] == want          # isolated
+    got = []
+    for k in (0, 1, 0, 1):                                                                            # announced queue
+        ctx.groth16_hint_next_dev(zs[1 - k].ptr)
+        got.append(ctx.create_proof_dev(pk, dr, zs[k].ptr, *rs[k]))
+    ctx.groth16_hint_next_dev(None)
+    assert got == [want[0], want[1], want[0], want[1]]
+    assert ctx.create_proof(pk, dr, zarrs[1], *rs[1]) == want[1]                                      # host witness -> host bytes
+    pk.free()
+    for z in zs:
+        z.free()
+    dr.free()
+
+
+def test_hint_next_with_split_buckets_and_plain_tables(ctx):
+    """The next proof's H-sort rewrites the sort scratch of slot 5 (ctr / heavy descriptors) that the CURRENT proof's H
+    reduce chain (k_fold) still reads when it runs on the other stream: it has to wait for that chain.  The race only
+    matters when H's buckets are split, so: tables without window multiples (ZK_PRECOMP=0: seg = 32, 16 bucket sets) and an
+    assignment whose h has many repeated scalars -- w0 = 1, w1 = 1 makes every w_i = 1, so a, b, c are constant on the domain
+    and z is all ones (every digit of every scalar in one bucket per window: maximally split buckets for the z jobs too).
+    A queue of such proofs with hints must give the bytes of the isolated proofs, repeatedly."""
+    import os
+    n = (1 << 16) + 9
+    rng = O.Prng(60606)
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    td = [mont(rng.fr()) for _ in range(7)]
+    dr = ctx.r1cs_mul_chain(n)
+    os.environ["ZK_PRECOMP"] = "0"
+    try:
+        pk = ctx.groth16_setup(dr, *td)
+    finally:
+        del os.environ["ZK_PRECOMP"]
+    assert ctx.lib.zk_bases_window_bits(pk.query_bases("h_query").h) == 0
+    # all-ones, a 2-cycle (w0 = 1, w1 = -1 -> 1, -1, -1, 1, -1, -1 ...: three distinct values), and a random chain
+    zs = [ctx.mul_chain_assignment_dev(n, mont(1), mont(1)), ctx.mul_chain_assignment_dev(n, mont(1), mont(O.R_MOD - 1)),
+          ctx.mul_chain_assignment_dev(n, mont(rng.fr()), mont(rng.fr()))]
+    rs = [(mont(rng.fr()), mont(rng.fr())) for _ in range(3)]
+    plain = [ctx.create_proof_dev(pk, dr, z.ptr, r, s) for z, (r, s) in zip(zs, rs)]
+    import zkref_c as OC
+    cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))
+    for z, (r, s), p in zip(zs, rs, plain):
+        zarr = ctx.download(z, (n + 3, 4))
+        assert p == OC.groth16_predict(cr, np.stack(td), zarr, OC.witness_map(cr, zarr), r, s)
+    for rep in range(4):
+        for k in range(3):
+            ctx.groth16_hint_next_dev(zs[(k + 1) % 3].ptr)
+            assert ctx.create_proof_dev(pk, dr, zs[k].ptr, *rs[k]) == plain[k], (rep, k)
+    ctx.groth16_hint_next_dev(None)
+    pk.free()
+
+
+def test_pending_front_does_not_outlive_its_key(ctx):
+    """hint -> prove -> free the key -> a new key (very likely at the same address) and the same z buffer: the pending front
+    of the old key (matched by address) must have been dropped with it (zk_pk_free calls zk_presort_free)."""
+    n = (1 << 16) + 3
+    rng = O.Prng(70707)
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    dr = ctx.r1cs_mul_chain(n)
+    z = ctx.mul_chain_assignment_dev(n, mont(rng.fr()), mont(rng.fr()))
+    r, s = mont(rng.fr()), mont(rng.fr())
+    proofs = []
+    for k in range(3):
+        td = [mont(rng.fr()) for _ in range(7)]
+        pk = ctx.groth16_setup(dr, *td)
+        want = ctx.create_proof_dev(pk, dr, z.ptr, r, s)
+        ctx.groth16_hint_next_dev(z.ptr)                      # leaves a front for (pk, z) pending after this proof
+        assert ctx.create_proof_dev(pk, dr, z.ptr, r, s) == want
+        proofs.append(want)
+        pk.free()                                             # the next key reuses the address; the front must be gone
+    assert len(set(proofs)) == 3
+
+
+def test_prove_queued_host_assignments(ctx):
+    """zk_groth16_prove_queued: a queue of different host assignments (page-locked and ordinary numpy memory), each call
+    announcing the next one; bytes equal the device-resident prover's for every element of the queue, also when an
+    announcement does not come true and when the queue ends (NULL)."""
+    n = (1 << 16) + 21
+    rng = O.Prng(80808)
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    td = [mont(rng.fr()) for _ in range(7)]
+    dr = ctx.r1cs_mul_chain(n)
+    pk = ctx.groth16_setup(dr, *td)
+    Q = 4
+    dev = [ctx.mul_chain_assignment_dev(n, mont(rng.fr()), mont(rng.fr())) for _ in range(Q)]
+    rs = [(mont(rng.fr()), mont(rng.fr())) for _ in range(Q)]
+    want = [ctx.create_proof_dev(pk, dr, z.ptr, r, s) for z, (r, s) in zip(dev, rs)]
+    assert len(set(want)) == Q
+    pinned = [ctx.host_alloc((n + 3) * 32) for _ in range(Q)]
+    host = []
+    for k in range(Q):
+        a = pinned[k].array((n + 3, 4)) if k % 2 == 0 else np.empty((n + 3, 4), dtype=np.uint64)
+        a[:] = ctx.download(dev[k], (n + 3, 4))
+        host.append(a)
+    for rep in range(2):
+        got = [ctx.create_proof_queued(pk, dr, host[k], *rs[k], z_next_host=host[k + 1] if k + 1 < Q else None) for k in range(Q)]
+        assert got == want
+    # an announcement that does not come true, then a plain call
+    assert ctx.create_proof_queued(pk, dr, host[0], *rs[0], z_next_host=host[1]) == want[0]
+    assert ctx.create_proof_queued(pk, dr, host[2], *rs[2], z_next_host=host[3]) == want[2]
+    assert ctx.create_proof(pk, dr, host[1], *rs[1]) == want[1]
+    assert ctx.create_proof_queued(pk, dr, host[3], *rs[3]) == want[3]
+    pk.free()
+    for p in pinned:
+        p.free()

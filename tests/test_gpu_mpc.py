@@ -170,7 +170,7 @@ def test_distnet_nccl_single_rank():
         party.be.open_vec(a.ptr, out, 64)
         assert np.array_equal(ctx.download(out, (64, 4)), ctx.download(a, (64, 4)))
         # ... and through the all-to-all + all-gather pattern used for three or more parties (RCCL all_to_all_single)
-        os.environ["ZK_OPEN"] = "a2a"
+        party.net.open_pattern = "a2a"
         try:
             for m in (64, 61, 1):
                 ctx.dev_zero(out, 64 * 32)
@@ -183,15 +183,16 @@ def test_distnet_nccl_single_rank():
             try:
                 party_n = mpc.Party(ctx, dist)
                 assert party_n.be.native_open
+                ctx.comm_set_open_pattern(2)
                 assert party_n.create_proof_shared(pk, dr, zshare, rs[0], rs[1]) == proof
             finally:
                 del os.environ["ZK_TRANSPORT"]
                 ctx.comm_destroy()
             # king_share through RCCL's scatter (one rank: the only share is the value itself)
-            ks = party.king_share_vec(a.ptr, 64, seed=3)
+            ks = party.king_share_vec(a.ptr, 64, key32=bytes(range(32)))
             assert np.array_equal(ctx.download(ks, (64, 4)), ctx.download(a, (64, 4)))
         finally:
-            del os.environ["ZK_OPEN"]
+            party.net.open_pattern = None
     finally:
         ctx.close()
         dist.destroy_process_group()
@@ -319,10 +320,11 @@ def test_collaborative_marlin_spdz(n_parties, n):
     assert all(r[2] for r in res)
 
 
-@pytest.mark.parametrize("n_parties", [2, 3])
-def test_king_share_vector(n_parties):
-    """Reveal::king_share on a device vector: the leader's N - 1 random shares plus the residual, scattered; the shares
-    sum to the secret and no single share equals it."""
+@pytest.mark.parametrize("n_parties,key32", [(2, None), (3, None), (3, bytes(range(32))), (8, None)])
+def test_king_share_vector(n_parties, key32):
+    """Reveal::king_share on a device vector: the leader's N - 1 uniform shares (ChaCha20 keyed from the OS CSPRNG by default,
+    from a caller's key in tests) plus the residual, scattered; the shares sum to the secret, no single share equals it,
+    two parties' masks differ, and two runs with the default key give different shares."""
     rng = O.Prng(1300 + n_parties)
     n = 777
     secret = [rng.fr() for _ in range(n)]
@@ -330,12 +332,58 @@ def test_king_share_vector(n_parties):
     def fn(p, ctx, net):
         party = mpc.Party(ctx, net=net)
         src = ctx.upload(cv.fr_to_mont(secret)) if p == 0 else None
-        mine = party.king_share_vec(src.ptr if src else None, n, seed=42)
-        return cv.fr_from_mont(ctx.download(mine, (n, 4)))
+        mine = party.king_share_vec(src.ptr if src else None, n, key32=key32)
+        again = party.king_share_vec(src.ptr if src else None, n, key32=key32)
+        return cv.fr_from_mont(ctx.download(mine, (n, 4))), cv.fr_from_mont(ctx.download(again, (n, 4)))
 
     res = run_parties(n_parties, fn)
-    assert [sum(c) % O.R_MOD for c in zip(*res)] == secret
-    assert all(r != secret for r in res)
+    first = [r[0] for r in res]
+    assert [sum(c) % O.R_MOD for c in zip(*first)] == secret
+    assert [sum(c) % O.R_MOD for c in zip(*[r[1] for r in res])] == secret
+    assert all(r != secret for r in first)
+    assert first[0] != first[1]
+    if key32 is None:
+        assert all(r[0] != r[1] for r in res)       # a fresh key per call
+    else:
+        assert all(r[0] == r[1] for r in res)       # reproducible under a caller's key
+
+
+def test_fr_random_uniform_and_keyed(ctx):
+    """zk_fr_random_dev: element i = ChaCha20(key, block i, stream) reduced mod r.  Checked against the host block function
+    (itself pinned to RFC 8439 in tests/test_fsrng.py), every value < r, distinct streams differ, and the values are spread
+    over the whole of [0, r): the top three bits of value * 8 / r are uniform (chi-square over 8 bins, 2^16 samples), the
+    largest value is within 0.1 % of r -- a mask confined to a sparse subset of F_r would fail both."""
+    import ctypes as C
+    n = 1 << 16
+    key = bytes((7 * i + 1) & 0xff for i in range(32))
+    out = ctx.alloc(n * 32)
+    ctx.fr_random_dev(out.ptr, n, key, stream_id=5)
+    raw = ctx.download(out, (n, 4))
+    vals = cv.fr_from_mont(raw)
+    assert all(0 <= v < O.R_MOD for v in vals)
+    # element i against the host's block function: the device forms (lo + 2^256 hi) * 2^261 mod r (its internal Montgomery
+    # form, 9 x 29 bits) and stores those words in the reference's layout (R = 2^256), i.e. the value wide * 2^5 mod r
+    lib = ctx.lib
+    for i in (0, 1, 12345, n - 1):
+        w = (C.c_uint32 * 4)(i, 0, 5, 0)
+        blk = (C.c_uint8 * 64)()
+        assert lib.zk_chacha_block(key, w, 20, blk) == 0
+        wide = int.from_bytes(bytes(blk), "little")
+        assert vals[i] == wide * 32 % O.R_MOD
+    bins = [0] * 8
+    for v in vals:
+        bins[v * 8 // O.R_MOD] += 1
+    chi2 = sum((b - n / 8) ** 2 / (n / 8) for b in bins)
+    assert chi2 < 30.0, bins                       # 7 degrees of freedom: P(chi2 > 30) ~ 1e-4
+    assert max(vals) > O.R_MOD - O.R_MOD // 1000 and min(vals) < O.R_MOD // 1000
+    assert len(set(vals)) == n
+    out2 = ctx.alloc(n * 32)
+    ctx.fr_random_dev(out2.ptr, n, key, stream_id=6)
+    assert cv.fr_from_mont(ctx.download(out2, (16, 4))) != vals[:16]
+    ctx.fr_random_dev(out2.ptr, n, key, stream_id=5)
+    assert np.array_equal(ctx.download(out2, (n, 4)), raw)
+    ctx.fr_random_dev(out2.ptr, 64)                                   # OS-keyed: just runs and differs
+    assert cv.fr_from_mont(ctx.download(out2, (16, 4))) != vals[:16]
 
 
 def test_native_rccl_open_single_rank(ctx):
@@ -350,21 +398,16 @@ def test_native_rccl_open_single_rank(ctx):
         vals = [rng.fr() for _ in range(1000)]
         v = ctx.upload(cv.fr_to_mont(vals))
         out = ctx.alloc(1000 * 32)
-        for mode in ("allgather", "a2a", None):
-            if mode:
-                os.environ["ZK_OPEN"] = mode
-            else:
-                os.environ.pop("ZK_OPEN", None)
+        for mode in (1, 2, 0):                              # all-gather, all-to-all of slices, by party count
+            ctx.comm_set_open_pattern(mode)
             for m in (1000, 999, 1):
                 ctx.dev_zero(out.ptr, 1000 * 32)
                 ctx.open_sum_fr_dev(v.ptr, m, out.ptr)
                 assert cv.fr_from_mont(ctx.download(out, (m, 4))) == vals[:m]
-        os.environ.pop("ZK_OPEN", None)
         w = ctx.upload(cv.fr_to_mont(vals))
         ctx.open_sum_fr_dev(w.ptr, 1000, w.ptr)           # in place
         assert cv.fr_from_mont(ctx.download(w, (1000, 4))) == vals
         with pytest.raises(Exception, match="already has a communicator"):
             ctx.comm_init(uid, 0, 1)
     finally:
-        os.environ.pop("ZK_OPEN", None)
         ctx.comm_destroy()

@@ -103,22 +103,20 @@ def _worker(rank, world, port, q):
             for part in a[1:]:
                 acc = OC.fr_vec_op(1, np.ascontiguousarray(acc), np.ascontiguousarray(part))
             dst[: m * 4] = torch.from_numpy(np.ascontiguousarray(acc).view(np.int64).reshape(-1))
-        for n_open in (1, 16, 17, 100):
+        for n_open in (1, 7, 16, 17, 100):
             vals = [[rng.fr() for _ in range(n_open)] for _ in range(world)]
             mine = torch.from_numpy(cv.fr_to_mont(vals[rank]).view(np.int64).reshape(-1).copy())
             want_sum = [sum(c) % O.R_MOD for c in zip(*vals)]
             for mode in ("a2a", "allgather", None):
-                if mode:
-                    os.environ["ZK_OPEN"] = mode
-                else:
-                    os.environ.pop("ZK_OPEN", None)
+                net.open_pattern = mode                       # the same choice on every rank (a DistNet constructor argument)
                 res = net.open_sum(mine, n_open, sum_parties, buffer)
                 got = cv.fr_from_mont(res.numpy().view(np.uint64).reshape(-1, 4)[:n_open])
                 assert got == want_sum, "open_sum(%s) wrong for n=%d" % (mode, n_open)
+        net.open_pattern = None
         # (6) king_share: the leader splits a vector and scatters the shares (transport scatter); they sum to the vector
         secret = [rng.fr() for _ in range(23)]
         S = be.put("secret", cv.fr_to_mont(secret)) if rank == 0 else None
-        mine = party.king_share_vec(S, 23, seed=5)
+        mine = party.king_share_vec(S, 23, key32=bytes([5] * 32))
         parts = [cv.fr_from_mont(a) for a in net.all_gather_small(be.store[mine])]
         assert [sum(c) % O.R_MOD for c in zip(*parts)] == secret
         assert parts[0] != secret or world == 1
@@ -130,8 +128,10 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_collaborative_prove_gloo(world):
+    """world = 8 is BASELINE config 5's party count (SPDZ shares, the all-to-all open with 8 slices on lengths that do not
+    divide by 8: mpc-net/src/multi.rs:469-525 ordering by party id, share/spdz.rs:177-196)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -146,6 +146,9 @@ PROTOTYPES = {
     "zk_groth16_hint_next_dev": (_I, [_P, _P]),
     "zk_groth16_prove_dev": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "zk_groth16_prove": (_I, [_P, _P, _P, _P, _P, _P, _P]),
+    "zk_groth16_prove_queued": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "zk_host_alloc": (_I, [_P, _SZ, C.POINTER(_P)]),
+    "zk_host_free": (_I, [_P, _P]),
     "zk_fr_powers_dev": (_I, [_P, _P, _P, _SZ, _P]),
     "zk_fr_batch_inverse_dev": (_I, [_P, _P, _SZ]),
     "zk_poly_evaluate_dev": (_I, [_P, _P, _SZ, _P, _P]),
@@ -162,6 +165,7 @@ PROTOTYPES = {
     "zk_comm_unique_id": (_I, [_P]),
     "zk_comm_init": (_I, [_P, _P, _I, _I]),
     "zk_comm_destroy": (_I, [_P]),
+    "zk_comm_set_open_pattern": (_I, [_P, _I]),
     "zk_open_sum_fr_dev": (_I, [_P, _P, _SZ, _P]),
     "zk_memcpy_d2d": (_I, [_P, _P, _P, _SZ]),
     "zk_dev_zero": (_I, [_P, _P, _SZ]),
@@ -182,6 +186,17 @@ PROTOTYPES = {
     "zk_fr_sum_parties_dev": (_I, [_P, _P, _SZ, _SZ, _P]),
     "zk_beaver_combine_dev": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ]),
     "zk_fr_vec_is_zero_dev": (_I, [_P, _P, _SZ, _P]),
+    "zk_fr_random_dev": (_I, [_P, _P, C.c_uint64, _P, _SZ]),
+    "zk_fsrng_new": (_I, [_P, _SZ, C.POINTER(_P)]),
+    "zk_fsrng_absorb": (_I, [_P, _P, _SZ]),
+    "zk_rng_from_seed": (_I, [_P, _I, C.POINTER(_P)]),
+    "zk_rng_free": (_I, [_P]),
+    "zk_rng_next_u64": (_I, [_P, _P]),
+    "zk_rng_next_u128": (_I, [_P, _P]),
+    "zk_rng_next_fr": (_I, [_P, _P]),
+    "zk_rng_fill_bytes": (_I, [_P, _P, _SZ]),
+    "zk_blake2s": (_I, [_P, _SZ, _P]),
+    "zk_chacha_block": (_I, [_P, _P, _I, _P]),
     "zk_set_profiling": (_I, [_P, _I]),
     "zk_last_timers": (_I, [_P, _P, _SZ, _P, _P, _I]),
 }

@@ -29,6 +29,91 @@ def _fr_struct(limbs4) -> _lib.Fr:
     return f
 
 
+class HostBuf:
+    """Page-locked host memory owned by a Context; `.array(shape)` is a numpy uint64 view of it."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = C.c_void_p()
+        ctx._ck(ctx.lib.zk_host_alloc(ctx.h, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def array(self, shape, dtype=np.uint64) -> np.ndarray:
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if n > self.nbytes:
+            raise ValueError("HostBuf too small")
+        buf = (C.c_uint8 * n).from_address(self.ptr)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr and self.ctx.h:
+            self.ctx.lib.zk_host_free(self.ctx.h, C.c_void_p(self.ptr))
+        self.ptr = None
+
+
+class Rng:
+    """Byte-exact host generators (zk_rng): FiatShamirRng<Blake2s> (Marlin's transcript), ChaChaRng, rand's StdRng."""
+
+    def __init__(self, h):
+        self.lib = _lib.load()
+        self.h = h
+
+    @classmethod
+    def fiat_shamir(cls, seed_bytes: bytes) -> "Rng":
+        lib = _lib.load()
+        h = C.c_void_p()
+        if lib.zk_fsrng_new(seed_bytes, len(seed_bytes), C.byref(h)) != 0:
+            raise ZkError("zk_fsrng_new failed")
+        return cls(h)
+
+    @classmethod
+    def from_seed(cls, seed32: bytes, rounds: int = 20) -> "Rng":
+        lib = _lib.load()
+        h = C.c_void_p()
+        if len(seed32) != 32 or lib.zk_rng_from_seed(seed32, rounds, C.byref(h)) != 0:
+            raise ZkError("zk_rng_from_seed failed")
+        return cls(h)
+
+    @classmethod
+    def test_rng(cls) -> "Rng":
+        """ark_std::test_rng() (arkworks/std/src/rand_helper.rs:31-39): StdRng (ChaCha12) from the fixed seed."""
+        seed = bytes([1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16)
+        return cls.from_seed(seed, 12)
+
+    def absorb(self, data: bytes):
+        if self.lib.zk_fsrng_absorb(self.h, data, len(data)) != 0:
+            raise ZkError("zk_fsrng_absorb: not a Fiat-Shamir generator")
+
+    def next_u64(self) -> int:
+        v = C.c_uint64()
+        self.lib.zk_rng_next_u64(self.h, C.byref(v))
+        return v.value
+
+    def next_u128(self) -> int:
+        v = (C.c_uint64 * 2)()
+        self.lib.zk_rng_next_u128(self.h, v)
+        return v[0] | (v[1] << 64)
+
+    def next_fr(self) -> np.ndarray:
+        """Fr::rand: the element in the reference's in-memory (Montgomery) form, (4,) uint64."""
+        out = np.zeros(4, dtype=np.uint64)
+        self.lib.zk_rng_next_fr(self.h, _ptr(out))
+        return out
+
+    def fill_bytes(self, n: int) -> bytes:
+        buf = (C.c_uint8 * n)()
+        self.lib.zk_rng_fill_bytes(self.h, buf, n)
+        return bytes(buf)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.zk_rng_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class DevBuf:
     """A device allocation owned by a Context."""
 
@@ -357,6 +442,10 @@ class Context:
         assert buf.size == 128
         self._ck(self.lib.zk_comm_init(self.h, _ptr(buf), rank, n_parties))
 
+    def comm_set_open_pattern(self, pattern: int):
+        """0: by party count, 1: all-gather, 2: all-to-all of slices (every party must choose the same)."""
+        self._ck(self.lib.zk_comm_set_open_pattern(self.h, pattern))
+
     def comm_destroy(self):
         self._ck(self.lib.zk_comm_destroy(self.h))
 
@@ -364,6 +453,12 @@ class Context:
         self._ck(self.lib.zk_open_sum_fr_dev(self.h, C.c_void_p(int(v)), n, C.c_void_p(int(out))))
 
     # ---- share algebra ----
+    def fr_random_dev(self, out, n: int, key32: bytes = None, stream_id: int = 0):
+        """n uniform field elements (zk_fr_random_dev).  key32 = None: keyed from the operating system's CSPRNG."""
+        if key32 is not None and len(key32) != 32:
+            raise ValueError("key32 must be 32 bytes")
+        self._ck(self.lib.zk_fr_random_dev(self.h, key32, C.c_uint64(stream_id), C.c_void_p(int(out)), n))
+
     def fr_sum_parties_dev(self, gathered, n_parties: int, n: int, out):
         self._ck(self.lib.zk_fr_sum_parties_dev(self.h, C.c_void_p(int(gathered)), n_parties, n, C.c_void_p(int(out))))
 
@@ -506,6 +601,22 @@ class Context:
     def groth16_hint_next_dev(self, z_next_dev):
         """Announce the assignment of the next create_proof_dev call (same key and constraint system); None withdraws."""
         self._ck(self.lib.zk_groth16_hint_next_dev(self.h, C.c_void_p(int(z_next_dev)) if z_next_dev else None))
+
+    def host_alloc(self, nbytes: int) -> "HostBuf":
+        """Page-locked host memory (zk_host_alloc) viewed as a numpy uint64 array."""
+        return HostBuf(self, nbytes)
+
+    def create_proof_queued(self, pk: "ProvingKey", r1cs: "R1cs", z_host: np.ndarray, r_mont4, s_mont4, z_next_host=None) -> bytes:
+        """zk_groth16_prove_queued: host assignment -> 192 proof bytes; z_next_host announces the next call's assignment.
+        The arrays are passed by address and must be C-contiguous uint64 (n, 4); keep them alive and unchanged."""
+        r, s = _fr_struct(r_mont4), _fr_struct(s_mont4)
+        out = np.zeros(192, dtype=np.uint8)
+        for a in (z_host, z_next_host):
+            if a is not None and not (a.flags["C_CONTIGUOUS"] and a.dtype == np.uint64):
+                raise ValueError("assignments must be C-contiguous uint64 arrays")
+        self._ck(self.lib.zk_groth16_prove_queued(self.h, pk.h, r1cs.h, _ptr(z_host), C.byref(r), C.byref(s),
+                                                  _ptr(z_next_host) if z_next_host is not None else None, _ptr(out)))
+        return out.tobytes()
 
     def groth16_msms_presort_dev(self, pk: "ProvingKey", r1cs: "R1cs", z_dev):
         """Enqueue the shared sort of z[1..] ahead of groth16_msms_dev on the same z_dev (asynchronous)."""

@@ -58,7 +58,7 @@ Rccl* rccl(std::string* err) {
     return &r;
 }
 
-struct Comm { ncclComm_t comm = nullptr; int rank = 0, n = 1; };
+struct Comm { ncclComm_t comm = nullptr; int rank = 0, n = 1; int pattern = 0; };   // pattern: zk_comm_set_open_pattern
 
 #define ZK_NCCL(ctx, R, expr)                                                                   \
     do {                                                                                          \
@@ -115,6 +115,15 @@ extern "C" int zk_comm_destroy(zk_ctx* ctx) {
     return ZK_OK;
 }
 
+// 0: by party count (all-gather for two parties, all-to-all of slices for three or more); 1: all-gather; 2: all-to-all.
+// Every party of the communicator must make the same call.
+extern "C" int zk_comm_set_open_pattern(zk_ctx* ctx, int pattern) {
+    if (!ctx || pattern < 0 || pattern > 2) return ZK_ERR_ARG;
+    if (!ctx->comm) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_comm_set_open_pattern: no communicator (zk_comm_init)");
+    ((Comm*)ctx->comm)->pattern = pattern;
+    return ZK_OK;
+}
+
 // out[i] = sum over parties of v[i] mod r, on every party (v, out: n field elements on the device; out may alias v)
 extern "C" int zk_open_sum_fr_dev(zk_ctx* ctx, const void* v_dev, size_t n, void* out_dev) {
     if (!ctx || (n && (!v_dev || !out_dev))) return ZK_ERR_ARG;
@@ -125,8 +134,9 @@ extern "C" int zk_open_sum_fr_dev(zk_ctx* ctx, const void* v_dev, size_t n, void
     if (!R) return ZK_ERR_STATE;
     const int P = c->n;
     hipStream_t st = ctx->stream;
-    const char* mode = getenv("ZK_OPEN");
-    const bool a2a = mode ? strcmp(mode, "a2a") == 0 : P >= 3;
+    // the exchange pattern is a property of the communicator (party count, or zk_comm_set_open_pattern on every party):
+    // parties that disagreed about it would wait for each other in different collectives
+    const bool a2a = c->pattern ? c->pattern == 2 : P >= 3;
     if (!a2a) {
         void* recv;
         ZK_TRY(zk_scratch(ctx, "open_recv", (size_t)P * n * 32, &recv));
@@ -142,11 +152,17 @@ extern "C" int zk_open_sum_fr_dev(zk_ctx* ctx, const void* v_dev, size_t n, void
     ZK_HIP(ctx, hipMemcpyAsync(send, v_dev, n * 32, hipMemcpyDeviceToDevice, st));
     if ((size_t)P * chunk > n) ZK_HIP(ctx, hipMemsetAsync(send + n * 32, 0, ((size_t)P * chunk - n) * 32, st));
     ZK_NCCL(ctx, R, R->GroupStart());
-    for (int p = 0; p < P; p++) {
-        ZK_NCCL(ctx, R, R->Send(send + (size_t)p * chunk * 32, chunk * 4, ncclUint64, p, c->comm, st));     // slice p goes to party p
-        ZK_NCCL(ctx, R, R->Recv(recv + (size_t)p * chunk * 32, chunk * 4, ncclUint64, p, c->comm, st));     // my slice of party p
+    ncclResult_t ge = ncclSuccess;
+    for (int p = 0; p < P && ge == ncclSuccess; p++) {
+        ge = R->Send(send + (size_t)p * chunk * 32, chunk * 4, ncclUint64, p, c->comm, st);                  // slice p goes to party p
+        if (ge == ncclSuccess) ge = R->Recv(recv + (size_t)p * chunk * 32, chunk * 4, ncclUint64, p, c->comm, st);   // my slice of party p
     }
-    ZK_NCCL(ctx, R, R->GroupEnd());
+    const ncclResult_t ge_end = R->GroupEnd();     // always closed: an open group would hang every later collective on this communicator
+    if (ge != ncclSuccess || ge_end != ncclSuccess) {
+        ctx->last_error = std::string("zk_open_sum_fr_dev: ncclSend/ncclRecv group -> ") +
+                          (R->GetErrorString ? R->GetErrorString(ge != ncclSuccess ? ge : ge_end) : "rccl error");
+        return ZK_ERR_HIP;
+    }
     ZK_TRY(zk_fr_sum_parties_dev(ctx, recv, (size_t)P, chunk, part));
     ZK_NCCL(ctx, R, R->AllGather(part, full, chunk * 4, ncclUint64, c->comm, st));
     ZK_HIP(ctx, hipMemcpyAsync(out_dev, full, n * 32, hipMemcpyDeviceToDevice, st));

@@ -51,6 +51,8 @@ extern "C" int zk_ctx_destroy(zk_ctx* ctx) {
     zk_domains_free(ctx);
     for (auto st : ctx->aux) (void)hipStreamDestroy(st);
     if (ctx->acc_stream) (void)hipStreamDestroy(ctx->acc_stream);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->next_z_ready) (void)hipEventDestroy(ctx->next_z_ready);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return ZK_OK;
@@ -77,6 +79,20 @@ extern "C" int zk_dev_free(zk_ctx* ctx, void* dev) {
     if (!ctx) return ZK_ERR_ARG;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZK_HIP(ctx, hipFree(dev));
+    return ZK_OK;
+}
+
+// Page-locked host memory for buffers that cross the boundary often (an assignment vector handed to zk_groth16_prove:
+// 32 MiB at 2^20 variables copies in ~0.6 ms from pinned memory, several ms from pageable memory).
+extern "C" int zk_host_alloc(zk_ctx* ctx, size_t bytes, void** host_out) {
+    if (!ctx || !host_out) return ZK_ERR_ARG;
+    ZK_HIP(ctx, hipSetDevice(ctx->device));
+    ZK_HIP(ctx, hipHostMalloc(host_out, bytes ? bytes : 16, hipHostMallocDefault));
+    return ZK_OK;
+}
+extern "C" int zk_host_free(zk_ctx* ctx, void* host) {
+    if (!ctx) return ZK_ERR_ARG;
+    if (host) ZK_HIP(ctx, hipHostFree(host));
     return ZK_OK;
 }
 

@@ -37,6 +37,13 @@ struct zk_ctx {
     void* comm = nullptr;                     // RCCL communicator of this party (comm.hip), created by zk_comm_init
     void* presort = nullptr;                  // groth16.hip: a sort of z[1..] enqueued ahead of zk_groth16_msms_dev (ZkPresort)
     const void* next_z = nullptr;             // groth16.hip: zk_groth16_hint_next_dev
+    // groth16.hip: zk_groth16_hint_next (host-slice form): the announced assignment is uploaded on its own stream into the
+    // idle one of two device slots while the current proof runs; next_z_ready is recorded behind that copy
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t next_z_ready = nullptr;
+    const void* next_z_host = nullptr;        // the host buffer that was announced (matched by address by zk_groth16_prove)
+    void* next_z_dev = nullptr;               // where its copy lives
+    int z_slot = 0;                           // which of the two "prove_z" slots the CURRENT proof reads
     std::mutex mu;
     // timing of the most recent instrumented call (ms), filled when ZK_PROFILE env or explicit request
     struct Timer { float ms = 0; int count = 0; };

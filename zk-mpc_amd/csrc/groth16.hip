@@ -214,6 +214,7 @@ extern "C" int zk_r1cs_upload(zk_ctx* ctx, const zk_r1cs_host* h, zk_r1cs** out)
 
 extern "C" int zk_r1cs_free(zk_ctx* ctx, zk_r1cs* r) {
     if (!r) return ZK_OK;
+    zk_presort_free(ctx);          // see zk_pk_free
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     for (auto& m : r->m) {
         if (m.row_ptr) (void)hipFree(m.row_ptr);
@@ -316,6 +317,9 @@ static int pk_make_l_pad(zk_ctx* ctx, zk_pk* pk) {
 
 extern "C" int zk_pk_free(zk_ctx* ctx, zk_pk* pk) {
     if (!pk) return ZK_OK;
+    // a pending presort / front (ZkPresort) is matched by address: it must not outlive the objects it points to, or a new
+    // key allocated at the same address would adopt a sort of the old key's tables
+    zk_presort_free(ctx);
     zk_bases* all[7] = {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l, pk->gamma_abc, pk->l_pad};
     for (auto* b : all) zk_bases_free(ctx, b);
     delete pk;
@@ -629,7 +633,13 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         ctx->next_z = nullptr;
         std::unique_ptr<ZkPresort> nf(new ZkPresort());
         nf->pk = pk; nf->z = zn; nf->r = r; nf->h = h_scratch; nf->front = true;
-        for (int k = 0; k < 4; k++)
+        if (zn == ctx->next_z_dev && ctx->next_z_ready) {      // announced from the host: its upload runs on the copy stream
+            ZK_HIP(ctx, hipStreamWaitEvent(s_acc, ctx->next_z_ready, 0));
+            ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->next_z_ready, 0));
+        }
+        // every reduce chain of THIS proof reads its job's segment tables (k_fold: ctr / heavy live in the sort scratch of the
+        // job's slot): the next proof's sorts rewrite slots 1 (z) and 5 (h), so both streams wait for all five chains
+        for (int k = 0; k < 5; k++)
             if (J[k]->reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(s_acc, J[k]->reduce_done, 0));
         rc = zk_msm_prepare(ctx, &nf->job, pk->b_g2, 1, (const char*)zn + 32, nvars, 1);
         if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &nf->job, s_acc, nullptr);
@@ -638,6 +648,8 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
             ZK_HIP(ctx, hipEventCreateWithFlags(&nf->wm_done, hipEventDisableTiming));
             ZK_HIP(ctx, hipEventRecord(nf->wm_done, ctx->stream));
             if (J[4]->accum_done) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, J[4]->accum_done, 0));
+            for (int k = 0; k < 5; k++)     // H's own chain (slot 5: k_fold reads ctr / heavy there) may be on the other stream
+                if (J[k]->reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, J[k]->reduce_done, 0));
             rc = zk_msm_prepare(ctx, &nf->jobh, pk->h, 0, h_scratch, std::min(pk->h->n, D), 5);
             nf->jobh.counting_sort = h_counting ? 1 : 0;
             if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &nf->jobh, ctx->stream, nullptr);
@@ -824,12 +836,44 @@ extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs*
     return ZK_OK;
 }
 
+// Host-slice prover for a queue: `z_host` is proved now, `z_next_host` (or NULL) is the assignment of the next call.  The
+// next assignment is uploaded at once on a copy stream into the one of two device slots this proof does not read, and this
+// proof enqueues its front exactly as zk_groth16_hint_next_dev does.  When the next call names the announced buffer (matched
+// by address: it must stay unchanged in between) nothing is copied again.  Page-locked memory (zk_host_alloc) makes the
+// upload asynchronous.
+extern "C" int zk_groth16_prove_queued(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const zk_fr* z_host, const zk_fr* r_,
+                                       const zk_fr* s_, const zk_fr* z_next_host, uint8_t proof[192]) {
+    if (!ctx || !pk || !r || !z_host) return ZK_ERR_ARG;
+    const size_t m = r->ni + r->nw;
+    void* z;
+    if (ctx->next_z_host == z_host && ctx->next_z_dev) {
+        // announced by the previous call: already uploaded (the front that reads it waited for the copy)
+        z = ctx->next_z_dev;
+        ctx->z_slot ^= 1;
+        ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->next_z_ready, 0));
+    } else {
+        ZK_TRY(zk_scratch(ctx, ctx->z_slot ? "prove_z1" : "prove_z0", m * 32, &z));
+        ZK_HIP(ctx, hipMemcpyAsync(z, z_host, m * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->next_z_host = nullptr;
+    ctx->next_z_dev = nullptr;
+    ctx->next_z = nullptr;
+    if (z_next_host) {
+        if (!ctx->copy_stream) ZK_HIP(ctx, zk_stream_create(&ctx->copy_stream, false));
+        if (!ctx->next_z_ready) ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->next_z_ready, hipEventDisableTiming));
+        void* zn;
+        // the other slot: its last reader was the previous proof, which has delivered its bytes
+        ZK_TRY(zk_scratch(ctx, ctx->z_slot ? "prove_z0" : "prove_z1", m * 32, &zn));
+        ZK_HIP(ctx, hipMemcpyAsync(zn, z_next_host, m * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+        ZK_HIP(ctx, hipEventRecord(ctx->next_z_ready, ctx->copy_stream));
+        ctx->next_z_host = z_next_host;
+        ctx->next_z_dev = zn;
+        ctx->next_z = zn;
+    }
+    return zk_groth16_prove_dev(ctx, pk, r, z, r_, s_, proof);
+}
+
 extern "C" int zk_groth16_prove(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const zk_fr* z_host, const zk_fr* r_, const zk_fr* s_,
                                 uint8_t proof[192]) {
-    if (!ctx || !pk || !r || !z_host) return ZK_ERR_ARG;
-    size_t m = r->ni + r->nw;
-    void* z;
-    ZK_TRY(zk_scratch(ctx, "prove_z", m * 32, &z));
-    ZK_HIP(ctx, hipMemcpyAsync(z, z_host, m * 32, hipMemcpyHostToDevice, ctx->stream));
-    return zk_groth16_prove_dev(ctx, pk, r, z, r_, s_, proof);
+    return zk_groth16_prove_queued(ctx, pk, r, z_host, r_, s_, nullptr, proof);
 }

@@ -1051,6 +1051,7 @@ extern "C" int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* h, size_t n, 
 extern "C" int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* h, size_t n, zk_bases** out) { return bases_upload_t<G2Field>(ctx, h, n, 2, out); }
 extern "C" int zk_bases_free(zk_ctx* ctx, zk_bases* b) {
     if (!b) return ZK_OK;
+    zk_presort_free(ctx);          // a pending presort's job points into b->dev / b->pre (groth16.hip: zk_pk_free)
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     if (b->owned && b->dev) (void)hipFree(b->dev);
     if (b->pre) (void)hipFree(b->pre);

@@ -40,10 +40,16 @@ import numpy as np
 class DistNet:
     """torch.distributed transport: backend "nccl" (= RCCL) for device buffers, "gloo" on CPU."""
 
-    def __init__(self, dist, device=None):
+    def __init__(self, dist, device=None, open_pattern=None):
+        """open_pattern: None = by party count (all-gather for two parties, all-to-all of slices for three or more),
+        "allgather" or "a2a" to force one; a constructor argument, not an environment variable: every party of a run
+        must make the same choice, or the parties wait for each other in different collectives."""
         import torch
         self.torch = torch
         self.dist = dist
+        if open_pattern not in (None, "allgather", "a2a"):
+            raise ValueError("open_pattern must be None, 'allgather' or 'a2a'")
+        self.open_pattern = open_pattern
         self.rank = dist.get_rank()
         self.n = dist.get_world_size()
         self.device = device if device is not None else torch.device("cpu")
@@ -73,7 +79,7 @@ class DistNet:
         buffer(name, nbytes) -> int64 tensor that stays valid until the next call with the same name."""
         N = self.n
         words = 4 * n
-        if N < 3 and os.environ.get("ZK_OPEN") != "a2a" or os.environ.get("ZK_OPEN") == "allgather":
+        if (N < 3 and self.open_pattern != "a2a") or self.open_pattern == "allgather":
             recv = buffer("open_recv", N * n * 32)
             self.dist.all_gather_into_tensor(recv, send[:words])
             out = buffer("open_out", n * 32)
@@ -236,28 +242,30 @@ class GpuBackend:
     def beaver_combine(self, sx, oy, tx, ty, tz, out, n):
         self.ctx.beaver_combine_dev(sx, oy, out, n, triple=(tx, ty, tz))
 
-    def king_share(self, values, n, seed):
-        """AdditiveFieldShare::king_share over a vector: the leader draws N-1 random share vectors, sets the last to
-        values - sum, and scatters them (share/additive.rs:98-107); `values` is a device vector on the leader, ignored
-        elsewhere.  Returns this party's share (device vector)."""
+    def king_share(self, values, n, key32=None):
+        """AdditiveFieldShare::king_share over a vector: the leader draws N-1 uniform share vectors (F::rand per element:
+        zk_fr_random_dev, ChaCha20 keyed from the operating system's CSPRNG; one stream id per receiving party), sets the
+        last to values - sum, and scatters them (share/additive.rs:98-107); `values` is a device vector on the leader,
+        ignored elsewhere.  key32: a 32-byte ChaCha20 key for reproducible shares -- tests only; the default (None) must be
+        used whenever the values are secret.  Returns this party's share (device vector)."""
         import torch
         ctx, net = self.ctx, self.net
         N = net.n
         parts = None
         if net.is_leader():
             dev = torch.device("cuda", ctx.device)
-            g = torch.Generator(device=dev)
-            g.manual_seed(int(seed))
+            if key32 is None:
+                key32 = os.urandom(32)          # one key per call; the N - 1 vectors take distinct stream ids under it
             parts = []
             last = torch.empty(n * 4, dtype=torch.int64, device=dev)
             torch.cuda.synchronize()
             ctx.memcpy_d2d(last.data_ptr(), values, n * 32)
-            for _ in range(N - 1):
-                t = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device=dev, generator=g)
-                t[:, 3] &= (1 << 60) - 1              # < 2^252 < r: a valid residue
+            for p in range(N - 1):
+                t = torch.empty(n * 4, dtype=torch.int64, device=dev)
                 torch.cuda.synchronize()
+                ctx.fr_random_dev(t.data_ptr(), n, key32, stream_id=p)
                 ctx.fr_vec_op_dev(2, last.data_ptr(), t.data_ptr(), last.data_ptr(), n)
-                parts.append(t.reshape(-1))
+                parts.append(t)
             ctx.sync()
             parts.append(last)
         if isinstance(net, DistNet):
@@ -335,6 +343,11 @@ class Party:
             dev = torch.device("cuda", ctx.device) if (dist.get_backend() == "nccl") else torch.device("cpu")
             net = DistNet(dist, dev)
         self.net = net
+        # leadership is decided from net.rank here and from ctx->party_id inside the library (zk_beaver_combine_dev adds
+        # the public sx*oy term on party 0): the two must be the same party, or every rank adds it
+        if ctx is not None and backend is None and (ctx.party_id != net.rank or ctx.n_parties != net.n):
+            raise ValueError("Party: Context(party_id=%d, n_parties=%d) does not match the transport (rank %d of %d)"
+                             % (ctx.party_id, ctx.n_parties, net.rank, net.n))
         self.be = backend if backend is not None else GpuBackend(ctx, net)
         self.ctx = ctx
         # ZK_TRANSPORT=native: the share-vector opens go through the library's own RCCL communicator (comm.hip) instead of
@@ -345,12 +358,23 @@ class Party:
             net.dist.broadcast_object_list(box, src=0)
             ctx.comm_init(box[0], net.rank, net.n)
             self.be.native_open = True
-        self._pk_cache = {}
         self.bytes_sent = 0   # payload bytes this party contributed to opens (cf. mpc-net/src/multi.rs:527-536)
 
     @property
     def leader(self) -> bool:
         return self.net.is_leader()
+
+    def _pk_points(self, pk):
+        """The key's O(1) public points, fetched once and kept ON the key object (a cache keyed by id(pk) would hand a new
+        key allocated at a recycled address the old key's points)."""
+        P = getattr(pk, "_mpc_points", None)
+        if P is None:
+            P = self.be.pk_points(pk)
+            try:
+                pk._mpc_points = P
+            except AttributeError:
+                pass
+        return P
 
     # ---- sharing helpers (input distribution; not on the proving path) ----
     def share_scalars(self, values, seed: int):
@@ -365,10 +389,11 @@ class Party:
             out.append(fr_to_mont([sh[self.net.rank]])[0])
         return out
 
-    def king_share_vec(self, values, n: int, seed: int = 0):
-        """Input distribution by the leader (Reveal::king_share / king_share_batch): see GpuBackend.king_share."""
+    def king_share_vec(self, values, n: int, key32=None):
+        """Input distribution by the leader (Reveal::king_share / king_share_batch): see GpuBackend.king_share.
+        key32 = None (the default, and the only choice for secret inputs): masks keyed from the OS CSPRNG."""
         self.bytes_sent += (self.net.n - 1) * n * 32 if self.leader else 0
-        return self.be.king_share(values, n, seed)
+        return self.be.king_share(values, n, key32)
 
     def share_assignment_dev(self, z_dev, r1cs, seed: int):
         """This party's additive share of a full assignment that is resident on its own device
@@ -479,10 +504,7 @@ class Party:
         be.witness_map_post(r1cs, a, c)                            # h shares in `a`
         g1, g2 = be.msms(pk, r1cs, z_share, a)                     # party-local MSMs (multi_scale_pub_group)
         h_acc, l_acc, a_acc, b1_acc = g1[0], g1[1], g1[2], g1[3]
-        key = id(pk)
-        if key not in self._pk_cache:
-            self._pk_cache[key] = be.pk_points(pk)
-        P = self._pk_cache[key]
+        P = self._pk_points(pk)
         pub1 = (lambda x: x) if self.leader else (lambda x: be.g1_zero())   # shift(): leader only
         pub2 = (lambda x: x) if self.leader else (lambda x: be.g2_zero())
         r_g1 = be.g1_mul(P["delta_g1"], r_share)                   # public point * shared scalar: local
@@ -735,10 +757,7 @@ class SpdzParty(Party):
         for lane in (0, 1):
             be.witness_map_post(r1cs, lanes[lane][0], lanes[lane][2])
             msm.append(be.msms(pk, r1cs, z_share[lane], lanes[lane][0]))       # 2 x 5 MSMs (spdz.rs:482-488)
-        key = id(pk)
-        if key not in self._pk_cache:
-            self._pk_cache[key] = be.pk_points(pk)
-        P = self._pk_cache[key]
+        P = self._pk_points(pk)
         pair = lambda f: tuple(f(lane) for lane in (0, 1))
         pub1 = (lambda x: x) if self.leader else (lambda x: be.g1_zero())      # shift: leader's sh; mac += mac_share * G
         pub2 = (lambda x: x) if self.leader else (lambda x: be.g2_zero())
