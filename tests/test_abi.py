@@ -121,14 +121,14 @@ def test_field_add_sub_boundaries():
 
 
 def test_fused_double_product_boundaries():
-    """fp_mul2 (a b + c d with one Montgomery reduction, the core of the Fq2 product) leaves up to 2.68 p before its two
-    conditional subtractions: operands next to p drive it through every range ([0,p), [p,2p), [2p,2.68p))."""
+    """fp_mul2 (a b + c d with one Montgomery reduction, the core of the Fq2 product), exact form: with Fq's 14 Montgomery
+    digits (RI = 2^406) the value before the single conditional subtraction is below q + 2^355; operands next to q."""
     import ctypes as C
     lib = Z.load()
     q = O.Q_MOD
     to_m = lambda v: np.ascontiguousarray(cv._ints_to_limbs([cv.fq_to_mont_int(v)], 6)[0])
     from_m = lambda a: cv.fq_from_mont_int(cv._limbs_to_ints(a.reshape(1, 6))[0])
-    RI = 1 << (29 * 13)
+    RI = 1 << (29 * 14)
     R = (1 << 384) % q
     rng = O.Prng(123)
     seen = set()
@@ -144,10 +144,12 @@ def test_fused_double_product_boundaries():
                 assert lib.zk_fq_mul2(*[x.ctypes.data_as(C.c_void_p) for x in args], out.ctypes.data_as(C.c_void_p)) == 0
                 assert from_m(out) == (a * b + c * d) % q
                 ra, rb, rc, rd = [(v * R) % q for v in (a, b, c, d)]
-                t = ra * rb + rc * rd
+                t = (ra * RI * pow(1 << 384, -1, q) % q) * (rb * RI * pow(1 << 384, -1, q) % q) + \
+                    (rc * RI * pow(1 << 384, -1, q) % q) * (rd * RI * pow(1 << 384, -1, q) % q)      # on the device's internal residues
                 pre = (t + ((-t * pow(q, -1, RI)) % RI) * q) // RI
-                seen.add(min(pre // q, 2))
-    assert seen == {0, 1, 2}
+                assert pre < q + (1 << 355)
+                seen.add(pre // q)
+    assert seen <= {0, 1}
 
 
 def test_neg5_almost_range_and_congruence():
@@ -172,3 +174,162 @@ def test_neg5_almost_range_and_congruence():
         assert all(int(x) < (1 << 29) for x in out)
         v = val(out)
         assert (v + 5 * a) % q == 0 and 0 < v <= q + (q >> 24)
+
+
+# ---- the lazy domain of Fq (fp29.cuh): representatives in [0, ~7 q], no conditional subtractions -----------------------------
+
+Q = O.Q_MOD
+RI14 = 1 << (29 * 14)
+EPS = 1 << 354
+
+
+def _limbs_wide(v):
+    """13 limbs: 12 of 29 bits and a top limb holding the rest (< 2^32)."""
+    assert 0 <= v < (1 << (29 * 12 + 32))
+    return [(v >> (29 * i)) & ((1 << 29) - 1) for i in range(12)] + [v >> (29 * 12)]
+
+
+def _val(a):
+    return sum(int(x) << (29 * i) for i, x in enumerate(a))
+
+
+def _lazy(op, *vals, n_out=1):
+    import ctypes as C
+    lib = Z.load()
+    inp = np.array([l for v in vals for l in _limbs_wide(v)], dtype=np.uint32)
+    out = np.zeros(13 * n_out, dtype=np.uint32)
+    assert lib.zk_fq_lazy_raw(op, inp.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+    return [out[13 * k:13 * k + 13] for k in range(n_out)]
+
+
+def _normalised(a, top_bits=29):
+    return all(int(x) < (1 << 29) for x in a[:12]) and int(a[12]) < (1 << top_bits)
+
+
+def _worst_columns(tops, split_top=False):
+    """Worst-case column sums (in the order the kernels accumulate them) of the product scanning with every low limb at
+    2^29 - 1, the given top limbs per operand ((a, b) or (a, b, c, d)) and every Montgomery digit at its maximum."""
+    L, LR = 13, 14
+    pl = [(Q >> (29 * i)) & ((1 << 29) - 1) for i in range(13)]
+    mmax = (1 << 29) - 1
+    ops = [[(1 << 29) - 1] * 12 + [t] for t in tops]
+    carry, cols = 0, []
+    for k in range(LR + L - 1):
+        col, up = carry, 0
+        for i in range(L):
+            j = k - i
+            if 0 <= j < L:
+                col += ops[0][i] * ops[1][j]
+                if len(ops) == 4:
+                    t = ops[2][i] * ops[3][j]
+                    if split_top and k == 2 * L - 2:
+                        col += t & ((1 << 29) - 1)
+                        up = t >> 29
+                    else:
+                        col += t
+        for i in range(LR):
+            if 0 <= k - i < L:
+                col += mmax * pl[k - i]
+        cols.append(col)
+        carry = (col >> 29) + up
+    return cols
+
+
+def test_lazy_domain_column_bounds():
+    """The 64-bit column accumulator of the product-scanning multiplications cannot overflow for the operand ranges the lazy
+    domain uses (ec.cuh::xyzz_madd_lazy, msm_g2pair.hip::madd_p_lazy): every low limb at 2^29 - 1, top limbs at the range
+    ends.  Four operands of 7 q DO overflow the top column -- that is what fp_mul2_lazy's TOPSPLIT is for."""
+    top = lambda k: ((k * Q + 2 * EPS) >> 348) + 1
+    assert max(_worst_columns((top(7), top(7)))) < (1 << 64)                       # P^2, P * X1-wide, R * T in G1
+    assert max(_worst_columns((top(3), top(7), top(2), top(2)))) < (1 << 64)       # G1: R T + (2p - PPP) Y1
+    assert max(_worst_columns((top(7), top(7), top(1), top(7)))) < (1 << 64)       # G2 even lane of P^2: P0 P0 + (-5 P1) P1
+    assert max(_worst_columns((top(5), top(7), top(5), top(7)))) < (1 << 64)       # G2 odd lane of R * T
+    assert max(_worst_columns((top(5), top(5), top(5), top(5)))) < (1 << 64)       # G2 odd lane of R^2
+    four = _worst_columns((top(7), top(7), top(7), top(7)))
+    assert max(four) >= (1 << 64) and max(four[:24]) < (1 << 64)                    # only the top column (24) passes 2^64 ...
+    assert max(_worst_columns((top(7), top(7), top(7), top(7)), split_top=True)) < (1 << 64)   # ... and not with the split
+
+
+def test_lazy_domain_primitives_against_big_integers():
+    """mul / sqr / mul2 without the final subtraction, the K p - b carry passes, X3's fused pass, the -5 a estimate and the full
+    reduction, on raw limbs: congruent to the exact result modulo q, inside the stated range, limbs normalised -- for operands
+    at the range ends (0, q, 2q .. 7q + eps) and random ones."""
+    import random
+    rnd = random.Random(99)
+    ends = [0, 1, Q - 1, Q, Q + EPS - 1, 2 * Q, 3 * Q + EPS, 5 * Q + EPS - 1, 7 * Q + EPS - 1, 7 * Q + 2 * EPS - 1]
+    wide = ends + [rnd.randrange(7 * Q + EPS) for _ in range(40)]
+    inv = pow(RI14, -1, Q)
+    for a in wide:
+        for b in wide[::3]:
+            (r,) = _lazy(0, a, b)
+            assert _val(r) % Q == a * b * inv % Q and _val(r) < Q + EPS and _normalised(r)
+        (r,) = _lazy(1, a)
+        assert _val(r) % Q == a * a * inv % Q and _val(r) < Q + EPS and _normalised(r)
+        (v,) = _lazy(9, a)
+        assert (_val(v) + 5 * a) % Q == 0 and 0 < _val(v) <= Q + (Q >> 22) and _normalised(v)
+        (c,) = _lazy(7, a)
+        assert _val(c) == a % Q and _normalised(c)
+    for _ in range(300):
+        a, b, c, d = [rnd.choice(wide) for _ in range(4)]
+        (r,) = _lazy(2, a, b, c, d)
+        assert _val(r) % Q == (a * b + c * d) * inv % Q and _val(r) < Q + 2 * EPS and _normalised(r)
+    maxw = 7 * Q + 2 * EPS - 1
+    for quad in [(maxw, maxw, maxw, maxw), (maxw, maxw - 5, maxw - 1, maxw)] + [tuple(rnd.randrange(maxw) for _ in range(4)) for _ in range(100)]:
+        (r,) = _lazy(11, *quad)                     # split top column: four wide operands
+        a, b, c, d = quad
+        assert _val(r) % Q == (a * b + c * d) * inv % Q and _val(r) < Q + 2 * EPS and _normalised(r)
+    for op, K in ((3, 2), (4, 4), (5, 6)):
+        for _ in range(200):
+            a = rnd.choice(wide[:12] + [rnd.randrange(Q + EPS)])
+            a = min(a, Q + EPS - 1)
+            b = rnd.randrange(K * Q + 1) if rnd.random() < 0.8 else rnd.choice([0, K * Q, K * Q - 1, Q])
+            (r,) = _lazy(op, a, b)
+            assert _val(r) == a + K * Q - b and _normalised(r, 32)
+    for _ in range(300):
+        rr, ppp, qq = [rnd.choice([0, Q + EPS - 1, Q - 1, 1] + [rnd.randrange(Q + EPS)] * 3) for _ in range(3)]
+        (r,) = _lazy(6, rr, ppp, qq)
+        assert _val(r) == rr + 4 * Q - ppp - 2 * qq and _normalised(r, 32) and _val(r) < 5 * Q + EPS
+    for y in (1, Q - 1, rnd.randrange(Q)):
+        (r,) = _lazy(8, y)
+        assert _val(r) == Q - y and _normalised(r)
+
+
+def test_lazy_madd_matches_the_group_law():
+    """ec.cuh::xyzz_madd_lazy on the host against the oracle's affine group law: chains of mixed additions started from a
+    point, with accumulator coordinates left in the lazy ranges between steps (x < 5q + eps, y, zz, zzz < q + eps), incl.
+    the equal-x cases P + P (doubling) and P - P (infinity) and negated points given as q - y."""
+    rng = O.Prng(2024)
+    to_int = lambda v: v * RI14 % Q                      # internal Montgomery form of the device (RI = 2^406)
+    from_int = lambda v: v * pow(RI14, -1, Q) % Q
+
+    def affine_of(c):                                    # canonical XYZZ limbs -> affine point (or None)
+        x, y, zz, zzz = [from_int(_val(a)) for a in c]
+        if zz == 0:
+            return None
+        return (x * pow(zz, -1, Q) % Q, y * pow(zzz, -1, Q) % Q)
+
+    pts = [O.g1_mul(O.G1_GEN, rng.fr()) for _ in range(12)]
+    acc_pt = pts[0]
+    acc = [to_int(pts[0][0]), to_int(pts[0][1]), to_int(1), to_int(1)]
+    seq = pts[1:] + [None, "dbl", "neg"]
+    for step in seq * 2:
+        if step == "dbl":
+            q = acc_pt
+        elif step == "neg":
+            q = (acc_pt[0], Q - acc_pt[1])
+        elif step is None:
+            q = (pts[3][0], Q - pts[3][1])               # a negated table point, passed as q - y like the kernel does
+        else:
+            q = step
+        out = _lazy(10, *acc, to_int(q[0]), to_int(q[1]), n_out=8)
+        lazy, canon = out[:4], out[4:]
+        want = O.g1_add(acc_pt, q)
+        assert affine_of(canon) == want, step
+        vals = [_val(a) for a in lazy]
+        assert vals[0] < 5 * Q + EPS and vals[1] < Q + 2 * EPS and vals[2] < Q + EPS and vals[3] < Q + EPS
+        assert all(_val(c) == v % Q for c, v in zip(canon, vals))
+        if want is None:                                 # restart from a fresh point (the kernel's accumulator would be all-zero)
+            acc_pt = pts[5]
+            acc = [to_int(pts[5][0]), to_int(pts[5][1]), to_int(1), to_int(1)]
+        else:
+            acc_pt, acc = want, vals                     # continue from the LAZY representative

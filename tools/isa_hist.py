@@ -105,6 +105,14 @@ def main():
     out = {"kernel": head.rstrip(":"), "whole": summarise(allops, "whole kernel (static)")}
     big = max(bl, key=len)
     out["largest_block"] = summarise(big, "largest basic block")
+    if "--main" in sys.argv:          # --main 19,20: the basic blocks (by index, see --list) that make up the hot path
+        idx = [int(x) for x in sys.argv[sys.argv.index("--main") + 1].split(",")]
+        out["main_path"] = summarise([op for i in idx for op in bl[i]], "main path = blocks %s" % idx)
+        out["main_path"]["blocks"] = idx
+    if "--list" in sys.argv:
+        for i, b in enumerate(bl):
+            c = collections.Counter(classify(o) for o in b)
+            print("   block %3d: %5d instructions %s ends with %s" % (i, len(b), dict(c), b[-1]))
     if "--json" in sys.argv:
         json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
 

@@ -106,6 +106,38 @@ ZK_HD XYZZ<F> xyzz_madd(const XYZZ<F>& acc, const Affine<F>& q) {
     return XYZZ<F>{x3, y3, F::mul(pp, acc.zz), F::mul(ppp, acc.zzz)};
 }
 
+// acc + q in the LAZY domain (fp29.cuh): the same formulas, no conditional subtraction anywhere on the main path.
+//   acc: x < 5 p + eps, y < p + eps, zz, zzz < p + eps (eps = 2^354), infinity = all-zero words;   q: affine, x fully
+//   reduced, y fully reduced or p - y (<= p), not infinity (the caller tests that on the table's own words).
+// Ranges (every product lands in [0, p + eps)):  P = u2 + 6p - X1 < 7p + eps;  R = s2 + 2p - Y1 < 3p + eps;
+//   X3 = R^2 + 4p - PPP - 2Q in (p - 3 eps, 5p + eps);  T = Q + 6p - X3 < 7p + eps;  Y3 = (R T + (2p - PPP) Y1) / RI + < p.
+// The equal-x case (doubling / cancellation) is detected exactly: P = 0 mod p iff P is one of p .. 7p, whose low limbs are
+// 1 .. 7; only then (2^-26 of random additions) are P and R reduced and compared.
+template <class F>
+ZK_HD XYZZ<F> xyzz_madd_lazy(const XYZZ<F>& acc, const Affine<F>& q) {
+    using T = typename F::T;
+    if (F::is_zero(acc.zz)) return XYZZ<F>{q.x, q.y, F::one(), F::one()};
+    const T u2 = F::mul_l(q.x, acc.zz);
+    const T s2 = F::mul_l(q.y, acc.zzz);
+    const T p = F::template sub_kp<6>(u2, acc.x);
+    const T r = F::template sub_kp<2>(s2, acc.y);
+    if (F::maybe_multiple_of_p(p)) {
+        if (F::is_zero(F::canon(p))) {
+            if (F::is_zero(F::canon(r))) return xyzz_dbl_affine<F>(Affine<F>{q.x, F::canon1(q.y)});
+            return xyzz_inf<F>();
+        }
+    }
+    const T pp = F::sqr_l(p);
+    const T ppp = F::mul_l(pp, p);
+    const T qq = F::mul_l(pp, acc.x);
+    const T x3 = F::x3_l(F::sqr_l(r), ppp, qq);
+    const T y3 = F::mulsub_l(r, F::template sub_kp<6>(qq, x3), ppp, acc.y);
+    return XYZZ<F>{x3, y3, F::mul_l(pp, acc.zz), F::mul_l(ppp, acc.zzz)};
+}
+// back to fully reduced coordinates (end of a segment)
+template <class F>
+ZK_HD XYZZ<F> xyzz_canon_lazy(const XYZZ<F>& a) { return XYZZ<F>{F::canon(a.x), F::canon1(a.y), F::canon1(a.zz), F::canon1(a.zzz)}; }
+
 // a + b ("add-2008-s"), complete.
 template <class F>
 ZK_HD XYZZ<F> xyzz_add(const XYZZ<F>& a, const XYZZ<F>& b) {

@@ -12,8 +12,9 @@
 // < 26 * 2^58 < 2^63, so every limb product is exactly ONE v_mad_u64_u32 into a 64-bit
 // accumulator and there are no carry instructions at all inside the product.
 //
-// An element is L limbs of 29 bits, value = sum l[i] * 2^(29 i), always fully reduced (< p).
-// mmul(a, b) = a*b / 2^(29 L) mod p.   "internal" form of x is x * 2^(29 L) mod p.
+// An element is L limbs of 29 bits, value = sum l[i] * 2^(29 i), always fully reduced (< p) outside the lazy domain (below).
+// mmul(a, b) = a*b / RI mod p with RI = 2^(29 LR), LR = P::LR Montgomery digits (L for Fr, L + 1 for Fq).
+// "internal" form of x is x * RI mod p.
 // The reference's in-memory form ("external") is W 32-bit words holding x * 2^(32 W) mod p;
 // conversion constants are in consts.cuh.
 #pragma once
@@ -146,91 +147,136 @@ ZK_HD Fp<P> fp_neg_lazy(const Fp<P>& a) {
     return r;
 }
 
-// Montgomery product a*b/2^(29L) mod p, finely integrated product scanning, one 64-bit accumulator.
+// ---- Montgomery products, product scanning with ONE 64-bit accumulator -----------------------------------------------------
+// LR = P::LR Montgomery digits (radix RI = 2^(29 LR)), L = P::L operand limbs.  The *_lazy forms return the value before any
+// final subtraction:  (a b + m p) / RI  <  a b / RI + p.
+//   LR = L  (Fr, the 753-bit field): operands < p give a result < 2p; fp_mul subtracts p once.
+//   LR = L + 1 (Fq): RI = 2^29 * 2^(29 L) > 6e8 p, so ANY operands below 2^(29 L + 3) (up to ~7 p: the top limb may carry up to
+//     ~31.6 bits, the limbs below it must be < 2^29) give a result in [0, p + 2^(29 (L - 1) + 6)): "almost reduced", all limbs
+//     < 2^29.  That is what lets the bucket-accumulation kernels drop every conditional subtraction (the lazy domain, below).
+// Column sums: a column holds at most L products a_i b_j and L products m_i p_j of 29 x 29 bits (2 L * 2^58) plus, for
+// unnormalised operands, two products with one wide top limb and (top column only) one with two; for the operand bounds of
+// the lazy domain the worst column is < 2^63.8 (tests/test_abi.py::test_lazy_domain_column_bounds recomputes it).
 template <class P>
-ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
-    constexpr int L = P::L;
-    uint32_t m[L], r[L];
+ZK_HD Fp<P> fp_mul_lazy(const Fp<P>& a, const Fp<P>& b) {
+    constexpr int L = P::L, LR = P::LR;
+    uint32_t m[LR], r[L];
     uint64_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < L; k++) {
+    for (int k = 0; k < LR; k++) {
 #pragma unroll
-        for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+        for (int i = (k >= L ? k - L + 1 : 0); i <= (k < L ? k : L - 1); i++) acc += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+        for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
         m[k] = ((uint32_t)acc * P::INV) & MASK29;
         acc += (uint64_t)m[k] * P::P[0];
         acc >>= 29;
     }
 #pragma unroll
-    for (int k = L; k < 2 * L - 1; k++) {
+    for (int k = LR; k < LR + L - 1; k++) {
 #pragma unroll
-        for (int i = k - L + 1; i < L; i++) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            acc += (uint64_t)m[i] * P::P[k - i];
-        }
-        r[k - L] = (uint32_t)acc & MASK29;
+        for (int i = k - L + 1; i < L; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - L + 1; i < LR; i++) acc += (uint64_t)m[i] * P::P[k - i];
+        r[k - LR] = (uint32_t)acc & MASK29;
         acc >>= 29;
     }
     r[L - 1] = (uint32_t)acc;
-    return fp_reduce_once<P>(r);
+    Fp<P> o;
+#pragma unroll
+    for (int i = 0; i < L; i++) o.l[i] = r[i];
+    return o;
 }
 
-// (a b + c d) / 2^(29L) mod p with ONE Montgomery reduction: the two limb products share the column accumulator
-// (39 products < 2^58 per column, < 2^64) and the reduction terms.  3 L^2 mads instead of 4 L^2 for two separate
-// products, and no field addition afterwards.  The value before the final subtraction is < (2 p^2 + 2^(29L) p) / 2^(29L)
-// < 2.68 p for BLS12-377's q (0.84 * 2^377), hence two conditional subtractions.  Used by the Fq2 product: measured
-// (tools/ubench_fq2.hip) 21.9 G Fq2-mul/s against 18.5 for Karatsuba with three separate products.
+template <class P>
+ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
+    const Fp<P> t = fp_mul_lazy<P>(a, b);
+    return fp_reduce_once<P>(t.l);
+}
+
+// (a b + c d) / RI with ONE Montgomery reduction: the two limb products share the column accumulator and the reduction
+// terms (3 L^2 mads instead of 4 L^2 for two separate products, no field addition afterwards).  Lazy result < (a b + c d) / RI
+// + p.  Used by the Fq2 product: measured (tools/ubench_fq2.hip) 21.9 G Fq2-mul/s against 18.5 for Karatsuba with three
+// separate products.
+// TOPSPLIT: all four operands may have wide top limbs (up to 7 p each: the odd lane of an Fq2 squaring, a0 a1 + a1 a0).  Then
+// the top column alone -- a_top b_top + c_top d_top, 2 * 5.9^2 * 2^58 -- would pass 2^64, so the second of those products is
+// entered in two parts, its low 29 bits in that column and the rest one column up (every other column stays below 2^63.8).
+template <class P, bool TOPSPLIT = false>
+ZK_HD Fp<P> fp_mul2_lazy(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d) {
+    constexpr int L = P::L, LR = P::LR;
+    static_assert(!TOPSPLIT || LR > L, "the split top column is a column of the result part");
+    uint32_t m[LR], r[L];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < LR; k++) {
+#pragma unroll
+        for (int i = (k >= L ? k - L + 1 : 0); i <= (k < L ? k : L - 1); i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+        }
+#pragma unroll
+        for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+        m[k] = ((uint32_t)acc * P::INV) & MASK29;
+        acc += (uint64_t)m[k] * P::P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = LR; k < LR + L - 1; k++) {
+        uint64_t up = 0;
+#pragma unroll
+        for (int i = k - L + 1; i < L; i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            if (TOPSPLIT && k == 2 * L - 2) {
+                const uint64_t t = (uint64_t)c.l[i] * d.l[k - i];
+                acc += t & MASK29;
+                up = t >> 29;
+            } else {
+                acc += (uint64_t)c.l[i] * d.l[k - i];
+            }
+        }
+#pragma unroll
+        for (int i = k - L + 1; i < LR; i++) acc += (uint64_t)m[i] * P::P[k - i];
+        r[k - LR] = (uint32_t)acc & MASK29;
+        acc = (acc >> 29) + up;
+    }
+    r[L - 1] = (uint32_t)acc;
+    Fp<P> o;
+#pragma unroll
+    for (int i = 0; i < L; i++) o.l[i] = r[i];
+    return o;
+}
+
+// exact form: fully reduced.  LR = L: the value before the subtractions is < (2 p^2 + RI p) / RI < 2.68 p for a 0.84 * 2^(29 L)
+// modulus (two conditional subtractions); LR > L: < p + 2^(29 (L - 1) + 7) (one).
 template <class P>
 ZK_HD Fp<P> fp_mul2(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d) {
     constexpr int L = P::L;
-    uint32_t m[L], r[L];
-    uint64_t acc = 0;
+    const Fp<P> t = fp_mul2_lazy<P>(a, b, c, d);
+    if constexpr (P::LR > P::L) {
+        return fp_reduce_once<P>(t.l);
+    } else {
+        // first subtraction: the difference can still be >= p, so its top limb is kept unmasked (it may exceed 29 bits)
+        uint32_t u[L];
+        int32_t cy = 0;
 #pragma unroll
-    for (int k = 0; k < L; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            acc += (uint64_t)c.l[i] * d.l[k - i];
+        for (int i = 0; i < L - 1; i++) {
+            int32_t s = (int32_t)t.l[i] - (int32_t)P::P[i] + cy;
+            u[i] = (uint32_t)s & MASK29;
+            cy = s >> 29;
         }
+        const int32_t top = (int32_t)t.l[L - 1] - (int32_t)P::P[L - 1] + cy;
+        u[L - 1] = (uint32_t)top;
+        const bool below = top < 0;        // t < p
+        uint32_t t2[L];
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
-        m[k] = ((uint32_t)acc * P::INV) & MASK29;
-        acc += (uint64_t)m[k] * P::P[0];
-        acc >>= 29;
+        for (int i = 0; i < L; i++) t2[i] = below ? t.l[i] : u[i];
+        return fp_reduce_once<P>(t2);      // now < 2p
     }
-#pragma unroll
-    for (int k = L; k < 2 * L - 1; k++) {
-#pragma unroll
-        for (int i = k - L + 1; i < L; i++) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            acc += (uint64_t)c.l[i] * d.l[k - i];
-            acc += (uint64_t)m[i] * P::P[k - i];
-        }
-        r[k - L] = (uint32_t)acc & MASK29;
-        acc >>= 29;
-    }
-    r[L - 1] = (uint32_t)acc;
-    // first subtraction: the difference can still be >= p, so its top limb is kept unmasked (it may exceed 29 bits)
-    uint32_t u[L];
-    int32_t cy = 0;
-#pragma unroll
-    for (int i = 0; i < L - 1; i++) {
-        int32_t s = (int32_t)r[i] - (int32_t)P::P[i] + cy;
-        u[i] = (uint32_t)s & MASK29;
-        cy = s >> 29;
-    }
-    const int32_t top = (int32_t)r[L - 1] - (int32_t)P::P[L - 1] + cy;
-    u[L - 1] = (uint32_t)top;
-    const bool below = top < 0;        // r < p
-    uint32_t t2[L];
-#pragma unroll
-    for (int i = 0; i < L; i++) t2[i] = below ? r[i] : u[i];
-    return fp_reduce_once<P>(t2);      // now < 2p
 }
 
 // -5 a mod p in ONE carry pass, almost reduced: returns V = k p - 5 a with k = floor(upper estimate of 5 a / p) + 1, so
-// V = -5 a (mod p) and 0 < V <= p (1 + 3e-8); all limbs < 2^29 (p (1 + 3e-8) < 2^(29 L) for BLS12-377's q = 0.84 * 2^377).
+// V = -5 a (mod p) and 0 < V <= p (1 + 2e-7) for any a < 8 p (a may be a lazy-domain value with a wide top limb); all limbs
+// < 2^29 (p (1 + 2e-7) < 2^(29 L) for BLS12-377's q = 0.84 * 2^377).
 // The estimate uses the top limb only: y = (a_top + 1) * ceil(5 * 2^58 / p_top) / 2^58 >= 5 a / p, too large by < 3e-8.
 // V is meant as the c operand of fp_mul2 (whose pre-subtraction bound 2.68 p has room for it) in the Fq2 product with
 // non-residue -5: the exact neg(mul5(a)) was three additions and a subtraction, each with its conditional reduction
@@ -246,43 +292,112 @@ ZK_HD Fp<P> fp_neg5_almost(const Fp<P>& a) {
 #pragma unroll
     for (int i = 0; i < L; i++) {
         int64_t s = (int64_t)((uint64_t)k * P::P[i]) + cy;
-        s += (int64_t)(int32_t)a.l[i] * (int64_t)(-5);
+        s -= (int64_t)(5ull * a.l[i]);                     // a may come from the lazy domain: its top limb can exceed 31 bits
         if (i < L - 1) { r.l[i] = (uint32_t)s & MASK29; cy = s >> 29; } else { r.l[i] = (uint32_t)s; }
     }
     return r;
 }
 
-// Montgomery square: cross products taken once against the doubled operand.
+// Montgomery square: cross products taken once, against the doubled LOWER-index limb (that one is always < 2^29, so the
+// doubling cannot overflow even when the operand's top limb is wide).
 template <class P>
-ZK_HD Fp<P> fp_sqr(const Fp<P>& a) {
-    constexpr int L = P::L;
-    uint32_t m[L], r[L], a2[L];
+ZK_HD Fp<P> fp_sqr_lazy(const Fp<P>& a) {
+    constexpr int L = P::L, LR = P::LR;
+    uint32_t m[LR], r[L], a2[L];
 #pragma unroll
     for (int i = 0; i < L; i++) a2[i] = a.l[i] << 1;
     uint64_t acc = 0;
 #pragma unroll
-    for (int k = 0; k < 2 * L - 1; k++) {
+    for (int k = 0; k < LR + L - 1; k++) {
+        if (k <= 2 * L - 2) {
 #pragma unroll
-        for (int i = 0; i < L; i++) {
-            int j = k - i;
-            if (j < 0 || j >= L) continue;
-            if (i < j) acc += (uint64_t)a.l[i] * a2[j];
-            else if (i == j) acc += (uint64_t)a.l[i] * a.l[i];
+            for (int i = (k >= L ? k - L + 1 : 0); 2 * i < k; i++) acc += (uint64_t)a2[i] * a.l[k - i];    // i < j = k - i
+            if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
         }
-        if (k < L) {
+        if (k < LR) {
 #pragma unroll
-            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
+            for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
             m[k] = ((uint32_t)acc * P::INV) & MASK29;
             acc += (uint64_t)m[k] * P::P[0];
         } else {
 #pragma unroll
-            for (int i = k - L + 1; i < L; i++) acc += (uint64_t)m[i] * P::P[k - i];
-            r[k - L] = (uint32_t)acc & MASK29;
+            for (int i = k - L + 1; i < LR; i++) acc += (uint64_t)m[i] * P::P[k - i];
+            r[k - LR] = (uint32_t)acc & MASK29;
         }
         acc >>= 29;
     }
     r[L - 1] = (uint32_t)acc;
-    return fp_reduce_once<P>(r);
+    Fp<P> o;
+#pragma unroll
+    for (int i = 0; i < L; i++) o.l[i] = r[i];
+    return o;
+}
+
+template <class P>
+ZK_HD Fp<P> fp_sqr(const Fp<P>& a) {
+    const Fp<P> t = fp_sqr_lazy<P>(a);
+    return fp_reduce_once<P>(t.l);
+}
+
+// ---- the lazy domain (fields with LR > L: Fq) ----------------------------------------------------------------------------------
+// Values are kept as a representative in [0, ~7 p]: limbs 0..L-2 below 2^29, the top limb as wide as it needs to be (< 2^31.6).
+// Products (fp_*_lazy above) bring anything back to [0, p + eps), eps = 2^(29 (L - 1) + 6); sums and differences are single
+// carry passes with a multiple of p added so that they stay non-negative -- no comparison, no select.
+//   fp_sub_kp<K>(a, b)   = a + K p - b                 needs b <= K p
+//   fp_x3_lazy(rr,ppp,qq)= rr + 4 p - ppp - 2 qq       needs ppp + 2 qq <= 4 p   (all three are products: < 3 p + 3 eps)
+//   fp_canon(a)          = a mod p, fully reduced      needs a < 8 p
+template <class P, int K>
+ZK_HD Fp<P> fp_sub_kp(const Fp<P>& a, const Fp<P>& b) {
+    constexpr int L = P::L;
+    Fp<P> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) {
+        const int32_t s = (int32_t)(a.l[i] + P::KP[K][i]) - (int32_t)b.l[i] + c;     // in (-2^29, 2^30 + 2^29)
+        r.l[i] = (uint32_t)s & MASK29;
+        c = s >> 29;
+    }
+    r.l[L - 1] = a.l[L - 1] + P::KP[K][L - 1] - b.l[L - 1] + (uint32_t)c;                // the true value is in [0, 2^32): wraps are harmless
+    return r;
+}
+
+template <class P>
+ZK_HD Fp<P> fp_x3_lazy(const Fp<P>& rr, const Fp<P>& ppp, const Fp<P>& qq) {
+    constexpr int L = P::L;
+    Fp<P> r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) {
+        const int32_t s = (int32_t)(rr.l[i] + P::KP[4][i]) - (int32_t)ppp.l[i] - (int32_t)(qq.l[i] << 1) + c;   // in (-2^31, 2^31)
+        r.l[i] = (uint32_t)s & MASK29;
+        c = s >> 29;
+    }
+    r.l[L - 1] = rr.l[L - 1] + P::KP[4][L - 1] - ppp.l[L - 1] - (qq.l[L - 1] << 1) + (uint32_t)c;
+    return r;
+}
+
+// t = a - k p if that is non-negative, else a (a has a possibly wide top limb; so has the result)
+template <class P, int K>
+ZK_HD Fp<P> fp_cond_sub_kp(const Fp<P>& a) {
+    constexpr int L = P::L;
+    uint32_t u[L];
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) {
+        const int32_t s = (int32_t)a.l[i] - (int32_t)P::KP[K][i] + c;
+        u[i] = (uint32_t)s & MASK29;
+        c = s >> 29;
+    }
+    const int64_t top = (int64_t)a.l[L - 1] - (int64_t)P::KP[K][L - 1] + c;
+    u[L - 1] = (uint32_t)top;
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = top < 0 ? a.l[i] : u[i];
+    return r;
+}
+template <class P>
+ZK_HD Fp<P> fp_canon(const Fp<P>& a) {
+    return fp_cond_sub_kp<P, 1>(fp_cond_sub_kp<P, 2>(fp_cond_sub_kp<P, 4>(a)));
 }
 
 // a^e for a plain-integer exponent given as 29-bit limbs (most significant limb last).
@@ -380,6 +495,20 @@ struct FqField {
     static ZK_HD T inv(const T& a) { return fp_inv<FqParams>(a); }
     static ZK_HD bool is_zero(const T& a) { return fp_is_zero<FqParams>(a); }
     static ZK_HD bool eq(const T& a, const T& b) { return fp_eq<FqParams>(a, b); }
+    // ---- lazy domain (see fp29.cuh "the lazy domain"): representatives in [0, ~7 p], no conditional subtractions ----
+    static ZK_HD T mul_l(const T& a, const T& b) { return fp_mul_lazy<FqParams>(a, b); }
+    static ZK_HD T sqr_l(const T& a) { return fp_sqr_lazy<FqParams>(a); }
+    template <int K> static ZK_HD T sub_kp(const T& a, const T& b) { return fp_sub_kp<FqParams, K>(a, b); }       // a + K p - b
+    template <int K> static ZK_HD T kp_minus(const T& b) { return fp_sub_kp<FqParams, K>(fp_zero<FqParams>(), b); }   // K p - b
+    static ZK_HD T x3_l(const T& rr, const T& ppp, const T& qq) { return fp_x3_lazy<FqParams>(rr, ppp, qq); }
+    // r t - ppp y with one Montgomery reduction; ppp enters as 2 p - ppp in (p - eps, 2 p]
+    static ZK_HD T mulsub_l(const T& r, const T& t, const T& ppp, const T& y) {
+        return fp_mul2_lazy<FqParams>(r, t, fp_sub_kp<FqParams, 2>(fp_zero<FqParams>(), ppp), y);
+    }
+    static ZK_HD T canon(const T& a) { return fp_canon<FqParams>(a); }                    // a < 8 p -> a mod p
+    static ZK_HD T canon1(const T& a) { return fp_cond_sub_kp<FqParams, 1>(a); }          // a < 2 p -> a mod p
+    // can a be a multiple of p?  k p has the low limb k (p = 1 mod 2^29), so for a in (0, 8 p) only low limbs 1..7 qualify
+    static ZK_HD bool maybe_multiple_of_p(const T& a) { return a.l[0] - 1u < 7u; }
     static ZK_HD T select(bool c, const T& a, const T& b) {  // c ? a : b
         T r;
 #pragma unroll

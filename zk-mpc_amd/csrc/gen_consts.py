@@ -45,12 +45,24 @@ def arr(name, v, n, comment=""):
         name, n, ", ".join("0x%08xu" % l for l in limbs(v, n)), ("  // " + comment) if comment else "")
 
 
-def field(struct, p, L, W, internal=(), raw=()):
-    RI = 1 << (B * L)
+def limbs_top(v, n):
+    """n limbs, the last one holding everything above bit 29 (n - 1) (it may exceed 29 bits)."""
+    assert v < (1 << (B * (n - 1) + 32))
+    return [(v >> (B * i)) & ((1 << B) - 1) for i in range(n - 1)] + [v >> (B * (n - 1))]
+
+
+def field(struct, p, L, W, internal=(), raw=(), LR=None):
+    LR = LR or L
+    RI = 1 << (B * LR)
     RE = 1 << (32 * W)
     assert RI > p
+    kp = ["        {%s}," % ", ".join("0x%08xu" % l for l in limbs_top(k * p, L)) for k in range(9)]
     out = ["struct %s {" % struct,
            "    static constexpr int L = %d;      // 29-bit limbs" % L,
+           "    static constexpr int LR = %d;     // Montgomery digits: the device's radix is RI = 2^(29 LR); LR = L + 1 leaves the" % LR,
+           "                                      // product below p + 2^(29 (2L - LR) + 6) without a final subtraction (lazy domain)",
+           "    static constexpr uint32_t KP[9][%d] = {   // k * p, k = 0..8; the top limb holds the excess over 29 bits" % L,
+           ] + kp + ["    };",
            "    static constexpr int W = %d;      // 32-bit words of the external (arkworks) layout" % W,
            "    static constexpr int BITS = %d;" % p.bit_length(),
            arr("P", p, L),
@@ -87,7 +99,10 @@ def main():
         ("WIDE_HI", (1 << 256) * (1 << (B * 9)) * (1 << (B * 9))),
     ]))
     print("static constexpr int FR_TWO_ADICITY = %d;" % FR_TWO_ADICITY)
-    print(field("FqParams", Q_MOD, 13, 12, internal=[
+    # Fq: ONE extra Montgomery digit (RI = 2^406, not 2^377).  q = 0.84 * 2^377 leaves no room between q and 2^(29 * 13):
+    # with 13 digits every product needs a conditional subtraction and every sum a full reduction (43 % of the instructions
+    # of a bucket addition).  With 14 digits a product of operands up to 7 q lands in [0, q + 2^354) by itself.
+    print(field("FqParams", Q_MOD, 13, 12, LR=14, internal=[
         ("G1_GEN_X", G1X), ("G1_GEN_Y", G1Y),             # curves/g1.rs:43-51
         ("G2_GEN_X0", G2X0), ("G2_GEN_X1", G2X1),         # curves/g2.rs:63-86
         ("G2_GEN_Y0", G2Y0), ("G2_GEN_Y1", G2Y1),

@@ -151,6 +151,40 @@ extern "C" int zk_fq_neg5_almost_raw(const uint32_t a13[13], uint32_t out13[13])
     for (int i = 0; i < 13; i++) out13[i] = v.l[i];
     return ZK_OK;
 }
+// Test hook for the lazy domain of Fq (fp29.cuh): raw 29-bit limbs in (13 words per element, the top one may be wide), raw
+// limbs out.  op 0: mul_lazy(a, b)  1: sqr_lazy(a)  2: mul2_lazy(a, b, c, d)  3..5: sub_kp<2|4|6>(a, b)  6: x3_lazy(rr, ppp, qq)
+// 7: canon(a)  8: kp_minus<1>(a)  9: neg5_almost(a)  10: xyzz_madd_lazy(acc[4], q[2]) -> 4 elements, then 4 more: its canon form
+// 11: mul2_lazy with the split top column (all four operands wide)
+extern "C" int zk_fq_lazy_raw(int op, const uint32_t* in, uint32_t* out) {
+    if (!in || !out) return ZK_ERR_ARG;
+    auto ld = [&](int k) { Fq a; for (int i = 0; i < 13; i++) a.l[i] = in[13 * k + i]; return a; };
+    auto st = [&](int k, const Fq& a) { for (int i = 0; i < 13; i++) out[13 * k + i] = a.l[i]; };
+    using F = FqField;
+    switch (op) {
+        case 0: st(0, F::mul_l(ld(0), ld(1))); break;
+        case 1: st(0, F::sqr_l(ld(0))); break;
+        case 2: st(0, fp_mul2_lazy<FqParams>(ld(0), ld(1), ld(2), ld(3))); break;
+        case 11: st(0, fp_mul2_lazy<FqParams, true>(ld(0), ld(1), ld(2), ld(3))); break;
+        case 3: st(0, F::sub_kp<2>(ld(0), ld(1))); break;
+        case 4: st(0, F::sub_kp<4>(ld(0), ld(1))); break;
+        case 5: st(0, F::sub_kp<6>(ld(0), ld(1))); break;
+        case 6: st(0, F::x3_l(ld(0), ld(1), ld(2))); break;
+        case 7: st(0, F::canon(ld(0))); break;
+        case 8: st(0, F::kp_minus<1>(ld(0))); break;
+        case 9: st(0, fp_neg5_almost<FqParams>(ld(0))); break;
+        case 10: {
+            XYZZ<F> acc{ld(0), ld(1), ld(2), ld(3)};
+            Affine<F> q{ld(4), ld(5)};
+            XYZZ<F> r = xyzz_madd_lazy<F>(acc, q);
+            st(0, r.x); st(1, r.y); st(2, r.zz); st(3, r.zzz);
+            XYZZ<F> c = xyzz_canon_lazy<F>(r);
+            st(4, c.x); st(5, c.y); st(6, c.zz); st(7, c.zzz);
+            break;
+        }
+        default: return ZK_ERR_ARG;
+    }
+    return ZK_OK;
+}
 extern "C" int zk_fq_mul(const zk_fq* a, const zk_fq* b, zk_fq* out) {
     if (!a || !b || !out) return ZK_ERR_ARG;
     Fq t = fp_mul<FqParams>(host_load_ext<FqParams>(a->l), host_load_ext<FqParams>(b->l));

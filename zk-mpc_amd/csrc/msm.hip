@@ -437,9 +437,13 @@ k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                     e = srt[k + 1];
                     p = aff_load16<F>(bases, e & 0x7fffffffu);
                 }
-                if (ce >> 31) cur.y = F::neg(cur.y);
-                acc = xyzz_madd<F>(acc, cur);
+                // lazy domain (fp29.cuh / ec.cuh::xyzz_madd_lazy): the accumulator is a representative in [0, ~5 p], a negative
+                // digit takes p - y in one carry pass; nothing is compared or selected until the segment is through
+                const bool inf = aff_is_inf<F>(cur);
+                if (ce >> 31) cur.y = F::template kp_minus<1>(cur.y);
+                if (!inf) acc = xyzz_madd_lazy<F>(acc, cur);
             }
+            acc = xyzz_canon_lazy<F>(acc);
         }
         xyzz_store16<F>(sums, d.dst, acc);
     }

@@ -69,6 +69,11 @@ __device__ __forceinline__ Fq mulp(const Left& A, const Fq& b, bool odd) {
     return fp_mul2<FqParams>(A.p, b, A.q, xchg(b));
 }
 
+template <bool TOPSPLIT = false>
+__device__ __forceinline__ Fq mulp_l(const Left& A, const Fq& b) {     // lazy domain: no final subtraction, result < p + eps
+    return fp_mul2_lazy<FqParams, TOPSPLIT>(A.p, b, A.q, xchg(b));
+}
+
 struct AffP { Fq x, y; };
 struct XyzzP { Fq x, y, zz, zzz; };
 
@@ -114,6 +119,34 @@ __device__ __forceinline__ XyzzP madd_p(const XyzzP& acc, const AffP& q, bool od
     return XyzzP{x3, y3, mulp(PP, acc.zz, odd), mulp(PPP, acc.zzz, odd)};
 }
 
+// acc + q in the lazy domain (fp29.cuh; the G1 form is ec.cuh::xyzz_madd_lazy): per lane the same ranges as there except
+// that Y3 is a difference of two products, M1 + 2p - M2 < 3p + eps, hence R = s2 + 4p - Y1 < 5p + eps.  q is not infinity
+// (the caller tests the table's own words); acc is all-zero words when it is infinity.  The equal-x case is found exactly:
+// P = 0 in Fq2 iff both components are multiples of p, whose low limbs are 1 .. 7 -- only then is anything reduced.
+__device__ __forceinline__ XyzzP madd_p_lazy(const XyzzP& acc, const AffP& q, bool odd) {
+    if (pair_zero(limbs_or(acc.zz))) return XyzzP{q.x, q.y, one_p(odd), one_p(odd)};
+    const Fq u2 = mulp_l(prep(q.x, odd), acc.zz);
+    const Fq s2 = mulp_l(prep(q.y, odd), acc.zzz);
+    const Fq p = B::sub_kp<6>(u2, acc.x);
+    const Fq r = B::sub_kp<4>(s2, acc.y);
+    const uint32_t maybe = B::maybe_multiple_of_p(p) ? 1u : 0u;
+    if (maybe & dpp_swap1(maybe)) {
+        if (pair_zero(limbs_or(B::canon(p)))) {
+            if (pair_zero(limbs_or(B::canon(r)))) return dbl_affine_p(AffP{q.x, B::canon1(q.y)}, odd);
+            return XyzzP{B::zero(), B::zero(), B::zero(), B::zero()};
+        }
+    }
+    const Fq pp = mulp_l<true>(prep(p, odd), p);      // the odd lane's p0 p1 + p1 p0 has FOUR wide operands (fp_mul2_lazy: TOPSPLIT)
+    const Left PP = prep(pp, odd);
+    const Fq ppp = mulp_l(PP, p);
+    const Fq qq = mulp_l(PP, acc.x);
+    const Left R = prep(r, odd);
+    const Fq x3 = B::x3_l(mulp_l(R, r), ppp, qq);
+    const Left PPP = prep(ppp, odd);
+    const Fq y3 = B::sub_kp<2>(mulp_l(R, B::sub_kp<6>(qq, x3)), mulp_l(PPP, acc.y));
+    return XyzzP{x3, y3, mulp_l(PP, acc.zz), mulp_l(PPP, acc.zzz)};
+}
+
 __device__ __forceinline__ Fq fq_load16(const uint32_t* w) { return felt_load16<FqField>(w); }
 
 // this lane's components of affine point i: x.c[odd] at words [odd*12, +12), y.c[odd] at [24 + odd*12, +12)
@@ -149,9 +182,12 @@ k_accum_g2pair(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ 
                     e = srt[k + 1];
                     p = aff_load_p(bases, e & 0x7fffffffu, oddw);
                 }
-                if (ce >> 31) cur.y = B::neg(cur.y);
-                acc = madd_p(acc, cur, odd);
+                // lazy domain: see msm.hip::k_accum
+                const bool inf = pair_zero(limbs_or(cur.x) | limbs_or(cur.y));
+                if (ce >> 31) cur.y = B::kp_minus<1>(cur.y);
+                if (!inf) acc = madd_p_lazy(acc, cur, odd);
             }
+            acc = XyzzP{B::canon(acc.x), B::canon(acc.y), B::canon1(acc.zz), B::canon1(acc.zzz)};
         }
         // XYZZ over Fq2 in memory: x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1, 12 words each
         uint32_t* w = sums + (size_t)d.dst * (8 * FW) + oddw * FW;
