@@ -379,6 +379,7 @@ int zk_rng_free(zk_rng* rng);
 int zk_rng_next_u64(zk_rng* rng, uint64_t* out);
 int zk_rng_next_u128(zk_rng* rng, uint64_t out[2]);
 int zk_rng_next_fr(zk_rng* rng, zk_fr* out);
+int zk_rng_fill_fr(zk_rng* rng, zk_fr* out, size_t n);   /* n draws of zk_rng_next_fr (DensePolynomial::rand) */
 int zk_rng_fill_bytes(zk_rng* rng, uint8_t* out, size_t n);
 /* Blake2s-256 (RFC 7693; the digest of FiatShamirRng) and the ChaCha block function (RFC 8439 2.3; words 12..15 of the
  * state are passed in: (counter lo, counter hi, stream lo, stream hi) for rand_chacha, (counter, nonce[3]) for the RFC). */

@@ -159,3 +159,73 @@ def test_marlin_pc_commit_with_bounds_and_hiding(ctx):
     # a polynomial above its bound is refused
     with pytest.raises(ValueError, match="exceeds its bound"):
         DM.commit_marlin_pc(ctx, pg, pgg, {"g_2": prover["h_2"]}, {"g_2": (1, None)})
+
+
+# ---- Marlin as a proof: transcript, hiding commitments, open_combinations, the oracle's verifier ----------------------------------
+
+def _oracle_keys(oix, beta, g_k, gg_k, h_k, extra=3):
+    import marlin_full_ref as MF
+    pp = O.KzgParams(MF.max_degree_for(oix) + extra, beta, g_k=g_k, gg_k=gg_k, h_k=h_k)
+    return MF.Keys(oix, pp)
+
+
+@pytest.mark.parametrize("n", [3, 6, 13])
+def test_marlin_proof_bytes_equal_the_oracle_prover(ctx, n):
+    """Marlin::prove on the device (marlin.py::prove: Fiat-Shamir through the library's FiatShamirRng<Blake2s>, MarlinKZG10
+    commitments with hiding and degree bounds, open_combinations) against the oracle's Python prover from the same ChaCha20 prover
+    rng: the same CanonicalSerialize bytes, the same challenges; the oracle's verifier accepts them and rejects a wrong input."""
+    import fsrng_ref as FR
+    import marlin_full_ref as MF
+    from zk_mpc_amd.api import Rng
+    rng, r1cs, sq, zz, dix = build(ctx, n, 4000 + n)
+    oix = M.Index(sq)
+    beta, g_k, gg_k, h_k = rng.fr(), rng.fr(), rng.fr(), rng.fr()
+    okeys = _oracle_keys(oix, beta, g_k, gg_k, h_k)
+    srs = DM.UniversalSrs(ctx, okeys.max_degree, beta, g_k, gg_k)
+    dkeys = DM.IndexKeys(dix, srs)
+    assert dkeys.ivk_bytes() == okeys.ivk_bytes()
+    seed = bytes((7 * i + n) & 0xff for i in range(32))
+    got = DM.prove(dkeys, ctx.upload(cv.fr_to_mont(zz)), Rng.from_seed(seed, 20))
+    want = MF.prove(okeys, zz, FR.ChaChaRng(seed, 20))
+    assert got.evaluations == want.evaluations
+    assert got.serialize(ctx) == want.serialize()
+    pub = zz[1:oix.num_instance]
+    dev_as_oracle = MF.Proof([[(c.comm_aff, c.shifted_aff, c.shifted is not None) for c in rnd] for rnd in got.commitments],
+                             got.evaluations, [(cv.g1_projective_to_affine(w), rv) for w, rv in got.pc_proof])
+    assert MF.verify(okeys, pub, dev_as_oracle)
+    assert not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], dev_as_oracle)
+
+
+@pytest.mark.parametrize("n", [1000, (1 << 14) - 3])
+def test_marlin_proof_verifies_at_size(ctx, n):
+    """Beyond what the Python prover does in seconds: the oracle's VERIFIER (transcript re-derived from the proof, the two
+    sum-check combinations, degree-bound adjustments, one pairing equation per query point) accepts the device's proof, given
+    the device's index commitments -- which the small cases above tie to the oracle's own -- and rejects a wrong public input
+    and a tampered evaluation."""
+    import marlin_full_ref as MF
+    from zk_mpc_amd.api import Rng
+    rng, r1cs, sq, zz, dix = build(ctx, n, 5000 + (n & 0xff))
+    beta, g_k, gg_k, h_k = rng.fr(), rng.fr(), rng.fr(), rng.fr()
+    max_degree = DM.ahp_max_degree(dix) + 5
+    srs = DM.UniversalSrs(ctx, max_degree, beta, g_k, gg_k)
+    dkeys = DM.IndexKeys(dix, srs)
+    proof = DM.prove(dkeys, ctx.upload(cv.fr_to_mont(zz)), Rng.from_seed(bytes(range(32)), 20))
+
+    class PP:                                        # what the verifier key holds (kzg10::VerifierKey), from the toxic waste
+        pass
+    pp = PP()
+    pp.beta = beta
+    pp.g, pp.gamma_g, pp.h = O.g1_mul(O.G1_GEN, g_k), O.g1_mul(O.G1_GEN, gg_k), O.g2_mul(O.G2_GEN, h_k)
+    pp.beta_h = O.g2_mul(pp.h, beta)
+    info = M.IndexInfo(dix.num_constraints, dix.num_non_zero, dix.num_instance)
+    info.num_variables, info.num_constraints, info.num_non_zero = dix.num_variables, dix.num_constraints, dix.num_non_zero
+    okeys = MF.Keys(info, pp, max_degree=max_degree, index_comms={l: dkeys.index_comms[l].comm_aff for l in MF.INDEX_LABELS})
+    assert okeys.ivk_bytes() == dkeys.ivk_bytes()
+    as_oracle = MF.Proof([[(c.comm_aff, c.shifted_aff, c.shifted is not None) for c in rnd] for rnd in proof.commitments],
+                         proof.evaluations, [(cv.g1_projective_to_affine(w), rv) for w, rv in proof.pc_proof])
+    pub = zz[1:dix.num_instance]
+    assert MF.verify(okeys, pub, as_oracle)
+    assert not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], as_oracle)
+    ev = list(proof.evaluations); ev[0] = (ev[0] + 1) % O.R_MOD
+    assert not MF.verify(okeys, pub, MF.Proof(as_oracle.commitments, ev, as_oracle.pc_proof))
+    assert len(proof.serialize(ctx)) == 8 + 3 * 8 + 9 * 49 + 2 * 48 + 8 + 7 * 32 + 8 + 3 + 8 + 2 * 49 + 32 + 1

@@ -42,7 +42,7 @@ def run_parties(n_parties, fn):
     return out
 
 
-@pytest.mark.parametrize("n_parties", [2, 3])
+@pytest.mark.parametrize("n_parties", [2, 3, 8])
 def test_beaver_batch_mul_real_and_dummy_triples(n_parties):
     rng = O.Prng(900 + n_parties)
     n = 1000
@@ -68,7 +68,7 @@ def test_beaver_batch_mul_real_and_dummy_triples(n_parties):
     assert all(v == 0 for v in res[1][1])      # dummy triples: everything lands on the leader (wire/field.rs:49-63)
 
 
-@pytest.mark.parametrize("n_parties,n", [(3, 6), (3, 1000), (2, (1 << 12) - 2)])
+@pytest.mark.parametrize("n_parties,n", [(3, 6), (3, 1000), (2, (1 << 12) - 2), (8, 301)])
 def test_collaborative_prove(n_parties, n):
     """BASELINE config 3 shape (3-party additive, mul-chain) at test size."""
     rng = O.Prng(1000 + n)
@@ -96,7 +96,7 @@ def test_collaborative_prove(n_parties, n):
     assert all(b == 2 * D * 32 + 3 * (144 + 32) + 144 + 288 + 144 for _, b in res)   # Appendix C traffic
 
 
-@pytest.mark.parametrize("n_parties,n", [(2, 100), (3, 5000)])
+@pytest.mark.parametrize("n_parties,n", [(2, 100), (3, 5000), (8, 77)])
 def test_collaborative_prove_spdz(n_parties, n):
     """The reference's `malicious` backend (SpdzFieldShare / SpdzGroupShare, key alpha = 1): two-lane shares, MAC-checked
     opens; the revealed proof equals the local proof, and a corrupted MAC share is detected."""
@@ -267,7 +267,7 @@ def test_collaborative_marlin(n_parties, n):
     assert all(s == seen[0] for s in seen)
 
 
-@pytest.mark.parametrize("n_parties,n", [(2, 6), (3, 40)])
+@pytest.mark.parametrize("n_parties,n", [(2, 6), (3, 40), (8, 21)])
 def test_collaborative_marlin_spdz(n_parties, n):
     """Marlin over SPDZ shares (two lanes, MAC-checked opens): the same revealed outputs as the additive run above on the
     same inputs, and a corrupted MAC share of the witness is detected."""
@@ -411,3 +411,93 @@ def test_native_rccl_open_single_rank(ctx):
             ctx.comm_init(uid, 0, 1)
     finally:
         ctx.comm_destroy()
+
+
+def _rccl_worker(rank, world, port, q):
+    """One RCCL rank per GPU (needs >= `world` devices): both transports of the share-vector open (DistNet.open_sum over
+    torch.distributed and the library's own communicator, zk_open_sum_fr_dev) in both patterns on lengths that do not divide
+    by the party count, king_share through the scatter, and a collaborative Groth16 proof against the local proof on the
+    summed inputs."""
+    import os
+    import sys
+    import traceback
+    try:
+        import torch
+        import torch.distributed as dist
+        ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for pth in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+            if pth not in sys.path:
+                sys.path.insert(0, pth)
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        ctx = Z.Context(rank, rank, world)
+        rng = O.Prng(9000)                                   # same stream on every rank
+        party = mpc.Party(ctx, dist)
+        for n in (1, 7, 64, 1001, world * 500 + 3):
+            vals = [[rng.fr() for _ in range(n)] for _ in range(world)]
+            want = [sum(c) % O.R_MOD for c in zip(*vals)]
+            v = ctx.upload(cv.fr_to_mont(vals[rank]))
+            out = party.be.vec("o%d" % n, n)
+            for pattern in (None, "allgather", "a2a"):
+                party.net.open_pattern = pattern
+                ctx.dev_zero(out, n * 32)
+                party.be.open_vec(v.ptr, out, n)
+                assert cv.fr_from_mont(ctx.download(out, (n, 4))) == want, ("torch", pattern, n)
+            party.net.open_pattern = None
+        box = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(box[0], rank, world)
+        for n in (1, 13, 999, world * 256 + 5):
+            vals = [[rng.fr() for _ in range(n)] for _ in range(world)]
+            want = [sum(c) % O.R_MOD for c in zip(*vals)]
+            v = ctx.upload(cv.fr_to_mont(vals[rank]))
+            o = ctx.alloc(n * 32)
+            for pattern in (0, 1, 2):
+                ctx.comm_set_open_pattern(pattern)
+                ctx.dev_zero(o.ptr, n * 32)
+                ctx.open_sum_fr_dev(v.ptr, n, o.ptr)
+                ctx.sync()
+                assert cv.fr_from_mont(ctx.download(o, (n, 4))) == want, ("native", pattern, n)
+        ctx.comm_destroy()
+        # collaborative proof == local proof on the summed inputs
+        n = 500
+        td = [mont1(rng.fr()) for _ in range(7)]
+        w0, w1, r, s = rng.fr(), rng.fr(), rng.fr(), rng.fr()
+        dr = ctx.r1cs_mul_chain(n)
+        pk = ctx.groth16_setup(dr, *td)
+        dz = ctx.mul_chain_assignment_dev(n, mont1(w0), mont1(w1))
+        zshare = party.share_assignment_dev(dz, dr, seed=11)
+        rs = party.share_scalars([r, s], seed=12)
+        proof = party.create_proof_shared(pk, dr, zshare, rs[0], rs[1])
+        assert proof == ctx.create_proof_dev(pk, dr, dz.ptr, mont1(r), mont1(s))
+        secret = ctx.upload(cv.fr_to_mont([rng.fr() for _ in range(100)])) if rank == 0 else None
+        mine = party.king_share_vec(secret.ptr if secret else None, 100)
+        tot = party.be.vec("ks", 100)
+        party.be.open_vec(mine, tot, 100)
+        if rank == 0:
+            assert np.array_equal(ctx.download(tot, (100, 4)), ctx.download(secret, (100, 4)))
+        ctx.close()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_rccl_multi_rank_opens_and_proof(world):
+    """Runs only on a box with at least `world` GPUs (the round's 1-GPU boxes skip it): MpcNet::broadcast_bytes semantics
+    (mpc-net/src/multi.rs:469-525) over RCCL with more than one rank."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, this box has %d" % (world, torch.cuda.device_count()))
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    c = mp.get_context("spawn")
+    q = c.Queue()
+    procs = [c.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=900) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(r[1] == "ok" for r in res), res

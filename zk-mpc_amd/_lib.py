@@ -195,6 +195,7 @@ PROTOTYPES = {
     "zk_rng_next_u64": (_I, [_P, _P]),
     "zk_rng_next_u128": (_I, [_P, _P]),
     "zk_rng_next_fr": (_I, [_P, _P]),
+    "zk_rng_fill_fr": (_I, [_P, _P, _SZ]),
     "zk_rng_fill_bytes": (_I, [_P, _P, _SZ]),
     "zk_blake2s": (_I, [_P, _SZ, _P]),
     "zk_chacha_block": (_I, [_P, _P, _I, _P]),

@@ -100,6 +100,13 @@ class Rng:
         self.lib.zk_rng_next_fr(self.h, _ptr(out))
         return out
 
+    def fill_fr(self, n: int) -> np.ndarray:
+        """n draws of Fr::rand: (n, 4) uint64 in the reference's in-memory form."""
+        out = np.zeros((n, 4), dtype=np.uint64)
+        if n and self.lib.zk_rng_fill_fr(self.h, _ptr(out), n) != 0:
+            raise ZkError("zk_rng_fill_fr failed")
+        return out
+
     def fill_bytes(self, n: int) -> bytes:
         buf = (C.c_uint8 * n)()
         self.lib.zk_rng_fill_bytes(self.h, buf, n)

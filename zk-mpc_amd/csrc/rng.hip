@@ -142,3 +142,12 @@ extern "C" int zk_rng_next_fr(zk_rng* r, zk_fr* out) {
         if (fr_words_valid(l)) { memcpy(out->l, l, 32); return ZK_OK; }
     }
 }
+// n x Fr::rand in a row (the 3 |H| coefficients of Marlin's mask polynomial are drawn this way, prover.rs:371-376).
+extern "C" int zk_rng_fill_fr(zk_rng* r, zk_fr* out, size_t n) {
+    if (!r || (n && !out)) return ZK_ERR_ARG;
+    for (size_t i = 0; i < n; i++) {
+        const int rc = zk_rng_next_fr(r, out + i);
+        if (rc != ZK_OK) return rc;
+    }
+    return ZK_OK;
+}

@@ -562,3 +562,327 @@ def mul_chain_system(ctx: Context, n: int):
 
 def download_poly(ctx: Context, p: DevPoly) -> list:
     return cv.fr_from_mont(ctx.download(p.ptr, (p.n, 4)))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Marlin as a proof: Marlin::{index, prove} (arkworks/marlin/src/lib.rs:100-319) over MarlinKZG10
+# ------------------------------------------------------------------------------------------------------------------------------
+# The Fiat-Shamir generator (FiatShamirRng<Blake2s>, marlin/src/rng.rs) is the library's zk_rng (csrc/fsrng.hpp); what is
+# absorbed are the bytes the reference's to_bytes! writes: items back to back without length prefixes (ff/src/bytes.rs), a G1
+# point as x | y | infinity with canonical little-endian coordinates (ec/.../short_weierstrass_jacobian.rs:315-322), a
+# marlin_pc commitment as comm | shifted_exists | shifted_comm-or-zero (marlin_pc/data_structures.rs:252-263), IndexInfo as three
+# u64 (ahp/indexer.rs:44-50), the empty prover messages as nothing (ahp/prover.rs:76-83).
+
+PROTOCOL_NAME = b"MARLIN-2019"                                       # lib.rs:76
+INDEX_LABELS = [m + s for m in "abc" for s in ("_row", "_col", "_val", "_row_col")]          # ahp/mod.rs:33-40
+ROUND_LABELS = [["w", "z_a", "z_b", "mask_poly"], ["t", "g_1", "h_1"], ["g_2", "h_2"]]       # ahp/mod.rs:43-49
+QUERY_SET = {"beta": ["g_1", "outer_sumcheck", "t", "z_b"],                                   # ahp/verifier.rs:103-170, BTree order
+             "gamma": ["a_denom", "b_denom", "c_denom", "g_2", "inner_sumcheck"]}
+EVAL_LABELS = ["a_denom", "b_denom", "c_denom", "g_1", "g_2", "t", "z_b"]                     # lib.rs:279-294: sorted, zero LCs left out
+
+
+def _fr_bytes(v: int) -> bytes:
+    return (v % R_MOD).to_bytes(32, "little")
+
+
+def _g1_to_bytes(pt) -> bytes:
+    if pt is None:                                                   # GroupAffine::zero() = (0, 1, infinity)
+        return (0).to_bytes(48, "little") + (1).to_bytes(48, "little") + b"\x01"
+    return pt[0].to_bytes(48, "little") + pt[1].to_bytes(48, "little") + b"\x00"
+
+
+class PcCommitment:
+    """marlin_pc::Commitment: comm and, for a degree-bounded oracle, shifted_comm (Jacobian arrays from the device)."""
+
+    def __init__(self, comm, shifted=None):
+        self.comm, self.shifted = comm, shifted
+        self.comm_aff = cv.g1_projective_to_affine(comm)
+        self.shifted_aff = cv.g1_projective_to_affine(shifted) if shifted is not None else None
+
+    def to_bytes(self) -> bytes:                                     # ToBytes (the transcript)
+        return _g1_to_bytes(self.comm_aff) + (b"\x01" if self.shifted is not None else b"\x00") + \
+            _g1_to_bytes(self.shifted_aff if self.shifted is not None else None)
+
+
+def ahp_max_degree(index: "Index") -> int:
+    """AHPForR1CS::max_degree (ahp/mod.rs:75-97), zk_bound = 1."""
+    h, k = index.dom_h.size, index.dom_k.size
+    return max(2 * h + 1 - 2, 3 * h + 2 - 3, h, 3 * k - 3)
+
+
+class UniversalSrs:
+    """KZG10::setup (poly-commit/src/kzg10/mod.rs:44-135) with explicit toxic waste: powers_of_g[i] = beta^i g for i <= max_degree
+    (a resident table with window multiples), powers_of_gamma_g[i] = beta^i gamma_g for the three indices a hiding bound of 1
+    uses (marlin_pc/mod.rs:98-102).  g = g_k G1, gamma_g = gamma_g_k G1; the G2 side (h, beta h) belongs to the verifier."""
+
+    def __init__(self, ctx: Context, max_degree: int, beta: int, g_k: int = 1, gamma_g_k: int = 7):
+        self.ctx, self.max_degree, self.beta = ctx, max_degree, beta % R_MOD
+        m = HostField.m
+        pw = ctx.alloc((max_degree + 1) * 32)
+        ctx.fr_powers_dev(m(beta), m(1), max_degree + 1, pw.ptr)
+        self.powers_g = ctx.fixed_base(pw.ptr, max_degree + 1, 1, m(g_k))
+        self.powers_g.precompute()
+        self.powers_gamma_g = ctx.fixed_base(pw.ptr, 3, 1, m(gamma_g_k))
+        ctx.sync()
+        pw.free()
+
+
+class IndexKeys:
+    """Marlin::index (lib.rs:101-146): trim the SRS to the index (degree bounds |H| - 2 and |K| - 2, hiding bound 1) and commit
+    to the twelve index polynomials without hiding.  Holds the IndexProverKey's data and the IndexVerifierKey's bytes."""
+
+    def __init__(self, index: "Index", srs: UniversalSrs):
+        if srs.max_degree < ahp_max_degree(index):
+            raise ValueError("IndexTooLarge")
+        self.index, self.srs = index, srs
+        self.bounds = {"g_1": index.dom_h.size - 2, "g_2": index.dom_k.size - 2}              # get_degree_bounds (ahp/mod.rs:100-110)
+        self.hiding = {"w": 1, "z_a": 1, "z_b": 1, "g_1": 1}                                  # prover.rs:383-387,548-552
+        polys = index.polynomials()
+        comms = commit(index.ctx, srs.powers_g, {l: polys[l] for l in INDEX_LABELS})
+        self.index_comms = {l: PcCommitment(comms[l]) for l in INDEX_LABELS}
+
+    def ivk_bytes(self) -> bytes:                                    # IndexVerifierKey::write: index_info | index_comms
+        ix = self.index
+        head = ix.num_variables.to_bytes(8, "little") + ix.num_constraints.to_bytes(8, "little") + ix.num_non_zero.to_bytes(8, "little")
+        return head + b"".join(self.index_comms[l].to_bytes() for l in INDEX_LABELS)
+
+
+class MarlinProof:
+    """marlin::Proof (data_structures.rs:99-110): commitments per round, the evaluations sorted by label, three empty prover
+    messages, one KZG10 proof (w, random_v) per query point (beta, gamma)."""
+
+    def __init__(self, commitments, evaluations, pc_proof, challenges):
+        self.commitments, self.evaluations, self.pc_proof, self.challenges = commitments, evaluations, pc_proof, challenges
+
+    def serialize(self, ctx: Context) -> bytes:
+        """CanonicalSerialize (derive order; Vec = u64 length + items, Option = one byte + item, points compressed)."""
+        u64 = lambda v: v.to_bytes(8, "little")
+        out = u64(len(self.commitments))
+        for rnd in self.commitments:
+            out += u64(len(rnd))
+            for c in rnd:
+                out += ctx.g1_serialize(c.comm) + (b"\x01" + ctx.g1_serialize(c.shifted) if c.shifted is not None else b"\x00")
+        out += u64(len(self.evaluations)) + b"".join(_fr_bytes(e) for e in self.evaluations)
+        out += u64(3) + b"\x00" * 3
+        out += u64(len(self.pc_proof))
+        for w, rv in self.pc_proof:
+            out += ctx.g1_serialize(w) + (b"\x01" + _fr_bytes(rv) if rv is not None else b"\x00")
+        return out + b"\x00"
+
+
+def _sample_outside(dom: Domain, fs) -> int:
+    """EvaluationDomain::sample_element_outside_domain (poly/src/domain/mod.rs:37-51)."""
+    t = HostField.i(fs.next_fr())
+    while dom.evaluate_vanishing_polynomial(t) == 0:
+        t = HostField.i(fs.next_fr())
+    return t
+
+
+def _host_poly_eval(coeffs, x: int) -> int:
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % R_MOD
+    return acc
+
+
+def _host_divide_by_linear(coeffs, z: int):
+    """Quotient of p / (X - z) for a short host polynomial (the blinding polynomials: three coefficients)."""
+    q, acc = [0] * max(len(coeffs) - 1, 0), 0
+    for i in range(len(coeffs) - 1, 0, -1):
+        acc = (coeffs[i] + acc * z) % R_MOD
+        q[i - 1] = acc
+    return q
+
+
+def _commit_round(keys: IndexKeys, labels, polys: dict, zk_rng):
+    """PC::commit(ck, oracles, Some(zk_rng)) (marlin_pc/mod.rs:172-243): the blinding polynomials are drawn oracle by oracle --
+    three coefficients for a hiding bound of 1, a second set for the shifted commitment of a degree-bounded oracle -- and all
+    MSMs of the round run as one pipelined batch.  Returns ({label: PcCommitment}, {label: (blind, shifted_blind)})."""
+    ctx, srs = keys.index.ctx, keys.srs
+    rands, blinds, keep = {}, {}, []
+    for l in labels:
+        hb = keys.hiding.get(l)
+        blind = [HostField.i(v) for v in zk_rng.fill_fr(hb + 2)] if hb is not None else []
+        sblind = None
+        if l in keys.bounds:
+            sblind = [HostField.i(v) for v in zk_rng.fill_fr(hb + 2)] if hb is not None else []
+        rands[l] = (blind, sblind)
+        if blind:
+            db = ctx.upload(cv.fr_to_mont(blind))
+            ds = ctx.upload(cv.fr_to_mont(sblind)) if sblind else None
+            keep += [db, ds]
+            blinds[l] = (DevPoly(db, len(blind)), DevPoly(ds, len(sblind)) if sblind else None)
+    bounds = {l: (keys.bounds.get(l), keys.hiding.get(l)) for l in labels}
+    res = commit_marlin_pc(ctx, srs.powers_g, srs.powers_gamma_g, {l: polys[l] for l in labels}, bounds, blinds)
+    return {l: PcCommitment(res[l]["comm"], res[l]["shifted_comm"]) for l in labels}, rands
+
+
+def _linear_combinations(index: "Index", public_input, ch, ev):
+    """AHPForR1CS::construct_linear_combinations (ahp/mod.rs:112-290): label -> [(coefficient, polynomial label or None for the
+    constant term)], sorted by label; ev(label) -> the evaluation of the single-polynomial combinations / denominators."""
+    F = index.dom_h.F
+    H, K = index.dom_h, index.dom_k
+    alpha, eta_a, eta_b, eta_c, beta, gamma = (ch[k] for k in ("alpha", "eta_a", "eta_b", "eta_c", "beta", "gamma"))
+    neg = lambda v: (-v) % R_MOD
+    x = [1] + list(public_input)
+    nx = len(x)
+    v_H_alpha, v_H_beta = H.evaluate_vanishing_polynomial(alpha), H.evaluate_vanishing_polynomial(beta)
+    v_X_beta = (pow(beta, nx, R_MOD) - 1) % R_MOD
+    # eval_unnormalized_bivariate_lagrange_poly (ahp/mod.rs:337-350): (v_H(alpha) - v_H(beta)) / (alpha - beta)
+    r_alpha_at_beta = (v_H_alpha - v_H_beta) * pow((alpha - beta) % R_MOD, -1, R_MOD) % R_MOD if alpha != beta else \
+        H.size * pow(alpha, H.size - 1, R_MOD) % R_MOD
+    # x(beta) through the Lagrange coefficients of the input domain (radix2/mod.rs:116-165)
+    wx = pow(int(HostField.i(_FR_TWO_ADIC_ROOT_MONT)), 1 << (_FR_TWO_ADICITY - _log2(nx)), R_MOD)
+    if v_X_beta == 0:
+        x_beta = next(xv for k, xv in enumerate(x) if pow(wx, k, R_MOD) == beta)
+    else:
+        x_beta, g = 0, 1
+        for xv in x:
+            x_beta = (x_beta + xv * (v_X_beta * pow(nx, -1, R_MOD) % R_MOD * g % R_MOD) % R_MOD * pow((beta - g) % R_MOD, -1, R_MOD)) % R_MOD
+            g = g * wx % R_MOD
+    z_b_beta, t_beta, g_1_beta = ev("z_b"), ev("t"), ev("g_1")
+    lcs = {"z_b": [(1, "z_b")], "g_1": [(1, "g_1")], "t": [(1, "t")], "g_2": [(1, "g_2")]}
+    lcs["outer_sumcheck"] = [(1, "mask_poly"),
+                             (_mulmod((r_alpha_at_beta, (eta_a + eta_c * z_b_beta) % R_MOD)), "z_a"),
+                             (_mulmod((r_alpha_at_beta, eta_b, z_b_beta)), None),
+                             (neg(_mulmod((t_beta, v_X_beta))), "w"),
+                             (neg(_mulmod((t_beta, x_beta))), None),
+                             (neg(v_H_beta), "h_1"),
+                             (neg(_mulmod((beta, g_1_beta))), None)]
+    ba = beta * alpha % R_MOD
+    for m in "abc":
+        lcs[m + "_denom"] = [(ba, None), (neg(alpha), m + "_row"), (neg(beta), m + "_col"), (1, m + "_row_col")]
+    da, db, dc, g_2_gamma = ev("a_denom"), ev("b_denom"), ev("c_denom"), ev("g_2")
+    v_K_gamma = K.evaluate_vanishing_polynomial(gamma)
+    vv = v_H_alpha * v_H_beta % R_MOD
+    b_expr = _mulmod((da, db, dc, (gamma * g_2_gamma + t_beta * pow(K.size, -1, R_MOD)) % R_MOD))
+    lcs["inner_sumcheck"] = [(_mulmod((eta_a, db, dc, vv)), "a_val"), (_mulmod((eta_b, da, dc, vv)), "b_val"),
+                             (_mulmod((eta_c, db, da, vv)), "c_val"), (neg(b_expr), None), (neg(v_K_gamma), "h_2")]
+    return dict(sorted(lcs.items()))
+
+
+def _mulmod(xs) -> int:
+    acc = 1
+    for v in xs:
+        acc = acc * v % R_MOD
+    return acc
+
+
+def prove(keys: IndexKeys, assignment_dev: DevBuf, zk_rng) -> MarlinProof:
+    """Marlin::prove (lib.rs:152-319) on the device: the three AHP rounds, MarlinKZG10 commitments with hiding, the Fiat-Shamir
+    transcript, the evaluations and open_combinations (marlin/mod.rs:213-306: one KZG10 proof per query point over the
+    challenge-weighted combination of the linear combinations, degree-bounded oracles through their shifted witnesses).
+    zk_rng: an api.Rng (the prover's randomness, drawn in the reference's order)."""
+    from .api import Rng
+    index, srs = keys.index, keys.srs
+    ctx = index.ctx
+    m, ival = HostField.m, HostField.i
+    st = prover_init(index, assignment_dev)
+    ni = index.num_instance
+    public_input = cv.fr_from_mont(ctx.download(assignment_dev.ptr + 32, (ni - 1, 4))) if ni > 1 else []
+    fs = Rng.fiat_shamir(PROTOCOL_NAME + keys.ivk_bytes() + b"".join(_fr_bytes(v) for v in public_input))
+    polys = dict(index.polynomials())
+    rands = {l: ([], None) for l in INDEX_LABELS}
+    comms = dict(keys.index_comms)
+    ch = {}
+    # ---- round 1: F::rand x 3 and the mask polynomial's coefficients, then the hiding commitments
+    md = mask_poly_degree(index)
+    rnd = ctx.upload(zk_rng.fill_fr(3 + md + 1))
+    r1 = prover_first_round(st, rnd)
+    polys.update(r1)
+    c1, q1 = _commit_round(keys, ROUND_LABELS[0], r1, zk_rng)
+    comms.update(c1); rands.update(q1)
+    fs.absorb(b"".join(c1[l].to_bytes() for l in ROUND_LABELS[0]))
+    ch["alpha"] = _sample_outside(index.dom_h, fs)
+    ch["eta_a"], ch["eta_b"], ch["eta_c"] = ival(fs.next_fr()), ival(fs.next_fr()), ival(fs.next_fr())
+    # ---- round 2
+    r2 = prover_second_round(st, ch["alpha"], ch["eta_a"], ch["eta_b"], ch["eta_c"])
+    polys.update(r2)
+    c2, q2 = _commit_round(keys, ROUND_LABELS[1], r2, zk_rng)
+    comms.update(c2); rands.update(q2)
+    fs.absorb(b"".join(c2[l].to_bytes() for l in ROUND_LABELS[1]))
+    ch["beta"] = _sample_outside(index.dom_h, fs)
+    # ---- round 3
+    r3 = prover_third_round(st, ch["beta"])
+    polys.update(r3)
+    c3, q3 = _commit_round(keys, ROUND_LABELS[2], r3, zk_rng)
+    comms.update(c3); rands.update(q3)
+    fs.absorb(b"".join(c3[l].to_bytes() for l in ROUND_LABELS[2]))
+    ch["gamma"] = ival(fs.next_fr())
+    # ---- evaluations (lib.rs:279-294)
+    ev_poly = lambda l, pt: ival(ctx.poly_evaluate_dev(polys[l].ptr, polys[l].n, m(pt)))
+    single = {"z_b": ev_poly("z_b", ch["beta"]), "g_1": ev_poly("g_1", ch["beta"]), "t": ev_poly("t", ch["beta"]),
+              "g_2": ev_poly("g_2", ch["gamma"])}
+    ba = ch["beta"] * ch["alpha"] % R_MOD
+    for mm in "abc":
+        single[mm + "_denom"] = (ba - ch["alpha"] * ev_poly(mm + "_row", ch["gamma"]) - ch["beta"] * ev_poly(mm + "_col", ch["gamma"])
+                                 + ev_poly(mm + "_row_col", ch["gamma"])) % R_MOD
+    lcs = _linear_combinations(index, public_input, ch, lambda l: single[l])
+    evaluations = [single[l] for l in EVAL_LABELS]
+    fs.absorb(b"".join(_fr_bytes(e) for e in evaluations))
+    xi = fs.next_u128() % R_MOD                                       # u128::rand(&mut fs_rng).into()  (lib.rs:300)
+    ch["xi"] = xi
+    # ---- open_combinations: per query point one polynomial sum_j xi^j LC_j, its blinding polynomial, and for a degree-bounded
+    # oracle the witness of the oracle itself over the shifted powers with the next power of xi (marlin_pc/mod.rs:245-340)
+    point = {"beta": ch["beta"], "gamma": ch["gamma"]}
+    jobs, plan, keep = [], [], []
+    for pl in ("beta", "gamma"):
+        z = point[pl]
+        terms, r_comb, shifted, sr = {}, [], [], []                   # terms: polynomial label -> accumulated coefficient
+        j = 0
+        for label in QUERY_SET[pl]:
+            lc = [(c, l) for c, l in lcs[label] if l is not None]
+            cj = pow(xi, j, R_MOD); j += 1
+            for c, l in lc:
+                terms[l] = (terms.get(l, 0) + c * cj) % R_MOD
+                blind = rands[l][0]
+                r_comb = [((r_comb[i] if i < len(r_comb) else 0) + (blind[i] if i < len(blind) else 0) * c % R_MOD * cj) % R_MOD
+                          for i in range(max(len(r_comb), len(blind)))]
+            if len(lcs[label]) == 1 and lc[0][1] in keys.bounds:
+                src = lc[0][1]
+                cj1 = pow(xi, j, R_MOD); j += 1
+                shifted.append((src, cj1))
+                sb = rands[src][1] or []
+                sr = [((sr[i] if i < len(sr) else 0) + (sb[i] if i < len(sb) else 0) * cj1) % R_MOD for i in range(max(len(sr), len(sb)))]
+        labels = list(terms)
+        comb = linear_combination(ctx, [polys[l] for l in labels], [terms[l] for l in labels])
+        q = ctx.alloc(max(comb.n - 1, 1) * 32)
+        ctx.poly_divide_by_linear_dev(comb.ptr, comb.n, m(z), q.ptr)
+        keep += [comb, q]
+        these = [(srs.powers_g, 0, q.ptr, comb.n - 1)]
+        hiding = any(r_comb)
+        rv = None
+        if hiding:
+            rw = _host_divide_by_linear(r_comb, z)
+            d = ctx.upload(cv.fr_to_mont(rw)); keep.append(d)
+            these.append((srs.powers_gamma_g, 0, d.ptr, len(rw)))
+            rv = _host_poly_eval(r_comb, z)
+        srw = []
+        for src, cj1 in shifted:
+            p = polys[src]
+            wq = ctx.alloc(max(p.n - 1, 1) * 32)
+            ctx.poly_divide_by_linear_dev(p.ptr, p.n, m(z), wq.ptr)
+            ctx.fr_vec_scale_dev(wq.ptr, m(cj1), wq.ptr, p.n - 1)
+            keep.append(wq)
+            these.append((srs.powers_g, srs.max_degree - keys.bounds[src], wq.ptr, p.n - 1))
+            sb = rands[src][1] or []
+            if sb:
+                w1 = _host_divide_by_linear(sb, z)
+                srw = [((srw[i] if i < len(srw) else 0) + w1[i] * cj1) % R_MOD for i in range(len(w1))]
+        if srw:
+            d = ctx.upload(cv.fr_to_mont(srw)); keep.append(d)
+            these.append((srs.powers_gamma_g, 0, d.ptr, len(srw)))
+        if shifted and rv is not None:
+            rv = (rv + _host_poly_eval(sr, z)) % R_MOD
+        plan.append((len(these), rv))
+        jobs += these
+    outs = ctx.msm_batch_dev(jobs)
+    pc_proof, k = [], 0
+    for cnt, rv in plan:
+        w = outs[k]
+        for o in outs[k + 1:k + cnt]:
+            w = ctx.g1_add(w, o)
+        k += cnt
+        pc_proof.append((w, rv))
+    ctx.sync()
+    return MarlinProof([[comms[l] for l in rnd] for rnd in ROUND_LABELS], evaluations, pc_proof, ch)
