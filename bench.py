@@ -35,9 +35,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 INT_MAD_PEAK = 32.16e12  # v_mad_u64_u32 wave-lane instr/s measured on MI355X (tools/ubench_int.hip, gpurun_out/ubench_int.txt)
-# v_mad_u64_u32 per XYZZ mixed addition (8M + 2S): 6 products, 2 squarings, one fused double product R(Q - X3) - Y1 PPP
-MADS_PER_MADD_G1 = 6 * 325 + 494 + 2 * 260
-MADS_PER_MADD_G2 = 10 * 1014                      # per lane PAIR: every Fq2 product is two fused double products of 507
+# v_mad_u64_u32 per XYZZ mixed addition (8M + 2S) with Fq's 14 Montgomery digits (fp29.cuh): a product is 13 x 13 limb products
+# + 14 x 12 reduction products (the modulus' low limb is 1: those 14 are plain additions) = 337, a squaring 91 + 168 = 259, the
+# fused double product R (Q - X3) - PPP Y1 is 2 x 169 + 168 = 506
+MADS_PER_MADD_G1 = 6 * 337 + 2 * 259 + 506
+MADS_PER_MADD_G2 = 10 * 2 * 506                   # per lane PAIR: each of the 10 Fq2 products is one fused double product per lane
 
 
 def seeded_fr(seed: int):
@@ -103,6 +105,7 @@ def other_workloads(ctx, log_h=20):
     tools/bench_marlin.py / tools/bench_she.py, fewer repetitions."""
     import numpy as np
     from zk_mpc_amd import marlin as DM
+    import zk_mpc_amd.convert as cv2
     out = {}
     rng = np.random.default_rng(11)
     m = DM.HostField.m
@@ -112,49 +115,62 @@ def other_workloads(ctx, log_h=20):
         a[:, 3] &= np.uint64((1 << 60) - 1)
         return a
     try:
+        from zk_mpc_amd.api import Rng
         n = (1 << log_h) - 3
         ni, nw, a, b, c = DM.mul_chain_system(ctx, n)
         index = DM.Index(ctx, ni, nw, a, b, c)
         H = index.dom_h.size
-        deg = 3 * max(H, index.dom_k.size) + 2
-        pw = ctx.alloc(deg * 32)
-        ctx.fr_powers_dev(m(0x1234567), m(1), deg, pw.ptr)
-        powers_g = ctx.fixed_base(pw.ptr, deg, 1, m(1))
-        powers_g.precompute()          # resident SRS: window multiples, 13 digits per scalar instead of 16
+        beta_srs, g_k, gg_k, h_k = 0x1234567, 3, 7, 5
+        srs = DM.UniversalSrs(ctx, DM.ahp_max_degree(index) + 5, beta_srs, g_k, gg_k)     # resident SRS with window multiples
+        keys = DM.IndexKeys(index, srs)                                                  # Marlin::index: commitments to the 12 index polynomials
         z = ctx.mul_chain_assignment_dev(n, m(3), m(5))
-        rnd = ctx.upload(rand_fr(3 + 3 * H))
-        ch = {k: int(rng.integers(2, 1 << 62)) for k in ("alpha", "eta_a", "eta_b", "eta_c", "beta", "gamma", "xi")}
         ctx.pooling = True
-
-        def prove():
-            st = DM.prover_init(index, z)
-            polys = dict(DM.prover_first_round(st, rnd))
-            comms = DM.commit(ctx, powers_g, polys)
-            r2 = DM.prover_second_round(st, ch["alpha"], ch["eta_a"], ch["eta_b"], ch["eta_c"])
-            comms.update(DM.commit(ctx, powers_g, r2))
-            r3 = DM.prover_third_round(st, ch["beta"])
-            comms.update(DM.commit(ctx, powers_g, r3))
-            polys.update(r2)
-            polys.update(r3)
-            for l, pt in (("g_1", "beta"), ("z_b", "beta"), ("t", "beta"), ("g_2", "gamma")):
-                ctx.poly_evaluate_dev(polys[l].ptr, polys[l].n, m(ch[pt]))
-            ixp = index.polynomials()
-            DM.batch_open(ctx, powers_g, [([polys[l] for l in ("g_1", "z_b", "t", "mask_poly", "z_a", "w", "h_1")], ch["beta"]),
-                                          ([polys["g_2"], polys["h_2"]] + [ixp[l] for l in sorted(ixp)], ch["gamma"])], ch["xi"])
-        prove()
+        seed = bytes(range(32))
+        proof = DM.prove(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
         ctx.sync()
         t0 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            prove()
+            proof = DM.prove(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
         ctx.sync()
         dt = (time.perf_counter() - t0) / reps
         ctx.pooling = False
         ctx.drop_pool()
-        out["marlin"] = {"workload": "Marlin AHP prover + 9 KZG10 commitments + 2 batched openings, mul-chain R1CS, |H| = |K| = 2^%d, "
-                                     "index and SRS resident, challenges supplied by the caller" % log_h,
-                         "constraints": n, "ms_per_proof": round(dt * 1e3, 2), "constraints_per_s": round(n / dt, 1)}
-        del index, powers_g, pw, z, rnd
+        out["marlin"] = {"workload": "Marlin::prove (AHP rounds + MarlinKZG10 commitments with hiding and degree bounds + Fiat-Shamir "
+                                     "transcript + open_combinations), mul-chain R1CS, |H| = |K| = 2^%d, index key and SRS resident, "
+                                     "prover randomness from a ChaCha20 rng (the mask polynomial sampled on the device)" % log_h,
+                         "constraints": n, "ms_per_proof": round(dt * 1e3, 2), "constraints_per_s": round(n / dt, 1),
+                         "proof_bytes": len(proof.serialize(ctx))}
+        # checker (outside the timing): the oracle's Marlin::verify re-derives the transcript from the proof and checks the two
+        # sum-check combinations and one KZG pairing equation per query point; a wrong public input must be rejected
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import marlin_full_ref as MF
+            import marlin_ref as MR
+            import zkref as O
+
+            class PP:
+                pass
+            pp = PP()
+            pp.beta = beta_srs
+            pp.g, pp.gamma_g, pp.h = O.g1_mul(O.G1_GEN, g_k), O.g1_mul(O.G1_GEN, gg_k), O.g2_mul(O.G2_GEN, h_k)
+            pp.beta_h = O.g2_mul(pp.h, beta_srs)
+            info = MR.IndexInfo(index.num_constraints, index.num_non_zero, index.num_instance)
+            info.num_variables, info.num_constraints, info.num_non_zero = index.num_variables, index.num_constraints, index.num_non_zero
+            okeys = MF.Keys(info, pp, max_degree=srs.max_degree, index_comms={l: keys.index_comms[l].comm_aff for l in MF.INDEX_LABELS})
+            as_oracle = MF.Proof([[(cc.comm_aff, cc.shifted_aff, cc.shifted is not None) for cc in rnd] for rnd in proof.commitments],
+                                 proof.evaluations, [(cv2.g1_projective_to_affine(w), rv) for w, rv in proof.pc_proof])
+            pub = cv2.fr_from_mont(ctx.download(z.ptr + 32, (index.num_instance - 1, 4)))
+            t1 = time.time()
+            ok = MF.verify(okeys, pub, as_oracle)
+            rej = not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], as_oracle)
+            out["marlin"]["oracle_verifier_accepts"] = bool(ok)
+            out["marlin"]["oracle_verifier_rejects_wrong_input"] = bool(rej)
+            out["marlin"]["verify_seconds"] = round(time.time() - t1, 1)
+        except Exception as e:
+            out["marlin"]["oracle_verifier_accepts"] = None
+            out["marlin"]["verifier_error"] = repr(e)
+        del index, srs, keys, z
     except Exception as e:  # the headline line must not depend on this leg
         ctx.pooling = False
         out["marlin"] = {"error": repr(e)}

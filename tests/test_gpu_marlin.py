@@ -209,7 +209,7 @@ def test_marlin_proof_verifies_at_size(ctx, n):
     max_degree = DM.ahp_max_degree(dix) + 5
     srs = DM.UniversalSrs(ctx, max_degree, beta, g_k, gg_k)
     dkeys = DM.IndexKeys(dix, srs)
-    proof = DM.prove(dkeys, ctx.upload(cv.fr_to_mont(zz)), Rng.from_seed(bytes(range(32)), 20))
+    proof = DM.prove(dkeys, ctx.upload(cv.fr_to_mont(zz)), Rng.from_seed(bytes(range(32)), 20), mask_on_device=(n > 1000))
 
     class PP:                                        # what the verifier key holds (kzg10::VerifierKey), from the toxic waste
         pass

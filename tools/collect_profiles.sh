@@ -6,14 +6,14 @@ T=${1:-r1}
 O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py > $O/${T}_bench_n1.json 2> $O/${T}_bench_n1.err
-rocprofv3 --kernel-trace --stats -d $O/${T}_trace -o t --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/${T}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/${T}_trace -o t --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-predict > $O/${T}_trace.log 2>&1
 python3 tools/trace_timeline.py $O/${T}_trace/t_kernel_trace.csv 100 -8 > $O/${T}_timeline.txt 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${T}_pmc_fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${T}_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${T}_pmc_write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/${T}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${T}_pmc_fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-predict > $O/${T}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${T}_pmc_write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-predict > $O/${T}_pmc_write.log 2>&1
 python3 tools/pmc_traffic.py $O/${T}_pmc_fetch $O/${T}_pmc_write $O/${T}_pmc_traffic.json "bench.py --steps 3 --warmup 1, 2^20 Groth16 proofs." > $O/${T}_pmc_traffic.txt 2>&1
 for p in "a:SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_WAVES" "b:SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_ANY" "c:MeanOccupancyPerCU" "d:SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM"; do
   tag=${p%%:*}; ctr=${p#*:}
-  rocprofv3 --kernel-trace --pmc $ctr -d $O/${T}_pmc_$tag -o v --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-hint > $O/${T}_pmc_$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr -d $O/${T}_pmc_$tag -o v --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-predict --no-hint > $O/${T}_pmc_$tag.log 2>&1
 done
 python3 tools/pmc_valu.py $O/${T}_pmc_valu.json $O/${T}_pmc_a $O/${T}_pmc_b $O/${T}_pmc_c $O/${T}_pmc_d > $O/${T}_pmc_valu.txt 2>&1
 python3 tools/bench_marlin.py --logs 16,18,20,21,22 > $O/${T}_marlin_bench.jsonl 2> $O/${T}_marlin_bench.err

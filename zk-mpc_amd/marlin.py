@@ -768,11 +768,15 @@ def _mulmod(xs) -> int:
     return acc
 
 
-def prove(keys: IndexKeys, assignment_dev: DevBuf, zk_rng) -> MarlinProof:
+def prove(keys: IndexKeys, assignment_dev: DevBuf, zk_rng, mask_on_device: bool = False) -> MarlinProof:
     """Marlin::prove (lib.rs:152-319) on the device: the three AHP rounds, MarlinKZG10 commitments with hiding, the Fiat-Shamir
     transcript, the evaluations and open_combinations (marlin/mod.rs:213-306: one KZG10 proof per query point over the
     challenge-weighted combination of the linear combinations, degree-bounded oracles through their shifted witnesses).
-    zk_rng: an api.Rng (the prover's randomness, drawn in the reference's order)."""
+    zk_rng: an api.Rng (the prover's randomness, drawn in the reference's order).
+    mask_on_device: the 3 |H| coefficients of the mask polynomial (DensePolynomial::rand, prover.rs:371-376) are private prover
+    randomness; drawn one by one from a host generator they cost more than the whole proof at 2^20 (0.4 s of scalar ChaCha).
+    With this flag they are sampled on the device (zk_fr_random_dev, ChaCha20 under a 32-byte key taken from zk_rng): the
+    same distribution, not the same stream -- proofs then differ from a reference run with the same seed, and verify alike."""
     from .api import Rng
     index, srs = keys.index, keys.srs
     ctx = index.ctx
@@ -787,7 +791,14 @@ def prove(keys: IndexKeys, assignment_dev: DevBuf, zk_rng) -> MarlinProof:
     ch = {}
     # ---- round 1: F::rand x 3 and the mask polynomial's coefficients, then the hiding commitments
     md = mask_poly_degree(index)
-    rnd = ctx.upload(zk_rng.fill_fr(3 + md + 1))
+    if mask_on_device:
+        rnd = ctx.alloc((3 + md + 1) * 32)
+        head = ctx.upload(zk_rng.fill_fr(3))
+        ctx.memcpy_d2d(rnd.ptr, head.ptr, 96)
+        ctx.fr_random_dev(rnd.ptr + 96, md + 1, zk_rng.fill_bytes(32))
+        ctx.sync()
+    else:
+        rnd = ctx.upload(zk_rng.fill_fr(3 + md + 1))
     r1 = prover_first_round(st, rnd)
     polys.update(r1)
     c1, q1 = _commit_round(keys, ROUND_LABELS[0], r1, zk_rng)
