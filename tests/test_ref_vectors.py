@@ -1,0 +1,179 @@
+"""Known-answer vectors produced BY THE REFERENCE (tools/ref_vectors/dump_kats.rs, run with cargo on a machine that has the
+reference checked out) against the oracle (CPU) and the library (GPU).  Skipped while tests/golden/ref_kats.json is absent:
+the reference cannot be built in the build image (no Rust toolchain) -- tools/ref_vectors/README.md is the recipe."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import fsrng_ref as FR
+import zkref as O
+import zk_mpc_amd.convert as cv
+
+PATH = os.environ.get("ZK_REF_KATS") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_kats.json")
+
+
+@pytest.fixture(scope="module")
+def kats():
+    if not os.path.exists(PATH):
+        pytest.skip("no reference vectors: run tools/ref_vectors/dump_kats.rs with cargo (tools/ref_vectors/README.md) and "
+                    "copy its output to tests/golden/ref_kats.json")
+    return json.load(open(PATH))
+
+
+def le(h):
+    return int.from_bytes(bytes.fromhex(h), "little")
+
+
+def g1_unc(h):
+    b = bytes.fromhex(h)
+    if b[95] & 0x40:
+        return None
+    return (int.from_bytes(b[:48], "little"), int.from_bytes(b[48:96], "little") & ((1 << 382) - 1))
+
+
+def test_rng_replay(kats):
+    r = FR.test_rng()
+    assert ["%016x" % r.next_u64() for _ in range(8)] == kats["test_rng_u64"]
+
+
+def replay(kats):
+    """The inputs in the order dump_kats.rs draws them; every replayed value is compared with the dumped one."""
+    r = FR.test_rng()
+    out = {"fr": [], "fq": []}
+    for row in kats["fr_ops"]:
+        a, b = r.next_fr(), r.next_fr()
+        assert (a, b) == (le(row[0]), le(row[1]))
+        out["fr"].append((a, b))
+    return out, r
+
+
+def test_field_ops_oracle(kats):
+    ins, _ = replay(kats)
+    p = O.R_MOD
+    for (a, b), row in zip(ins["fr"], kats["fr_ops"]):
+        assert [a * b % p, (a + b) % p, (a - b) % p, pow(a, -1, p)] == [le(x) for x in row[2:]]
+    q = O.Q_MOD
+    for row in kats["fq_ops"]:
+        a, b = le(row[0]), le(row[1])
+        assert [a * b % q, (a + b) % q, (a - b) % q, a * a % q] == [le(x) for x in row[2:]]
+        import zkref_c as OC
+        am, bm = cv._ints_to_limbs([cv.fq_to_mont_int(a)], 6)[0], cv._ints_to_limbs([cv.fq_to_mont_int(b)], 6)[0]
+        assert cv.fq_from_mont_int(cv._limbs_to_ints(OC.fq_mul(am, bm).reshape(1, 6))[0]) == le(row[2])
+
+
+def test_group_law_oracle(kats):
+    g = kats["group"]
+    k1, k2 = le(g["k1"]), le(g["k2"])
+    P, Qp = O.g1_mul(O.G1_GEN, k1), O.g1_mul(O.G1_GEN, k2)
+    want = [g1_unc(h) for h in g["g1"]]
+    assert [P, Qp, O.g1_add(P, Qp), O.g1_add(P, P), O.g1_add(P, O.g1_neg(Qp))] == want
+    assert O.g1_serialize_uncompressed(P).hex() == g["g1"][0]
+    P2 = O.g2_mul(O.G2_GEN, k1)
+    assert O.g2_serialize_uncompressed(P2).hex() == g["g2"][0]
+    assert O.g2_serialize_uncompressed(O.g2_add(P2, O.g2_mul(O.G2_GEN, k2))).hex() == g["g2"][2]
+
+
+def _msm_inputs(kats, r=None):
+    if r is None:
+        _, r = replay(kats)
+        for _ in kats["fq_ops"]:
+            for _ in range(2):
+                # Fq::rand: six u64, top 7 bits cleared (384 - 377), rejection -- not needed as values, only to advance the stream
+                while True:
+                    l = [r.next_u64() for _ in range(6)]
+                    l[5] &= (1 << 57) - 1
+                    if sum(x << (64 * i) for i, x in enumerate(l)) < O.Q_MOD:
+                        break
+        r.next_fr(); r.next_fr()                       # k1, k2 of the group block
+    n = kats["msm"]["n"]
+    ks = [r.next_fr() for _ in range(n)]
+    ss = [r.next_fr() for _ in range(n)]
+    assert ks[0] == le(kats["msm"]["k_first"]) and ss[0] == le(kats["msm"]["s_first"])
+    return ks, ss, r
+
+
+def test_msm_oracle(kats):
+    ks, ss, _ = _msm_inputs(kats)
+    e = sum(k * s for k, s in zip(ks, ss)) % O.R_MOD
+    assert O.g1_serialize_uncompressed(O.g1_mul(O.G1_GEN, e)).hex() == kats["msm"]["g1"]
+    assert O.g2_serialize_uncompressed(O.g2_mul(O.G2_GEN, e)).hex() == kats["msm"]["g2"]
+
+
+def test_fft_oracle(kats):
+    f = kats["fft"]
+    v = [le(x) for x in f["input"]]
+    d = O.Domain(64)
+    assert d.fft(v) == [le(x) for x in f["fft"]]
+    assert d.ifft(v) == [le(x) for x in f["ifft"]]
+    assert d.coset_fft(v) == [le(x) for x in f["coset_fft"]]
+    assert d.coset_ifft(v) == [le(x) for x in f["coset_ifft"]]
+
+
+def _simple_circuit(g):
+    a, b = le(g["a"]), le(g["b"])
+    r1cs = O.R1CS(2, 2, [[(1, 2)]] * 6, [[(1, 3)]] * 6, [[(1, 1)]] * 6)
+    z = [1, a * b % O.R_MOD, a, b]
+    td = O.Trapdoor(*[le(g[k]) for k in ("alpha", "beta", "gamma", "delta", "tau", "g1_k", "g2_k")])
+    return r1cs, z, td
+
+
+def test_groth16_proof_bytes_oracle(kats):
+    g = kats["groth16_simple"]
+    r1cs, z, td = _simple_circuit(g)
+    assert td.tau == FR.test_rng().next_fr()            # generate_parameters draws tau first from a fresh test_rng()
+    pks = O.ProvingKeyScalars(r1cs, td)
+    proof = O.proof_serialize(*O.predict_proof(r1cs, pks, z, le(g["r"]), le(g["s"])))
+    assert proof.hex() == g["proof"]
+
+
+def test_she_mul_oracle(kats):
+    s = kats["she_mul"]
+    x, y = [le(v) for v in s["x"]], [le(v) for v in s["y"]]
+    assert O.encodedtext_mul(x, y) == [le(v) for v in s["xy"]]
+
+
+# ---- the library against the same file ---------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_device_against_reference_vectors(ctx, kats):
+    from helpers import csr, td_mont, mont1
+    # field ops through the vector kernels
+    rows = kats["fr_ops"]
+    a = ctx.upload(cv.fr_to_mont([le(r[0]) for r in rows])); b = ctx.upload(cv.fr_to_mont([le(r[1]) for r in rows]))
+    out = ctx.alloc(len(rows) * 32)
+    for op, col in ((0, 2), (1, 3), (2, 4)):
+        ctx.fr_vec_op_dev(op, a.ptr, b.ptr, out.ptr, len(rows))
+        assert cv.fr_from_mont(ctx.download(out, (len(rows), 4))) == [le(r[col]) for r in rows]
+    # MSM through the host-slice entry points
+    ks, ss, _ = _msm_inputs(kats)
+    dk = ctx.upload(cv.fr_to_mont(ks))
+    for group, key in ((1, "g1"), (2, "g2")):
+        bases = ctx.fixed_base(dk.ptr, len(ks), group, mont1(1))
+        arr = bases.download()
+        res = (ctx.multi_scalar_mul_g1 if group == 1 else ctx.multi_scalar_mul_g2)(arr, cv.fr_to_mont(ss))
+        got = (cv.g1_projective_to_affine if group == 1 else cv.g2_projective_to_affine)(res)
+        ser = O.g1_serialize_uncompressed if group == 1 else O.g2_serialize_uncompressed
+        assert ser(got).hex() == kats["msm"][key]
+    # the four transforms
+    f = kats["fft"]
+    v = cv.fr_to_mont([le(x) for x in f["input"]])
+    for name, fn in (("fft", ctx.fft_in_place), ("ifft", ctx.ifft_in_place), ("coset_fft", ctx.coset_fft_in_place),
+                     ("coset_ifft", ctx.coset_ifft_in_place)):
+        assert cv.fr_from_mont(fn(v.copy(), 6)) == [le(x) for x in f[name]]
+    # Groth16: setup with the reference's toxic waste, the reference's proof bytes
+    g = kats["groth16_simple"]
+    r1cs, z, td = _simple_circuit(g)
+    dr = ctx.r1cs_upload(2, 2, csr(r1cs.a), csr(r1cs.b), csr(r1cs.c))
+    tdm = td_mont(td)
+    pk = ctx.groth16_setup(dr, *[tdm[i] for i in range(7)])
+    assert ctx.create_proof(pk, dr, cv.fr_to_mont(z), mont1(le(g["r"])), mont1(le(g["s"]))).hex() == g["proof"]
+    pk.free()
+    # SHE ring product
+    s = kats["she_mul"]
+    n = s["n"]
+    x = ctx.upload(cv.fq753_to_mont([le(v) for v in s["x"]])); y = ctx.upload(cv.fq753_to_mont([le(v) for v in s["y"]]))
+    o = ctx.alloc(n * 96)
+    ctx.encodedtext_mul_dev(x.ptr, y.ptr, o.ptr, n)
+    assert cv.fq753_from_mont(ctx.download(o, (n, 12))) == [le(v) for v in s["xy"]]

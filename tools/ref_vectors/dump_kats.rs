@@ -1,0 +1,137 @@
+//! dump_kats.rs -- known-answer vectors FROM THE REFERENCE (Yoii-Inc/zk-mpc with its vendored arkworks 0.3).
+//!
+//! This file is not part of the product and cannot be built in the build image (no Rust toolchain there).  On any machine
+//! with the reference checked out and `cargo` (stable 1.84, rust-toolchain.toml):
+//!
+//!   cp tools/ref_vectors/dump_kats.rs <zk-mpc>/examples/dump_kats.rs
+//!   cat tools/ref_vectors/Cargo.example.toml >> <zk-mpc>/Cargo.toml          # the [[example]] stanza
+//!   (cd <zk-mpc> && cargo run --release --example dump-kats -- ref_kats.json)
+//!   cp <zk-mpc>/ref_kats.json <this repo>/tests/golden/ref_kats.json
+//!   python -m pytest tests/test_ref_vectors.py              # CPU: the oracle against the file
+//!   python -m pytest tests/test_ref_vectors.py -m gpu       # GPU: libzkmpc_hip against the file
+//!
+//! Every input is drawn from `ark_std::test_rng()` (arkworks/std/src/rand_helper.rs:31-39) in the order written below, so
+//! that the consumer can REPLAY the inputs (oracle/fsrng_ref.py::test_rng, zk_rng_from_seed(seed, 12)) and needs only the
+//! outputs; the inputs are dumped as well, which also pins the replay of the generator itself.
+//! All field elements are written as the hex of their canonical little-endian bytes (`into_repr().to_bytes_le()`), points
+//! as the hex of `CanonicalSerialize::serialize_uncompressed` / `serialize` as noted.
+
+use ark_bls12_377::{Bls12_377, Fq, Fr, G1Affine, G1Projective, G2Affine, G2Projective};
+use ark_ec::msm::VariableBaseMSM;
+use ark_ec::{AffineCurve, ProjectiveCurve};
+use ark_ff::{BigInteger, Field, PrimeField, UniformRand};
+use ark_groth16::{create_proof, generate_parameters, Proof, ProvingKey};
+use ark_poly::{EvaluationDomain, Radix2EvaluationDomain};
+use ark_serialize::CanonicalSerialize;
+use ark_std::test_rng;
+use std::fmt::Write as _;
+use zk_mpc::circuits::circuit::MySimpleCircuit;
+
+fn fr_hex(x: &Fr) -> String { hex::encode(x.into_repr().to_bytes_le()) }
+fn fq_hex(x: &Fq) -> String { hex::encode(x.into_repr().to_bytes_le()) }
+fn ser<T: CanonicalSerialize>(x: &T) -> String { let mut v = Vec::new(); x.serialize(&mut v).unwrap(); hex::encode(v) }
+fn ser_unc<T: CanonicalSerialize>(x: &T) -> String { let mut v = Vec::new(); x.serialize_uncompressed(&mut v).unwrap(); hex::encode(v) }
+fn list(v: Vec<String>) -> String { format!("[{}]", v.iter().map(|s| format!("\"{}\"", s)).collect::<Vec<_>>().join(",")) }
+
+fn main() {
+    let out_path = std::env::args().nth(1).unwrap_or_else(|| "ref_kats.json".to_string());
+    let mut j = String::from("{\n");
+    let rng = &mut test_rng();
+
+    // (1) the generator itself: the first eight u64 of test_rng()  (StdRng = ChaCha12)
+    {
+        use ark_std::rand::RngCore;
+        let mut r = test_rng();
+        let w: Vec<String> = (0..8).map(|_| format!("{:016x}", r.next_u64())).collect();
+        writeln!(j, "\"test_rng_u64\": {},", list(w)).unwrap();
+    }
+
+    // (2) Fr / Fq arithmetic: 8 pairs each, a*b, a+b, a-b, a^-1  (ff/src/fields/arithmetic.rs, macros.rs)
+    let mut fr_rows = Vec::new();
+    for _ in 0..8 {
+        let (a, b) = (Fr::rand(rng), Fr::rand(rng));
+        fr_rows.push(list(vec![fr_hex(&a), fr_hex(&b), fr_hex(&(a * b)), fr_hex(&(a + b)), fr_hex(&(a - b)), fr_hex(&a.inverse().unwrap())]));
+    }
+    writeln!(j, "\"fr_ops\": [{}],", fr_rows.join(",")).unwrap();
+    let mut fq_rows = Vec::new();
+    for _ in 0..8 {
+        let (a, b) = (Fq::rand(rng), Fq::rand(rng));
+        fq_rows.push(list(vec![fq_hex(&a), fq_hex(&b), fq_hex(&(a * b)), fq_hex(&(a + b)), fq_hex(&(a - b)), fq_hex(&a.square())]));
+    }
+    writeln!(j, "\"fq_ops\": [{}],", fq_rows.join(",")).unwrap();
+
+    // (3) group law: P = k1 G, Q = k2 G; P + Q, 2P, P - Q  (short_weierstrass_jacobian.rs:557-784), uncompressed bytes
+    {
+        let (k1, k2) = (Fr::rand(rng), Fr::rand(rng));
+        let g1 = G1Affine::prime_subgroup_generator();
+        let g2 = G2Affine::prime_subgroup_generator();
+        let (p1, q1) = (g1.mul(k1), g1.mul(k2));
+        let (p2, q2) = (g2.mul(k1), g2.mul(k2));
+        writeln!(j, "\"group\": {{\"k1\": \"{}\", \"k2\": \"{}\", \"g1\": {}, \"g2\": {}}},", fr_hex(&k1), fr_hex(&k2),
+                 list(vec![ser_unc(&p1.into_affine()), ser_unc(&q1.into_affine()), ser_unc(&(p1 + q1).into_affine()),
+                           ser_unc(&p1.double().into_affine()), ser_unc(&(p1 - q1).into_affine())]),
+                 list(vec![ser_unc(&p2.into_affine()), ser_unc(&q2.into_affine()), ser_unc(&(p2 + q2).into_affine()),
+                           ser_unc(&p2.double().into_affine()), ser_unc(&(p2 - q2).into_affine())])).unwrap();
+    }
+
+    // (4) VariableBaseMSM on 2^10 - 1 terms (the size of test-templates/src/msm.rs): bases k_i G (k_i drawn first), then scalars
+    {
+        let n = (1usize << 10) - 1;
+        let ks: Vec<Fr> = (0..n).map(|_| Fr::rand(rng)).collect();
+        let ss: Vec<Fr> = (0..n).map(|_| Fr::rand(rng)).collect();
+        let g1 = G1Affine::prime_subgroup_generator();
+        let g2 = G2Affine::prime_subgroup_generator();
+        let b1: Vec<G1Affine> = G1Projective::batch_normalization_into_affine(&ks.iter().map(|k| g1.mul(*k)).collect::<Vec<_>>());
+        let b2: Vec<G2Affine> = G2Projective::batch_normalization_into_affine(&ks.iter().map(|k| g2.mul(*k)).collect::<Vec<_>>());
+        let sr: Vec<_> = ss.iter().map(|s| s.into_repr()).collect();
+        let m1 = VariableBaseMSM::multi_scalar_mul(&b1, &sr).into_affine();
+        let m2 = VariableBaseMSM::multi_scalar_mul(&b2, &sr).into_affine();
+        writeln!(j, "\"msm\": {{\"n\": {}, \"k_first\": \"{}\", \"s_first\": \"{}\", \"g1\": \"{}\", \"g2\": \"{}\"}},", n,
+                 fr_hex(&ks[0]), fr_hex(&ss[0]), ser_unc(&m1), ser_unc(&m2)).unwrap();
+    }
+
+    // (5) the four transforms on 2^6 random points (radix2/fft.rs, domain/mod.rs:138-157)
+    {
+        let d = Radix2EvaluationDomain::<Fr>::new(64).unwrap();
+        let v: Vec<Fr> = (0..64).map(|_| Fr::rand(rng)).collect();
+        let hexes = |x: &Vec<Fr>| list(x.iter().map(fr_hex).collect());
+        let (mut a, mut b, mut c, mut e) = (v.clone(), v.clone(), v.clone(), v.clone());
+        d.fft_in_place(&mut a); d.ifft_in_place(&mut b); d.coset_fft_in_place(&mut c); d.coset_ifft_in_place(&mut e);
+        writeln!(j, "\"fft\": {{\"input\": {}, \"fft\": {}, \"ifft\": {}, \"coset_fft\": {}, \"coset_ifft\": {}}},",
+                 hexes(&v), hexes(&a), hexes(&b), hexes(&c), hexes(&e)).unwrap();
+    }
+
+    // (6) Groth16 on MySimpleCircuit (src/circuits/circuit.rs:80-111; BASELINE config 1's circuit) with explicit toxic waste:
+    //     alpha, beta, gamma, delta, g1 = k1 G, g2 = k2 G, then a, b, r, s -- all from the rng in this order; generate_parameters
+    //     draws tau from a FRESH test_rng() (its first accepted Fr::rand), create_proof takes r and s.
+    {
+        let (alpha, beta, gamma, delta) = (Fr::rand(rng), Fr::rand(rng), Fr::rand(rng), Fr::rand(rng));
+        let (k1, k2) = (Fr::rand(rng), Fr::rand(rng));
+        let (a, b, r, s) = (Fr::rand(rng), Fr::rand(rng), Fr::rand(rng), Fr::rand(rng));
+        let g1 = G1Affine::prime_subgroup_generator().mul(k1);
+        let g2 = G2Affine::prime_subgroup_generator().mul(k2);
+        let pk: ProvingKey<Bls12_377> = generate_parameters::<Bls12_377, _, _>(
+            MySimpleCircuit::<Fr> { a: None, b: None }, alpha, beta, gamma, delta, g1, g2, &mut test_rng()).unwrap();
+        let proof: Proof<Bls12_377> = create_proof(MySimpleCircuit { a: Some(a), b: Some(b) }, &pk, r, s).unwrap();
+        let tau = Fr::rand(&mut test_rng());
+        writeln!(j, "\"groth16_simple\": {{\"alpha\": \"{}\", \"beta\": \"{}\", \"gamma\": \"{}\", \"delta\": \"{}\", \"g1_k\": \"{}\", \"g2_k\": \"{}\", \
+                     \"tau\": \"{}\", \"a\": \"{}\", \"b\": \"{}\", \"r\": \"{}\", \"s\": \"{}\", \"proof\": \"{}\", \"vk\": \"{}\", \"pk_sha_len\": {}}},",
+                 fr_hex(&alpha), fr_hex(&beta), fr_hex(&gamma), fr_hex(&delta), fr_hex(&k1), fr_hex(&k2), fr_hex(&tau),
+                 fr_hex(&a), fr_hex(&b), fr_hex(&r), fr_hex(&s), ser(&proof), ser(&pk.vk), ser(&pk).len() / 2).unwrap();
+    }
+
+    // (7) SHE: Encodedtext * Encodedtext in F_q[X]/(X^N + 1), N = 4 (src/she/encodedtext.rs:115-134), q = MNT4-753 base field
+    {
+        use ark_mnt4_753::Fq as Fq753;
+        use zk_mpc::she::Encodedtext;
+        let n = 4usize;
+        let x: Vec<Fq753> = (0..n).map(|_| Fq753::rand(rng)).collect();
+        let y: Vec<Fq753> = (0..n).map(|_| Fq753::rand(rng)).collect();
+        let z = Encodedtext::from_vec(x.clone()) * Encodedtext::from_vec(y.clone());
+        let h = |v: &Vec<Fq753>| list(v.iter().map(|e| hex::encode(e.into_repr().to_bytes_le())).collect());
+        writeln!(j, "\"she_mul\": {{\"n\": {}, \"x\": {}, \"y\": {}, \"xy\": {}}}", n, h(&x), h(&y), h(&z.vals)).unwrap();
+    }
+    j.push_str("}\n");
+    std::fs::write(&out_path, j).unwrap();
+    println!("wrote {}", out_path);
+}

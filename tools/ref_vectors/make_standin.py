@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""A STAND-IN for ref_kats.json written by the ORACLE (not by the reference): same schema, same order of rng draws as
+dump_kats.rs.  Its only purpose is to exercise tests/test_ref_vectors.py's consumer logic (schema, replay order, byte
+formats) while no reference-generated file exists; it pins nothing and must never be committed as tests/golden/ref_kats.json.
+
+  python tools/ref_vectors/make_standin.py /tmp/standin.json && ZK_REF_KATS=/tmp/standin.json python -m pytest tests/test_ref_vectors.py
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import fsrng_ref as FR  # noqa: E402
+import zkref as O  # noqa: E402
+
+
+def hx(v, n):
+    return int(v).to_bytes(n, "little").hex()
+
+
+def fq_rand(r, mod, words, shave):
+    while True:
+        l = [r.next_u64() for _ in range(words)]
+        l[-1] &= (1 << (64 - shave)) - 1
+        v = sum(x << (64 * i) for i, x in enumerate(l))
+        if v < mod:
+            return v * pow(1 << (64 * words), -1, mod) % mod      # the words are the Montgomery form
+
+
+def main():
+    out = {}
+    r0 = FR.test_rng()
+    out["test_rng_u64"] = ["%016x" % r0.next_u64() for _ in range(8)]
+    r = FR.test_rng()
+    p, q = O.R_MOD, O.Q_MOD
+    rows = []
+    for _ in range(8):
+        a, b = r.next_fr(), r.next_fr()
+        rows.append([hx(a, 32), hx(b, 32), hx(a * b % p, 32), hx((a + b) % p, 32), hx((a - b) % p, 32), hx(pow(a, -1, p), 32)])
+    out["fr_ops"] = rows
+    rows = []
+    for _ in range(8):
+        a, b = fq_rand(r, q, 6, 7), fq_rand(r, q, 6, 7)
+        rows.append([hx(a, 48), hx(b, 48), hx(a * b % q, 48), hx((a + b) % q, 48), hx((a - b) % q, 48), hx(a * a % q, 48)])
+    out["fq_ops"] = rows
+    k1, k2 = r.next_fr(), r.next_fr()
+    P1, Q1 = O.g1_mul(O.G1_GEN, k1), O.g1_mul(O.G1_GEN, k2)
+    P2, Q2 = O.g2_mul(O.G2_GEN, k1), O.g2_mul(O.G2_GEN, k2)
+    u1, u2 = O.g1_serialize_uncompressed, O.g2_serialize_uncompressed
+    out["group"] = {"k1": hx(k1, 32), "k2": hx(k2, 32),
+                    "g1": [u1(x).hex() for x in (P1, Q1, O.g1_add(P1, Q1), O.g1_add(P1, P1), O.g1_add(P1, O.g1_neg(Q1)))],
+                    "g2": [u2(x).hex() for x in (P2, Q2, O.g2_add(P2, Q2), O.g2_add(P2, P2), O.g2_add(P2, O.g2_neg(Q2)))]}
+    n = (1 << 10) - 1
+    ks = [r.next_fr() for _ in range(n)]
+    ss = [r.next_fr() for _ in range(n)]
+    e = sum(k * s for k, s in zip(ks, ss)) % p
+    out["msm"] = {"n": n, "k_first": hx(ks[0], 32), "s_first": hx(ss[0], 32), "g1": u1(O.g1_mul(O.G1_GEN, e)).hex(),
+                  "g2": u2(O.g2_mul(O.G2_GEN, e)).hex()}
+    v = [r.next_fr() for _ in range(64)]
+    d = O.Domain(64)
+    h = lambda xs: [hx(x, 32) for x in xs]
+    out["fft"] = {"input": h(v), "fft": h(d.fft(v)), "ifft": h(d.ifft(v)), "coset_fft": h(d.coset_fft(v)), "coset_ifft": h(d.coset_ifft(v))}
+    alpha, beta, gamma, delta, g1k, g2k, a, b, rr, ss_ = [r.next_fr() for _ in range(10)]
+    tau = FR.test_rng().next_fr()
+    r1cs = O.R1CS(2, 2, [[(1, 2)]] * 6, [[(1, 3)]] * 6, [[(1, 1)]] * 6)
+    z = [1, a * b % p, a, b]
+    pks = O.ProvingKeyScalars(r1cs, O.Trapdoor(alpha, beta, gamma, delta, tau, g1k, g2k))
+    proof = O.proof_serialize(*O.predict_proof(r1cs, pks, z, rr, ss_))
+    out["groth16_simple"] = dict(alpha=hx(alpha, 32), beta=hx(beta, 32), gamma=hx(gamma, 32), delta=hx(delta, 32), g1_k=hx(g1k, 32),
+                                 g2_k=hx(g2k, 32), tau=hx(tau, 32), a=hx(a, 32), b=hx(b, 32), r=hx(rr, 32), s=hx(ss_, 32),
+                                 proof=proof.hex(), vk="", pk_sha_len=0)
+    N = 4
+    x = [fq_rand(r, O.Q753, 12, 15) for _ in range(N)]
+    y = [fq_rand(r, O.Q753, 12, 15) for _ in range(N)]
+    out["she_mul"] = {"n": N, "x": [hx(t, 96) for t in x], "y": [hx(t, 96) for t in y], "xy": [hx(t, 96) for t in O.encodedtext_mul(x, y)]}
+    json.dump(out, open(sys.argv[1], "w"))
+
+
+if __name__ == "__main__":
+    main()
