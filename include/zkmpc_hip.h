@@ -140,6 +140,21 @@ int zk_bases_deserialize_uncompressed(zk_ctx* ctx, int group, const uint8_t* byt
  * :110-125), sign from the flag; error if an x is not on the curve; no subgroup check. */
 int zk_bases_deserialize_compressed(zk_ctx* ctx, int group, const uint8_t* bytes_host, size_t n, zk_bases** out);
 
+/* CanonicalSerialize framing of the Groth16 keys (arkworks/groth16/src/data_structures.rs:43-58,133-151) and of a KZG10
+ * UniversalParams (poly-commit/src/kzg10/data_structures.rs:40-80, the file save_srs_to_file writes: src/marlin.rs:371-376), in the
+ * compressed or the uncompressed form, so that keys and SRS files interchange with the Rust side.  The *_size functions give
+ * the exact byte count; serialisers fail if `cap` is smaller. */
+size_t zk_vk_serialized_size(const zk_pk* pk, int compressed);
+size_t zk_pk_serialized_size(const zk_pk* pk, int compressed);
+int zk_vk_serialize(zk_ctx* ctx, const zk_pk* pk, int compressed, uint8_t* out_host, size_t cap);
+int zk_pk_serialize(zk_ctx* ctx, const zk_pk* pk, int compressed, uint8_t* out_host, size_t cap);
+int zk_pk_deserialize(zk_ctx* ctx, const uint8_t* bytes_host, size_t len, int compressed, zk_pk** out);   /* resident key, like zk_pk_upload */
+size_t zk_kzg_srs_serialized_size(size_t n_powers_g, size_t n_powers_gamma_g, int compressed);
+int zk_kzg_srs_serialize(zk_ctx* ctx, const zk_bases* powers_g, const zk_bases* powers_gamma_g, const zk_g2_affine* h,
+                         const zk_g2_affine* beta_h, int compressed, uint8_t* out_host, size_t cap);
+int zk_kzg_srs_deserialize(zk_ctx* ctx, const uint8_t* bytes_host, size_t len, int compressed, zk_bases** powers_g,
+                           zk_bases** powers_gamma_g, zk_g2_affine* h, zk_g2_affine* beta_h);
+
 /* n_jobs independent MSMs pipelined over the library's sort / accumulate streams (one job sorts while the previous one
  * accumulates).  outs[k] receives a zk_g1_projective or zk_g2_projective according to bases[k]'s group; base_offsets may
  * be NULL.  Same result as n_jobs calls of zk_msm_g1_dev / zk_msm_g2_dev. */

@@ -83,3 +83,54 @@ def test_groth16_keys_wire_format(ctx):
     assert proof == ctx.create_proof(pk3, dr, zm, mont1(r), mont1(s))
     A, B, Cc = O.create_proof(r1cs, opk, z, r, s)
     assert proof == O.proof_serialize(A, B, Cc)
+
+
+def test_kzg_srs_wire_format(ctx):
+    """UniversalParams::serialize (kzg10/data_structures.rs:40-80; the file src/marlin.rs:371-376 writes) laid out by hand from
+    the struct -- Vec powers_of_g | BTreeMap powers_of_gamma_g (u64 key, point) | h | beta_h | empty neg_powers_of_h -- with the
+    oracle's point bytes, both forms; the SRS read back commits to the same point."""
+    rng = O.Prng(953)
+    max_degree = 37
+    beta, g_k, gg_k, h_k = rng.fr(), rng.fr(), rng.fr(), rng.fr()
+    pp = O.KzgParams(max_degree, beta, g_k=g_k, gg_k=gg_k, h_k=h_k)
+    pw = ctx.alloc((max_degree + 2) * 32)
+    ctx.fr_powers_dev(mont1(beta), mont1(1), max_degree + 2, pw.ptr)
+    powers_g = ctx.fixed_base(pw.ptr, max_degree + 1, 1, mont1(g_k))
+    powers_gamma_g = ctx.fixed_base(pw.ptr, max_degree + 2, 1, mont1(gg_k))
+    h = cv.g2_affine_to_array([pp.h])[0]
+    beta_h = cv.g2_affine_to_array([pp.beta_h])[0]
+    u64 = lambda v: v.to_bytes(8, "little")
+    for compressed in (True, False):
+        s1, s2 = (O.g1_serialize, O.g2_serialize) if compressed else (O.g1_serialize_uncompressed, O.g2_serialize_uncompressed)
+        want = u64(max_degree + 1) + b"".join(s1(p) for p in pp.powers_of_g)
+        want += u64(max_degree + 2) + b"".join(u64(i) + s1(p) for i, p in enumerate(pp.powers_of_gamma_g))
+        want += s2(pp.h) + s2(pp.beta_h) + u64(0)
+        got = S.kzg_srs_bytes(ctx, powers_g, powers_gamma_g, h, beta_h, compressed)
+        assert got == want
+        pg, pgg, h2, bh2 = S.kzg_srs_from_bytes(ctx, got, compressed)
+        assert cv.g1_array_to_affine(pg.download()) == pp.powers_of_g
+        assert cv.g1_array_to_affine(pgg.download()) == pp.powers_of_gamma_g
+        assert cv.g2_array_to_affine(h2.reshape(1, 24)) == [pp.h] and cv.g2_array_to_affine(bh2.reshape(1, 24)) == [pp.beta_h]
+        coeffs = [rng.fr() for _ in range(max_degree + 1)]
+        dc = ctx.upload(cv.fr_to_mont(coeffs))
+        assert cv.g1_projective_to_affine(ctx.kzg_commit_dev(pg, dc.ptr, len(coeffs))) == O.kzg_commit(pp, coeffs)
+        with pytest.raises(Exception, match="truncated|trailing|neg_powers"):
+            S.kzg_srs_from_bytes(ctx, got[:-3], compressed)
+        pg.free(); pgg.free()
+
+
+def test_key_framing_rejects_malformed_input(ctx):
+    rng = O.Prng(954)
+    n = 9
+    r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
+    td = O.Trapdoor(*[rng.fr() for _ in range(7)])
+    opk = O.ProvingKey(O.ProvingKeyScalars(r1cs, td))
+    data = O.pk_serialize(opk, False)
+    with pytest.raises(Exception, match="truncated"):
+        S.proving_key_from_bytes(ctx, data[:-10])
+    with pytest.raises(Exception, match="trailing"):
+        S.proving_key_from_bytes(ctx, data + b"\\0")
+    bad = bytearray(data)
+    bad[5] ^= 1                                                  # alpha_g1.x: not on the curve any more
+    with pytest.raises(Exception, match="not on the curve"):
+        S.proving_key_from_bytes(ctx, bytes(bad))

@@ -163,6 +163,14 @@ PROTOTYPES = {
     "zk_bases_deserialize_uncompressed": (_I, [_P, _I, _P, _SZ, C.POINTER(_P)]),
     "zk_bases_deserialize_compressed": (_I, [_P, _I, _P, _SZ, C.POINTER(_P)]),
     "zk_msm_batch_dev": (_I, [_P, _SZ, _P, _P, _P, _P, _P]),
+    "zk_vk_serialized_size": (_SZ, [_P, _I]),
+    "zk_pk_serialized_size": (_SZ, [_P, _I]),
+    "zk_vk_serialize": (_I, [_P, _P, _I, _P, _SZ]),
+    "zk_pk_serialize": (_I, [_P, _P, _I, _P, _SZ]),
+    "zk_pk_deserialize": (_I, [_P, _P, _SZ, _I, C.POINTER(_P)]),
+    "zk_kzg_srs_serialized_size": (_SZ, [_SZ, _SZ, _I]),
+    "zk_kzg_srs_serialize": (_I, [_P, _P, _P, _P, _P, _I, _P, _SZ]),
+    "zk_kzg_srs_deserialize": (_I, [_P, _P, _SZ, _I, C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "zk_comm_unique_id": (_I, [_P]),
     "zk_comm_init": (_I, [_P, _P, _I, _I]),
     "zk_comm_destroy": (_I, [_P]),

@@ -1,7 +1,8 @@
-"""arkworks wire formats of the Groth16 key material: `CanonicalSerialize` layouts of
-VerifyingKey / ProvingKey (arkworks/groth16/src/data_structures.rs:43-58,133-151), so that keys made or held by
-this library interchange with the Rust prover / verifier.  Point bytes come from the device (`zk_bases_serialize`);
-this module only orders the fields and writes the `Vec` length prefixes (serialize/src/lib.rs:263-272).
+"""arkworks wire formats of the Groth16 key material and of a KZG10 SRS: `CanonicalSerialize` layouts of
+VerifyingKey / ProvingKey (arkworks/groth16/src/data_structures.rs:43-58,133-151) and UniversalParams
+(poly-commit/src/kzg10/data_structures.rs:40-80), so that keys made or held by this library interchange with the Rust
+prover / verifier.  Framing and point bytes are the library's (zk_pk_serialize, zk_pk_deserialize, zk_kzg_srs_*): this
+module is the ctypes mirror.
 
 Proofs are already emitted in wire form by `create_proof` (192 B: a | b | c compressed)."""
 from __future__ import annotations
@@ -13,72 +14,54 @@ from .api import Bases, Context, ProvingKey
 _G1_QUERIES = ("a_query", "b_g1_query", "h_query", "l_query", "gamma_abc_g1")
 
 
-def _points(ctx: Context, arr: np.ndarray, group: int, compressed: bool) -> bytes:
-    b = ctx.bases_upload(np.asarray(arr, dtype=np.uint64).reshape(-1, 12 if group == 1 else 24), group)
-    try:
-        return b.serialize(compressed)
-    finally:
-        b.free()
-
-
-def _vec(bases: Bases, compressed: bool) -> bytes:
-    return len(bases).to_bytes(8, "little") + bases.serialize(compressed)
+def _buf(n: int):
+    import ctypes as C
+    return (C.c_uint8 * n)()
 
 
 def verifying_key_bytes(ctx: Context, pk: ProvingKey, compressed: bool = True) -> bytes:
-    """alpha_g1 | beta_g2 | gamma_g2 | delta_g2 | gamma_abc_g1 (Vec)."""
-    return (_points(ctx, pk.vk_g1(0), 1, compressed)
-            + _points(ctx, np.stack([pk.vk_g2(0), pk.vk_g2(2), pk.vk_g2(1)]), 2, compressed)
-            + _vec(pk.query_bases("gamma_abc_g1"), compressed))
+    """VerifyingKey::serialize[_uncompressed] (zk_vk_serialize): alpha_g1 | beta_g2 | gamma_g2 | delta_g2 | gamma_abc_g1 (Vec)."""
+    n = ctx.lib.zk_vk_serialized_size(pk.h, int(compressed))
+    out = _buf(n)
+    ctx._ck(ctx.lib.zk_vk_serialize(ctx.h, pk.h, int(compressed), out, n))
+    return bytes(out)
 
 
 def proving_key_bytes(ctx: Context, pk: ProvingKey, compressed: bool = True) -> bytes:
-    """vk | beta_g1 | delta_g1 | a_query | b_g1_query | b_g2_query | h_query | l_query."""
-    out = [verifying_key_bytes(ctx, pk, compressed), _points(ctx, np.stack([pk.vk_g1(1), pk.vk_g1(2)]), 1, compressed)]
-    for name in ("a_query", "b_g1_query", "b_g2_query", "h_query", "l_query"):
-        out.append(_vec(pk.query_bases(name), compressed))
-    return b"".join(out)
-
-
-class _Reader:
-    def __init__(self, data: bytes):
-        self.data, self.pos = memoryview(data), 0
-
-    def take(self, n: int) -> bytes:
-        if self.pos + n > len(self.data):
-            raise ValueError("truncated key")
-        out = self.data[self.pos:self.pos + n]
-        self.pos += n
-        return bytes(out)
-
-    def u64(self) -> int:
-        return int.from_bytes(self.take(8), "little")
+    """ProvingKey::serialize[_uncompressed] (zk_pk_serialize): vk | beta_g1 | delta_g1 | a_query | b_g1_query | b_g2_query |
+    h_query | l_query."""
+    n = ctx.lib.zk_pk_serialized_size(pk.h, int(compressed))
+    out = _buf(n)
+    ctx._ck(ctx.lib.zk_pk_serialize(ctx.h, pk.h, int(compressed), out, n))
+    return bytes(out)
 
 
 def proving_key_from_bytes(ctx: Context, data: bytes, compressed: bool = False):
-    """Load a ProvingKey written with `serialize_uncompressed` or, with compressed=True, with `serialize` (one square
-    root per point on the device).  Returns (ProvingKey, gamma_g2, gamma_abc_g1): the prover does not use the last two,
-    the verifier does."""
-    r = _Reader(data)
+    """ProvingKey::deserialize (compressed: one square root per point on the device) or deserialize_uncompressed through
+    zk_pk_deserialize: the tables go straight to the device and the key is resident like one from zk_pk_upload.
+    Returns (ProvingKey, gamma_g2, gamma_abc_g1): the prover does not use the last two, the verifier does."""
+    import ctypes as C
+    h = C.c_void_p()
+    ctx._ck(ctx.lib.zk_pk_deserialize(ctx.h, data, len(data), int(compressed), C.byref(h)))
+    pk = ProvingKey(ctx, h)
+    return pk, pk.vk_g2(2), pk.download("gamma_abc_g1")
 
-    def pts(n: int, group: int) -> np.ndarray:
-        raw = r.take(n * (48 if group == 1 else 96) * (1 if compressed else 2))
-        b = (ctx.bases_deserialize_compressed if compressed else ctx.bases_deserialize_uncompressed)(raw, n, group)
-        try:
-            return b.download()
-        finally:
-            b.free()
 
-    alpha_g1 = pts(1, 1)[0]
-    beta_g2, gamma_g2, delta_g2 = pts(3, 2)
-    gamma_abc = pts(r.u64(), 1)
-    beta_g1, delta_g1 = pts(2, 1)
-    a_query = pts(r.u64(), 1)
-    b_g1_query = pts(r.u64(), 1)
-    b_g2_query = pts(r.u64(), 2)
-    h_query = pts(r.u64(), 1)
-    l_query = pts(r.u64(), 1)
-    if r.pos != len(r.data):
-        raise ValueError("trailing bytes after the proving key")
-    pk = ctx.pk_upload(alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query, b_g1_query, b_g2_query, h_query, l_query)
-    return pk, gamma_g2, gamma_abc
+def kzg_srs_bytes(ctx: Context, powers_g: Bases, powers_gamma_g: Bases, h24, beta_h24, compressed: bool = True) -> bytes:
+    """UniversalParams::serialize (poly-commit/src/kzg10/data_structures.rs:40-80; src/marlin.rs:371-376 writes it to a file):
+    powers_of_g (Vec) | powers_of_gamma_g (BTreeMap 0..n-1) | h | beta_h | neg_powers_of_h (empty)."""
+    n = ctx.lib.zk_kzg_srs_serialized_size(len(powers_g), len(powers_gamma_g), int(compressed))
+    out = _buf(n)
+    h24 = np.ascontiguousarray(h24, dtype=np.uint64)
+    beta_h24 = np.ascontiguousarray(beta_h24, dtype=np.uint64)
+    ctx._ck(ctx.lib.zk_kzg_srs_serialize(ctx.h, powers_g.h, powers_gamma_g.h, h24.ctypes.data, beta_h24.ctypes.data, int(compressed), out, n))
+    return bytes(out)
+
+
+def kzg_srs_from_bytes(ctx: Context, data: bytes, compressed: bool = True):
+    """-> (powers_g Bases, powers_gamma_g Bases, h (24,) uint64, beta_h (24,) uint64)."""
+    import ctypes as C
+    pg, pgg = C.c_void_p(), C.c_void_p()
+    h, bh = np.zeros(24, dtype=np.uint64), np.zeros(24, dtype=np.uint64)
+    ctx._ck(ctx.lib.zk_kzg_srs_deserialize(ctx.h, data, len(data), int(compressed), C.byref(pg), C.byref(pgg), h.ctypes.data, bh.ctypes.data))
+    return Bases(ctx, pg, 1), Bases(ctx, pgg, 1), h, bh
