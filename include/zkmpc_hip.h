@@ -40,6 +40,7 @@ typedef struct zk_ctx zk_ctx;
 typedef struct zk_bases zk_bases;   /* device-resident MSM base table (G1 or G2) */
 typedef struct zk_r1cs zk_r1cs;     /* device-resident ConstraintMatrices (CSR) */
 typedef struct zk_pk zk_pk;         /* device-resident Groth16 ProvingKey */
+typedef struct zk_rng zk_rng;       /* host generator: FiatShamirRng / ChaChaRng / StdRng (see "randomness" below) */
 
 typedef struct { uint64_t l[4]; } zk_fr;                 /* Fp256<FrParameters> */
 typedef struct { uint64_t l[6]; } zk_fq;                 /* Fp384<FqParameters> */
@@ -314,6 +315,38 @@ int zk_marlin_round3_ab_evals_dev(zk_ctx* ctx, const zk_marlin_matrix_evals on_b
                                   const zk_fr* beta, const zk_fr eta[3], const zk_fr* vh_alpha_vh_beta, void* a_out_dev,
                                   void* b_out_dev);
 
+/* Marlin::prove (arkworks/marlin/src/lib.rs:152-319) as one call: the three AHP rounds, MarlinKZG10 commitments (hiding bound 1 on
+ * w, z_a, z_b, g_1; degree bounds |H| - 2 on g_1 and |K| - 2 on g_2 through the shifted powers), the Fiat-Shamir transcript
+ * (FiatShamirRng<Blake2s> over the bytes to_bytes! writes), the evaluations and open_combinations, on an index the caller built
+ * once (Marlin::index is set-up: zk-mpc_amd/marlin.py::Index / IndexKeys do it with the calls above) and hands over as
+ * device-resident tables:
+ *   index_polys     a_row a_col a_val a_row_col b_... c_... (ahp/mod.rs:33-40): coefficient vectors
+ *   on_k / on_b     evaluations of row / col / val (/ row_col) of A*, B*, C* on K and on the domain B of size >= 3|K| - 3
+ *   r1cs / r1cs_t   the balanced, padded matrices (z_A, z_B) and their transposes with rows re-indexed into H (calculate_t)
+ *   w_idx / x_idx   the index maps of prover.rs:343-353 (|H| u32 each; 0xFFFFFFFF = zero)
+ *   ivk_bytes       IndexVerifierKey::write: index_info | index_comms (marlin/src/data_structures.rs:36-43), the transcript's seed
+ * powers_g: powers_of_g[0 ..= max_degree] of the SRS; powers_gamma_g: powers_of_gamma_g[0 .. 2].  z_dev: the padded assignment
+ * (instance first).  zk_rng: the prover's randomness (zk_rng_from_seed / zk_fsrng_new), drawn in the reference's order;
+ * mask_on_device != 0 samples the 3|H| mask coefficients on the device under a key taken from zk_rng (same distribution, a
+ * different stream: 0.4 s of scalar ChaCha at 2^20 otherwise).  The proof is written in CanonicalSerialize form
+ * (marlin/src/data_structures.rs:99-110); cap must be >= zk_marlin_proof_max_size().  Errors: an unsatisfied system fails
+ * the outer sum-check (ZK_ERR_STATE), as the reference's assertions do. */
+typedef struct { const void* ptr; size_t n; } zk_poly_ref;
+typedef struct {
+    size_t num_constraints, num_variables, num_non_zero, num_instance;
+    const zk_r1cs* r1cs;
+    const zk_r1cs* r1cs_t;
+    zk_poly_ref index_polys[12];
+    zk_marlin_matrix_evals on_k[3], on_b[3];
+    const uint32_t* w_idx;
+    const uint32_t* x_idx;
+    const uint8_t* ivk_bytes;
+    size_t ivk_len;
+} zk_marlin_index;
+size_t zk_marlin_proof_max_size(void);
+int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* index, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
+                    const void* z_dev, zk_rng* zk_rng, int mask_on_device, uint8_t* proof_out, size_t cap, size_t* proof_len);
+
 /* ---- SHE ring arithmetic of the preprocessing phase (row a15) ----
  * Elements are ark_mnt4_753::Fq = Fp768 (12 x u64 little-endian, Montgomery R = 2^768), the `Fq` of src/she.rs:17.
  * An Encodedtext of degree N is N consecutive elements; a Ciphertext is c0 | c1 | c2 (3N elements,
@@ -386,7 +419,6 @@ int zk_fr_random_dev(zk_ctx* ctx, const uint8_t* key32, uint64_t stream_id, void
  *   zk_rng_next_fr                   Fr::rand: 4 x next_u64, top 3 bits cleared, rejected unless < r; the words are the
  *                                    element's Montgomery form (ff/src/fields/arithmetic.rs:200-219)
  *   zk_rng_next_u128                 u128::rand (marlin/src/lib.rs:300: the opening challenge), low half in out[0] */
-typedef struct zk_rng zk_rng;
 int zk_fsrng_new(const uint8_t* seed_bytes, size_t len, zk_rng** out);
 int zk_fsrng_absorb(zk_rng* rng, const uint8_t* bytes, size_t len);
 int zk_rng_from_seed(const uint8_t seed[32], int rounds, zk_rng** out);

@@ -229,3 +229,24 @@ def test_marlin_proof_verifies_at_size(ctx, n):
     ev = list(proof.evaluations); ev[0] = (ev[0] + 1) % O.R_MOD
     assert not MF.verify(okeys, pub, MF.Proof(as_oracle.commitments, ev, as_oracle.pc_proof))
     assert len(proof.serialize(ctx)) == 8 + 3 * 8 + 9 * 49 + 2 * 48 + 8 + 7 * 32 + 8 + 3 + 8 + 2 * 49 + 32 + 1
+
+
+@pytest.mark.parametrize("n", [3, 13, 1000])
+def test_native_marlin_prove_equals_the_python_sequence(ctx, n):
+    """zk_marlin_prove (one C++ entry point) emits the bytes of marlin.py::prove (the ~200-call sequence the collaborative
+    provers build on) from the same prover rng -- and, through it, of the oracle's prover at the small sizes -- for the
+    host-drawn and the device-sampled mask polynomial; an unsatisfied system is refused."""
+    from zk_mpc_amd.api import Rng
+    rng, r1cs, sq, zz, dix = build(ctx, n, 6000 + n)
+    srs = DM.UniversalSrs(ctx, DM.ahp_max_degree(dix) + 2, rng.fr(), rng.fr(), rng.fr())
+    keys = DM.IndexKeys(dix, srs)
+    z = ctx.upload(cv.fr_to_mont(zz))
+    seed = bytes((3 * i + 1) & 0xff for i in range(32))
+    for on_dev in (False, True):
+        want = DM.prove(keys, z, Rng.from_seed(seed, 20), mask_on_device=on_dev).serialize(ctx)
+        got = DM.prove_native(keys, z, Rng.from_seed(seed, 20), mask_on_device=on_dev)
+        assert got == want
+        assert DM.prove_native(keys, z, Rng.from_seed(seed, 20), mask_on_device=on_dev) == want      # scratch reuse across calls
+    bad = list(zz); bad[dix.num_instance + 1] = (bad[dix.num_instance + 1] + 1) % O.R_MOD
+    with pytest.raises(Exception, match="sum over H|divisible"):
+        DM.prove_native(keys, ctx.upload(cv.fr_to_mont(bad)), Rng.from_seed(seed, 20))

@@ -31,6 +31,17 @@ class MarlinMatrixEvals(C.Structure):
     _fields_ = [("row", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("row_col", C.c_void_p)]
 
 
+class PolyRef(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("n", C.c_size_t)]
+
+
+class MarlinIndex(C.Structure):
+    _fields_ = [("num_constraints", C.c_size_t), ("num_variables", C.c_size_t), ("num_non_zero", C.c_size_t), ("num_instance", C.c_size_t),
+                ("r1cs", C.c_void_p), ("r1cs_t", C.c_void_p), ("index_polys", PolyRef * 12),
+                ("on_k", MarlinMatrixEvals * 3), ("on_b", MarlinMatrixEvals * 3),
+                ("w_idx", C.c_void_p), ("x_idx", C.c_void_p), ("ivk_bytes", C.c_char_p), ("ivk_len", C.c_size_t)]
+
+
 class Fq753(C.Structure):
     _fields_ = [("l", C.c_uint64 * 12)]
 
@@ -184,6 +195,8 @@ PROTOTYPES = {
     "zk_fr_gather_dev": (_I, [_P, _P, _P, _SZ, _P]),
     "zk_marlin_round3_f_evals_dev": (_I, [_P, _P, _SZ, _P, _P, _P, _P, _P]),
     "zk_marlin_round3_ab_evals_dev": (_I, [_P, _P, _SZ, _P, _P, _P, _P, _P, _P]),
+    "zk_marlin_proof_max_size": (_SZ, []),
+    "zk_marlin_prove": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _SZ, _P]),
     "zk_she_vec_op_dev": (_I, [_P, _I, _P, _P, _P, _SZ]),
     "zk_she_vec_scale_dev": (_I, [_P, _P, _P, _P, _SZ]),
     "zk_she_negacyclic_mul_dev": (_I, [_P, _P, _P, _P, _SZ, _SZ]),

@@ -1,0 +1,555 @@
+// marlin_prove.hip -- Marlin::prove as ONE entry point: the three AHP rounds, MarlinKZG10 commitments, the Fiat-Shamir
+// transcript, the evaluations and open_combinations, sequenced on the host in C++ over the library's own kernels.
+//
+// Replaces (reference):
+//   Marlin::prove                                  arkworks/marlin/src/lib.rs:152-319
+//   AHPForR1CS::prover_{init,first,second,third}_round   arkworks/marlin/src/ahp/prover.rs:216-716
+//   AHPForR1CS::{verifier_*_round, verifier_query_set, construct_linear_combinations}   ahp/verifier.rs:42-170, ahp/mod.rs:112-290
+//   MarlinKZG10::{commit, open}, Marlin::open_combinations   poly-commit/src/marlin/marlin_pc/mod.rs:172-340, marlin/mod.rs:213-306
+//   FiatShamirRng / to_bytes! encodings            marlin/src/rng.rs, ff/src/bytes.rs, marlin_pc/data_structures.rs:252-263
+// The same sequence exists as zk-mpc_amd/marlin.py::prove (kept: it is what the collaborative provers build on, and the two are
+// tested against each other and against the oracle's independent prover byte for byte).  The index (Marlin::index: matrix
+// arithmetisation, index commitments) is a one-off set-up and stays with the caller, who hands over device-resident tables.
+#include "../../include/zkmpc_hip.h"
+#include "devutil.cuh"
+#include "hostgroup.hpp"
+#include "internal.hpp"
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace zk;
+
+namespace {
+
+// ---- Fr on the host (internal Montgomery form of the device arithmetic) ----
+struct HF {
+    Fr v;
+    static HF zero() { return HF{fp_zero<FrParams>()}; }
+    static HF one() { return HF{fp_one<FrParams>()}; }
+    static HF from_u64(uint64_t x) {
+        Fr t = fp_zero<FrParams>();
+        t.l[0] = (uint32_t)(x & MASK29); t.l[1] = (uint32_t)((x >> 29) & MASK29); t.l[2] = (uint32_t)(x >> 58);
+        return HF{fp_canon_to_int<FrParams>(t)};
+    }
+    static HF from_abi(const zk_fr& a) { return HF{fp_ext_to_int<FrParams>(host_load_ext<FrParams>(a.l))}; }
+    zk_fr abi() const { zk_fr o; host_store_ext<FrParams>(o.l, fp_int_to_ext<FrParams>(v)); return o; }
+    HF operator+(const HF& b) const { return HF{fp_add<FrParams>(v, b.v)}; }
+    HF operator-(const HF& b) const { return HF{fp_sub<FrParams>(v, b.v)}; }
+    HF operator*(const HF& b) const { return HF{fp_mul<FrParams>(v, b.v)}; }
+    HF neg() const { return HF{fp_neg<FrParams>(v)}; }
+    HF inv() const { return HF{fp_inv<FrParams>(v)}; }
+    bool is_zero() const { return fp_is_zero<FrParams>(v); }
+    bool operator==(const HF& b) const { return fp_eq<FrParams>(v, b.v); }
+    HF pow(uint64_t e) const {
+        HF r = one();
+        bool started = false;
+        for (int b = 63; b >= 0; b--) {
+            if (started) r = r * r;
+            if ((e >> b) & 1) { r = started ? r * *this : *this; started = true; }
+        }
+        return r;
+    }
+    void bytes(std::vector<uint8_t>& out) const {          // Fp::write: into_repr(), little endian
+        uint32_t w[8];
+        fp_pack<FrParams>(w, fp_int_to_canon<FrParams>(v));
+        for (int i = 0; i < 8; i++) for (int b = 0; b < 4; b++) out.push_back((uint8_t)(w[i] >> (8 * b)));
+    }
+};
+
+struct Dom {
+    size_t size; uint32_t log; HF gen;
+    explicit Dom(size_t num_coeffs) {
+        log = 0;
+        while (((size_t)1 << log) < num_coeffs) log++;
+        size = (size_t)1 << log;
+        Fr w = fp_const<FrParams>(FrParams::TWO_ADIC_ROOT);
+        for (uint32_t i = 0; i < (uint32_t)FR_TWO_ADICITY - log; i++) w = fp_sqr<FrParams>(w);
+        gen = HF{w};
+    }
+    HF vanishing(const HF& t) const { return t.pow(size) - HF::one(); }
+};
+
+struct Poly { char* p = nullptr; size_t n = 0; };        // n coefficients on the device
+struct Comm { Affine<G1Field> c, s; bool has_shift = false; };
+
+struct Prover {
+    zk_ctx* ctx;
+    const zk_marlin_index* ix;
+    const zk_bases *pg, *pgg;
+    size_t max_degree;
+    zk_rng* rng;
+    int rc = ZK_OK;
+    std::map<std::string, Poly> polys;
+    std::map<std::string, std::pair<std::vector<HF>, std::vector<HF>>> rands;   // label -> (blind, shifted blind)
+    std::map<std::string, Comm> comms;
+    std::map<std::string, size_t> bounds;
+
+    char* dev(const std::string& name, size_t elems) {
+        void* p = nullptr;
+        if (rc == ZK_OK) rc = zk_scratch(ctx, ("mp." + name).c_str(), std::max<size_t>(elems, 1) * 32, &p);
+        return (char*)p;
+    }
+    void ck(int r) { if (rc == ZK_OK) rc = r; }
+    void d2d(void* dst, const void* src, size_t elems) { if (elems) ck(zk_memcpy_d2d(ctx, dst, src, elems * 32)); }
+    void zero(void* dst, size_t elems) { if (elems) ck(zk_dev_zero(ctx, dst, elems * 32)); }
+    void op(int o, const void* a, const void* b, void* out, size_t n) { if (n) ck(zk_fr_vec_op_dev(ctx, o, a, b, out, n)); }
+    void scale(const void* a, const HF& k, void* out, size_t n) { zk_fr kk = k.abi(); if (n) ck(zk_fr_vec_scale_dev(ctx, a, &kk, out, n)); }
+    void ntt(void* buf, const Dom& d, int inverse) { ck(zk_fr_ntt_dev(ctx, buf, d.log, inverse, 0)); }
+    char* fft(const Dom& d, const Poly& p, const std::string& name) {     // evaluate_over_domain: zero-pad, forward transform
+        char* out = dev(name, d.size);
+        if (rc != ZK_OK) return out;
+        if (p.n < d.size) zero(out + 32 * p.n, d.size - p.n);
+        d2d(out, p.p, std::min(p.n, d.size));
+        ntt(out, d, 0);
+        return out;
+    }
+    bool is_zero(const void* v, size_t n) { int z = 0; ck(zk_fr_vec_is_zero_dev(ctx, v, n, &z)); return z != 0; }
+    HF eval(const Poly& p, const HF& x) { zk_fr xx = x.abi(), o; ck(zk_poly_evaluate_dev(ctx, p.p, p.n, &xx, &o)); return HF::from_abi(o); }
+    HF next_fr(zk_rng* r) { zk_fr o; ck(zk_rng_next_fr(r, &o)); return HF::from_abi(o); }
+    // p + r (X^n - 1) for deg p < n: one more coefficient
+    Poly blind(const char* poly, size_t n, const char* r_dev, const std::string& name) {
+        char* out = dev(name, n + 1);
+        d2d(out, poly, n);
+        d2d(out + 32 * n, r_dev, 1);
+        op(ZK_OP_SUB, out, r_dev, out, 1);
+        return Poly{out, n + 1};
+    }
+};
+
+void g1_tobytes(const Affine<G1Field>& a, std::vector<uint8_t>& out) {     // GroupAffine::write: x | y | infinity; zero() = (0, 1, true)
+    uint8_t b[48];
+    if (aff_is_inf<G1Field>(a)) {
+        out.insert(out.end(), 48, 0);
+        out.push_back(1); out.insert(out.end(), 47, 0);
+        out.push_back(1);
+        return;
+    }
+    fq_canonical_bytes(a.x, b); out.insert(out.end(), b, b + 48);
+    fq_canonical_bytes(a.y, b); out.insert(out.end(), b, b + 48);
+    out.push_back(0);
+}
+void comm_tobytes(const Comm& c, std::vector<uint8_t>& out) {              // marlin_pc::Commitment::write
+    g1_tobytes(c.c, out);
+    out.push_back(c.has_shift ? 1 : 0);
+    g1_tobytes(c.has_shift ? c.s : aff_inf<G1Field>(), out);
+}
+Affine<G1Field> proj_to_aff(const zk_g1_projective& p) { return xyzz_to_affine<G1Field>(host_proj_from_abi<G1Field>((const uint64_t*)&p)); }
+
+HF host_eval(const std::vector<HF>& c, const HF& x) {
+    HF acc = HF::zero();
+    for (size_t i = c.size(); i-- > 0;) acc = acc * x + c[i];
+    return acc;
+}
+std::vector<HF> host_div_linear(const std::vector<HF>& c, const HF& z) {   // quotient of p / (X - z)
+    std::vector<HF> q(c.size() > 1 ? c.size() - 1 : 0, HF::zero());
+    HF acc = HF::zero();
+    for (size_t i = c.size(); i-- > 1;) { acc = c[i] + acc * z; q[i - 1] = acc; }
+    return q;
+}
+void acc_scaled(std::vector<HF>& dst, const std::vector<HF>& src, const HF& k) {
+    if (dst.size() < src.size()) dst.resize(src.size(), HF::zero());
+    for (size_t i = 0; i < src.size(); i++) dst[i] = dst[i] + src[i] * k;
+}
+
+const char* const INDEX_LABELS[12] = {"a_row", "a_col", "a_val", "a_row_col", "b_row", "b_col", "b_val", "b_row_col",
+                                      "c_row", "c_col", "c_val", "c_row_col"};
+struct Term { HF c; const char* label; };      // label = nullptr: the constant term (LCTerm::One)
+
+}  // namespace
+
+extern "C" size_t zk_marlin_proof_max_size(void) { return 8 + 3 * 8 + 9 * 49 + 2 * 48 + 8 + 7 * 32 + 8 + 3 + 8 + 2 * (49 + 32) + 1; }
+
+extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
+                               const void* z_dev, zk_rng* zk_rng_, int mask_on_device, uint8_t* proof_out, size_t cap, size_t* proof_len) {
+    if (!ctx || !ix || !powers_g || !powers_gamma_g || !z_dev || !zk_rng_ || !proof_out || !proof_len) return ZK_ERR_ARG;
+    if (powers_g->group != 1 || powers_gamma_g->group != 1 || powers_gamma_g->n < 3) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: SRS tables");
+    if (cap < zk_marlin_proof_max_size()) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: output buffer smaller than zk_marlin_proof_max_size()");
+    if (ix->num_constraints != ix->num_variables) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: NonSquareMatrix");
+    if (ix->num_instance == 0 || (ix->num_instance & (ix->num_instance - 1))) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: InvalidPublicInputLength");
+    Prover P{ctx, ix, powers_g, powers_gamma_g, powers_g->n - 1, zk_rng_};
+    const Dom H(ix->num_constraints), K(ix->num_non_zero), X(ix->num_instance), B(3 * Dom(ix->num_non_zero).size - 3);
+    const size_t n = H.size, ni = ix->num_instance;
+    {   // AHPForR1CS::max_degree (ahp/mod.rs:75-97)
+        const size_t need = std::max(std::max(2 * n - 1, 3 * n - 1), std::max(n, 3 * K.size - 3));
+        if (P.max_degree < need) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: IndexTooLarge for this SRS");
+    }
+    if (B.size < 4 * K.size - 3) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: |K| < 4 is not supported by this entry point");
+    P.bounds["g_1"] = n - 2;
+    P.bounds["g_2"] = K.size - 2;
+    const char* zb = (const char*)z_dev;
+    for (int i = 0; i < 12; i++) {
+        P.polys[INDEX_LABELS[i]] = Poly{(char*)ix->index_polys[i].ptr, ix->index_polys[i].n};
+        P.rands[INDEX_LABELS[i]] = {};
+    }
+
+    // ---- transcript seed: PROTOCOL_NAME | index_vk | public_input (lib.rs:161-164) ----
+    std::vector<HF> pub(ni - 1);
+    {
+        std::vector<zk_fr> tmp(ni);
+        ZK_TRY(zk_memcpy_d2h(ctx, tmp.data(), zb, ni * 32));
+        for (size_t i = 1; i < ni; i++) pub[i - 1] = HF::from_abi(tmp[i]);
+    }
+    std::vector<uint8_t> seed;
+    const char* name = "MARLIN-2019";
+    seed.insert(seed.end(), name, name + 11);
+    seed.insert(seed.end(), ix->ivk_bytes, ix->ivk_bytes + ix->ivk_len);
+    for (auto& v : pub) v.bytes(seed);
+    zk_rng* fs = nullptr;
+    ZK_TRY(zk_fsrng_new(seed.data(), seed.size(), &fs));
+    struct FsGuard { zk_rng* r; ~FsGuard() { zk_rng_free(r); } } guard{fs};
+    auto sample_outside = [&](const Dom& d) { HF t = P.next_fr(fs); while (d.vanishing(t).is_zero()) t = P.next_fr(fs); return t; };
+
+    // MarlinKZG10::commit for one round (marlin_pc/mod.rs:172-243): blinding polynomials in the reference's rng order, all MSMs
+    // of the round as one pipelined batch; then the round's bytes into the transcript
+    auto commit_round = [&](std::initializer_list<const char*> labels) -> int {
+        std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
+        std::vector<std::pair<std::string, int>> slot;                          // (label, 0 = comm / 1 = shifted)
+        int k = 0;
+        for (const char* l : labels) {
+            const bool hiding = !strcmp(l, "w") || !strcmp(l, "z_a") || !strcmp(l, "z_b") || !strcmp(l, "g_1");
+            const bool bounded = P.bounds.count(l) != 0;
+            std::vector<HF> blind, sblind;
+            if (hiding) for (int i = 0; i < 3; i++) blind.push_back(P.next_fr(P.rng));
+            if (hiding && bounded) for (int i = 0; i < 3; i++) sblind.push_back(P.next_fr(P.rng));
+            P.rands[l] = {blind, sblind};
+            const Poly& p = P.polys[l];
+            jb.push_back(P.pg); joff.push_back(0); jsc.push_back(p.p); jlen.push_back(p.n); slot.push_back({l, 0});
+            auto upload = [&](const std::vector<HF>& v) -> char* {
+                char* d = P.dev("blind" + std::to_string(k++), v.size());
+                std::vector<zk_fr> h(v.size());
+                for (size_t i = 0; i < v.size(); i++) h[i] = v[i].abi();
+                if (P.rc == ZK_OK) P.ck(zk_memcpy_h2d(ctx, d, h.data(), v.size() * 32));
+                return d;
+            };
+            if (hiding) { jb.push_back(P.pgg); joff.push_back(0); jsc.push_back(upload(blind)); jlen.push_back(3); slot.push_back({l, 0}); }
+            if (bounded) {
+                if (p.n - 1 > P.bounds[l]) { ctx->last_error = std::string("zk_marlin_prove: ") + l + " exceeds its degree bound"; return ZK_ERR_STATE; }
+                jb.push_back(P.pg); joff.push_back(P.max_degree - P.bounds[l]); jsc.push_back(p.p); jlen.push_back(p.n); slot.push_back({l, 1});
+                if (hiding) { jb.push_back(P.pgg); joff.push_back(0); jsc.push_back(upload(sblind)); jlen.push_back(3); slot.push_back({l, 1}); }
+            }
+        }
+        ZK_TRY(P.rc);
+        std::vector<zk_g1_projective> outs(jb.size());
+        std::vector<void*> outp(jb.size());
+        for (size_t i = 0; i < jb.size(); i++) outp[i] = &outs[i];
+        ZK_TRY(zk_msm_batch_dev(ctx, jb.size(), jb.data(), joff.data(), jsc.data(), jlen.data(), outp.data()));
+        std::map<std::string, zk_g1_projective> acc[2];
+        for (size_t i = 0; i < jb.size(); i++) {
+            auto& m = acc[slot[i].second];
+            auto it = m.find(slot[i].first);
+            if (it == m.end()) m[slot[i].first] = outs[i];
+            else { zk_g1_projective t; zk_g1_add(&it->second, &outs[i], &t); it->second = t; }
+        }
+        std::vector<uint8_t> bytes;
+        for (const char* l : labels) {
+            Comm c;
+            c.c = proj_to_aff(acc[0][l]);
+            c.has_shift = acc[1].count(l) != 0;
+            c.s = c.has_shift ? proj_to_aff(acc[1][l]) : aff_inf<G1Field>();
+            P.comms[l] = c;
+            comm_tobytes(c, bytes);
+        }
+        return zk_fsrng_absorb(fs, bytes.data(), bytes.size());                  // to_bytes![comms, EmptyMessage]
+    };
+
+    // =========================== round 1 (prover.rs:216-404) ===========================
+    char* z_a = P.dev("z_a", n); char* z_b = P.dev("z_b", n);
+    ZK_TRY(P.rc);
+    ZK_TRY(zk_r1cs_matvec_dev(ctx, ix->r1cs, 0, z_dev, z_a, n));
+    ZK_TRY(zk_r1cs_matvec_dev(ctx, ix->r1cs, 1, z_dev, z_b, n));
+    const size_t md = 3 * n + 2 - 3;                                             // mask polynomial degree, zk_bound = 1
+    char* rnd = P.dev("rnd", 3 + md + 1);
+    ZK_TRY(P.rc);
+    {
+        const size_t host_n = mask_on_device ? 3 : 3 + md + 1;
+        std::vector<zk_fr> h(host_n);
+        ZK_TRY(zk_rng_fill_fr(P.rng, h.data(), host_n));
+        ZK_TRY(zk_memcpy_h2d(ctx, rnd, h.data(), host_n * 32));
+        if (mask_on_device) {
+            uint8_t key[32];
+            ZK_TRY(zk_rng_fill_bytes(P.rng, key, 32));
+            ZK_TRY(zk_fr_random_dev(ctx, key, 0, rnd + 96, md + 1));
+        }
+    }
+    char* xb = P.dev("x_poly", X.size);
+    P.d2d(xb, zb, X.size);
+    P.ntt(xb, X, 1);
+    const Poly x_poly{xb, X.size};
+    char* x_evals = P.fft(H, x_poly, "x_evals");
+    char* w_evals = P.dev("w_evals", n); char* tmp = P.dev("tmp_h", n);
+    ZK_TRY(P.rc);
+    ZK_TRY(zk_fr_gather_dev(ctx, zb, ix->w_idx, n, w_evals));
+    ZK_TRY(zk_fr_gather_dev(ctx, x_evals, ix->x_idx, n, tmp));
+    P.op(ZK_OP_SUB, w_evals, tmp, w_evals, n);
+    P.ntt(w_evals, H, 1);
+    const Poly w_h = P.blind(w_evals, n, rnd, "w_h");
+    const size_t nwq = n + 1 - X.size;
+    char* wq = P.dev("w_poly", nwq); char* wr = P.dev("w_rem", X.size);
+    ZK_TRY(P.rc);
+    ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, w_h.p, n + 1, X.log, wq, wr));
+    if (!P.is_zero(wr, X.size)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: w polynomial is not divisible by v_X");
+    P.polys["w"] = Poly{wq, nwq};
+    char* za = P.dev("za_c", n); char* zbb = P.dev("zb_c", n);
+    P.d2d(za, z_a, n); P.d2d(zbb, z_b, n);
+    P.ntt(za, H, 1); P.ntt(zbb, H, 1);
+    P.polys["z_a"] = P.blind(za, n, rnd + 32, "z_a_poly");
+    P.polys["z_b"] = P.blind(zbb, n, rnd + 64, "z_b_poly");
+    char* mask = P.dev("mask", md + 1); char* mq = P.dev("mask_q", md + 1); char* mr = P.dev("mask_r", n);
+    P.d2d(mask, rnd + 96, md + 1);
+    ZK_TRY(P.rc);
+    ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, mask, md + 1, H.log, mq, mr));
+    P.op(ZK_OP_SUB, mask, mr, mask, 1);                                          // the sum over H becomes zero
+    P.polys["mask_poly"] = Poly{mask, md + 1};
+    ZK_TRY(P.rc);
+    ZK_TRY(commit_round({"w", "z_a", "z_b", "mask_poly"}));
+    const HF alpha = sample_outside(H), eta_a = P.next_fr(fs), eta_b = P.next_fr(fs), eta_c = P.next_fr(fs);
+
+    // =========================== round 2 (prover.rs:438-565) ===========================
+    const HF v_h_alpha = H.vanishing(alpha), one = HF::one();
+    char* elems = P.dev("h_elems", n);
+    char* ra = P.dev("r_alpha", n);
+    ZK_TRY(P.rc);
+    { zk_fr g = H.gen.abi(), o = one.abi(), a = alpha.abi();
+      ZK_TRY(zk_fr_powers_dev(ctx, &g, &o, n, elems));
+      ZK_TRY(zk_fr_powers_dev(ctx, &o, &a, n, ra)); }                            // the constant vector alpha
+    P.op(ZK_OP_SUB, ra, elems, ra, n);
+    ZK_TRY(P.rc);
+    ZK_TRY(zk_fr_batch_inverse_dev(ctx, ra, n));
+    P.scale(ra, v_h_alpha, ra, n);                                               // r(alpha, X) on H (ahp/mod.rs:352-360)
+    char* t_ev = P.dev("t_ev", n);
+    const HF etas[3] = {eta_a, eta_b, eta_c};
+    for (int which = 0; which < 3; which++) {                                    // calculate_t on the transposed matrices
+        ZK_TRY(P.rc);
+        ZK_TRY(zk_r1cs_matvec_dev(ctx, ix->r1cs_t, which, ra, which == 0 ? t_ev : tmp, n));
+        if (which == 0) P.scale(t_ev, etas[0], t_ev, n);
+        else { P.scale(tmp, etas[which], tmp, n); P.op(ZK_OP_ADD, t_ev, tmp, t_ev, n); }
+    }
+    P.ntt(t_ev, H, 1);
+    P.polys["t"] = Poly{t_ev, n};
+    P.ntt(ra, H, 1);
+    const Poly r_alpha_poly{ra, n};
+    char* zp = P.dev("z_poly", n + 1);                                           // z = w v_X + x
+    P.zero(zp, n + 1);
+    P.d2d(zp + 32 * X.size, wq, nwq);
+    P.op(ZK_OP_SUB, zp, wq, zp, nwq);
+    P.op(ZK_OP_ADD, zp, xb, zp, X.size);
+    const Poly z_poly{zp, n + 1};
+    const Dom MUL(std::max(std::max(md + 1, n + 2 * n + 1), n + n + 1));
+    char* e_a = P.fft(MUL, P.polys["z_a"], "e_a"); char* e_b = P.fft(MUL, P.polys["z_b"], "e_b");
+    char* e_s = P.dev("e_s", MUL.size);
+    P.op(ZK_OP_MUL, e_a, e_b, e_s, MUL.size);                                    // z_a z_b: the one product of two witness vectors
+    P.scale(e_s, eta_c, e_s, MUL.size);
+    P.scale(e_a, eta_a, e_a, MUL.size);
+    P.op(ZK_OP_ADD, e_s, e_a, e_s, MUL.size);
+    P.scale(e_b, eta_b, e_b, MUL.size);
+    P.op(ZK_OP_ADD, e_s, e_b, e_s, MUL.size);
+    char* e_r = P.fft(MUL, r_alpha_poly, "e_r"); char* e_z = P.fft(MUL, z_poly, "e_z"); char* e_t = P.fft(MUL, P.polys["t"], "e_t");
+    P.op(ZK_OP_MUL, e_r, e_s, e_r, MUL.size);
+    P.op(ZK_OP_MUL, e_z, e_t, e_z, MUL.size);
+    P.op(ZK_OP_SUB, e_r, e_z, e_r, MUL.size);
+    P.ntt(e_r, MUL, 1);                                                          // q_1 (prover.rs:517-541)
+    P.op(ZK_OP_ADD, e_r, mask, e_r, md + 1);
+    char* hq = P.dev("h1_q", MUL.size - n); char* hr = P.dev("h1_r", n);
+    ZK_TRY(P.rc);
+    ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, e_r, MUL.size, H.log, hq, hr));
+    if (!P.is_zero(hr, 1)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: outer sum-check: the sum over H is not zero (unsatisfied constraint system)");
+    P.polys["g_1"] = Poly{hr + 32, n - 1};
+    P.polys["h_1"] = Poly{hq, std::min(MUL.size - n, 2 * n + 2 - 1)};
+    ZK_TRY(commit_round({"t", "g_1", "h_1"}));
+    const HF beta = sample_outside(H);
+
+    // =========================== round 3 (prover.rs:583-716) ===========================
+    const HF vv = v_h_alpha * H.vanishing(beta);
+    char* f_ev = P.dev("f_ev", K.size);
+    char* a_ev = P.dev("a_ev", B.size); char* b_ev = P.dev("b_ev", B.size);
+    ZK_TRY(P.rc);
+    { zk_fr al = alpha.abi(), be = beta.abi(), v = vv.abi(), et[3] = {eta_a.abi(), eta_b.abi(), eta_c.abi()};
+      ZK_TRY(zk_marlin_round3_f_evals_dev(ctx, ix->on_k, K.size, &al, &be, et, &v, f_ev));
+      ZK_TRY(zk_marlin_round3_ab_evals_dev(ctx, ix->on_b, B.size, &al, &be, et, &v, a_ev, b_ev)); }
+    P.ntt(f_ev, K, 1);
+    const Poly f{f_ev, K.size};
+    P.polys["g_2"] = Poly{f_ev + 32, K.size - 1};
+    char* f_on_b = P.fft(B, f, "f_on_b");                                       // a - b f on B itself (degree <= 4|K| - 4 < |B|)
+    P.op(ZK_OP_MUL, b_ev, f_on_b, b_ev, B.size);
+    P.op(ZK_OP_SUB, a_ev, b_ev, a_ev, B.size);
+    P.ntt(a_ev, B, 1);
+    char* h2q = P.dev("h2_q", B.size - K.size); char* h2r = P.dev("h2_r", K.size);
+    ZK_TRY(P.rc);
+    ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, a_ev, B.size, K.log, h2q, h2r));
+    if (!P.is_zero(h2r, K.size)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: inner sum-check: a - b f is not divisible by v_K");
+    P.polys["h_2"] = Poly{h2q, B.size - K.size};
+    ZK_TRY(commit_round({"g_2", "h_2"}));
+    const HF gamma = P.next_fr(fs);
+
+    // =========================== evaluations and linear combinations ===========================
+    std::map<std::string, HF> single;
+    single["z_b"] = P.eval(P.polys["z_b"], beta); single["g_1"] = P.eval(P.polys["g_1"], beta);
+    single["t"] = P.eval(P.polys["t"], beta); single["g_2"] = P.eval(P.polys["g_2"], gamma);
+    const HF ba = beta * alpha;
+    for (const char* m : {"a", "b", "c"}) {
+        const std::string s(m);
+        single[s + "_denom"] = ba - alpha * P.eval(P.polys[s + "_row"], gamma) - beta * P.eval(P.polys[s + "_col"], gamma) +
+                               P.eval(P.polys[s + "_row_col"], gamma);
+    }
+    ZK_TRY(P.rc);
+    // construct_linear_combinations (ahp/mod.rs:112-290)
+    const HF v_h_beta = H.vanishing(beta), v_x_beta = beta.pow(ni) - one;
+    const HF r_alpha_at_beta = (alpha == beta) ? HF::from_u64(n) * alpha.pow(n - 1) : (v_h_alpha - v_h_beta) * (alpha - beta).inv();
+    HF x_beta = HF::zero();
+    {
+        std::vector<HF> x{one};
+        x.insert(x.end(), pub.begin(), pub.end());
+        if (v_x_beta.is_zero()) {
+            HF g = one;
+            for (size_t k = 0; k < ni; k++, g = g * X.gen) if (g == beta) x_beta = x[k];
+        } else {
+            const HF l0 = v_x_beta * HF::from_u64(ni).inv();
+            HF g = one;
+            for (size_t k = 0; k < ni; k++, g = g * X.gen) x_beta = x_beta + x[k] * (l0 * g * (beta - g).inv());
+        }
+    }
+    const HF z_b_beta = single["z_b"], t_beta = single["t"], g_1_beta = single["g_1"], g_2_gamma = single["g_2"];
+    const HF da = single["a_denom"], db = single["b_denom"], dc = single["c_denom"];
+    std::map<std::string, std::vector<Term>> lcs;
+    lcs["z_b"] = {{one, "z_b"}}; lcs["g_1"] = {{one, "g_1"}}; lcs["t"] = {{one, "t"}}; lcs["g_2"] = {{one, "g_2"}};
+    lcs["outer_sumcheck"] = {{one, "mask_poly"}, {r_alpha_at_beta * (eta_a + eta_c * z_b_beta), "z_a"}, {r_alpha_at_beta * eta_b * z_b_beta, nullptr},
+                             {(t_beta * v_x_beta).neg(), "w"}, {(t_beta * x_beta).neg(), nullptr}, {v_h_beta.neg(), "h_1"},
+                             {(beta * g_1_beta).neg(), nullptr}};
+    lcs["a_denom"] = {{ba, nullptr}, {alpha.neg(), "a_row"}, {beta.neg(), "a_col"}, {one, "a_row_col"}};
+    lcs["b_denom"] = {{ba, nullptr}, {alpha.neg(), "b_row"}, {beta.neg(), "b_col"}, {one, "b_row_col"}};
+    lcs["c_denom"] = {{ba, nullptr}, {alpha.neg(), "c_row"}, {beta.neg(), "c_col"}, {one, "c_row_col"}};
+    const HF b_expr = da * db * dc * (gamma * g_2_gamma + t_beta * HF::from_u64(K.size).inv());
+    lcs["inner_sumcheck"] = {{eta_a * db * dc * vv, "a_val"}, {eta_b * da * dc * vv, "b_val"}, {eta_c * db * da * vv, "c_val"},
+                             {b_expr.neg(), nullptr}, {K.vanishing(gamma).neg(), "h_2"}};
+    const char* const EVAL_LABELS[7] = {"a_denom", "b_denom", "c_denom", "g_1", "g_2", "t", "z_b"};
+    std::vector<HF> evaluations;
+    std::vector<uint8_t> ev_bytes;
+    for (const char* l : EVAL_LABELS) { evaluations.push_back(single[l]); single[l].bytes(ev_bytes); }
+    ZK_TRY(zk_fsrng_absorb(fs, ev_bytes.data(), ev_bytes.size()));
+    HF xi;
+    {   // u128::rand(&mut fs_rng).into()  (lib.rs:300)
+        uint64_t w[2];
+        ZK_TRY(zk_rng_next_u128(fs, w));
+        xi = HF::from_u64(w[0]) + HF::from_u64(w[1]) * HF::from_u64((uint64_t)1 << 32) * HF::from_u64((uint64_t)1 << 32);
+    }
+
+    // =========================== open_combinations (marlin/mod.rs:213-306, marlin_pc/mod.rs:245-340) ===========================
+    const std::vector<std::string> QUERY[2] = {{"g_1", "outer_sumcheck", "t", "z_b"}, {"a_denom", "b_denom", "c_denom", "g_2", "inner_sumcheck"}};
+    const HF points[2] = {beta, gamma};
+    std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
+    size_t counts[2] = {0, 0};
+    bool has_rv[2] = {false, false};
+    HF rvs[2];
+    int upl = 0;
+    for (int q = 0; q < 2; q++) {
+        const HF z = points[q];
+        std::vector<std::pair<std::string, HF>> terms;                            // polynomial label -> accumulated coefficient (first-use order)
+        std::vector<HF> r_comb, sr, srw;
+        std::vector<std::pair<std::string, HF>> shifted;
+        HF cj = one;                                                              // xi^j
+        for (const std::string& label : QUERY[q]) {
+            const auto& lc = lcs[label];
+            std::vector<Term> ps;
+            for (const Term& t : lc) if (t.label) ps.push_back(t);
+            const HF c0 = cj;
+            cj = cj * xi;
+            for (const Term& t : ps) {
+                auto it = std::find_if(terms.begin(), terms.end(), [&](const std::pair<std::string, HF>& e) { return e.first == t.label; });
+                if (it == terms.end()) terms.push_back({t.label, t.c * c0}); else it->second = it->second + t.c * c0;
+                acc_scaled(r_comb, P.rands[t.label].first, t.c * c0);
+            }
+            if (lc.size() == 1 && P.bounds.count(ps[0].label)) {
+                const HF c1 = cj;
+                cj = cj * xi;
+                shifted.push_back({ps[0].label, c1});
+                acc_scaled(sr, P.rands[ps[0].label].second, c1);
+            }
+        }
+        size_t cn = 0;
+        for (auto& t : terms) cn = std::max(cn, P.polys[t.first].n);
+        char* comb = P.dev("comb" + std::to_string(q), cn); char* ctmp = P.dev("combtmp", cn);
+        P.zero(comb, cn);
+        for (auto& t : terms) { const Poly& p = P.polys[t.first]; P.scale(p.p, t.second, ctmp, p.n); P.op(ZK_OP_ADD, comb, ctmp, comb, p.n); }
+        char* quo = P.dev("quo" + std::to_string(q), cn);
+        ZK_TRY(P.rc);
+        { zk_fr zz = z.abi(); ZK_TRY(zk_poly_divide_by_linear_dev(ctx, comb, cn, &zz, quo, nullptr)); }
+        const size_t first_job = jb.size();
+        jb.push_back(P.pg); joff.push_back(0); jsc.push_back(quo); jlen.push_back(cn - 1);
+        auto upload = [&](const std::vector<HF>& v) -> char* {
+            char* d = P.dev("openblind" + std::to_string(upl++), v.size());
+            std::vector<zk_fr> h(v.size());
+            for (size_t i = 0; i < v.size(); i++) h[i] = v[i].abi();
+            if (P.rc == ZK_OK) P.ck(zk_memcpy_h2d(ctx, d, h.data(), v.size() * 32));
+            return d;
+        };
+        bool hiding = false;
+        for (auto& v : r_comb) hiding = hiding || !v.is_zero();
+        if (hiding) {
+            const std::vector<HF> rw = host_div_linear(r_comb, z);
+            jb.push_back(P.pgg); joff.push_back(0); jsc.push_back(upload(rw)); jlen.push_back(rw.size());
+            has_rv[q] = true;
+            rvs[q] = host_eval(r_comb, z);
+        }
+        int si = 0;
+        for (auto& sh : shifted) {
+            const Poly& p = P.polys[sh.first];
+            char* wq2 = P.dev("swit" + std::to_string(q) + "_" + std::to_string(si++), p.n);
+            ZK_TRY(P.rc);
+            { zk_fr zz = z.abi(); ZK_TRY(zk_poly_divide_by_linear_dev(ctx, p.p, p.n, &zz, wq2, nullptr)); }
+            P.scale(wq2, sh.second, wq2, p.n - 1);
+            jb.push_back(P.pg); joff.push_back(P.max_degree - P.bounds[sh.first]); jsc.push_back(wq2); jlen.push_back(p.n - 1);
+            const std::vector<HF>& sb = P.rands[sh.first].second;
+            if (!sb.empty()) acc_scaled(srw, host_div_linear(sb, z), sh.second);
+        }
+        if (!srw.empty()) { jb.push_back(P.pgg); joff.push_back(0); jsc.push_back(upload(srw)); jlen.push_back(srw.size()); }
+        if (!shifted.empty() && has_rv[q]) rvs[q] = rvs[q] + host_eval(sr, z);
+        counts[q] = jb.size() - first_job;
+    }
+    ZK_TRY(P.rc);
+    std::vector<zk_g1_projective> outs(jb.size());
+    std::vector<void*> outp(jb.size());
+    for (size_t i = 0; i < jb.size(); i++) outp[i] = &outs[i];
+    ZK_TRY(zk_msm_batch_dev(ctx, jb.size(), jb.data(), joff.data(), jsc.data(), jlen.data(), outp.data()));
+    Affine<G1Field> wit[2];
+    {
+        size_t k = 0;
+        for (int q = 0; q < 2; q++) {
+            zk_g1_projective w = outs[k];
+            for (size_t i = 1; i < counts[q]; i++) { zk_g1_projective t; zk_g1_add(&w, &outs[k + i], &t); w = t; }
+            k += counts[q];
+            wit[q] = proj_to_aff(w);
+        }
+    }
+
+    // =========================== Proof::serialize (data_structures.rs:99-110, derive order) ===========================
+    std::vector<uint8_t> out;
+    auto u64 = [&](uint64_t v) { for (int i = 0; i < 8; i++) out.push_back((uint8_t)(v >> (8 * i))); };
+    auto g1c = [&](const Affine<G1Field>& a) { uint8_t b[48]; g1_serialize(a, b); out.insert(out.end(), b, b + 48); };
+    const std::vector<std::vector<const char*>> ROUNDS = {{"w", "z_a", "z_b", "mask_poly"}, {"t", "g_1", "h_1"}, {"g_2", "h_2"}};
+    u64(3);
+    for (auto& rnd_labels : ROUNDS) {
+        u64(rnd_labels.size());
+        for (const char* l : rnd_labels) {
+            const Comm& c = P.comms[l];
+            g1c(c.c);
+            out.push_back(c.has_shift ? 1 : 0);
+            if (c.has_shift) g1c(c.s);
+        }
+    }
+    u64(evaluations.size());
+    for (auto& e : evaluations) e.bytes(out);
+    u64(3); out.push_back(0); out.push_back(0); out.push_back(0);               // three EmptyMessage
+    u64(2);
+    for (int q = 0; q < 2; q++) {
+        g1c(wit[q]);
+        out.push_back(has_rv[q] ? 1 : 0);
+        if (has_rv[q]) rvs[q].bytes(out);
+    }
+    out.push_back(0);                                                            // BatchLCProof.evals = None
+    if (out.size() > cap) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: output buffer too small");
+    memcpy(proof_out, out.data(), out.size());
+    *proof_len = out.size();
+    return ZK_OK;
+}

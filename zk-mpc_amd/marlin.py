@@ -897,3 +897,32 @@ def prove(keys: IndexKeys, assignment_dev: DevBuf, zk_rng, mask_on_device: bool 
         pc_proof.append((w, rv))
     ctx.sync()
     return MarlinProof([[comms[l] for l in rnd] for rnd in ROUND_LABELS], evaluations, pc_proof, ch)
+
+
+def prove_native(keys: IndexKeys, assignment_dev: DevBuf, zk_rng, mask_on_device: bool = False) -> bytes:
+    """Marlin::prove through the library's single entry point zk_marlin_prove (csrc/marlin_prove.hip): the same sequence as
+    `prove` above, on the host in C++.  Returns the CanonicalSerialize bytes of the proof."""
+    import ctypes as C
+    index, srs = keys.index, keys.srs
+    ctx = index.ctx
+    d = _lib.MarlinIndex()
+    d.num_constraints, d.num_variables = index.num_constraints, index.num_variables
+    d.num_non_zero, d.num_instance = index.num_non_zero, index.num_instance
+    d.r1cs, d.r1cs_t = index.r1cs.h, index.r1cs_t.h
+    polys = index.polynomials()
+    for i, l in enumerate(INDEX_LABELS):
+        d.index_polys[i].ptr, d.index_polys[i].n = polys[l].ptr, polys[l].n
+    for i, m in enumerate("abc"):
+        ek, eb = index.arith[m].evals_on_K, index.arith[m].evals_on_B
+        d.on_k[i].row, d.on_k[i].col, d.on_k[i].val, d.on_k[i].row_col = ek["row"].ptr, ek["col"].ptr, ek["val"].ptr, None
+        d.on_b[i].row, d.on_b[i].col, d.on_b[i].val, d.on_b[i].row_col = eb["row"].ptr, eb["col"].ptr, eb["val"].ptr, eb["row_col"].ptr
+    d_iw, d_ix = index.w_evals_index()
+    d.w_idx, d.x_idx = d_iw.ptr, d_ix.ptr
+    ivk = keys.ivk_bytes()
+    d.ivk_bytes, d.ivk_len = ivk, len(ivk)
+    cap = ctx.lib.zk_marlin_proof_max_size()
+    out = (C.c_uint8 * cap)()
+    n = C.c_size_t()
+    ctx._ck(ctx.lib.zk_marlin_prove(ctx.h, C.byref(d), srs.powers_g.h, srs.powers_gamma_g.h, C.c_void_p(assignment_dev.ptr), zk_rng.h,
+                                    int(mask_on_device), out, cap, C.byref(n)))
+    return bytes(out[:n.value])
