@@ -126,21 +126,26 @@ def other_workloads(ctx, log_h=20):
         z = ctx.mul_chain_assignment_dev(n, m(3), m(5))
         ctx.pooling = True
         seed = bytes(range(32))
-        proof = DM.prove(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
+        proof_bytes = DM.prove_native(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)     # zk_marlin_prove: one C-ABI call
         ctx.sync()
         t0 = time.perf_counter()
         reps = 3
         for _ in range(reps):
-            proof = DM.prove(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
+            proof_bytes = DM.prove_native(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
         ctx.sync()
         dt = (time.perf_counter() - t0) / reps
+        # the same proof through the Python sequence of the C-ABI pieces (what the collaborative provers build on): equal bytes,
+        # and an object the oracle's verifier can take apart
+        proof = DM.prove(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
+        same = proof.serialize(ctx) == proof_bytes
         ctx.pooling = False
         ctx.drop_pool()
         out["marlin"] = {"workload": "Marlin::prove (AHP rounds + MarlinKZG10 commitments with hiding and degree bounds + Fiat-Shamir "
                                      "transcript + open_combinations), mul-chain R1CS, |H| = |K| = 2^%d, index key and SRS resident, "
                                      "prover randomness from a ChaCha20 rng (the mask polynomial sampled on the device)" % log_h,
                          "constraints": n, "ms_per_proof": round(dt * 1e3, 2), "constraints_per_s": round(n / dt, 1),
-                         "proof_bytes": len(proof.serialize(ctx))}
+                         "entry_point": "zk_marlin_prove", "proof_bytes": len(proof_bytes),
+                         "equals_python_sequence": bool(same)}
         # checker (outside the timing): the oracle's Marlin::verify re-derives the transcript from the proof and checks the two
         # sum-check combinations and one KZG pairing equation per query point; a wrong public input must be rejected
         try:

@@ -153,6 +153,20 @@ void acc_scaled(std::vector<HF>& dst, const std::vector<HF>& src, const HF& k) {
     for (size_t i = 0; i < src.size(); i++) dst[i] = dst[i] + src[i] * k;
 }
 
+// sum_i c_i G_i for the three powers_of_gamma_g a hiding bound of 1 uses: on the host (a three-term MSM through the device
+// pipeline costs a full sort / accumulate / reduce round trip, ~0.5 ms; this is three scalar multiplications in 64-bit limbs)
+zk_g1_projective small_msm(const zk_g1_projective* pts, const std::vector<HF>& c) {
+    zk_g1_projective acc{};
+    bool first = true;
+    for (size_t i = 0; i < c.size(); i++) {
+        zk_fr k = c[i].abi();
+        zk_g1_projective t, u;
+        zk_g1_mul(&pts[i], &k, &t);
+        if (first) { acc = t; first = false; } else { zk_g1_add(&acc, &t, &u); acc = u; }
+    }
+    return acc;
+}
+
 const char* const INDEX_LABELS[12] = {"a_row", "a_col", "a_val", "a_row_col", "b_row", "b_col", "b_val", "b_row_col",
                                       "c_row", "c_col", "c_val", "c_row_col"};
 struct Term { HF c; const char* label; };      // label = nullptr: the constant term (LCTerm::One)
@@ -184,6 +198,13 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         P.rands[INDEX_LABELS[i]] = {};
     }
 
+    zk_g1_projective gamma_pts[3];
+    {
+        zk_g1_affine a[3];
+        ZK_TRY(zk_bases_download_g1(ctx, powers_gamma_g, 0, 3, a));
+        for (int i = 0; i < 3; i++) zk_g1_from_affine(&a[i], &gamma_pts[i]);
+    }
+
     // ---- transcript seed: PROTOCOL_NAME | index_vk | public_input (lib.rs:161-164) ----
     std::vector<HF> pub(ni - 1);
     {
@@ -206,7 +227,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     auto commit_round = [&](std::initializer_list<const char*> labels) -> int {
         std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
         std::vector<std::pair<std::string, int>> slot;                          // (label, 0 = comm / 1 = shifted)
-        int k = 0;
+        std::map<std::string, zk_g1_projective> acc[2];
         for (const char* l : labels) {
             const bool hiding = !strcmp(l, "w") || !strcmp(l, "z_a") || !strcmp(l, "z_b") || !strcmp(l, "g_1");
             const bool bounded = P.bounds.count(l) != 0;
@@ -216,18 +237,11 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
             P.rands[l] = {blind, sblind};
             const Poly& p = P.polys[l];
             jb.push_back(P.pg); joff.push_back(0); jsc.push_back(p.p); jlen.push_back(p.n); slot.push_back({l, 0});
-            auto upload = [&](const std::vector<HF>& v) -> char* {
-                char* d = P.dev("blind" + std::to_string(k++), v.size());
-                std::vector<zk_fr> h(v.size());
-                for (size_t i = 0; i < v.size(); i++) h[i] = v[i].abi();
-                if (P.rc == ZK_OK) P.ck(zk_memcpy_h2d(ctx, d, h.data(), v.size() * 32));
-                return d;
-            };
-            if (hiding) { jb.push_back(P.pgg); joff.push_back(0); jsc.push_back(upload(blind)); jlen.push_back(3); slot.push_back({l, 0}); }
+            if (hiding) acc[0][l] = small_msm(gamma_pts, blind);
             if (bounded) {
                 if (p.n - 1 > P.bounds[l]) { ctx->last_error = std::string("zk_marlin_prove: ") + l + " exceeds its degree bound"; return ZK_ERR_STATE; }
                 jb.push_back(P.pg); joff.push_back(P.max_degree - P.bounds[l]); jsc.push_back(p.p); jlen.push_back(p.n); slot.push_back({l, 1});
-                if (hiding) { jb.push_back(P.pgg); joff.push_back(0); jsc.push_back(upload(sblind)); jlen.push_back(3); slot.push_back({l, 1}); }
+                if (hiding) acc[1][l] = small_msm(gamma_pts, sblind);
             }
         }
         ZK_TRY(P.rc);
@@ -235,7 +249,6 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         std::vector<void*> outp(jb.size());
         for (size_t i = 0; i < jb.size(); i++) outp[i] = &outs[i];
         ZK_TRY(zk_msm_batch_dev(ctx, jb.size(), jb.data(), joff.data(), jsc.data(), jlen.data(), outp.data()));
-        std::map<std::string, zk_g1_projective> acc[2];
         for (size_t i = 0; i < jb.size(); i++) {
             auto& m = acc[slot[i].second];
             auto it = m.find(slot[i].first);
@@ -440,9 +453,9 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     const HF points[2] = {beta, gamma};
     std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
     size_t counts[2] = {0, 0};
+    std::vector<zk_g1_projective> extra[2];                                      // the blinding witnesses, computed on the host
     bool has_rv[2] = {false, false};
     HF rvs[2];
-    int upl = 0;
     for (int q = 0; q < 2; q++) {
         const HF z = points[q];
         std::vector<std::pair<std::string, HF>> terms;                            // polynomial label -> accumulated coefficient (first-use order)
@@ -477,18 +490,10 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         { zk_fr zz = z.abi(); ZK_TRY(zk_poly_divide_by_linear_dev(ctx, comb, cn, &zz, quo, nullptr)); }
         const size_t first_job = jb.size();
         jb.push_back(P.pg); joff.push_back(0); jsc.push_back(quo); jlen.push_back(cn - 1);
-        auto upload = [&](const std::vector<HF>& v) -> char* {
-            char* d = P.dev("openblind" + std::to_string(upl++), v.size());
-            std::vector<zk_fr> h(v.size());
-            for (size_t i = 0; i < v.size(); i++) h[i] = v[i].abi();
-            if (P.rc == ZK_OK) P.ck(zk_memcpy_h2d(ctx, d, h.data(), v.size() * 32));
-            return d;
-        };
         bool hiding = false;
         for (auto& v : r_comb) hiding = hiding || !v.is_zero();
         if (hiding) {
-            const std::vector<HF> rw = host_div_linear(r_comb, z);
-            jb.push_back(P.pgg); joff.push_back(0); jsc.push_back(upload(rw)); jlen.push_back(rw.size());
+            extra[q].push_back(small_msm(gamma_pts, host_div_linear(r_comb, z)));
             has_rv[q] = true;
             rvs[q] = host_eval(r_comb, z);
         }
@@ -503,7 +508,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
             const std::vector<HF>& sb = P.rands[sh.first].second;
             if (!sb.empty()) acc_scaled(srw, host_div_linear(sb, z), sh.second);
         }
-        if (!srw.empty()) { jb.push_back(P.pgg); joff.push_back(0); jsc.push_back(upload(srw)); jlen.push_back(srw.size()); }
+        if (!srw.empty()) extra[q].push_back(small_msm(gamma_pts, srw));
         if (!shifted.empty() && has_rv[q]) rvs[q] = rvs[q] + host_eval(sr, z);
         counts[q] = jb.size() - first_job;
     }
@@ -518,6 +523,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         for (int q = 0; q < 2; q++) {
             zk_g1_projective w = outs[k];
             for (size_t i = 1; i < counts[q]; i++) { zk_g1_projective t; zk_g1_add(&w, &outs[k + i], &t); w = t; }
+            for (auto& e : extra[q]) { zk_g1_projective t; zk_g1_add(&w, &e, &t); w = t; }
             k += counts[q];
             wit[q] = proj_to_aff(w);
         }
