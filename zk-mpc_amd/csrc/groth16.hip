@@ -538,9 +538,13 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         ZK_FAIL(ctx, ZK_ERR_ARG, "groth16: proving key does not match the constraint system");
     ZK_TRY(ensure_aux(ctx, 1));
     hipStream_t s_sort = ctx->aux[0], s_red = ctx->aux[0], s_acc = ctx->acc_stream;
-    hipEvent_t e0, e1;
-    ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-    ZK_HIP(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    struct Events {                               // destroyed on every exit path (the error returns below used to leak them)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } evs;
+    ZK_HIP(ctx, hipEventCreateWithFlags(&evs.e0, hipEventDisableTiming));
+    ZK_HIP(ctx, hipEventCreateWithFlags(&evs.e1, hipEventDisableTiming));
+    const hipEvent_t e0 = evs.e0, e1 = evs.e1;
     ZK_HIP(ctx, hipEventRecord(e0, ctx->stream));
     ZkMsmJob own[5];  // 0: B in G2, 1: A, 2: B in G1, 3: L, 4: H
     ZkMsmJob* J[5] = {&own[0], &own[1], &own[2], &own[3], &own[4]};
@@ -619,8 +623,14 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     // through): on one stream the last job's chain queued behind its predecessor's, which was still waiting for slots
     // beside the last accumulate kernel, and ~0.6 ms of it ran after the GPU had otherwise gone idle.
     static const int alt = getenv("ZK_REDUCE_ALT") ? atoi(getenv("ZK_REDUCE_ALT")) : 2;   // 0: all on main, 1: last on sort, 2: every other one
-    for (int k = 0; k < 5 && rc == ZK_OK; k++)
-        rc = zk_msm_enqueue_reduce(ctx, J[ord[k]], (ord[k] == 0 || (alt == 1 && k == 4) || (alt == 2 && (k & 1) == 0)) ? s_red : ctx->stream);
+    // experiment (ZK_REDUCE_TAIL=1): the G1 reduce chains held back until the last accumulate kernel is through, so that they run
+    // beside each other at the tail instead of beside (and stretching) the accumulate kernels
+    static const bool reduce_tail = getenv("ZK_REDUCE_TAIL") && atoi(getenv("ZK_REDUCE_TAIL")) != 0;
+    for (int k = 0; k < 5 && rc == ZK_OK; k++) {
+        hipStream_t rs = (ord[k] == 0 || (alt == 1 && k == 4) || (alt == 2 && (k & 1) == 0)) ? s_red : ctx->stream;
+        if (reduce_tail && ord[k] != 0 && J[ord[4]]->accum_done) ZK_HIP(ctx, hipStreamWaitEvent(rs, J[ord[4]]->accum_done, 0));
+        rc = zk_msm_enqueue_reduce(ctx, J[ord[k]], rs);
+    }
     // The caller announced the next assignment (zk_groth16_hint_next_dev): enqueue that proof's front now, behind this
     // proof's kernels.  Its z-sort goes on the accumulate stream (in order behind the five accumulate kernels, the readers of
     // this proof's sort products; it also waits for the reduce chains, whose fold kernels read the segment tables), its
@@ -673,8 +683,6 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         (void)hipStreamSynchronize(ctx->stream);
     }
     tm.resolve();
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return rc;
 }
 
