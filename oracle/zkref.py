@@ -6,7 +6,10 @@ path over BLS12-377.  It is the checker for the HIP product path: only tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.  The product
 (zk-mpc_amd/) never imports anything from oracle/.
 
-PARITY PINNING.  The Rust reference cannot be compiled or run in the build container (no
+PARITY PINNING: "parity unpinned" in the sense of the task statement -- no output of the Rust code is
+compared with.  The recipe that closes the gap on a machine with cargo is tools/ref_vectors/ (its output,
+tests/golden/ref_kats.json, is consumed by tests/test_ref_vectors.py when present).
+The Rust reference cannot be compiled or run in the build container (no
 cargo/rustc) and it ships no known-answer files for this path (its tests are property and
 accept/reject tests).  This oracle is therefore pinned by
   (1) the reference's own parameter constants, restated below with their file:line and
