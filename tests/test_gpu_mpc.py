@@ -501,3 +501,72 @@ def test_rccl_multi_rank_opens_and_proof(world):
     res = [q.get(timeout=900) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
     assert all(r[1] == "ok" for r in res), res
+
+
+class _SumRng:
+    """The single prover's view of P parties' generators: every draw is the sum of the parties' draws (MpcField::rand gives
+    each party a share of the prover's randomness)."""
+
+    def __init__(self, seeds):
+        from zk_mpc_amd.api import Rng
+        self.rngs = [Rng.from_seed(s, 20) for s in seeds]
+
+    def fill_fr(self, n):
+        tot = [0] * n
+        for r in self.rngs:
+            for i, v in enumerate(cv.fr_from_mont(r.fill_fr(n))):
+                tot[i] = (tot[i] + v) % O.R_MOD
+        return cv.fr_to_mont(tot) if n else np.zeros((0, 4), dtype=np.uint64)
+
+
+@pytest.mark.parametrize("n_parties,n,spdz", [(2, 6, False), (3, 40, False), (2, 13, True), (8, 21, True)])
+def test_collaborative_marlin_full_proof(n_parties, n, spdz):
+    """MpcMarlin::prove as a PROOF (src/marlin.rs:56): each party runs the rounds on its shares with its own generator, the
+    witness-dependent commitments / evaluations / opening witnesses are revealed (MAC-checked under SPDZ), the transcript
+    runs on the revealed values.  Every party ends with the same bytes; they equal the single prover's proof on the summed
+    inputs with the summed randomness; the oracle's Marlin::verify accepts them and rejects a wrong public input."""
+    import marlin_full_ref as MF
+    import marlin_ref as M
+    from zk_mpc_amd import marlin as DM
+    from zk_mpc_amd.api import Rng
+    rng = O.Prng(7700 + n + n_parties)
+    r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
+    sq, zz = M.pad_and_square(r1cs, z)
+    zs = additive_shares(zz, n_parties, rng, public_prefix=sq.num_instance)
+    zm = additive_shares(zz, n_parties, rng, public_prefix=sq.num_instance)
+    beta_srs, g_k, gg_k, h_k = rng.fr(), rng.fr(), rng.fr(), rng.fr()
+    seeds = [bytes((11 * p + i) & 0xff for i in range(32)) for p in range(n_parties)]
+    a, b, c = DM.Csr.from_rows(sq.a), DM.Csr.from_rows(sq.b), DM.Csr.from_rows(sq.c)
+
+    def setup(ctx):
+        index = DM.Index(ctx, sq.num_instance, sq.num_witness, a, b, c)
+        srs = DM.UniversalSrs(ctx, DM.ahp_max_degree(index) + 3, beta_srs, g_k, gg_k)
+        return DM.IndexKeys(index, srs)
+
+    def fn(p, ctx, net):
+        party = (mpc.SpdzParty if spdz else mpc.Party)(ctx, net=net)
+        keys = setup(ctx)
+        up = lambda v: ctx.upload(cv.fr_to_mont(v))
+        if spdz:
+            proof = party.marlin_prove_full_spdz(keys, (up(zs[p]), up(zm[p])), Rng.from_seed(seeds[p], 20))
+        else:
+            proof = party.marlin_prove_full(keys, up(zs[p]), Rng.from_seed(seeds[p], 20))
+        return proof.serialize(ctx), proof.evaluations, [[(cc.comm_aff, cc.shifted_aff, cc.shifted is not None) for cc in rnd] for rnd in proof.commitments], \
+            [(cv.g1_projective_to_affine(w), rv) for w, rv in proof.pc_proof]
+
+    res = run_parties(n_parties, fn)
+    assert all(r[0] == res[0][0] for r in res)
+    ctx = Z.Context(0)
+    try:
+        keys = setup(ctx)
+        local = DM.prove(keys, ctx.upload(cv.fr_to_mont(zz)), _SumRng(seeds))
+        assert local.serialize(ctx) == res[0][0]
+        oix = M.Index(sq)
+        pp = O.KzgParams(keys.srs.max_degree, beta_srs, g_k=g_k, gg_k=gg_k, h_k=h_k)
+        okeys = MF.Keys(oix, pp)
+        as_oracle = MF.Proof(res[0][2], res[0][1], res[0][3])
+        pub = zz[1:oix.num_instance]
+        assert MF.verify(okeys, pub, as_oracle)
+        assert not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], as_oracle)
+    finally:
+        ctx.close()

@@ -694,12 +694,9 @@ def _host_divide_by_linear(coeffs, z: int):
     return q
 
 
-def _commit_round(keys: IndexKeys, labels, polys: dict, zk_rng):
-    """PC::commit(ck, oracles, Some(zk_rng)) (marlin_pc/mod.rs:172-243): the blinding polynomials are drawn oracle by oracle --
-    three coefficients for a hiding bound of 1, a second set for the shifted commitment of a degree-bounded oracle -- and all
-    MSMs of the round run as one pipelined batch.  Returns ({label: PcCommitment}, {label: (blind, shifted_blind)})."""
-    ctx, srs = keys.index.ctx, keys.srs
-    rands, blinds, keep = {}, {}, []
+def _draw_round_randomness(keys: IndexKeys, labels, zk_rng) -> dict:
+    """The blinding polynomials of one PC::commit call, in the reference's order: label -> (blind, shifted blind)."""
+    rands = {}
     for l in labels:
         hb = keys.hiding.get(l)
         blind = [HostField.i(v) for v in zk_rng.fill_fr(hb + 2)] if hb is not None else []
@@ -707,6 +704,22 @@ def _commit_round(keys: IndexKeys, labels, polys: dict, zk_rng):
         if l in keys.bounds:
             sblind = [HostField.i(v) for v in zk_rng.fill_fr(hb + 2)] if hb is not None else []
         rands[l] = (blind, sblind)
+    return rands
+
+
+def _commit_round(keys: IndexKeys, labels, polys: dict, zk_rng, rands: dict = None, raw: bool = False):
+    """PC::commit(ck, oracles, Some(zk_rng)) (marlin_pc/mod.rs:172-243): the blinding polynomials are drawn oracle by oracle --
+    three coefficients for a hiding bound of 1, a second set for the shifted commitment of a degree-bounded oracle -- and all
+    MSMs of the round run as one pipelined batch.  Returns ({label: PcCommitment}, {label: (blind, shifted_blind)}).
+    rands: randomness drawn beforehand (a SPDZ prover commits its share lane and its MAC lane under the same draws);
+    raw: return the MSM results ({label: {"comm", "shifted_comm"}}) instead of PcCommitment objects (a collaborative prover
+    reveals the sums over parties first)."""
+    ctx, srs = keys.index.ctx, keys.srs
+    if rands is None:
+        rands = _draw_round_randomness(keys, labels, zk_rng)
+    blinds, keep = {}, []
+    for l in labels:
+        blind, sblind = rands[l]
         if blind:
             db = ctx.upload(cv.fr_to_mont(blind))
             ds = ctx.upload(cv.fr_to_mont(sblind)) if sblind else None
@@ -714,6 +727,8 @@ def _commit_round(keys: IndexKeys, labels, polys: dict, zk_rng):
             blinds[l] = (DevPoly(db, len(blind)), DevPoly(ds, len(sblind)) if sblind else None)
     bounds = {l: (keys.bounds.get(l), keys.hiding.get(l)) for l in labels}
     res = commit_marlin_pc(ctx, srs.powers_g, srs.powers_gamma_g, {l: polys[l] for l in labels}, bounds, blinds)
+    if raw:
+        return res, rands
     return {l: PcCommitment(res[l]["comm"], res[l]["shifted_comm"]) for l in labels}, rands
 
 

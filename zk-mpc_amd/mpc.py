@@ -577,6 +577,15 @@ class Party:
         return {"commitments": comms, "evaluations": evals, "w_beta": self.reveal_g1(w_beta), "w_gamma": w_gamma, "challenges": ch}
 
 
+    # ---- collaborative Marlin as a PROOF: transcript, hiding commitments, open_combinations over shares ----
+    def marlin_prove_full(self, keys, z_share, zk_rng, triple_fn=None):
+        """MpcMarlin::prove (src/marlin.rs:56 -> arkworks/marlin/src/lib.rs:152-319 with F = MpcField) over additive shares:
+        the complete proof, as `marlin.prove` emits it for one prover.  z_share: this party's share of the padded assignment
+        (DevBuf; instance on the leader); zk_rng: this party's OWN generator -- every draw is a share (MpcField::rand), the
+        effective randomness is the sum over parties.  The revealed proof is identical on every party and equal to the local
+        proof on the summed inputs and summed randomness."""
+        return _marlin_prove_full(self, keys, [z_share], zk_rng, triple_fn, spdz=False)
+
 # ------------------------------------------------------------------------------------------------
 # SPDZ (malicious-majority backend): every share carries a MAC share; opens are MAC-checked
 # ------------------------------------------------------------------------------------------------
@@ -777,3 +786,188 @@ class SpdzParty(Party):
         g_c = add1(add1(add1(add1(s_g_a, r_g1_b), neg1(r_s_delta)), l_acc), h_acc)
         Ap, Bp, Cp = self.spdz_open_g1(g_a), self.spdz_open_g2(g2_b), self.spdz_open_g1(g_c)   # SpdzGroupShare::reveal
         return be.g1_serialize(Ap) + be.g2_serialize(Bp) + be.g1_serialize(Cp)
+
+
+    def marlin_prove_full_spdz(self, keys, z_share, zk_rng, triple_fn=None):
+        """The same over SPDZ shares (the `malicious` feature; BASELINE config 5's prover): z_share = (share, MAC) DevBufs, every
+        open MAC-checked.  The MAC lane of this party's fresh randomness is the share itself (key alpha = 1 on the leader:
+        sum of MAC shares = sum of shares), as the reference's from_add_shared does."""
+        return _marlin_prove_full(self, keys, list(z_share), zk_rng, triple_fn, spdz=True)
+
+
+def _marlin_prove_full(party, keys, z_lanes, zk_rng, triple_fn, spdz: bool):
+    from . import convert as cv
+    from . import marlin as DM
+    from .api import Rng
+    be = party.be
+    ctx = be.ctx
+    index, srs = keys.index, keys.srs
+    m, ival = DM.HostField.m, DM.HostField.i
+    R_MOD = DM.R_MOD
+    lanes = range(len(z_lanes))
+    shared = Party.SHARED_POLYS
+    leader = party.leader
+
+    def open_g1(pts):                                   # pts: one projective array per lane
+        return party.spdz_open_g1(tuple(pts)) if spdz else party.reveal_g1(pts[0])
+
+    def open_fr(vals):                                  # vals: one (4,) Montgomery array per lane
+        return ival(party.spdz_open_fr(tuple(vals)) if spdz else party._open_fr(vals[0]))
+
+    # the public input is the instance part of the assignment: shared as from_public (the leader holds it), opened for the transcript
+    ni = index.num_instance
+    pub = []
+    if ni > 1:
+        tmp = be.vec("marlin_pub", ni)
+        if spdz:
+            party.spdz_open_vec((z_lanes[0].ptr, z_lanes[1].ptr), tmp, ni)
+        else:
+            be.open_vec(z_lanes[0].ptr, tmp, ni)
+        pub = cv.fr_from_mont(ctx.download(tmp, (ni, 4)))[1:]
+    fs = Rng.fiat_shamir(DM.PROTOCOL_NAME + keys.ivk_bytes() + b"".join(DM._fr_bytes(v) for v in pub))
+    st = [DM.prover_init(index, z, shared=True) for z in z_lanes]
+    polys = [dict(index.polynomials()) for _ in lanes]
+    rands = {l: ([], None) for l in DM.INDEX_LABELS}
+    comms = dict(keys.index_comms)
+    ch = {}
+
+    def commit_round(labels, round_polys):
+        """Shares of the commitments on every lane under the same draws, then the reveal of the witness-dependent ones
+        (`comms.publicize()`, lib.rs:180,205,228); public oracles commit alike on every party."""
+        rr = DM._draw_round_randomness(keys, labels, zk_rng)
+        res = [DM._commit_round(keys, labels, round_polys[lane], zk_rng, rands=rr, raw=True)[0] for lane in lanes]
+        out = {}
+        for l in labels:
+            if l in shared:
+                c = open_g1([res[lane][l]["comm"] for lane in lanes])
+                sc = open_g1([res[lane][l]["shifted_comm"] for lane in lanes]) if res[0][l]["shifted_comm"] is not None else None
+            else:
+                c, sc = res[0][l]["comm"], res[0][l]["shifted_comm"]
+            out[l] = DM.PcCommitment(c, sc)
+        rands.update(rr)
+        comms.update(out)
+        fs.absorb(b"".join(out[l].to_bytes() for l in labels))
+
+    # ---- round 1: every draw is this party's share of the prover's randomness
+    md = DM.mask_poly_degree(index)
+    rnd = ctx.upload(zk_rng.fill_fr(3 + md + 1))
+    r1 = [DM.prover_first_round(st[lane], rnd) for lane in lanes]
+    for lane in lanes:
+        polys[lane].update(r1[lane])
+    commit_round(DM.ROUND_LABELS[0], r1)
+    ch["alpha"] = DM._sample_outside(index.dom_h, fs)
+    ch["eta_a"], ch["eta_b"], ch["eta_c"] = ival(fs.next_fr()), ival(fs.next_fr()), ival(fs.next_fr())
+    # ---- round 2: the lanes advance in lock-step around ONE Beaver product and one opened zero test
+    steps = [DM.second_round_steps(st[lane], ch["alpha"], ch["eta_a"], ch["eta_b"], ch["eta_c"]) for lane in lanes]
+    req = [next(g) for g in steps]
+    n_mul = req[0][4]
+    if spdz:
+        party.spdz_beaver_batch_mul((req[0][1], req[1][1]), (req[0][2], req[1][2]), (req[0][3], req[1][3]), n_mul,
+                                    triple_fn(n_mul) if triple_fn else None)
+    else:
+        party.beaver_batch_mul(req[0][1], req[0][2], req[0][3], n_mul, triple_fn(n_mul) if triple_fn else None)
+    req = [g.send(None) for g in steps]
+    opened = be.vec("marlin_open", req[0][2])
+    if spdz:
+        party.spdz_open_vec((req[0][1], req[1][1]), opened, req[0][2])
+    else:
+        be.open_vec(req[0][1], opened, req[0][2])
+    ok = be.is_zero_vec(opened, req[0][2])
+    r2 = []
+    for g in steps:
+        try:
+            g.send(ok)
+            raise RuntimeError("second round did not finish")
+        except StopIteration as done:
+            r2.append(done.value)
+    for lane in lanes:
+        polys[lane].update(r2[lane])
+    commit_round(DM.ROUND_LABELS[1], r2)
+    ch["beta"] = DM._sample_outside(index.dom_h, fs)
+    # ---- round 3: public values only
+    r3 = DM.prover_third_round(st[0], ch["beta"])
+    for lane in lanes:
+        polys[lane].update(r3)
+    commit_round(DM.ROUND_LABELS[2], [r3 for _ in lanes])
+    ch["gamma"] = ival(fs.next_fr())
+    # ---- evaluations: shared oracles are evaluated on the shares and opened (`evaluations.publicize()`)
+    ev = lambda lane, l, pt: ctx.poly_evaluate_dev(polys[lane][l].ptr, polys[lane][l].n, m(pt))
+    single = {l: open_fr([ev(lane, l, ch["beta"]) for lane in lanes]) for l in ("z_b", "g_1")}
+    single["t"], single["g_2"] = ival(ev(0, "t", ch["beta"])), ival(ev(0, "g_2", ch["gamma"]))
+    ba = ch["beta"] * ch["alpha"] % R_MOD
+    for mm in "abc":
+        single[mm + "_denom"] = (ba - ch["alpha"] * ival(ev(0, mm + "_row", ch["gamma"])) - ch["beta"] * ival(ev(0, mm + "_col", ch["gamma"]))
+                                 + ival(ev(0, mm + "_row_col", ch["gamma"]))) % R_MOD
+    lcs = DM._linear_combinations(index, pub, ch, lambda l: single[l])
+    evaluations = [single[l] for l in DM.EVAL_LABELS]
+    fs.absorb(b"".join(DM._fr_bytes(e) for e in evaluations))
+    xi = fs.next_u128() % R_MOD
+    ch["xi"] = xi
+    # ---- open_combinations on the shares: the witness of a share combination is a share of the witness; public polynomials
+    # enter a shared combination through shift(), i.e. on the leader (in both lanes: mac_share = 1 there)
+    point = {"beta": ch["beta"], "gamma": ch["gamma"]}
+    pc_proof, keep = [], []
+    for pl in ("beta", "gamma"):
+        z = point[pl]
+        terms, shifted, j = {}, [], 0
+        r_comb, sr = [], []
+        for label in DM.QUERY_SET[pl]:
+            lc = [(c, l) for c, l in lcs[label] if l is not None]
+            cj = pow(xi, j, R_MOD); j += 1
+            for c, l in lc:
+                terms[l] = (terms.get(l, 0) + c * cj) % R_MOD
+                blind = rands[l][0]
+                r_comb = [((r_comb[i] if i < len(r_comb) else 0) + (blind[i] if i < len(blind) else 0) * c % R_MOD * cj) % R_MOD
+                          for i in range(max(len(r_comb), len(blind)))]
+            if len(lcs[label]) == 1 and lc[0][1] in keys.bounds:
+                src = lc[0][1]
+                cj1 = pow(xi, j, R_MOD); j += 1
+                shifted.append((src, cj1))
+                sb = rands[src][1] or []
+                sr = [((sr[i] if i < len(sr) else 0) + (sb[i] if i < len(sb) else 0) * cj1) % R_MOD for i in range(max(len(sr), len(sb)))]
+        labels = list(terms)
+        any_shared = any(l in shared for l in labels)
+        hiding = any(len(rands[l][0]) > 0 for l in labels)
+        wit = []
+        for lane in (lanes if any_shared else [0]):
+            mine = [polys[lane][l] if (l in shared or leader or not any_shared) else None for l in labels]
+            comb = DM.linear_combination(ctx, mine, [terms[l] for l in labels])
+            q = ctx.alloc(max(comb.n - 1, 1) * 32)
+            ctx.poly_divide_by_linear_dev(comb.ptr, comb.n, m(z), q.ptr)
+            keep += [comb, q]
+            jobs = [(srs.powers_g, 0, q.ptr, comb.n - 1)]
+            if hiding:
+                rw = DM._host_divide_by_linear(r_comb, z)
+                d = ctx.upload(cv.fr_to_mont(rw)); keep.append(d)
+                jobs.append((srs.powers_gamma_g, 0, d.ptr, len(rw)))
+            srw = []
+            for src, cj1 in shifted:
+                pp = polys[lane][src]
+                if src in shared or leader or not any_shared:
+                    wq = ctx.alloc(max(pp.n - 1, 1) * 32)
+                    ctx.poly_divide_by_linear_dev(pp.ptr, pp.n, m(z), wq.ptr)
+                    ctx.fr_vec_scale_dev(wq.ptr, m(cj1), wq.ptr, pp.n - 1)
+                    keep.append(wq)
+                    jobs.append((srs.powers_g, srs.max_degree - keys.bounds[src], wq.ptr, pp.n - 1))
+                sb = rands[src][1] or []
+                if sb:
+                    w1 = DM._host_divide_by_linear(sb, z)
+                    srw = [((srw[i] if i < len(srw) else 0) + w1[i] * cj1) % R_MOD for i in range(len(w1))]
+            if srw:
+                d = ctx.upload(cv.fr_to_mont(srw)); keep.append(d)
+                jobs.append((srs.powers_gamma_g, 0, d.ptr, len(srw)))
+            outs = ctx.msm_batch_dev(jobs)
+            w = outs[0]
+            for o in outs[1:]:
+                w = ctx.g1_add(w, o)
+            wit.append(w)
+        rv = None
+        if hiding:
+            rv_share = DM._host_poly_eval(r_comb, z)
+            if shifted:
+                rv_share = (rv_share + DM._host_poly_eval(sr, z)) % R_MOD
+            rv = open_fr([m(rv_share) for _ in lanes])      # the MAC lane of fresh local randomness is the share itself
+        w = open_g1(wit) if any_shared else wit[0]
+        pc_proof.append((w, rv))
+    ctx.sync()
+    return DM.MarlinProof([[comms[l] for l in rnd_labels] for rnd_labels in DM.ROUND_LABELS], evaluations, pc_proof, ch)
