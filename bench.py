@@ -218,6 +218,110 @@ def predict_proof(ctx, n, zarr, td, r_, s_, threads):
     return OC.groth16_predict(cr, np.stack(td), zarr, h, r_, s_), "ok"
 
 
+def marlin_bench(args, ctx, dist, rank, world, real_stdout):
+    """--marlin: Marlin::prove on the mul-chain system with |H| = |K| = 2^L (BASELINE config 4: one GPU, zk_marlin_prove;
+    config 5's shape with --gpus N [--spdz]: the N-party collaborative prover, every party the full-size rounds and MSMs on its
+    shares).  A step = one proof; the last proof is checked by the oracle's Marlin::verify outside the timed region."""
+    import types
+    import torch
+    import zk_mpc_amd.convert as cv
+    from zk_mpc_amd import marlin as DM
+    from zk_mpc_amd.api import Rng
+    m = DM.HostField.m
+    n = (1 << args.log_constraints) - 3
+    ni, nw, a, b, c = DM.mul_chain_system(ctx, n)
+    index = DM.Index(ctx, ni, nw, a, b, c)
+    beta_srs, g_k, gg_k, h_k = 0x1234567, 3, 7, 5
+    t0 = time.time()
+    srs = DM.UniversalSrs(ctx, DM.ahp_max_degree(index) + 5, beta_srs, g_k, gg_k)
+    keys = DM.IndexKeys(index, srs)
+    t_setup = time.time() - t0
+    z = ctx.mul_chain_assignment_dev(n, m(3), m(5))
+    seed = bytes((rank * 17 + i) & 0xff for i in range(32))
+    ctx.pooling = True
+    if dist is None:
+        def step():
+            return DM.prove_native(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
+    else:
+        from zk_mpc_amd import mpc
+        party = (mpc.SpdzParty if args.spdz else mpc.Party)(ctx, dist)
+        shape = types.SimpleNamespace(num_instance=ni, num_witness=nw)
+        z0 = party.share_assignment_dev(z, shape, seed=1234)
+        keep = [party._keep]
+        zl = [z0]
+        if args.spdz:
+            zl.append(party.share_assignment_dev(z, shape, seed=4321))
+            keep.append(party._keep)
+        zb = [types.SimpleNamespace(ptr=p) for p in zl]
+
+        def step():
+            if args.spdz:
+                return party.marlin_prove_full_spdz(keys, (zb[0], zb[1]), Rng.from_seed(seed, 20))
+            return party.marlin_prove_full(keys, zb[0], Rng.from_seed(seed, 20))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+    for _ in range(2 + args.warmup):
+        proof = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        proof = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    if dist is None:
+        obj = DM.prove(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
+        same = obj.serialize(ctx) == proof
+        proof_bytes = proof
+    else:
+        obj, same = proof, None
+        proof_bytes = proof.serialize(ctx)
+    verdict = {}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import marlin_full_ref as MF
+        import marlin_ref as MR
+        import zkref as O
+
+        class PP:
+            pass
+        pp = PP()
+        pp.beta = beta_srs
+        pp.g, pp.gamma_g, pp.h = O.g1_mul(O.G1_GEN, g_k), O.g1_mul(O.G1_GEN, gg_k), O.g2_mul(O.G2_GEN, h_k)
+        pp.beta_h = O.g2_mul(pp.h, beta_srs)
+        info = MR.IndexInfo(index.num_constraints, index.num_non_zero, index.num_instance)
+        info.num_variables, info.num_constraints, info.num_non_zero = index.num_variables, index.num_constraints, index.num_non_zero
+        okeys = MF.Keys(info, pp, max_degree=srs.max_degree, index_comms={l: keys.index_comms[l].comm_aff for l in MF.INDEX_LABELS})
+        as_oracle = MF.Proof([[(cc.comm_aff, cc.shifted_aff, cc.shifted is not None) for cc in rnd] for rnd in obj.commitments],
+                             obj.evaluations, [(cv.g1_projective_to_affine(w), rv) for w, rv in obj.pc_proof])
+        pub = cv.fr_from_mont(ctx.download(z.ptr + 32, (index.num_instance - 1, 4)))
+        verdict = {"oracle_verifier_accepts": bool(MF.verify(okeys, pub, as_oracle)),
+                   "oracle_verifier_rejects_wrong_input": bool(not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], as_oracle))}
+    except Exception as e:
+        verdict = {"oracle_verifier_accepts": None, "verifier_error": repr(e)}
+    K = args.steps
+    out = {"metric": "R1CS constraints/sec (prove), Marlin/KZG10 BLS12-377", "value": round(n * K / dt * world, 1), "unit": "constraints/s",
+           "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u32x13 / u32x9 (29-bit limbs, int64 accumulate)", "data": "synthetic",
+           "config": {"workload": "Marlin::prove, mul-chain R1CS, |H| = |K| = 2^%d, %s" % (
+               args.log_constraints, "local prove (zk_marlin_prove)" if dist is None else "%d-party %s collaborative prove" % (
+                   world, "SPDZ" if args.spdz else "additive-share")), "constraints": n, "parties": world},
+           "proof_constraints_per_s": round(n * K / dt, 1), "proof_bytes": len(proof_bytes), "equals_python_sequence": same,
+           "setup_s": round(t_setup, 2), "proof_sha": __import__("hashlib").sha256(proof_bytes).hexdigest()[:16], **verdict}
+    if dist is not None:
+        out["bytes_sent_per_party"] = int(party.bytes_sent)
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,6 +339,8 @@ def main():
     ap.add_argument("--natural-domain", action="store_true",
                     help="n = 2^L constraints, so that the QAP domain is 2^(L+1) (the reference's natural sizing, src/groth16.rs:256-257)")
     ap.add_argument("--spdz", action="store_true", help="N > 1: SPDZ (malicious) shares instead of additive ones")
+    ap.add_argument("--marlin", action="store_true",
+                    help="prove with Marlin/KZG instead of Groth16 (BASELINE configs 4 and 5: --gpus 1, or --gpus 8 --spdz --log-constraints 22)")
     args = ap.parse_args()
 
     # stdout must carry exactly ONE JSON line: libraries (RCCL prints a version banner on stdout at communicator
@@ -266,6 +372,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.marlin:
+        ctx = Z.Context(local_rank, rank, world)
+        marlin_bench(args, ctx, dist, rank, world, real_stdout)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     n = (1 << args.log_constraints) - (0 if args.natural_domain else 2)      # + 2 instance variables -> domain 2^L exactly
     ctx = Z.Context(local_rank, rank, world)
     mont = lambda v: cv.fr_to_mont([v])[0]
