@@ -84,6 +84,31 @@ def field(struct, p, L, W, internal=(), raw=(), LR=None):
     return "\n".join(out)
 
 
+def sub_offset(p, L, K, j):
+    """K p written with limbs 0..L-2 in [j 2^29, (j + 1) 2^29) and whatever is left in the top limb: a + offset - b needs no
+    borrow for any b whose limbs 0..L-2 are below j 2^29 (and whose top limb is below the offset's)."""
+    t = K * p - sum((j << B) << (B * i) for i in range(L - 1))
+    assert t >= 0
+    lo = [((t >> (B * i)) & ((1 << B) - 1)) + (j << B) for i in range(L - 1)]
+    c = lo + [t >> (B * (L - 1))]
+    assert sum(v << (B * i) for i, v in enumerate(c)) == K * p and c[-1] < (1 << 29)
+    return c
+
+
+def fr_lazy():
+    """Constants of the lazy Fr domain of the NTT butterflies (frlazy.cuh): 2^261 / r = 445.5 leaves 8.8 bits of head room."""
+    L = 9
+    out = ["struct FrLazy {"]
+    out.append(arr("RC", (1 << (B * L)) - R_MOD, L, "2^261 - r: a + q RC = (a - q r) + q 2^261"))
+    out.append("    static constexpr uint32_t MQ = %du;      // floor(2^264 / r): q = (top limb * MQ) >> 32 <= floor(a / r)" % ((1 << 264) // R_MOD))
+    for name, K, j in (("OFF2", 2, 1), ("OFF3", 3, 1), ("OFF5", 5, 2)):
+        c = sub_offset(R_MOD, L, K, j)
+        out.append("    static constexpr uint32_t %s[%d] = {%s};  // %d r, limbs 0..7 in [%d * 2^29, %d * 2^29)" % (
+            name, L, ", ".join("0x%08xu" % v for v in c), K, j, j + 1))
+    out.append("};")
+    return "\n".join(out)
+
+
 def main():
     two_adic_root = pow(FR_GENERATOR, (R_MOD - 1) >> FR_TWO_ADICITY, R_MOD)
     print("// GENERATED by gen_consts.py -- do not edit.  29-bit little-endian limbs.")
@@ -99,6 +124,7 @@ def main():
         ("WIDE_HI", (1 << 256) * (1 << (B * 9)) * (1 << (B * 9))),
     ]))
     print("static constexpr int FR_TWO_ADICITY = %d;" % FR_TWO_ADICITY)
+    print(fr_lazy())
     # Fq: ONE extra Montgomery digit (RI = 2^406, not 2^377).  q = 0.84 * 2^377 leaves no room between q and 2^(29 * 13):
     # with 13 digits every product needs a conditional subtraction and every sum a full reduction (43 % of the instructions
     # of a bucket addition).  With 14 digits a product of operands up to 7 q lands in [0, q + 2^354) by itself.

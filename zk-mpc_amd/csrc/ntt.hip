@@ -20,13 +20,14 @@
 // + N inter-pass twiddles per pass boundary.  Traffic: 2 * 32 B * N per pass + the swap pass.
 #include "../../include/zkmpc_hip.h"
 #include "devutil.cuh"
+#include "frlazy.cuh"
 #include "internal.hpp"
 
 using namespace zk;
 
 struct zk_domain {
     uint32_t log_n = 0;
-    uint32_t* tw = nullptr;     // w^i, i < N          (internal form, 8 words each)
+    uint32_t* tw = nullptr;     // w^i, i < N          (internal form, nine 29-bit limbs each: tab_load)
     uint32_t* cos = nullptr;    // g^i                  (coset FFT pre-scale)
     uint32_t* icos = nullptr;   // g^-i / N             (coset iFFT post-scale)
     Fr size_inv;                // 1/N, internal form
@@ -36,6 +37,7 @@ struct zk_domain {
 namespace {
 
 constexpr int LOGM_MAX = 10;
+constexpr int NTT_THREADS = 1024;
 constexpr int TILE_ELEMS = 4096;  // x 36 B = 144 KiB of LDS
 
 struct FrK { uint32_t l[9]; };
@@ -51,7 +53,24 @@ FrK to_frk(const Fr& a) {
     return k;
 }
 
-// out[i] = start * base^i  (internal form in, internal form out)
+// Table entries (twiddles, coset scales) are kept as their nine 29-bit limbs, 36 B each: a product takes them as they are
+// (re-slicing eight packed words into nine limbs was ~25 instructions in front of every twiddle product).
+struct __attribute__((packed, aligned(4))) Limbs9 { uint32_t l[9]; };
+__device__ __forceinline__ Fr tab_load(const uint32_t* tab, size_t i) {
+    const Limbs9 t = reinterpret_cast<const Limbs9*>(tab)[i];
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = t.l[k];
+    return r;
+}
+__device__ __forceinline__ void tab_store(uint32_t* tab, size_t i, const Fr& v) {
+    Limbs9 t;
+#pragma unroll
+    for (int k = 0; k < 9; k++) t.l[k] = v.l[k];
+    reinterpret_cast<Limbs9*>(tab)[i] = t;
+}
+
+// out[i] = start * base^i  (internal form in, limb-form table out)
 __global__ void __launch_bounds__(256) k_powers(uint32_t* out, FrK base_k, FrK start_k, size_t n) {
     constexpr int CH = 32;
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -67,7 +86,7 @@ __global__ void __launch_bounds__(256) k_powers(uint32_t* out, FrK base_k, FrK s
     }
     p = fr_mul(p, frk(start_k));
     for (int j = 0; j < CH && i0 + j < n; j++) {
-        fr_store(out, i0 + j, p);
+        tab_store(out, i0 + j, p);
         p = fr_mul(p, base);
     }
 }
@@ -86,80 +105,158 @@ __device__ __forceinline__ void lds_store(uint32_t* lds, uint32_t E, uint32_t li
     for (int k = 0; k < 9; k++) lds[k * E + li] = v.l[k];
 }
 
-// One DIF pass.  Tile = C columns x M points; column id = block * S + l.
-// FINAL (last pass, logS == 0): the element lands directly at its bit-reversed position in `out` (a different buffer:
-// the scattered stores would otherwise overwrite tiles that have not been read yet), multiplied by the post-scale
-// (POST 1: constant k = 1/N; POST 2: table post[dst] = g^-dst / N) -- this replaces a separate permutation pass
-// (72 us at 2^20, seven times per witness map).
+#define ZK_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// What a pass reads and writes in global memory.  Tile = C columns x M points; column id = block * C + c; element (m, c)
+// of the tile is data[((col >> logS) << logB) + (m << logS) + (col & (S - 1))] (c fastest: C * 32 B contiguous runs).
+// FINAL (last pass of a multi-pass transform, logS == 0): the element lands directly at its bit-reversed position in `out` (a
+// different buffer: the scattered stores would otherwise overwrite tiles that have not been read yet), multiplied by the
+// post-scale (POST 1: constant k = 1/N; POST 2: table post[dst] = g^-dst / N) -- this replaces a separate permutation pass.
 template <int POST>
-__global__ void __launch_bounds__(1024)
+struct PassIO {
+    const uint32_t* data;
+    uint32_t* out;
+    const uint32_t* __restrict__ tw;
+    const uint32_t* __restrict__ pre;
+    const uint32_t* __restrict__ post;
+    uint32_t log_n, logS, logM, logB, N1, col0;
+    int inverse, final_rev;
+
+    __device__ __forceinline__ uint32_t index(uint32_t m, uint32_t c) const {
+        const uint32_t col = col0 + c;
+        return ((col >> logS) << logB) + (m << logS) + (col & ((1u << logS) - 1));
+    }
+    // canonical, or < 1.03 r from the pass before; the coset pre-scale g^idx rides on the first pass's load
+    __device__ __forceinline__ Fr load(uint32_t m, uint32_t c) const {
+        const uint32_t idx = index(m, c);
+        Fr v = fr_load(data, idx);
+        if (pre) v = frl_mul(v, tab_load(pre, idx));
+        return v;
+    }
+    // v: any lazy value (wide limbs allowed).  A pass that is not the last multiplies by the inter-pass twiddle w_B^(l q),
+    // q = bitrev(m), and hands on a value below 1.03 r (it fits the 256-bit words); the last one hands back canonical values.
+    __device__ __forceinline__ void emit(uint32_t m, uint32_t c, Fr v, const FrK& post_k) const {
+        const uint32_t idx = index(m, c);
+        uint32_t dst = idx;
+        if (logS) {
+            const uint32_t l = (col0 + c) & ((1u << logS) - 1);
+            const uint32_t q = __brev(m) >> (32 - logM);
+            uint32_t ex = (l * q) << (log_n - logB);
+            if (inverse) ex = (0u - ex) & N1;
+            v = frl_mul(v, tab_load(tw, ex));
+        } else if (final_rev && POST) {
+            dst = __brev(idx) >> (32 - log_n);
+            const Fr t = frl_mul(v, POST == 1 ? frk(post_k) : tab_load(post, dst));
+            v = fp_reduce_once<FrParams>(t.l);
+        } else {
+            if (final_rev) dst = __brev(idx) >> (32 - log_n);
+            v = frl_canon(v);
+        }
+        fr_store(out, dst, v);
+    }
+};
+
+// One radix-4 butterfly of a stage (frlazy.cuh: frl_radix4, here with its loads and stores placed so that at most two tile
+// elements, two sums / products and one twiddle are live at a time: four waves per SIMD without spills).  The tile elements are
+// (m0 + k gB, c), k < 4.
+// FIRST: the pass's first stage reads global memory itself (no load phase, no LDS round trip: the waves whose data arrives
+// start their products while the others still wait).  LAST: the pass's last stage (its second level has twiddle 1) hands its
+// four outputs, as wide sums, straight to PassIO::emit (whose product, or frl_canon, brings them back into range).
+template <bool FIRST, bool LAST, int POST>
+__device__ __forceinline__ void radix4_item(const PassIO<POST>& io, const FrK& post_k, uint32_t* lds, uint32_t E, uint32_t logC, uint32_t m0,
+                                            uint32_t gB, uint32_t c, uint32_t ea, uint32_t eb, uint32_t ec) {
+    const uint32_t i0 = (m0 << logC) | c, st = gB << logC;
+    const Fr wa = tab_load(io.tw, ea), wb = tab_load(io.tw, eb);     // first: their latency runs under the reads below
+    Fr s0, s1, d0, d1;
+    {
+        const Fr x0 = FIRST ? io.load(m0, c) : lds_load(lds, E, i0), x2 = FIRST ? io.load(m0 + 2 * gB, c) : lds_load(lds, E, i0 + 2 * st);
+        s0 = frl_add(x0, x2);
+        d0 = frl_mul(frl_sub<3>(x0, x2), wa);
+    }
+    ZK_SCHED_FENCE();
+    Fr wc;
+    if (!LAST) wc = tab_load(io.tw, ec);                             // lands under the second product
+    {
+        const Fr x1 = FIRST ? io.load(m0 + gB, c) : lds_load(lds, E, i0 + st), x3 = FIRST ? io.load(m0 + 3 * gB, c) : lds_load(lds, E, i0 + 3 * st);
+        s1 = frl_add(x1, x3);
+        d1 = frl_mul(frl_sub<3>(x1, x3), wb);
+    }
+    ZK_SCHED_FENCE();
+    Fr y0 = frl_add(s0, s1), y2 = frl_add(d0, d1);
+    Fr u = frl_sub<5>(s0, s1), v = frl_sub<2>(d0, d1);
+    if (LAST) {
+        io.emit(m0, c, y0, post_k);
+        ZK_SCHED_FENCE();
+        io.emit(m0 + gB, c, u, post_k);
+        ZK_SCHED_FENCE();
+        io.emit(m0 + 2 * gB, c, y2, post_k);
+        ZK_SCHED_FENCE();
+        io.emit(m0 + 3 * gB, c, v, post_k);
+    } else {
+        lds_store(lds, E, i0, frl_reduce(y0));
+        lds_store(lds, E, i0 + 2 * st, frl_norm(y2));
+        ZK_SCHED_FENCE();
+        u = frl_mul(u, wc);
+        ZK_SCHED_FENCE();
+        v = frl_mul(v, wc);
+        lds_store(lds, E, i0 + st, u);
+        lds_store(lds, E, i0 + 3 * st, v);
+    }
+}
+
+// One DIF pass: logM levels of the size-M transforms of a tile, as radix-4 register butterflies in the lazy domain
+// (frlazy.cuh) with the tile in LDS between stages; one radix-2 level comes first when logM is odd.  Twiddle exponents in
+// units of w = w_N: level s of the size-M transform uses w_M^(jj 2^s) = w^((jj << s) << (log_n - logM)).
+template <int POST>
+__global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(const uint32_t* data, uint32_t* out, const uint32_t* __restrict__ tw,
            const uint32_t* __restrict__ pre, uint32_t log_n, uint32_t logS, uint32_t logM, uint32_t logC, int inverse,
            int final_rev, FrK post_k, const uint32_t* __restrict__ post) {
     extern __shared__ uint32_t lds[];
-    const uint32_t M = 1u << logM, C = 1u << logC, E = M * C;
+    const uint32_t C = 1u << logC, E = C << logM;
     const uint32_t N1 = (1u << log_n) - 1;
-    const uint32_t logB = logS + logM;
     const uint32_t tid = threadIdx.x, NT = blockDim.x;
-    const uint32_t col0 = blockIdx.x << logC;
-
-    // ---- load tile (c fastest -> contiguous runs), optional coset pre-scale ----
-    for (uint32_t e = tid; e < E; e += NT) {
-        uint32_t c = e & (C - 1), m = e >> logC;
-        uint32_t col = col0 + c;
-        uint32_t idx = ((col >> logS) << logB) + (m << logS) + (col & ((1u << logS) - 1));
-        Fr v = fr_load(data, idx);
-        if (pre) v = fr_mul(v, fr_load(pre, idx));
-        lds_store(lds, E, e, v);
-    }
-    __syncthreads();
-
-    // ---- logM butterfly levels in LDS ----
-    const uint32_t nb = E >> 1;
-    for (uint32_t s = 0; s < logM; s++) {
-        const uint32_t lg = logM - 1 - s;  // log2(gap)
-        const uint32_t g = 1u << lg;
-        for (uint32_t b = tid; b < nb; b += NT) {
-            uint32_t c = b & (C - 1), j = b >> logC;
-            uint32_t jj = j & (g - 1);
-            uint32_t m_lo = ((j >> lg) << (lg + 1)) | jj;
-            uint32_t lo = (m_lo << logC) | c, hi = ((m_lo + g) << logC) | c;
-            Fr x = lds_load(lds, E, lo), y = lds_load(lds, E, hi);
-            Fr sum = fr_add(x, y), d = fr_sub(x, y);
-            if (jj) {
-                uint32_t ex = (jj << s) << (log_n - logM);
-                if (inverse) ex = (0u - ex) & N1;
-                d = fr_mul(d, fr_load(tw, ex));
-            }
-            lds_store(lds, E, lo, sum);
-            lds_store(lds, E, hi, d);
-        }
-        __syncthreads();
-    }
-
-    // ---- inter-pass twiddle w_B^(l*q), q = bitrev(m), and store in place ----
-    for (uint32_t e = tid; e < E; e += NT) {
-        uint32_t c = e & (C - 1), m = e >> logC;
-        uint32_t col = col0 + c;
-        uint32_t l = col & ((1u << logS) - 1);
-        uint32_t idx = ((col >> logS) << logB) + (m << logS) + l;
-        Fr v = lds_load(lds, E, e);
-        if (logS) {
-            uint32_t q = __brev(m) >> (32 - logM);
-            uint32_t lq = l * q;
-            if (lq) {
-                uint32_t ex = lq << (log_n - logB);
-                if (inverse) ex = (0u - ex) & N1;
-                v = fr_mul(v, fr_load(tw, ex));
+    const PassIO<POST> io{data, out, tw, pre, post, log_n, logS, logM, logS + logM, N1, blockIdx.x << logC, inverse, final_rev};
+    const uint32_t tsh = log_n - logM;
+    const uint32_t nst = (logM + 1) >> 1;       // stages: the last one stores to global memory, the first one loads from it
+    uint32_t s = 0, stage = 0;
+    if (logM & 1) {
+        const uint32_t g = 1u << (logM - 1);
+        for (uint32_t b = tid; b < (E >> 1); b += NT) {
+            const uint32_t c = b & (C - 1), j = b >> logC;        // j < g: the only block of this level
+            uint32_t ex = j << tsh;
+            if (inverse) ex = (0u - ex) & N1;
+            const Fr w = tab_load(tw, ex);
+            Fr x = io.load(j, c), y = io.load(j + g, c);
+            frl_radix2(x, y, w);
+            if (nst == 1) {
+                io.emit(j, c, x, post_k);
+                io.emit(j + g, c, y, post_k);
+            } else {
+                lds_store(lds, E, (j << logC) | c, x);
+                lds_store(lds, E, ((j + g) << logC) | c, y);
             }
         }
-        uint32_t dst = idx;
-        if (final_rev) {
-            dst = __brev(idx) >> (32 - log_n);
-            if (POST == 1) v = fr_mul(v, frk(post_k));
-            if (POST == 2) v = fr_mul(v, fr_load(post, dst));
+        if (nst > 1) __syncthreads();
+        s = 1;
+        stage = 1;
+    }
+    for (; s < logM; s += 2, stage++) {
+        const uint32_t lgA = logM - 1 - s, lgB = lgA - 1, gB = 1u << lgB;
+        const uint32_t quarter = 1u << (log_n - 2);
+        const bool first = stage == 0, last = stage + 1 == nst;
+        for (uint32_t b = tid; b < (E >> 2); b += NT) {
+            const uint32_t c = b & (C - 1), j = b >> logC;
+            const uint32_t jj = j & (gB - 1);
+            const uint32_t m0 = ((j >> lgB) << (lgA + 1)) | jj;
+            uint32_t ea = (jj << s) << tsh, eb = ea + quarter, ec = ea << 1;
+            if (inverse) { ea = (0u - ea) & N1; eb = (0u - eb) & N1; ec = (0u - ec) & N1; }
+            if (first && last) radix4_item<true, true>(io, post_k, lds, E, logC, m0, gB, c, ea, eb, ec);
+            else if (first) radix4_item<true, false>(io, post_k, lds, E, logC, m0, gB, c, ea, eb, ec);
+            else if (last) radix4_item<false, true>(io, post_k, lds, E, logC, m0, gB, c, ea, eb, ec);
+            else radix4_item<false, false>(io, post_k, lds, E, logC, m0, gB, c, ea, eb, ec);
         }
-        fr_store(out, dst, v);
+        if (!last) __syncthreads();
     }
 }
 
@@ -174,12 +271,12 @@ __global__ void __launch_bounds__(256) k_bitrev_scale(uint32_t* data, uint32_t l
         Fr a = fr_load(data, i);
         if (i == r) {
             if (MODE == 1) a = fr_mul(a, kk);
-            if (MODE == 2) a = fr_mul(a, fr_load(post, i));
+            if (MODE == 2) a = fr_mul(a, tab_load(post, i));
             if (MODE) fr_store(data, i, a);
         } else {
             Fr b = fr_load(data, r);
             if (MODE == 1) { a = fr_mul(a, kk); b = fr_mul(b, kk); }
-            if (MODE == 2) { a = fr_mul(a, fr_load(post, r)); b = fr_mul(b, fr_load(post, i)); }
+            if (MODE == 2) { a = fr_mul(a, tab_load(post, r)); b = fr_mul(b, tab_load(post, i)); }
             fr_store(data, i, b);
             fr_store(data, r, a);
         }
@@ -196,7 +293,7 @@ Fr host_pow_u64(const Fr& a, uint64_t e) {
 }
 
 int build_powers(zk_ctx* ctx, uint32_t** out, const Fr& base, const Fr& start, size_t n) {
-    ZK_HIP(ctx, hipMalloc((void**)out, n * 32));
+    ZK_HIP(ctx, hipMalloc((void**)out, n * 36));
     size_t threads = (n + 31) / 32;
     hipLaunchKernelGGL(k_powers, (unsigned)((threads + 255) / 256), 256, 0, ctx->stream, *out, to_frk(base), to_frk(start), n);
     ZK_HIP(ctx, hipGetLastError());
@@ -284,7 +381,7 @@ int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset
             uint32_t logE = log_n < 12 ? log_n : 12;      // tile elements = min(N, 4096)
             uint32_t logC = logE - logM;
             uint32_t E = 1u << logE;
-            uint32_t nt = E / 2 > 1024 ? 1024 : (E / 2 < 64 ? 64 : E / 2);
+            uint32_t nt = E / 4 > NTT_THREADS ? NTT_THREADS : (E / 4 < 64 ? 64 : E / 4);
             uint32_t tiles = 1u << (log_n - logE);
             const uint32_t* pre = (p == 0 && coset && !inverse) ? d->cos : nullptr;
             const uint32_t* src = (tmp && p > 0) ? tmp : data;
