@@ -183,6 +183,7 @@ int zk_fq_add(const zk_fq* a, const zk_fq* b, zk_fq* out);
 int zk_fq_sub(const zk_fq* a, const zk_fq* b, zk_fq* out);
 int zk_fq_mul(const zk_fq* a, const zk_fq* b, zk_fq* out);
 int zk_fq_neg5_almost_raw(const uint32_t a13[13], uint32_t out13[13]);   /* test hook: raw 29-bit limbs of k p - 5 a (fp29.cuh::fp_neg5_almost) */
+int zk_fr_lazy_raw(int op, const uint32_t* in9s, uint32_t* out9s);     /* test hook: the lazy Fr domain of the NTT butterflies (frlazy.cuh) on raw 29-bit limbs */
 int zk_fq_lazy_raw(int op, const uint32_t* in13s, uint32_t* out13s);   /* test hook: the lazy-domain primitives of fp29.cuh / ec.cuh on raw 29-bit limbs (hostapi.hip lists the ops) */
 int zk_fq_mul2(const zk_fq* a, const zk_fq* b, const zk_fq* c, const zk_fq* d, zk_fq* out);   /* a b + c d, the fused double product of the Fq2 multiplication */
 int zk_fr_inverse(const zk_fr* a, zk_fr* out);                    /* Field::inverse (macros.rs:389-443); error on zero */

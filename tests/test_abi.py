@@ -333,3 +333,133 @@ def test_lazy_madd_matches_the_group_law():
             acc = [to_int(pts[5][0]), to_int(pts[5][1]), to_int(1), to_int(1)]
         else:
             acc_pt, acc = want, vals                     # continue from the LAZY representative
+
+
+# ---- the lazy Fr domain of the NTT butterflies (csrc/frlazy.cuh) -----------------------------------------------------------
+RR = O.R_MOD
+RI9 = 1 << 261
+M29 = (1 << 29) - 1
+
+
+def _fr_lazy(op, *elems, n_out=1):
+    """elems: lists of nine u32 limbs (any limb width)."""
+    import ctypes as C
+    lib = Z.load()
+    inp = np.array([l for e in elems for l in e], dtype=np.uint32)
+    out = np.zeros(9 * n_out, dtype=np.uint32)
+    assert lib.zk_fr_lazy_raw(op, inp.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+    return [[int(x) for x in out[9 * k:9 * k + 9]] for k in range(n_out)]
+
+
+def _l9(v):
+    assert 0 <= v < RI9
+    return [(v >> (29 * i)) & M29 for i in range(9)]
+
+
+def _spread(v, rnd, limb_cap):
+    """The same value with limbs pushed above 29 bits where the value allows: limb i borrows from limb i + 1."""
+    l = _l9(v)
+    for i in range(8):
+        k = min(l[i + 1], (limb_cap - l[i]) >> 29)
+        k = rnd.randrange(k + 1) if k > 0 else 0
+        l[i] += k << 29
+        l[i + 1] -= k
+    assert sum(x << (29 * i) for i, x in enumerate(l)) == v and all(0 <= x < (1 << 32) for x in l)
+    return l
+
+
+def test_fr_lazy_domain_column_bounds():
+    """fp_mul_lazy<FrParams> with a wide left operand: the worst column of the product scanning (every limb of the data
+    operand at the largest value a butterfly can produce, 2^31.33 for s0 - s1 + 5r; twiddle limbs and Montgomery digits at
+    2^29 - 1) stays below 2^64, and the offsets of frl_sub dominate the limbs they are meant to absorb."""
+    pl = _l9(RR)
+    worst_a = (1 << 30) - 2 + max(int(x) for x in _fr_consts()["OFF5"][:8])          # s0_i + OFF5_i - 0
+    assert worst_a < 2 ** 31.34
+    carry, top = 0, 0
+    for k in range(17):
+        col = carry
+        for i in range(9):
+            if 0 <= k - i < 9:
+                col += worst_a * M29 + M29 * pl[k - i]
+        top = max(top, col)
+        carry = col >> 29
+    assert top < (1 << 64)
+    c = _fr_consts()
+    for name, K, j in (("OFF2", 2, 1), ("OFF3", 3, 1), ("OFF5", 5, 2)):
+        off = [int(x) for x in c[name]]
+        assert sum(x << (29 * i) for i, x in enumerate(off)) == K * RR
+        assert all(j << 29 <= x < (j + 1) << 29 for x in off[:8])
+    # top limbs: the subtrahend's top limb never exceeds the offset's (b < 1.03 r / 2.1 r / 4.2 r respectively)
+    assert c["OFF2"][8] >= (103 * RR // 100) >> 232 and c["OFF3"][8] >= (21 * RR // 10) >> 232 and c["OFF5"][8] >= (42 * RR // 10) >> 232
+    assert sum(int(x) << (29 * i) for i, x in enumerate(c["RC"])) == RI9 - RR and c["MQ"] == (1 << 264) // RR
+
+
+def _fr_consts():
+    src = open(os.path.join(os.path.dirname(__file__), "..", "zk-mpc_amd", "csrc", "consts.cuh")).read()
+    body = src[src.index("struct FrLazy"):]
+    body = body[:body.index("\n};")]
+    out = {}
+    for m in re.finditer(r"(\w+)\[9\] = \{([^}]*)\}", body):
+        out[m.group(1)] = [int(x.strip().rstrip("u"), 16) for x in m.group(2).split(",")]
+    out["MQ"] = int(re.search(r"MQ = (\d+)u", body).group(1))
+    return out
+
+
+def test_fr_lazy_primitives_against_big_integers():
+    """frl_reduce / frl_norm / frl_sub / frl_mul / frl_canon on raw limbs against Python integers: exact values where the
+    operation is exact, congruence and the stated range where it reduces; operands at the range ends and with limbs spread
+    above 29 bits."""
+    import random
+    rnd = random.Random(7)
+    inv = pow(RI9, -1, RR)
+    ends = [0, 1, RR - 1, RR, 2 * RR, 21 * RR // 10, 42 * RR // 10, 84 * RR // 10, 92 * RR // 10 - 1, 16 * RR, 438 * RR, RI9 - 1]
+    for v in ends + [rnd.randrange(RI9) for _ in range(200)] + [rnd.randrange(10 * RR) for _ in range(200)]:
+        for limbs in (_l9(v), _spread(v, rnd, (1 << 32) - (1 << 10))):
+            (r,) = _fr_lazy(0, limbs)
+            assert _val(r) % RR == v % RR and _val(r) < 113 * RR // 100 and all(x <= M29 for x in r)
+            (c,) = _fr_lazy(6, limbs)
+            assert _val(c) == v % RR and all(x <= M29 for x in c)
+        lim = _spread(v, rnd, (1 << 32) - 16)
+        (n,) = _fr_lazy(1, lim)
+        assert _val(n) == v and all(x <= M29 for x in n)
+    for op, K, bmax, blimb in ((2, 2, 103 * RR // 100, 1 << 29), (3, 3, 21 * RR // 10, 1 << 29), (4, 5, 42 * RR // 10, 1 << 30)):
+        for _ in range(300):
+            a = rnd.choice([0, RR, bmax - 1, rnd.randrange(bmax)])
+            b = rnd.choice([0, bmax - 1, rnd.randrange(bmax)])
+            la = _spread(a, rnd, blimb - 1) if blimb > (1 << 29) else _l9(a)
+            lb = _spread(b, rnd, blimb - 1) if blimb > (1 << 29) else _l9(b)
+            (r,) = _fr_lazy(op, la, lb)
+            assert _val(r) == a + K * RR - b and all(0 <= x < 2 ** 31.34 for x in r)
+    for _ in range(300):
+        a = rnd.choice([92 * RR // 10 - 1, RI9 - 1, rnd.randrange(RI9), rnd.randrange(10 * RR)])
+        w = rnd.choice([RR - 1, 1, rnd.randrange(RR)])
+        (r,) = _fr_lazy(5, _spread(a, rnd, int(2 ** 31.33)), _l9(w))
+        assert _val(r) % RR == a * w * inv % RR and _val(r) * RI9 < RR * (RI9 + a) and all(x <= M29 for x in r)
+
+
+def test_fr_lazy_butterflies():
+    """frl_radix4 / frl_radix2 (the sequences ntt.hip runs) against the two DIF levels of radix2/fft.rs:185-307 computed with
+    Python integers; inputs anywhere in the stage-input range (< 2.1 r), outputs back inside it."""
+    import random
+    rnd = random.Random(11)
+    inv = pow(RI9, -1, RR)
+    hi = 21 * RR // 10
+    for it in range(300):
+        xs = [rnd.choice([0, hi - 1, RR, rnd.randrange(hi)]) for _ in range(4)]
+        wa, wb, wc = [rnd.choice([RR - 1, rnd.randrange(RR)]) for _ in range(3)]
+        m = lambda a, w: a * w * inv % RR
+        want = [(xs[0] + xs[1] + xs[2] + xs[3]) % RR,
+                m(xs[0] + xs[2] - xs[1] - xs[3], wc),
+                (m(xs[0] - xs[2], wa) + m(xs[1] - xs[3], wb)) % RR,
+                m(m(xs[0] - xs[2], wa) - m(xs[1] - xs[3], wb), wc)]
+        ys = _fr_lazy(7, *[_l9(x) for x in xs], _l9(wa), _l9(wb), _l9(wc), n_out=4)
+        assert [_val(y) % RR for y in ys] == want
+        assert all(_val(y) < hi and all(l <= M29 for l in y) for y in ys)
+        # last stage: second-level twiddle 1, outputs stay wide (< 9.2 r, limbs < 2^31.34) for the product that follows
+        ys = _fr_lazy(8, *[_l9(x) for x in xs], _l9(wa), _l9(wb), _l9(wc), n_out=4)
+        want1 = [want[0], (xs[0] + xs[2] - xs[1] - xs[3]) % RR, want[2], (m(xs[0] - xs[2], wa) - m(xs[1] - xs[3], wb)) % RR]
+        assert [_val(y) % RR for y in ys] == want1
+        assert all(_val(y) < 92 * RR // 10 and all(l < 2 ** 31.34 for l in y) for y in ys)
+        y2 = _fr_lazy(9, _l9(xs[0]), _l9(xs[1]), _l9(wa), n_out=2)
+        assert [_val(y) % RR for y in y2] == [(xs[0] + xs[1]) % RR, m(xs[0] - xs[1], wa)]
+        assert all(_val(y) < 113 * RR // 100 and all(l <= M29 for l in y) for y in y2)

@@ -134,6 +134,7 @@ PROTOTYPES = {
     "zk_fq_mul2": (_I, [_P, _P, _P, _P, _P]),
     "zk_fq_neg5_almost_raw": (_I, [_P, _P]),
     "zk_fq_lazy_raw": (_I, [_I, _P, _P]),
+    "zk_fr_lazy_raw": (_I, [_I, _P, _P]),
     "zk_fr_from_canonical": (_I, [_P, _P]),
     "zk_fr_to_canonical": (_I, [_P, _P]),
     "zk_r1cs_upload": (_I, [_P, _P, C.POINTER(_P)]),

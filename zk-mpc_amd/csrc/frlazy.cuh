@@ -2,7 +2,7 @@
 //
 // The butterflies of Radix2EvaluationDomain::{fft,ifft}_in_place (arkworks/algebra/poly/src/domain/radix2/fft.rs:185-307)
 // are x' = x + y, y' = (x - y) w with every sum, difference and product brought back below r.  r = 0.002 * 2^261, so nine
-// 29-bit limbs have 8.8 bits of head room (2^261 / r = 445.5) and almost all of those reductions can go:
+// 29-bit limbs have 8.8 bits of head room (2^261 / r = 438.8) and almost all of those reductions can go:
 //   * sums are nine limb-wise additions, no carry pass (limbs may grow to 2^31.4: the products take any u32 limb as long as
 //     a column of the product stays below 2^64 -- tests/test_abi.py::test_fr_lazy_domain recomputes the worst column);
 //   * differences add a multiple of r written so that no limb can go negative (FrLazy::OFF*): nine add-subs, no borrow;
@@ -19,8 +19,9 @@
 //   y1 = (s0 - s1 + 5r) wc                      < 1.03 r  / < 2^29        (operand < 9.2 r, limbs < 2^31.33)
 //   y2 = norm(d0 + d1)                          < 2.04 r  / < 2^29
 //   y3 = (d0 - d1 + 2r) wc                      < 1.01 r  / < 2^29        (operand < 3.1 r, limbs < 2^30.6)
-// so every output is again < 2.1 r with limbs < 2^29.  In the last stage of a pass wc = 1: y1 and y3 stay unmultiplied (wide
-// limbs) and go straight into the product that follows (the inter-pass twiddle, the post-scale) or into frl_canon.
+// so every output is again < 2.1 r with limbs < 2^29.  In the last stage of a pass wc = 1: all four outputs stay as they are
+// (wide limbs, < 9.2 r) and go straight into the product that follows (the inter-pass twiddle, the post-scale) or into
+// frl_canon.
 #pragma once
 #include "fp29.cuh"
 
@@ -86,7 +87,9 @@ ZK_HD Fr frl_canon(const Fr& a) {
 
 // Two DIF levels on (x0, x1, x2, x3) = the elements at m, m + g/2, m + g, m + 3g/2 (g = the gap of the first level):
 // wa, wb = the first level's twiddles of the pairs (x0, x2) and (x1, x3) (wb = wa * w^(N/4)), wc = the second level's twiddle of
-// both of its pairs (wa^2).  MUL_B false: the second level's twiddle is 1 and y1, y3 are left as wide sums (see the header).
+// both of its pairs (wa^2).  MUL_B false: the second level's twiddle is 1 and all four outputs are left as wide sums (a
+// product or frl_canon follows).  ntt.hip::radix4_item is this sequence with its loads and stores placed in between (register
+// pressure); this form is what the host-side test drives (hostapi.hip::zk_fr_lazy_raw).
 template <bool MUL_B>
 ZK_HD void frl_radix4(Fr& x0, Fr& x1, Fr& x2, Fr& x3, const Fr& wa, const Fr& wb, const Fr& wc) {
     const Fr s0 = frl_add(x0, x2), s1 = frl_add(x1, x3);

@@ -96,7 +96,7 @@ def sub_offset(p, L, K, j):
 
 
 def fr_lazy():
-    """Constants of the lazy Fr domain of the NTT butterflies (frlazy.cuh): 2^261 / r = 445.5 leaves 8.8 bits of head room."""
+    """Constants of the lazy Fr domain of the NTT butterflies (frlazy.cuh): 2^261 / r = 438.8 leaves 8.8 bits of head room."""
     L = 9
     out = ["struct FrLazy {"]
     out.append(arr("RC", (1 << (B * L)) - R_MOD, L, "2^261 - r: a + q RC = (a - q r) + q 2^261"))

@@ -5,6 +5,7 @@
 #include "../../include/zkmpc_hip.h"
 #include "hostgroup.hpp"
 #include "hostfield64.hpp"
+#include "frlazy.cuh"
 
 using namespace zk;
 
@@ -179,6 +180,38 @@ extern "C" int zk_fq_lazy_raw(int op, const uint32_t* in, uint32_t* out) {
             st(0, r.x); st(1, r.y); st(2, r.zz); st(3, r.zzz);
             XYZZ<F> c = xyzz_canon_lazy<F>(r);
             st(4, c.x); st(5, c.y); st(6, c.zz); st(7, c.zzz);
+            break;
+        }
+        default: return ZK_ERR_ARG;
+    }
+    return ZK_OK;
+}
+// Test hook for the lazy Fr domain of the NTT butterflies (frlazy.cuh): raw limbs in (9 words per element, any u32), raw
+// limbs out.  op 0: reduce(a)  1: norm(a)  2..4: sub<2|3|5>(a, b)  5: mul(a, w)  6: canon(a)
+// 7 / 8: radix4<true|false>(x0..x3, wa, wb, wc) -> 4 elements  9: radix2(x0, x1, w) -> 2 elements
+extern "C" int zk_fr_lazy_raw(int op, const uint32_t* in, uint32_t* out) {
+    if (!in || !out) return ZK_ERR_ARG;
+    auto ld = [&](int k) { Fr a; for (int i = 0; i < 9; i++) a.l[i] = in[9 * k + i]; return a; };
+    auto st = [&](int k, const Fr& a) { for (int i = 0; i < 9; i++) out[9 * k + i] = a.l[i]; };
+    switch (op) {
+        case 0: st(0, frl_reduce(ld(0))); break;
+        case 1: st(0, frl_norm(ld(0))); break;
+        case 2: st(0, frl_sub<2>(ld(0), ld(1))); break;
+        case 3: st(0, frl_sub<3>(ld(0), ld(1))); break;
+        case 4: st(0, frl_sub<5>(ld(0), ld(1))); break;
+        case 5: st(0, frl_mul(ld(0), ld(1))); break;
+        case 6: st(0, frl_canon(ld(0))); break;
+        case 7: case 8: {
+            Fr x0 = ld(0), x1 = ld(1), x2 = ld(2), x3 = ld(3);
+            if (op == 7) frl_radix4<true>(x0, x1, x2, x3, ld(4), ld(5), ld(6));
+            else frl_radix4<false>(x0, x1, x2, x3, ld(4), ld(5), ld(6));
+            st(0, x0); st(1, x1); st(2, x2); st(3, x3);
+            break;
+        }
+        case 9: {
+            Fr x0 = ld(0), x1 = ld(1);
+            frl_radix2(x0, x1, ld(2));
+            st(0, x0); st(1, x1);
             break;
         }
         default: return ZK_ERR_ARG;

@@ -216,7 +216,11 @@ k_ntt_pass(const uint32_t* data, uint32_t* out, const uint32_t* __restrict__ tw,
     const uint32_t C = 1u << logC, E = C << logM;
     const uint32_t N1 = (1u << log_n) - 1;
     const uint32_t tid = threadIdx.x, NT = blockDim.x;
-    const PassIO<POST> io{data, out, tw, pre, post, log_n, logS, logM, logS + logM, N1, blockIdx.x << logC, inverse, final_rev};
+    // neighbouring tiles share cache lines when C * 32 B < 128 B: blocks are dealt round-robin over the 8 XCDs, so block b takes
+    // tile (b % 8) * (tiles / 8) + b / 8 -- the tiles of one line then sit on one XCD (one L2), next to each other in time
+    uint32_t tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const PassIO<POST> io{data, out, tw, pre, post, log_n, logS, logM, logS + logM, N1, tile << logC, inverse, final_rev};
     const uint32_t tsh = log_n - logM;
     const uint32_t nst = (logM + 1) >> 1;       // stages: the last one stores to global memory, the first one loads from it
     uint32_t s = 0, stage = 0;
@@ -378,7 +382,18 @@ int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset
         for (uint32_t p = 0; p < passes; p++) {
             uint32_t logM = base + (p < extra ? 1 : 0);
             uint32_t logS = remaining - logM;
-            uint32_t logE = log_n < 12 ? log_n : 12;      // tile elements = min(N, 4096)
+            // tile elements: 4096 for large transforms; small ones are cut into >= 256 tiles so that every CU gets work (a
+            // thread runs one radix-4 butterfly per stage either way; one wave alone issues a multiply-add every ~10 cycles,
+            // so a pass takes the same ~20 us whether a CU hosts one wave or four -- tools/ubench_chain.hip)
+            // Three-pass transforms (N > 2^20) run 1024-element tiles (four independent blocks per CU: one block's loads and
+            // stores run under the others' butterflies; 2^24: 2.8 -> 2.2 ms); 10-level passes need 4096 to keep 128-B runs.
+            uint32_t logE = log_n < 20 ? (log_n > 8 ? log_n - 8 : 0) : (passes >= 3 ? 10 : 12);
+            if (logE < base + (extra ? 1 : 0)) logE = base + (extra ? 1 : 0);
+            if (passes == 1) logE = log_n;
+            if (const char* ev = getenv("ZK_NTT_LOGE")) {      // experiment knob
+                const uint32_t v = (uint32_t)atoi(ev);
+                if (passes > 1 && v >= base + (extra ? 1 : 0) && v <= 12 && v <= log_n) logE = v;
+            }
             uint32_t logC = logE - logM;
             uint32_t E = 1u << logE;
             uint32_t nt = E / 4 > NTT_THREADS ? NTT_THREADS : (E / 4 < 64 ? 64 : E / 4);
