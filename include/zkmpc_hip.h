@@ -285,6 +285,10 @@ int zk_fr_powers_dev(zk_ctx* ctx, const zk_fr* base, const zk_fr* start, size_t 
 int zk_fr_batch_inverse_dev(zk_ctx* ctx, void* v_dev, size_t n);
 /* DensePolynomial::evaluate (poly/src/polynomial/univariate/dense.rs:53-75); n coefficients, low degree first. */
 int zk_poly_evaluate_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, const zk_fr* point, zk_fr* out);
+/* The same for `count` (polynomial, point) pairs in two launches and one copy back: out[i] = polys[i](points[i]).  What
+ * Marlin::prove's evaluation step (marlin/src/lib.rs:262-292: every polynomial of the query set at beta or gamma) calls. */
+typedef struct { const void* ptr; size_t n; } zk_poly_ref;   /* device coefficients, low degree first */
+int zk_poly_evaluate_batch_dev(zk_ctx* ctx, const zk_poly_ref* polys, const zk_fr* points, size_t count, zk_fr* out);
 /* p / (X - z): quotient (n-1 coefficients) and remainder p(z) (KZG10::compute_witness_polynomial, kzg10/mod.rs:212-235). */
 int zk_poly_divide_by_linear_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, const zk_fr* z, void* q_dev, zk_fr* rem);
 /* DensePolynomial::divide_by_vanishing_poly for the radix-2 domain of size 2^log_domain (dense.rs:166-173):
@@ -332,7 +336,6 @@ int zk_marlin_round3_ab_evals_dev(zk_ctx* ctx, const zk_marlin_matrix_evals on_b
  * different stream: 0.4 s of scalar ChaCha at 2^20 otherwise).  The proof is written in CanonicalSerialize form
  * (marlin/src/data_structures.rs:99-110); cap must be >= zk_marlin_proof_max_size().  Errors: an unsatisfied system fails
  * the outer sum-check (ZK_ERR_STATE), as the reference's assertions do. */
-typedef struct { const void* ptr; size_t n; } zk_poly_ref;
 typedef struct {
     size_t num_constraints, num_variables, num_non_zero, num_instance;
     const zk_r1cs* r1cs;

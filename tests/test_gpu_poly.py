@@ -30,6 +30,33 @@ def test_evaluate_and_divide_by_linear(ctx, n):
             assert wr == [O.poly_evaluate(c, z)]
 
 
+def test_evaluate_batch(ctx):
+    """zk_poly_evaluate_batch_dev: pairs of different lengths (incl. empty, one coefficient, spans that end on a block edge,
+    more than 256 spans so that the join folds several per thread) and different points, one call."""
+    rng = O.Prng(3100)
+    sizes = [0, 1, 15, 16, 17, 4095, 4096, 4097, 8192, 70001, (1 << 20) + 4097 + 5]
+    polys, cs, pts = [], [], []
+    keep = []
+    for n in sizes:
+        c = [rng.fr() for _ in range(min(n, 70001))]
+        if n > len(c):                      # long one: a short random head, zeros, a random tail (Horner in python stays cheap)
+            c = c[:300] + [0] * (n - 600) + c[300:600]
+        d = up(ctx, c)
+        keep.append(d)
+        polys.append((d.ptr, n))
+        cs.append(c)
+        pts.append(rng.fr() if n != 16 else 0)
+    out = ctx.poly_evaluate_batch_dev(polys, cv.fr_to_mont(pts))
+    got = cv.fr_from_mont(out)
+
+    def horner(c, z):
+        acc, i = 0, len(c)
+        nz = [(j, v) for j, v in enumerate(c) if v]
+        return sum(v * pow(z, j, O.R_MOD) for j, v in nz) % O.R_MOD
+    assert got == [horner(c, z) for c, z in zip(cs, pts)]
+    assert ctx.poly_evaluate_batch_dev([], np.zeros((0, 4), dtype=np.uint64)).shape == (0, 4)
+
+
 def test_divide_by_root_of_domain(ctx):
     """z inside the evaluation domain (where an evaluate-and-interpolate division would divide by zero)."""
     rng = O.Prng(31)

@@ -165,6 +165,7 @@ PROTOTYPES = {
     "zk_fr_powers_dev": (_I, [_P, _P, _P, _SZ, _P]),
     "zk_fr_batch_inverse_dev": (_I, [_P, _P, _SZ]),
     "zk_poly_evaluate_dev": (_I, [_P, _P, _SZ, _P, _P]),
+    "zk_poly_evaluate_batch_dev": (_I, [_P, _P, _P, _SZ, _P]),
     "zk_poly_divide_by_linear_dev": (_I, [_P, _P, _SZ, _P, _P, _P]),
     "zk_poly_divide_by_vanishing_dev": (_I, [_P, _P, _SZ, _U32, _P, _P]),
     "zk_poly_mul_dev": (_I, [_P, _P, _SZ, _P, _SZ, _P]),

@@ -330,6 +330,18 @@ class Context:
         self._ck(self.lib.zk_poly_evaluate_dev(self.h, C.c_void_p(int(coeffs)), n, C.byref(pt), _ptr(out)))
         return out
 
+    def poly_evaluate_batch_dev(self, polys, points4) -> np.ndarray:
+        """polys: [(device pointer, n)], points4: (count, 4) u64 -> (count, 4) u64; two launches and one copy back for all."""
+        from ._lib import PolyRef
+        k = len(polys)
+        refs = (PolyRef * max(k, 1))()
+        for i, (ptr, n) in enumerate(polys):
+            refs[i].ptr, refs[i].n = int(ptr), int(n)
+        pts = np.ascontiguousarray(np.asarray(points4, dtype=np.uint64).reshape(k, 4))
+        out = np.zeros((k, 4), dtype=np.uint64)
+        self._ck(self.lib.zk_poly_evaluate_batch_dev(self.h, refs, _ptr(pts), k, _ptr(out)))
+        return out
+
     def poly_divide_by_linear_dev(self, coeffs, n: int, z4, q):
         z = _fr_struct(z4)
         rem = np.zeros(4, dtype=np.uint64)

@@ -398,14 +398,28 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
 
     // =========================== evaluations and linear combinations ===========================
     std::map<std::string, HF> single;
-    single["z_b"] = P.eval(P.polys["z_b"], beta); single["g_1"] = P.eval(P.polys["g_1"], beta);
-    single["t"] = P.eval(P.polys["t"], beta); single["g_2"] = P.eval(P.polys["g_2"], gamma);
-    const HF ba = beta * alpha;
-    for (const char* m : {"a", "b", "c"}) {
-        const std::string s(m);
-        single[s + "_denom"] = ba - alpha * P.eval(P.polys[s + "_row"], gamma) - beta * P.eval(P.polys[s + "_col"], gamma) +
-                               P.eval(P.polys[s + "_row_col"], gamma);
+    {   // the thirteen evaluations of the query set in one batch (two launches, one copy back)
+        std::vector<std::pair<std::string, HF>> want = {{"z_b", beta}, {"g_1", beta}, {"t", beta}, {"g_2", gamma}};
+        for (const char* m : {"a", "b", "c"})
+            for (const char* part : {"_row", "_col", "_row_col"}) want.push_back({std::string(m) + part, gamma});
+        std::vector<zk_poly_ref> refs;
+        std::vector<zk_fr> pts(want.size()), vals(want.size());
+        for (size_t i = 0; i < want.size(); i++) {
+            const Poly& p = P.polys[want[i].first];
+            refs.push_back(zk_poly_ref{p.p, p.n});
+            pts[i] = want[i].second.abi();
+        }
+        ZK_TRY(zk_poly_evaluate_batch_dev(ctx, refs.data(), pts.data(), want.size(), vals.data()));
+        std::map<std::string, HF> at;
+        for (size_t i = 0; i < want.size(); i++) at[want[i].first] = HF::from_abi(vals[i]);
+        for (const char* l : {"z_b", "g_1", "t", "g_2"}) single[l] = at[l];
+        const HF ba0 = beta * alpha;
+        for (const char* m : {"a", "b", "c"}) {
+            const std::string s(m);
+            single[s + "_denom"] = ba0 - alpha * at[s + "_row"] - beta * at[s + "_col"] + at[s + "_row_col"];
+        }
     }
+    const HF ba = beta * alpha;
     ZK_TRY(P.rc);
     // construct_linear_combinations (ahp/mod.rs:112-290)
     const HF v_h_beta = H.vanishing(beta), v_x_beta = beta.pow(ni) - one;

@@ -183,6 +183,70 @@ int solve_recurrence(zk_ctx* ctx, const void* c, size_t n, const Fr& z, void* ou
     return ZK_OK;
 }
 
+// ---- batched evaluation: any number of (polynomial, point) pairs in two launches and one copy back --------------------------
+// Stage 1: a block owns a span of 256 x EV_CH coefficients of one polynomial; a thread folds EV_CH of them by Horner, the
+// block combines its 256 chunk values by a tree (level l multiplies the right-hand neighbour by z^(EV_CH 2^l)) into the value
+// of the span's own polynomial at z.  Stage 2: one block per polynomial folds R consecutive span values per thread with the
+// multiplier z^SPAN and combines the 256 results the same way.  Depth: EV_CH + 8 + R + 8 dependent multiply-adds (~60 us)
+// whatever the number of pairs; the recursive scan above needs three to six launches and a host round trip per polynomial.
+constexpr int EV_CH = 16;
+constexpr int EV_SPAN = 256 * EV_CH;
+struct EvalJob {
+    const void* c;
+    size_t n;
+    uint32_t first_block, nblocks, R, pad;
+    uint32_t z[9], lvl1[8][9], zspan[9], lvl2[8][9];       // internal form
+};
+__device__ __forceinline__ Fr limbs9(const uint32_t* l) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = l[i];
+    return r;
+}
+// h[0] <- sum_t h[t] * base^t over the 256 values of the block, base^(2^l) given as lvl[l]
+__device__ __forceinline__ Fr block_power_tree(uint32_t (*lds)[256], const uint32_t (*lvl)[9], Fr v) {
+    const uint32_t tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 9; k++) lds[k][tid] = v.l[k];
+    __syncthreads();
+    for (int l = 0; l < 8; l++) {
+        const uint32_t d = 1u << l;
+        if ((tid & (2 * d - 1)) == 0) {
+            Fr r;
+#pragma unroll
+            for (int k = 0; k < 9; k++) r.l[k] = lds[k][tid + d];
+            v = fr_add(v, fr_mul(r, limbs9(lvl[l])));
+#pragma unroll
+            for (int k = 0; k < 9; k++) lds[k][tid] = v.l[k];
+        }
+        __syncthreads();
+    }
+    return v;
+}
+__global__ void __launch_bounds__(256) k_eval_spans(const EvalJob* jobs, uint32_t njobs, void* partial) {
+    __shared__ uint32_t lds[9][256];
+    uint32_t j = 0;
+    while (j + 1 < njobs && jobs[j + 1].first_block <= blockIdx.x) j++;
+    const EvalJob& J = jobs[j];
+    const Fr z = limbs9(J.z);
+    const size_t lo = ((size_t)(blockIdx.x - J.first_block) * 256 + threadIdx.x) * EV_CH;
+    const size_t hi = lo + EV_CH < J.n ? lo + EV_CH : J.n;
+    Fr acc = fp_zero<FrParams>();
+    for (size_t i = hi; i > lo; i--) acc = fr_add(fr_mul(acc, z), fr_load(J.c, i - 1));
+    acc = block_power_tree(lds, J.lvl1, acc);
+    if (threadIdx.x == 0) fr_store(partial, blockIdx.x, acc);
+}
+__global__ void __launch_bounds__(256) k_eval_join(const EvalJob* jobs, const void* partial, void* out) {
+    __shared__ uint32_t lds[9][256];
+    const EvalJob& J = jobs[blockIdx.x];
+    const Fr zs = limbs9(J.zspan);
+    const size_t lo = (size_t)threadIdx.x * J.R, hi = lo + J.R < J.nblocks ? lo + J.R : J.nblocks;
+    Fr acc = fp_zero<FrParams>();
+    for (size_t i = hi; i > lo; i--) acc = fr_add(fr_mul(acc, zs), fr_load(partial, J.first_block + i - 1));
+    acc = block_power_tree(lds, J.lvl2, acc);
+    if (threadIdx.x == 0) fr_store(out, blockIdx.x, acc);
+}
+
 }  // namespace
 
 extern "C" int zk_fr_powers_dev(zk_ctx* ctx, const zk_fr* base, const zk_fr* start, size_t n, void* out_dev) {
@@ -208,12 +272,53 @@ extern "C" int zk_fr_batch_inverse_dev(zk_ctx* ctx, void* v_dev, size_t n) {
     return ZK_OK;
 }
 
+// DensePolynomial::evaluate for `count` (polynomial, point) pairs at once: out[i] = polys[i](points[i]).
+extern "C" int zk_poly_evaluate_batch_dev(zk_ctx* ctx, const zk_poly_ref* polys, const zk_fr* points, size_t count, zk_fr* out) {
+    if (!ctx || (count && (!polys || !points || !out))) return ZK_ERR_ARG;
+    if (!count) return ZK_OK;
+    std::vector<EvalJob> jobs(count);
+    uint32_t blocks = 0;
+    for (size_t i = 0; i < count; i++) {
+        if (polys[i].n && !polys[i].ptr) return ZK_ERR_ARG;
+        EvalJob& J = jobs[i];
+        J.c = polys[i].ptr;
+        J.n = polys[i].n;
+        J.first_block = blocks;
+        J.nblocks = (uint32_t)((polys[i].n + EV_SPAN - 1) / EV_SPAN);
+        if (!J.nblocks) J.nblocks = 1;
+        J.R = (J.nblocks + 255) / 256;
+        J.pad = 0;
+        blocks += J.nblocks;
+        const Fr z = host_int(&points[i]);
+        auto put = [](uint32_t* d, const Fr& v) { for (int k = 0; k < 9; k++) d[k] = v.l[k]; };
+        put(J.z, z);
+        Fr p = host_pow(z, EV_CH);
+        for (int l = 0; l < 8; l++) { put(J.lvl1[l], p); p = fp_sqr<FrParams>(p); }     // p ends as z^(EV_CH * 256) = z^SPAN
+        put(J.zspan, p);
+        p = host_pow(p, J.R);
+        for (int l = 0; l < 8; l++) { put(J.lvl2[l], p); p = fp_sqr<FrParams>(p); }
+    }
+    char* scr;
+    const size_t jobs_bytes = (count * sizeof(EvalJob) + 255) & ~(size_t)255;
+    ZK_TRY(zk_scratch(ctx, "poly_eval_batch", jobs_bytes + (size_t)blocks * 32 + count * 32, (void**)&scr));
+    void* partial = scr + jobs_bytes;
+    void* res = scr + jobs_bytes + (size_t)blocks * 32;
+    ZK_HIP(ctx, hipMemcpyAsync(scr, jobs.data(), count * sizeof(EvalJob), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_eval_spans, blocks, 256, 0, ctx->stream, (const EvalJob*)scr, (uint32_t)count, partial);
+    hipLaunchKernelGGL(k_eval_join, (unsigned)count, 256, 0, ctx->stream, (const EvalJob*)scr, (const void*)partial, res);
+    ZK_HIP(ctx, hipGetLastError());
+    std::vector<uint32_t> w(count * 8);
+    ZK_HIP(ctx, hipMemcpyAsync(w.data(), res, count * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // also keeps `jobs` alive until the upload has been consumed
+    for (size_t i = 0; i < count; i++)
+        for (int k = 0; k < 4; k++) out[i].l[k] = (uint64_t)w[8 * i + 2 * k] | ((uint64_t)w[8 * i + 2 * k + 1] << 32);
+    return ZK_OK;
+}
+
 extern "C" int zk_poly_evaluate_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, const zk_fr* point, zk_fr* out) {
     if (!ctx || !point || !out || (n && !coeffs_dev)) return ZK_ERR_ARG;
-    Fr q0;
-    ZK_TRY(solve_recurrence(ctx, coeffs_dev, n, host_int(point), nullptr, 0, &q0, 0));
-    host_store_ext<FrParams>(out->l, fp_int_to_ext<FrParams>(q0));
-    return ZK_OK;
+    const zk_poly_ref p{coeffs_dev, n};
+    return zk_poly_evaluate_batch_dev(ctx, &p, point, 1, out);
 }
 
 extern "C" int zk_poly_divide_by_linear_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, const zk_fr* z, void* q_dev, zk_fr* rem) {
