@@ -14,9 +14,10 @@
 // form, so data * constant needs a single Montgomery product (fp29.cuh header).
 //
 // Horner and synthetic division are first-order linear recurrences Q_j = c_j + z * Q_{j+1}.  They are solved as a
-// two-level scan: every thread folds a chunk of 64 coefficients (giving the chunk's value for carry-in 0), the
-// chunk heads obey the same recurrence with multiplier z^64 and are solved recursively, then every thread replays
-// its chunk from the now-known carry-in.  2n products, fully coalesced-by-chunk traffic, HBM-light.
+// three-level scan: every thread folds a chunk of 16 coefficients (the chunk's value for carry-in 0), a block combines its
+// 256 chunks in LDS with the powers z^(16 2^l), one block combines the spans with the powers of z^4096; the division then
+// replays every chunk from its now-known carry-in.  2n (evaluation: n) products, coalesced-by-chunk traffic, two or three
+// launches of fixed depth (~60 dependent multiply-adds) whatever n.
 #include "../../include/zkmpc_hip.h"
 #include "devutil.cuh"
 #include "hostgroup.hpp"
@@ -27,7 +28,6 @@ using namespace zk;
 
 namespace {
 
-constexpr int CH = 64;       // recurrence chunk per thread
 constexpr int INV_CH = 32;   // batch-inversion chunk per thread
 
 struct FrK { uint32_t l[9]; };
@@ -51,31 +51,6 @@ Fr host_pow(const Fr& a, uint64_t e) {
         if ((e >> b) & 1) { r = started ? fp_mul<FrParams>(r, a) : a; started = true; }
     }
     return r;
-}
-
-// heads[t] = sum_{j < CH} c[t*CH + j] * z^j   (chunk value for carry-in 0)
-__global__ void __launch_bounds__(256) k_chunk_heads(const void* c, size_t n, FrK zk_, void* heads, size_t m) {
-    const Fr z = frk(zk_);
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < m; t += (size_t)gridDim.x * blockDim.x) {
-        size_t lo = t * CH, hi = lo + CH < n ? lo + CH : n;
-        Fr acc = fp_zero<FrParams>();
-        for (size_t j = hi; j-- > lo;) acc = fr_add(fr_mul(acc, z), fr_load(c, j));
-        fr_store(heads, t, acc);
-    }
-}
-
-// Q_j = c_j + z * Q_{j+1} inside chunk t with carry-in H[t+1] (0 for the last chunk).  Writes Q_j to out[j + shift]
-// for j + shift >= 0 (shift = -1 drops Q_0, the remainder, and yields the quotient of the division by X - z).
-__global__ void __launch_bounds__(256) k_chunk_fill(const void* c, size_t n, FrK zk_, const void* H, size_t m, void* out, int shift) {
-    const Fr z = frk(zk_);
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < m; t += (size_t)gridDim.x * blockDim.x) {
-        size_t lo = t * CH, hi = lo + CH < n ? lo + CH : n;
-        Fr acc = (t + 1 < m) ? fr_load(H, t + 1) : fp_zero<FrParams>();
-        for (size_t j = hi; j-- > lo;) {
-            acc = fr_add(fr_mul(acc, z), fr_load(c, j));
-            if ((long long)j + shift >= 0) fr_store(out, (size_t)((long long)j + shift), acc);
-        }
-    }
 }
 
 // Division by X^N - 1: with the coefficients viewed as an m x N row-major matrix (row k = c[kN .. kN+N-1]) the quotient
@@ -151,38 +126,6 @@ __global__ void __launch_bounds__(256) k_powers(void* out, FrK base_k, FrK start
     }
 }
 
-// Solves Q_j = c_j + z Q_{j+1} (Q_n = 0).  If out != null writes Q_j to out[j + shift]; returns Q_0 in *q0.
-int solve_recurrence(zk_ctx* ctx, const void* c, size_t n, const Fr& z, void* out, int shift, Fr* q0, int depth) {
-    if (n == 0) { *q0 = fp_zero<FrParams>(); return ZK_OK; }
-    const size_t m = (n + CH - 1) / CH;
-    char name[48];
-    snprintf(name, sizeof name, "poly_heads.%d", depth);
-    void* heads;
-    ZK_TRY(zk_scratch(ctx, name, m * 32 + 32, &heads));
-    hipLaunchKernelGGL(k_chunk_heads, zk_grid(m, 256), 256, 0, ctx->stream, c, n, to_frk(z), heads, m);
-    ZK_HIP(ctx, hipGetLastError());
-    void* H = nullptr;
-    if (m > 1) {
-        snprintf(name, sizeof name, "poly_H.%d", depth);
-        ZK_TRY(zk_scratch(ctx, name, m * 32 + 32, &H));
-        Fr zc = host_pow(z, CH);
-        Fr dummy;
-        ZK_TRY(solve_recurrence(ctx, heads, m, zc, H, 0, &dummy, depth + 1));   // H[t] = Q_{t*CH}
-        if (q0) *q0 = dummy;
-    } else {
-        H = heads;
-        uint32_t w[8];
-        ZK_HIP(ctx, hipMemcpyAsync(w, heads, 32, hipMemcpyDeviceToHost, ctx->stream));
-        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (q0) *q0 = fp_ext_to_int<FrParams>(fp_unpack<FrParams>(w));
-    }
-    if (out) {
-        hipLaunchKernelGGL(k_chunk_fill, zk_grid(m, 256), 256, 0, ctx->stream, c, n, to_frk(z), H, m, out, shift);
-        ZK_HIP(ctx, hipGetLastError());
-    }
-    return ZK_OK;
-}
-
 // ---- batched evaluation: any number of (polynomial, point) pairs in two launches and one copy back --------------------------
 // Stage 1: a block owns a span of 256 x EV_CH coefficients of one polynomial; a thread folds EV_CH of them by Horner, the
 // block combines its 256 chunk values by a tree (level l multiplies the right-hand neighbour by z^(EV_CH 2^l)) into the value
@@ -223,11 +166,8 @@ __device__ __forceinline__ Fr block_power_tree(uint32_t (*lds)[256], const uint3
     }
     return v;
 }
-__global__ void __launch_bounds__(256) k_eval_spans(const EvalJob* jobs, uint32_t njobs, void* partial) {
+__device__ __forceinline__ void eval_span(const EvalJob& J, void* partial) {
     __shared__ uint32_t lds[9][256];
-    uint32_t j = 0;
-    while (j + 1 < njobs && jobs[j + 1].first_block <= blockIdx.x) j++;
-    const EvalJob& J = jobs[j];
     const Fr z = limbs9(J.z);
     const size_t lo = ((size_t)(blockIdx.x - J.first_block) * 256 + threadIdx.x) * EV_CH;
     const size_t hi = lo + EV_CH < J.n ? lo + EV_CH : J.n;
@@ -236,6 +176,12 @@ __global__ void __launch_bounds__(256) k_eval_spans(const EvalJob* jobs, uint32_
     acc = block_power_tree(lds, J.lvl1, acc);
     if (threadIdx.x == 0) fr_store(partial, blockIdx.x, acc);
 }
+__global__ void __launch_bounds__(256) k_eval_spans(const EvalJob* jobs, uint32_t njobs, void* partial) {
+    uint32_t j = 0;
+    while (j + 1 < njobs && jobs[j + 1].first_block <= blockIdx.x) j++;
+    eval_span(jobs[j], partial);
+}
+__global__ void __launch_bounds__(256) k_eval_spans1(const EvalJob J, void* partial) { eval_span(J, partial); }    // one job, by value
 __global__ void __launch_bounds__(256) k_eval_join(const EvalJob* jobs, const void* partial, void* out) {
     __shared__ uint32_t lds[9][256];
     const EvalJob& J = jobs[blockIdx.x];
@@ -245,6 +191,77 @@ __global__ void __launch_bounds__(256) k_eval_join(const EvalJob* jobs, const vo
     for (size_t i = hi; i > lo; i--) acc = fr_add(fr_mul(acc, zs), fr_load(partial, J.first_block + i - 1));
     acc = block_power_tree(lds, J.lvl2, acc);
     if (threadIdx.x == 0) fr_store(out, blockIdx.x, acc);
+}
+
+// ---- division by X - z: the same recurrence with every Q_j written out, three launches, no host round trip ----------------
+// Q_j = c_j + z Q_{j+1} (Q_n = 0); the quotient is Q_1 .. Q_{n-1}, the remainder Q_0 = p(z).  k_eval_spans gives every
+// span's own value; k_span_carries turns them into every span's carry-in Q_{(b+1) SPAN} (a suffix scan over the spans with the
+// multiplier z^SPAN: R spans per thread, Hillis-Steele over the 256 threads, replay) and the remainder; k_fill_spans redoes the
+// chunk values of a span, scans them with its carry-in and replays every chunk from its now-known carry-in, writing Q_j to
+// out[j + shift].  Depth ~ 2 EV_CH + 2 R + 3 * 8 multiply-adds (the recursive form this replaces: 3 x 64 per level, 3 to 4
+// levels, and a copy to the host at the bottom).
+// inclusive suffix scan over the block: returns I_t = sum_{u >= t} v_u M^(u - t), M^(2^l) = lvl[l]; buf: 2 x 9 x 256 words
+__device__ __forceinline__ Fr block_suffix_scan(uint32_t (*buf)[9][256], const uint32_t (*lvl)[9], Fr v) {
+    const uint32_t tid = threadIdx.x;
+    int cur = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) buf[0][k][tid] = v.l[k];
+    __syncthreads();
+    for (int l = 0; l < 8; l++) {
+        const uint32_t d = 1u << l;
+        if (tid + d < 256) {
+            Fr r;
+#pragma unroll
+            for (int k = 0; k < 9; k++) r.l[k] = buf[cur][k][tid + d];
+            v = fr_add(v, fr_mul(r, limbs9(lvl[l])));
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) buf[cur ^ 1][k][tid] = v.l[k];
+        cur ^= 1;
+        __syncthreads();
+    }
+    return v;       // buf[cur] holds every thread's I_t
+}
+__global__ void __launch_bounds__(256) k_span_carries(const EvalJob J, const void* partial, void* carry, void* rem) {
+    __shared__ uint32_t buf[2][9][256];
+    const Fr zs = limbs9(J.zspan);
+    const uint32_t tid = threadIdx.x;
+    const size_t lo = (size_t)tid * J.R, hi = lo + J.R < J.nblocks ? lo + J.R : J.nblocks;
+    Fr acc = fp_zero<FrParams>();
+    for (size_t i = hi; i > lo; i--) acc = fr_add(fr_mul(acc, zs), fr_load(partial, i - 1));
+    block_suffix_scan(buf, J.lvl2, acc);            // 8 levels: the final values sit in buf[0]
+    Fr c = fp_zero<FrParams>();
+    if (tid + 1 < 256) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) c.l[k] = buf[0][k][tid + 1];
+    }
+    for (size_t i = hi; i > lo; i--) {
+        fr_store(carry, i - 1, c);
+        c = fr_add(fr_mul(c, zs), fr_load(partial, i - 1));
+    }
+    if (tid == 0 && rem) fr_store(rem, 0, c);
+}
+__global__ void __launch_bounds__(256) k_fill_spans(const EvalJob J, const void* carry, void* out, int shift) {
+    __shared__ uint32_t buf[2][9][256];
+    const Fr z = limbs9(J.z);
+    const uint32_t tid = threadIdx.x;
+    const size_t lo = ((size_t)blockIdx.x * 256 + tid) * EV_CH;
+    const size_t hi = lo + EV_CH < J.n ? lo + EV_CH : (lo < J.n ? J.n : lo);
+    const Fr cin = fr_load(carry, blockIdx.x);
+    Fr h = fp_zero<FrParams>();
+    for (size_t i = hi; i > lo; i--) h = fr_add(fr_mul(h, z), fr_load(J.c, i - 1));
+    if (tid == 255) h = fr_add(h, fr_mul(cin, limbs9(J.lvl1[0])));      // the span's carry-in enters behind its last chunk
+    block_suffix_scan(buf, J.lvl1, h);
+    Fr acc = cin;
+    if (tid + 1 < 256) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) acc.l[k] = buf[0][k][tid + 1];
+    }
+    for (size_t i = hi; i > lo; i--) {
+        acc = fr_add(fr_mul(acc, z), fr_load(J.c, i - 1));
+        const long long o = (long long)(i - 1) + shift;
+        if (o >= 0) fr_store(out, (size_t)o, acc);
+    }
 }
 
 }  // namespace
@@ -272,6 +289,25 @@ extern "C" int zk_fr_batch_inverse_dev(zk_ctx* ctx, void* v_dev, size_t n) {
     return ZK_OK;
 }
 
+namespace {
+void eval_job_fill(EvalJob& J, const void* c, size_t n, uint32_t first_block, const Fr& z) {
+    J.c = c;
+    J.n = n;
+    J.first_block = first_block;
+    J.nblocks = (uint32_t)((n + EV_SPAN - 1) / EV_SPAN);
+    if (!J.nblocks) J.nblocks = 1;
+    J.R = (J.nblocks + 255) / 256;
+    J.pad = 0;
+    auto put = [](uint32_t* d, const Fr& v) { for (int k = 0; k < 9; k++) d[k] = v.l[k]; };
+    put(J.z, z);
+    Fr p = host_pow(z, EV_CH);
+    for (int l = 0; l < 8; l++) { put(J.lvl1[l], p); p = fp_sqr<FrParams>(p); }     // p ends as z^(EV_CH * 256) = z^SPAN
+    put(J.zspan, p);
+    p = host_pow(p, J.R);
+    for (int l = 0; l < 8; l++) { put(J.lvl2[l], p); p = fp_sqr<FrParams>(p); }
+}
+}  // namespace
+
 // DensePolynomial::evaluate for `count` (polynomial, point) pairs at once: out[i] = polys[i](points[i]).
 extern "C" int zk_poly_evaluate_batch_dev(zk_ctx* ctx, const zk_poly_ref* polys, const zk_fr* points, size_t count, zk_fr* out) {
     if (!ctx || (count && (!polys || !points || !out))) return ZK_ERR_ARG;
@@ -280,23 +316,8 @@ extern "C" int zk_poly_evaluate_batch_dev(zk_ctx* ctx, const zk_poly_ref* polys,
     uint32_t blocks = 0;
     for (size_t i = 0; i < count; i++) {
         if (polys[i].n && !polys[i].ptr) return ZK_ERR_ARG;
-        EvalJob& J = jobs[i];
-        J.c = polys[i].ptr;
-        J.n = polys[i].n;
-        J.first_block = blocks;
-        J.nblocks = (uint32_t)((polys[i].n + EV_SPAN - 1) / EV_SPAN);
-        if (!J.nblocks) J.nblocks = 1;
-        J.R = (J.nblocks + 255) / 256;
-        J.pad = 0;
-        blocks += J.nblocks;
-        const Fr z = host_int(&points[i]);
-        auto put = [](uint32_t* d, const Fr& v) { for (int k = 0; k < 9; k++) d[k] = v.l[k]; };
-        put(J.z, z);
-        Fr p = host_pow(z, EV_CH);
-        for (int l = 0; l < 8; l++) { put(J.lvl1[l], p); p = fp_sqr<FrParams>(p); }     // p ends as z^(EV_CH * 256) = z^SPAN
-        put(J.zspan, p);
-        p = host_pow(p, J.R);
-        for (int l = 0; l < 8; l++) { put(J.lvl2[l], p); p = fp_sqr<FrParams>(p); }
+        eval_job_fill(jobs[i], polys[i].ptr, polys[i].n, blocks, host_int(&points[i]));
+        blocks += jobs[i].nblocks;
     }
     char* scr;
     const size_t jobs_bytes = (count * sizeof(EvalJob) + 255) & ~(size_t)255;
@@ -323,9 +344,24 @@ extern "C" int zk_poly_evaluate_dev(zk_ctx* ctx, const void* coeffs_dev, size_t 
 
 extern "C" int zk_poly_divide_by_linear_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, const zk_fr* z, void* q_dev, zk_fr* rem) {
     if (!ctx || !z || (n && !coeffs_dev) || (n > 1 && !q_dev)) return ZK_ERR_ARG;
-    Fr q0;
-    ZK_TRY(solve_recurrence(ctx, coeffs_dev, n, host_int(z), n > 1 ? q_dev : nullptr, -1, &q0, 0));
-    if (rem) host_store_ext<FrParams>(rem->l, fp_int_to_ext<FrParams>(q0));
+    EvalJob job;                                    // 680 B: travels as a kernel argument, no copy, nothing to keep alive
+    eval_job_fill(job, coeffs_dev, n, 0, host_int(z));
+    const uint32_t blocks = job.nblocks;
+    char* scr;
+    ZK_TRY(zk_scratch(ctx, "poly_divlin", (size_t)blocks * 64 + 32, (void**)&scr));
+    void* partial = scr;
+    void* carry = scr + (size_t)blocks * 32;
+    void* rem_dev = scr + (size_t)blocks * 64;
+    hipLaunchKernelGGL(k_eval_spans1, blocks, 256, 0, ctx->stream, job, partial);
+    hipLaunchKernelGGL(k_span_carries, 1, 256, 0, ctx->stream, job, (const void*)partial, carry, rem ? rem_dev : nullptr);
+    if (n > 1) hipLaunchKernelGGL(k_fill_spans, blocks, 256, 0, ctx->stream, job, (const void*)carry, q_dev, -1);
+    ZK_HIP(ctx, hipGetLastError());
+    if (rem) {
+        uint32_t w[8];
+        ZK_HIP(ctx, hipMemcpyAsync(w, rem_dev, 32, hipMemcpyDeviceToHost, ctx->stream));
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < 4; k++) rem->l[k] = (uint64_t)w[2 * k] | ((uint64_t)w[2 * k + 1] << 32);
+    }
     return ZK_OK;
 }
 
