@@ -15,6 +15,7 @@
 #include "hostgroup.hpp"
 #include "internal.hpp"
 #include <algorithm>
+#include <future>
 #include <map>
 #include <string>
 #include <vector>
@@ -198,6 +199,8 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         P.rands[INDEX_LABELS[i]] = {};
     }
 
+    // ZK_MARLIN_SYNC_BLINDS=1 (experiment): the host-side blinding terms inline instead of on host threads
+    const std::launch blind_policy = getenv("ZK_MARLIN_SYNC_BLINDS") ? std::launch::deferred : std::launch::async;
     zk_g1_projective gamma_pts[3];
     {
         zk_g1_affine a[3];
@@ -228,6 +231,11 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
         std::vector<std::pair<std::string, int>> slot;                          // (label, 0 = comm / 1 = shifted)
         std::map<std::string, zk_g1_projective> acc[2];
+        // the blinding terms (three host scalar multiplications each, ~1.2 ms) run on host threads under the device batch
+        std::vector<std::pair<std::pair<int, std::string>, std::future<zk_g1_projective>>> blinds;
+        auto blind_async = [&](int which, const char* l, const std::vector<HF>& c) {
+            blinds.push_back({{which, l}, std::async(blind_policy, [&gamma_pts, c] { return small_msm(gamma_pts, c); })});
+        };
         for (const char* l : labels) {
             const bool hiding = !strcmp(l, "w") || !strcmp(l, "z_a") || !strcmp(l, "z_b") || !strcmp(l, "g_1");
             const bool bounded = P.bounds.count(l) != 0;
@@ -237,18 +245,20 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
             P.rands[l] = {blind, sblind};
             const Poly& p = P.polys[l];
             jb.push_back(P.pg); joff.push_back(0); jsc.push_back(p.p); jlen.push_back(p.n); slot.push_back({l, 0});
-            if (hiding) acc[0][l] = small_msm(gamma_pts, blind);
+            if (hiding) blind_async(0, l, blind);
             if (bounded) {
                 if (p.n - 1 > P.bounds[l]) { ctx->last_error = std::string("zk_marlin_prove: ") + l + " exceeds its degree bound"; return ZK_ERR_STATE; }
                 jb.push_back(P.pg); joff.push_back(P.max_degree - P.bounds[l]); jsc.push_back(p.p); jlen.push_back(p.n); slot.push_back({l, 1});
-                if (hiding) acc[1][l] = small_msm(gamma_pts, sblind);
+                if (hiding) blind_async(1, l, sblind);
             }
         }
         ZK_TRY(P.rc);
         std::vector<zk_g1_projective> outs(jb.size());
         std::vector<void*> outp(jb.size());
         for (size_t i = 0; i < jb.size(); i++) outp[i] = &outs[i];
-        ZK_TRY(zk_msm_batch_dev(ctx, jb.size(), jb.data(), joff.data(), jsc.data(), jlen.data(), outp.data()));
+        const int brc = zk_msm_batch_dev(ctx, jb.size(), jb.data(), joff.data(), jsc.data(), jlen.data(), outp.data());
+        for (auto& b : blinds) acc[b.first.first][b.first.second] = b.second.get();      // joined before any return
+        ZK_TRY(brc);
         for (size_t i = 0; i < jb.size(); i++) {
             auto& m = acc[slot[i].second];
             auto it = m.find(slot[i].first);
@@ -467,7 +477,8 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     const HF points[2] = {beta, gamma};
     std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
     size_t counts[2] = {0, 0};
-    std::vector<zk_g1_projective> extra[2];                                      // the blinding witnesses, computed on the host
+    std::vector<std::future<zk_g1_projective>> extra[2];                         // the blinding witnesses: host threads, joined after the batch
+    auto small_async = [&](const std::vector<HF>& c) { return std::async(blind_policy, [&gamma_pts, c] { return small_msm(gamma_pts, c); }); };
     bool has_rv[2] = {false, false};
     HF rvs[2];
     for (int q = 0; q < 2; q++) {
@@ -507,7 +518,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         bool hiding = false;
         for (auto& v : r_comb) hiding = hiding || !v.is_zero();
         if (hiding) {
-            extra[q].push_back(small_msm(gamma_pts, host_div_linear(r_comb, z)));
+            extra[q].push_back(small_async(host_div_linear(r_comb, z)));
             has_rv[q] = true;
             rvs[q] = host_eval(r_comb, z);
         }
@@ -522,7 +533,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
             const std::vector<HF>& sb = P.rands[sh.first].second;
             if (!sb.empty()) acc_scaled(srw, host_div_linear(sb, z), sh.second);
         }
-        if (!srw.empty()) extra[q].push_back(small_msm(gamma_pts, srw));
+        if (!srw.empty()) extra[q].push_back(small_async(srw));
         if (!shifted.empty() && has_rv[q]) rvs[q] = rvs[q] + host_eval(sr, z);
         counts[q] = jb.size() - first_job;
     }
@@ -530,14 +541,17 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     std::vector<zk_g1_projective> outs(jb.size());
     std::vector<void*> outp(jb.size());
     for (size_t i = 0; i < jb.size(); i++) outp[i] = &outs[i];
-    ZK_TRY(zk_msm_batch_dev(ctx, jb.size(), jb.data(), joff.data(), jsc.data(), jlen.data(), outp.data()));
+    const int orc = zk_msm_batch_dev(ctx, jb.size(), jb.data(), joff.data(), jsc.data(), jlen.data(), outp.data());
+    std::vector<zk_g1_projective> extra_pts[2];
+    for (int q = 0; q < 2; q++) for (auto& f : extra[q]) extra_pts[q].push_back(f.get());
+    ZK_TRY(orc);
     Affine<G1Field> wit[2];
     {
         size_t k = 0;
         for (int q = 0; q < 2; q++) {
             zk_g1_projective w = outs[k];
             for (size_t i = 1; i < counts[q]; i++) { zk_g1_projective t; zk_g1_add(&w, &outs[k + i], &t); w = t; }
-            for (auto& e : extra[q]) { zk_g1_projective t; zk_g1_add(&w, &e, &t); w = t; }
+            for (auto& e : extra_pts[q]) { zk_g1_projective t; zk_g1_add(&w, &e, &t); w = t; }
             k += counts[q];
             wit[q] = proj_to_aff(w);
         }
