@@ -4,19 +4,28 @@ kernels in flight are summed; an instant counts as "filled" when that sum reache
 Prints the filled / under-filled / idle split and the kernels that own the under-filled time (latency-bound launches: scans'
 upper levels, single-block reductions, host synchronisation).
 
-usage: trace_underfill.py kernel_trace.csv [window_ms=90] [fill_threads=131072]"""
+usage: trace_underfill.py kernel_trace.csv [window_ms=90] [fill_threads=131072] [--period=KERNEL[:idx]]"""
 import csv, re, sys, collections
 
 f = sys.argv[1]
-win = float(sys.argv[2]) if len(sys.argv) > 2 else 90.0
-fill = int(sys.argv[3]) if len(sys.argv) > 3 else 131072
+pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+win = float(pos[1]) if len(pos) > 1 else 90.0
+fill = int(pos[2]) if len(pos) > 2 else 131072
 rows = []
 for r in csv.DictReader(open(f)):
     m = re.search(r"(k_\w+|rocprim\w*|\w+)(<|\()", r["Kernel_Name"])
     g = int(r["Grid_Size_X"]) * max(1, int(r.get("Grid_Size_Y", 1) or 1)) * max(1, int(r.get("Grid_Size_Z", 1) or 1))
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), m.group(1) if m else r["Kernel_Name"][:30], g))
-end = max(e for _, e, _, _ in rows)
-rows = [r for r in rows if r[0] >= end - win * 1e6]
+period = [a for a in sys.argv if a.startswith("--period=")]
+if period:        # --period=KERNEL[:idx]: the window runs from the idx-th launch of KERNEL (default -3) to the next one
+    name, _, idx = period[0][9:].partition(":")
+    starts = sorted(s for s, _, k, _ in rows if k == name)
+    i = int(idx) if idx else -3
+    lo, hi = starts[i], starts[i + 1]
+    rows = [r for r in rows if lo <= r[0] < hi]
+else:
+    end = max(e for _, e, _, _ in rows)
+    rows = [r for r in rows if r[0] >= end - win * 1e6]
 ev = []
 for i, (s, e, k, g) in enumerate(rows):
     ev.append((s, 1, i))

@@ -518,7 +518,26 @@ int ensure_aux(zk_ctx* ctx, size_t k) {
         ZK_HIP(ctx, zk_stream_create(&st, true));
         ctx->aux.push_back(st);
     }
-    if (!ctx->acc_stream) ZK_HIP(ctx, zk_stream_create(&ctx->acc_stream, false));
+    if (!ctx->acc_stream) {
+        // ZK_ACC_CU_RESERVE=N: the accumulate stream is created with a CU mask that leaves N compute units to the other streams
+        // (sorts, reduce chains, witness map).  An accumulate kernel fills every wave slot it is offered (232 registers per lane:
+        // no other wave fits beside two of its own on a SIMD), and a co-running kernel otherwise only advances at the rate its
+        // blocks retire -- a 0.45 ms sort takes 3 ms beside it.
+        const char* e = getenv("ZK_ACC_CU_RESERVE");
+        const int reserve = e ? atoi(e) : 0;
+        if (reserve > 0 && reserve < ctx->n_cu) {
+            const int words = (ctx->n_cu + 31) / 32;
+            std::vector<uint32_t> mask(words, 0);
+            const char* hi = getenv("ZK_ACC_CU_RESERVE_HIGH");     // which end of the mask is withheld (the bit -> CU mapping is the driver's)
+            for (int i = 0; i < ctx->n_cu; i++) {
+                const bool keep = hi ? i < ctx->n_cu - reserve : i >= reserve;
+                if (keep) mask[i / 32] |= 1u << (i % 32);
+            }
+            ZK_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->acc_stream, (uint32_t)words, mask.data()));
+        } else {
+            ZK_HIP(ctx, zk_stream_create(&ctx->acc_stream, false));
+        }
+    }
     return ZK_OK;
 }
 
@@ -688,10 +707,14 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
 
 }  // namespace
 
-// Several independent MSMs as a software pipeline over the sort / accumulate streams: job k+1 is sorted while job k
-// accumulates, reduces follow in job order, three scratch slots rotate.  Used for the commitments of one Marlin round
-// (lib.rs:171-247: PC::commit over the round's oracles) and for the two MSMs of SpdzGroupShare::multi_scale_pub_group
-// (share/spdz.rs:482-488).  Outputs are Jacobian points (G1 or G2 according to each job's table).
+// Several independent MSMs as a software pipeline over the sort / accumulate / reduce streams, enqueued in one go: three
+// scratch slots rotate, a job's sort waits (on the device) for the reduce of the slot's previous user, so the sort stream runs up
+// to two jobs ahead of the accumulate stream and the host only waits at the end.  Jobs run longest first: the head of the
+// pipeline (one sort nothing hides) is paid once either way, and behind a long accumulate kernel the shorter jobs' sorts are
+// ready in time -- in submission order the round-1 batch of Marlin (n, n, n, 3n) left the accumulate stream waiting ~1.5 ms
+// for the 3n job's sort, which takes 3.3 ms beside an accumulate kernel (0.45 ms alone).
+// Used for the commitments of one Marlin round (lib.rs:171-247: PC::commit over the round's oracles) and for the two MSMs of
+// SpdzGroupShare::multi_scale_pub_group (share/spdz.rs:482-488).  Outputs are Jacobian points (G1 or G2 according to each job's table).
 extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* const* bases, const size_t* base_offsets,
                                 const void* const* scalars_dev, const size_t* lens, void* const* outs) {
     if (!ctx || (n_jobs && (!bases || !scalars_dev || !lens || !outs))) return ZK_ERR_ARG;
@@ -704,27 +727,28 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
     zk_presort_free(ctx);            // the batch rotates over the same scratch slots
     ZK_TRY(ensure_aux(ctx, 1));
     constexpr size_t SLOTS = 3;
-    hipStream_t s_sort = ctx->aux[0], s_acc = ctx->acc_stream;
+    static const bool serial_sort = getenv("ZK_BATCH_SERIAL_SORT") != nullptr;      // experiment: sorts in line with the accumulates
+    hipStream_t s_acc = ctx->acc_stream, s_sort = serial_sort ? s_acc : ctx->aux[0];
     hipEvent_t e0;
     ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventRecord(e0, ctx->stream));        // the scalars were produced on the context stream
     ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e0, 0));
     ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e0, 0));
+    std::vector<size_t> perm(n_jobs);
+    for (size_t k = 0; k < n_jobs; k++) perm[k] = k;
+    static const bool in_order = getenv("ZK_BATCH_IN_ORDER") != nullptr;      // experiment: submission order
+    if (!in_order) std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
     std::vector<ZkMsmJob> jobs(n_jobs);
-    size_t finished = 0;
     int rc = ZK_OK;
     static const bool red_on_main = !(getenv("ZK_BATCH_REDUCE_STREAM") && !strcmp(getenv("ZK_BATCH_REDUCE_STREAM"), "sort"));
-    auto start = [&](size_t k) -> int {
-        while (k >= finished + SLOTS) {                  // the slot's previous user must have delivered its result
-            ZK_TRY(zk_msm_finish(ctx, &jobs[finished], outs[finished]));
-            finished++;
-        }
-        ZK_TRY(zk_msm_prepare(ctx, &jobs[k], bases[k], base_offsets ? base_offsets[k] : 0, scalars_dev[k], lens[k], 1 + (int)(k % SLOTS)));
-        return zk_msm_enqueue_sort(ctx, &jobs[k], s_sort, nullptr);
-    };
-    rc = start(0);
     for (size_t k = 0; k < n_jobs && rc == ZK_OK; k++) {
-        if (k + 1 < n_jobs) rc = start(k + 1);
+        const size_t j = perm[k];
+        jobs[k].pin_key = 16 + (int)k;                   // its own pinned result buffer: the host reads them all at the end
+        rc = zk_msm_prepare(ctx, &jobs[k], bases[j], base_offsets ? base_offsets[j] : 0, scalars_dev[j], lens[j], 1 + (int)(k % SLOTS));
+        // the slot's previous user must be through its reduce chain (k_fold reads the sort scratch, the chain the sums) before
+        // this job's sort rewrites the slot; that job's accumulate kernel is then done as well
+        if (rc == ZK_OK && k >= SLOTS && jobs[k - SLOTS].reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(s_sort, jobs[k - SLOTS].reduce_done, 0));
+        if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[k], s_sort, nullptr);
         if (rc == ZK_OK) rc = zk_msm_enqueue_accum(ctx, &jobs[k], s_acc);
         // reduces on the context stream (idle here), not behind the sorts: on the sort stream the sort of job k+2 queued
         // behind the reduce of job k, i.e. behind the accumulate of job k, and the accumulate stream then waited for it
@@ -732,9 +756,10 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
         // ZK_BATCH_REDUCE_STREAM=sort restores the old placement.
         if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, &jobs[k], red_on_main ? ctx->stream : s_sort);
     }
-    for (; finished < n_jobs && rc == ZK_OK; finished++) rc = zk_msm_finish(ctx, &jobs[finished], outs[finished]);
+    for (size_t k = 0; k < n_jobs && rc == ZK_OK; k++) rc = zk_msm_finish(ctx, &jobs[k], outs[perm[k]]);
     (void)hipStreamSynchronize(s_sort);
     (void)hipStreamSynchronize(s_acc);
+    (void)hipStreamSynchronize(ctx->stream);
     (void)hipEventDestroy(e0);
     return rc;
 }

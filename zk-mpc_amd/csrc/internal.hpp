@@ -50,6 +50,7 @@ struct ZkPhaseTimer {
 // An MSM in flight (msm.hip): prepare -> enqueue_sort -> enqueue_accum -> enqueue_reduce -> finish.
 struct ZkMsmJob {
     int group = 1, slot = 0;
+    int pin_key = -1;                 // pinned result buffer (ctx->pinned key); -1: the slot's.  Jobs enqueued without a host wait in between need their own
     int counting_sort = 0;            // 1: take the atomic counting sort even for a merged bucket set (its small kernels co-run with an accumulate kernel)
     size_t n = 0, max_segs = 0, max_heavy = 0;
     uint32_t c = 0, W = 0, NB = 0, seg = 0, T1 = 0, nbits = 0;

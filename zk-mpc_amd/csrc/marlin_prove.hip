@@ -15,6 +15,7 @@
 #include "hostgroup.hpp"
 #include "internal.hpp"
 #include <algorithm>
+#include <chrono>
 #include <future>
 #include <map>
 #include <string>
@@ -183,6 +184,21 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     if (cap < zk_marlin_proof_max_size()) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: output buffer smaller than zk_marlin_proof_max_size()");
     if (ix->num_constraints != ix->num_variables) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: NonSquareMatrix");
     if (ix->num_instance == 0 || (ix->num_instance & (ix->num_instance - 1))) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: InvalidPublicInputLength");
+    // ZK_MARLIN_TIMING=1: host wall-clock laps of the phases on stderr (a lap includes whatever device work the host waited for)
+    struct Laps {
+        bool on = getenv("ZK_MARLIN_TIMING") != nullptr;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), t = t0;
+        std::string line;
+        void lap(const char* what) {
+            if (!on) return;
+            const auto now = std::chrono::steady_clock::now();
+            char b[64];
+            snprintf(b, sizeof b, " %s %.2f", what, std::chrono::duration<double, std::milli>(now - t).count());
+            line += b;
+            t = now;
+        }
+        ~Laps() { if (on) fprintf(stderr, "zk_marlin_prove ms:%s | total %.2f\n", line.c_str(), std::chrono::duration<double, std::milli>(t - t0).count()); }
+    } laps;
     Prover P{ctx, ix, powers_g, powers_gamma_g, powers_g->n - 1, zk_rng_};
     const Dom H(ix->num_constraints), K(ix->num_non_zero), X(ix->num_instance), B(3 * Dom(ix->num_non_zero).size - 3);
     const size_t n = H.size, ni = ix->num_instance;
@@ -277,6 +293,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         return zk_fsrng_absorb(fs, bytes.data(), bytes.size());                  // to_bytes![comms, EmptyMessage]
     };
 
+    laps.lap("setup");
     // =========================== round 1 (prover.rs:216-404) ===========================
     char* z_a = P.dev("z_a", n); char* z_b = P.dev("z_b", n);
     ZK_TRY(P.rc);
@@ -326,9 +343,12 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     P.op(ZK_OP_SUB, mask, mr, mask, 1);                                          // the sum over H becomes zero
     P.polys["mask_poly"] = Poly{mask, md + 1};
     ZK_TRY(P.rc);
+    laps.lap("polys");
     ZK_TRY(commit_round({"w", "z_a", "z_b", "mask_poly"}));
+    laps.lap("commit");
     const HF alpha = sample_outside(H), eta_a = P.next_fr(fs), eta_b = P.next_fr(fs), eta_c = P.next_fr(fs);
 
+    laps.lap("round1");
     // =========================== round 2 (prover.rs:438-565) ===========================
     const HF v_h_alpha = H.vanishing(alpha), one = HF::one();
     char* elems = P.dev("h_elems", n);
@@ -380,9 +400,12 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     if (!P.is_zero(hr, 1)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: outer sum-check: the sum over H is not zero (unsatisfied constraint system)");
     P.polys["g_1"] = Poly{hr + 32, n - 1};
     P.polys["h_1"] = Poly{hq, std::min(MUL.size - n, 2 * n + 2 - 1)};
+    laps.lap("polys");
     ZK_TRY(commit_round({"t", "g_1", "h_1"}));
+    laps.lap("commit");
     const HF beta = sample_outside(H);
 
+    laps.lap("round2");
     // =========================== round 3 (prover.rs:583-716) ===========================
     const HF vv = v_h_alpha * H.vanishing(beta);
     char* f_ev = P.dev("f_ev", K.size);
@@ -403,9 +426,12 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, a_ev, B.size, K.log, h2q, h2r));
     if (!P.is_zero(h2r, K.size)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: inner sum-check: a - b f is not divisible by v_K");
     P.polys["h_2"] = Poly{h2q, B.size - K.size};
+    laps.lap("polys");
     ZK_TRY(commit_round({"g_2", "h_2"}));
+    laps.lap("commit");
     const HF gamma = P.next_fr(fs);
 
+    laps.lap("round3");
     // =========================== evaluations and linear combinations ===========================
     std::map<std::string, HF> single;
     {   // the thirteen evaluations of the query set in one batch (two launches, one copy back)
@@ -472,6 +498,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         xi = HF::from_u64(w[0]) + HF::from_u64(w[1]) * HF::from_u64((uint64_t)1 << 32) * HF::from_u64((uint64_t)1 << 32);
     }
 
+    laps.lap("evals+lc");
     // =========================== open_combinations (marlin/mod.rs:213-306, marlin_pc/mod.rs:245-340) ===========================
     const std::vector<std::string> QUERY[2] = {{"g_1", "outer_sumcheck", "t", "z_b"}, {"a_denom", "b_denom", "c_denom", "g_2", "inner_sumcheck"}};
     const HF points[2] = {beta, gamma};
@@ -557,6 +584,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         }
     }
 
+    laps.lap("open");
     // =========================== Proof::serialize (data_structures.rs:99-110, derive order) ===========================
     std::vector<uint8_t> out;
     auto u64 = [&](uint64_t v) { for (int i = 0; i < 8; i++) out.push_back((uint8_t)(v >> (8 * i))); };

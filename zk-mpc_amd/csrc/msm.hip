@@ -844,7 +844,7 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
     // pinned destination: a pageable one would make the "async" copy block the host until this job is done
-    auto& pin = ctx->pinned[job->slot];
+    auto& pin = ctx->pinned[job->pin_key >= 0 ? job->pin_key : job->slot];
     const size_t bytes = std::max<size_t>((size_t)64 * 17, (size_t)job->Rw * nout) * XW * 4;
     if (pin.bytes < bytes) {
         if (pin.p) (void)hipHostFree(pin.p);
