@@ -463,3 +463,42 @@ def test_fr_lazy_butterflies():
         y2 = _fr_lazy(9, _l9(xs[0]), _l9(xs[1]), _l9(wa), n_out=2)
         assert [_val(y) % RR for y in y2] == [(xs[0] + xs[1]) % RR, m(xs[0] - xs[1], wa)]
         assert all(_val(y) < 113 * RR // 100 and all(l <= M29 for l in y) for y in y2)
+
+
+def test_lazy_add_matches_the_group_law():
+    """ec.cuh::xyzz_add_lazy (the bucket reduction's running sums) on the host against the oracle's group law: sums of
+    multiples of the generator given in XYZZ form with non-trivial zz / zzz, operands left in the lazy ranges between steps,
+    incl. P + P, P - P and the infinity operands."""
+    rng = O.Prng(777)
+    to_int = lambda v: v * RI14 % Q
+    from_int = lambda v: v * pow(RI14, -1, Q) % Q
+
+    def xyzz_of(pt, lam):                                  # affine -> XYZZ with Z = lam (internal form)
+        if pt is None:
+            return [0, 0, 0, 0]
+        zz, zzz = lam * lam % Q, lam * lam * lam % Q
+        return [to_int(pt[0] * zz % Q), to_int(pt[1] * zzz % Q), to_int(zz), to_int(zzz)]
+
+    def affine_of(c):
+        x, y, zz, zzz = [from_int(_val(a) % Q) for a in c]
+        if zz == 0:
+            return None
+        return (x * pow(zz, -1, Q) % Q, y * pow(zzz, -1, Q) % Q)
+
+    pts = [O.g1_mul(O.G1_GEN, rng.fr()) for _ in range(6)]
+    neg = lambda p: (p[0], (Q - p[1]) % Q)
+    cases = [(pts[0], pts[1]), (pts[2], pts[2]), (pts[3], neg(pts[3])), (None, pts[4]), (pts[4], None), (None, None)]
+    for pa, pb in cases:
+        a = xyzz_of(pa, rng.fr() % Q or 1)
+        b = xyzz_of(pb, rng.fr() % Q or 1)
+        out = _lazy(12, *a, *b, n_out=8)
+        assert affine_of(out[4:]) == O.g1_add(pa, pb)
+        assert all(_normalised(c) for c in out[4:]) and all(_val(c) < Q for c in out[4:])
+    # a chain that keeps its accumulator in the lazy ranges (x < 5q + eps, the rest < q + eps)
+    acc_pt, acc = pts[0], xyzz_of(pts[0], 5)
+    for k in range(1, 6):
+        out = _lazy(12, *[_val(c) if not isinstance(c, int) else c for c in acc], *xyzz_of(pts[k], 3 + k), n_out=8)
+        acc_pt = O.g1_add(acc_pt, pts[k])
+        acc = out[:4]
+        assert _val(acc[0]) < 5 * Q + EPS and all(_val(c) < Q + EPS for c in acc[1:])
+        assert affine_of(out[4:]) == acc_pt

@@ -138,6 +138,39 @@ ZK_HD XYZZ<F> xyzz_madd_lazy(const XYZZ<F>& acc, const Affine<F>& q) {
 template <class F>
 ZK_HD XYZZ<F> xyzz_canon_lazy(const XYZZ<F>& a) { return XYZZ<F>{F::canon(a.x), F::canon1(a.y), F::canon1(a.zz), F::canon1(a.zzz)}; }
 
+// a + b ("add-2008-s") in the LAZY domain: what the bucket reduction's running sums use (msm.hip: k_reduce, k_bitsum, k_fold).
+//   a, b: coordinates in the ranges xyzz_madd_lazy leaves (x < 5p + eps, y, zz, zzz < p + eps; fully reduced ones included),
+//   infinity = all-zero words.  The result is in the same ranges.
+// Ranges: U1, U2, S1, S2 < p + eps;  P = U2 + 2p - U1 in (p - eps, 3p + eps), R likewise;  X3, T, Y3 as in xyzz_madd_lazy.
+// The equal-x case is found exactly (P = 0 mod p iff P is p, 2p or 3p: low limbs 1 .. 3).
+template <class F>
+ZK_HD XYZZ<F> xyzz_add_lazy(const XYZZ<F>& a, const XYZZ<F>& b) {
+    using T = typename F::T;
+    if (F::is_zero(a.zz)) return b;
+    if (F::is_zero(b.zz)) return a;
+    const T u1 = F::mul_l(a.x, b.zz);
+    const T u2 = F::mul_l(b.x, a.zz);
+    const T s1 = F::mul_l(a.y, b.zzz);
+    const T s2 = F::mul_l(b.y, a.zzz);
+    const T p = F::template sub_kp<2>(u2, u1);
+    const T r = F::template sub_kp<2>(s2, s1);
+    if (F::maybe_multiple_of_p(p)) {
+        if (F::is_zero(F::canon(p))) {
+            if (F::is_zero(F::canon(r))) return xyzz_dbl<F>(xyzz_canon_lazy<F>(a));
+            return xyzz_inf<F>();
+        }
+    }
+    const T pp = F::sqr_l(p);
+    const T ppp = F::mul_l(p, pp);
+    const T qq = F::mul_l(u1, pp);
+    const T x3 = F::x3_l(F::sqr_l(r), ppp, qq);
+    const T y3 = F::mulsub_l(r, F::template sub_kp<6>(qq, x3), ppp, s1);
+    return XYZZ<F>{x3, y3, F::mul_l(F::mul_l(a.zz, b.zz), pp), F::mul_l(F::mul_l(a.zzz, b.zzz), ppp)};
+}
+// x brought below p (the packed 12-word form holds 377 bits: y, zz, zzz < p + eps fit as they are, x < 5p + eps does not)
+template <class F>
+ZK_HD XYZZ<F> xyzz_packable_lazy(const XYZZ<F>& a) { return XYZZ<F>{F::canon(a.x), a.y, a.zz, a.zzz}; }
+
 // a + b ("add-2008-s"), complete.
 template <class F>
 ZK_HD XYZZ<F> xyzz_add(const XYZZ<F>& a, const XYZZ<F>& b) {

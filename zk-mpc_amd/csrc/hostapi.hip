@@ -156,6 +156,7 @@ extern "C" int zk_fq_neg5_almost_raw(const uint32_t a13[13], uint32_t out13[13])
 // limbs out.  op 0: mul_lazy(a, b)  1: sqr_lazy(a)  2: mul2_lazy(a, b, c, d)  3..5: sub_kp<2|4|6>(a, b)  6: x3_lazy(rr, ppp, qq)
 // 7: canon(a)  8: kp_minus<1>(a)  9: neg5_almost(a)  10: xyzz_madd_lazy(acc[4], q[2]) -> 4 elements, then 4 more: its canon form
 // 11: mul2_lazy with the split top column (all four operands wide)
+// 12: xyzz_add_lazy(a[4], b[4]) -> 4 elements, then 4 more: its canon form
 extern "C" int zk_fq_lazy_raw(int op, const uint32_t* in, uint32_t* out) {
     if (!in || !out) return ZK_ERR_ARG;
     auto ld = [&](int k) { Fq a; for (int i = 0; i < 13; i++) a.l[i] = in[13 * k + i]; return a; };
@@ -177,6 +178,14 @@ extern "C" int zk_fq_lazy_raw(int op, const uint32_t* in, uint32_t* out) {
             XYZZ<F> acc{ld(0), ld(1), ld(2), ld(3)};
             Affine<F> q{ld(4), ld(5)};
             XYZZ<F> r = xyzz_madd_lazy<F>(acc, q);
+            st(0, r.x); st(1, r.y); st(2, r.zz); st(3, r.zzz);
+            XYZZ<F> c = xyzz_canon_lazy<F>(r);
+            st(4, c.x); st(5, c.y); st(6, c.zz); st(7, c.zzz);
+            break;
+        }
+        case 12: {
+            XYZZ<F> a{ld(0), ld(1), ld(2), ld(3)}, b{ld(4), ld(5), ld(6), ld(7)};
+            XYZZ<F> r = xyzz_add_lazy<F>(a, b);
             st(0, r.x); st(1, r.y); st(2, r.zz); st(3, r.zzz);
             XYZZ<F> c = xyzz_canon_lazy<F>(r);
             st(4, c.x); st(5, c.y); st(6, c.zz); st(7, c.zzz);

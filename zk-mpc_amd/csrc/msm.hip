@@ -466,6 +466,26 @@ __device__ __forceinline__ XYZZ<F> lds_get_xyzz(const uint32_t* lds, uint32_t t)
     return xyzz_load<F>(w);
 }
 
+// The running sums of the bucket reduction: G1 in the lazy domain (ec.cuh::xyzz_add_lazy: no conditional subtraction on the
+// main path, ~16 % fewer instructions per addition); G2 has its own lane-pair chain (msm_g2pair.hip) and keeps the exact form
+// here.  radd_pack: a sum made fit for the packed 12-word form (LDS tree, the level buffers); radd_canon: fully reduced
+// (what leaves for the host).
+template <class F>
+__device__ __forceinline__ XYZZ<F> radd(const XYZZ<F>& a, const XYZZ<F>& b) {
+    if constexpr (F::WORDS == 12) return xyzz_add_lazy<F>(a, b);
+    else return xyzz_add<F>(a, b);
+}
+template <class F>
+__device__ __forceinline__ XYZZ<F> rpack(const XYZZ<F>& a) {
+    if constexpr (F::WORDS == 12) return xyzz_packable_lazy<F>(a);
+    else return a;
+}
+template <class F>
+__device__ __forceinline__ XYZZ<F> rcanon(const XYZZ<F>& a) {
+    if constexpr (F::WORDS == 12) return xyzz_canon_lazy<F>(a);
+    else return a;
+}
+
 // Split buckets are folded back into one sum per bucket by ONE launch (every launch of a reduce chain waits for a free
 // slot beside the running accumulate kernel, so fewer launches is a shorter chain): the first `light_blocks` blocks take
 // buckets with few segments, one thread per bucket adding them up serially; the remaining blocks take the very heavy
@@ -482,8 +502,8 @@ k_fold(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint32_t lig
             const HeavyDesc h = heavy[hb];
             if (h.nseg > 32) continue;
             XYZZ<F> acc = xyzz_load16<F>(sums, (size_t)h.first);
-            for (uint32_t j = 1; j < h.nseg; j++) acc = xyzz_add<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
-            xyzz_store16<F>(sums, h.key, acc);
+            for (uint32_t j = 1; j < h.nseg; j++) acc = radd<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
+            xyzz_store16<F>(sums, h.key, rcanon<F>(acc));
         }
         return;
     }
@@ -491,14 +511,14 @@ k_fold(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint32_t lig
         const HeavyDesc h = heavy[hb];
         if (h.nseg <= 32) continue;
         XYZZ<F> acc = xyzz_inf<F>();
-        for (uint32_t j = tid; j < h.nseg; j += 64) acc = xyzz_add<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
-        lds_put_xyzz<F, 64>(lds, tid, acc);
+        for (uint32_t j = tid; j < h.nseg; j += 64) acc = radd<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
+        lds_put_xyzz<F, 64>(lds, tid, rpack<F>(acc));
         __syncthreads();
         for (uint32_t d = 32; d >= 1; d >>= 1) {
-            if (tid < d) lds_put_xyzz<F, 64>(lds, tid, xyzz_add<F>(lds_get_xyzz<F, 64>(lds, tid), lds_get_xyzz<F, 64>(lds, tid + d)));
+            if (tid < d) lds_put_xyzz<F, 64>(lds, tid, rpack<F>(radd<F>(lds_get_xyzz<F, 64>(lds, tid), lds_get_xyzz<F, 64>(lds, tid + d))));
             __syncthreads();
         }
-        if (tid == 0) xyzz_store16<F>(sums, h.key, lds_get_xyzz<F, 64>(lds, 0));
+        if (tid == 0) xyzz_store16<F>(sums, h.key, rcanon<F>(lds_get_xyzz<F, 64>(lds, 0)));
         __syncthreads();
     }
 }
@@ -520,13 +540,14 @@ k_reduce(const uint32_t* S_in, const uint32_t* W_in, uint32_t* S_out, uint32_t* 
     XYZZ<F> running = xyzz_inf<F>(), acc = xyzz_inf<F>(), wsum = xyzz_inf<F>();
     for (uint32_t k = hi; k-- > lo;) {
         size_t idx = (size_t)w * T_in + k;
-        if (W_in) wsum = xyzz_add<F>(wsum, xyzz_load16<F>(W_in, idx));
-        running = xyzz_add<F>(running, xyzz_load16<F>(S_in, idx));
-        if (k > lo || one_based) acc = xyzz_add<F>(acc, running);
+        if (W_in) wsum = radd<F>(wsum, xyzz_load16<F>(W_in, idx));
+        running = radd<F>(running, xyzz_load16<F>(S_in, idx));
+        if (k > lo || one_based) acc = radd<F>(acc, running);
     }
-    acc = xyzz_add<F>(acc, wsum);
+    acc = rcanon<F>(radd<F>(acc, wsum));
     xyzz_store16<F>(W_out, t, acc);
     if (!last) {
+        running = rcanon<F>(running);
         for (uint32_t k = 0; k < klog; k++) running = xyzz_dbl<F>(running);
         xyzz_store16<F>(S_out, t, running);
     }
@@ -545,20 +566,20 @@ k_bitsum(const uint32_t* S_in, const uint32_t* W_in, uint32_t* out, uint32_t T, 
     const uint32_t tid = threadIdx.x;
     XYZZ<F> acc = xyzz_inf<F>();
     if (j == nbits) {
-        for (uint32_t t = tid; t < T; t += 256) acc = xyzz_add<F>(acc, xyzz_load16<F>(W_in, (size_t)w * T + t));
+        for (uint32_t t = tid; t < T; t += 256) acc = radd<F>(acc, xyzz_load16<F>(W_in, (size_t)w * T + t));
     } else if (j == nbits + 1) {
-        for (uint32_t t = tid; t < T; t += 256) acc = xyzz_add<F>(acc, xyzz_load16<F>(S_in, (size_t)w * T + t));
+        for (uint32_t t = tid; t < T; t += 256) acc = radd<F>(acc, xyzz_load16<F>(S_in, (size_t)w * T + t));
     } else {
         for (uint32_t t = tid; t < T; t += 256)
-            if ((t >> j) & 1) acc = xyzz_add<F>(acc, xyzz_load16<F>(S_in, (size_t)w * T + t));
+            if ((t >> j) & 1) acc = radd<F>(acc, xyzz_load16<F>(S_in, (size_t)w * T + t));
     }
-    lds_put_xyzz<F, 256>(lds, tid, acc);
+    lds_put_xyzz<F, 256>(lds, tid, rpack<F>(acc));
     __syncthreads();
     for (uint32_t d = 128; d >= 1; d >>= 1) {
-        if (tid < d) lds_put_xyzz<F, 256>(lds, tid, xyzz_add<F>(lds_get_xyzz<F, 256>(lds, tid), lds_get_xyzz<F, 256>(lds, tid + d)));
+        if (tid < d) lds_put_xyzz<F, 256>(lds, tid, rpack<F>(radd<F>(lds_get_xyzz<F, 256>(lds, tid), lds_get_xyzz<F, 256>(lds, tid + d))));
         __syncthreads();
     }
-    if (tid == 0) xyzz_store16<F>(out, blockIdx.x, lds_get_xyzz<F, 256>(lds, 0));
+    if (tid == 0) xyzz_store16<F>(out, blockIdx.x, rcanon<F>(lds_get_xyzz<F, 256>(lds, 0)));
 }
 
 // Arkworks-layout affine points (Montgomery R = 2^384) -> packed internal form.  all-zero = infinity stays zero.
