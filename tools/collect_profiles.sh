@@ -20,4 +20,11 @@ python3 tools/bench_marlin.py --logs 16,18,20,21,22 > $O/${T}_marlin_bench.jsonl
 rocprofv3 --kernel-trace --stats -d $O/${T}_marlin_trace -o m --output-format csv -- python3 tools/bench_marlin.py --logs 20 --reps 3 > $O/${T}_marlin_trace.log 2>&1
 python3 tools/bench_msm.py 24 > $O/${T}_micro_msm_ntt.json 2> $O/${T}_micro.err
 python3 tools/bench_she.py > $O/${T}_she_bench.jsonl 2> $O/${T}_she.err
+python3 tools/bench_ntt.py 24 20 10 > $O/${T}_ntt_bench.jsonl 2> $O/${T}_ntt.err
+for L in 16 18 20; do python3 bench.py --marlin --log-constraints $L --steps 4 --warmup 1 2>> $O/${T}_marlin_prove.err; done > $O/${T}_marlin_prove.jsonl
+rocprofv3 --kernel-trace -d $O/${T}_marlin_prove_trace -o m --output-format csv -- python3 bench.py --marlin --log-constraints 20 --steps 3 --warmup 1 > $O/${T}_marlin_prove_trace.log 2>&1
+python3 tools/trace_underfill.py $O/${T}_marlin_prove_trace/m_kernel_trace.csv --period=k_denoms_k:-4 > $O/${T}_marlin_underfill.txt 2>&1
+python3 tools/trace_gaps.py $O/${T}_marlin_prove_trace/m_kernel_trace.csv 0 100 --period=k_denoms_k:-4 >> $O/${T}_marlin_underfill.txt 2>&1
+for c in "SQ_INSTS_VALU SQ_INSTS_VALU_INT64 SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS"; do d=$O/${T}_nttpmc_$(echo $c | cut -c4-16 | tr ' ' '_'); rocprofv3 --kernel-trace --pmc $c -d $d -o p --output-format csv -- python3 tools/bench_ntt.py 20 2 20 > $d.log 2>&1; done
+[ -x tools/_bin/ubench_chain ] && tools/_bin/ubench_chain > $O/${T}_ubench_chain.txt 2>&1
 ls $O | grep "^${T}_"
