@@ -181,16 +181,18 @@ k_digit_keys(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, 
 }
 
 // offs[b] = first position of bucket b in the sorted keys, for every b <= NB (empty buckets get the next bucket's start;
-// offs[NB] = number of non-zero digits).  A thread at the first element of a run fills the offsets of its own bucket and of
-// the empty buckets just below it; the last thread fills what lies above the last key.
+// offs[NB] = number of non-zero digits: the key of a zero digit is NB).  One binary search per bucket: 2^19 x 24 reads whatever
+// the keys are.  (The first form walked the gaps between neighbouring keys from the keys' side: with all scalars zero, or all
+// equal, one thread filled 2^19 offsets by itself -- 7 ms.)
 __global__ void __launch_bounds__(256)
 k_offs_from_sorted(const uint32_t* __restrict__ skey, size_t total, uint32_t NB, uint32_t* __restrict__ offs) {
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t k = skey[t];
-        const uint32_t lo = t ? skey[t - 1] + 1 : 0u;          // keys are <= NB, so no wrap
-        for (uint32_t b = lo; b <= k; b++) offs[b] = (uint32_t)t;
-        if (t == total - 1)
-            for (uint32_t b = k + 1; b <= NB; b++) offs[b] = (uint32_t)total;
+    for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b <= NB; b += (size_t)gridDim.x * blockDim.x) {
+        size_t lo = 0, hi = total;                       // first t with skey[t] >= b
+        while (lo < hi) {
+            const size_t mid = (lo + hi) >> 1;
+            if (skey[mid] < (uint32_t)b) lo = mid + 1; else hi = mid;
+        }
+        offs[b] = (uint32_t)lo;
     }
 }
 __global__ void __launch_bounds__(256) k_counts_from_offs(const uint32_t* __restrict__ offs, uint32_t NB, uint32_t* __restrict__ counts) {
@@ -775,7 +777,7 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
                            job->n_tab, job->tab_off);
         if (zk_sort_pairs(st, tmp, tmp_bytes, b.dig, skey, vals, b.sorted, total, key_bits) != 0)
             ZK_FAIL(ctx, ZK_ERR_HIP, "msm: radix sort failed");
-        hipLaunchKernelGGL(k_offs_from_sorted, zk_grid(total, 256), 256, 0, st, (const uint32_t*)skey, total, NBt, b.offs);
+        hipLaunchKernelGGL(k_offs_from_sorted, zk_grid((size_t)NBt + 1, 256), 256, 0, st, (const uint32_t*)skey, total, NBt, b.offs);
         hipLaunchKernelGGL(k_counts_from_offs, zk_grid(NBt, 256), 256, 0, st, (const uint32_t*)b.offs, NBt, b.counts);
         ZK_TRY(scans(1, NBt));                                 // rewrites offs (same values) and produces the segment counts
         hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
