@@ -197,6 +197,8 @@ def test_msm_precomputed_window_multiples(ctx, group, n):
     check([prng.fr() for _ in range(n)])
     check([(prng.u64() & 1) if i % 5 else prng.fr() for i in range(n)])          # boolean-heavy witness
     check([12345678901234567890123] * n)                                          # all equal
+    check([0] * n)                                                                # all zero: every digit is the 'none' key
+    check([0] * (n - 3) + [5, 0, r - 1])                                          # nearly all zero
     check([r - 1, r - 2, 1, 0, (r - 1) // 2, 1 << 252, (1 << 16) - 1, 1 << 16] * (n // 8))
     check([prng.fr() for _ in range(n - 7)], off=7)                               # offset + shorter
     bases.free()
