@@ -474,17 +474,30 @@ class Party:
             acc = self.be.fr_add(acc, q)
         return acc
 
-    def scale_g1(self, s_pt, o_sc):
-        """GroupShare::scale with DummyGroupTripleSource: x = 0, y = [leader ? 1 : 0], z = 0."""
+    def scale_g1(self, s_pt, o_sc, lazy=False):
+        """GroupShare::scale with DummyGroupTripleSource: x = 0, y = [leader ? 1 : 0], z = 0.
+        lazy: the two opens happen here, in program order; the local arithmetic behind them (a full scalar multiplication on
+        the leader) goes to a host thread and the call returns its future."""
         be = self.be
         y = be.fr_one() if self.leader else np.zeros(4, dtype=np.uint64)
         sx = self._open_g(s_pt, be.g1_add)                         # open(s + x), x = 0
         oy = self._open_fr(be.fr_add(o_sc, y))                     # open(o + y)
-        out = be.g1_neg(be.g1_mul(sx, y))                          # z - scale_pub_group(sx, y)       (z = 0)
-        # - x * oy with x = 0 contributes nothing
-        if self.leader:
-            out = be.g1_add(out, be.g1_mul(sx, oy))                # shift(sx * oy): leader only
-        return out
+
+        def finish():
+            out = be.g1_neg(be.g1_mul(sx, y))                      # z - scale_pub_group(sx, y)       (z = 0)
+            # - x * oy with x = 0 contributes nothing
+            if self.leader:
+                out = be.g1_add(out, be.g1_mul(sx, oy))            # shift(sx * oy): leader only
+            return out
+        return self._early(finish) if lazy else finish()
+
+    def _early(self, fn, *args):
+        """fn(*args) on a host thread: a future.  For host-side group algebra that need not wait for the device."""
+        pool = getattr(self, "_pool", None)
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = self._pool = ThreadPoolExecutor(max_workers=6)
+        return pool.submit(fn, *args)
 
     # ---- reveal ----
     def reveal_g1(self, p): return self._open_g(p, self.be.g1_add)
@@ -497,6 +510,11 @@ class Party:
         Returns the revealed 192-byte proof (identical on every party)."""
         be = self.be
         D = be.domain_size(r1cs)
+        P = self._pk_points(pk)
+        # public point x shared scalar is local host arithmetic (0.4 ms per G1, 1.2 ms per G2 scalar multiplication): the three
+        # that do not depend on the MSMs run on host threads under the device work (the library calls release the GIL)
+        early = self._early(be.g1_mul, P["delta_g1"], r_share), self._early(be.g1_mul, P["delta_g1"], s_share), \
+            self._early(be.g2_mul, P["delta_g2"], s_share)
         a, b, c = be.vec("wm_a", D), be.vec("wm_b", D), be.vec("wm_c", D)
         be.witness_map_pre(r1cs, z_share, a, b, c)                 # local: linear in the shares
         be.msms_presort(pk, r1cs, z_share)                         # the MSMs' shared sort of z runs under the open below
@@ -504,20 +522,19 @@ class Party:
         be.witness_map_post(r1cs, a, c)                            # h shares in `a`
         g1, g2 = be.msms(pk, r1cs, z_share, a)                     # party-local MSMs (multi_scale_pub_group)
         h_acc, l_acc, a_acc, b1_acc = g1[0], g1[1], g1[2], g1[3]
-        P = self._pk_points(pk)
         pub1 = (lambda x: x) if self.leader else (lambda x: be.g1_zero())   # shift(): leader only
         pub2 = (lambda x: x) if self.leader else (lambda x: be.g2_zero())
-        r_g1 = be.g1_mul(P["delta_g1"], r_share)                   # public point * shared scalar: local
-        r_s_delta = self.scale_g1(r_g1, s_share)                   # :115
+        r_g1 = early[0].result()                                   # delta_g1 * r: public point * shared scalar, local
+        r_s_delta = self.scale_g1(r_g1, s_share, lazy=True)        # :115
         g_a = be.g1_add(be.g1_add(be.g1_add(r_g1, pub1(P["a0"])), a_acc), pub1(P["alpha_g1"]))   # calculate_coeff
-        s_g_a = self.scale_g1(g_a, s_share)                        # :140
-        s_g1 = be.g1_mul(P["delta_g1"], s_share)
+        s_g_a = self.scale_g1(g_a, s_share, lazy=True)             # :140
+        s_g1 = early[1].result()
         g1_b = be.g1_add(be.g1_add(be.g1_add(s_g1, pub1(P["b0_g1"])), b1_acc), pub1(P["beta_g1"]))
-        s_g2 = be.g2_mul(P["delta_g2"], s_share)
+        s_g2 = early[2].result()
         g2_b = be.g2_add(be.g2_add(be.g2_add(s_g2, pub2(P["b0_g2"])), g2), pub2(P["beta_g2"]))
-        r_g1_b = self.scale_g1(g1_b, r_share)                      # :161
-        g_c = be.g1_add(s_g_a, r_g1_b)                             # :169-174
-        g_c = be.g1_add(g_c, be.g1_neg(r_s_delta))
+        r_g1_b = self.scale_g1(g1_b, r_share, lazy=True)           # :161
+        g_c = be.g1_add(s_g_a.result(), r_g1_b.result())           # :169-174
+        g_c = be.g1_add(g_c, be.g1_neg(r_s_delta.result()))
         g_c = be.g1_add(g_c, l_acc)
         g_c = be.g1_add(g_c, h_acc)
         A, B, C = self.reveal_g1(g_a), self.reveal_g2(g2_b), self.reveal_g1(g_c)     # Proof::reveal
@@ -679,19 +696,20 @@ class SpdzParty(Party):
     def _minus_one(self):
         return self.be.fr_sub(np.zeros(4, dtype=np.uint64), self.be.fr_one())
 
-    def spdz_scale_g1(self, s_pt, o_sc):
-        """GroupShare::scale over SPDZ shares with DummyGroupTripleSource (x = 0, y = from_add_shared(leader?1:0), z = 0)."""
+    def spdz_scale_g1(self, s_pt, o_sc, lazy=False):
+        """GroupShare::scale over SPDZ shares with DummyGroupTripleSource (x = 0, y = from_add_shared(leader?1:0), z = 0).
+        lazy: as Party.scale_g1 (the opens here, the local arithmetic on a host thread, a future back)."""
         be = self.be
         y = be.fr_one() if self.leader else np.zeros(4, dtype=np.uint64)
         sx = self.spdz_open_g1(s_pt)                                              # x = 0
         oy = self.spdz_open_fr((be.fr_add(o_sc[0], y), be.fr_add(o_sc[1], y)))    # from_add_shared: mac = share (key 1)
-        out = []
-        for lane in (0, 1):
+
+        def finish():
             t = be.g1_neg(be.g1_mul(sx, y))                                       # - scale_pub_group(sx, y)
             if self.leader:
                 t = be.g1_add(t, be.g1_mul(sx, oy))                               # shift: sh on the leader, mac += mac_share * G
-            out.append(t)
-        return tuple(out)
+            return (t, t)                                                         # both lanes hold the same value (key 1)
+        return self._early(finish) if lazy else finish()
 
     def marlin_prove_shared_spdz(self, index, powers_g, z_share, randomness_share, challenge_fn, triple_fn=None) -> dict:
         """Marlin::prove over SPDZ shares (the `malicious` feature, BASELINE config 5 shape): the AHP rounds run on the
@@ -754,6 +772,10 @@ class SpdzParty(Party):
         z_share = (sh, mac) device vectors; r_share, s_share = (sh, mac) scalars."""
         be = self.be
         D = be.domain_size(r1cs)
+        P = self._pk_points(pk)
+        early = {(k, lane): self._early(fn, P[pt], sc[lane]) for lane in (0, 1)       # see create_proof_shared
+                 for k, fn, pt, sc in (("r_g1", be.g1_mul, "delta_g1", r_share), ("s_g1", be.g1_mul, "delta_g1", s_share),
+                                       ("s_g2", be.g2_mul, "delta_g2", s_share))}
         lanes = []
         for lane in (0, 1):
             a, b, c = be.vec("wm_a%d" % lane, D), be.vec("wm_b%d" % lane, D), be.vec("wm_c%d" % lane, D)
@@ -766,7 +788,6 @@ class SpdzParty(Party):
         for lane in (0, 1):
             be.witness_map_post(r1cs, lanes[lane][0], lanes[lane][2])
             msm.append(be.msms(pk, r1cs, z_share[lane], lanes[lane][0]))       # 2 x 5 MSMs (spdz.rs:482-488)
-        P = self._pk_points(pk)
         pair = lambda f: tuple(f(lane) for lane in (0, 1))
         pub1 = (lambda x: x) if self.leader else (lambda x: be.g1_zero())      # shift: leader's sh; mac += mac_share * G
         pub2 = (lambda x: x) if self.leader else (lambda x: be.g2_zero())
@@ -774,16 +795,16 @@ class SpdzParty(Party):
         neg1 = lambda u: (be.g1_neg(u[0]), be.g1_neg(u[1]))
         h_acc, l_acc, a_acc, b1_acc = [pair(lambda lane, k=k: msm[lane][0][k]) for k in range(4)]
         b2_acc = pair(lambda lane: msm[lane][1])
-        r_g1 = pair(lambda lane: be.g1_mul(P["delta_g1"], r_share[lane]))
-        r_s_delta = self.spdz_scale_g1(r_g1, s_share)
+        r_g1 = pair(lambda lane: early[("r_g1", lane)].result())
+        r_s_delta = self.spdz_scale_g1(r_g1, s_share, lazy=True)
         g_a = pair(lambda lane: be.g1_add(be.g1_add(be.g1_add(r_g1[lane], pub1(P["a0"])), a_acc[lane]), pub1(P["alpha_g1"])))
-        s_g_a = self.spdz_scale_g1(g_a, s_share)
-        s_g1 = pair(lambda lane: be.g1_mul(P["delta_g1"], s_share[lane]))
+        s_g_a = self.spdz_scale_g1(g_a, s_share, lazy=True)
+        s_g1 = pair(lambda lane: early[("s_g1", lane)].result())
         g1_b = pair(lambda lane: be.g1_add(be.g1_add(be.g1_add(s_g1[lane], pub1(P["b0_g1"])), b1_acc[lane]), pub1(P["beta_g1"])))
-        s_g2 = pair(lambda lane: be.g2_mul(P["delta_g2"], s_share[lane]))
+        s_g2 = pair(lambda lane: early[("s_g2", lane)].result())
         g2_b = pair(lambda lane: be.g2_add(be.g2_add(be.g2_add(s_g2[lane], pub2(P["b0_g2"])), b2_acc[lane]), pub2(P["beta_g2"])))
-        r_g1_b = self.spdz_scale_g1(g1_b, r_share)
-        g_c = add1(add1(add1(add1(s_g_a, r_g1_b), neg1(r_s_delta)), l_acc), h_acc)
+        r_g1_b = self.spdz_scale_g1(g1_b, r_share, lazy=True)
+        g_c = add1(add1(add1(add1(s_g_a.result(), r_g1_b.result()), neg1(r_s_delta.result())), l_acc), h_acc)
         Ap, Bp, Cp = self.spdz_open_g1(g_a), self.spdz_open_g2(g2_b), self.spdz_open_g1(g_c)   # SpdzGroupShare::reveal
         return be.g1_serialize(Ap) + be.g2_serialize(Bp) + be.g1_serialize(Cp)
 
