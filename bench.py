@@ -256,8 +256,8 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
 
         def step():
             if args.spdz:
-                return party.marlin_prove_full_spdz(keys, (zb[0], zb[1]), Rng.from_seed(seed, 20))
-            return party.marlin_prove_full(keys, zb[0], Rng.from_seed(seed, 20))
+                return party.marlin_prove_full_spdz(keys, (zb[0], zb[1]), Rng.from_seed(seed, 20), mask_on_device=True)
+            return party.marlin_prove_full(keys, zb[0], Rng.from_seed(seed, 20), mask_on_device=True)
 
     def barrier():
         if dist is not None:

@@ -595,13 +595,13 @@ class Party:
 
 
     # ---- collaborative Marlin as a PROOF: transcript, hiding commitments, open_combinations over shares ----
-    def marlin_prove_full(self, keys, z_share, zk_rng, triple_fn=None):
+    def marlin_prove_full(self, keys, z_share, zk_rng, triple_fn=None, mask_on_device=False):
         """MpcMarlin::prove (src/marlin.rs:56 -> arkworks/marlin/src/lib.rs:152-319 with F = MpcField) over additive shares:
         the complete proof, as `marlin.prove` emits it for one prover.  z_share: this party's share of the padded assignment
         (DevBuf; instance on the leader); zk_rng: this party's OWN generator -- every draw is a share (MpcField::rand), the
         effective randomness is the sum over parties.  The revealed proof is identical on every party and equal to the local
         proof on the summed inputs and summed randomness."""
-        return _marlin_prove_full(self, keys, [z_share], zk_rng, triple_fn, spdz=False)
+        return _marlin_prove_full(self, keys, [z_share], zk_rng, triple_fn, spdz=False, mask_on_device=mask_on_device)
 
 # ------------------------------------------------------------------------------------------------
 # SPDZ (malicious-majority backend): every share carries a MAC share; opens are MAC-checked
@@ -809,14 +809,14 @@ class SpdzParty(Party):
         return be.g1_serialize(Ap) + be.g2_serialize(Bp) + be.g1_serialize(Cp)
 
 
-    def marlin_prove_full_spdz(self, keys, z_share, zk_rng, triple_fn=None):
+    def marlin_prove_full_spdz(self, keys, z_share, zk_rng, triple_fn=None, mask_on_device=False):
         """The same over SPDZ shares (the `malicious` feature; BASELINE config 5's prover): z_share = (share, MAC) DevBufs, every
         open MAC-checked.  The MAC lane of this party's fresh randomness is the share itself (key alpha = 1 on the leader:
         sum of MAC shares = sum of shares), as the reference's from_add_shared does."""
-        return _marlin_prove_full(self, keys, list(z_share), zk_rng, triple_fn, spdz=True)
+        return _marlin_prove_full(self, keys, list(z_share), zk_rng, triple_fn, spdz=True, mask_on_device=mask_on_device)
 
 
-def _marlin_prove_full(party, keys, z_lanes, zk_rng, triple_fn, spdz: bool):
+def _marlin_prove_full(party, keys, z_lanes, zk_rng, triple_fn, spdz: bool, mask_on_device: bool = False):
     from . import convert as cv
     from . import marlin as DM
     from .api import Rng
@@ -828,6 +828,16 @@ def _marlin_prove_full(party, keys, z_lanes, zk_rng, triple_fn, spdz: bool):
     lanes = range(len(z_lanes))
     shared = Party.SHARED_POLYS
     leader = party.leader
+    import os as _os
+    import time as _time
+    _laps, _t = [], [_time.perf_counter()]
+
+    def lap(name):                                      # ZK_MPC_TIMING=1: host wall-clock laps on stderr
+        if _os.environ.get("ZK_MPC_TIMING"):
+            ctx.sync()
+            now = _time.perf_counter()
+            _laps.append("%s %.1f" % (name, (now - _t[0]) * 1e3))
+            _t[0] = now
 
     def open_g1(pts):                                   # pts: one projective array per lane
         return party.spdz_open_g1(tuple(pts)) if spdz else party.reveal_g1(pts[0])
@@ -856,7 +866,9 @@ def _marlin_prove_full(party, keys, z_lanes, zk_rng, triple_fn, spdz: bool):
         """Shares of the commitments on every lane under the same draws, then the reveal of the witness-dependent ones
         (`comms.publicize()`, lib.rs:180,205,228); public oracles commit alike on every party."""
         rr = DM._draw_round_randomness(keys, labels, zk_rng)
-        res = [DM._commit_round(keys, labels, round_polys[lane], zk_rng, rands=rr, raw=True)[0] for lane in lanes]
+        # public oracles (t, g_2, h_2) are the same on every lane: committed once
+        res = [DM._commit_round(keys, labels if lane == 0 else [l for l in labels if l in shared], round_polys[lane], zk_rng, rands=rr,
+                                raw=True)[0] for lane in lanes]
         out = {}
         for l in labels:
             if l in shared:
@@ -871,11 +883,23 @@ def _marlin_prove_full(party, keys, z_lanes, zk_rng, triple_fn, spdz: bool):
 
     # ---- round 1: every draw is this party's share of the prover's randomness
     md = DM.mask_poly_degree(index)
-    rnd = ctx.upload(zk_rng.fill_fr(3 + md + 1))
+    if mask_on_device:
+        # this party's share of the mask polynomial sampled on the device under a key from its rng (marlin.py::prove:
+        # 3 |H| draws from a host ChaCha generator take 0.19 s at 2^20, more than the rest of the proof)
+        rnd = ctx.alloc((3 + md + 1) * 32)
+        head = ctx.upload(zk_rng.fill_fr(3))
+        ctx.memcpy_d2d(rnd.ptr, head.ptr, 96)
+        ctx.fr_random_dev(rnd.ptr + 96, md + 1, zk_rng.fill_bytes(32))
+        ctx.sync()
+    else:
+        rnd = ctx.upload(zk_rng.fill_fr(3 + md + 1))
+    lap("init+rng")
     r1 = [DM.prover_first_round(st[lane], rnd) for lane in lanes]
     for lane in lanes:
         polys[lane].update(r1[lane])
+    lap("round1")
     commit_round(DM.ROUND_LABELS[0], r1)
+    lap("commit1")
     ch["alpha"] = DM._sample_outside(index.dom_h, fs)
     ch["eta_a"], ch["eta_b"], ch["eta_c"] = ival(fs.next_fr()), ival(fs.next_fr()), ival(fs.next_fr())
     # ---- round 2: the lanes advance in lock-step around ONE Beaver product and one opened zero test
@@ -903,13 +927,17 @@ def _marlin_prove_full(party, keys, z_lanes, zk_rng, triple_fn, spdz: bool):
             r2.append(done.value)
     for lane in lanes:
         polys[lane].update(r2[lane])
+    lap("round2")
     commit_round(DM.ROUND_LABELS[1], r2)
+    lap("commit2")
     ch["beta"] = DM._sample_outside(index.dom_h, fs)
     # ---- round 3: public values only
     r3 = DM.prover_third_round(st[0], ch["beta"])
     for lane in lanes:
         polys[lane].update(r3)
+    lap("round3")
     commit_round(DM.ROUND_LABELS[2], [r3 for _ in lanes])
+    lap("commit3")
     ch["gamma"] = ival(fs.next_fr())
     # ---- evaluations: shared oracles are evaluated on the shares and opened (`evaluations.publicize()`)
     ev = lambda lane, l, pt: ctx.poly_evaluate_dev(polys[lane][l].ptr, polys[lane][l].n, m(pt))
@@ -924,6 +952,7 @@ def _marlin_prove_full(party, keys, z_lanes, zk_rng, triple_fn, spdz: bool):
     fs.absorb(b"".join(DM._fr_bytes(e) for e in evaluations))
     xi = fs.next_u128() % R_MOD
     ch["xi"] = xi
+    lap("evals")
     # ---- open_combinations on the shares: the witness of a share combination is a share of the witness; public polynomials
     # enter a shared combination through shift(), i.e. on the leader (in both lanes: mac_share = 1 there)
     point = {"beta": ch["beta"], "gamma": ch["gamma"]}
@@ -991,4 +1020,8 @@ def _marlin_prove_full(party, keys, z_lanes, zk_rng, triple_fn, spdz: bool):
         w = open_g1(wit) if any_shared else wit[0]
         pc_proof.append((w, rv))
     ctx.sync()
+    lap("open")
+    if _laps:
+        import sys as _sys
+        print("marlin_prove_full ms: " + " ".join(_laps), file=_sys.stderr)
     return DM.MarlinProof([[comms[l] for l in rnd_labels] for rnd_labels in DM.ROUND_LABELS], evaluations, pc_proof, ch)
