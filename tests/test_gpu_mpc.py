@@ -519,8 +519,8 @@ class _SumRng:
         return cv.fr_to_mont(tot) if n else np.zeros((0, 4), dtype=np.uint64)
 
 
-@pytest.mark.parametrize("n_parties,n,spdz", [(2, 6, False), (3, 40, False), (2, 13, True), (8, 21, True)])
-def test_collaborative_marlin_full_proof(n_parties, n, spdz):
+@pytest.mark.parametrize("n_parties,n,spdz,mask_dev", [(2, 6, False, False), (3, 40, False, True), (2, 13, True, True), (8, 21, True, False)])
+def test_collaborative_marlin_full_proof(n_parties, n, spdz, mask_dev):
     """MpcMarlin::prove as a PROOF (src/marlin.rs:56): each party runs the rounds on its shares with its own generator, the
     witness-dependent commitments / evaluations / opening witnesses are revealed (MAC-checked under SPDZ), the transcript
     runs on the revealed values.  Every party ends with the same bytes; they equal the single prover's proof on the summed
@@ -548,9 +548,9 @@ def test_collaborative_marlin_full_proof(n_parties, n, spdz):
         keys = setup(ctx)
         up = lambda v: ctx.upload(cv.fr_to_mont(v))
         if spdz:
-            proof = party.marlin_prove_full_spdz(keys, (up(zs[p]), up(zm[p])), Rng.from_seed(seeds[p], 20))
+            proof = party.marlin_prove_full_spdz(keys, (up(zs[p]), up(zm[p])), Rng.from_seed(seeds[p], 20), mask_on_device=mask_dev)
         else:
-            proof = party.marlin_prove_full(keys, up(zs[p]), Rng.from_seed(seeds[p], 20))
+            proof = party.marlin_prove_full(keys, up(zs[p]), Rng.from_seed(seeds[p], 20), mask_on_device=mask_dev)
         return proof.serialize(ctx), proof.evaluations, [[(cc.comm_aff, cc.shifted_aff, cc.shifted is not None) for cc in rnd] for rnd in proof.commitments], \
             [(cv.g1_projective_to_affine(w), rv) for w, rv in proof.pc_proof]
 
@@ -559,8 +559,9 @@ def test_collaborative_marlin_full_proof(n_parties, n, spdz):
     ctx = Z.Context(0)
     try:
         keys = setup(ctx)
-        local = DM.prove(keys, ctx.upload(cv.fr_to_mont(zz)), _SumRng(seeds))
-        assert local.serialize(ctx) == res[0][0]
+        if not mask_dev:        # with the mask sampled on the device the joint randomness is not the sum of the host streams
+            local = DM.prove(keys, ctx.upload(cv.fr_to_mont(zz)), _SumRng(seeds))
+            assert local.serialize(ctx) == res[0][0]
         oix = M.Index(sq)
         pp = O.KzgParams(keys.srs.max_degree, beta_srs, g_k=g_k, gg_k=gg_k, h_k=h_k)
         okeys = MF.Keys(oix, pp)
