@@ -167,11 +167,14 @@ def test_msm_large_discrete_log_check(ctx, log_n):
         prod.free()
 
 
-@pytest.mark.parametrize("group,n", [(1, 5000), (1, 1 << 16), (2, 6000)])
-def test_msm_precomputed_window_multiples(ctx, group, n):
+@pytest.mark.parametrize("group,n,part", [(1, 5000, 0), (1, 1 << 16, 0), (2, 6000, 0), (1, 5000, 1), (1, (1 << 16) + 77, 1)])
+def test_msm_precomputed_window_multiples(ctx, group, n, part, monkeypatch):
     """Resident bases with precomputed 2^(c w) multiples (one bucket set for all windows): random scalars,
     witness-like 0/1-heavy scalars, all-equal scalars (every point in one bucket per window), extreme scalars and
-    an offset sub-range must give the same group element as the discrete-log identity."""
+    an offset sub-range must give the same group element as the discrete-log identity.  part = 1: through the partition sort
+    (ZK_SORT_PART, an experiment kept behind its switch) instead of the radix sort."""
+    if part:
+        monkeypatch.setenv("ZK_SORT_PART", "1")
     rs = np.random.RandomState(group * 100 + (n & 0xff))
     km = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64)
     km[:, 3] &= np.uint64((1 << 60) - 1)

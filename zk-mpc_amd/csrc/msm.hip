@@ -180,6 +180,206 @@ k_digit_keys(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, 
     }
 }
 
+// ---- partition sort (experiment, ZK_SORT_PART=1): the same grouping in ~270 MB of traffic instead of the radix sort's ~900 MB ----
+// Only the grouping by bucket matters (the order inside a bucket does not: the group is commutative, outputs are canonical), and
+// the pairs need not exist before they are grouped.  Buckets are cut into bins of 2^PART_F = 1024 consecutive bucket ids:
+//   k_part_hist    bin sizes: the digits are computed from the scalars, counted per block in LDS, one global add per (block, bin)
+//   k_part_scan    exclusive scan of the (<= 4096) bin sizes
+//   k_part_scatter the digits are computed AGAIN (cheaper than keeping 13 pairs per scalar); a block of 1024 lanes takes 2048
+//                  scalars, reserves one run per bin with one global atomic, and writes (low key bits, entry) into its runs
+//   k_part_bins    one block per bin: 1024-counter histogram of the low key bits in LDS, scan -> the bucket offsets of the bin
+//                  (written straight to offs: no pass over sorted keys), then the entries go to their bucket's range
+// Zero digits produce no pair at all.  Heavy buckets (0/1 witnesses, repeated scalars) make a bin long, not the method slow: a
+// bin is streamed, never staged.
+constexpr uint32_t PART_F = 10;           // low key bits sorted inside a bin: bins of 1024 bucket ids (runs of ~50 pairs per block and bin)
+constexpr uint32_t PART_BIN = 1u << PART_F;
+constexpr uint32_t PART_TILE = 2048;      // scalars per block step (1024 lanes x 2)
+
+// words of (canonical scalar + bias) of scalar i into column `col` of kw (9 x PART_TILE words)
+__device__ __forceinline__ void part_load_scalar(const void* scalars, size_t i, const Bias& bias, uint32_t (*kw)[PART_TILE], uint32_t col) {
+    Fr s = fp_ext_to_canon<FrParams>(fr_load(scalars, i));
+    uint32_t w8[8];
+    fp_pack<FrParams>(w8, s);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        uint64_t t = (uint64_t)(k < 8 ? w8[k] : 0u) + bias.w[k] + carry;
+        kw[k][col] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+    }
+}
+// digit w of the scalar in column col: false for a zero digit; bucket = its id in the ONE sorted bucket space, neg = its sign
+__device__ __forceinline__ bool part_digit(const uint32_t (*kw)[PART_TILE], uint32_t col, const WinOff& wo, uint32_t w, uint32_t NB, int merged,
+                                           uint32_t& bucket, uint32_t& neg) {
+    const uint32_t bit = wo.off[w], cw = wo.off[w + 1] - bit;
+    const uint32_t half = 1u << (cw - 1), mask = (1u << cw) - 1;
+    const uint32_t wi = bit >> 5, sh = bit & 31;
+    uint64_t two = kw[wi][col];
+    if (wi + 1 < 9) two |= (uint64_t)kw[wi + 1][col] << 32;
+    const int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (int32_t)half;
+    if (d == 0) return false;
+    const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+    bucket = (merged ? 0u : w * NB) + mag - 1;
+    neg = d < 0 ? 0x80000000u : 0u;
+    return true;
+}
+
+__global__ void __launch_bounds__(1024)
+k_part_hist(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, int merged, uint32_t NC, uint32_t* bin_count) {
+    extern __shared__ uint32_t part_lds[];
+    uint32_t (*kw)[PART_TILE] = reinterpret_cast<uint32_t (*)[PART_TILE]>(part_lds);
+    uint32_t* cnt = part_lds + 9 * PART_TILE;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b = tid; b < NC; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    for (size_t t0 = (size_t)blockIdx.x * PART_TILE; t0 < n; t0 += (size_t)gridDim.x * PART_TILE) {
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint32_t col = tid + k * 1024;
+            const size_t i = t0 + col;
+            if (i >= n) continue;
+            part_load_scalar(scalars, i, bias, kw, col);
+            for (uint32_t w = 0; w < W; w++) {
+                uint32_t bucket, neg;
+                if (part_digit(kw, col, wo, w, NB, merged, bucket, neg)) atomicAdd(&cnt[bucket >> PART_F], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < NC; b += 1024)
+        if (cnt[b]) atomicAdd(&bin_count[b], cnt[b]);
+}
+
+// bin_start[b] = sum of the sizes of the bins before b (b <= NC), cursor = a copy the scatter consumes.  One block, NC <= 4096.
+__global__ void __launch_bounds__(1024) k_part_scan(const uint32_t* bin_count, uint32_t NC, uint32_t* bin_start, uint32_t* cursor) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    uint32_t v[4], s = 0;
+    for (uint32_t k = 0; k < 4; k++) { const uint32_t b = tid * 4 + k; v[k] = b < NC ? bin_count[b] : 0; s += v[k]; }
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint32_t x = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t b = tid * 4 + k;
+        if (b <= NC) { bin_start[b] = run; if (b < NC) cursor[b] = run; }
+        run += v[k];
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_part_scatter(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, int merged, uint32_t NC, uint32_t n_tab,
+               uint32_t tab_off, uint32_t* cursor, uint16_t* key8, uint32_t* val) {
+    extern __shared__ uint32_t part_lds[];
+    uint32_t (*kw)[PART_TILE] = reinterpret_cast<uint32_t (*)[PART_TILE]>(part_lds);
+    uint32_t* cnt = part_lds + 9 * PART_TILE;
+    uint32_t* base = cnt + NC;
+    const uint32_t tid = threadIdx.x;
+    for (size_t t0 = (size_t)blockIdx.x * PART_TILE; t0 < n; t0 += (size_t)gridDim.x * PART_TILE) {
+        for (uint32_t b = tid; b < NC; b += 1024) cnt[b] = 0;
+        __syncthreads();
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint32_t col = tid + k * 1024;
+            const size_t i = t0 + col;
+            if (i >= n) continue;
+            part_load_scalar(scalars, i, bias, kw, col);
+            for (uint32_t w = 0; w < W; w++) {
+                uint32_t bucket, neg;
+                if (part_digit(kw, col, wo, w, NB, merged, bucket, neg)) atomicAdd(&cnt[bucket >> PART_F], 1u);
+            }
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < NC; b += 1024) {
+            const uint32_t c = cnt[b];
+            if (c) base[b] = atomicAdd(&cursor[b], c);        // this block's run inside bin b
+            cnt[b] = 0;
+        }
+        __syncthreads();
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint32_t col = tid + k * 1024;
+            const size_t i = t0 + col;
+            if (i >= n) continue;
+            for (uint32_t w = 0; w < W; w++) {
+                uint32_t bucket, neg;
+                if (!part_digit(kw, col, wo, w, NB, merged, bucket, neg)) continue;
+                const uint32_t bin = bucket >> PART_F;
+                const uint32_t pos = base[bin] + atomicAdd(&cnt[bin], 1u);
+                key8[pos] = (uint16_t)(bucket & (PART_BIN - 1));
+                val[pos] = (merged ? (uint32_t)(w * n_tab + tab_off + i) : (uint32_t)i) | neg;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One block per bin: offs[bucket] for the bin's buckets, and its entries moved to their bucket's range of `sorted`.  A bin that
+// fits (PART_STAGE entries: all but the bins of heavy buckets) is put in order in LDS and leaves as one contiguous copy --
+// scattered 4-byte stores cost a 64-byte L2 transaction each; a longer bin scatters straight to memory.
+constexpr uint32_t PART_STAGE = 28672;          // x 4 B = 112 KiB of LDS
+__global__ void __launch_bounds__(PART_BIN)
+k_part_bins(const uint16_t* __restrict__ key8, const uint32_t* __restrict__ val, const uint32_t* __restrict__ bin_start, uint32_t NC,
+            uint32_t NBt, uint32_t* __restrict__ sorted, uint32_t* __restrict__ offs) {
+    extern __shared__ uint32_t part_lds[];
+    uint32_t* hist = part_lds;                   // PART_BIN counters, later cursors
+    uint32_t* wsum = part_lds + PART_BIN;        // one total per wave (16)
+    uint32_t* stage = part_lds + PART_BIN + 64;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t lo = bin_start[b], hi = bin_start[b + 1], cnt = hi - lo;
+    hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i0 = lo + tid; i0 < hi; i0 += 4 * PART_BIN) {       // four loads in flight per lane
+        uint32_t k[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) k[u] = i0 + u * PART_BIN < hi ? key8[i0 + u * PART_BIN] : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (k[u] != 0xffffffffu) atomicAdd(&hist[k[u]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the PART_BIN counters: inside a wave by shuffles, across the 16 waves through LDS
+    const uint32_t mine = hist[tid];
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x = __shfl_up(inc, d, 64);
+        if ((tid & 63) >= (uint32_t)d) inc += x;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (tid >> 6); w++) before += wsum[w];
+    const uint32_t off = before + inc - mine;              // exclusive
+    const uint32_t id = (b << PART_F) + tid;
+    if (id <= NBt) offs[id] = lo + off;
+    if (b == NC - 1 && tid == PART_BIN - 1 && ((NC << PART_F) == NBt)) offs[NBt] = hi;       // the end marker when the last bin is full
+    __syncthreads();
+    hist[tid] = off;                                       // now the cursors
+    __syncthreads();
+    const bool staged = cnt <= PART_STAGE;
+    for (uint32_t i0 = lo + tid; i0 < hi; i0 += 4 * PART_BIN) {
+        uint32_t k[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool in = i0 + u * PART_BIN < hi;
+            k[u] = in ? key8[i0 + u * PART_BIN] : 0xffffffffu;
+            v[u] = in ? val[i0 + u * PART_BIN] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (k[u] == 0xffffffffu) continue;
+            const uint32_t p = atomicAdd(&hist[k[u]], 1u);
+            if (staged) stage[p] = v[u]; else sorted[lo + p] = v[u];
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += PART_BIN) sorted[lo + i] = stage[i];
+    }
+}
+
 // offs[b] = first position of bucket b in the sorted keys, for every b <= NB (empty buckets get the next bucket's start;
 // offs[NB] = number of non-zero digits: the key of a zero digit is NB).  One binary search per bucket: 2^19 x 24 reads whatever
 // the keys are.  (The first form walked the gaps between neighbouring keys from the keys' side: with all scalars zero, or all
@@ -773,11 +973,39 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
         const size_t tmp_bytes = zk_sort_pairs_temp_bytes(total, key_bits);
         snprintf(nm2, sizeof nm2, "msm_sorttmp.%d", job->slot);
         ZK_TRY(zk_scratch(ctx, nm2, tmp_bytes, &tmp));
-        hipLaunchKernelGGL(k_digit_keys, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, vals, merged, NBt,
-                           job->n_tab, job->tab_off);
-        if (zk_sort_pairs(st, tmp, tmp_bytes, b.dig, skey, vals, b.sorted, total, key_bits) != 0)
-            ZK_FAIL(ctx, ZK_ERR_HIP, "msm: radix sort failed");
-        hipLaunchKernelGGL(k_offs_from_sorted, zk_grid((size_t)NBt + 1, 256), 256, 0, st, (const uint32_t*)skey, total, NBt, b.offs);
+        // ZK_SORT_PART=1 (experiment, read per call so that a test can switch it): the partition sort above instead of rocPRIM's
+        // radix sort of materialised pairs.  A third of the traffic, yet not faster: 0.59 ms alone against 0.54 (the pairs leave
+        // k_part_scatter as ~50-entry runs from 512 blocks, 64-byte L2 transactions for 6-byte payloads; the bins kernel is bound
+        // by its 27 M returning LDS atomics), and no difference in the pipelines (Groth16 18.0 / 18.0 ms, Marlin 82.3 / 81.7 ms).
+        const bool part = getenv("ZK_SORT_PART") && atoi(getenv("ZK_SORT_PART")) != 0;
+        const uint32_t NC = (NBt + PART_BIN - 1) >> PART_F;
+        if (part && NC <= 4096) {
+            uint32_t* bins;
+            snprintf(nm2, sizeof nm2, "msm_bins.%d", job->slot);
+            ZK_TRY(zk_scratch(ctx, nm2, (size_t)(3 * (NC + 1)) * 4, (void**)&bins));
+            uint32_t *bin_count = bins, *bin_start = bins + (NC + 1), *cursor = bins + 2 * (NC + 1);
+            if (!ctx->flags["part_lds"]) {
+                ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (9 * PART_TILE + 4096) * 4));
+                ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_part_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (9 * PART_TILE + 2 * 4096) * 4));
+                ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_part_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (PART_BIN + 64 + PART_STAGE) * 4));
+                ctx->flags["part_lds"] = 1;
+            }
+            ZK_HIP(ctx, hipMemsetAsync(bin_count, 0, (size_t)(NC + 1) * 4, st));
+            const unsigned tiles = (unsigned)((n + PART_TILE - 1) / PART_TILE);
+            const unsigned pg = tiles < 512 ? tiles : 512;
+            hipLaunchKernelGGL(k_part_hist, pg, 1024, (9 * PART_TILE + NC) * 4, st, job->scalars, n, wo, W, NB, bias, merged, NC, bin_count);
+            hipLaunchKernelGGL(k_part_scan, 1, 1024, 0, st, (const uint32_t*)bin_count, NC, bin_start, cursor);
+            hipLaunchKernelGGL(k_part_scatter, pg, 1024, (9 * PART_TILE + 2 * NC) * 4, st, job->scalars, n, wo, W, NB, bias, merged, NC,
+                               job->n_tab, job->tab_off, cursor, (uint16_t*)b.dig, vals);
+            hipLaunchKernelGGL(k_part_bins, NC, PART_BIN, (PART_BIN + 64 + PART_STAGE) * 4, st, (const uint16_t*)b.dig, (const uint32_t*)vals, (const uint32_t*)bin_start, NC, NBt,
+                               b.sorted, b.offs);
+        } else {
+            hipLaunchKernelGGL(k_digit_keys, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, vals, merged, NBt,
+                               job->n_tab, job->tab_off);
+            if (zk_sort_pairs(st, tmp, tmp_bytes, b.dig, skey, vals, b.sorted, total, key_bits) != 0)
+                ZK_FAIL(ctx, ZK_ERR_HIP, "msm: radix sort failed");
+            hipLaunchKernelGGL(k_offs_from_sorted, zk_grid((size_t)NBt + 1, 256), 256, 0, st, (const uint32_t*)skey, total, NBt, b.offs);
+        }
         hipLaunchKernelGGL(k_counts_from_offs, zk_grid(NBt, 256), 256, 0, st, (const uint32_t*)b.offs, NBt, b.counts);
         ZK_TRY(scans(1, NBt));                                 // rewrites offs (same values) and produces the segment counts
         hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
