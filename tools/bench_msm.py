@@ -18,12 +18,13 @@ def main():
     one = cv.fr_to_mont([1])[0]
     for group, top in ((1, max_log), (2, max_log - 2)):
         bases = ctx.fixed_base(d.ptr, 1 << top, group, one)
-        for lg in range(16, top + 1, 2):
+        ctx.sync()
+        for lg in reversed(range(16, top + 1, 2)):      # largest first: the scratch arena is sized once
             n = 1 << lg
-            for _ in range(3):                      # the first calls at a new size grow the scratch arena
+            for _ in range(4):                      # the first calls at a new size grow the scratch arena
                 ctx.msm_dev(bases, 0, d.ptr, n)
             ctx.sync()
-            reps = 3
+            reps = 5
             t0 = time.perf_counter()
             for _ in range(reps):
                 ctx.msm_dev(bases, 0, d.ptr, n)
