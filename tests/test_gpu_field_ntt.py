@@ -38,7 +38,7 @@ def test_batch_product_in_place_host(ctx):
     ctx.batch_product_in_place(am[:0], bm[:0])  # empty input
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 5, 8, 10, 11, 12, 13])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, 14, 15, 17])
 def test_ntt_variants(ctx, log_n):
     rng = O.Prng(200 + log_n)
     N = 1 << log_n
@@ -68,7 +68,7 @@ def test_ntt_zero_padding(ctx):
     assert cv.fr_from_mont(ctx.fft_in_place(cv.fr_to_mont(v), 6)) == dom.fft(v)
 
 
-@pytest.mark.parametrize("log_n", [16, 20, 21])
+@pytest.mark.parametrize("log_n", [16, 18, 19, 20, 21, 22])
 def test_ntt_large_properties(ctx, log_n):
     """Size-independent properties at the benchmark sizes: round trips, linearity, a spot DFT value."""
     N = 1 << log_n
