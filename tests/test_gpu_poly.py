@@ -57,6 +57,22 @@ def test_evaluate_batch(ctx):
     assert ctx.poly_evaluate_batch_dev([], np.zeros((0, 4), dtype=np.uint64)).shape == (0, 4)
 
 
+def test_divide_by_linear_beyond_256_spans(ctx):
+    """More than 256 spans of 4096 coefficients: the one-block suffix scan of the spans folds two per thread."""
+    rng = O.Prng(3200)
+    n = (1 << 20) + 4097 + 3
+    c = [rng.fr() for _ in range(2000)] + [0] * (n - 4000) + [rng.fr() for _ in range(2000)]
+    z = rng.fr()
+    d, q = up(ctx, c), ctx.alloc(n * 32)
+    rem = ctx.poly_divide_by_linear_dev(d.ptr, n, mont1(z), q.ptr)
+    want, acc = [0] * (n - 1), 0
+    for i in range(n - 1, 0, -1):
+        acc = (c[i] + acc * z) % O.R_MOD
+        want[i - 1] = acc
+    assert cv.fr_from_mont(ctx.download(q, (n - 1, 4))) == want
+    assert cv.fr_from_mont(rem.reshape(1, 4)) == [(c[0] + acc * z) % O.R_MOD]
+
+
 def test_divide_by_root_of_domain(ctx):
     """z inside the evaluation domain (where an evaluate-and-interpolate division would divide by zero)."""
     rng = O.Prng(31)
