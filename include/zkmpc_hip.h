@@ -166,6 +166,7 @@ int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* const* bases, c
 int zk_g1_add(const zk_g1_projective* a, const zk_g1_projective* b, zk_g1_projective* out);
 int zk_g2_add(const zk_g2_projective* a, const zk_g2_projective* b, zk_g2_projective* out);
 int zk_g1_neg(const zk_g1_projective* a, zk_g1_projective* out);
+int zk_g2_neg(const zk_g2_projective* a, zk_g2_projective* out);
 int zk_g1_mul(const zk_g1_projective* a, const zk_fr* k, zk_g1_projective* out);   /* ProjectiveCurve::mul */
 int zk_g2_mul(const zk_g2_projective* a, const zk_fr* k, zk_g2_projective* out);
 int zk_g1_from_affine(const zk_g1_affine* a, zk_g1_projective* out);

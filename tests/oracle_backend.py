@@ -130,6 +130,7 @@ class OracleBackend:
     def g1_add(self, a, b): return _proj1(O.g1_add(self._a1(a), self._a1(b)))
     def g2_add(self, a, b): return _proj2(O.g2_add(self._a2(a), self._a2(b)))
     def g1_neg(self, a): return _proj1(O.g1_neg(self._a1(a)))
+    def g2_neg(self, a): return _proj2(O.g2_neg(self._a2(a)))
     def g1_mul(self, a, k): return _proj1(O.g1_mul(self._a1(a), cv.fr_from_mont(np.asarray(k).reshape(1, 4))[0]))
     def g2_mul(self, a, k): return _proj2(O.g2_mul(self._a2(a), cv.fr_from_mont(np.asarray(k).reshape(1, 4))[0]))
     def g1_zero(self): return _proj1(None)

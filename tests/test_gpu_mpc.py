@@ -85,7 +85,10 @@ def test_collaborative_prove(n_parties, n):
         dr = ctx.r1cs_mul_chain(n)
         pk = ctx.groth16_setup(dr, *[tdm[i] for i in range(7)])
         dz = ctx.upload(cv.fr_to_mont(zs[p]))
-        return party.create_proof_shared(pk, dr, dz.ptr, mont1(rsh[p]), mont1(ssh[p])), party.bytes_sent
+        proof = party.create_proof_shared(pk, dr, dz.ptr, mont1(rsh[p]), mont1(ssh[p]))
+        sent = party.bytes_sent
+        assert party.create_proof_shared(pk, dr, dz.ptr, mont1(rsh[p]), mont1(ssh[p]), fused=False) == proof
+        return proof, (sent, party.bytes_sent - sent)
 
     res = run_parties(n_parties, fn)
     cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))
@@ -93,7 +96,8 @@ def test_collaborative_prove(n_parties, n):
     want = OC.groth16_predict(cr, tdm, zm, OC.witness_map(cr, zm), mont1(r), mont1(s))
     assert all(pr == want for pr, _ in res)
     D = 1 << cr.domain_log
-    assert all(b == 2 * D * 32 + 3 * (144 + 32) + 144 + 288 + 144 for _, b in res)   # Appendix C traffic
+    # Appendix C traffic in the reference's order of opens; fused, s + y is opened once and A is the opened point of the second scale
+    assert all(b == (2 * D * 32 + 2 * 32 + 3 * 144 + 288 + 144, 2 * D * 32 + 3 * (144 + 32) + 144 + 288 + 144) for _, b in res)
 
 
 @pytest.mark.parametrize("n_parties,n", [(2, 100), (3, 5000), (8, 77)])

@@ -66,6 +66,8 @@ def _worker(rank, world, port, q):
         proof = party.create_proof_shared(pk, r1cs, Z, cv.fr_to_mont([rsh[rank]])[0], cv.fr_to_mont([ssh[rank]])[0])
         want = O.proof_serialize(*O.predict_proof(r1cs, pks, z, r, s))
         assert proof == want, "revealed %d-party proof differs from the local proof on the summed inputs" % world
+        # the reference's order of opens (one collective each) gives the same bytes as the fused opens (the default)
+        assert party.create_proof_shared(pk, r1cs, Z, cv.fr_to_mont([rsh[rank]])[0], cv.fr_to_mont([ssh[rank]])[0], fused=False) == want
         assert party.bytes_sent >= 2 * be.dom.size * 32
         # (4) SPDZ (malicious backend): two-lane shares, MAC-checked opens; mac shares are independent sharings (key alpha = 1)
         sp = mpc.SpdzParty(net=net, backend=be)
@@ -75,6 +77,7 @@ def _worker(rank, world, port, q):
         rm, sm = O.additive_share(r, world, rng), O.additive_share(s, world, rng)
         proof2 = sp.create_proof_shared_spdz(pk, r1cs, Zs, (m1(rsh[rank]), m1(rm[rank])), (m1(ssh[rank]), m1(sm[rank])))
         assert proof2 == want, "SPDZ proof differs"
+        assert sp.create_proof_shared_spdz(pk, r1cs, Zs, (m1(rsh[rank]), m1(rm[rank])), (m1(ssh[rank]), m1(sm[rank])), fused=False) == want
         # a corrupted MAC share must be caught by the next open
         bad = np.array(be.store[Zs[1]], copy=True)
         if rank == world - 1:

@@ -119,6 +119,7 @@ PROTOTYPES = {
     "zk_g1_add": (_I, [_P, _P, _P]),
     "zk_g2_add": (_I, [_P, _P, _P]),
     "zk_g1_neg": (_I, [_P, _P]),
+    "zk_g2_neg": (_I, [_P, _P]),
     "zk_g1_mul": (_I, [_P, _P, _P]),
     "zk_g2_mul": (_I, [_P, _P, _P]),
     "zk_g1_from_affine": (_I, [_P, _P]),

@@ -507,6 +507,11 @@ class Context:
         self._ck(self.lib.zk_g1_neg(_ptr(a), _ptr(out)))
         return out
 
+    def g2_neg(self, a):
+        out = np.zeros(36, dtype=np.uint64)
+        self._ck(self.lib.zk_g2_neg(_ptr(a), _ptr(out)))
+        return out
+
     def g1_mul(self, a, k_mont4):
         out = np.zeros(18, dtype=np.uint64)
         k = np.ascontiguousarray(k_mont4, dtype=np.uint64)

@@ -52,6 +52,11 @@ extern "C" int zk_g1_neg(const zk_g1_projective* a, zk_g1_projective* out) {
     host64_write_projective<Fq64Field>(xyzz_to_affine<Fq64Field>(xyzz_neg<Fq64Field>(host64_proj_from_abi<Fq64Field>((const uint64_t*)a))), (uint64_t*)out);
     return ZK_OK;
 }
+extern "C" int zk_g2_neg(const zk_g2_projective* a, zk_g2_projective* out) {
+    if (!a || !out) return ZK_ERR_ARG;
+    host64_write_projective<Fq264Field>(xyzz_to_affine<Fq264Field>(xyzz_neg<Fq264Field>(host64_proj_from_abi<Fq264Field>((const uint64_t*)a))), (uint64_t*)out);
+    return ZK_OK;
+}
 extern "C" int zk_g1_mul(const zk_g1_projective* a, const zk_fr* k, zk_g1_projective* out) {
     return mul_t<Fq64Field>((const uint64_t*)a, k, (uint64_t*)out);
 }

@@ -300,6 +300,7 @@ class GpuBackend:
     def g1_add(self, a, b): return self.ctx.g1_add(a, b)
     def g2_add(self, a, b): return self.ctx.g2_add(a, b)
     def g1_neg(self, a): return self.ctx.g1_neg(a)
+    def g2_neg(self, a): return self.ctx.g2_neg(a)
     def g1_mul(self, a, k): return self.ctx.g1_mul(a, k)
     def g2_mul(self, a, k): return self.ctx.g2_mul(a, k)
     def g1_from_affine(self, a): return self.ctx.g1_from_affine(a)
@@ -499,15 +500,46 @@ class Party:
             pool = self._pool = ThreadPoolExecutor(max_workers=6)
         return pool.submit(fn, *args)
 
+    def _open_many(self, frs=(), g1s=(), g2s=()):
+        """Several opens in ONE collective: the sums over parties of scalar / G1 / G2 shares (the values are those of the
+        one-by-one opens; a proof has a dozen small opens and each costs a collective with a host round trip)."""
+        be = self.be
+        items = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1) for x in list(frs) + list(g1s) + list(g2s)]
+        if not items:
+            return [], [], []
+        arr = np.concatenate(items)
+        parts = self.net.all_gather_small(arr)
+        self.bytes_sent += arr.nbytes
+        outs, pos = ([], [], []), 0
+        for k, (group, width, add) in enumerate(((frs, 4, be.fr_add), (g1s, 18, be.g1_add), (g2s, 36, be.g2_add))):
+            for _ in group:
+                acc = np.array(parts[0][pos:pos + width], dtype=np.uint64)
+                for q in parts[1:]:
+                    acc = add(acc, np.ascontiguousarray(q[pos:pos + width], dtype=np.uint64))
+                outs[k].append(acc)
+                pos += width
+        return outs
+
+    def _scale_finish(self, sx, oy, y):
+        """The local part of GroupShare::scale behind its two opens: z - sx*y (+ sx*oy on the leader), z = 0."""
+        be = self.be
+        out = be.g1_neg(be.g1_mul(sx, y))
+        if self.leader:
+            out = be.g1_add(out, be.g1_mul(sx, oy))
+        return out
+
     # ---- reveal ----
     def reveal_g1(self, p): return self._open_g(p, self.be.g1_add)
     def reveal_g2(self, p): return self._open_g(p, self.be.g2_add)
 
     # ---- the collaborative prover ----
-    def create_proof_shared(self, pk, r1cs, z_share, r_share, s_share, triple=None) -> bytes:
+    def create_proof_shared(self, pk, r1cs, z_share, r_share, s_share, triple=None, fused=True) -> bytes:
         """create_proof over additive shares (src/groth16.rs:68-183 with E = MpcPairingEngine).
         z_share: this party's share of the full assignment (device vector); r_share, s_share: (4,) uint64.
-        Returns the revealed 192-byte proof (identical on every party)."""
+        Returns the revealed 192-byte proof (identical on every party).
+        fused (default): the nine small opens of the three `scale` calls and of Proof::reveal travel in two collectives (every
+        opened value is the same as in the reference's order; A is the opened s + x of the second scale).  fused=False keeps
+        the reference's call order, one collective per open."""
         be = self.be
         D = be.domain_size(r1cs)
         P = self._pk_points(pk)
@@ -525,6 +557,18 @@ class Party:
         pub1 = (lambda x: x) if self.leader else (lambda x: be.g1_zero())   # shift(): leader only
         pub2 = (lambda x: x) if self.leader else (lambda x: be.g2_zero())
         r_g1 = early[0].result()                                   # delta_g1 * r: public point * shared scalar, local
+        if fused:
+            y = be.fr_one() if self.leader else np.zeros(4, dtype=np.uint64)
+            g_a = be.g1_add(be.g1_add(be.g1_add(r_g1, pub1(P["a0"])), a_acc), pub1(P["alpha_g1"]))
+            g1_b = be.g1_add(be.g1_add(be.g1_add(early[1].result(), pub1(P["b0_g1"])), b1_acc), pub1(P["beta_g1"]))
+            g2_b = be.g2_add(be.g2_add(be.g2_add(early[2].result(), pub2(P["b0_g2"])), g2), pub2(P["beta_g2"]))
+            (oy_s, oy_r), (sx_rd, sx_a, sx_b), (B,) = self._open_many([be.fr_add(s_share, y), be.fr_add(r_share, y)], [r_g1, g_a, g1_b], [g2_b])
+            parts = [self._early(self._scale_finish, sx, oy, y) for sx, oy in ((sx_rd, oy_s), (sx_a, oy_s), (sx_b, oy_r))]
+            g_c = be.g1_add(parts[1].result(), parts[2].result())
+            g_c = be.g1_add(g_c, be.g1_neg(parts[0].result()))
+            g_c = be.g1_add(be.g1_add(g_c, l_acc), h_acc)
+            C = self.reveal_g1(g_c)
+            return be.g1_serialize(sx_a) + be.g2_serialize(B) + be.g1_serialize(C)
         r_s_delta = self.scale_g1(r_g1, s_share, lazy=True)        # :115
         g_a = be.g1_add(be.g1_add(be.g1_add(r_g1, pub1(P["a0"])), a_acc), pub1(P["alpha_g1"]))   # calculate_coeff
         s_g_a = self.scale_g1(g_a, s_share, lazy=True)             # :140
@@ -684,14 +728,28 @@ class SpdzParty(Party):
             raise MacCheckError("SPDZ MAC check failed on a group open")
         return x
 
+    def _spdz_open_many(self, frs=(), g1s=(), g2s=()):
+        """Party._open_many over SPDZ pairs (share, mac): the shares are opened in one collective, all the MAC checks
+        (sum over parties of [leader ? x : 0] - mac_i = 0 with key share 1 on the leader: spdz.rs:177-196) in a second one."""
+        be = self.be
+        xf, x1, x2 = self._open_many([v[0] for v in frs], [v[0] for v in g1s], [v[0] for v in g2s])
+        zf = np.zeros(4, dtype=np.uint64)
+        df = [be.fr_sub(x if self.leader else zf, v[1]) for x, v in zip(xf, frs)]
+        d1 = [be.g1_add(x if self.leader else be.g1_zero(), be.g1_neg(v[1])) for x, v in zip(x1, g1s)]
+        d2 = [be.g2_add(x if self.leader else be.g2_zero(), be.g2_neg(v[1])) for x, v in zip(x2, g2s)]
+        tf, t1, t2 = self._open_many(df, d1, d2)
+        if any(np.any(t) for t in tf) or any(be.g1_serialize(t) != be.g1_serialize(be.g1_zero()) for t in t1) or \
+                any(be.g2_serialize(t) != be.g2_serialize(be.g2_zero()) for t in t2):
+            raise MacCheckError("SPDZ MAC check failed on a fused open")
+        return xf, x1, x2
+
     def spdz_open_g1(self, v):
         be = self.be
         return self._spdz_open_g(v, be.g1_add, be.g1_neg, be.g1_zero, be.g1_serialize)
 
     def spdz_open_g2(self, v):
         be = self.be
-        neg2 = lambda p: be.g2_mul(p, self._minus_one())
-        return self._spdz_open_g(v, be.g2_add, neg2, be.g2_zero, be.g2_serialize)
+        return self._spdz_open_g(v, be.g2_add, be.g2_neg, be.g2_zero, be.g2_serialize)
 
     def _minus_one(self):
         return self.be.fr_sub(np.zeros(4, dtype=np.uint64), self.be.fr_one())
@@ -767,9 +825,11 @@ class SpdzParty(Party):
         return {"commitments": comms, "evaluations": evals, "w_beta": self.spdz_open_g1((w[0][0], w[1][0])), "w_gamma": w[0][1],
                 "challenges": ch}
 
-    def create_proof_shared_spdz(self, pk, r1cs, z_share, r_share, s_share, triple=None) -> bytes:
+    def create_proof_shared_spdz(self, pk, r1cs, z_share, r_share, s_share, triple=None, fused=True) -> bytes:
         """create_proof with E = MpcPairingEngine<_, SpdzPairingShare> (the `malicious` feature).
-        z_share = (sh, mac) device vectors; r_share, s_share = (sh, mac) scalars."""
+        z_share = (sh, mac) device vectors; r_share, s_share = (sh, mac) scalars.
+        fused: as create_proof_shared -- the opens of the three scale calls and of B in one collective, their MAC checks in a
+        second one, then C and its check."""
         be = self.be
         D = be.domain_size(r1cs)
         P = self._pk_points(pk)
@@ -796,6 +856,19 @@ class SpdzParty(Party):
         h_acc, l_acc, a_acc, b1_acc = [pair(lambda lane, k=k: msm[lane][0][k]) for k in range(4)]
         b2_acc = pair(lambda lane: msm[lane][1])
         r_g1 = pair(lambda lane: early[("r_g1", lane)].result())
+        if fused:
+            y = be.fr_one() if self.leader else np.zeros(4, dtype=np.uint64)
+            g_a = pair(lambda lane: be.g1_add(be.g1_add(be.g1_add(r_g1[lane], pub1(P["a0"])), a_acc[lane]), pub1(P["alpha_g1"])))
+            g1_b = pair(lambda lane: be.g1_add(be.g1_add(be.g1_add(early[("s_g1", lane)].result(), pub1(P["b0_g1"])), b1_acc[lane]), pub1(P["beta_g1"])))
+            g2_b = pair(lambda lane: be.g2_add(be.g2_add(be.g2_add(early[("s_g2", lane)].result(), pub2(P["b0_g2"])), b2_acc[lane]), pub2(P["beta_g2"])))
+            sy = (be.fr_add(s_share[0], y), be.fr_add(s_share[1], y))              # o + y, y = from_add_shared(leader ? 1 : 0)
+            ry = (be.fr_add(r_share[0], y), be.fr_add(r_share[1], y))
+            (oy_s, oy_r), (sx_rd, sx_a, sx_b), (B,) = self._spdz_open_many([sy, ry], [r_g1, g_a, g1_b], [g2_b])
+            parts = [self._early(self._scale_finish, sx, oy, y) for sx, oy in ((sx_rd, oy_s), (sx_a, oy_s), (sx_b, oy_r))]
+            both = lambda f: (lambda t: (t, t))(f.result())                        # scale: both lanes hold the same value (key 1)
+            g_c = add1(add1(add1(add1(both(parts[1]), both(parts[2])), neg1(both(parts[0]))), l_acc), h_acc)
+            Cp = self.spdz_open_g1(g_c)
+            return be.g1_serialize(sx_a) + be.g2_serialize(B) + be.g1_serialize(Cp)
         r_s_delta = self.spdz_scale_g1(r_g1, s_share, lazy=True)
         g_a = pair(lambda lane: be.g1_add(be.g1_add(be.g1_add(r_g1[lane], pub1(P["a0"])), a_acc[lane]), pub1(P["alpha_g1"])))
         s_g_a = self.spdz_scale_g1(g_a, s_share, lazy=True)
