@@ -262,6 +262,9 @@ int zk_groth16_hint_next_dev(zk_ctx* ctx, const void* z_next_dev);
  * mpc-algebra/src/share/field.rs:97-129 so that the sort runs during the exchange.  Dropped if another MSM batch or a
  * different z_dev comes first. */
 int zk_groth16_msms_presort_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const void* z_dev);
+/* The four MSMs over z (B in G2, A, B in G1, L) enqueued to the end; zk_groth16_msms_dev with the same pk / r / z then adds the H
+ * job and collects all five: the collaborative prover's Beaver open and second witness-map half run under them. */
+int zk_groth16_msms_begin_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z);
 int zk_groth16_msms_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const void* z_dev,
                         const void* h_dev, zk_g1_projective out_g1[4], zk_g2_projective* out_g2);
 /* create_proof (src/groth16.rs:68-183 / arkworks/groth16/src/prover.rs:44-153) for a plain

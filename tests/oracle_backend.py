@@ -118,6 +118,9 @@ class OracleBackend:
     def msms_presort(self, pk, r1cs, z):
         pass                                   # a scheduling hint of the device backend
 
+    def msms_begin(self, pk, r1cs, z):
+        pass
+
     def msms(self, pk: OraclePk, r1cs, z, h):
         zz, hh = self.store[z], self.store[h]
         ni = self.r1cs.num_instance

@@ -157,6 +157,7 @@ PROTOTYPES = {
     "zk_groth16_witness_map_post_dev": (_I, [_P, _P, _P, _P]),
     "zk_groth16_msms_dev": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "zk_groth16_msms_presort_dev": (_I, [_P, _P, _P, _P]),
+    "zk_groth16_msms_begin_dev": (_I, [_P, _P, _P, _P]),
     "zk_groth16_hint_next_dev": (_I, [_P, _P]),
     "zk_groth16_prove_dev": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "zk_groth16_prove": (_I, [_P, _P, _P, _P, _P, _P, _P]),

@@ -646,6 +646,10 @@ class Context:
         """Enqueue the shared sort of z[1..] ahead of groth16_msms_dev on the same z_dev (asynchronous)."""
         self._ck(self.lib.zk_groth16_msms_presort_dev(self.h, pk.h, r1cs.h, C.c_void_p(int(z_dev))))
 
+    def groth16_msms_begin_dev(self, pk: "ProvingKey", r1cs: "R1cs", z_dev):
+        """Enqueue the four MSMs over z to the end (asynchronous); groth16_msms_dev on the same z_dev adds the H job and collects."""
+        self._ck(self.lib.zk_groth16_msms_begin_dev(self.h, pk.h, r1cs.h, C.c_void_p(int(z_dev))))
+
     def groth16_msms_dev(self, pk: "ProvingKey", r1cs: "R1cs", z_dev, h_dev):
         g1 = np.zeros((4, 18), dtype=np.uint64)
         g2 = np.zeros(36, dtype=np.uint64)

@@ -496,6 +496,12 @@ struct ZkPresort {
     void* h = nullptr;                 // where the witness map put h
     ZkMsmJob jobh;
     hipEvent_t wm_done = nullptr;
+    // zk_groth16_msms_begin_dev: not only the sort of z but the four MSMs over z -- A, B in G1, B in G2, L: sorted, their
+    // accumulate kernels and reduce chains enqueued -- are under way; zk_groth16_msms_dev then adds the H job and collects all
+    // five.  The collaborative prover calls it before its Beaver open: the exchange and the second half of the witness map run
+    // under 12 ms of accumulate kernels that do not need h.
+    bool begun = false;
+    ZkMsmJob j1, j2, j3;
     ~ZkPresort() { if (wm_done) (void)hipEventDestroy(wm_done); }
 };
 void zk_presort_free(zk_ctx* ctx) {
@@ -503,7 +509,7 @@ void zk_presort_free(zk_ctx* ctx) {
     ZkPresort* p = (ZkPresort*)ctx->presort;
     ctx->presort = nullptr;
     if (ctx->aux.size()) (void)hipStreamSynchronize(ctx->aux[0]);   // its kernels write the job's scratch slot
-    if (p->front) {                                                 // the front runs on the accumulate and context streams
+    if (p->front || p->begun) {                                     // these run on the accumulate and context streams as well
         if (ctx->acc_stream) (void)hipStreamSynchronize(ctx->acc_stream);
         (void)hipStreamSynchronize(ctx->stream);
     }
@@ -580,23 +586,25 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         zk_presort_free(ctx);
         pre = nullptr;
     }
+    const bool begun = presorted && pre->begun && h_in && pre->r == r;     // the four z jobs are already enqueued to the end
     if (presorted) J[0] = &pre->job;
     if (fronted) J[4] = &pre->jobh;
+    if (begun) { J[1] = &pre->j1; J[2] = &pre->j2; J[3] = &pre->j3; }
     // z was produced on the context stream.  (With a front that stream already carries this proof's witness map and H-sort:
     // waiting for it here would hold the sort stream -- and the G2 reduce chain on it -- until the H-sort is through.)
     if (!fronted) ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e0, 0));
     int rc = presorted ? ZK_OK : zk_msm_prepare(ctx, J[0], pk->b_g2, 1, zb + 32, nvars, 1);                 // src/groth16.rs:160 (query[1..])
-    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, J[1], pk->a, 1, zb + 32, nvars, 2);              // :137
-    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, J[2], pk->b_g1, 1, zb + 32, nvars, 3);           // :148
+    if (rc == ZK_OK && !begun) rc = zk_msm_prepare(ctx, J[1], pk->a, 1, zb + 32, nvars, 2);              // :137
+    if (rc == ZK_OK && !begun) rc = zk_msm_prepare(ctx, J[2], pk->b_g1, 1, zb + 32, nvars, 3);           // :148
     // :110: aux_assignment against l_query; over the padded table the same sum reads z[1..] (the instance meets infinity)
     const bool l_shared = pk->l_pad && pk->l_pad->n == nvars + 1 && (pk->l_pad->pre != nullptr) == (pk->a->pre != nullptr) &&
                           pk->l_pad->c_pre == pk->a->c_pre;
-    if (rc == ZK_OK) rc = l_shared ? zk_msm_prepare(ctx, J[3], pk->l_pad, 1, zb + 32, nvars, 4)
-                                   : zk_msm_prepare(ctx, J[3], pk->l, 0, zb + r->ni * 32, r->nw, 4);
+    if (rc == ZK_OK && !begun) rc = l_shared ? zk_msm_prepare(ctx, J[3], pk->l_pad, 1, zb + 32, nvars, 4)
+                                             : zk_msm_prepare(ctx, J[3], pk->l, 0, zb + r->ni * 32, r->nw, 4);
     if (rc == ZK_OK && !presorted) rc = zk_msm_enqueue_sort(ctx, J[0], s_sort, nullptr);
-    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, J[1], s_sort, J[0]);
-    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, J[2], s_sort, J[0]);
-    if (rc == ZK_OK && l_shared) rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, J[0]);
+    if (rc == ZK_OK && !begun) rc = zk_msm_enqueue_sort(ctx, J[1], s_sort, J[0]);
+    if (rc == ZK_OK && !begun) rc = zk_msm_enqueue_sort(ctx, J[2], s_sort, J[0]);
+    if (rc == ZK_OK && !begun && l_shared) rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, J[0]);
     const void* h = h_in;
     ZkPhaseTimer tm(ctx);
     static const bool gate = !(getenv("ZK_WM_GATE") && atoi(getenv("ZK_WM_GATE")) == 0);
@@ -622,7 +630,7 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         }
     }
     // L's sort after the witness map (it is not needed before the fourth accumulate kernel)
-    if (rc == ZK_OK && !l_shared) {
+    if (rc == ZK_OK && !l_shared && !begun) {
         ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e1, 0));
         rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, nullptr);
     }
@@ -634,7 +642,9 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         for (; cnt < 5 && e[cnt] >= '0' && e[cnt] <= '4' && !seen[e[cnt] - '0']; cnt++) { tmp[cnt] = e[cnt] - '0'; seen[tmp[cnt]] = true; }
         if (cnt == 5) for (int k = 0; k < 5; k++) ord[k] = tmp[k];
     }
-    for (int k = 0; k < 5 && rc == ZK_OK; k++) rc = zk_msm_enqueue_accum(ctx, J[ord[k]], s_acc);
+    if (begun) { ord[0] = 0; ord[1] = 1; ord[2] = 2; ord[3] = 3; ord[4] = 4; }        // the order zk_groth16_msms_begin_dev used
+    for (int k = 0; k < 5 && rc == ZK_OK; k++)
+        if (!begun || ord[k] == 4) rc = zk_msm_enqueue_accum(ctx, J[ord[k]], s_acc);
     // B-in-G2's reduce chain (the long one) stays on the sort stream; the four G1 reduces go to the main stream, idle by
     // then, so that each runs right behind its own accumulate kernel instead of queueing behind the G2 chain (that
     // queueing left 4 x 0.7 ms of reduces after the last accumulate).
@@ -647,6 +657,7 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     static const bool reduce_tail = getenv("ZK_REDUCE_TAIL") && atoi(getenv("ZK_REDUCE_TAIL")) != 0;
     for (int k = 0; k < 5 && rc == ZK_OK; k++) {
         hipStream_t rs = (ord[k] == 0 || (alt == 1 && k == 4) || (alt == 2 && (k & 1) == 0)) ? s_red : ctx->stream;
+        if (begun && ord[k] == 0) continue;                 // B in G2's chain went out with zk_groth16_msms_begin_dev
         if (reduce_tail && ord[k] != 0 && J[ord[4]]->accum_done) ZK_HIP(ctx, hipStreamWaitEvent(rs, J[ord[4]]->accum_done, 0));
         rc = zk_msm_enqueue_reduce(ctx, J[ord[k]], rs);
     }
@@ -788,6 +799,53 @@ extern "C" int zk_groth16_msms_presort_dev(zk_ctx* ctx, const zk_pk* pk, const z
     p->z = z;
     ZK_TRY(zk_msm_prepare(ctx, &p->job, pk->b_g2, 1, (const char*)z + 32, nvars, 1));
     ZK_TRY(zk_msm_enqueue_sort(ctx, &p->job, ctx->aux[0], nullptr));
+    ctx->presort = p.release();
+    return ZK_OK;
+}
+
+// The four MSMs over z -- B in G2, A, B in G1, L -- enqueued to the end (sort, accumulate, reduce); returns at once.
+// zk_groth16_msms_dev(ctx, pk, r, z, h, ...) with the same pk / r / z then only adds the H job and collects the five results.
+// For the collaborative prover (mpc.py::create_proof_shared): the Beaver open of the witness map's product and the second
+// half of the witness map run under accumulate kernels that do not need h.  The context stream stays free for the caller's
+// own kernels.
+extern "C" int zk_groth16_msms_begin_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z) {
+    if (!ctx || !pk || !r || !z) return ZK_ERR_ARG;
+    zk_presort_free(ctx);
+    const size_t nvars = (r->ni - 1) + r->nw;
+    if (pk->a->n != nvars + 1 || pk->b_g1->n != nvars + 1 || pk->b_g2->n != nvars + 1 || pk->l->n != r->nw)
+        ZK_FAIL(ctx, ZK_ERR_ARG, "groth16: proving key does not match the constraint system");
+    ZK_TRY(ensure_aux(ctx, 1));
+    hipStream_t s_sort = ctx->aux[0], s_acc = ctx->acc_stream;
+    hipEvent_t e0;
+    ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    ZK_HIP(ctx, hipEventRecord(e0, ctx->stream));          // z was produced on the context stream
+    ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e0, 0));
+    ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e0, 0));
+    (void)hipEventDestroy(e0);
+    std::unique_ptr<ZkPresort> p(new ZkPresort());
+    p->pk = pk; p->z = z; p->r = r; p->begun = true;
+    const char* zb = (const char*)z;
+    const bool l_shared = pk->l_pad && pk->l_pad->n == nvars + 1 && (pk->l_pad->pre != nullptr) == (pk->a->pre != nullptr) &&
+                          pk->l_pad->c_pre == pk->a->c_pre;
+    ZkMsmJob* J[4] = {&p->job, &p->j1, &p->j2, &p->j3};
+    int rc = zk_msm_prepare(ctx, J[0], pk->b_g2, 1, zb + 32, nvars, 1);
+    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, J[1], pk->a, 1, zb + 32, nvars, 2);
+    if (rc == ZK_OK) rc = zk_msm_prepare(ctx, J[2], pk->b_g1, 1, zb + 32, nvars, 3);
+    if (rc == ZK_OK) rc = l_shared ? zk_msm_prepare(ctx, J[3], pk->l_pad, 1, zb + 32, nvars, 4)
+                                   : zk_msm_prepare(ctx, J[3], pk->l, 0, zb + r->ni * 32, r->nw, 4);
+    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, J[0], s_sort, nullptr);
+    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, J[1], s_sort, J[0]);
+    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, J[2], s_sort, J[0]);
+    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, l_shared ? J[0] : nullptr);
+    for (int k = 0; k < 4 && rc == ZK_OK; k++) rc = zk_msm_enqueue_accum(ctx, J[k], s_acc);
+    // only the G2 job's reduce chain here (sort stream); the G1 chains are enqueued by zk_groth16_msms_dev, which spreads them over
+    // the context stream (the caller's own kernels are through by then) and the sort stream as the one-call form does
+    if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, J[0], s_sort);
+    if (rc != ZK_OK) {                                   // whatever was enqueued drains before the jobs (and their events) go
+        (void)hipStreamSynchronize(s_sort);
+        (void)hipStreamSynchronize(s_acc);
+        return rc;
+    }
     ctx->presort = p.release();
     return ZK_OK;
 }

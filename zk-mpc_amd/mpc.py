@@ -293,6 +293,9 @@ class GpuBackend:
     def msms_presort(self, pk, r1cs, z):
         self.ctx.groth16_msms_presort_dev(pk, r1cs, z)
 
+    def msms_begin(self, pk, r1cs, z):
+        self.ctx.groth16_msms_begin_dev(pk, r1cs, z)
+
     def msms(self, pk, r1cs, z, h):
         return self.ctx.groth16_msms_dev(pk, r1cs, z, h)
 
@@ -549,7 +552,7 @@ class Party:
             self._early(be.g2_mul, P["delta_g2"], s_share)
         a, b, c = be.vec("wm_a", D), be.vec("wm_b", D), be.vec("wm_c", D)
         be.witness_map_pre(r1cs, z_share, a, b, c)                 # local: linear in the shares
-        be.msms_presort(pk, r1cs, z_share)                         # the MSMs' shared sort of z runs under the open below
+        be.msms_begin(pk, r1cs, z_share)                           # the four MSMs over z run under the open and the second half below
         self.beaver_batch_mul(a, b, a, D, triple)                  # the one shared x shared vector product (:285)
         be.witness_map_post(r1cs, a, c)                            # h shares in `a`
         g1, g2 = be.msms(pk, r1cs, z_share, a)                     # party-local MSMs (multi_scale_pub_group)
@@ -843,6 +846,7 @@ class SpdzParty(Party):
             lanes.append((a, b, c))
         A = (lanes[0][0], lanes[1][0])
         B = (lanes[0][1], lanes[1][1])
+        be.msms_begin(pk, r1cs, z_share[0])                        # the share lane's four MSMs over z run under the opens below
         self.spdz_beaver_batch_mul(A, B, A, D, triple)
         msm = []
         for lane in (0, 1):
