@@ -630,6 +630,11 @@ k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
         XYZZ<F> acc = xyzz_inf<F>();
         if (d.len) {
             const uint32_t* srt = sorted + d.start;
+#ifdef ZK_ACCUM_NO_PREFETCH
+            for (uint32_t k = 0; k < d.len; k++) {
+                const uint32_t ce = srt[k];
+                Affine<F> cur = aff_load16<F>(bases, ce & 0x7fffffffu);
+#else
             uint32_t e = srt[0];
             Affine<F> p = aff_load16<F>(bases, e & 0x7fffffffu);
             for (uint32_t k = 0; k < d.len; k++) {
@@ -639,6 +644,7 @@ k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                     e = srt[k + 1];
                     p = aff_load16<F>(bases, e & 0x7fffffffu);
                 }
+#endif
                 // lazy domain (fp29.cuh / ec.cuh::xyzz_madd_lazy): the accumulator is a representative in [0, ~5 p], a negative
                 // digit takes p - y in one carry pass; nothing is compared or selected until the segment is through
                 const bool inf = aff_is_inf<F>(cur);
