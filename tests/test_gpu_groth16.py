@@ -353,3 +353,37 @@ def test_prove_queued_host_assignments(ctx):
     pk.free()
     for p in pinned:
         p.free()
+
+
+def test_msms_begin_then_finish_and_its_misuse(ctx):
+    """zk_groth16_msms_begin_dev: the four MSMs over z enqueued ahead, zk_groth16_msms_dev adds the H job -- same five sums as the
+    one-call form.  A begin that is not followed by its own finish (another z, another entry point in between, a proof, the
+    key freed) must be dropped without a trace."""
+    n = (1 << 16) + 5
+    rng = O.Prng(81818)
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    dr = ctx.r1cs_mul_chain(n)
+    pk = ctx.groth16_setup(dr, *[mont(rng.fr()) for _ in range(7)])
+    D = 1 << 17
+    z1 = ctx.mul_chain_assignment_dev(n, mont(rng.fr()), mont(rng.fr()))
+    z2 = ctx.mul_chain_assignment_dev(n, mont(rng.fr()), mont(rng.fr()))
+    h1, h2 = ctx.alloc(D * 32), ctx.alloc(D * 32)
+    ctx.witness_map_dev(dr, z1.ptr, h1.ptr)
+    ctx.witness_map_dev(dr, z2.ptr, h2.ptr)
+    same = lambda a, b: np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    want1, want2 = ctx.groth16_msms_dev(pk, dr, z1.ptr, h1.ptr), ctx.groth16_msms_dev(pk, dr, z2.ptr, h2.ptr)
+    assert not same(want1, want2)
+    tmp = ctx.alloc(D * 32)
+    for _ in range(2):                                   # the plain use, twice in a row
+        ctx.groth16_msms_begin_dev(pk, dr, z1.ptr)
+        ctx.fr_vec_op_dev(1, h2.ptr, h2.ptr, tmp.ptr, D)                    # the caller's own kernels on the context stream
+        assert same(ctx.groth16_msms_dev(pk, dr, z1.ptr, h1.ptr), want1)
+    ctx.groth16_msms_begin_dev(pk, dr, z1.ptr)           # begun for z1, finished for z2: the begun jobs are dropped
+    assert same(ctx.groth16_msms_dev(pk, dr, z2.ptr, h2.ptr), want2)
+    ctx.groth16_msms_begin_dev(pk, dr, z2.ptr)           # another entry point in between (it rotates over the same scratch slots)
+    r, s = mont(rng.fr()), mont(rng.fr())
+    proof = ctx.create_proof_dev(pk, dr, z1.ptr, r, s)
+    assert same(ctx.groth16_msms_dev(pk, dr, z2.ptr, h2.ptr), want2)
+    assert ctx.create_proof_dev(pk, dr, z1.ptr, r, s) == proof
+    ctx.groth16_msms_begin_dev(pk, dr, z1.ptr)           # begun and never finished: the key goes first
+    pk.free()
