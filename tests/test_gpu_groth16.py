@@ -385,5 +385,8 @@ def test_msms_begin_then_finish_and_its_misuse(ctx):
     proof = ctx.create_proof_dev(pk, dr, z1.ptr, r, s)
     assert same(ctx.groth16_msms_dev(pk, dr, z2.ptr, h2.ptr), want2)
     assert ctx.create_proof_dev(pk, dr, z1.ptr, r, s) == proof
+    ctx.groth16_msms_begin_dev(pk, dr, z1.ptr)           # the SAME z, but a whole proof instead of the finishing call
+    assert ctx.create_proof_dev(pk, dr, z1.ptr, r, s) == proof
+    assert same(ctx.groth16_msms_dev(pk, dr, z1.ptr, h1.ptr), want1)
     ctx.groth16_msms_begin_dev(pk, dr, z1.ptr)           # begun and never finished: the key goes first
     pk.free()

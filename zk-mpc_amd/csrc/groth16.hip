@@ -578,7 +578,9 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     ZkPresort* pre = (ZkPresort*)ctx->presort;
     ctx->presort = nullptr;
     std::unique_ptr<ZkPresort> pre_owner(pre);
-    const bool presorted = pre && pre->pk == pk && pre->z == z && pre->job.n == nvars;
+    // (a begun set can only be taken over whole, by the call that brings h: anything else drains and drops it below -- its jobs
+    // own the scratch slots this call is about to use)
+    const bool presorted = pre && pre->pk == pk && pre->z == z && pre->job.n == nvars && (!pre->begun || (h_in && pre->r == r));
     const bool fronted = presorted && pre->front && !h_in && pre->r == r && pre->h == h_scratch;
     if (pre && !presorted) {                       // a front / sort for other inputs: let it drain before its scratch is reused
         pre_owner.release();
