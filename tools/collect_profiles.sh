@@ -21,6 +21,7 @@ rocprofv3 --kernel-trace --stats -d $O/${T}_marlin_trace -o m --output-format cs
 python3 tools/bench_msm.py 24 > $O/${T}_micro_msm_ntt.json 2> $O/${T}_micro.err
 python3 tools/bench_she.py > $O/${T}_she_bench.jsonl 2> $O/${T}_she.err
 python3 tools/bench_ntt.py 24 20 10 > $O/${T}_ntt_bench.jsonl 2> $O/${T}_ntt.err
+python3 tools/bench_vec.py > $O/${T}_vec_bench.jsonl 2> $O/${T}_vec.err
 for L in 16 18 20; do python3 bench.py --marlin --log-constraints $L --steps 4 --warmup 1 2>> $O/${T}_marlin_prove.err; done > $O/${T}_marlin_prove.jsonl
 rocprofv3 --kernel-trace -d $O/${T}_marlin_prove_trace -o m --output-format csv -- python3 bench.py --marlin --log-constraints 20 --steps 3 --warmup 1 > $O/${T}_marlin_prove_trace.log 2>&1
 python3 tools/trace_underfill.py $O/${T}_marlin_prove_trace/m_kernel_trace.csv --period=k_denoms_k:-4 > $O/${T}_marlin_underfill.txt 2>&1
