@@ -53,11 +53,10 @@ struct ZkMsmJob {
     int pin_key = -1;                 // pinned result buffer (ctx->pinned key); -1: the slot's.  Jobs enqueued without a host wait in between need their own
     int counting_sort = 0;            // 1: take the atomic counting sort even for a merged bucket set (its small kernels co-run with an accumulate kernel)
     size_t n = 0, max_segs = 0, max_heavy = 0;
-    uint32_t c = 0, W = 0, NB = 0, seg = 0, T1 = 0, nbits = 0;
+    uint32_t c = 0, W = 0, NB = 0, seg = 0;
     uint16_t off[65] = {0};           // window w covers scalar bits [off[w], off[w+1])
     uint32_t Wb = 0;                  // bucket sets: W, or 1 when the bases carry precomputed window multiples
-    uint32_t levels = 1, T2 = 0;      // chunked running-sum levels before the bit-decomposition sums (2 for G2: its additions are 4x dearer)
-    uint32_t Rw = 0, RNB = 0;         // the reduce phase sees Rw windows of RNB buckets (merged mode: one big set cut into 2^15-bucket windows)
+    uint32_t log_nb = 0, nout = 0;    // reduce phase (msm_reduce.cuh): a bucket set of 2^log_nb buckets leaves nout = log_nb + 1 points for the host
     uint32_t n_tab = 0, tab_off = 0;  // merged mode: table stride and offset of this MSM's first base
     const uint32_t* bases_dev = nullptr;
     const void* scalars = nullptr;
@@ -88,7 +87,8 @@ void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bas
                             const uint32_t* order, const uint32_t* ctr, uint32_t* sums);
 struct ZkG2PairReduce {   // the arguments of msm.hip's reduce chain
     const void* heavy; const uint32_t* ctr;
-    uint32_t *sums, *lvS, *lvW, *lvS2, *lvW2, *bits;
-    uint32_t RNB, T1, T2, Rw, levels, nbits, nout, klog, light_blocks, heavy_blocks;
+    uint32_t *sums, *rowP, *colP, *bits;
+    uint32_t log_nb, n_win, light_blocks, heavy_blocks;
 };
-int zk_launch_reduce_g2pair(hipStream_t st, const ZkG2PairReduce& a);
+int zk_launch_reduce_g2pair(zk_ctx* ctx, hipStream_t st, const ZkG2PairReduce& a);
+constexpr uint32_t ZK_G2PAIR_RED_PTS = 128;   // points (lane pairs) per block of the G2 reduce kernels

@@ -30,6 +30,7 @@
 #include "hostgroup.hpp"
 #include "hostfield64.hpp"
 #include "internal.hpp"
+#include "msm_reduce.cuh"
 #include <algorithm>
 #include <future>
 #include <vector>
@@ -37,8 +38,6 @@
 using namespace zk;
 
 namespace {
-
-constexpr int REDUCE_K_LOG = 3;  // 8 elements per thread per reduction level
 
 struct MsmPlan {
     uint32_t c;        // widest window (bits): buckets per window NB = 2^(c-1)
@@ -731,64 +730,22 @@ k_fold(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint32_t lig
     }
 }
 
-// One reduction level (see file header).  Elements per window: T_in; chunk = 2^klog elements.
-// in : S_in[w*T_in + t], optional W_in[w*T_in + t]
-// out: S_out[w*T_out + c] = 2^klog * sum S ; W_out[w*T_out + c] = sum W + sum (t - lo (+1)) S_t
-// At most 256 registers (it would take 322): a wave of this kernel then shares a SIMD with one accumulate wave
-// (232 + 256 <= 512).  With 322 it had the SIMD to itself while running a latency-bound chain of 16 dependent additions,
-// and the accumulate kernel beside it lost the SIMD for that time.
-template <class F>
-__global__ void __launch_bounds__(64, 2)
-k_reduce(const uint32_t* S_in, const uint32_t* W_in, uint32_t* S_out, uint32_t* W_out, uint32_t T_in,
-         uint32_t T_out, uint32_t klog, uint32_t n_windows, int one_based, int last) {
-    size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (t >= (size_t)n_windows * T_out) return;
-    uint32_t w = (uint32_t)(t / T_out), c = (uint32_t)(t - (size_t)w * T_out);
-    uint32_t lo = c << klog, hi = min(lo + (1u << klog), T_in);
-    XYZZ<F> running = xyzz_inf<F>(), acc = xyzz_inf<F>(), wsum = xyzz_inf<F>();
-    for (uint32_t k = hi; k-- > lo;) {
-        size_t idx = (size_t)w * T_in + k;
-        if (W_in) wsum = radd<F>(wsum, xyzz_load16<F>(W_in, idx));
-        running = radd<F>(running, xyzz_load16<F>(S_in, idx));
-        if (k > lo || one_based) acc = radd<F>(acc, running);
-    }
-    acc = rcanon<F>(radd<F>(acc, wsum));
-    xyzz_store16<F>(W_out, t, acc);
-    if (!last) {
-        running = rcanon<F>(running);
-        for (uint32_t k = 0; k < klog; k++) running = xyzz_dbl<F>(running);
-        xyzz_store16<F>(S_out, t, running);
-    }
-}
-
-// Upper part of the bucket reduction in ONE launch.  After the first chunk level a window holds T
-// pairs (S_t, W_t) and its sum is  sum_t W_t + sum_t t*S_t = sum_t W_t + sum_j 2^j * (sum_{t: bit j of t} S_t).
-// Block (w, j) computes the j-th inner sum (j < nbits) or sum_t W_t (j == nbits) with 256 lanes:
-// strided serial adds, then an LDS tree.  Depth ~ T/256 + 8 additions instead of ~24 per extra chunk level.
-template <class F>
-__global__ void __launch_bounds__(256)
-k_bitsum(const uint32_t* S_in, const uint32_t* W_in, uint32_t* out, uint32_t T, uint32_t nbits, uint32_t nout) {
-    constexpr int XW = 4 * F::WORDS;
-    extern __shared__ uint32_t lds[];  // 256 * XW words
-    const uint32_t w = blockIdx.x / nout, j = blockIdx.x % nout;   // nout = nbits + 1, or nbits + 2 with the plain sum of S
-    const uint32_t tid = threadIdx.x;
-    XYZZ<F> acc = xyzz_inf<F>();
-    if (j == nbits) {
-        for (uint32_t t = tid; t < T; t += 256) acc = radd<F>(acc, xyzz_load16<F>(W_in, (size_t)w * T + t));
-    } else if (j == nbits + 1) {
-        for (uint32_t t = tid; t < T; t += 256) acc = radd<F>(acc, xyzz_load16<F>(S_in, (size_t)w * T + t));
-    } else {
-        for (uint32_t t = tid; t < T; t += 256)
-            if ((t >> j) & 1) acc = radd<F>(acc, xyzz_load16<F>(S_in, (size_t)w * T + t));
-    }
-    lds_put_xyzz<F, 256>(lds, tid, rpack<F>(acc));
-    __syncthreads();
-    for (uint32_t d = 128; d >= 1; d >>= 1) {
-        if (tid < d) lds_put_xyzz<F, 256>(lds, tid, rpack<F>(radd<F>(lds_get_xyzz<F, 256>(lds, tid), lds_get_xyzz<F, 256>(lds, tid + d))));
-        __syncthreads();
-    }
-    if (tid == 0) xyzz_store16<F>(out, blockIdx.x, rcanon<F>(lds_get_xyzz<F, 256>(lds, 0)));
-}
+// The bucket reduction proper is msm_reduce.cuh (row / column sums of the bucket grid, then bit sums); this is its point policy
+// for G1: one lane per point, sums in the lazy domain, 256 points per block (48 KiB of LDS for the trees).
+struct RedG1 {
+    using F = G1Field;
+    using X = XYZZ<F>;
+    static constexpr int NT = 256, PTS = 256, MINW = 2;      // <= 256 registers: a wave shares a SIMD with an accumulate wave
+    static __device__ __forceinline__ uint32_t pt() { return threadIdx.x; }
+    static __device__ __forceinline__ X inf() { return xyzz_inf<F>(); }
+    static __device__ __forceinline__ X load(const uint32_t* base, size_t i) { return xyzz_load16<F>(base, i); }
+    static __device__ __forceinline__ void store(uint32_t* base, size_t i, const X& p) { xyzz_store16<F>(base, i, p); }
+    static __device__ __forceinline__ X add(const X& a, const X& b) { return radd<F>(a, b); }
+    static __device__ __forceinline__ X pack(const X& a) { return rpack<F>(a); }
+    static __device__ __forceinline__ X canon(const X& a) { return rcanon<F>(a); }
+    static __device__ __forceinline__ void lds_put(uint32_t* lds, uint32_t slot, const X& p) { lds_put_xyzz<F, PTS>(lds, slot, p); }
+    static __device__ __forceinline__ X lds_get(const uint32_t* lds, uint32_t slot) { return lds_get_xyzz<F, PTS>(lds, slot); }
+};
 
 // Arkworks-layout affine points (Montgomery R = 2^384) -> packed internal form.  all-zero = infinity stays zero.
 template <class F>
@@ -818,7 +775,7 @@ __global__ void __launch_bounds__(256) k_bases_export(const uint32_t* in, uint32
 // and reduce phases of the neighbouring jobs run beside them on other streams.
 template <class F>
 struct MsmBufs {
-    uint32_t *dig, *sorted, *counts, *offs, *seg_local, *small, *order, *sums, *lvS, *lvW, *lvS2, *lvW2, *bits;
+    uint32_t *dig, *sorted, *counts, *offs, *seg_local, *small, *order, *sums, *rowP, *colP, *bits;
     SegDesc* desc;
     HeavyDesc* heavy;
 };
@@ -855,20 +812,11 @@ int msm_prepare_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base
     uint32_t seg = 32;
     while (seg < per_lane && seg < 4096) seg <<= 1;
     job->seg = seg;
-    // Reduce phase geometry.  A merged bucket set of 2^(c-1) > 2^15 buckets is cut into "virtual windows" of 2^15:
-    // sum_b b B_b = sum_v [ R_v + v 2^15 S_v ] with R_v the ordinary window sum of slice v and S_v its plain sum, so the
-    // kernels keep the grid shapes they have for 16 real windows (one slice per block row) instead of one long chain.
-    job->RNB = (merged && p.NB > 32768u) ? 32768u : p.NB;
-    job->Rw = job->Wb * (p.NB / job->RNB);
-    job->T1 = (job->RNB + (1u << REDUCE_K_LOG) - 1) >> REDUCE_K_LOG;
-    // G2: a second chunk level (8 -> 64 buckets per element) before the bit-decomposition sums: 2*T1 additions instead of
-    // ~nbits*T1/2 + 2*T1 in the LDS-tree kernel, which is the part of the G2 reduce chain that co-runs with (and slows)
-    // the G1 accumulate kernels; G1 keeps one level (one launch less in a chain whose launches each wait for a slot)
-    job->levels = (F::WORDS == 24 && job->T1 >= 512) ? 2u : 1u;
-    job->T2 = job->levels == 2 ? (job->T1 + (1u << REDUCE_K_LOG) - 1) >> REDUCE_K_LOG : job->T1;
-    uint32_t nbits = 0;
-    while ((1u << nbits) < job->T2) nbits++;
-    job->nbits = nbits;
+    // Reduce phase geometry (msm_reduce.cuh): every bucket set is a grid of 2^rl x 2^cl buckets, rl + cl = log2(NB)
+    uint32_t lg = 0;
+    while ((1u << lg) < p.NB) lg++;
+    job->log_nb = lg;
+    job->nout = lg + 1;
     return ZK_OK;
 }
 
@@ -895,14 +843,10 @@ int msm_bufs_t(zk_ctx* ctx, ZkMsmJob* job, MsmBufs<F>& b, bool need_sort) {
         ZK_TRY(zk_scratch(ctx, slotname("msm_order"), job->max_segs * 4, (void**)&b.order));
     }
     ZK_TRY(zk_scratch(ctx, slotname("msm_sums"), (nbuck + max_heavy_segs) * XW * 4, (void**)&b.sums));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_lvS"), (size_t)job->Rw * job->T1 * XW * 4, (void**)&b.lvS));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_lvW"), (size_t)job->Rw * job->T1 * XW * 4, (void**)&b.lvW));
-    ZK_TRY(zk_scratch(ctx, slotname("msm_bits"), (size_t)job->Rw * (job->nbits + 2) * XW * 4, (void**)&b.bits));
-    b.lvS2 = b.lvW2 = nullptr;
-    if (job->levels == 2) {
-        ZK_TRY(zk_scratch(ctx, slotname("msm_lvS2"), (size_t)job->Rw * job->T2 * XW * 4, (void**)&b.lvS2));
-        ZK_TRY(zk_scratch(ctx, slotname("msm_lvW2"), (size_t)job->Rw * job->T2 * XW * 4, (void**)&b.lvW2));
-    }
+    const GridGeom gg = make_grid_geom(job->log_nb, (uint32_t)Wb, 256);     // the partial counts do not depend on the block size
+    ZK_TRY(zk_scratch(ctx, slotname("msm_rowP"), grid_row_points(gg) * XW * 4, (void**)&b.rowP));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_colP"), grid_col_points(gg) * XW * 4, (void**)&b.colP));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_bits"), (size_t)Wb * job->nout * XW * 4, (void**)&b.bits));
     return ZK_OK;
 }
 
@@ -1076,40 +1020,31 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     tm->begin(g1 ? "msm_g1.reduce" : "msm_g2.reduce");
     const unsigned light_blocks = (unsigned)std::min<size_t>((job->max_heavy + 63) / 64, 512);
     const unsigned heavy_blocks = (unsigned)std::min<size_t>(job->max_heavy, 1024);
-    const uint32_t nout = job->nbits + (job->Rw > job->Wb ? 2u : 1u);
     if constexpr (F::WORDS != 12) {
         // G2: the same chain on lane pairs (msm_g2pair.hip)
-        ZkG2PairReduce a{job->heavy, job->ctr, b.sums, b.lvS, b.lvW, b.lvS2, b.lvW2, b.bits, job->RNB, job->T1, job->T2, job->Rw,
-                         job->levels, job->nbits, nout, (uint32_t)REDUCE_K_LOG, 2 * light_blocks, heavy_blocks};
-        ZK_TRY(zk_launch_reduce_g2pair(st, a));
+        ZkG2PairReduce a{job->heavy, job->ctr, b.sums, b.rowP, b.colP, b.bits, job->log_nb, job->Wb, 2 * light_blocks, heavy_blocks};
+        ZK_TRY(zk_launch_reduce_g2pair(ctx, st, a));
     } else {
         hipLaunchKernelGGL(k_fold<F>, light_blocks + heavy_blocks, 64, 64 * XW * 4, st, (const HeavyDesc*)job->heavy, job->ctr, b.sums,
                            light_blocks);
-        const size_t threads = (size_t)job->Rw * job->T1;
-        hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads + 63) / 64), 64, 0, st, b.sums, nullptr, b.lvS, b.lvW, job->RNB, job->T1,
-                           (uint32_t)REDUCE_K_LOG, job->Rw, 1, 0);
-        const uint32_t *topS = b.lvS, *topW = b.lvW;
-        if (job->levels == 2) {
-            const size_t threads2 = (size_t)job->Rw * job->T2;
-            hipLaunchKernelGGL(k_reduce<F>, (unsigned)((threads2 + 63) / 64), 64, 0, st, (const uint32_t*)b.lvS, (const uint32_t*)b.lvW, b.lvS2,
-                               b.lvW2, job->T1, job->T2, (uint32_t)REDUCE_K_LOG, job->Rw, 0, 0);
-            topS = b.lvS2;
-            topW = b.lvW2;
-        }
-        hipLaunchKernelGGL(k_bitsum<F>, job->Rw * nout, 256, 256 * XW * 4, st, topS, topW, b.bits, job->T2, job->nbits, nout);   // 48 KiB of LDS
+        const GridGeom gg = make_grid_geom(job->log_nb, job->Wb, RedG1::PTS);
+        hipLaunchKernelGGL(k_grid_l1<RedG1>, gg.row_blocks + gg.col_blocks, RedG1::NT, RedG1::PTS * XW * 4, st, (const uint32_t*)b.sums,
+                           b.rowP, b.colP, gg);
+        hipLaunchKernelGGL(k_grid_bits<RedG1>, gg.n_win * job->nout, RedG1::NT, RedG1::PTS * XW * 4, st, (const uint32_t*)b.rowP,
+                           (const uint32_t*)b.colP, b.bits, gg);                                                      // 48 KiB of LDS each
     }
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
     // pinned destination: a pageable one would make the "async" copy block the host until this job is done
     auto& pin = ctx->pinned[job->pin_key >= 0 ? job->pin_key : job->slot];
-    const size_t bytes = std::max<size_t>((size_t)64 * 17, (size_t)job->Rw * nout) * XW * 4;
+    const size_t bytes = std::max<size_t>((size_t)64 * 17, (size_t)job->Wb * job->nout) * XW * 4;
     if (pin.bytes < bytes) {
         if (pin.p) (void)hipHostFree(pin.p);
         ZK_HIP(ctx, hipHostMalloc(&pin.p, bytes, hipHostMallocDefault));
         pin.bytes = bytes;
     }
     job->hw = (uint32_t*)pin.p;
-    ZK_HIP(ctx, hipMemcpyAsync(job->hw, b.bits, (size_t)job->Rw * nout * XW * 4, hipMemcpyDeviceToHost, st));
+    ZK_HIP(ctx, hipMemcpyAsync(job->hw, b.bits, (size_t)job->Wb * job->nout * XW * 4, hipMemcpyDeviceToHost, st));
     // finish() waits for this event, not for the stream: later jobs' reduce phases may be queued behind on the same stream
     ZK_HIP(ctx, hipEventCreateWithFlags(&job->reduce_done, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventRecord(job->reduce_done, st));
@@ -1126,24 +1061,29 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
     if (job->reduce_done) ZK_HIP(ctx, hipEventSynchronize(job->reduce_done));
     else ZK_HIP(ctx, hipStreamSynchronize(job->stream));
     for (auto* t : job->timers) t->resolve();
-    // window sum = W-part + sum_j 2^j * bit-sum_j ; then Horner over windows, most significant first
-    // (variable_base.rs:94-105).  All in the 64-bit host field.
+    // window sum = 2^cl * sum_j 2^j rowbit_j + sum_j 2^j colbit_j + (plain sum): ONE Horner chain over the row bits followed by
+    // the column bits (msm_reduce.cuh), then Horner over the windows, most significant first (variable_base.rs:94-105).  All
+    // in the 64-bit host field.
     using H = typename Host64Of<F>::type;
-    const bool sliced = job->Rw > job->Wb;              // merged bucket set cut into virtual windows (msm_prepare_t)
-    const uint32_t nout = job->nbits + (sliced ? 2u : 1u);
+    const uint32_t nout = job->nout;
     auto window_sum = [&](uint32_t w) {
         const uint32_t* base = job->hw + (size_t)w * nout * XW;
         XYZZ<H> ws = xyzz_inf<H>();
-        for (int j = (int)job->nbits - 1; j >= 0; j--) {
+        const uint32_t cl = job->log_nb / 2, rl = job->log_nb - cl;
+        for (int j = (int)rl - 1; j >= 0; j--) {
             ws = xyzz_dbl<H>(ws);
             ws = xyzz_add<H>(ws, xyzz_to_host64<F>(xyzz_load<F>(base + (size_t)j * XW)));
         }
-        return xyzz_add<H>(ws, xyzz_to_host64<F>(xyzz_load<F>(base + (size_t)job->nbits * XW)));
+        for (int j = (int)cl - 1; j >= 0; j--) {
+            ws = xyzz_dbl<H>(ws);
+            ws = xyzz_add<H>(ws, xyzz_to_host64<F>(xyzz_load<F>(base + (size_t)(rl + j) * XW)));
+        }
+        return xyzz_add<H>(ws, xyzz_to_host64<F>(xyzz_load<F>(base + (size_t)(nout - 1) * XW)));
     };
     XYZZ<H> total = xyzz_inf<H>();
-    // the per-window Horner chains (13 doublings + 13 additions each, ~0.8 ms in all for 16 windows on one core) are
-    // independent: four host threads take them, because the last job's finish sits on the proof's critical path
-    const uint32_t nwin = sliced ? job->Rw : job->Wb;
+    // the per-window Horner chains (~15 doublings + 16 additions each for 16 windows) are independent: four host threads take
+    // them, because the last job's finish sits on the proof's critical path.  A merged bucket set is one window: one chain.
+    const uint32_t nwin = job->Wb;
     std::vector<XYZZ<H>> wsum(nwin);
     {
         const uint32_t nthreads = nwin >= 8 ? 4u : 1u;
@@ -1153,24 +1093,10 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
         for (uint32_t w = 0; w < nwin; w += nthreads) wsum[w] = window_sum(w);
         for (auto& f : tasks) f.get();
     }
-    if (sliced) {
-        // total = sum_v R_v + 2^15 sum_v v S_v; the device's plain sums are 2^K sum S (k_reduce pre-multiplies by the chunk size)
-        XYZZ<H> run = xyzz_inf<H>(), vs = xyzz_inf<H>();
-        for (uint32_t v = job->Rw; v-- > 0;) {
-            total = xyzz_add<H>(total, wsum[v]);
-            if (v > 0) {
-                run = xyzz_add<H>(run, xyzz_to_host64<F>(xyzz_load<F>(job->hw + ((size_t)v * nout + job->nbits + 1) * XW)));
-                vs = xyzz_add<H>(vs, run);
-            }
-        }
-        for (uint32_t k = REDUCE_K_LOG * job->levels; k < 15; k++) vs = xyzz_dbl<H>(vs);   // the plain sums carry 2^(K levels)
-        total = xyzz_add<H>(total, vs);
-    } else {
-        for (int w = (int)job->Wb - 1; w >= 0; w--) {
-            const uint32_t cw = (uint32_t)(job->off[w + 1] - job->off[w]);   // 2^cw * (sum of the higher windows) + this window
-            for (uint32_t k = 0; k < cw; k++) total = xyzz_dbl<H>(total);
-            total = xyzz_add<H>(total, wsum[(uint32_t)w]);
-        }
+    for (int w = (int)job->Wb - 1; w >= 0; w--) {
+        const uint32_t cw = job->Wb == 1 ? 0u : (uint32_t)(job->off[w + 1] - job->off[w]);   // 2^cw * (sum of the higher windows) + this window
+        for (uint32_t k = 0; k < cw; k++) total = xyzz_dbl<H>(total);
+        total = xyzz_add<H>(total, wsum[(uint32_t)w]);
     }
     host64_write_projective<H>(xyzz_to_affine<H>(total), (uint64_t*)out_host);
     return ZK_OK;

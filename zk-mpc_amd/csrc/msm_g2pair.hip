@@ -21,6 +21,7 @@
 #include "devutil.cuh"
 #include "../../include/zkmpc_hip.h"
 #include "internal.hpp"
+#include "msm_reduce.cuh"
 #include <stdlib.h>
 
 using namespace zk;
@@ -285,53 +286,22 @@ k_fold_g2pair(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint3
     }
 }
 
-// msm.hip::k_reduce on pairs (one chunk of 2^klog elements per pair)
-__global__ void __launch_bounds__(64, 2)   // <= 256 registers: shares a SIMD with an accumulate wave (msm.hip::k_reduce)
-k_reduce_g2pair(const uint32_t* S_in, const uint32_t* W_in, uint32_t* S_out, uint32_t* W_out, uint32_t T_in, uint32_t T_out,
-                uint32_t klog, uint32_t n_windows, int one_based, int last) {
-    const size_t t = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 1;
-    const uint32_t odd = threadIdx.x & 1u;
-    if (t >= (size_t)n_windows * T_out) return;
-    const uint32_t w = (uint32_t)(t / T_out), c = (uint32_t)(t - (size_t)w * T_out);
-    const uint32_t lo = c << klog, hi = min(lo + (1u << klog), T_in);
-    XP running = xyzz_inf<FP>(), acc = xyzz_inf<FP>(), wsum = xyzz_inf<FP>();
-    for (uint32_t k = hi; k-- > lo;) {
-        const size_t idx = (size_t)w * T_in + k;
-        if (W_in) wsum = xyzz_add<FP>(wsum, xyzz_load_pair(W_in, idx, odd));
-        running = xyzz_add<FP>(running, xyzz_load_pair(S_in, idx, odd));
-        if (k > lo || one_based) acc = xyzz_add<FP>(acc, running);
-    }
-    acc = xyzz_add<FP>(acc, wsum);
-    xyzz_store_pair(W_out, t, odd, acc);
-    if (!last) {
-        for (uint32_t k = 0; k < klog; k++) running = xyzz_dbl<FP>(running);
-        xyzz_store_pair(S_out, t, odd, running);
-    }
-}
-
-// msm.hip::k_bitsum on pairs: 512 lanes = 256 pairs per block (96 KiB of LDS for the tree)
-__global__ void __launch_bounds__(512)
-k_bitsum_g2pair(const uint32_t* S_in, const uint32_t* W_in, uint32_t* out, uint32_t T, uint32_t nbits, uint32_t nout) {
-    extern __shared__ uint32_t lds[];  // 512 * 48 words
-    const uint32_t w = blockIdx.x / nout, j = blockIdx.x % nout;
-    const uint32_t tid = threadIdx.x, lt = tid >> 1, odd = tid & 1u;
-    XP acc = xyzz_inf<FP>();
-    if (j == nbits) {
-        for (uint32_t t = lt; t < T; t += 256) acc = xyzz_add<FP>(acc, xyzz_load_pair(W_in, (size_t)w * T + t, odd));
-    } else if (j == nbits + 1) {
-        for (uint32_t t = lt; t < T; t += 256) acc = xyzz_add<FP>(acc, xyzz_load_pair(S_in, (size_t)w * T + t, odd));
-    } else {
-        for (uint32_t t = lt; t < T; t += 256)
-            if ((t >> j) & 1) acc = xyzz_add<FP>(acc, xyzz_load_pair(S_in, (size_t)w * T + t, odd));
-    }
-    lds_put_pair<512>(lds, tid, acc);
-    __syncthreads();
-    for (uint32_t d = 128; d >= 1; d >>= 1) {
-        if (lt < d) lds_put_pair<512>(lds, tid, xyzz_add<FP>(lds_get_pair<512>(lds, tid), lds_get_pair<512>(lds, tid + 2 * d)));
-        __syncthreads();
-    }
-    if (lt == 0) xyzz_store_pair(out, blockIdx.x, odd, lds_get_pair<512>(lds, tid));
-}
+// Point policy of msm_reduce.cuh for G2: a lane PAIR per point (even lane c0, odd lane c1 of every Fq2 coordinate), 128 points
+// per 256-lane block; a point's two halves sit in neighbouring LDS slots.
+struct RedG2Pair {
+    using X = XP;
+    static constexpr int NT = 256, PTS = (int)ZK_G2PAIR_RED_PTS, MINW = 2;     // <= 256 registers, like the accumulate kernel
+    static __device__ __forceinline__ uint32_t pt() { return threadIdx.x >> 1; }
+    static __device__ __forceinline__ uint32_t odd() { return threadIdx.x & 1u; }
+    static __device__ __forceinline__ X inf() { return xyzz_inf<FP>(); }
+    static __device__ __forceinline__ X load(const uint32_t* base, size_t i) { return xyzz_load_pair(base, i, odd()); }
+    static __device__ __forceinline__ void store(uint32_t* base, size_t i, const X& p) { xyzz_store_pair(base, i, odd(), p); }
+    static __device__ __forceinline__ X add(const X& a, const X& b) { return xyzz_add<FP>(a, b); }
+    static __device__ __forceinline__ X pack(const X& a) { return a; }
+    static __device__ __forceinline__ X canon(const X& a) { return a; }
+    static __device__ __forceinline__ void lds_put(uint32_t* lds, uint32_t slot, const X& p) { lds_put_pair<NT>(lds, 2 * slot + odd(), p); }
+    static __device__ __forceinline__ X lds_get(const uint32_t* lds, uint32_t slot) { return lds_get_pair<NT>(lds, 2 * slot + odd()); }
+};
 
 }  // namespace
 
@@ -347,26 +317,14 @@ void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bas
 }
 
 // The G2 reduce chain of msm.hip::msm_enqueue_reduce_t, same buffers and geometry, on lane pairs.
-int zk_launch_reduce_g2pair(hipStream_t st, const ZkG2PairReduce& a) {
+int zk_launch_reduce_g2pair(zk_ctx* ctx, hipStream_t st, const ZkG2PairReduce& a) {
     hipLaunchKernelGGL(k_fold_g2pair, a.light_blocks + a.heavy_blocks, 64, 64 * 4 * FW * 4, st, (const HeavyDesc*)a.heavy, a.ctr, a.sums,
                        a.light_blocks);
-    const size_t threads = (size_t)a.Rw * a.T1;
-    hipLaunchKernelGGL(k_reduce_g2pair, (unsigned)((2 * threads + 63) / 64), 64, 0, st, (const uint32_t*)a.sums, (const uint32_t*)nullptr,
-                       a.lvS, a.lvW, a.RNB, a.T1, a.klog, a.Rw, 1, 0);
-    const uint32_t *topS = a.lvS, *topW = a.lvW;
-    if (a.levels == 2) {
-        const size_t threads2 = (size_t)a.Rw * a.T2;
-        hipLaunchKernelGGL(k_reduce_g2pair, (unsigned)((2 * threads2 + 63) / 64), 64, 0, st, (const uint32_t*)a.lvS, (const uint32_t*)a.lvW,
-                           a.lvS2, a.lvW2, a.T1, a.T2, a.klog, a.Rw, 0, 0);
-        topS = a.lvS2;
-        topW = a.lvW2;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_bitsum_g2pair, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 4 * FW * 4) != hipSuccess)
-            return ZK_ERR_HIP;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_bitsum_g2pair, a.Rw * a.nout, 512, 512 * 4 * FW * 4, st, topS, topW, a.bits, a.T2, a.nbits, a.nout);
+    const GridGeom gg = make_grid_geom(a.log_nb, a.n_win, RedG2Pair::PTS);
+    const size_t lds = (size_t)RedG2Pair::NT * 4 * FW * 4;            // 48 KiB
+    hipLaunchKernelGGL(k_grid_l1<RedG2Pair>, gg.row_blocks + gg.col_blocks, RedG2Pair::NT, lds, st, (const uint32_t*)a.sums, a.rowP, a.colP, gg);
+    hipLaunchKernelGGL(k_grid_bits<RedG2Pair>, gg.n_win * grid_nout(gg), RedG2Pair::NT, lds, st, (const uint32_t*)a.rowP, (const uint32_t*)a.colP,
+                       a.bits, gg);
+    ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
 }

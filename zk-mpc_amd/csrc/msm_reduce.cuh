@@ -1,0 +1,164 @@
+// msm_reduce.cuh -- the bucket reduction  sum_b (b + 1) * B_b  of a window as a GRID of row and column sums (gfx950).
+//
+// Replaces the running-sum loop of VariableBaseMSM::multi_scalar_mul (arkworks/algebra/ec/src/msm/variable_base.rs:82-88:
+// `running_sum += b; res += running_sum`, two dependent additions per bucket, strictly serial) with two INDEPENDENT
+// additions per bucket that fill the chip:
+//     bucket b = hi * C + lo  (R = 2^rl rows of C = 2^cl buckets)
+//     sum_b (b + 1) B_b  =  C * sum_hi hi * Row_hi  +  sum_lo lo * Col_lo  +  sum_lo Col_lo
+//     Row_hi = sum_lo B[hi][lo]      Col_lo = sum_hi B[hi][lo]
+// k_grid_l1   every lane sums K = 8 buckets of one row (or one column), TW = 32 lanes then combine through an LDS tree whose
+//             active lanes are kept contiguous (whole waves retire, none idles half-masked): 2^19 buckets -> 2 048 row partials
+//             and 2 048 column partials in one launch, depth 7 + 5 additions, all of it at full occupancy
+// k_grid_bits sum_hi hi * Row_hi = sum_j 2^j * (sum of the rows whose index has bit j): one block per bit (and one for the plain
+//             sum), a strided pass over the selected partials and an LDS tree; rl + cl + 1 points per window go to the host,
+//             which finishes with one Horner chain (msm.hip: msm_finish_t)
+// The previous form (one chunk level of running sums + bit sums over 2^15-bucket slices) did ~3.6 additions per bucket in
+// chains of 16 + 24 dependent additions at one wave per SIMD; this one does ~2.1 in chains of 12 + 12.
+//
+// The kernels are written once over a "point policy" P (msm.hip: G1, one lane per point, lazy Fq domain; msm_g2pair.hip: G2,
+// a lane PAIR per point):
+//   P::NT lanes per block, P::PTS points per block, P::pt() this lane's point slot, P::X the point type,
+//   inf / load / store (packed XYZZ in memory) / add / pack (fit for the packed form) / canon (fully reduced) / lds_put / lds_get.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace zk {
+
+struct GridGeom {
+    uint32_t rl, cl;           // R = 2^rl rows, C = 2^cl columns per window
+    uint32_t n_win;            // windows (bucket sets) back to back in `sums`
+    uint32_t Kr, TWr, Pr, lgPr;   // row sums (over lo): K serial x TW tree lanes; Pr = C / (Kr TWr) partials per row remain
+    uint32_t Kc, TWc, Pc;         // column sums (over hi): Pc = R / (Kc TWc) partials per column remain
+    uint32_t row_blocks, col_blocks;
+};
+
+static inline void grid_split(uint32_t D, uint32_t& K, uint32_t& TW, uint32_t& P) {
+    K = D < 8 ? D : 8;
+    TW = D / K < 32 ? D / K : 32;
+    P = D / (K * TW);
+}
+// log_nb = log2(buckets per window); pts = points per block of the kernels (P::PTS)
+static inline GridGeom make_grid_geom(uint32_t log_nb, uint32_t n_win, uint32_t pts) {
+    GridGeom g;
+    g.cl = log_nb / 2;
+    g.rl = log_nb - g.cl;
+    g.n_win = n_win;
+    grid_split(1u << g.cl, g.Kr, g.TWr, g.Pr);
+    grid_split(1u << g.rl, g.Kc, g.TWc, g.Pc);
+    g.lgPr = 0;
+    while ((1u << g.lgPr) < g.Pr) g.lgPr++;
+    const size_t row_groups = ((size_t)n_win << g.rl) * g.Pr, col_groups = ((size_t)n_win << g.cl) * g.Pc;
+    const size_t gr = pts / g.TWr, gc = pts / g.TWc;           // groups per block
+    g.row_blocks = (uint32_t)((row_groups + gr - 1) / gr);
+    g.col_blocks = (uint32_t)((col_groups + gc - 1) / gc);
+    return g;
+}
+static inline size_t grid_row_points(const GridGeom& g) { return ((size_t)g.n_win << g.rl) * g.Pr; }
+static inline size_t grid_col_points(const GridGeom& g) { return ((size_t)g.n_win << g.cl) * g.Pc; }
+static inline uint32_t grid_nout(const GridGeom& g) { return g.rl + g.cl + 1; }
+
+#ifdef __HIPCC__
+// rowP[(w R + hi) Pr + part], colP[(w Pc + part) C + lo]: partial sums, packed form
+template <class P>
+__global__ void __launch_bounds__(P::NT, P::MINW)
+k_grid_l1(const uint32_t* __restrict__ sums, uint32_t* __restrict__ rowP, uint32_t* __restrict__ colP, GridGeom g) {
+    extern __shared__ uint32_t grid_lds[];
+    using X = typename P::X;
+    const uint32_t pt = P::pt();
+    const bool is_row = blockIdx.x < g.row_blocks;
+    const uint32_t R = 1u << g.rl, C = 1u << g.cl;
+    const uint32_t TW = is_row ? g.TWr : g.TWc, K = is_row ? g.Kr : g.Kc;
+    const uint32_t G = P::PTS / TW;                                   // groups per block
+    const uint32_t q = is_row ? pt / TW : pt % G, i = is_row ? pt % TW : pt / G;      // group in the block, lane in the group
+    const size_t n_groups = is_row ? ((size_t)g.n_win << g.rl) * g.Pr : ((size_t)g.n_win << g.cl) * g.Pc;
+    const size_t g0 = (size_t)(is_row ? blockIdx.x : blockIdx.x - g.row_blocks) * G;
+    const size_t gg = g0 + q;
+    uint32_t* out = is_row ? rowP : colP;
+    X acc = P::inf();
+    if (gg < n_groups) {
+        size_t base, step;
+        if (is_row) {
+            const uint32_t part = (uint32_t)(gg % g.Pr);
+            const size_t row = gg / g.Pr;                                          // w R + hi
+            base = row * C + (size_t)part * K * TW + i;                            // lanes of a group read neighbouring buckets
+            step = TW;
+        } else {
+            const uint32_t lo = (uint32_t)(gg & (C - 1));
+            const size_t rest = gg >> g.cl;
+            const uint32_t part = (uint32_t)(rest % g.Pc);
+            const size_t w = rest / g.Pc;
+            base = (w * R + (size_t)part * K * TW + i) * C + lo;                   // neighbouring lanes read neighbouring columns
+            step = (size_t)TW * C;
+        }
+        acc = P::load(sums, base);
+        for (uint32_t k = 1; k < K; k++) acc = P::add(acc, P::load(sums, base + k * step));
+    }
+    if (TW == 1) {                                                    // block-uniform: tiny windows, nothing to combine
+        if (gg < n_groups) P::store(out, gg, P::pack(acc));
+        return;
+    }
+    // LDS tree over the TW lanes of each group.  Slot of (group q, lane i) = this lane's own slot: q TW + i (rows), i G + q
+    // (columns).  At a level with d active lanes per group the G d additions go to the FIRST G d lanes of the block.
+    P::lds_put(grid_lds, pt, P::pack(acc));
+    __syncthreads();
+    for (uint32_t d = TW >> 1; d >= 1; d >>= 1) {
+        const bool on = pt < G * d;
+        const uint32_t qq = pt / d, ii = pt % d;
+        const uint32_t a = is_row ? qq * TW + ii : ii * G + qq;
+        const uint32_t b = is_row ? a + d : a + d * G;
+        X s = P::inf();
+        if (on) s = P::pack(P::add(P::lds_get(grid_lds, a), P::lds_get(grid_lds, b)));
+        if (d == 1) {
+            if (on && g0 + qq < n_groups) P::store(out, g0 + qq, s);
+            break;
+        }
+        __syncthreads();                      // every read of this level before its writes (a is read by its own lane only, b by none other)
+        if (on) P::lds_put(grid_lds, a, s);
+        __syncthreads();
+    }
+}
+
+// out[w * nout + j], nout = rl + cl + 1:  j < rl: sum of the rows with bit j;  rl <= j < rl + cl: sum of the columns with bit
+// j - rl;  j = rl + cl: sum of all columns.  Fully reduced (the host reads them).
+template <class P>
+__global__ void __launch_bounds__(P::NT, P::MINW)
+k_grid_bits(const uint32_t* __restrict__ rowP, const uint32_t* __restrict__ colP, uint32_t* __restrict__ out, GridGeom g) {
+    extern __shared__ uint32_t grid_lds[];
+    using X = typename P::X;
+    const uint32_t nout = g.rl + g.cl + 1;
+    const uint32_t w = blockIdx.x / nout, j = blockIdx.x % nout;
+    const uint32_t pt = P::pt();
+    X acc = P::inf();
+    const uint32_t* src;
+    uint32_t T, pos;                          // T points per window; the selected ones have bit `pos` of their index set
+    bool all = false;
+    if (j < g.rl) { src = rowP; T = (1u << g.rl) * g.Pr; pos = j + g.lgPr; }
+    else { src = colP; T = g.Pc << g.cl; pos = j - g.rl; all = pos == g.cl; }
+    if (all) {
+        for (uint32_t t = pt; t < T; t += P::PTS) acc = P::add(acc, P::load(src, (size_t)w * T + t));
+    } else {
+        const uint32_t low = (1u << pos) - 1;
+        for (uint32_t s = pt; s < (T >> 1); s += P::PTS) {           // the s-th index with bit pos set: every lane does the same number
+            const uint32_t t = ((s & ~low) << 1) | (1u << pos) | (s & low);
+            acc = P::add(acc, P::load(src, (size_t)w * T + t));
+        }
+    }
+    P::lds_put(grid_lds, pt, P::pack(acc));
+    __syncthreads();
+    for (uint32_t d = P::PTS >> 1; d >= 1; d >>= 1) {
+        const bool on = pt < d;
+        X s = P::inf();
+        if (on) s = P::add(P::lds_get(grid_lds, pt), P::lds_get(grid_lds, pt + d));
+        if (d == 1) {
+            if (on) P::store(out, blockIdx.x, P::canon(s));
+            break;
+        }
+        __syncthreads();
+        if (on) P::lds_put(grid_lds, pt, P::pack(s));
+        __syncthreads();
+    }
+}
+#endif  // __HIPCC__
+
+}  // namespace zk
