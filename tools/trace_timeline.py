@@ -14,6 +14,8 @@ for r in rows:
     n = r['Kernel_Name']; m = re.search(r'(k_\w+)(<[^>]*>)?', n)
     r['k'] = (m.group(1) + ('.g2' if 'Fq2' in n else '.g1' if 'FqField' in n else '')) if m else n[:30]
     if r['k'].endswith('_g2pair'): r['k'] = r['k'][:-7] + '.g2'      # the lane-pair G2 kernels of msm_g2pair.hip
+    if 'RedG2Pair' in n: r['k'] += '.g2'                             # msm_reduce.cuh kernels by point policy
+    elif 'RedG1' in n: r['k'] += '.g1'
     if 'rocprim' in n: r['k'] = 'rocprim.radix_sort'                 # onesweep histogram / digit passes (msm_sort.hip)
 acc = [i for i, r in enumerate(rows) if r['k'] == 'k_accum.g2']
 t0 = rows[acc[which]]['s'] - 5_000_000

@@ -286,8 +286,42 @@ k_fold_g2pair(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint3
     }
 }
 
+// a + b ("add-2008-s") on a lane pair in the lazy domain -- the pair form of ec.cuh::xyzz_add_lazy, with the ranges of
+// madd_p_lazy above: x < 5p + eps, y < 3p + eps (a difference of two products), zz, zzz < p + eps; fully reduced coordinates
+// included; infinity = all-zero words.  The result is in the same ranges.  U1, U2, S1, S2 < p + eps; P = U2 + 2p - U1 and
+// R = S2 + 2p - S1 in (p - eps, 3p + eps): every double product stays inside the column bounds that R * T (5p x 7p on both
+// lanes) already needs (tests/test_abi.py::test_lazy_domain_column_bounds).  P = 0 in Fq2 iff both components are p, 2p or 3p.
+__device__ __forceinline__ XP add_p_lazy(const XP& a, const XP& b, bool odd) {
+    if (pair_zero(limbs_or(a.zz))) return b;
+    if (pair_zero(limbs_or(b.zz))) return a;
+    const Fq u1 = mulp_l(prep(a.x, odd), b.zz);
+    const Fq u2 = mulp_l(prep(b.x, odd), a.zz);
+    const Fq s1 = mulp_l(prep(a.y, odd), b.zzz);
+    const Fq s2 = mulp_l(prep(b.y, odd), a.zzz);
+    const Fq p = B::sub_kp<2>(u2, u1);
+    const Fq r = B::sub_kp<2>(s2, s1);
+    const uint32_t maybe = B::maybe_multiple_of_p(p) ? 1u : 0u;
+    if (maybe & dpp_swap1(maybe)) {
+        if (pair_zero(limbs_or(B::canon(p)))) {
+            if (pair_zero(limbs_or(B::canon(r))))
+                return xyzz_dbl<FP>(XP{B::canon(a.x), B::canon(a.y), B::canon1(a.zz), B::canon1(a.zzz)});
+            return xyzz_inf<FP>();
+        }
+    }
+    const Fq pp = mulp_l(prep(p, odd), p);
+    const Left PP = prep(pp, odd);
+    const Fq ppp = mulp_l(PP, p);
+    const Fq qq = mulp_l(PP, u1);
+    const Left R = prep(r, odd);
+    const Fq x3 = B::x3_l(mulp_l(R, r), ppp, qq);
+    const Left PPP = prep(ppp, odd);
+    const Fq y3 = B::sub_kp<2>(mulp_l(R, B::sub_kp<6>(qq, x3)), mulp_l(PPP, s1));
+    return XP{x3, y3, mulp_l(PP, mulp_l(prep(a.zz, odd), b.zz)), mulp_l(PPP, mulp_l(prep(a.zzz, odd), b.zzz))};
+}
+
 // Point policy of msm_reduce.cuh for G2: a lane PAIR per point (even lane c0, odd lane c1 of every Fq2 coordinate), 128 points
-// per 256-lane block; a point's two halves sit in neighbouring LDS slots.
+// per 256-lane block; a point's two halves sit in neighbouring LDS slots.  Sums in the lazy domain; the packed 12-word form
+// holds 377 bits, so x and y are brought below p where a sum is packed.
 struct RedG2Pair {
     using X = XP;
     static constexpr int NT = 256, PTS = (int)ZK_G2PAIR_RED_PTS, MINW = 2;     // <= 256 registers, like the accumulate kernel
@@ -296,9 +330,9 @@ struct RedG2Pair {
     static __device__ __forceinline__ X inf() { return xyzz_inf<FP>(); }
     static __device__ __forceinline__ X load(const uint32_t* base, size_t i) { return xyzz_load_pair(base, i, odd()); }
     static __device__ __forceinline__ void store(uint32_t* base, size_t i, const X& p) { xyzz_store_pair(base, i, odd(), p); }
-    static __device__ __forceinline__ X add(const X& a, const X& b) { return xyzz_add<FP>(a, b); }
-    static __device__ __forceinline__ X pack(const X& a) { return a; }
-    static __device__ __forceinline__ X canon(const X& a) { return a; }
+    static __device__ __forceinline__ X add(const X& a, const X& b) { return add_p_lazy(a, b, odd() != 0); }
+    static __device__ __forceinline__ X pack(const X& a) { return X{B::canon(a.x), B::canon(a.y), a.zz, a.zzz}; }
+    static __device__ __forceinline__ X canon(const X& a) { return X{B::canon(a.x), B::canon(a.y), B::canon1(a.zz), B::canon1(a.zzz)}; }
     static __device__ __forceinline__ void lds_put(uint32_t* lds, uint32_t slot, const X& p) { lds_put_pair<NT>(lds, 2 * slot + odd(), p); }
     static __device__ __forceinline__ X lds_get(const uint32_t* lds, uint32_t slot) { return lds_get_pair<NT>(lds, 2 * slot + odd()); }
 };

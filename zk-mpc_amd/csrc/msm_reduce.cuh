@@ -59,6 +59,10 @@ static inline size_t grid_col_points(const GridGeom& g) { return ((size_t)g.n_wi
 static inline uint32_t grid_nout(const GridGeom& g) { return g.rl + g.cl + 1; }
 
 #ifdef __HIPCC__
+// Both kernels run ONE loop whose body holds the only call of P::add: the serial steps (operand from memory) and the tree
+// levels (both operands from LDS) are iterations of the same loop.  A point addition is ~7 k instructions (~55 KB): two or
+// three inlined copies do not fit the instruction cache a CU pair shares, beside an accumulate kernel's own 38 KB loop.
+//
 // rowP[(w R + hi) Pr + part], colP[(w Pc + part) C + lo]: partial sums, packed form
 template <class P>
 __global__ void __launch_bounds__(P::NT, P::MINW)
@@ -75,9 +79,8 @@ k_grid_l1(const uint32_t* __restrict__ sums, uint32_t* __restrict__ rowP, uint32
     const size_t g0 = (size_t)(is_row ? blockIdx.x : blockIdx.x - g.row_blocks) * G;
     const size_t gg = g0 + q;
     uint32_t* out = is_row ? rowP : colP;
-    X acc = P::inf();
+    size_t base = 0, step = 0;
     if (gg < n_groups) {
-        size_t base, step;
         if (is_row) {
             const uint32_t part = (uint32_t)(gg % g.Pr);
             const size_t row = gg / g.Pr;                                          // w R + hi
@@ -91,31 +94,41 @@ k_grid_l1(const uint32_t* __restrict__ sums, uint32_t* __restrict__ rowP, uint32
             base = (w * R + (size_t)part * K * TW + i) * C + lo;                   // neighbouring lanes read neighbouring columns
             step = (size_t)TW * C;
         }
-        acc = P::load(sums, base);
-        for (uint32_t k = 1; k < K; k++) acc = P::add(acc, P::load(sums, base + k * step));
     }
-    if (TW == 1) {                                                    // block-uniform: tiny windows, nothing to combine
-        if (gg < n_groups) P::store(out, gg, P::pack(acc));
-        return;
-    }
-    // LDS tree over the TW lanes of each group.  Slot of (group q, lane i) = this lane's own slot: q TW + i (rows), i G + q
-    // (columns).  At a level with d active lanes per group the G d additions go to the FIRST G d lanes of the block.
-    P::lds_put(grid_lds, pt, P::pack(acc));
-    __syncthreads();
-    for (uint32_t d = TW >> 1; d >= 1; d >>= 1) {
-        const bool on = pt < G * d;
-        const uint32_t qq = pt / d, ii = pt % d;
-        const uint32_t a = is_row ? qq * TW + ii : ii * G + qq;
-        const uint32_t b = is_row ? a + d : a + d * G;
-        X s = P::inf();
-        if (on) s = P::pack(P::add(P::lds_get(grid_lds, a), P::lds_get(grid_lds, b)));
-        if (d == 1) {
-            if (on && g0 + qq < n_groups) P::store(out, g0 + qq, s);
-            break;
+    uint32_t nlev = 0;
+    while ((1u << nlev) < TW) nlev++;
+    // Tree over the TW lanes of each group through LDS.  Slot of (group q, lane i) = the lane's own slot: q TW + i (rows),
+    // i G + q (columns).  At a level with d active lanes per group the G d additions go to the FIRST G d lanes of the block, so
+    // whole waves retire and none runs half-masked.  One barrier per level: a level writes slots (q, i < d), each read at that
+    // level by its own writer only; the slots (q, d <= i < 2d) it also reads are not written.
+    X acc = P::inf();
+    uint32_t a = 0;
+    for (uint32_t it = 0; it < K + nlev; it++) {
+        X v = P::inf();
+        bool act;
+        uint32_t qq = 0;
+        if (it < K) {
+            act = gg < n_groups;
+            if (act) v = P::load(sums, base + it * step);
+        } else {
+            if (it == K) P::lds_put(grid_lds, pt, P::pack(acc));
+            __syncthreads();
+            const uint32_t d = TW >> (it - K + 1);
+            act = pt < G * d;
+            qq = pt / d;
+            const uint32_t ii = pt % d;
+            a = is_row ? qq * TW + ii : ii * G + qq;
+            if (act) {
+                acc = P::lds_get(grid_lds, a);
+                v = P::lds_get(grid_lds, is_row ? a + d : a + d * G);
+            }
         }
-        __syncthreads();                      // every read of this level before its writes (a is read by its own lane only, b by none other)
-        if (on) P::lds_put(grid_lds, a, s);
-        __syncthreads();
+        if (act) acc = P::add(acc, v);
+        if (it >= K && it + 1 < K + nlev && act) P::lds_put(grid_lds, a, P::pack(acc));
+        if (it + 1 == K + nlev) {
+            const size_t og = nlev ? g0 + qq : gg;
+            if (act && og < n_groups) P::store(out, og, P::pack(acc));
+        }
     }
 }
 
@@ -129,34 +142,37 @@ k_grid_bits(const uint32_t* __restrict__ rowP, const uint32_t* __restrict__ colP
     const uint32_t nout = g.rl + g.cl + 1;
     const uint32_t w = blockIdx.x / nout, j = blockIdx.x % nout;
     const uint32_t pt = P::pt();
-    X acc = P::inf();
     const uint32_t* src;
     uint32_t T, pos;                          // T points per window; the selected ones have bit `pos` of their index set
     bool all = false;
     if (j < g.rl) { src = rowP; T = (1u << g.rl) * g.Pr; pos = j + g.lgPr; }
     else { src = colP; T = g.Pc << g.cl; pos = j - g.rl; all = pos == g.cl; }
-    if (all) {
-        for (uint32_t t = pt; t < T; t += P::PTS) acc = P::add(acc, P::load(src, (size_t)w * T + t));
-    } else {
-        const uint32_t low = (1u << pos) - 1;
-        for (uint32_t s = pt; s < (T >> 1); s += P::PTS) {           // the s-th index with bit pos set: every lane does the same number
-            const uint32_t t = ((s & ~low) << 1) | (1u << pos) | (s & low);
-            acc = P::add(acc, P::load(src, (size_t)w * T + t));
+    const uint32_t nsel = all ? T : T >> 1, low = (1u << pos) - 1;
+    const uint32_t nser = (nsel + P::PTS - 1) / P::PTS;
+    uint32_t nlev = 0;
+    while ((1u << nlev) < (uint32_t)P::PTS) nlev++;
+    X acc = P::inf();
+    for (uint32_t it = 0; it < nser + nlev; it++) {
+        X v = P::inf();
+        bool act;
+        if (it < nser) {
+            const uint32_t s = it * P::PTS + pt;                     // the s-th selected index: every lane does the same number
+            act = s < nsel;
+            const uint32_t t = all ? s : (((s & ~low) << 1) | (1u << pos) | (s & low));
+            if (act) v = P::load(src, (size_t)w * T + t);
+        } else {
+            if (it == nser) P::lds_put(grid_lds, pt, P::pack(acc));
+            __syncthreads();
+            const uint32_t d = (uint32_t)P::PTS >> (it - nser + 1);
+            act = pt < d;
+            if (act) {
+                acc = P::lds_get(grid_lds, pt);
+                v = P::lds_get(grid_lds, pt + d);
+            }
         }
-    }
-    P::lds_put(grid_lds, pt, P::pack(acc));
-    __syncthreads();
-    for (uint32_t d = P::PTS >> 1; d >= 1; d >>= 1) {
-        const bool on = pt < d;
-        X s = P::inf();
-        if (on) s = P::add(P::lds_get(grid_lds, pt), P::lds_get(grid_lds, pt + d));
-        if (d == 1) {
-            if (on) P::store(out, blockIdx.x, P::canon(s));
-            break;
-        }
-        __syncthreads();
-        if (on) P::lds_put(grid_lds, pt, P::pack(s));
-        __syncthreads();
+        if (act) acc = P::add(acc, v);
+        if (it >= nser && it + 1 < nser + nlev && act) P::lds_put(grid_lds, pt, P::pack(acc));
+        if (it + 1 == nser + nlev && pt == 0) P::store(out, blockIdx.x, P::canon(acc));
     }
 }
 #endif  // __HIPCC__
