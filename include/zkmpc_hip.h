@@ -7,7 +7,11 @@
  *
  * Conventions
  *  - every function returns 0 (ZK_OK) or a negative error code; zk_last_error() has the text.
- *    Nothing aborts or throws across the boundary.
+ *    Nothing aborts or throws across the boundary: every `int` entry point runs inside an exception barrier
+ *    (std::bad_alloc -> ZK_ERR_NOMEM, any other C++ exception -> ZK_ERR_STATE).
+ *  - a context OWNS its device: every entry point that takes a zk_ctx makes ctx's device the calling thread's current HIP
+ *    device for the duration of the call and restores the previous one on return, so several parties on several GPUs can
+ *    live in one process (the reference's LocalTestNet, mpc-net/src/multi.rs:419-443) whatever device their threads hold.
  *  - "host" pointers are caller-owned and never retained.  "dev" pointers are HIP device
  *    pointers on the context's device.  Opaque handles are library-owned.
  *  - Field elements use the reference's in-memory form: little-endian u64 limbs in
@@ -58,6 +62,10 @@ const char* zk_last_error(zk_ctx* ctx);
 int zk_ctx_sync(zk_ctx* ctx);
 void* zk_ctx_stream(zk_ctx* ctx);          /* hipStream_t, for event timing by the caller */
 int zk_version(void);
+/* Diagnostic: raises a C++ exception INSIDE the boundary wrapper of this library and returns what a caller sees -- kind 0:
+ * std::bad_alloc (-> ZK_ERR_NOMEM), 1: std::runtime_error, 2: a non-std object, 3: std::system_error (-> ZK_ERR_STATE);
+ * kind 4 runs a helper task through the thread-exhaustion fallback (-> ZK_OK).  Needs no device. */
+int zk_selftest_exception_barrier(int kind);
 
 int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** dev_out);
 int zk_dev_free(zk_ctx* ctx, void* dev);

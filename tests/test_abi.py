@@ -47,6 +47,50 @@ def test_no_oracle_import_in_product():
                 assert "zkref" not in src and "oracle/" not in src.replace("oracle/ (", ""), f
 
 
+def test_every_int_entry_point_runs_inside_the_boundary_wrapper():
+    """Every `extern "C" int` definition of csrc/*.hip starts with ZK_API_BEGIN (ctx.hpp: the calling thread's device becomes
+    ctx->device for the call, and no C++ exception leaves the library); the getters that return something else make no HIP
+    call and allocate nothing."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import wrap_abi
+    import glob
+    total, bare = 0, []
+    for path in sorted(glob.glob(os.path.join(ROOT, "zk-mpc_amd", "csrc", "*.hip"))):
+        src = open(path).read()
+        for name, has_ctx, a, b in wrap_abi.entries(src):
+            total += 1
+            body = src[a + 1:b].lstrip()
+            if not body.startswith("ZK_API_BEGIN(ctx)" if has_ctx else "ZK_API_BEGIN_NOCTX"):
+                bare.append(name)
+        for m in re.finditer(r'^extern "C" (?!int )[^\n]*?(zk_\w+)\(', src, re.M):       # non-int getters
+            a = src.index("{", m.end())
+            body = src[a:wrap_abi.match_brace(src, a)]
+            assert not re.search(r"\bhip[A-Z]|std::|\bnew\b", body), m.group(1)
+    assert total >= 125 and not bare, bare
+
+
+def test_exception_barrier_and_thread_fallback():
+    lib = Z.load()
+    assert [lib.zk_selftest_exception_barrier(k) for k in range(6)] == [-3, -4, -4, -4, 0, -2]
+
+
+def test_no_mutable_process_global_state_in_csrc():
+    """re-entrant, per-party context, no process-global device state.  What may be static: constants, env knobs read
+    once (`static const`), and the dlopen'ed RCCL table (`static const Rccl`, initialised once by the language)."""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "zk-mpc_amd", "csrc", "*")):
+        if not path.endswith((".hip", ".hpp", ".cuh")):
+            continue
+        for i, line in enumerate(open(path).read().split("\n")):
+            t = line.strip()
+            if t.startswith("//") or "static" not in t:
+                continue
+            t = re.sub(r"//.*", "", t)
+            if re.search(r"\bstatic\s+(?!const\b|constexpr\b|inline\b|__device__|ZK_HD\b|_assert)", t) and not re.search(r"\)\s*(const\s*)?\{|\)\s*;|\)\s*$|\(", t):
+                raise AssertionError("%s:%d: %s" % (os.path.basename(path), i + 1, line))
+
+
 class _Host(Z.Context):
     def __init__(self):
         self.lib = Z.load()

@@ -17,12 +17,14 @@ from oracle_backend import additive_shares
 pytestmark = pytest.mark.gpu
 
 
-def run_parties(n_parties, fn):
+def run_parties(n_parties, fn, devices=None):
+    """devices: the HIP device of each party's context (default: all on device 0).  The party threads never select a device
+    themselves: a context owns its device (ctx.hpp: ZkDeviceGuard at every entry point)."""
     nets = mpc.LocalNet.create(n_parties)
     out, err = [None] * n_parties, []
 
     def work(p):
-        ctx = Z.Context(0, p, n_parties)
+        ctx = Z.Context(devices[p] if devices else 0, p, n_parties)
         try:
             out[p] = fn(p, ctx, nets[p])
         except Exception as e:  # pragma: no cover
@@ -98,6 +100,49 @@ def test_collaborative_prove(n_parties, n):
     D = 1 << cr.domain_log
     # Appendix C traffic in the reference's order of opens; fused, s + y is opened once and A is the opened point of the second scale
     assert all(b == (2 * D * 32 + 2 * 32 + 3 * 144 + 288 + 144, 2 * D * 32 + 3 * (144 + 32) + 144 + 288 + 144) for _, b in res)
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs in one process")
+@pytest.mark.parametrize("spdz", [False, True])
+def test_parties_on_different_gpus_inside_one_process(spdz):
+    """The reference's LocalTestNet shape (mpc-net/src/multi.rs:419-443): several parties as tasks of ONE process -- here each
+    on its own GPU, Context(p, p, n), with threads that never call hipSetDevice.  Every entry point has to run on its
+    context's device (scratch, streams, events, kernel launches); the revealed proof equals the local proof on the sums."""
+    ndev = _device_count()
+    n_parties, n = min(ndev, 3), 1000
+    rng = O.Prng(4242 + int(spdz))
+    w0, w1 = rng.fr(), rng.fr()
+    r1cs, z = O.mul_chain_r1cs(n, w0, w1)
+    td = O.Trapdoor(rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr(), rng.fr())
+    r, s = rng.fr(), rng.fr()
+    zs = additive_shares(z, n_parties, rng, public_prefix=2)
+    zm = additive_shares(z, n_parties, rng, public_prefix=2)          # independent sharing of alpha*z, alpha = 1
+    rsh, ssh = O.additive_share(r, n_parties, rng), O.additive_share(s, n_parties, rng)
+    rm, sm = O.additive_share(r, n_parties, rng), O.additive_share(s, n_parties, rng)
+    tdm = td_mont(td)
+
+    def fn(p, ctx, net):
+        assert ctx.device == p
+        dr = ctx.r1cs_mul_chain(n)
+        pk = ctx.groth16_setup(dr, *[tdm[i] for i in range(7)])
+        if spdz:
+            party = mpc.SpdzParty(ctx, net=net)
+            dz, dm = ctx.upload(cv.fr_to_mont(zs[p])), ctx.upload(cv.fr_to_mont(zm[p]))
+            return party.create_proof_shared_spdz(pk, dr, (dz.ptr, dm.ptr), (mont1(rsh[p]), mont1(rm[p])), (mont1(ssh[p]), mont1(sm[p])))
+        party = mpc.Party(ctx, net=net)
+        dz = ctx.upload(cv.fr_to_mont(zs[p]))
+        return party.create_proof_shared(pk, dr, dz.ptr, mont1(rsh[p]), mont1(ssh[p]))
+
+    res = run_parties(n_parties, fn, devices=list(range(n_parties)))
+    cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))
+    zm = cv.fr_to_mont(z)
+    want = OC.groth16_predict(cr, tdm, zm, OC.witness_map(cr, zm), mont1(r), mont1(s))
+    assert all(pr == want for pr in res)
 
 
 @pytest.mark.parametrize("n_parties,n", [(2, 100), (3, 5000), (8, 77)])

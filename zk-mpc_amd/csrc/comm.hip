@@ -34,23 +34,25 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
-Rccl* rccl(std::string* err) {
-    static Rccl r;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        const char* names[] = {getenv("ZK_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* nm : names) {
-            if (!nm) continue;
-            if ((r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
-        }
-        if (r.lib) {
-#define ZK_SYM(f) *(void**)(&r.f) = dlsym(r.lib, "nccl" #f)
-            ZK_SYM(GetUniqueId); ZK_SYM(CommInitRank); ZK_SYM(CommDestroy); ZK_SYM(AllGather); ZK_SYM(Send); ZK_SYM(Recv);
-            ZK_SYM(GroupStart); ZK_SYM(GroupEnd); ZK_SYM(GetErrorString);
-#undef ZK_SYM
-        }
+// Loaded once per process, by whichever thread comes first (a function-local static is initialised exactly once even when
+// several parties' threads arrive together, the LocalTestNet shape of mpc-net/src/multi.rs:419-443); immutable afterwards.
+Rccl load_rccl() {
+    Rccl r;
+    const char* names[] = {getenv("ZK_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nm : names) {
+        if (!nm) continue;
+        if ((r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
     }
+    if (r.lib) {
+#define ZK_SYM(f) *(void**)(&r.f) = dlsym(r.lib, "nccl" #f)
+        ZK_SYM(GetUniqueId); ZK_SYM(CommInitRank); ZK_SYM(CommDestroy); ZK_SYM(AllGather); ZK_SYM(Send); ZK_SYM(Recv);
+        ZK_SYM(GroupStart); ZK_SYM(GroupEnd); ZK_SYM(GetErrorString);
+#undef ZK_SYM
+    }
+    return r;
+}
+const Rccl* rccl(std::string* err) {
+    static const Rccl r = load_rccl();
     if (!r.lib || !r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd) {
         if (err) *err = "RCCL not available (dlopen librccl.so failed or symbols missing; set ZK_RCCL_LIB)";
         return nullptr;
@@ -72,20 +74,23 @@ struct Comm { ncclComm_t comm = nullptr; int rank = 0, n = 1; int pattern = 0; }
 }  // namespace
 
 extern "C" int zk_comm_unique_id(uint8_t out[128]) {
+    ZK_API_BEGIN_NOCTX
     if (!out) return ZK_ERR_ARG;
-    Rccl* R = rccl(nullptr);
+    const Rccl* R = rccl(nullptr);
     if (!R) return ZK_ERR_STATE;
     ncclUniqueId id;
     if (R->GetUniqueId(&id) != ncclSuccess) return ZK_ERR_HIP;
     static_assert(sizeof id == 128, "ncclUniqueId is 128 bytes");
     memcpy(out, &id, 128);
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_comm_init(zk_ctx* ctx, const uint8_t id_bytes[128], int rank, int n_parties) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !id_bytes || n_parties < 1 || rank < 0 || rank >= n_parties) return ZK_ERR_ARG;
     if (ctx->comm) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_comm_init: this context already has a communicator");
-    Rccl* R = rccl(&ctx->last_error);
+    const Rccl* R = rccl(&ctx->last_error);
     if (!R) return ZK_ERR_STATE;
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     ncclUniqueId id;
@@ -101,36 +106,42 @@ extern "C" int zk_comm_init(zk_ctx* ctx, const uint8_t id_bytes[128], int rank, 
     }
     ctx->comm = c;
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_comm_destroy(zk_ctx* ctx) {
+    ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     if (!ctx->comm) return ZK_OK;
     Comm* c = (Comm*)ctx->comm;
-    Rccl* R = rccl(nullptr);
+    const Rccl* R = rccl(nullptr);
     (void)hipStreamSynchronize(ctx->stream);
     if (R && R->CommDestroy && c->comm) (void)R->CommDestroy(c->comm);
     delete c;
     ctx->comm = nullptr;
     return ZK_OK;
+    ZK_API_END
 }
 
 // 0: by party count (all-gather for two parties, all-to-all of slices for three or more); 1: all-gather; 2: all-to-all.
 // Every party of the communicator must make the same call.
 extern "C" int zk_comm_set_open_pattern(zk_ctx* ctx, int pattern) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || pattern < 0 || pattern > 2) return ZK_ERR_ARG;
     if (!ctx->comm) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_comm_set_open_pattern: no communicator (zk_comm_init)");
     ((Comm*)ctx->comm)->pattern = pattern;
     return ZK_OK;
+    ZK_API_END
 }
 
 // out[i] = sum over parties of v[i] mod r, on every party (v, out: n field elements on the device; out may alias v)
 extern "C" int zk_open_sum_fr_dev(zk_ctx* ctx, const void* v_dev, size_t n, void* out_dev) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (n && (!v_dev || !out_dev))) return ZK_ERR_ARG;
     if (!ctx->comm) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_open_sum_fr_dev: no communicator (zk_comm_init)");
     if (n == 0) return ZK_OK;
     Comm* c = (Comm*)ctx->comm;
-    Rccl* R = rccl(&ctx->last_error);
+    const Rccl* R = rccl(&ctx->last_error);
     if (!R) return ZK_ERR_STATE;
     const int P = c->n;
     hipStream_t st = ctx->stream;
@@ -167,4 +178,5 @@ extern "C" int zk_open_sum_fr_dev(zk_ctx* ctx, const void* v_dev, size_t n, void
     ZK_NCCL(ctx, R, R->AllGather(part, full, chunk * 4, ncclUint64, c->comm, st));
     ZK_HIP(ctx, hipMemcpyAsync(out_dev, full, n * 32, hipMemcpyDeviceToDevice, st));
     return ZK_OK;
+    ZK_API_END
 }

@@ -2,9 +2,21 @@
 #include "../../include/zkmpc_hip.h"
 #include "ctx.hpp"
 #include "internal.hpp"
+#include <stdexcept>
 #include <string.h>
 
-extern "C" int zk_version(void) { return 1; }
+extern "C" int zk_version(void) { ZK_API_BEGIN_NOCTX return 1; ZK_API_END }
+
+extern "C" int zk_selftest_exception_barrier(int kind) {
+    ZK_API_BEGIN_NOCTX
+    if (kind == 0) throw std::bad_alloc();
+    if (kind == 1) throw std::runtime_error("selftest");
+    if (kind == 2) throw 42;
+    if (kind == 3) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+    if (kind == 4) return zk_async([] { return 7; }).get() == 7 ? ZK_OK : ZK_ERR_STATE;
+    return ZK_ERR_ARG;
+    ZK_API_END
+}
 
 // Stream priorities (experiment, off unless ZK_STREAM_PRIO=1): accumulate stream lowest, every other stream highest, in
 // the hope that the dispatcher hands freed slots to the short sort / reduce / witness-map kernels instead of to the
@@ -20,6 +32,7 @@ hipError_t zk_stream_create(hipStream_t* st, bool high) {
 }
 
 extern "C" int zk_ctx_create(int device, int party_id, int n_parties, zk_ctx** out) {
+    ZK_API_BEGIN_NOCTX
     if (!out || n_parties < 1 || party_id < 0 || party_id >= n_parties) return ZK_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ZK_ERR_HIP;  // no CPU fallback
@@ -36,9 +49,11 @@ extern "C" int zk_ctx_create(int device, int party_id, int n_parties, zk_ctx** o
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
     *out = c;
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_ctx_destroy(zk_ctx* ctx) {
+    ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -56,70 +71,89 @@ extern "C" int zk_ctx_destroy(zk_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" const char* zk_last_error(zk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
 extern "C" int zk_ctx_sync(zk_ctx* ctx) {
+    ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" void* zk_ctx_stream(zk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 extern "C" int zk_dev_alloc(zk_ctx* ctx, size_t bytes, void** dev_out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !dev_out) return ZK_ERR_ARG;
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     ZK_HIP(ctx, hipMalloc(dev_out, bytes ? bytes : 16));
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_dev_free(zk_ctx* ctx, void* dev) {
+    ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZK_HIP(ctx, hipFree(dev));
     return ZK_OK;
+    ZK_API_END
 }
 
 // Page-locked host memory for buffers that cross the boundary often (an assignment vector handed to zk_groth16_prove:
 // 32 MiB at 2^20 variables copies in ~0.6 ms from pinned memory, several ms from pageable memory).
 extern "C" int zk_host_alloc(zk_ctx* ctx, size_t bytes, void** host_out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !host_out) return ZK_ERR_ARG;
     ZK_HIP(ctx, hipSetDevice(ctx->device));
     ZK_HIP(ctx, hipHostMalloc(host_out, bytes ? bytes : 16, hipHostMallocDefault));
     return ZK_OK;
+    ZK_API_END
 }
 extern "C" int zk_host_free(zk_ctx* ctx, void* host) {
+    ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     if (host) ZK_HIP(ctx, hipHostFree(host));
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_memcpy_h2d(zk_ctx* ctx, void* dev, const void* host, size_t bytes) {
+    ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_memcpy_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes) {
+    ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     ZK_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_memcpy_d2d(zk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (bytes && (!dst || !src))) return ZK_ERR_ARG;
     if (bytes) ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_dev_zero(zk_ctx* ctx, void* dev, size_t bytes) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (bytes && !dev)) return ZK_ERR_ARG;
     if (bytes) ZK_HIP(ctx, hipMemsetAsync(dev, 0, bytes, ctx->stream));
     return ZK_OK;
+    ZK_API_END
 }
 
 int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out) {
@@ -140,13 +174,16 @@ int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out) {
 }
 
 extern "C" int zk_set_profiling(zk_ctx* ctx, int on) {
+    ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     ctx->profiling = on != 0;
     ctx->timers.clear();
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_last_timers(zk_ctx* ctx, char* names, size_t name_stride, float* ms, int* counts, int max_entries) {
+    ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     int k = 0;
     for (auto& kv : ctx->timers) {
@@ -159,4 +196,5 @@ extern "C" int zk_last_timers(zk_ctx* ctx, char* names, size_t name_stride, floa
     }
     ctx->timers.clear();
     return k;
+    ZK_API_END
 }

@@ -6,9 +6,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <exception>
+#include <future>
 #include <map>
 #include <mutex>
+#include <new>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #define ZK_OK 0
@@ -42,6 +46,9 @@ struct zk_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t next_z_ready = nullptr;
     const void* next_z_host = nullptr;        // the host buffer that was announced (matched by address by zk_groth16_prove)
+    const void* next_z_pk = nullptr;          // ... together with the key, the constraint system and the length it was announced for
+    const void* next_z_r = nullptr;
+    size_t next_z_m = 0;
     void* next_z_dev = nullptr;               // where its copy lives
     int z_slot = 0;                           // which of the two "prove_z" slots the CURRENT proof reads
     std::mutex mu;
@@ -75,6 +82,57 @@ struct zk_ctx {
     } while (0)
 
 hipError_t zk_stream_create(hipStream_t* st, bool high_priority);   // core.hip
+
+// ---- the C-ABI boundary --------------------------------------------------------------------------------------------------
+// Every `extern "C" int` entry point runs its body inside zk_api_guarded:
+//   * the calling thread's current HIP device becomes ctx->device for the duration of the call and is restored afterwards --
+//     a context owns its device, whatever the thread had selected (several parties on several GPUs inside one process, the
+//     reference's LocalTestNet shape: mpc-net/src/multi.rs:419-443; SURVEY 8b "no process-global device state");
+//   * no C++ exception crosses the boundary (the bodies use std::vector / std::map / std::string / std::async): bad_alloc
+//     becomes ZK_ERR_NOMEM, anything else ZK_ERR_STATE, with the text in zk_last_error -- the header's "never abort" contract.
+struct ZkDeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit ZkDeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev && hipSetDevice(dev) == hipSuccess) switched = true;
+    }
+    ~ZkDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    ZkDeviceGuard(const ZkDeviceGuard&) = delete;
+    ZkDeviceGuard& operator=(const ZkDeviceGuard&) = delete;
+};
+
+template <class Fn>
+static inline int zk_api_guarded(zk_ctx* ctx, Fn&& body) noexcept {
+    // (ctx may be destroyed by the body -- zk_ctx_destroy -- so nothing below touches it after a normal return)
+    try {
+        if (!ctx) return body();
+        ZkDeviceGuard guard(ctx->device);
+        return body();
+    } catch (const std::bad_alloc&) {
+        try { if (ctx) ctx->last_error = "out of host memory (std::bad_alloc)"; } catch (...) {}
+        return ZK_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        try { if (ctx) ctx->last_error = std::string("C++ exception at the C ABI: ") + e.what(); } catch (...) {}
+        return ZK_ERR_STATE;
+    } catch (...) {
+        try { if (ctx) ctx->last_error = "unknown C++ exception at the C ABI"; } catch (...) {}
+        return ZK_ERR_STATE;
+    }
+}
+// A host-side helper task (window Horner chains, the O(1) scalar multiplications of a proof, Marlin's blinding terms): on its
+// own thread when one can be had, otherwise run by whoever waits for it -- thread exhaustion must not fail a proof.
+template <class Fn>
+static inline auto zk_async(Fn&& fn) -> std::future<decltype(fn())> {
+    try {
+        return std::async(std::launch::async, fn);
+    } catch (const std::system_error&) {
+        return std::async(std::launch::deferred, fn);
+    }
+}
+
+#define ZK_API_BEGIN(ctx) return zk_api_guarded((zk_ctx*)(ctx), [&]() -> int {
+#define ZK_API_BEGIN_NOCTX return zk_api_guarded((zk_ctx*)nullptr, [&]() -> int {
+#define ZK_API_END });
 
 // Returns a device buffer of at least `bytes` bound to `name`; contents are unspecified.
 int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out);

@@ -162,10 +162,14 @@ int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W) {
 }  // namespace
 
 extern "C" int zk_fixed_base_g1_dev(zk_ctx* ctx, const zk_fr* gen_k, const void* scalars, size_t n, zk_bases** out) {
+    ZK_API_BEGIN(ctx)
     return fixed_base_run<G1Field>(ctx, g1_generator(), gen_k, scalars, n, 1, out);
+    ZK_API_END
 }
 extern "C" int zk_fixed_base_g2_dev(zk_ctx* ctx, const zk_fr* gen_k, const void* scalars, size_t n, zk_bases** out) {
+    ZK_API_BEGIN(ctx)
     return fixed_base_run<G2Field>(ctx, g2_generator(), gen_k, scalars, n, 2, out);
+    ZK_API_END
 }
 
 // Window multiples 2^(c w) * base_i, w < W = ceil(255 / c), for tables that stay resident (proving-key queries, an SRS).
@@ -206,6 +210,7 @@ int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b) {
 extern "C" uint32_t zk_bases_window_bits(const zk_bases* b) { return b ? b->c_pre : 0; }
 
 extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b) {
+    ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     if (!b || b->pre || b->n < 4096) return ZK_OK;
     uint32_t c = precompute_window_bits(b->n);
@@ -214,4 +219,5 @@ extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b) {
     const uint32_t W = (255 + c - 1) / c;
     if (b->group == 1) return precompute_t<G1Field>(ctx, b, c, W);
     return precompute_t<G2Field>(ctx, b, c, W);
+    ZK_API_END
 }

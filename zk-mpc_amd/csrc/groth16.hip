@@ -118,6 +118,7 @@ int spmv(zk_ctx* ctx, const zk_r1cs* r, int which, const void* z, size_t n_copy,
 // out[r] = <row r of matrix `which`, z> for r < num_constraints, zero up to out_len (inner_prod_fn of the Marlin prover,
 // marlin/src/ahp/prover.rs:258-278; the same product as evaluate_constraint, src/groth16.rs:205-234).
 extern "C" int zk_r1cs_matvec_dev(zk_ctx* ctx, const zk_r1cs* r, int which, const void* z_dev, void* out_dev, size_t out_len) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !r || !z_dev || !out_dev || which < 0 || which > 2) return ZK_ERR_ARG;
     if (out_len < r->nc) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_r1cs_matvec_dev: out_len is smaller than the number of constraints");
     const auto& m = r->m[which];
@@ -125,6 +126,7 @@ extern "C" int zk_r1cs_matvec_dev(zk_ctx* ctx, const zk_r1cs* r, int which, cons
                        (size_t)0, out_len, out_dev);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 namespace {
@@ -200,6 +202,7 @@ int first_point(zk_ctx* ctx, const zk_bases* b, Affine<F>* out) {
 extern "C" uint32_t zk_r1cs_domain_log(const zk_r1cs* r) { return r ? r->log_d : 0; }
 
 extern "C" int zk_r1cs_upload(zk_ctx* ctx, const zk_r1cs_host* h, zk_r1cs** out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !h || !out || h->num_instance == 0) return ZK_ERR_ARG;
     zk_r1cs* r = new zk_r1cs();
     r->nc = h->num_constraints; r->ni = h->num_instance; r->nw = h->num_witness;
@@ -210,9 +213,11 @@ extern "C" int zk_r1cs_upload(zk_ctx* ctx, const zk_r1cs_host* h, zk_r1cs** out)
     if (rc != ZK_OK) { zk_r1cs_free(ctx, r); return rc; }
     *out = r;
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_r1cs_free(zk_ctx* ctx, zk_r1cs* r) {
+    ZK_API_BEGIN(ctx)
     if (!r) return ZK_OK;
     zk_presort_free(ctx);          // see zk_pk_free
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
@@ -223,9 +228,11 @@ extern "C" int zk_r1cs_free(zk_ctx* ctx, zk_r1cs* r) {
     }
     delete r;
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_r1cs_mul_chain(zk_ctx* ctx, size_t n, zk_r1cs** out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !out || n == 0 || n > ((size_t)1 << 27)) return ZK_ERR_ARG;
     // variables: [1, pub] ++ witness[w_0..w_n]; w_{n+1} is the public input (index 1)
     auto idx = [n](size_t j) -> uint32_t { return j <= n ? (uint32_t)(2 + j) : 1u; };
@@ -241,9 +248,11 @@ extern "C" int zk_r1cs_mul_chain(zk_ctx* ctx, size_t n, zk_r1cs** out) {
     h.a_col = ca.data(); h.b_col = cb.data(); h.c_col = cc.data();
     h.a_coeff = h.b_coeff = h.c_coeff = ones.data();
     return zk_r1cs_upload(ctx, &h, out);
+    ZK_API_END
 }
 
 extern "C" int zk_mul_chain_assignment_dev(zk_ctx* ctx, size_t n, const zk_fr* w0, const zk_fr* w1, void* z_dev) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !w0 || !w1 || !z_dev || n == 0) return ZK_ERR_ARG;
     // the chain is inherently sequential: computed on the host (input generation, not on the proving path)
     std::vector<Fr> w(n + 2);
@@ -257,12 +266,14 @@ extern "C" int zk_mul_chain_assignment_dev(zk_ctx* ctx, size_t n, const zk_fr* w
     ZK_HIP(ctx, hipMemcpyAsync(z_dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZK_OK;
+    ZK_API_END
 }
 
 // ---- witness map -----------------------------------------------------------------------------
 
 extern "C" int zk_groth16_witness_map_pre_dev(zk_ctx* ctx, const zk_r1cs* r, const void* z, int include_instance, void* a,
                                               void* b, void* c) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !r || !z || !a || !b || !c) return ZK_ERR_ARG;
     // a[nc..nc+ni] = instance assignment (src/groth16.rs:272-276).  For shares, z already holds each
     // party's share of the instance (the leader holds the public value, the others zero), so the
@@ -276,17 +287,21 @@ extern "C" int zk_groth16_witness_map_pre_dev(zk_ctx* ctx, const zk_r1cs* r, con
         ZK_TRY(zk_ntt_launch(ctx, v[k], r->log_d, 0, 1));  // coset_fft     (:281-282,296)
     }
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_groth16_witness_map_post_dev(zk_ctx* ctx, const zk_r1cs* r, void* ab, const void* c) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !r || !ab || !c) return ZK_ERR_ARG;
     uint32_t zinv[9];
     ZK_TRY(zk_ntt_vanishing_inv(ctx, r->log_d, zinv));
     ZK_TRY(zk_vec_sub_scale_launch(ctx, ab, c, zinv, ab, (size_t)1 << r->log_d));  // (ab - c) / Z(g)   (:298-302)
     return zk_ntt_launch(ctx, ab, r->log_d, 1, 1);                                   // coset_ifft        (:303)
+    ZK_API_END
 }
 
 extern "C" int zk_groth16_witness_map_dev(zk_ctx* ctx, const zk_r1cs* r, const void* z, void* h) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !r || !z || !h) return ZK_ERR_ARG;
     size_t D = (size_t)1 << r->log_d;
     void *b, *c;
@@ -295,6 +310,7 @@ extern "C" int zk_groth16_witness_map_dev(zk_ctx* ctx, const zk_r1cs* r, const v
     ZK_TRY(zk_groth16_witness_map_pre_dev(ctx, r, z, 1, h, b, c));
     ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_MUL, h, b, h, D));  // batch_product_in_place (:285)
     return zk_groth16_witness_map_post_dev(ctx, r, h, c);
+    ZK_API_END
 }
 
 // ---- proving key -----------------------------------------------------------------------------
@@ -316,6 +332,7 @@ static int pk_make_l_pad(zk_ctx* ctx, zk_pk* pk) {
 }
 
 extern "C" int zk_pk_free(zk_ctx* ctx, zk_pk* pk) {
+    ZK_API_BEGIN(ctx)
     if (!pk) return ZK_OK;
     // a pending presort / front (ZkPresort) is matched by address: it must not outlive the objects it points to, or a new
     // key allocated at the same address would adopt a sort of the old key's tables
@@ -324,9 +341,11 @@ extern "C" int zk_pk_free(zk_ctx* ctx, zk_pk* pk) {
     for (auto* b : all) zk_bases_free(ctx, b);
     delete pk;
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_pk_upload(zk_ctx* ctx, const zk_pk_host* h, zk_pk** out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !h || !out) return ZK_ERR_ARG;
     zk_pk* pk = new zk_pk();
     int rc = zk_bases_upload_g1(ctx, h->a_query, h->a_len, &pk->a);
@@ -349,6 +368,7 @@ extern "C" int zk_pk_upload(zk_ctx* ctx, const zk_pk_host* h, zk_pk** out) {
     pk->b0_g2 = h->b_g2_len ? host_aff_from_abi<G2Field>((const uint64_t*)&h->b_g2_query[0]) : aff_inf<G2Field>();
     *out = pk;
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" size_t zk_pk_query_len(const zk_pk* pk, int which) {
@@ -363,30 +383,39 @@ extern "C" const zk_bases* zk_pk_query_bases(const zk_pk* pk, int which) {
     return all[which];
 }
 extern "C" int zk_pk_download_g1(zk_ctx* ctx, const zk_pk* pk, int which, size_t off, size_t n, zk_g1_affine* out) {
+    ZK_API_BEGIN(ctx)
     if (!pk || which == 2 || which < 0 || which > 5) return ZK_ERR_ARG;
     const zk_bases* all[6] = {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l, pk->gamma_abc};
     return zk_bases_download_g1(ctx, all[which], off, n, out);
+    ZK_API_END
 }
 extern "C" int zk_pk_download_g2(zk_ctx* ctx, const zk_pk* pk, int which, size_t off, size_t n, zk_g2_affine* out) {
+    ZK_API_BEGIN(ctx)
     if (!pk || which != 2) return ZK_ERR_ARG;
     return zk_bases_download_g2(ctx, pk->b_g2, off, n, out);
+    ZK_API_END
 }
 extern "C" int zk_pk_vk_g1(const zk_pk* pk, int which, zk_g1_affine* out) {
+    ZK_API_BEGIN_NOCTX
     if (!pk || !out || which < 0 || which > 2) return ZK_ERR_ARG;
     const Affine<G1Field>* v[3] = {&pk->alpha_g1, &pk->beta_g1, &pk->delta_g1};
     host_aff_to_abi<G1Field>((uint64_t*)out, *v[which]);
     return ZK_OK;
+    ZK_API_END
 }
 extern "C" int zk_pk_vk_g2(const zk_pk* pk, int which, zk_g2_affine* out) {
+    ZK_API_BEGIN_NOCTX
     if (!pk || !out || which < 0 || which > 2) return ZK_ERR_ARG;
     const Affine<G2Field>* v[3] = {&pk->beta_g2, &pk->delta_g2, &pk->gamma_g2};
     host_aff_to_abi<G2Field>((uint64_t*)out, *v[which]);
     return ZK_OK;
+    ZK_API_END
 }
 
 // generate_parameters with explicit toxic waste (generator.rs:44-231)
 extern "C" int zk_groth16_setup(zk_ctx* ctx, const zk_r1cs* r, const zk_fr* alpha_, const zk_fr* beta_, const zk_fr* gamma_,
                                 const zk_fr* delta_, const zk_fr* tau_, const zk_fr* g1_k, const zk_fr* g2_k, zk_pk** out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !r || !alpha_ || !beta_ || !gamma_ || !delta_ || !tau_ || !g1_k || !g2_k || !out) return ZK_ERR_ARG;
     auto ld = [](const zk_fr* x) { return fp_ext_to_int<FrParams>(host_load_ext<FrParams>(x->l)); };
     const Fr alpha = ld(alpha_), beta = ld(beta_), gamma = ld(gamma_), delta = ld(delta_), t = ld(tau_);
@@ -477,6 +506,7 @@ extern "C" int zk_groth16_setup(zk_ctx* ctx, const zk_r1cs* r, const zk_fr* alph
     if (rc != ZK_OK) { zk_pk_free(ctx, pk); return rc; }
     *out = pk;
     return ZK_OK;
+    ZK_API_END
 }
 
 // ---- prover ----------------------------------------------------------------------------------
@@ -730,6 +760,7 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
 // SpdzGroupShare::multi_scale_pub_group (share/spdz.rs:482-488).  Outputs are Jacobian points (G1 or G2 according to each job's table).
 extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* const* bases, const size_t* base_offsets,
                                 const void* const* scalars_dev, const size_t* lens, void* const* outs) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (n_jobs && (!bases || !scalars_dev || !lens || !outs))) return ZK_ERR_ARG;
     for (size_t k = 0; k < n_jobs; k++) {
         if (!bases[k] || !outs[k] || (lens[k] && !scalars_dev[k])) return ZK_ERR_ARG;
@@ -775,17 +806,21 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipEventDestroy(e0);
     return rc;
+    ZK_API_END
 }
 
 // The next zk_groth16_prove_dev on this context will be for `z_next_dev` (same key, same constraint system): the proof
 // in between enqueues that proof's front (z-sort, witness map, H-sort) behind its own kernels.  Pass NULL to withdraw.
 extern "C" int zk_groth16_hint_next_dev(zk_ctx* ctx, const void* z_next_dev) {
+    ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     ctx->next_z = z_next_dev;
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_groth16_msms_presort_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !pk || !r || !z) return ZK_ERR_ARG;
     zk_presort_free(ctx);
     const size_t nvars = (r->ni - 1) + r->nw;
@@ -803,6 +838,7 @@ extern "C" int zk_groth16_msms_presort_dev(zk_ctx* ctx, const zk_pk* pk, const z
     ZK_TRY(zk_msm_enqueue_sort(ctx, &p->job, ctx->aux[0], nullptr));
     ctx->presort = p.release();
     return ZK_OK;
+    ZK_API_END
 }
 
 // The four MSMs over z -- B in G2, A, B in G1, L -- enqueued to the end (sort, accumulate, reduce); returns at once.
@@ -811,6 +847,7 @@ extern "C" int zk_groth16_msms_presort_dev(zk_ctx* ctx, const zk_pk* pk, const z
 // half of the witness map run under accumulate kernels that do not need h.  The context stream stays free for the caller's
 // own kernels.
 extern "C" int zk_groth16_msms_begin_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !pk || !r || !z) return ZK_ERR_ARG;
     zk_presort_free(ctx);
     const size_t nvars = (r->ni - 1) + r->nw;
@@ -850,16 +887,20 @@ extern "C" int zk_groth16_msms_begin_dev(zk_ctx* ctx, const zk_pk* pk, const zk_
     }
     ctx->presort = p.release();
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_groth16_msms_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const void* h,
                                    zk_g1_projective out_g1[4], zk_g2_projective* out_g2) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !pk || !r || !z || !h || !out_g1 || !out_g2) return ZK_ERR_ARG;
     return run_msms(ctx, pk, r, z, h, nullptr, out_g1, out_g2);
+    ZK_API_END
 }
 
 extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const zk_fr* r_, const zk_fr* s_,
                                     uint8_t proof[192]) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !pk || !r || !z || !r_ || !s_ || !proof) return ZK_ERR_ARG;
     const size_t D = (size_t)1 << r->log_d;
     void* h;
@@ -890,18 +931,18 @@ extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs*
         const X1 b1_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[3]);
         const X2 b2_acc = host64_proj_from_abi<H2>((const uint64_t*)&m2);
         // calculate_coeff (src/groth16.rs:185-201): initial + query[0] + acc + vk_param
-        chain_a = std::async(std::launch::async, [&, a_acc] {
+        chain_a = zk_async([&, a_acc] {
             const X1 r_g1 = host64_scalar_mul<H1>(delta1, rw);
             r_s_delta = host64_scalar_mul<H1>(r_g1, sw);                                                     // :115
             g_a = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(r_g1, a0), a_acc), alpha);
             s_g_a = host64_scalar_mul<H1>(g_a, sw);                                                           // :140
         });
-        chain_b = std::async(std::launch::async, [&, b1_acc] {
+        chain_b = zk_async([&, b1_acc] {
             const X1 s_g1 = host64_scalar_mul<H1>(delta1, sw);
             const X1 g1_b = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(s_g1, b0), b1_acc), beta1);
             r_g1_b = host64_scalar_mul<H1>(g1_b, rw);                                                         // :161
         });
-        chain_g2 = std::async(std::launch::async, [&, b2_acc] {
+        chain_g2 = zk_async([&, b2_acc] {
             const X2 s_g2 = host64_scalar_mul<H2>(delta2, sw);
             const X2 g2_b = xyzz_madd<H2>(xyzz_add<H2>(xyzz_madd<H2>(s_g2, b02), b2_acc), beta2);
             b_aff = xyzz_to_affine<H2>(g2_b);
@@ -929,6 +970,7 @@ extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs*
         t.count += 1;
     }
     return ZK_OK;
+    ZK_API_END
 }
 
 // Host-slice prover for a queue: `z_host` is proved now, `z_next_host` (or NULL) is the assignment of the next call.  The
@@ -938,21 +980,30 @@ extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs*
 // upload asynchronous.
 extern "C" int zk_groth16_prove_queued(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const zk_fr* z_host, const zk_fr* r_,
                                        const zk_fr* s_, const zk_fr* z_next_host, uint8_t proof[192]) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !pk || !r || !z_host) return ZK_ERR_ARG;
     const size_t m = r->ni + r->nw;
     void* z;
-    if (ctx->next_z_host == z_host && ctx->next_z_dev) {
-        // announced by the previous call: already uploaded (the front that reads it waited for the copy)
+    if (ctx->next_z_host == z_host && ctx->next_z_dev && ctx->next_z_pk == pk && ctx->next_z_r == r && ctx->next_z_m == m) {
+        // announced by the previous call for this key, this system and this length: already uploaded (the front that reads it
+        // waited for the copy)
         z = ctx->next_z_dev;
         ctx->z_slot ^= 1;
         ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->next_z_ready, 0));
     } else {
+        // Not the announced assignment (or announced for another key / system / length: the upload may be shorter than m).  A
+        // front enqueued for the announced one still reads the other slot, and its z-sort / witness map may run for as long as
+        // this proof takes: let it drain before either slot is written (run_msms would only drop it later).
+        zk_presort_free(ctx);
+        if (ctx->copy_stream) ZK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
         ZK_TRY(zk_scratch(ctx, ctx->z_slot ? "prove_z1" : "prove_z0", m * 32, &z));
         ZK_HIP(ctx, hipMemcpyAsync(z, z_host, m * 32, hipMemcpyHostToDevice, ctx->stream));
     }
     ctx->next_z_host = nullptr;
     ctx->next_z_dev = nullptr;
     ctx->next_z = nullptr;
+    ctx->next_z_pk = ctx->next_z_r = nullptr;
+    ctx->next_z_m = 0;
     if (z_next_host) {
         if (!ctx->copy_stream) ZK_HIP(ctx, zk_stream_create(&ctx->copy_stream, false));
         if (!ctx->next_z_ready) ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->next_z_ready, hipEventDisableTiming));
@@ -964,13 +1015,17 @@ extern "C" int zk_groth16_prove_queued(zk_ctx* ctx, const zk_pk* pk, const zk_r1
         ctx->next_z_host = z_next_host;
         ctx->next_z_dev = zn;
         ctx->next_z = zn;
+        ctx->next_z_pk = pk; ctx->next_z_r = r; ctx->next_z_m = m;
     }
     return zk_groth16_prove_dev(ctx, pk, r, z, r_, s_, proof);
+    ZK_API_END
 }
 
 extern "C" int zk_groth16_prove(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const zk_fr* z_host, const zk_fr* r_, const zk_fr* s_,
                                 uint8_t proof[192]) {
+    ZK_API_BEGIN(ctx)
     return zk_groth16_prove_queued(ctx, pk, r, z_host, r_, s_, nullptr, proof);
+    ZK_API_END
 }
 
 // ---- arkworks CanonicalSerialize framing of the Groth16 keys and of a KZG10 SRS --------------------------------------
@@ -1041,6 +1096,7 @@ extern "C" size_t zk_pk_serialized_size(const zk_pk* pk, int compressed) {
     return zk_vk_serialized_size(pk, compressed) + 2 * g1 + 5 * 8 + g1 * (pk->a->n + pk->b_g1->n + pk->h->n + pk->l->n) + g2 * pk->b_g2->n;
 }
 extern "C" int zk_vk_serialize(zk_ctx* ctx, const zk_pk* pk, int compressed, uint8_t* out, size_t cap) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !pk || !out) return ZK_ERR_ARG;
     if (cap < zk_vk_serialized_size(pk, compressed)) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_vk_serialize: buffer too small");
     uint8_t* p = out;
@@ -1050,8 +1106,10 @@ extern "C" int zk_vk_serialize(zk_ctx* ctx, const zk_pk* pk, int compressed, uin
     ZK_TRY((ser_small<G2Field, zk_g2_affine>(ctx, g2s, 3, 2, compressed, p)));
     p += 3 * zk_point_serialized_size(2, compressed);
     return put_vec(ctx, p, pk->gamma_abc, compressed);
+    ZK_API_END
 }
 extern "C" int zk_pk_serialize(zk_ctx* ctx, const zk_pk* pk, int compressed, uint8_t* out, size_t cap) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !pk || !out) return ZK_ERR_ARG;
     if (cap < zk_pk_serialized_size(pk, compressed)) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_pk_serialize: buffer too small");
     ZK_TRY(zk_vk_serialize(ctx, pk, compressed, out, cap));
@@ -1061,10 +1119,12 @@ extern "C" int zk_pk_serialize(zk_ctx* ctx, const zk_pk* pk, int compressed, uin
     p += 2 * zk_point_serialized_size(1, compressed);
     for (const zk_bases* q : {pk->a, pk->b_g1, pk->b_g2, pk->h, pk->l}) ZK_TRY(put_vec(ctx, p, q, compressed));
     return ZK_OK;
+    ZK_API_END
 }
 // ProvingKey::deserialize / deserialize_uncompressed: the key becomes resident (window multiples, padded l_query) like one
 // from zk_pk_upload; gamma_g2 and gamma_abc_g1 are kept for zk_vk_serialize / zk_pk_vk_g2 / zk_pk_download_g1(which = 5).
 extern "C" int zk_pk_deserialize(zk_ctx* ctx, const uint8_t* bytes, size_t len, int compressed, zk_pk** out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !bytes || !out) return ZK_ERR_ARG;
     const uint8_t *p = bytes, *end = bytes + len;
     zk_pk* pk = new zk_pk();
@@ -1098,6 +1158,7 @@ extern "C" int zk_pk_deserialize(zk_ctx* ctx, const uint8_t* bytes, size_t len, 
     if (rc != ZK_OK) { zk_pk_free(ctx, pk); return rc; }
     *out = pk;
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" size_t zk_kzg_srs_serialized_size(size_t n_powers_g, size_t n_powers_gamma_g, int compressed) {
@@ -1108,6 +1169,7 @@ extern "C" size_t zk_kzg_srs_serialized_size(size_t n_powers_g, size_t n_powers_
 // (setup(.., produce_g2_powers = false), which is what MarlinKZG10::setup asks for: marlin_pc/mod.rs:77).
 extern "C" int zk_kzg_srs_serialize(zk_ctx* ctx, const zk_bases* powers_g, const zk_bases* powers_gamma_g, const zk_g2_affine* h,
                                     const zk_g2_affine* beta_h, int compressed, uint8_t* out, size_t cap) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !powers_g || !powers_gamma_g || !h || !beta_h || !out || powers_g->group != 1 || powers_gamma_g->group != 1) return ZK_ERR_ARG;
     if (cap < zk_kzg_srs_serialized_size(powers_g->n, powers_gamma_g->n, compressed)) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_kzg_srs_serialize: buffer too small");
     uint8_t* p = out;
@@ -1122,9 +1184,11 @@ extern "C" int zk_kzg_srs_serialize(zk_ctx* ctx, const zk_bases* powers_g, const
     p += 2 * zk_point_serialized_size(2, compressed);
     put_u64(p, 0);
     return ZK_OK;
+    ZK_API_END
 }
 extern "C" int zk_kzg_srs_deserialize(zk_ctx* ctx, const uint8_t* bytes, size_t len, int compressed, zk_bases** powers_g,
                                       zk_bases** powers_gamma_g, zk_g2_affine* h, zk_g2_affine* beta_h) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !bytes || !powers_g || !powers_gamma_g || !h || !beta_h) return ZK_ERR_ARG;
     const uint8_t *p = bytes, *end = bytes + len;
     zk_bases *pg = nullptr, *pgg = nullptr, *hh = nullptr;
@@ -1162,4 +1226,5 @@ extern "C" int zk_kzg_srs_deserialize(zk_ctx* ctx, const uint8_t* bytes, size_t 
     *powers_g = pg;
     *powers_gamma_g = pgg;
     return ZK_OK;
+    ZK_API_END
 }

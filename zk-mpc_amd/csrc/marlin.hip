@@ -98,15 +98,18 @@ int load_mats(zk_ctx* ctx, const zk_marlin_matrix_evals* e, bool need_row_col, M
 }  // namespace
 
 extern "C" int zk_fr_gather_dev(zk_ctx* ctx, const void* src, const uint32_t* idx_dev, size_t n, void* out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (n && (!src || !idx_dev || !out))) return ZK_ERR_ARG;
     if (n == 0) return ZK_OK;
     hipLaunchKernelGGL(k_gather, zk_grid(n, 256), 256, 0, ctx->stream, src, idx_dev, n, out);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_marlin_round3_f_evals_dev(zk_ctx* ctx, const zk_marlin_matrix_evals on_k[3], size_t k_size, const zk_fr* alpha,
                                             const zk_fr* beta, const zk_fr eta[3], const zk_fr* vh_alpha_vh_beta, void* f_out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !on_k || !alpha || !beta || !eta || !vh_alpha_vh_beta || !f_out || k_size == 0) return ZK_ERR_ARG;
     Mats M;
     ZK_TRY(load_mats(ctx, on_k, false, &M));
@@ -122,11 +125,13 @@ extern "C" int zk_marlin_round3_f_evals_dev(zk_ctx* ctx, const zk_marlin_matrix_
     hipLaunchKernelGGL(k_f_vals, zk_grid(k_size, 256), 256, 0, ctx->stream, M, (const void*)den, k[0], k[1], k[2], k_size, f_out);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_marlin_round3_ab_evals_dev(zk_ctx* ctx, const zk_marlin_matrix_evals on_b[3], size_t b_size, const zk_fr* alpha,
                                              const zk_fr* beta, const zk_fr eta[3], const zk_fr* vh_alpha_vh_beta, void* a_out,
                                              void* b_out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !on_b || !alpha || !beta || !eta || !vh_alpha_vh_beta || !a_out || !b_out || b_size == 0) return ZK_ERR_ARG;
     Mats M;
     ZK_TRY(load_mats(ctx, on_b, true, &M));
@@ -140,4 +145,5 @@ extern "C" int zk_marlin_round3_ab_evals_dev(zk_ctx* ctx, const zk_marlin_matrix
                        to_frk(fix2), b_size, a_out, b_out);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }

@@ -179,6 +179,7 @@ extern "C" size_t zk_marlin_proof_max_size(void) { return 8 + 3 * 8 + 9 * 49 + 2
 
 extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
                                const void* z_dev, zk_rng* zk_rng_, int mask_on_device, uint8_t* proof_out, size_t cap, size_t* proof_len) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !ix || !powers_g || !powers_gamma_g || !z_dev || !zk_rng_ || !proof_out || !proof_len) return ZK_ERR_ARG;
     if (powers_g->group != 1 || powers_gamma_g->group != 1 || powers_gamma_g->n < 3) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: SRS tables");
     if (cap < zk_marlin_proof_max_size()) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: output buffer smaller than zk_marlin_proof_max_size()");
@@ -216,7 +217,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     }
 
     // ZK_MARLIN_SYNC_BLINDS=1 (experiment): the host-side blinding terms inline instead of on host threads
-    const std::launch blind_policy = getenv("ZK_MARLIN_SYNC_BLINDS") ? std::launch::deferred : std::launch::async;
+    const bool blind_deferred = getenv("ZK_MARLIN_SYNC_BLINDS") != nullptr;     // experiment: the blinding terms in line
     zk_g1_projective gamma_pts[3];
     {
         zk_g1_affine a[3];
@@ -250,7 +251,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         // the blinding terms (three host scalar multiplications each, ~1.2 ms) run on host threads under the device batch
         std::vector<std::pair<std::pair<int, std::string>, std::future<zk_g1_projective>>> blinds;
         auto blind_async = [&](int which, const char* l, const std::vector<HF>& c) {
-            blinds.push_back({{which, l}, std::async(blind_policy, [&gamma_pts, c] { return small_msm(gamma_pts, c); })});
+            blinds.push_back({{which, l}, (blind_deferred ? std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); }) : zk_async([&gamma_pts, c] { return small_msm(gamma_pts, c); }))});
         };
         for (const char* l : labels) {
             const bool hiding = !strcmp(l, "w") || !strcmp(l, "z_a") || !strcmp(l, "z_b") || !strcmp(l, "g_1");
@@ -505,7 +506,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
     size_t counts[2] = {0, 0};
     std::vector<std::future<zk_g1_projective>> extra[2];                         // the blinding witnesses: host threads, joined after the batch
-    auto small_async = [&](const std::vector<HF>& c) { return std::async(blind_policy, [&gamma_pts, c] { return small_msm(gamma_pts, c); }); };
+    auto small_async = [&](const std::vector<HF>& c) { return (blind_deferred ? std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); }) : zk_async([&gamma_pts, c] { return small_msm(gamma_pts, c); })); };
     bool has_rv[2] = {false, false};
     HF rvs[2];
     for (int q = 0; q < 2; q++) {
@@ -614,4 +615,5 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     memcpy(proof_out, out.data(), out.size());
     *proof_len = out.size();
     return ZK_OK;
+    ZK_API_END
 }

@@ -1089,7 +1089,7 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
         const uint32_t nthreads = nwin >= 8 ? 4u : 1u;
         std::vector<std::future<void>> tasks;
         for (uint32_t t = 1; t < nthreads; t++)
-            tasks.push_back(std::async(std::launch::async, [&, t] { for (uint32_t w = t; w < nwin; w += nthreads) wsum[w] = window_sum(w); }));
+            tasks.push_back(zk_async([&, t] { for (uint32_t w = t; w < nwin; w += nthreads) wsum[w] = window_sum(w); }));
         for (uint32_t w = 0; w < nwin; w += nthreads) wsum[w] = window_sum(w);
         for (auto& f : tasks) f.get();
     }
@@ -1234,9 +1234,10 @@ int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const voi
     return msm_run_t<G2Field>(ctx, bases, base_offset, scalars_dev, n, out);
 }
 
-extern "C" int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* h, size_t n, zk_bases** out) { return bases_upload_t<G1Field>(ctx, h, n, 1, out); }
-extern "C" int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* h, size_t n, zk_bases** out) { return bases_upload_t<G2Field>(ctx, h, n, 2, out); }
+extern "C" int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* h, size_t n, zk_bases** out) { ZK_API_BEGIN(ctx) return bases_upload_t<G1Field>(ctx, h, n, 1, out); ZK_API_END }
+extern "C" int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* h, size_t n, zk_bases** out) { ZK_API_BEGIN(ctx) return bases_upload_t<G2Field>(ctx, h, n, 2, out); ZK_API_END }
 extern "C" int zk_bases_free(zk_ctx* ctx, zk_bases* b) {
+    ZK_API_BEGIN(ctx)
     if (!b) return ZK_OK;
     zk_presort_free(ctx);          // a pending presort's job points into b->dev / b->pre (groth16.hip: zk_pk_free)
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
@@ -1244,28 +1245,41 @@ extern "C" int zk_bases_free(zk_ctx* ctx, zk_bases* b) {
     if (b->pre) (void)hipFree(b->pre);
     delete b;
     return ZK_OK;
+    ZK_API_END
 }
 extern "C" size_t zk_bases_len(const zk_bases* b) { return b ? b->n : 0; }
 extern "C" int zk_bases_download_g1(zk_ctx* ctx, const zk_bases* b, size_t off, size_t n, zk_g1_affine* out) {
+    ZK_API_BEGIN(ctx)
     if (b && b->group != 1) return ZK_ERR_ARG;
     return bases_download_t<G1Field>(ctx, b, off, n, out);
+    ZK_API_END
 }
 extern "C" int zk_bases_download_g2(zk_ctx* ctx, const zk_bases* b, size_t off, size_t n, zk_g2_affine* out) {
+    ZK_API_BEGIN(ctx)
     if (b && b->group != 2) return ZK_ERR_ARG;
     return bases_download_t<G2Field>(ctx, b, off, n, out);
+    ZK_API_END
 }
 
 extern "C" int zk_msm_g1(zk_ctx* ctx, const zk_g1_affine* bases, size_t nb, const zk_fr* scalars, size_t ns, zk_g1_projective* out) {
+    ZK_API_BEGIN(ctx)
     return msm_host_t<G1Field>(ctx, bases, nb, scalars, ns, 1, out);
+    ZK_API_END
 }
 extern "C" int zk_msm_g2(zk_ctx* ctx, const zk_g2_affine* bases, size_t nb, const zk_fr* scalars, size_t ns, zk_g2_projective* out) {
+    ZK_API_BEGIN(ctx)
     return msm_host_t<G2Field>(ctx, bases, nb, scalars, ns, 2, out);
+    ZK_API_END
 }
 extern "C" int zk_msm_g1_dev(zk_ctx* ctx, const zk_bases* bases, size_t off, const void* scalars, size_t n, zk_g1_projective* out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !bases || !out || bases->group != 1 || (n && !scalars)) return ZK_ERR_ARG;
     return msm_run_t<G1Field>(ctx, bases, off, scalars, n, out);
+    ZK_API_END
 }
 extern "C" int zk_msm_g2_dev(zk_ctx* ctx, const zk_bases* bases, size_t off, const void* scalars, size_t n, zk_g2_projective* out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !bases || !out || bases->group != 2 || (n && !scalars)) return ZK_ERR_ARG;
     return msm_run_t<G2Field>(ctx, bases, off, scalars, n, out);
+    ZK_API_END
 }

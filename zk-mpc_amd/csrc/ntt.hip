@@ -390,10 +390,9 @@ int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset
             uint32_t logE = log_n < 20 ? (log_n > 8 ? log_n - 8 : 0) : (passes >= 3 ? 10 : 12);
             if (logE < base + (extra ? 1 : 0)) logE = base + (extra ? 1 : 0);
             if (passes == 1) logE = log_n;
-            if (const char* ev = getenv("ZK_NTT_LOGE")) {      // experiment knob
-                const uint32_t v = (uint32_t)atoi(ev);
-                if (passes > 1 && v >= base + (extra ? 1 : 0) && v <= 12 && v <= log_n) logE = v;
-            }
+            static const uint32_t env_loge = getenv("ZK_NTT_LOGE") ? (uint32_t)atoi(getenv("ZK_NTT_LOGE")) : 0u;      // experiment knob, read once
+            if (env_loge && passes > 1 && env_loge >= base + (extra ? 1 : 0) && env_loge <= 12 && env_loge <= log_n) logE = env_loge;
+            if (logE < logM || logE > 12) ZK_FAIL(ctx, ZK_ERR_STATE, "ntt: tile smaller than a pass's transform (logE < logM) or larger than the LDS tile");
             uint32_t logC = logE - logM;
             uint32_t E = 1u << logE;
             uint32_t nt = E / 4 > NTT_THREADS ? NTT_THREADS : (E / 4 < 64 ? 64 : E / 4);
@@ -423,11 +422,14 @@ int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset
 }
 
 extern "C" int zk_fr_ntt_dev(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !buf) return ZK_ERR_ARG;
     return zk_ntt_launch(ctx, buf, log_n, inverse, coset);
+    ZK_API_END
 }
 
 extern "C" int zk_fr_fft_in_place(zk_ctx* ctx, zk_fr* vec, size_t n, uint32_t log_n, int inverse, int coset) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !vec) return ZK_ERR_ARG;
     size_t N = (size_t)1 << log_n;
     if (n > N) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_fr_fft_in_place: n exceeds the domain size");
@@ -439,13 +441,16 @@ extern "C" int zk_fr_fft_in_place(zk_ctx* ctx, zk_fr* vec, size_t n, uint32_t lo
     ZK_HIP(ctx, hipMemcpyAsync(vec, d, N * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_fr_divide_by_vanishing_on_coset_dev(zk_ctx* ctx, void* evals, uint32_t log_n) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !evals) return ZK_ERR_ARG;
     zk_domain* d;
     ZK_TRY(get_domain(ctx, log_n, false, &d));
     return zk_vec_scale_launch(ctx, evals, d->zinv.l, evals, (size_t)1 << log_n);
+    ZK_API_END
 }
 
 // used by groth16.hip: (ab - c) / Z(g) fused

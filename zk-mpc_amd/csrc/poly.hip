@@ -267,6 +267,7 @@ __global__ void __launch_bounds__(256) k_fill_spans(const EvalJob J, const void*
 }  // namespace
 
 extern "C" int zk_fr_powers_dev(zk_ctx* ctx, const zk_fr* base, const zk_fr* start, size_t n, void* out_dev) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !base || !start || (n && !out_dev)) return ZK_ERR_ARG;
     if (!n) return ZK_OK;
     Fr b = host_int(base);
@@ -276,9 +277,11 @@ extern "C" int zk_fr_powers_dev(zk_ctx* ctx, const zk_fr* base, const zk_fr* sta
                        to_frk(fp_ext_to_int<FrParams>(s_ext)), n);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_fr_batch_inverse_dev(zk_ctx* ctx, void* v_dev, size_t n) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (n && !v_dev)) return ZK_ERR_ARG;
     if (!n) return ZK_OK;
     uint32_t* scr;
@@ -287,6 +290,7 @@ extern "C" int zk_fr_batch_inverse_dev(zk_ctx* ctx, void* v_dev, size_t n) {
     hipLaunchKernelGGL(k_batch_inverse, zk_grid(chunks, 64, 8192), 64, 0, ctx->stream, v_dev, n, scr);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 namespace {
@@ -310,6 +314,7 @@ void eval_job_fill(EvalJob& J, const void* c, size_t n, uint32_t first_block, co
 
 // DensePolynomial::evaluate for `count` (polynomial, point) pairs at once: out[i] = polys[i](points[i]).
 extern "C" int zk_poly_evaluate_batch_dev(zk_ctx* ctx, const zk_poly_ref* polys, const zk_fr* points, size_t count, zk_fr* out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (count && (!polys || !points || !out))) return ZK_ERR_ARG;
     if (!count) return ZK_OK;
     std::vector<EvalJob> jobs(count);
@@ -334,15 +339,19 @@ extern "C" int zk_poly_evaluate_batch_dev(zk_ctx* ctx, const zk_poly_ref* polys,
     for (size_t i = 0; i < count; i++)
         for (int k = 0; k < 4; k++) out[i].l[k] = (uint64_t)w[8 * i + 2 * k] | ((uint64_t)w[8 * i + 2 * k + 1] << 32);
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_poly_evaluate_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, const zk_fr* point, zk_fr* out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !point || !out || (n && !coeffs_dev)) return ZK_ERR_ARG;
     const zk_poly_ref p{coeffs_dev, n};
     return zk_poly_evaluate_batch_dev(ctx, &p, point, 1, out);
+    ZK_API_END
 }
 
 extern "C" int zk_poly_divide_by_linear_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, const zk_fr* z, void* q_dev, zk_fr* rem) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !z || (n && !coeffs_dev) || (n > 1 && !q_dev)) return ZK_ERR_ARG;
     EvalJob job;                                    // 680 B: travels as a kernel argument, no copy, nothing to keep alive
     eval_job_fill(job, coeffs_dev, n, 0, host_int(z));
@@ -363,9 +372,11 @@ extern "C" int zk_poly_divide_by_linear_dev(zk_ctx* ctx, const void* coeffs_dev,
         for (int k = 0; k < 4; k++) rem->l[k] = (uint64_t)w[2 * k] | ((uint64_t)w[2 * k + 1] << 32);
     }
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_poly_divide_by_vanishing_dev(zk_ctx* ctx, const void* coeffs_dev, size_t n, uint32_t log_domain, void* q_dev, void* r_dev) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !r_dev || (n && !coeffs_dev) || log_domain > 28) return ZK_ERR_ARG;
     const size_t N = (size_t)1 << log_domain;
     const size_t nq = n > N ? n - N : 0;
@@ -387,9 +398,11 @@ extern "C" int zk_poly_divide_by_vanishing_dev(zk_ctx* ctx, const void* coeffs_d
     hipLaunchKernelGGL(k_divv_fill, zk_grid(G * N, 256), 256, 0, ctx->stream, coeffs_dev, n, N, R, G, (const void*)sums, q_dev, nq, r_dev);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_poly_mul_dev(zk_ctx* ctx, const void* a_dev, size_t na, const void* b_dev, size_t nb, void* out_dev) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !out_dev || !na || !nb || !a_dev || !b_dev) return ZK_ERR_ARG;
     const size_t nout = na + nb - 1;
     uint32_t lg = 0;
@@ -408,11 +421,13 @@ extern "C" int zk_poly_mul_dev(zk_ctx* ctx, const void* a_dev, size_t na, const 
     ZK_TRY(zk_ntt_launch(ctx, ta, lg, 1, 0));
     ZK_HIP(ctx, hipMemcpyAsync(out_dev, ta, nout * 32, hipMemcpyDeviceToDevice, ctx->stream));
     return ZK_OK;
+    ZK_API_END
 }
 
 // KZG10::commit: MSM(powers_of_g, coeffs) + MSM(powers_of_gamma_g, blinding coeffs)
 extern "C" int zk_kzg_commit_dev(zk_ctx* ctx, const zk_bases* powers_g, const void* coeffs_dev, size_t n,
                                  const zk_bases* powers_gamma_g, const void* blind_dev, size_t n_blind, zk_g1_projective* out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !powers_g || !out || (n && !coeffs_dev) || powers_g->group != 1) return ZK_ERR_ARG;
     if (n > powers_g->n) ZK_FAIL(ctx, ZK_ERR_ARG, "kzg commit: polynomial degree exceeds the supported degree");   // check_degree_is_too_large
     zk_g1_projective c;
@@ -425,12 +440,14 @@ extern "C" int zk_kzg_commit_dev(zk_ctx* ctx, const zk_bases* powers_g, const vo
     }
     *out = c;
     return ZK_OK;
+    ZK_API_END
 }
 
 // KZG10::open: w = commit(p / (X - z)) [+ commit_gamma(blind / (X - z))], random_v = blind(z)
 extern "C" int zk_kzg_open_dev(zk_ctx* ctx, const zk_bases* powers_g, const void* coeffs_dev, size_t n, const zk_fr* point,
                                const zk_bases* powers_gamma_g, const void* blind_dev, size_t n_blind,
                                zk_g1_projective* w_out, zk_fr* random_v_out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !powers_g || !point || !w_out || (n && !coeffs_dev) || powers_g->group != 1) return ZK_ERR_ARG;
     void* q;
     ZK_TRY(zk_scratch(ctx, "kzg_witness", (n ? n : 1) * 32, &q));
@@ -448,4 +465,5 @@ extern "C" int zk_kzg_open_dev(zk_ctx* ctx, const zk_bases* powers_g, const void
     }
     *w_out = w;
     return ZK_OK;
+    ZK_API_END
 }

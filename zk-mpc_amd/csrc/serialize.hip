@@ -249,17 +249,23 @@ extern "C" size_t zk_point_serialized_size(int group, int compressed) {
 }
 
 extern "C" int zk_bases_serialize(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, int compressed, uint8_t* out_host) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !b || (n && !out_host)) return ZK_ERR_ARG;
     return b->group == 2 ? serialize_t<G2Field>(ctx, b, offset, n, compressed, out_host)
                          : serialize_t<G1Field>(ctx, b, offset, n, compressed, out_host);
+    ZK_API_END
 }
 
 extern "C" int zk_bases_deserialize_uncompressed(zk_ctx* ctx, int group, const uint8_t* bytes_host, size_t n, zk_bases** out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !out || (n && !bytes_host) || (group != 1 && group != 2)) return ZK_ERR_ARG;
     return group == 2 ? deserialize_t<G2Field>(ctx, group, bytes_host, n, 0, out) : deserialize_t<G1Field>(ctx, group, bytes_host, n, 0, out);
+    ZK_API_END
 }
 
 extern "C" int zk_bases_deserialize_compressed(zk_ctx* ctx, int group, const uint8_t* bytes_host, size_t n, zk_bases** out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !out || (n && !bytes_host) || (group != 1 && group != 2)) return ZK_ERR_ARG;
     return group == 2 ? deserialize_t<G2Field>(ctx, group, bytes_host, n, 1, out) : deserialize_t<G1Field>(ctx, group, bytes_host, n, 1, out);
+    ZK_API_END
 }

@@ -510,6 +510,7 @@ int check_n(zk_ctx* ctx, size_t n, const char* who) {
 }  // namespace
 
 extern "C" int zk_she_vec_op_dev(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (n && (!a || !out))) return ZK_ERR_ARG;
     if (op != ZK_OP_MUL && op != ZK_OP_ADD && op != ZK_OP_SUB && op != ZK_OP_NEG) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_she_vec_op_dev: unknown op");
     if (op != ZK_OP_NEG && n && !b) return ZK_ERR_ARG;
@@ -517,18 +518,22 @@ extern "C" int zk_she_vec_op_dev(zk_ctx* ctx, int op, const void* a, const void*
     hipLaunchKernelGGL(k_she_vec_op, zk_grid(n, 256), 256, 0, ctx->stream, op, a, b, out, n);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_she_vec_scale_dev(zk_ctx* ctx, const void* a, const zk_fq753* k, void* out, size_t n) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !k || (n && (!a || !out))) return ZK_ERR_ARG;
     if (n == 0) return ZK_OK;
     F7 kk = fp_ext_to_int<Fq753Params>(host_load_ext<Fq753Params>(k->l));
     hipLaunchKernelGGL(k_she_vec_scale, zk_grid(n, 256), 256, 0, ctx->stream, a, to_f7k(kk), out, n);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_she_negacyclic_mul_dev(zk_ctx* ctx, const void* a, const void* b, void* out, size_t n, size_t batch) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (batch && (!a || !b || !out))) return ZK_ERR_ARG;
     ZK_TRY(check_n(ctx, n, "zk_she_negacyclic_mul_dev"));
     if (batch == 0) return ZK_OK;
@@ -544,9 +549,11 @@ extern "C" int zk_she_negacyclic_mul_dev(zk_ctx* ctx, const void* a, const void*
     ZK_TRY(she_forward(ctx, tb, rows_of(b, 1, n), fb, log_n, batch));
     InvArgs ia{rows_of(fa, 1, n), rows_of(fb, 1, n), NO_ROWS, NO_ROWS, rows_of(out, 1, n), nullptr, 0};
     return she_inverse(ctx, tb, ia, log_n, batch);
+    ZK_API_END
 }
 
 extern "C" int zk_she_ciphertext_mul_dev(zk_ctx* ctx, const void* x, const void* y, void* out, size_t n, size_t batch) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (batch && (!x || !y || !out))) return ZK_ERR_ARG;
     ZK_TRY(check_n(ctx, n, "zk_she_ciphertext_mul_dev"));
     if (batch == 0) return ZK_OK;
@@ -576,10 +583,12 @@ extern "C" int zk_she_ciphertext_mul_dev(zk_ctx* ctx, const void* x, const void*
     ZK_TRY(she_inverse(ctx, tb, InvArgs{x0, y0, NO_ROWS, NO_ROWS, rows_of(ob, 1, 3 * n), nullptr, 0}, log_n, batch));
     ZK_TRY(she_inverse(ctx, tb, InvArgs{x0, y1, x1, y0, rows_of(ob + poly, 1, 3 * n), nullptr, 0}, log_n, batch));
     return she_inverse(ctx, tb, InvArgs{x1, y1, NO_ROWS, NO_ROWS, rows_of(ob + 2 * poly, 1, 3 * n), nullptr, 1}, log_n, batch);
+    ZK_API_END
 }
 
 extern "C" int zk_she_encrypt_dev(zk_ctx* ctx, const void* e, const void* pk_a, const void* pk_b, const void* r, const zk_fq753* p,
                                   void* out, size_t n, size_t batch) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !p || (batch && (!e || !pk_a || !pk_b || !r || !out))) return ZK_ERR_ARG;
     ZK_TRY(check_n(ctx, n, "zk_she_encrypt_dev"));
     if (batch == 0) return ZK_OK;
@@ -610,9 +619,11 @@ extern "C" int zk_she_encrypt_dev(zk_ctx* ctx, const void* e, const void* pk_a, 
     hipLaunchKernelGGL(k_she_encrypt_tail, zk_grid(batch * n, 256), 256, 0, ctx->stream, out, e, r, to_f7k(pp), (uint32_t)n, (uint64_t)batch);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_she_decrypt_dev(zk_ctx* ctx, const void* ct, const void* sk, void* out, size_t n, size_t batch) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (batch && (!ct || !sk || !out))) return ZK_ERR_ARG;
     ZK_TRY(check_n(ctx, n, "zk_she_decrypt_dev"));
     if (batch == 0) return ZK_OK;
@@ -645,6 +656,7 @@ extern "C" int zk_she_decrypt_dev(zk_ctx* ctx, const void* ct, const void* sk, v
     hipLaunchKernelGGL(k_she_decrypt_tail, zk_grid(batch * n, 256), 256, 0, ctx->stream, ct, (const void*)t, out, (uint32_t)n, (uint64_t)batch);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 // zeta^(+-j) for the primitive 2n-th root zeta = cyclotomic_moduli's root (src/she/polynomial.rs:107-119), ext form.
@@ -666,6 +678,7 @@ static int she_fr_twist(zk_ctx* ctx, uint32_t log_n, bool inverse, void** out) {
 }
 
 extern "C" int zk_she_encode_dev(zk_ctx* ctx, const void* plain_fr, void* out, size_t n, size_t batch) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (batch && (!plain_fr || !out))) return ZK_ERR_ARG;
     ZK_TRY(check_n(ctx, n, "zk_she_encode_dev"));
     if (!is_pow2(n)) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_she_encode_dev: the slot count must be a power of two (X^N + 1 cyclotomic)");
@@ -682,9 +695,11 @@ extern "C" int zk_she_encode_dev(zk_ctx* ctx, const void* plain_fr, void* out, s
     hipLaunchKernelGGL(k_she_fr_to_fq, zk_grid(batch * n, 256), 256, 0, ctx->stream, (const void*)w, out, batch * n);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_she_decode_dev(zk_ctx* ctx, const void* enc, void* out_fr, size_t n, size_t batch) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (batch && (!enc || !out_fr))) return ZK_ERR_ARG;
     ZK_TRY(check_n(ctx, n, "zk_she_decode_dev"));
     if (!is_pow2(n)) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_she_decode_dev: the slot count must be a power of two (X^N + 1 cyclotomic)");
@@ -697,4 +712,5 @@ extern "C" int zk_she_decode_dev(zk_ctx* ctx, const void* enc, void* out_fr, siz
     ZK_HIP(ctx, hipGetLastError());
     for (size_t b = 0; b < batch && log_n; b++) ZK_TRY(zk_ntt_launch(ctx, (char*)out_fr + b * n * 32, log_n, 0, 0));
     return ZK_OK;
+    ZK_API_END
 }

@@ -129,17 +129,22 @@ int zk_vec_sub_scale_launch(zk_ctx* ctx, const void* a, const void* b, const uin
 }
 
 extern "C" int zk_fr_vec_op_dev(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (n && (!a || !b || !out))) return ZK_ERR_ARG;
     return zk_vec_op_launch(ctx, op, a, b, out, n);
+    ZK_API_END
 }
 
 extern "C" int zk_fr_vec_scale_dev(zk_ctx* ctx, const void* a, const zk_fr* k, void* out, size_t n) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !k || (n && (!a || !out))) return ZK_ERR_ARG;
     Fr kk = fp_ext_to_int<FrParams>(host_load_ext<FrParams>(k->l));
     return zk_vec_scale_launch(ctx, a, kk.l, out, n);
+    ZK_API_END
 }
 
 extern "C" int zk_fr_batch_product_in_place(zk_ctx* ctx, zk_fr* selfs, const zk_fr* others, size_t n) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (n && (!selfs || !others))) return ZK_ERR_ARG;
     if (n == 0) return ZK_OK;
     void *da, *db;
@@ -151,18 +156,22 @@ extern "C" int zk_fr_batch_product_in_place(zk_ctx* ctx, zk_fr* selfs, const zk_
     ZK_HIP(ctx, hipMemcpyAsync(selfs, da, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_fr_sum_parties_dev(zk_ctx* ctx, const void* g, size_t np, size_t n, void* out) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || np == 0 || (n && (!g || !out))) return ZK_ERR_ARG;
     if (n == 0) return ZK_OK;
     hipLaunchKernelGGL(k_sum_parties, zk_grid(n, 256), 256, 0, ctx->stream, g, np, n, out);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_beaver_combine_dev(zk_ctx* ctx, const void* sx, const void* oy, const void* tx, const void* ty,
                                      const void* tz, void* out, size_t n) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || (n && (!sx || !oy || !out))) return ZK_ERR_ARG;
     if (n == 0) return ZK_OK;
     int leader = ctx->party_id == 0;
@@ -174,9 +183,11 @@ extern "C" int zk_beaver_combine_dev(zk_ctx* ctx, const void* sx, const void* oy
         hipLaunchKernelGGL(k_beaver<false>, zk_grid(n, 256), 256, 0, ctx->stream, sx, oy, tx, ty, tz, out, n, leader);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
+    ZK_API_END
 }
 
 extern "C" int zk_fr_vec_is_zero_dev(zk_ctx* ctx, const void* v, size_t n, int* is_zero) {
+    ZK_API_BEGIN(ctx)
     if (!ctx || !is_zero || (n && !v)) return ZK_ERR_ARG;
     uint32_t* flag;
     ZK_TRY(zk_scratch(ctx, "vec_flag", 16, (void**)&flag));
@@ -187,4 +198,5 @@ extern "C" int zk_fr_vec_is_zero_dev(zk_ctx* ctx, const void* v, size_t n, int* 
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *is_zero = h == 0;
     return ZK_OK;
+    ZK_API_END
 }
