@@ -68,9 +68,10 @@ def test_ntt_zero_padding(ctx):
     assert cv.fr_from_mont(ctx.fft_in_place(cv.fr_to_mont(v), 6)) == dom.fft(v)
 
 
-@pytest.mark.parametrize("log_n", [16, 18, 19, 20, 21, 22])
+@pytest.mark.parametrize("log_n", [16, 18, 19, 20, 21, 22, 23, 24])
 def test_ntt_large_properties(ctx, log_n):
-    """Size-independent properties at the benchmark sizes: round trips, linearity, a spot DFT value."""
+    """Size-independent properties at the benchmark sizes: round trips, linearity, a spot DFT value.  21 ... 24 are the
+    three-pass sizes (1 024-element tiles); 2^24 = 4|H| of the Marlin leg at 2^22 constraints (BASELINE config 5)."""
     N = 1 << log_n
     rs = np.random.RandomState(log_n)
     a = rs.randint(0, 1 << 62, size=(N, 4), dtype=np.uint64)
