@@ -134,6 +134,64 @@ def test_she_mul_oracle(kats):
     assert O.encodedtext_mul(x, y) == [le(v) for v in s["xy"]]
 
 
+def _marlin_layout(m):
+    """The byte layout of what Marlin's transcript absorbs (to_bytes!: lib.rs:161-164,183,207,230): PROTOCOL_NAME | IndexInfo
+    (three u64) | 12 index commitments | padded public input; a commitment is x | y | infinity | has-shift | shifted point
+    (48 + 48 + 1 + 1 + 97 bytes: marlin_pc/data_structures.rs:252-263, short_weierstrass_jacobian.rs:315-322)."""
+    seed = bytes.fromhex(m["seed"])
+    CB = 97 + 1 + 97
+    assert seed[:11] == b"MARLIN-2019"
+    nv, nc, nnz = [int.from_bytes(seed[11 + 8 * i:19 + 8 * i], "little") for i in range(3)]
+    assert nv == nc and len(seed) == 11 + 24 + 12 * CB + 32 * len(m["public_input"])
+    assert seed[11 + 24 + 12 * CB:] == b"".join(bytes.fromhex(v) for v in m["public_input"])
+    for k in range(12):
+        c = seed[35 + k * CB:35 + (k + 1) * CB]
+        assert c[96] == 0 and c[97] == 0 and c[98:] == bytes(48) + (1).to_bytes(48, "little") + b"\x01"    # index comms: no shift, zero()
+    ab = [bytes.fromhex(x) for x in m["absorb"]]
+    assert [len(x) for x in ab] == [4 * CB, 3 * CB, 2 * CB]                                # 4 + 3 + 2 oracles, empty prover messages
+    assert ab[1][CB + 97] == 1 and ab[2][97] == 1                                          # g_1 and g_2 carry shifted commitments
+    h = 1
+    while h < nc:
+        h *= 2
+    return seed, ab, h
+
+
+def test_marlin_transcript_oracle(kats):
+    """FiatShamirRng<Blake2s> (marlin/src/rng.rs:44-67) replayed on the bytes the reference absorbed: the oracle's generator draws
+    the reference's alpha, eta_a, eta_b, eta_c, beta, gamma."""
+    m = kats["marlin_simple"]
+    seed, ab, h = _marlin_layout(m)
+    dom = O.Domain(h)
+    fs = FR.FiatShamirRng(seed)
+    outside = lambda: next(t for t in iter(fs.next_fr, None) if pow(t, h, O.R_MOD) != 1)
+    fs.absorb(ab[0])
+    got = {"alpha": outside(), "eta_a": fs.next_fr(), "eta_b": fs.next_fr(), "eta_c": fs.next_fr()}
+    fs.absorb(ab[1])
+    got["beta"] = outside()
+    fs.absorb(ab[2])
+    got["gamma"] = fs.next_fr()
+    assert got == {k: le(m[k]) for k in got}
+    assert dom.size == h
+
+
+def test_marlin_transcript_library(kats):
+    """The same replay through the PRODUCT's FiatShamirRng (csrc/fsrng.hpp behind zk_fsrng_new / zk_fsrng_absorb / zk_rng_next_fr:
+    host code, no device needed) -- the generator zk_marlin_prove draws its challenges from."""
+    from zk_mpc_amd.api import Rng
+    m = kats["marlin_simple"]
+    seed, ab, h = _marlin_layout(m)
+    fs = Rng.fiat_shamir(seed)
+    nxt = lambda: cv.fr_from_mont(fs.next_fr().reshape(1, 4))[0]
+    outside = lambda: next(t for t in iter(nxt, None) if pow(t, h, O.R_MOD) != 1)
+    fs.absorb(ab[0])
+    got = {"alpha": outside(), "eta_a": nxt(), "eta_b": nxt(), "eta_c": nxt()}
+    fs.absorb(ab[1])
+    got["beta"] = outside()
+    fs.absorb(ab[2])
+    got["gamma"] = nxt()
+    assert got == {k: le(m[k]) for k in got}
+
+
 # ---- the library against the same file ---------------------------------------------------------------------------------------
 
 @pytest.mark.gpu

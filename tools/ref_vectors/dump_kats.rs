@@ -13,9 +13,15 @@
 //! Every input is drawn from `ark_std::test_rng()` (arkworks/std/src/rand_helper.rs:31-39) in the order written below, so
 //! that the consumer can REPLAY the inputs (oracle/fsrng_ref.py::test_rng, zk_rng_from_seed(seed, 12)) and needs only the
 //! outputs; the inputs are dumped as well, which also pins the replay of the generator itself.
+//! AUDIT (round 3): every call below was checked by reading against the vendored signature it uses; the file:line of each is in
+//! the comment next to it.  One error was found and fixed that way: `AffineCurve::mul` takes `S: Into<BigInt>`
+//! (arkworks/algebra/ec/src/lib.rs:284) and this vendored ff has no `From<Fp> for BigInteger` (only `Into<BigUint>`,
+//! ff/src/fields/macros.rs:747), so scalars go in as `k.into_repr()` -- exactly as generator.rs:144-148 does.
 //! All field elements are written as the hex of their canonical little-endian bytes (`into_repr().to_bytes_le()`), points
 //! as the hex of `CanonicalSerialize::serialize_uncompressed` / `serialize` as noted.
 
+// crate names: Cargo.toml [dependencies] (ark-bls12-377, ark-ec, ark-ff, ark-groth16, ark-poly, ark-serialize, ark-std, ark-marlin,
+// ark-poly-commit, ark-mnt4-753, blake2 = "0.9", hex = "0.4.3"); the library target of package "zk-mpc" is `zk_mpc` (src/lib.rs)
 use ark_bls12_377::{Bls12_377, Fq, Fr, G1Affine, G1Projective, G2Affine, G2Projective};
 use ark_ec::msm::VariableBaseMSM;
 use ark_ec::{AffineCurve, ProjectiveCurve};
@@ -25,7 +31,7 @@ use ark_poly::{EvaluationDomain, Radix2EvaluationDomain};
 use ark_serialize::CanonicalSerialize;
 use ark_std::test_rng;
 use std::fmt::Write as _;
-use zk_mpc::circuits::circuit::MySimpleCircuit;
+use zk_mpc::circuits::circuit::MySimpleCircuit;      // src/lib.rs:1 `pub mod circuits`; src/circuits/circuit.rs:80-83 (pub fields a, b: Option<F>)
 
 fn fr_hex(x: &Fr) -> String { hex::encode(x.into_repr().to_bytes_le()) }
 fn fq_hex(x: &Fq) -> String { hex::encode(x.into_repr().to_bytes_le()) }
@@ -36,17 +42,19 @@ fn list(v: Vec<String>) -> String { format!("[{}]", v.iter().map(|s| format!("\"
 fn main() {
     let out_path = std::env::args().nth(1).unwrap_or_else(|| "ref_kats.json".to_string());
     let mut j = String::from("{\n");
-    let rng = &mut test_rng();
+    let rng = &mut test_rng();      // arkworks/std/src/rand_helper.rs:31-39: StdRng::from_seed([1,0,0,0,23,0,0,0,200,1,0,0,210,30,0,...])
 
     // (1) the generator itself: the first eight u64 of test_rng()  (StdRng = ChaCha12)
     {
-        use ark_std::rand::RngCore;
+        use ark_std::rand::RngCore;          // rand_helper.rs:8 `pub use rand;`
         let mut r = test_rng();
         let w: Vec<String> = (0..8).map(|_| format!("{:016x}", r.next_u64())).collect();
         writeln!(j, "\"test_rng_u64\": {},", list(w)).unwrap();
     }
 
-    // (2) Fr / Fq arithmetic: 8 pairs each, a*b, a+b, a-b, a^-1  (ff/src/fields/arithmetic.rs, macros.rs)
+    // (2) Fr / Fq arithmetic: 8 pairs each, a*b, a+b, a-b, a^-1  (ff/src/fields/arithmetic.rs:7-57, macros.rs:389-443,638-717)
+    //     UniformRand::rand<R: Rng + ?Sized>(rng: &mut R) (rand_helper.rs:10-12) -> impl_prime_field_standard_sample
+    //     (ff/src/fields/arithmetic.rs:194-219); Field::inverse -> Option (ff/src/fields/mod.rs), Field::square
     let mut fr_rows = Vec::new();
     for _ in 0..8 {
         let (a, b) = (Fr::rand(rng), Fr::rand(rng));
@@ -61,12 +69,15 @@ fn main() {
     writeln!(j, "\"fq_ops\": [{}],", fq_rows.join(",")).unwrap();
 
     // (3) group law: P = k1 G, Q = k2 G; P + Q, 2P, P - Q  (short_weierstrass_jacobian.rs:557-784), uncompressed bytes
+    //     AffineCurve::prime_subgroup_generator (ec/src/lib.rs), AffineCurve::mul<S: Into<BigInt>>(&self, S) -> Projective
+    //     (ec/src/lib.rs:284), Add / Sub by value from impl_additive_ops_from_ref! (short_weierstrass_jacobian.rs:709),
+    //     ProjectiveCurve::double(&self), into_affine; serialize_uncompressed (short_weierstrass_jacobian.rs:861-883)
     {
         let (k1, k2) = (Fr::rand(rng), Fr::rand(rng));
         let g1 = G1Affine::prime_subgroup_generator();
         let g2 = G2Affine::prime_subgroup_generator();
-        let (p1, q1) = (g1.mul(k1), g1.mul(k2));
-        let (p2, q2) = (g2.mul(k1), g2.mul(k2));
+        let (p1, q1) = (g1.mul(k1.into_repr()), g1.mul(k2.into_repr()));
+        let (p2, q2) = (g2.mul(k1.into_repr()), g2.mul(k2.into_repr()));
         writeln!(j, "\"group\": {{\"k1\": \"{}\", \"k2\": \"{}\", \"g1\": {}, \"g2\": {}}},", fr_hex(&k1), fr_hex(&k2),
                  list(vec![ser_unc(&p1.into_affine()), ser_unc(&q1.into_affine()), ser_unc(&(p1 + q1).into_affine()),
                            ser_unc(&p1.double().into_affine()), ser_unc(&(p1 - q1).into_affine())]),
@@ -75,14 +86,16 @@ fn main() {
     }
 
     // (4) VariableBaseMSM on 2^10 - 1 terms (the size of test-templates/src/msm.rs): bases k_i G (k_i drawn first), then scalars
+    //     VariableBaseMSM::multi_scalar_mul<G: AffineCurve>(bases: &[G], scalars: &[BigInt]) (ec/src/msm/variable_base.rs:11-14);
+    //     ProjectiveCurve::batch_normalization_into_affine(&[Self]) -> Vec<Affine> (ec/src/lib.rs:177-181)
     {
         let n = (1usize << 10) - 1;
         let ks: Vec<Fr> = (0..n).map(|_| Fr::rand(rng)).collect();
         let ss: Vec<Fr> = (0..n).map(|_| Fr::rand(rng)).collect();
         let g1 = G1Affine::prime_subgroup_generator();
         let g2 = G2Affine::prime_subgroup_generator();
-        let b1: Vec<G1Affine> = G1Projective::batch_normalization_into_affine(&ks.iter().map(|k| g1.mul(*k)).collect::<Vec<_>>());
-        let b2: Vec<G2Affine> = G2Projective::batch_normalization_into_affine(&ks.iter().map(|k| g2.mul(*k)).collect::<Vec<_>>());
+        let b1: Vec<G1Affine> = G1Projective::batch_normalization_into_affine(&ks.iter().map(|k| g1.mul(k.into_repr())).collect::<Vec<_>>());
+        let b2: Vec<G2Affine> = G2Projective::batch_normalization_into_affine(&ks.iter().map(|k| g2.mul(k.into_repr())).collect::<Vec<_>>());
         let sr: Vec<_> = ss.iter().map(|s| s.into_repr()).collect();
         let m1 = VariableBaseMSM::multi_scalar_mul(&b1, &sr).into_affine();
         let m2 = VariableBaseMSM::multi_scalar_mul(&b2, &sr).into_affine();
@@ -90,7 +103,8 @@ fn main() {
                  fr_hex(&ks[0]), fr_hex(&ss[0]), ser_unc(&m1), ser_unc(&m2)).unwrap();
     }
 
-    // (5) the four transforms on 2^6 random points (radix2/fft.rs, domain/mod.rs:138-157)
+    // (5) the four transforms on 2^6 random points (radix2/fft.rs, domain/mod.rs:78-157: fn *_in_place<T: DomainCoeff<F>>(&self, &mut Vec<T>));
+    //     Radix2EvaluationDomain::new(usize) -> Option<Self> (radix2/mod.rs:51-82)
     {
         let d = Radix2EvaluationDomain::<Fr>::new(64).unwrap();
         let v: Vec<Fr> = (0..64).map(|_| Fr::rand(rng)).collect();
@@ -104,12 +118,16 @@ fn main() {
     // (6) Groth16 on MySimpleCircuit (src/circuits/circuit.rs:80-111; BASELINE config 1's circuit) with explicit toxic waste:
     //     alpha, beta, gamma, delta, g1 = k1 G, g2 = k2 G, then a, b, r, s -- all from the rng in this order; generate_parameters
     //     draws tau from a FRESH test_rng() (its first accepted Fr::rand), create_proof takes r and s.
+    //     generate_parameters<E, C, R>(circuit, alpha, beta, gamma, delta, g1_generator: E::G1Projective, g2_generator:
+    //     E::G2Projective, rng: &mut R) (arkworks/groth16/src/generator.rs:44-53); tau = domain.sample_element_outside_domain(rng,
+    //     false) = F::rand until Z(t) != 0 (generator.rs:80, poly/src/domain/mod.rs:37-51);
+    //     create_proof<E, C>(circuit, pk: &ProvingKey<E>, r, s) (arkworks/groth16/src/prover.rs:44-49)
     {
         let (alpha, beta, gamma, delta) = (Fr::rand(rng), Fr::rand(rng), Fr::rand(rng), Fr::rand(rng));
         let (k1, k2) = (Fr::rand(rng), Fr::rand(rng));
         let (a, b, r, s) = (Fr::rand(rng), Fr::rand(rng), Fr::rand(rng), Fr::rand(rng));
-        let g1 = G1Affine::prime_subgroup_generator().mul(k1);
-        let g2 = G2Affine::prime_subgroup_generator().mul(k2);
+        let g1 = G1Affine::prime_subgroup_generator().mul(k1.into_repr());
+        let g2 = G2Affine::prime_subgroup_generator().mul(k2.into_repr());
         let pk: ProvingKey<Bls12_377> = generate_parameters::<Bls12_377, _, _>(
             MySimpleCircuit::<Fr> { a: None, b: None }, alpha, beta, gamma, delta, g1, g2, &mut test_rng()).unwrap();
         let proof: Proof<Bls12_377> = create_proof(MySimpleCircuit { a: Some(a), b: Some(b) }, &pk, r, s).unwrap();
@@ -121,6 +139,7 @@ fn main() {
     }
 
     // (7) SHE: Encodedtext * Encodedtext in F_q[X]/(X^N + 1), N = 4 (src/she/encodedtext.rs:115-134), q = MNT4-753 base field
+    //     src/she.rs:13 `pub use encodedtext::Encodedtext` (= Texts<Fq>, encodedtext.rs:13); Texts::from_vec (texts.rs:26), pub vals (:6)
     {
         use ark_mnt4_753::Fq as Fq753;
         use zk_mpc::she::Encodedtext;
@@ -129,7 +148,52 @@ fn main() {
         let y: Vec<Fq753> = (0..n).map(|_| Fq753::rand(rng)).collect();
         let z = Encodedtext::from_vec(x.clone()) * Encodedtext::from_vec(y.clone());
         let h = |v: &Vec<Fq753>| list(v.iter().map(|e| hex::encode(e.into_repr().to_bytes_le())).collect());
-        writeln!(j, "\"she_mul\": {{\"n\": {}, \"x\": {}, \"y\": {}, \"xy\": {}}}", n, h(&x), h(&y), h(&z.vals)).unwrap();
+        writeln!(j, "\"she_mul\": {{\"n\": {}, \"x\": {}, \"y\": {}, \"xy\": {}}},", n, h(&x), h(&y), h(&z.vals)).unwrap();
+    }
+
+    // (8) Marlin on MySimpleCircuit: the Fiat-Shamir TRANSCRIPT (the least pinned byte format of the path) and a whole proof.
+    //     LocalMarlin = Marlin<Fr, MarlinKZG10<Bls12_377, DensePolynomial<Fr>>, Blake2s> (src/marlin.rs:160-163);
+    //     Marlin::{PROTOCOL_NAME (lib.rs:76), universal_setup(nc, nv, nnz, rng) (:80-85), index(&srs, c) (:101), prove(&ipk, c, zk_rng) (:152)};
+    //     the seed and the three absorbed strings are rebuilt exactly as Marlin::verify builds them (lib.rs:333-370): the public
+    //     input padded to |domain_x| - 1, to_bytes![PROTOCOL_NAME, index_vk, public_input], to_bytes![comms, prover_messages[i]];
+    //     FiatShamirRng::{from_seed, absorb} (marlin/src/rng.rs:44-67, `pub mod rng` lib.rs:46); AHPForR1CS::verifier_{first,second}_round
+    //     (ahp/verifier.rs:44-92) with pub alpha / eta_a / eta_b / eta_c / beta (:24-40); gamma = F::rand on the rng (:98).
+    //     Draw order: a, b from `rng`; the SRS from a fresh test_rng(); the prover's zk_rng is a fresh test_rng() as in src/marlin.rs:42,55.
+    {
+        use ark_ff::{to_bytes, ToBytes, Zero};
+        use ark_marlin::{rng::FiatShamirRng, AHPForR1CS, Marlin};
+        use ark_poly::{univariate::DensePolynomial, GeneralEvaluationDomain};
+        use ark_poly_commit::marlin_pc::MarlinKZG10;
+        use blake2::Blake2s;
+        type PC = MarlinKZG10<Bls12_377, DensePolynomial<Fr>>;
+        type M = Marlin<Fr, PC, Blake2s>;
+        let (a, b) = (Fr::rand(rng), Fr::rand(rng));
+        let srs = M::universal_setup(64, 16, 64, &mut test_rng()).unwrap();
+        let (ipk, ivk) = M::index(&srs, MySimpleCircuit::<Fr> { a: None, b: None }).unwrap();
+        let proof = M::prove(&ipk, MySimpleCircuit { a: Some(a), b: Some(b) }, &mut test_rng()).unwrap();
+        let public_input = {
+            let raw = vec![a * b];
+            let domain_x = GeneralEvaluationDomain::<Fr>::new(raw.len() + 1).unwrap();
+            let mut v = raw.clone();
+            v.resize(core::cmp::max(raw.len(), domain_x.size() - 1), Fr::zero());
+            v
+        };
+        assert!(M::verify(&ivk, &[a * b], &proof, &mut test_rng()).unwrap());
+        let seed = to_bytes![&M::PROTOCOL_NAME, &ivk, &public_input].unwrap();
+        let ab: Vec<Vec<u8>> = (0..3).map(|i| to_bytes![&proof.commitments[i], proof.prover_messages[i]].unwrap()).collect();
+        let mut fs = FiatShamirRng::<Blake2s>::from_seed(&seed);
+        fs.absorb(&ab[0]);
+        let (m1, st) = AHPForR1CS::verifier_first_round(ivk.index_info, &mut fs).unwrap();
+        fs.absorb(&ab[1]);
+        let (m2, _st) = AHPForR1CS::verifier_second_round(st, &mut fs);
+        fs.absorb(&ab[2]);
+        let gamma = Fr::rand(&mut fs);
+        writeln!(j, "\"marlin_simple\": {{\"a\": \"{}\", \"b\": \"{}\", \"public_input\": {}, \"seed\": \"{}\", \"absorb\": {}, \
+                     \"alpha\": \"{}\", \"eta_a\": \"{}\", \"eta_b\": \"{}\", \"eta_c\": \"{}\", \"beta\": \"{}\", \"gamma\": \"{}\", \
+                     \"proof\": \"{}\", \"ivk\": \"{}\", \"srs\": \"{}\"}}",
+                 fr_hex(&a), fr_hex(&b), list(public_input.iter().map(fr_hex).collect()), hex::encode(&seed),
+                 list(ab.iter().map(hex::encode).collect()), fr_hex(&m1.alpha), fr_hex(&m1.eta_a), fr_hex(&m1.eta_b), fr_hex(&m1.eta_c),
+                 fr_hex(&m2.beta), fr_hex(&gamma), ser(&proof), ser(&ivk), ser(&srs)).unwrap();
     }
     j.push_str("}\n");
     std::fs::write(&out_path, j).unwrap();

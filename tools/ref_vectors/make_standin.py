@@ -74,6 +74,26 @@ def main():
     x = [fq_rand(r, O.Q753, 12, 15) for _ in range(N)]
     y = [fq_rand(r, O.Q753, 12, 15) for _ in range(N)]
     out["she_mul"] = {"n": N, "x": [hx(t, 96) for t in x], "y": [hx(t, 96) for t in y], "xy": [hx(t, 96) for t in O.encodedtext_mul(x, y)]}
+    # (8) the Marlin transcript of MySimpleCircuit: a, b from r; the SRS and the prover's zk_rng from fresh test_rng()s
+    import marlin_full_ref as MF
+    import marlin_ref as M
+    a, b = r.next_fr(), r.next_fr()
+    r1cs = O.R1CS(2, 2, [[(1, 2)]] * 6, [[(1, 3)]] * 6, [[(1, 1)]] * 6)
+    sq, zz = M.pad_and_square(r1cs, [1, a * b % p, a, b])
+    index = M.Index(sq)
+    srs_rng = FR.test_rng()
+    pp = O.KzgParams(MF.max_degree_for(index) + 3, srs_rng.next_fr(), g_k=srs_rng.next_fr(), gg_k=srs_rng.next_fr(), h_k=srs_rng.next_fr())
+    keys = MF.Keys(index, pp)
+    proof = MF.prove(keys, zz, FR.test_rng())
+    pub = zz[1:index.num_instance]
+    assert MF.verify(keys, pub, proof)
+    seed = MF.PROTOCOL_NAME + keys.ivk_bytes() + b"".join(MF.fr_bytes(v) for v in pub)
+    absorb = [b"".join(MF.comm_bytes(c) for c in rnd) for rnd in proof.commitments]
+    ch, _ = MF.transcript_challenges(keys.ivk_bytes(), index, pub, proof.commitments)
+    out["marlin_simple"] = dict(a=hx(a, 32), b=hx(b, 32), public_input=[hx(v, 32) for v in pub], seed=seed.hex(), absorb=[x.hex() for x in absorb],
+                                alpha=hx(ch["alpha"], 32), eta_a=hx(ch["eta_a"], 32), eta_b=hx(ch["eta_b"], 32), eta_c=hx(ch["eta_c"], 32),
+                                beta=hx(ch["beta"], 32), gamma=hx(ch["gamma"], 32), proof=proof.serialize().hex(), ivk="", srs="",
+                                domain_h=index.dom_h.size)
     json.dump(out, open(sys.argv[1], "w"))
 
 
