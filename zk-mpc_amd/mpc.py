@@ -207,8 +207,26 @@ class GpuBackend:
     def sub(self, a, b, out, n):
         self.ctx.fr_vec_op_dev(2, a, b, out, n)
 
+    def open_stats(self, proofs: int = 1) -> dict:
+        """Wall time this party spent inside the vector opens since the counters were last read (each open ends with a device
+        synchronisation, so the figure includes the local sum); `proofs` divides the totals."""
+        s, c, e = getattr(self, "_open_s", 0.0), getattr(self, "_open_calls", 0), getattr(self, "_open_elems", 0)
+        self._open_s, self._open_calls, self._open_elems = 0.0, 0, 0
+        return {"opens_per_proof": round(c / max(proofs, 1), 2), "ms_per_open": round(s / c * 1e3, 3) if c else None,
+                "ms_per_proof": round(s / max(proofs, 1) * 1e3, 3), "elements_per_open": (e // c) if c else 0}
+
     def open_vec(self, v, out, n):
         """out = sum over parties of v (AdditiveFieldShare::batch_open)."""
+        import time as _time
+        t0 = _time.perf_counter()
+        try:
+            self._open_vec(v, out, n)
+        finally:
+            self._open_s = getattr(self, "_open_s", 0.0) + (_time.perf_counter() - t0)
+            self._open_calls = getattr(self, "_open_calls", 0) + 1
+            self._open_elems = getattr(self, "_open_elems", 0) + n
+
+    def _open_vec(self, v, out, n):
         net, ctx = self.net, self.ctx
         if getattr(self, "native_open", False):
             ctx.open_sum_fr_dev(v, n, out)       # zk_open_sum_fr_dev: RCCL inside the library, on the context's stream
