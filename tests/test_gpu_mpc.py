@@ -620,3 +620,87 @@ def test_collaborative_marlin_full_proof(n_parties, n, spdz, mask_dev):
         assert not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], as_oracle)
     finally:
         ctx.close()
+
+
+# ---- several OS processes, one GPU, host-staged transport (gloo) ---------------------------------------------------------------
+def _marlin_proc_worker(rank, world, port, spdz, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import marlin_ref as M
+    from zk_mpc_amd import marlin as DM
+    from zk_mpc_amd.api import Rng
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = None
+    try:
+        n = 9
+        rng = O.Prng(8800 + world)                            # same seed on every rank: same circuit, same shares
+        r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
+        sq, zz = M.pad_and_square(r1cs, z)
+        zs = additive_shares(zz, world, rng, public_prefix=sq.num_instance)
+        zm = additive_shares(zz, world, rng, public_prefix=sq.num_instance)
+        beta_srs, g_k, gg_k, h_k = rng.fr(), rng.fr(), rng.fr(), rng.fr()
+        ctx = Z.Context(0, rank, world)                       # every process its own context on the one GPU
+        net = mpc.DistNet(dist)                               # CPU tensors over gloo: the opens are staged through host memory
+        party = (mpc.SpdzParty if spdz else mpc.Party)(ctx, net=net)
+        a, b, c = DM.Csr.from_rows(sq.a), DM.Csr.from_rows(sq.b), DM.Csr.from_rows(sq.c)
+        index = DM.Index(ctx, sq.num_instance, sq.num_witness, a, b, c)
+        srs = DM.UniversalSrs(ctx, DM.ahp_max_degree(index) + 3, beta_srs, g_k, gg_k)
+        keys = DM.IndexKeys(index, srs)
+        up = lambda v: ctx.upload(cv.fr_to_mont(v))
+        seed = bytes((17 * rank + i) & 0xff for i in range(32))
+        if spdz:
+            proof = party.marlin_prove_full_spdz(keys, (up(zs[rank]), up(zm[rank])), Rng.from_seed(seed, 20))
+        else:
+            proof = party.marlin_prove_full(keys, up(zs[rank]), Rng.from_seed(seed, 20))
+        q.put((rank, proof.serialize(ctx), proof.evaluations,
+               [[(cc.comm_aff, cc.shifted_aff, cc.shifted is not None) for cc in rnd] for rnd in proof.commitments],
+               [(cv.g1_projective_to_affine(w), rv) for w, rv in proof.pc_proof], srs.max_degree, int(party.bytes_sent)))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "ERROR %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        if ctx is not None:
+            ctx.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,spdz", [(2, False), (3, False), (2, True), (3, True)])
+def test_collaborative_marlin_across_os_processes(world, spdz):
+    """MpcMarlin::prove (src/marlin.rs:56) with the parties as OS PROCESSES, as the reference runs them (one process per party
+    over its TCP mesh, examples/bin_test_marlin.rs) -- here `world` processes on one GPU, torch.distributed/gloo between them,
+    every open staged through host memory.  All parties end with the same proof bytes; the oracle's Marlin::verify accepts
+    them and rejects a wrong public input."""
+    import socket
+    import torch.multiprocessing as mp
+    import marlin_full_ref as MF
+    import marlin_ref as M
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_marlin_proc_worker, args=(r, world, port, spdz, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    [p.join(timeout=60) for p in procs]
+    assert all(len(r) > 2 for r in res), [r[1] for r in res if len(r) == 2]
+    assert all(r[1] == res[0][1] for r in res) and len(res[0][1]) > 900
+    rng = O.Prng(8800 + world)
+    r1cs, z = O.mul_chain_r1cs(9, rng.fr(), rng.fr())
+    sq, zz = M.pad_and_square(r1cs, z)
+    additive_shares(zz, world, rng, public_prefix=sq.num_instance); additive_shares(zz, world, rng, public_prefix=sq.num_instance)
+    beta_srs, g_k, gg_k, h_k = rng.fr(), rng.fr(), rng.fr(), rng.fr()
+    oix = M.Index(sq)
+    okeys = MF.Keys(oix, O.KzgParams(res[0][5], beta_srs, g_k=g_k, gg_k=gg_k, h_k=h_k))
+    as_oracle = MF.Proof(res[0][3], res[0][2], res[0][4])
+    pub = zz[1:oix.num_instance]
+    assert MF.verify(okeys, pub, as_oracle)
+    assert not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], as_oracle)
+    assert all(r[6] > 0 for r in res)

@@ -184,7 +184,7 @@ class GpuBackend:
         is a torch tensor, so the vector can be handed to all_gather without a copy."""
         key = (name, n)
         if key not in self._bufs:
-            if isinstance(self.net, DistNet):
+            if isinstance(self.net, DistNet) and self.net.device.type == "cuda":
                 t, ptr = self.net.new_buffer(n * 32)
                 self._bufs[key] = (t, ptr)
                 self._tensors[ptr] = t
@@ -232,7 +232,7 @@ class GpuBackend:
             ctx.open_sum_fr_dev(v, n, out)       # zk_open_sum_fr_dev: RCCL inside the library, on the context's stream
             ctx.sync()
             return
-        if isinstance(net, DistNet):
+        if isinstance(net, DistNet) and net.device.type == "cuda":
             st = self._tensors.get(v)
             if st is None:                       # not one of our tensors: stage it
                 sp = self.vec("xchg_send", n)
@@ -249,9 +249,12 @@ class GpuBackend:
             res = net.open_sum(st, n, sum_parties, buffer)
             ctx.memcpy_d2d(out, res.data_ptr(), n * 32)
             ctx.sync()
-        else:  # LocalNet: parties share one process; stage through host memory
+        else:
+            # LocalNet (parties share one process), or a torch.distributed backend without device collectives (gloo: the
+            # exchange crosses host memory, as the reference's TCP mesh does -- mpc-net/src/multi.rs:469-525); the sum runs on
+            # the device either way
             mine = ctx.download(v, (n, 4))
-            allv = net.exchange(mine)
+            allv = net.all_gather_small(mine) if isinstance(net, DistNet) else net.exchange(mine)
             g = ctx.upload(np.concatenate(allv, axis=0))
             ctx.fr_sum_parties_dev(g.ptr, net.n, n, out)
             ctx.sync()
@@ -286,10 +289,15 @@ class GpuBackend:
                 parts.append(t)
             ctx.sync()
             parts.append(last)
-        if isinstance(net, DistNet):
+        if isinstance(net, DistNet) and net.device.type == "cuda":
             mine = net.scatter(parts, n * 32)
             self._tensors[mine.data_ptr()] = mine
             return mine.data_ptr()
+        if isinstance(net, DistNet):          # no device collectives (gloo): the shares cross host memory
+            mine = net.scatter([p.cpu() for p in parts] if parts is not None else None, n * 32)
+            b = ctx.upload(mine.numpy().view(np.uint64).reshape(n, 4))
+            self._bufs[("king_share", n, len(self._bufs))] = (b, b.ptr)
+            return b.ptr
         host = [p.cpu().numpy().view(np.uint64).reshape(n, 4) for p in parts] if parts is not None else None
         b = ctx.upload(net.scatter(host, n * 32))
         self._bufs[("king_share", n, len(self._bufs))] = (b, b.ptr)
