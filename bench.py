@@ -477,6 +477,7 @@ def main():
     ap.add_argument("--natural-domain", action="store_true",
                     help="n = 2^L constraints, so that the QAP domain is 2^(L+1) (the reference's natural sizing, src/groth16.rs:256-257)")
     ap.add_argument("--spdz", action="store_true", help="N > 1: SPDZ (malicious) shares instead of additive ones")
+    ap.add_argument("--python-mpc", action="store_true", help="additive collaborative prover: the Python sequence instead of zk_groth16_prove_shared")
     ap.add_argument("--marlin", action="store_true",
                     help="prove with Marlin/KZG instead of Groth16 (BASELINE configs 4 and 5: --gpus 1, or --gpus 8 --spdz --log-constraints 22)")
     args = ap.parse_args()
@@ -563,7 +564,10 @@ def main():
             sc = party.share_scalars([r_plain, s_plain], seed=99)
 
             def step(i):
-                last_proof[0] = party.create_proof_shared(pk, r1cs, zshare, sc[0], sc[1])
+                # one library call per proof (zk_groth16_prove_shared; the transport reached through callbacks): --python-mpc
+                # keeps the Python sequence of the same calls
+                fn = party.create_proof_shared if args.python_mpc else party.create_proof_shared_native
+                last_proof[0] = fn(pk, r1cs, zshare, sc[0], sc[1])
                 return last_proof[0]
 
     def barrier():
@@ -788,6 +792,7 @@ def main():
             out["aggregate_constraint_shares_per_s"] = round(per_proof * world, 1)
             out["opens_in_timed_proofs"] = opens_timed
             out["same_proof_on_all_ranks"] = bool(same_on_all_ranks)
+            out["prover_entry"] = ("mpc.py sequence" if (args.spdz or args.python_mpc) else "zk_groth16_prove_shared (one C-ABI call per proof)")
             out["open_probe"] = open_probe
             out["bytes_sent_per_party"] = int(party.bytes_sent)
         if dist is None:

@@ -406,6 +406,28 @@ int zk_comm_set_open_pattern(zk_ctx* ctx, int pattern);
  * two: one all-gather and a local sum.  Asynchronous on the context stream. */
 int zk_open_sum_fr_dev(zk_ctx* ctx, const void* v_dev, size_t n, void* out_dev);
 
+/* ---- the collaborative prover (rows a6, a10-a13) as one call --------------------------------- */
+/* The transport a collaborative prover needs from its host: the reference's MpcNet (mpc-net/src/lib.rs:60-64) on whatever mesh the
+ * host already has.  all_gather_bytes = MpcNet::broadcast_bytes: every party contributes `len` bytes, `out_all` receives
+ * n_parties * len bytes ordered by party id; returns 0 on success.  open_sum_fr_dev (optional) = AdditiveFieldShare::batch_open of
+ * a device vector (out may alias v); NULL: the context's RCCL communicator (zk_comm_init / zk_open_sum_fr_dev).  A single party
+ * (n_parties = 1) needs neither. */
+typedef struct zk_net_vtable {
+    void* user;
+    int (*all_gather_bytes)(void* user, const uint8_t* mine, size_t len, uint8_t* out_all);
+    int (*open_sum_fr_dev)(void* user, const void* v_dev, size_t n, void* out_dev);
+} zk_net_vtable;
+/* create_proof::<MpcPairingEngine, C> over additive shares (src/groth16.rs:68-183): the local half of the witness map, the four
+ * MSMs over z started, FieldShare::batch_mul of the D-element product (share/field.rs:97-129; tx/ty/tz = this party's Beaver triple
+ * shares as device vectors, or all NULL for DummyFieldTripleSource), the second half, the H job, calculate_coeff on shares, the three
+ * GroupShare::scale calls (share/group.rs:72-111, dummy group triples) and Proof::reveal (arkworks/groth16/src/reveal.rs:7-10).
+ * z_share_dev: this party's share of the full assignment (the instance part shared like the rest); r_share / s_share: shares of
+ * the proof's randomness.  Every party returns the same 192 bytes -- those of create_proof on the summed inputs.  *bytes_sent
+ * (optional) = payload bytes this party contributed to opens. */
+int zk_groth16_prove_shared(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const void* z_share_dev, const zk_fr* r_share,
+                            const zk_fr* s_share, const void* tx_dev, const void* ty_dev, const void* tz_dev,
+                            const zk_net_vtable* net, uint8_t proof[192], uint64_t* bytes_sent);
+
 /* ---- share algebra on device vectors (rows a11, a13) ------------------------------------- */
 /* out[i] = sum_p gathered[p*n + i] mod r: the receive side of AdditiveFieldShare::batch_open
  * (mpc-algebra/src/share/additive.rs:124-131) after an all-gather of the parties' vectors. */

@@ -89,8 +89,14 @@ def test_collaborative_prove(n_parties, n):
         dz = ctx.upload(cv.fr_to_mont(zs[p]))
         proof = party.create_proof_shared(pk, dr, dz.ptr, mont1(rsh[p]), mont1(ssh[p]))
         sent = party.bytes_sent
+        sent2 = party.bytes_sent
         assert party.create_proof_shared(pk, dr, dz.ptr, mont1(rsh[p]), mont1(ssh[p]), fused=False) == proof
-        return proof, (sent, party.bytes_sent - sent)
+        unfused = party.bytes_sent - sent2
+        # the one-call C entry (zk_groth16_prove_shared; the transport reached through callbacks): same bytes, same traffic
+        sent3 = party.bytes_sent
+        assert party.create_proof_shared_native(pk, dr, dz.ptr, mont1(rsh[p]), mont1(ssh[p])) == proof
+        assert party.bytes_sent - sent3 == sent
+        return proof, (sent, unfused)
 
     res = run_parties(n_parties, fn)
     cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))

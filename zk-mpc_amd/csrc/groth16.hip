@@ -1028,6 +1028,203 @@ extern "C" int zk_groth16_prove(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, 
     ZK_API_END
 }
 
+// ---- the collaborative prover as ONE entry point ---------------------------------------------------------------------------------
+// create_proof::<MpcPairingEngine, C> over additive shares (src/groth16.rs:68-183): what mpc.py::Party.create_proof_shared
+// sequences from ~40 calls, for a host that cannot call Python.  The transport is the caller's (zk_net_vtable: the reference's
+// MpcNet::broadcast_bytes on its TCP mesh, mpc-net/src/lib.rs:60-64) for the small opens; the two vector opens of the Beaver
+// product go through the vtable's open_sum_fr_dev or, when that is NULL, through the context's own RCCL communicator
+// (zk_open_sum_fr_dev).  Opens happen in the fused order of create_proof_shared: the nine small opens of the three
+// GroupShare::scale calls (share/group.rs:72-111, DummyGroupTripleSource) and of Proof::reveal travel in two exchanges; every
+// opened value is the reference's, and so are the 192 bytes.
+namespace {
+
+struct FrK { uint32_t l[9]; };
+__device__ __forceinline__ Fr frk(const FrK& k) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = k.l[i];
+    return r;
+}
+FrK to_frk(const Fr& a) {
+    FrK k;
+    for (int i = 0; i < 9; i++) k.l[i] = a.l[i];
+    return k;
+}
+// the 256-bit word of a field element is below the modulus (is_valid, ff/src/fields/macros.rs:255-260): what arrives from a peer
+bool fr_abi_valid(const uint64_t l[4]) {
+    Fr m;
+    for (int i = 0; i < 9; i++) m.l[i] = FrParams::P[i];
+    uint64_t pm[4];
+    host_store_ext<FrParams>(pm, m);
+    for (int i = 3; i >= 0; i--) {
+        if (l[i] < pm[i]) return true;
+        if (l[i] > pm[i]) return false;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(256) k_vec_add_const(const void* a, FrK k, void* out, size_t n) {
+    const Fr kk = frk(k);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        fr_store(out, i, fr_add(fr_load(a, i), kk));
+}
+
+struct SharedNet {
+    zk_ctx* ctx;
+    const zk_net_vtable* vt;
+    size_t bytes = 0;
+    int parties() const { return ctx->n_parties; }
+    // out[p * len ..] = party p's bytes (MpcNet::broadcast_bytes); a single party needs no transport
+    int gather(const uint8_t* mine, size_t len, std::vector<uint8_t>& all) {
+        all.resize((size_t)parties() * len);
+        bytes += len;
+        if (parties() == 1) { memcpy(all.data(), mine, len); return ZK_OK; }
+        if (!vt || !vt->all_gather_bytes) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_groth16_prove_shared: several parties need zk_net_vtable::all_gather_bytes");
+        if (vt->all_gather_bytes(vt->user, mine, len, all.data()) != 0) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_groth16_prove_shared: all_gather_bytes failed");
+        return ZK_OK;
+    }
+    int open_vec(const void* v, size_t n, void* out) {
+        bytes += n * 32;
+        if (vt && vt->open_sum_fr_dev) {
+            ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));             // the callback may use its own stream
+            if (vt->open_sum_fr_dev(vt->user, v, n, out) != 0) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_groth16_prove_shared: open_sum_fr_dev callback failed");
+            return ZK_OK;
+        }
+        if (parties() == 1) {
+            if (out != v) ZK_HIP(ctx, hipMemcpyAsync(out, v, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+            return ZK_OK;
+        }
+        return zk_open_sum_fr_dev(ctx, v, n, out);
+    }
+};
+
+}  // namespace
+
+extern "C" int zk_groth16_prove_shared(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z_share, const zk_fr* r_share,
+                                       const zk_fr* s_share, const void* tx, const void* ty, const void* tz, const zk_net_vtable* net,
+                                       uint8_t proof[192], uint64_t* bytes_sent) {
+    ZK_API_BEGIN(ctx)
+    if (!ctx || !pk || !r || !z_share || !r_share || !s_share || !proof) return ZK_ERR_ARG;
+    const bool dummy = !tx && !ty && !tz;
+    if (!dummy && (!tx || !ty || !tz)) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_groth16_prove_shared: give all of tx, ty, tz or none");
+    using H1 = Fq64Field;
+    using H2 = Fq264Field;
+    using X1 = XYZZ<H1>;
+    using X2 = XYZZ<H2>;
+    const bool leader = ctx->party_id == 0;
+    const size_t D = (size_t)1 << r->log_d;
+    SharedNet nt{ctx, net};
+    uint32_t rw[8], sw[8];
+    fr_abi_to_canon_words(r_share->l, rw);
+    fr_abi_to_canon_words(s_share->l, sw);
+    const X1 delta1 = xyzz_from_affine<H1>(aff_to_host64<G1Field>(pk->delta_g1));
+    const X2 delta2 = xyzz_from_affine<H2>(aff_to_host64<G2Field>(pk->delta_g2));
+    // public point x shared scalar: local host arithmetic (scale_pub_group, share/additive.rs:502-508), under the device work
+    auto f_r_g1 = zk_async([&] { return host64_scalar_mul<H1>(delta1, rw); });
+    auto f_s_g1 = zk_async([&] { return host64_scalar_mul<H1>(delta1, sw); });
+    auto f_s_g2 = zk_async([&] { return host64_scalar_mul<H2>(delta2, sw); });
+    struct Join {                                        // the helper tasks reference this frame: never leave it before they are done
+        std::future<X1>&a, &b; std::future<X2>& c;
+        ~Join() { if (a.valid()) a.wait(); if (b.valid()) b.wait(); if (c.valid()) c.wait(); }
+    } join{f_r_g1, f_s_g1, f_s_g2};
+    void *a, *b, *c, *sx, *oy;
+    ZK_TRY(zk_scratch(ctx, "shared_a", D * 32, &a));
+    ZK_TRY(zk_scratch(ctx, "shared_b", D * 32, &b));
+    ZK_TRY(zk_scratch(ctx, "shared_c", D * 32, &c));
+    ZK_TRY(zk_scratch(ctx, "shared_sx", D * 32, &sx));
+    ZK_TRY(zk_scratch(ctx, "shared_oy", D * 32, &oy));
+    ZK_TRY(zk_groth16_witness_map_pre_dev(ctx, r, z_share, 1, a, b, c));           // local: linear in the shares
+    ZK_TRY(zk_groth16_msms_begin_dev(ctx, pk, r, z_share));                       // the four MSMs over z run under the opens
+    // FieldShare::batch_mul (share/field.rs:97-129): open(s + x), open(o + y), then the local tail
+    if (dummy) {
+        if (leader) {                                     // DummyFieldTripleSource: the leader holds 1, the rest 0 (wire/field.rs:49-63)
+            Fr one_ext = fp_mul<FrParams>(fp_one<FrParams>(), fp_const<FrParams>(FrParams::INT_TO_EXT));
+            hipLaunchKernelGGL(k_vec_add_const, zk_grid(D, 256), 256, 0, ctx->stream, (const void*)a, to_frk(one_ext), sx, D);
+            hipLaunchKernelGGL(k_vec_add_const, zk_grid(D, 256), 256, 0, ctx->stream, (const void*)b, to_frk(one_ext), oy, D);
+            ZK_HIP(ctx, hipGetLastError());
+        } else {
+            ZK_HIP(ctx, hipMemcpyAsync(sx, a, D * 32, hipMemcpyDeviceToDevice, ctx->stream));
+            ZK_HIP(ctx, hipMemcpyAsync(oy, b, D * 32, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    } else {
+        ZK_TRY(zk_vec_op_launch(ctx, 1, a, tx, sx, D));
+        ZK_TRY(zk_vec_op_launch(ctx, 1, b, ty, oy, D));
+    }
+    ZK_TRY(nt.open_vec(sx, D, sx));
+    ZK_TRY(nt.open_vec(oy, D, oy));
+    ZK_TRY(zk_beaver_combine_dev(ctx, sx, oy, tx, ty, tz, a, D));
+    ZK_TRY(zk_groth16_witness_map_post_dev(ctx, r, a, c));                        // h shares in `a`
+    zk_g1_projective m1[4];
+    zk_g2_projective m2;
+    ZK_TRY(zk_groth16_msms_dev(ctx, pk, r, z_share, a, m1, &m2));                 // party-local MSMs (multi_scale_pub_group)
+    const X1 h_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[0]), l_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[1]);
+    const X1 a_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[2]), b1_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[3]);
+    const X2 b2_acc = host64_proj_from_abi<H2>((const uint64_t*)&m2);
+    auto pub1 = [&](const Affine<G1Field>& p) { return leader ? xyzz_from_affine<H1>(aff_to_host64<G1Field>(p)) : xyzz_inf<H1>(); };   // shift(): leader only
+    auto pub2 = [&](const Affine<G2Field>& p) { return leader ? xyzz_from_affine<H2>(aff_to_host64<G2Field>(p)) : xyzz_inf<H2>(); };
+    const X1 r_g1 = f_r_g1.get();
+    const X1 g_a = xyzz_add<H1>(xyzz_add<H1>(xyzz_add<H1>(r_g1, pub1(pk->a0)), a_acc), pub1(pk->alpha_g1));                 // calculate_coeff (:185-201)
+    const X1 g1_b = xyzz_add<H1>(xyzz_add<H1>(xyzz_add<H1>(f_s_g1.get(), pub1(pk->b0_g1)), b1_acc), pub1(pk->beta_g1));
+    const X2 g2_b = xyzz_add<H2>(xyzz_add<H2>(xyzz_add<H2>(f_s_g2.get(), pub2(pk->b0_g2)), b2_acc), pub2(pk->beta_g2));
+    // first exchange: open(o + y) for o = s, r (y = the leader's 1: the dummy group triple), open(s + x) for the three scaled
+    // points (x = 0) and the reveal of B
+    const Fr y = leader ? fp_mul<FrParams>(fp_one<FrParams>(), fp_const<FrParams>(FrParams::INT_TO_EXT)) : fp_zero<FrParams>();
+    uint64_t msg[2 * 4 + 3 * 18 + 36];
+    host_store_ext<FrParams>(msg, fp_add<FrParams>(host_load_ext<FrParams>(s_share->l), y));
+    host_store_ext<FrParams>(msg + 4, fp_add<FrParams>(host_load_ext<FrParams>(r_share->l), y));
+    host64_write_projective<H1>(xyzz_to_affine<H1>(r_g1), msg + 8);
+    host64_write_projective<H1>(xyzz_to_affine<H1>(g_a), msg + 26);
+    host64_write_projective<H1>(xyzz_to_affine<H1>(g1_b), msg + 44);
+    host64_write_projective<H2>(xyzz_to_affine<H2>(g2_b), msg + 62);
+    std::vector<uint8_t> all;
+    ZK_TRY(nt.gather((const uint8_t*)msg, sizeof msg, all));
+    Fr oy_s = fp_zero<FrParams>(), oy_r = fp_zero<FrParams>();
+    X1 sx_rd = xyzz_inf<H1>(), sx_a = xyzz_inf<H1>(), sx_b = xyzz_inf<H1>();
+    X2 B = xyzz_inf<H2>();
+    for (int p = 0; p < nt.parties(); p++) {
+        uint64_t w[sizeof msg / 8];
+        memcpy(w, all.data() + (size_t)p * sizeof msg, sizeof msg);
+        for (int k = 0; k < 2; k++)
+            if (!fr_abi_valid(w + 4 * k)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_groth16_prove_shared: a party sent a non-canonical field element");
+        oy_s = fp_add<FrParams>(oy_s, host_load_ext<FrParams>(w));
+        oy_r = fp_add<FrParams>(oy_r, host_load_ext<FrParams>(w + 4));
+        sx_rd = xyzz_add<H1>(sx_rd, host64_proj_from_abi<H1>(w + 8));
+        sx_a = xyzz_add<H1>(sx_a, host64_proj_from_abi<H1>(w + 26));
+        sx_b = xyzz_add<H1>(sx_b, host64_proj_from_abi<H1>(w + 44));
+        B = xyzz_add<H2>(B, host64_proj_from_abi<H2>(w + 62));
+    }
+    // the local part of GroupShare::scale behind its two opens: z - sx*y (+ sx*oy on the leader), z = 0, y = [leader]
+    auto scale_finish = [&](const X1& sxp, const Fr& oyv) {
+        if (!leader) return xyzz_inf<H1>();
+        uint64_t l4[4];
+        uint32_t kw[8];
+        host_store_ext<FrParams>(l4, oyv);
+        fr_abi_to_canon_words(l4, kw);
+        return xyzz_add<H1>(host64_scalar_mul<H1>(sxp, kw), xyzz_neg<H1>(sxp));
+    };
+    auto p0 = zk_async([&] { return scale_finish(sx_rd, oy_s); });       // r s delta            (:115)
+    auto p1 = zk_async([&] { return scale_finish(sx_a, oy_s); });        // s A                  (:140)
+    const X1 part2 = scale_finish(sx_b, oy_r);                           // r B1                 (:161)
+    X1 g_c = xyzz_add<H1>(p1.get(), part2);
+    g_c = xyzz_add<H1>(g_c, xyzz_neg<H1>(p0.get()));
+    g_c = xyzz_add<H1>(xyzz_add<H1>(g_c, l_acc), h_acc);                 // :169-174
+    uint64_t cmsg[18];
+    host64_write_projective<H1>(xyzz_to_affine<H1>(g_c), cmsg);
+    ZK_TRY(nt.gather((const uint8_t*)cmsg, sizeof cmsg, all));          // Proof::reveal of C (A and B were opened above)
+    X1 C = xyzz_inf<H1>();
+    for (int p = 0; p < nt.parties(); p++) {
+        uint64_t w[18];
+        memcpy(w, all.data() + (size_t)p * sizeof cmsg, sizeof cmsg);
+        C = xyzz_add<H1>(C, host64_proj_from_abi<H1>(w));
+    }
+    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<H1>(sx_a)), proof);
+    g2_serialize(aff_from_host64<G2Field>(xyzz_to_affine<H2>(B)), proof + 48);
+    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<H1>(C)), proof + 144);
+    if (bytes_sent) *bytes_sent = nt.bytes;
+    return ZK_OK;
+    ZK_API_END
+}
+
 // ---- arkworks CanonicalSerialize framing of the Groth16 keys and of a KZG10 SRS --------------------------------------
 // VerifyingKey  (arkworks/groth16/src/data_structures.rs:43-58):   alpha_g1 | beta_g2 | gamma_g2 | delta_g2 | Vec gamma_abc_g1
 // ProvingKey    (data_structures.rs:133-151):                      vk | beta_g1 | delta_g1 | Vec a_query | Vec b_g1_query |

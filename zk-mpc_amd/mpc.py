@@ -562,6 +562,53 @@ class Party:
     def reveal_g2(self, p): return self._open_g(p, self.be.g2_add)
 
     # ---- the collaborative prover ----
+    def create_proof_shared_native(self, pk, r1cs, z_share, r_share, s_share, triple=None) -> bytes:
+        """create_proof over additive shares as ONE library call (zk_groth16_prove_shared): what a Rust host would do.  The
+        library calls back into this party's transport for the two small exchanges (MpcNet::broadcast_bytes) and for the two
+        vector opens; everything else -- witness map halves, MSMs, Beaver tail, group algebra on shares -- stays inside.
+        Same opened values and the same 192 bytes as create_proof_shared(fused=True), which remains the second implementation
+        the tests compare it with."""
+        import ctypes as C
+        be, net, ctx = self.be, self.net, self.ctx
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8))
+        OV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+        class NetVtable(C.Structure):
+            _fields_ = [("user", C.c_void_p), ("all_gather_bytes", AG), ("open_sum_fr_dev", OV)]
+        errors = []
+
+        def all_gather(_user, mine, length, out_all):
+            try:
+                arr = np.ctypeslib.as_array(mine, shape=(length,)).copy()
+                parts = net.all_gather_small(arr.view(np.uint64))
+                flat = np.concatenate([np.ascontiguousarray(p, dtype=np.uint64).reshape(-1) for p in parts]).view(np.uint8)
+                C.memmove(out_all, flat.ctypes.data, flat.nbytes)
+                return 0
+            except Exception as e:      # an exception must not unwind through the C frames
+                errors.append(e)
+                return -1
+
+        def open_vec(_user, v, n, out):
+            try:
+                be._open_vec(v, out, n)
+                return 0
+            except Exception as e:
+                errors.append(e)
+                return -1
+        vt = NetVtable(None, AG(all_gather), OV(open_vec))
+        from .api import _fr_struct
+        r, s_ = _fr_struct(r_share), _fr_struct(s_share)
+        out = np.zeros(192, dtype=np.uint8)
+        sent = C.c_uint64(0)
+        t = [C.c_void_p(int(x)) for x in triple] if triple is not None else [None, None, None]
+        rc = ctx.lib.zk_groth16_prove_shared(ctx.h, pk.h, r1cs.h, C.c_void_p(int(z_share)), C.byref(r), C.byref(s_), t[0], t[1], t[2],
+                                             C.byref(vt) if net.n > 1 else None, out.ctypes.data_as(C.c_void_p), C.byref(sent))
+        if errors:
+            raise errors[0]
+        ctx._ck(rc)
+        self.bytes_sent += int(sent.value)
+        return out.tobytes()
+
     def create_proof_shared(self, pk, r1cs, z_share, r_share, s_share, triple=None, fused=True) -> bytes:
         """create_proof over additive shares (src/groth16.rs:68-183 with E = MpcPairingEngine).
         z_share: this party's share of the full assignment (device vector); r_share, s_share: (4,) uint64.
