@@ -721,7 +721,7 @@ def main():
             mads = madds * mads_per_madd
             traffic, traffic_src = None, None
             try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), not measured live
-                for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+                for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
                     pth = os.path.join(ROOT, "profiles", f)
                     if os.path.exists(pth) and args.log_constraints == 20 and not args.natural_domain:
                         traffic = json.load(open(pth))["kernels"]["k_accum<G1>"]["hbm_bytes"]

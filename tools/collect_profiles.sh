@@ -7,7 +7,7 @@ O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py > $O/${T}_bench_n1.json 2> $O/${T}_bench_n1.err
 rocprofv3 --kernel-trace --stats -d $O/${T}_trace -o t --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-predict > $O/${T}_trace.log 2>&1
-python3 tools/trace_timeline.py $O/${T}_trace/t_kernel_trace.csv 100 -8 > $O/${T}_timeline.txt 2>&1
+python3 tools/trace_timeline.py $O/${T}_trace/t_kernel_trace.csv 60 7 > $O/${T}_timeline.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/${T}_pmc_fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-predict > $O/${T}_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/${T}_pmc_write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-predict > $O/${T}_pmc_write.log 2>&1
 python3 tools/pmc_traffic.py $O/${T}_pmc_fetch $O/${T}_pmc_write $O/${T}_pmc_traffic.json "bench.py --steps 3 --warmup 1, 2^20 Groth16 proofs." > $O/${T}_pmc_traffic.txt 2>&1
