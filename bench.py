@@ -557,7 +557,8 @@ def main():
             rsh, ssh = (ra[0], rb[0]), (ra[1], rb[1])
 
             def step(i):
-                last_proof[0] = party.create_proof_shared_spdz(pk, r1cs, zshare, rsh, ssh)
+                fn = party.create_proof_shared_spdz if args.python_mpc else party.create_proof_shared_spdz_native
+                last_proof[0] = fn(pk, r1cs, zshare, rsh, ssh)
                 return last_proof[0]
         else:
             zshare = party.share_assignment_dev(zs[0], r1cs, seed=1234)
@@ -792,7 +793,8 @@ def main():
             out["aggregate_constraint_shares_per_s"] = round(per_proof * world, 1)
             out["opens_in_timed_proofs"] = opens_timed
             out["same_proof_on_all_ranks"] = bool(same_on_all_ranks)
-            out["prover_entry"] = ("mpc.py sequence" if (args.spdz or args.python_mpc) else "zk_groth16_prove_shared (one C-ABI call per proof)")
+            out["prover_entry"] = ("mpc.py sequence" if args.python_mpc else
+                                   "zk_groth16_prove_shared%s (one C-ABI call per proof)" % ("_spdz" if args.spdz else ""))
             out["open_probe"] = open_probe
             out["bytes_sent_per_party"] = int(party.bytes_sent)
         if dist is None:

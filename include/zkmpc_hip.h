@@ -39,6 +39,7 @@ extern "C" {
 #define ZK_ERR_ARG -2
 #define ZK_ERR_NOMEM -3
 #define ZK_ERR_STATE -4
+#define ZK_ERR_MAC -5     /* a SPDZ MAC check failed (SpdzFieldShare / SpdzGroupShare batch_open: the reference asserts) */
 
 typedef struct zk_ctx zk_ctx;
 typedef struct zk_bases zk_bases;   /* device-resident MSM base table (G1 or G2) */
@@ -427,6 +428,15 @@ typedef struct zk_net_vtable {
 int zk_groth16_prove_shared(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const void* z_share_dev, const zk_fr* r_share,
                             const zk_fr* s_share, const void* tx_dev, const void* ty_dev, const void* tz_dev,
                             const zk_net_vtable* net, uint8_t proof[192], uint64_t* bytes_sent);
+/* The same with E = MpcPairingEngine<_, SpdzPairingShare> (the `malicious` feature: SpdzFieldShare / SpdzGroupShare,
+ * mpc-algebra/src/share/spdz.rs:50-265,278-489, MAC key alpha = 1 held by the leader): every argument is a pair of lanes
+ * [0] = share, [1] = MAC share; everything linear runs on both lanes (2 x 5 MSMs: spdz.rs:482-488), every open is followed by the
+ * exchange of [leader ? opened : 0] - mac, whose sum must vanish (spdz.rs:177-196) -- otherwise ZK_ERR_MAC.  tx/ty/tz_lanes: NULL
+ * (or NULL lanes) for the dummy triple source. */
+int zk_groth16_prove_shared_spdz(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const void* const z_lanes_dev[2],
+                                 const zk_fr r_lanes[2], const zk_fr s_lanes[2], const void* const tx_lanes_dev[2],
+                                 const void* const ty_lanes_dev[2], const void* const tz_lanes_dev[2], const zk_net_vtable* net,
+                                 uint8_t proof[192], uint64_t* bytes_sent);
 
 /* ---- share algebra on device vectors (rows a11, a13) ------------------------------------- */
 /* out[i] = sum_p gathered[p*n + i] mod r: the receive side of AdditiveFieldShare::batch_open

@@ -172,7 +172,13 @@ def test_collaborative_prove_spdz(n_parties, n):
         pk = ctx.groth16_setup(dr, *[tdm[i] for i in range(7)])
         dzs, dzm = ctx.upload(cv.fr_to_mont(zs[p])), ctx.upload(cv.fr_to_mont(zm[p]))
         rr, ss = (mont1(rsh[p]), mont1(rm[p])), (mont1(ssh[p]), mont1(sm[p]))
+        sent0 = party.bytes_sent
         good = party.create_proof_shared_spdz(pk, dr, (dzs.ptr, dzm.ptr), rr, ss)
+        sent = party.bytes_sent - sent0
+        # the one-call C entry (zk_groth16_prove_shared_spdz): same bytes, same traffic; a bad MAC comes back as ZK_ERR_MAC
+        sent0 = party.bytes_sent
+        assert party.create_proof_shared_spdz_native(pk, dr, (dzs.ptr, dzm.ptr), rr, ss) == good
+        assert party.bytes_sent - sent0 == sent
         bad = cv.fr_to_mont(zm[p])
         if p == n_parties - 1:
             bad[5, 0] ^= np.uint64(1)
@@ -182,6 +188,11 @@ def test_collaborative_prove_spdz(n_parties, n):
             caught = False
         except mpc.MacCheckError:
             caught = True
+        try:
+            party.create_proof_shared_spdz_native(pk, dr, (dzs.ptr, dbad.ptr), rr, ss)
+            caught = False
+        except mpc.MacCheckError:
+            pass
         return good, caught
 
     res = run_parties(n_parties, fn)

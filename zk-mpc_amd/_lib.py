@@ -93,6 +93,7 @@ PROTOTYPES = {
     "zk_ctx_stream": (_P, [_P]),
     "zk_version": (_I, []),
     "zk_groth16_prove_shared": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "zk_groth16_prove_shared_spdz": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "zk_selftest_exception_barrier": (_I, [_I]),
     "zk_dev_alloc": (_I, [_P, _SZ, C.POINTER(_P)]),
     "zk_dev_free": (_I, [_P, _P]),

@@ -20,6 +20,7 @@
 #define ZK_ERR_ARG -2
 #define ZK_ERR_NOMEM -3
 #define ZK_ERR_STATE -4
+#define ZK_ERR_MAC -5
 
 struct zk_domain;  // ntt.hip
 

@@ -1100,128 +1100,240 @@ struct SharedNet {
 
 }  // namespace
 
+namespace {
+
+__global__ void __launch_bounds__(256) k_vec_neg(const void* a, void* out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        fr_store(out, i, fr_sub(fp_zero<FrParams>(), fr_load(a, i)));
+}
+
+using SH1 = Fq64Field;
+using SH2 = Fq264Field;
+using SX1 = XYZZ<SH1>;
+using SX2 = XYZZ<SH2>;
+
+// SpdzFieldShare::batch_open on a device vector (mpc-algebra/src/share/spdz.rs:177-196, key alpha = 1 held by the leader):
+// x = open(share lane); then every party publishes [leader ? x : 0] - mac and the sum must vanish element by element.
+int spdz_open_vec(SharedNet& nt, const void* sh, const void* mac, size_t n, void* out, void* dx) {
+    zk_ctx* ctx = nt.ctx;
+    ZK_TRY(nt.open_vec(sh, n, out));
+    if (ctx->party_id == 0) {
+        ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_SUB, out, mac, dx, n));
+    } else {
+        hipLaunchKernelGGL(k_vec_neg, zk_grid(n, 256), 256, 0, ctx->stream, mac, dx, n);
+        ZK_HIP(ctx, hipGetLastError());
+    }
+    ZK_TRY(nt.open_vec(dx, n, dx));
+    int zero = 0;
+    ZK_TRY(zk_fr_vec_is_zero_dev(ctx, dx, n, &zero));
+    if (!zero) ZK_FAIL(ctx, ZK_ERR_MAC, "SPDZ MAC check failed on a vector open");
+    return ZK_OK;
+}
+
+// LANES = 1: additive shares (AdditiveFieldShare / AdditiveGroupShare); LANES = 2: SPDZ (share lane, MAC lane), every open
+// MAC-checked.  z / rs / ss / tx..tz are indexed by lane.
+template <int LANES>
+int prove_shared_impl(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* const z[2], const zk_fr* const rs[2],
+                      const zk_fr* const ss[2], const void* const tx[2], const void* const ty[2], const void* const tz[2],
+                      const zk_net_vtable* net, uint8_t proof[192], uint64_t* bytes_sent) {
+    const bool dummy = !tx[0] && !ty[0] && !tz[0];
+    for (int l = 0; l < LANES; l++)
+        if (dummy ? (tx[l] || ty[l] || tz[l]) : (!tx[l] || !ty[l] || !tz[l])) ZK_FAIL(ctx, ZK_ERR_ARG, "prove_shared: give a whole Beaver triple (every lane) or none");
+    const bool leader = ctx->party_id == 0;
+    const size_t D = (size_t)1 << r->log_d;
+    SharedNet nt{ctx, net};
+    uint32_t rw[2][8], sw[2][8];
+    for (int l = 0; l < LANES; l++) { fr_abi_to_canon_words(rs[l]->l, rw[l]); fr_abi_to_canon_words(ss[l]->l, sw[l]); }
+    const SX1 delta1 = xyzz_from_affine<SH1>(aff_to_host64<G1Field>(pk->delta_g1));
+    const SX2 delta2 = xyzz_from_affine<SH2>(aff_to_host64<G2Field>(pk->delta_g2));
+    // public point x shared scalar: local host arithmetic (scale_pub_group, share/additive.rs:502-508), under the device work
+    std::future<SX1> f_r_g1[2], f_s_g1[2];
+    std::future<SX2> f_s_g2[2];
+    struct Join {                                        // the helper tasks reference this frame: never leave it before they are done
+        std::future<SX1>*a, *b; std::future<SX2>* c;
+        ~Join() { for (int l = 0; l < 2; l++) { if (a[l].valid()) a[l].wait(); if (b[l].valid()) b[l].wait(); if (c[l].valid()) c[l].wait(); } }
+    } join{f_r_g1, f_s_g1, f_s_g2};
+    for (int l = 0; l < LANES; l++) {
+        f_r_g1[l] = zk_async([&, l] { return host64_scalar_mul<SH1>(delta1, rw[l]); });
+        f_s_g1[l] = zk_async([&, l] { return host64_scalar_mul<SH1>(delta1, sw[l]); });
+        f_s_g2[l] = zk_async([&, l] { return host64_scalar_mul<SH2>(delta2, sw[l]); });
+    }
+    void *a[2], *b[2], *c[2], *sxl[2], *oyl[2], *sx, *oy, *dx;
+    char nm[32];
+    for (int l = 0; l < LANES; l++) {
+        const char* names[5] = {"shared_a%d", "shared_b%d", "shared_c%d", "shared_sxl%d", "shared_oyl%d"};
+        void** dst[5] = {&a[l], &b[l], &c[l], &sxl[l], &oyl[l]};
+        for (int k = 0; k < 5; k++) { snprintf(nm, sizeof nm, names[k], l); ZK_TRY(zk_scratch(ctx, nm, D * 32, dst[k])); }
+    }
+    ZK_TRY(zk_scratch(ctx, "shared_sx", D * 32, &sx));
+    ZK_TRY(zk_scratch(ctx, "shared_oy", D * 32, &oy));
+    ZK_TRY(zk_scratch(ctx, "shared_dx", D * 32, &dx));
+    for (int l = 0; l < LANES; l++) ZK_TRY(zk_groth16_witness_map_pre_dev(ctx, r, z[l], 1, a[l], b[l], c[l]));     // local: linear in the shares
+    ZK_TRY(zk_groth16_msms_begin_dev(ctx, pk, r, z[0]));                          // the share lane's four MSMs over z run under the opens
+    // FieldShare::batch_mul (share/field.rs:97-129): open(s + x), open(o + y), then the local tail -- per lane
+    const Fr one_ext = fp_mul<FrParams>(fp_one<FrParams>(), fp_const<FrParams>(FrParams::INT_TO_EXT));
+    for (int l = 0; l < LANES; l++) {
+        if (dummy) {                                      // DummyFieldTripleSource: the leader holds 1 (in both lanes), the rest 0 (wire/field.rs:49-63)
+            if (leader) {
+                hipLaunchKernelGGL(k_vec_add_const, zk_grid(D, 256), 256, 0, ctx->stream, (const void*)a[l], to_frk(one_ext), sxl[l], D);
+                hipLaunchKernelGGL(k_vec_add_const, zk_grid(D, 256), 256, 0, ctx->stream, (const void*)b[l], to_frk(one_ext), oyl[l], D);
+                ZK_HIP(ctx, hipGetLastError());
+            } else {
+                ZK_HIP(ctx, hipMemcpyAsync(sxl[l], a[l], D * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                ZK_HIP(ctx, hipMemcpyAsync(oyl[l], b[l], D * 32, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        } else {
+            ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_ADD, a[l], tx[l], sxl[l], D));
+            ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_ADD, b[l], ty[l], oyl[l], D));
+        }
+    }
+    if (LANES == 1) {
+        ZK_TRY(nt.open_vec(sxl[0], D, sx));
+        ZK_TRY(nt.open_vec(oyl[0], D, oy));
+    } else {
+        ZK_TRY(spdz_open_vec(nt, sxl[0], sxl[1], D, sx, dx));
+        ZK_TRY(spdz_open_vec(nt, oyl[0], oyl[1], D, oy, dx));
+    }
+    zk_g1_projective m1[2][4];
+    zk_g2_projective m2[2];
+    for (int l = 0; l < LANES; l++) {                     // the shift of sx * oy lands on the leader in BOTH lanes (mac_share = 1 there)
+        ZK_TRY(zk_beaver_combine_dev(ctx, sx, oy, tx[l], ty[l], tz[l], a[l], D));
+        ZK_TRY(zk_groth16_witness_map_post_dev(ctx, r, a[l], c[l]));                    // h shares in a[l]
+        ZK_TRY(zk_groth16_msms_dev(ctx, pk, r, z[l], a[l], m1[l], &m2[l]));            // party-local MSMs (multi_scale_pub_group; spdz.rs:482-488: twice)
+    }
+    auto pub1 = [&](const Affine<G1Field>& p) { return leader ? xyzz_from_affine<SH1>(aff_to_host64<G1Field>(p)) : xyzz_inf<SH1>(); };   // shift(): leader only
+    auto pub2 = [&](const Affine<G2Field>& p) { return leader ? xyzz_from_affine<SH2>(aff_to_host64<G2Field>(p)) : xyzz_inf<SH2>(); };
+    SX1 h_acc[2], l_acc[2], r_g1[2], g_a[2], g1_b[2];
+    SX2 g2_b[2];
+    for (int l = 0; l < LANES; l++) {
+        h_acc[l] = host64_proj_from_abi<SH1>((const uint64_t*)&m1[l][0]);
+        l_acc[l] = host64_proj_from_abi<SH1>((const uint64_t*)&m1[l][1]);
+        const SX1 a_acc = host64_proj_from_abi<SH1>((const uint64_t*)&m1[l][2]), b1_acc = host64_proj_from_abi<SH1>((const uint64_t*)&m1[l][3]);
+        const SX2 b2_acc = host64_proj_from_abi<SH2>((const uint64_t*)&m2[l]);
+        r_g1[l] = f_r_g1[l].get();
+        g_a[l] = xyzz_add<SH1>(xyzz_add<SH1>(xyzz_add<SH1>(r_g1[l], pub1(pk->a0)), a_acc), pub1(pk->alpha_g1));                 // calculate_coeff (:185-201)
+        g1_b[l] = xyzz_add<SH1>(xyzz_add<SH1>(xyzz_add<SH1>(f_s_g1[l].get(), pub1(pk->b0_g1)), b1_acc), pub1(pk->beta_g1));
+        g2_b[l] = xyzz_add<SH2>(xyzz_add<SH2>(xyzz_add<SH2>(f_s_g2[l].get(), pub2(pk->b0_g2)), b2_acc), pub2(pk->beta_g2));
+    }
+    // first exchange: open(o + y) for o = s, r (y = the leader's 1: the dummy group triple; from_add_shared: mac = share), open(s + x)
+    // for the three scaled points (x = 0) and the reveal of B.  SPDZ: a second exchange of [leader ? opened : 0] - mac, all zero.
+    constexpr size_t MW = 2 * 4 + 3 * 18 + 36;
+    const Fr y = leader ? one_ext : fp_zero<FrParams>();
+    auto pack = [&](int l, uint64_t* msg) {
+        host_store_ext<FrParams>(msg, fp_add<FrParams>(host_load_ext<FrParams>(ss[l]->l), y));
+        host_store_ext<FrParams>(msg + 4, fp_add<FrParams>(host_load_ext<FrParams>(rs[l]->l), y));
+        host64_write_projective<SH1>(xyzz_to_affine<SH1>(r_g1[l]), msg + 8);
+        host64_write_projective<SH1>(xyzz_to_affine<SH1>(g_a[l]), msg + 26);
+        host64_write_projective<SH1>(xyzz_to_affine<SH1>(g1_b[l]), msg + 44);
+        host64_write_projective<SH2>(xyzz_to_affine<SH2>(g2_b[l]), msg + 62);
+    };
+    struct Opened { Fr f[2]; SX1 g[3]; SX2 B; };
+    auto sum = [&](const std::vector<uint8_t>& all, Opened& o) -> int {
+        o.f[0] = o.f[1] = fp_zero<FrParams>();
+        o.g[0] = o.g[1] = o.g[2] = xyzz_inf<SH1>();
+        o.B = xyzz_inf<SH2>();
+        for (int p = 0; p < nt.parties(); p++) {
+            uint64_t w[MW];
+            memcpy(w, all.data() + (size_t)p * sizeof w, sizeof w);
+            for (int k = 0; k < 2; k++) {
+                if (!fr_abi_valid(w + 4 * k)) ZK_FAIL(ctx, ZK_ERR_STATE, "prove_shared: a party sent a non-canonical field element");
+                o.f[k] = fp_add<FrParams>(o.f[k], host_load_ext<FrParams>(w + 4 * k));
+            }
+            for (int k = 0; k < 3; k++) o.g[k] = xyzz_add<SH1>(o.g[k], host64_proj_from_abi<SH1>(w + 8 + 18 * k));
+            o.B = xyzz_add<SH2>(o.B, host64_proj_from_abi<SH2>(w + 62));
+        }
+        return ZK_OK;
+    };
+    uint64_t msg[MW];
+    std::vector<uint8_t> all;
+    Opened op;
+    pack(0, msg);
+    ZK_TRY(nt.gather((const uint8_t*)msg, sizeof msg, all));
+    ZK_TRY(sum(all, op));
+    if (LANES == 2) {
+        // [leader ? x : 0] - mac for every opened value, published and summed: SpdzFieldShare / SpdzGroupShare batch_open's check
+        uint64_t mm[MW], dm[MW];
+        pack(1, mm);
+        for (int k = 0; k < 2; k++)
+            host_store_ext<FrParams>(dm + 4 * k, fp_sub<FrParams>(leader ? op.f[k] : fp_zero<FrParams>(), host_load_ext<FrParams>(mm + 4 * k)));
+        for (int k = 0; k < 3; k++)
+            host64_write_projective<SH1>(xyzz_to_affine<SH1>(xyzz_add<SH1>(leader ? op.g[k] : xyzz_inf<SH1>(), xyzz_neg<SH1>(host64_proj_from_abi<SH1>(mm + 8 + 18 * k)))), dm + 8 + 18 * k);
+        host64_write_projective<SH2>(xyzz_to_affine<SH2>(xyzz_add<SH2>(leader ? op.B : xyzz_inf<SH2>(), xyzz_neg<SH2>(host64_proj_from_abi<SH2>(mm + 62)))), dm + 62);
+        Opened chk;
+        ZK_TRY(nt.gather((const uint8_t*)dm, sizeof dm, all));
+        ZK_TRY(sum(all, chk));
+        bool ok = fp_is_zero<FrParams>(chk.f[0]) && fp_is_zero<FrParams>(chk.f[1]) && xyzz_is_inf<SH2>(chk.B);
+        for (int k = 0; k < 3; k++) ok = ok && xyzz_is_inf<SH1>(chk.g[k]);
+        if (!ok) ZK_FAIL(ctx, ZK_ERR_MAC, "SPDZ MAC check failed on a fused open");
+    }
+    const Fr oy_s = op.f[0], oy_r = op.f[1];
+    const SX1 sx_rd = op.g[0], sx_a = op.g[1], sx_b = op.g[2];
+    // the local part of GroupShare::scale behind its two opens: z - sx*y (+ sx*oy on the leader), z = 0, y = [leader]; both SPDZ
+    // lanes hold the same value (key 1)
+    auto scale_finish = [&](const SX1& sxp, const Fr& oyv) {
+        if (!leader) return xyzz_inf<SH1>();
+        uint64_t l4[4];
+        uint32_t kw[8];
+        host_store_ext<FrParams>(l4, oyv);
+        fr_abi_to_canon_words(l4, kw);
+        return xyzz_add<SH1>(host64_scalar_mul<SH1>(sxp, kw), xyzz_neg<SH1>(sxp));
+    };
+    auto p0 = zk_async([&] { return scale_finish(sx_rd, oy_s); });       // r s delta            (:115)
+    auto p1 = zk_async([&] { return scale_finish(sx_a, oy_s); });        // s A                  (:140)
+    const SX1 part2 = scale_finish(sx_b, oy_r);                          // r B1                 (:161)
+    SX1 t = xyzz_add<SH1>(p1.get(), part2);
+    t = xyzz_add<SH1>(t, xyzz_neg<SH1>(p0.get()));
+    SX1 g_c[2];
+    for (int l = 0; l < LANES; l++) g_c[l] = xyzz_add<SH1>(xyzz_add<SH1>(t, l_acc[l]), h_acc[l]);      // :169-174
+    uint64_t cmsg[18];
+    host64_write_projective<SH1>(xyzz_to_affine<SH1>(g_c[0]), cmsg);
+    ZK_TRY(nt.gather((const uint8_t*)cmsg, sizeof cmsg, all));          // Proof::reveal of C (A and B were opened above)
+    auto sum_g1 = [&](const std::vector<uint8_t>& v) {
+        SX1 acc = xyzz_inf<SH1>();
+        for (int p = 0; p < nt.parties(); p++) {
+            uint64_t w[18];
+            memcpy(w, v.data() + (size_t)p * sizeof w, sizeof w);
+            acc = xyzz_add<SH1>(acc, host64_proj_from_abi<SH1>(w));
+        }
+        return acc;
+    };
+    const SX1 C = sum_g1(all);
+    if (LANES == 2) {
+        host64_write_projective<SH1>(xyzz_to_affine<SH1>(xyzz_add<SH1>(leader ? C : xyzz_inf<SH1>(), xyzz_neg<SH1>(g_c[1]))), cmsg);
+        ZK_TRY(nt.gather((const uint8_t*)cmsg, sizeof cmsg, all));
+        if (!xyzz_is_inf<SH1>(sum_g1(all))) ZK_FAIL(ctx, ZK_ERR_MAC, "SPDZ MAC check failed on the reveal of C");
+    }
+    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<SH1>(sx_a)), proof);
+    g2_serialize(aff_from_host64<G2Field>(xyzz_to_affine<SH2>(op.B)), proof + 48);
+    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<SH1>(C)), proof + 144);
+    if (bytes_sent) *bytes_sent = nt.bytes;
+    return ZK_OK;
+}
+
+}  // namespace
+
 extern "C" int zk_groth16_prove_shared(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z_share, const zk_fr* r_share,
                                        const zk_fr* s_share, const void* tx, const void* ty, const void* tz, const zk_net_vtable* net,
                                        uint8_t proof[192], uint64_t* bytes_sent) {
     ZK_API_BEGIN(ctx)
     if (!ctx || !pk || !r || !z_share || !r_share || !s_share || !proof) return ZK_ERR_ARG;
-    const bool dummy = !tx && !ty && !tz;
-    if (!dummy && (!tx || !ty || !tz)) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_groth16_prove_shared: give all of tx, ty, tz or none");
-    using H1 = Fq64Field;
-    using H2 = Fq264Field;
-    using X1 = XYZZ<H1>;
-    using X2 = XYZZ<H2>;
-    const bool leader = ctx->party_id == 0;
-    const size_t D = (size_t)1 << r->log_d;
-    SharedNet nt{ctx, net};
-    uint32_t rw[8], sw[8];
-    fr_abi_to_canon_words(r_share->l, rw);
-    fr_abi_to_canon_words(s_share->l, sw);
-    const X1 delta1 = xyzz_from_affine<H1>(aff_to_host64<G1Field>(pk->delta_g1));
-    const X2 delta2 = xyzz_from_affine<H2>(aff_to_host64<G2Field>(pk->delta_g2));
-    // public point x shared scalar: local host arithmetic (scale_pub_group, share/additive.rs:502-508), under the device work
-    auto f_r_g1 = zk_async([&] { return host64_scalar_mul<H1>(delta1, rw); });
-    auto f_s_g1 = zk_async([&] { return host64_scalar_mul<H1>(delta1, sw); });
-    auto f_s_g2 = zk_async([&] { return host64_scalar_mul<H2>(delta2, sw); });
-    struct Join {                                        // the helper tasks reference this frame: never leave it before they are done
-        std::future<X1>&a, &b; std::future<X2>& c;
-        ~Join() { if (a.valid()) a.wait(); if (b.valid()) b.wait(); if (c.valid()) c.wait(); }
-    } join{f_r_g1, f_s_g1, f_s_g2};
-    void *a, *b, *c, *sx, *oy;
-    ZK_TRY(zk_scratch(ctx, "shared_a", D * 32, &a));
-    ZK_TRY(zk_scratch(ctx, "shared_b", D * 32, &b));
-    ZK_TRY(zk_scratch(ctx, "shared_c", D * 32, &c));
-    ZK_TRY(zk_scratch(ctx, "shared_sx", D * 32, &sx));
-    ZK_TRY(zk_scratch(ctx, "shared_oy", D * 32, &oy));
-    ZK_TRY(zk_groth16_witness_map_pre_dev(ctx, r, z_share, 1, a, b, c));           // local: linear in the shares
-    ZK_TRY(zk_groth16_msms_begin_dev(ctx, pk, r, z_share));                       // the four MSMs over z run under the opens
-    // FieldShare::batch_mul (share/field.rs:97-129): open(s + x), open(o + y), then the local tail
-    if (dummy) {
-        if (leader) {                                     // DummyFieldTripleSource: the leader holds 1, the rest 0 (wire/field.rs:49-63)
-            Fr one_ext = fp_mul<FrParams>(fp_one<FrParams>(), fp_const<FrParams>(FrParams::INT_TO_EXT));
-            hipLaunchKernelGGL(k_vec_add_const, zk_grid(D, 256), 256, 0, ctx->stream, (const void*)a, to_frk(one_ext), sx, D);
-            hipLaunchKernelGGL(k_vec_add_const, zk_grid(D, 256), 256, 0, ctx->stream, (const void*)b, to_frk(one_ext), oy, D);
-            ZK_HIP(ctx, hipGetLastError());
-        } else {
-            ZK_HIP(ctx, hipMemcpyAsync(sx, a, D * 32, hipMemcpyDeviceToDevice, ctx->stream));
-            ZK_HIP(ctx, hipMemcpyAsync(oy, b, D * 32, hipMemcpyDeviceToDevice, ctx->stream));
-        }
-    } else {
-        ZK_TRY(zk_vec_op_launch(ctx, 1, a, tx, sx, D));
-        ZK_TRY(zk_vec_op_launch(ctx, 1, b, ty, oy, D));
-    }
-    ZK_TRY(nt.open_vec(sx, D, sx));
-    ZK_TRY(nt.open_vec(oy, D, oy));
-    ZK_TRY(zk_beaver_combine_dev(ctx, sx, oy, tx, ty, tz, a, D));
-    ZK_TRY(zk_groth16_witness_map_post_dev(ctx, r, a, c));                        // h shares in `a`
-    zk_g1_projective m1[4];
-    zk_g2_projective m2;
-    ZK_TRY(zk_groth16_msms_dev(ctx, pk, r, z_share, a, m1, &m2));                 // party-local MSMs (multi_scale_pub_group)
-    const X1 h_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[0]), l_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[1]);
-    const X1 a_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[2]), b1_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[3]);
-    const X2 b2_acc = host64_proj_from_abi<H2>((const uint64_t*)&m2);
-    auto pub1 = [&](const Affine<G1Field>& p) { return leader ? xyzz_from_affine<H1>(aff_to_host64<G1Field>(p)) : xyzz_inf<H1>(); };   // shift(): leader only
-    auto pub2 = [&](const Affine<G2Field>& p) { return leader ? xyzz_from_affine<H2>(aff_to_host64<G2Field>(p)) : xyzz_inf<H2>(); };
-    const X1 r_g1 = f_r_g1.get();
-    const X1 g_a = xyzz_add<H1>(xyzz_add<H1>(xyzz_add<H1>(r_g1, pub1(pk->a0)), a_acc), pub1(pk->alpha_g1));                 // calculate_coeff (:185-201)
-    const X1 g1_b = xyzz_add<H1>(xyzz_add<H1>(xyzz_add<H1>(f_s_g1.get(), pub1(pk->b0_g1)), b1_acc), pub1(pk->beta_g1));
-    const X2 g2_b = xyzz_add<H2>(xyzz_add<H2>(xyzz_add<H2>(f_s_g2.get(), pub2(pk->b0_g2)), b2_acc), pub2(pk->beta_g2));
-    // first exchange: open(o + y) for o = s, r (y = the leader's 1: the dummy group triple), open(s + x) for the three scaled
-    // points (x = 0) and the reveal of B
-    const Fr y = leader ? fp_mul<FrParams>(fp_one<FrParams>(), fp_const<FrParams>(FrParams::INT_TO_EXT)) : fp_zero<FrParams>();
-    uint64_t msg[2 * 4 + 3 * 18 + 36];
-    host_store_ext<FrParams>(msg, fp_add<FrParams>(host_load_ext<FrParams>(s_share->l), y));
-    host_store_ext<FrParams>(msg + 4, fp_add<FrParams>(host_load_ext<FrParams>(r_share->l), y));
-    host64_write_projective<H1>(xyzz_to_affine<H1>(r_g1), msg + 8);
-    host64_write_projective<H1>(xyzz_to_affine<H1>(g_a), msg + 26);
-    host64_write_projective<H1>(xyzz_to_affine<H1>(g1_b), msg + 44);
-    host64_write_projective<H2>(xyzz_to_affine<H2>(g2_b), msg + 62);
-    std::vector<uint8_t> all;
-    ZK_TRY(nt.gather((const uint8_t*)msg, sizeof msg, all));
-    Fr oy_s = fp_zero<FrParams>(), oy_r = fp_zero<FrParams>();
-    X1 sx_rd = xyzz_inf<H1>(), sx_a = xyzz_inf<H1>(), sx_b = xyzz_inf<H1>();
-    X2 B = xyzz_inf<H2>();
-    for (int p = 0; p < nt.parties(); p++) {
-        uint64_t w[sizeof msg / 8];
-        memcpy(w, all.data() + (size_t)p * sizeof msg, sizeof msg);
-        for (int k = 0; k < 2; k++)
-            if (!fr_abi_valid(w + 4 * k)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_groth16_prove_shared: a party sent a non-canonical field element");
-        oy_s = fp_add<FrParams>(oy_s, host_load_ext<FrParams>(w));
-        oy_r = fp_add<FrParams>(oy_r, host_load_ext<FrParams>(w + 4));
-        sx_rd = xyzz_add<H1>(sx_rd, host64_proj_from_abi<H1>(w + 8));
-        sx_a = xyzz_add<H1>(sx_a, host64_proj_from_abi<H1>(w + 26));
-        sx_b = xyzz_add<H1>(sx_b, host64_proj_from_abi<H1>(w + 44));
-        B = xyzz_add<H2>(B, host64_proj_from_abi<H2>(w + 62));
-    }
-    // the local part of GroupShare::scale behind its two opens: z - sx*y (+ sx*oy on the leader), z = 0, y = [leader]
-    auto scale_finish = [&](const X1& sxp, const Fr& oyv) {
-        if (!leader) return xyzz_inf<H1>();
-        uint64_t l4[4];
-        uint32_t kw[8];
-        host_store_ext<FrParams>(l4, oyv);
-        fr_abi_to_canon_words(l4, kw);
-        return xyzz_add<H1>(host64_scalar_mul<H1>(sxp, kw), xyzz_neg<H1>(sxp));
-    };
-    auto p0 = zk_async([&] { return scale_finish(sx_rd, oy_s); });       // r s delta            (:115)
-    auto p1 = zk_async([&] { return scale_finish(sx_a, oy_s); });        // s A                  (:140)
-    const X1 part2 = scale_finish(sx_b, oy_r);                           // r B1                 (:161)
-    X1 g_c = xyzz_add<H1>(p1.get(), part2);
-    g_c = xyzz_add<H1>(g_c, xyzz_neg<H1>(p0.get()));
-    g_c = xyzz_add<H1>(xyzz_add<H1>(g_c, l_acc), h_acc);                 // :169-174
-    uint64_t cmsg[18];
-    host64_write_projective<H1>(xyzz_to_affine<H1>(g_c), cmsg);
-    ZK_TRY(nt.gather((const uint8_t*)cmsg, sizeof cmsg, all));          // Proof::reveal of C (A and B were opened above)
-    X1 C = xyzz_inf<H1>();
-    for (int p = 0; p < nt.parties(); p++) {
-        uint64_t w[18];
-        memcpy(w, all.data() + (size_t)p * sizeof cmsg, sizeof cmsg);
-        C = xyzz_add<H1>(C, host64_proj_from_abi<H1>(w));
-    }
-    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<H1>(sx_a)), proof);
-    g2_serialize(aff_from_host64<G2Field>(xyzz_to_affine<H2>(B)), proof + 48);
-    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<H1>(C)), proof + 144);
-    if (bytes_sent) *bytes_sent = nt.bytes;
-    return ZK_OK;
+    const void* z[2] = {z_share, nullptr};
+    const zk_fr *rs[2] = {r_share, nullptr}, *ss[2] = {s_share, nullptr};
+    const void *txs[2] = {tx, nullptr}, *tys[2] = {ty, nullptr}, *tzs[2] = {tz, nullptr};
+    return prove_shared_impl<1>(ctx, pk, r, z, rs, ss, txs, tys, tzs, net, proof, bytes_sent);
+    ZK_API_END
+}
+
+extern "C" int zk_groth16_prove_shared_spdz(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* const z_lanes[2],
+                                            const zk_fr r_lanes[2], const zk_fr s_lanes[2], const void* const tx_lanes[2],
+                                            const void* const ty_lanes[2], const void* const tz_lanes[2], const zk_net_vtable* net,
+                                            uint8_t proof[192], uint64_t* bytes_sent) {
+    ZK_API_BEGIN(ctx)
+    if (!ctx || !pk || !r || !z_lanes || !z_lanes[0] || !z_lanes[1] || !r_lanes || !s_lanes || !proof) return ZK_ERR_ARG;
+    const zk_fr *rs[2] = {&r_lanes[0], &r_lanes[1]}, *ss[2] = {&s_lanes[0], &s_lanes[1]};
+    const void* none[2] = {nullptr, nullptr};
+    return prove_shared_impl<2>(ctx, pk, r, z_lanes, rs, ss, tx_lanes ? tx_lanes : none, ty_lanes ? ty_lanes : none,
+                                tz_lanes ? tz_lanes : none, net, proof, bytes_sent);
     ZK_API_END
 }
 

@@ -562,14 +562,11 @@ class Party:
     def reveal_g2(self, p): return self._open_g(p, self.be.g2_add)
 
     # ---- the collaborative prover ----
-    def create_proof_shared_native(self, pk, r1cs, z_share, r_share, s_share, triple=None) -> bytes:
-        """create_proof over additive shares as ONE library call (zk_groth16_prove_shared): what a Rust host would do.  The
-        library calls back into this party's transport for the two small exchanges (MpcNet::broadcast_bytes) and for the two
-        vector opens; everything else -- witness map halves, MSMs, Beaver tail, group algebra on shares -- stays inside.
-        Same opened values and the same 192 bytes as create_proof_shared(fused=True), which remains the second implementation
-        the tests compare it with."""
+    def _net_vtable(self):
+        """zk_net_vtable over this party's transport: (struct, errors, keep-alive).  all_gather_bytes = MpcNet::broadcast_bytes
+        (mpc-net/src/lib.rs:60-64), open_sum_fr_dev = the vector open of this backend."""
         import ctypes as C
-        be, net, ctx = self.be, self.net, self.ctx
+        be, net = self.be, self.net
         AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8))
         OV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -595,14 +592,25 @@ class Party:
             except Exception as e:
                 errors.append(e)
                 return -1
-        vt = NetVtable(None, AG(all_gather), OV(open_vec))
+        cbs = (AG(all_gather), OV(open_vec))
+        return NetVtable(None, cbs[0], cbs[1]), errors, cbs
+
+    def create_proof_shared_native(self, pk, r1cs, z_share, r_share, s_share, triple=None) -> bytes:
+        """create_proof over additive shares as ONE library call (zk_groth16_prove_shared): what a Rust host would do.  The
+        library calls back into this party's transport for the two small exchanges (MpcNet::broadcast_bytes) and for the two
+        vector opens; everything else -- witness map halves, MSMs, Beaver tail, group algebra on shares -- stays inside.
+        Same opened values and the same 192 bytes as create_proof_shared(fused=True), which remains the second implementation
+        the tests compare it with."""
+        import ctypes as C
+        ctx = self.ctx
+        vt, errors, _keep = self._net_vtable()
         from .api import _fr_struct
         r, s_ = _fr_struct(r_share), _fr_struct(s_share)
         out = np.zeros(192, dtype=np.uint8)
         sent = C.c_uint64(0)
         t = [C.c_void_p(int(x)) for x in triple] if triple is not None else [None, None, None]
         rc = ctx.lib.zk_groth16_prove_shared(ctx.h, pk.h, r1cs.h, C.c_void_p(int(z_share)), C.byref(r), C.byref(s_), t[0], t[1], t[2],
-                                             C.byref(vt) if net.n > 1 else None, out.ctypes.data_as(C.c_void_p), C.byref(sent))
+                                             C.byref(vt) if self.net.n > 1 else None, out.ctypes.data_as(C.c_void_p), C.byref(sent))
         if errors:
             raise errors[0]
         ctx._ck(rc)
@@ -900,6 +908,31 @@ class SpdzParty(Party):
             w.append(DM.batch_open(ctx, powers_g, [(at_beta, ch["beta"])] + ([(at_gamma, ch["gamma"])] if lane == 0 else []), ch["xi"]))
         return {"commitments": comms, "evaluations": evals, "w_beta": self.spdz_open_g1((w[0][0], w[1][0])), "w_gamma": w[0][1],
                 "challenges": ch}
+
+    def create_proof_shared_spdz_native(self, pk, r1cs, z_share, r_share, s_share, triple=None) -> bytes:
+        """create_proof over SPDZ shares as ONE library call (zk_groth16_prove_shared_spdz); arguments as create_proof_shared_spdz.
+        A failed MAC check comes back as ZK_ERR_MAC and is raised as MacCheckError."""
+        import ctypes as C
+        from . import _lib
+        ctx = self.ctx
+        vt, errors, _keep = self._net_vtable()
+        P2 = C.c_void_p * 2
+        FR2 = _lib.Fr * 2
+        lanes = lambda v: P2(int(v[0]), int(v[1]))
+        frs = lambda v: FR2(*[_lib.Fr((C.c_uint64 * 4)(*[int(w) for w in np.asarray(x, dtype=np.uint64)])) for x in v])
+        zl, rl, sl = lanes(z_share), frs(r_share), frs(s_share)
+        t = [lanes((triple[k][0], triple[k][1])) for k in range(3)] if triple is not None else [None, None, None]
+        out = np.zeros(192, dtype=np.uint8)
+        sent = C.c_uint64(0)
+        rc = ctx.lib.zk_groth16_prove_shared_spdz(ctx.h, pk.h, r1cs.h, zl, rl, sl, t[0], t[1], t[2],
+                                                  C.byref(vt) if self.net.n > 1 else None, out.ctypes.data_as(C.c_void_p), C.byref(sent))
+        if errors:
+            raise errors[0]
+        if rc == -5:
+            raise MacCheckError((ctx.lib.zk_last_error(ctx.h) or b"").decode())
+        ctx._ck(rc)
+        self.bytes_sent += int(sent.value)
+        return out.tobytes()
 
     def create_proof_shared_spdz(self, pk, r1cs, z_share, r_share, s_share, triple=None, fused=True) -> bytes:
         """create_proof with E = MpcPairingEngine<_, SpdzPairingShare> (the `malicious` feature).
