@@ -131,6 +131,17 @@ __global__ void __launch_bounds__(256) k_dbl_c(const uint32_t* in_aff, uint32_t*
     }
 }
 
+// packed points (2 * WORDS words each) -> one point per `stride` words; the padding words are never read
+template <class F>
+__global__ void __launch_bounds__(256) k_repack(const uint32_t* in, uint32_t* out, size_t n, uint32_t stride) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4* s = reinterpret_cast<const uint4*>(in + i * (2 * F::WORDS));
+        uint4* d = reinterpret_cast<uint4*>(out + i * stride);
+#pragma unroll
+        for (int k = 0; k < 2 * F::WORDS / 4; k++) d[k] = s[k];
+    }
+}
+
 template <class F>
 int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W) {
     const size_t n = b->n, PW = 2 * F::WORDS;
@@ -156,6 +167,25 @@ int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W) {
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     b->c_pre = c;
     b->W_pre = W;
+    b->pre_stride = 0;
+    // G1: a 96-byte point in a packed table straddles two 128-byte lines half of the time and the accumulate kernel's gather
+    // then fetches 2.6x the bytes it uses (profiles/r2_pmc_traffic.json: 3.45 GB per launch for 1.31 GB of points).  The window
+    // multiples -- read once per digit, at random -- are re-laid one point per line: a third more memory, half the traffic.
+    // (ZK_PRE_PAD=0 keeps the packed table.)  G2's 192-byte points take two lines either way.
+    static const bool pad = !(getenv("ZK_PRE_PAD") && atoi(getenv("ZK_PRE_PAD")) == 0);
+    if (pad && F::WORDS == 12 && (size_t)W * n * 32 * 4 <= mem_free / 3) {
+        uint32_t* padded = nullptr;
+        if (hipMalloc((void**)&padded, (size_t)W * n * 32 * 4) == hipSuccess) {
+            hipLaunchKernelGGL(k_repack<F>, zk_grid((size_t)W * n, 256), 256, 0, ctx->stream, (const uint32_t*)b->pre, padded, (size_t)W * n, 32u);
+            ZK_HIP(ctx, hipGetLastError());
+            ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(b->pre);
+            b->pre = padded;
+            b->pre_stride = 32;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     return ZK_OK;
 }
 

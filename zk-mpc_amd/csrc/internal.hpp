@@ -27,6 +27,7 @@ struct zk_bases {
     // With them every window of an MSM drops into ONE bucket set (fixed_base.hip: zk_bases_precompute).
     uint32_t* pre = nullptr;
     uint32_t c_pre = 0, W_pre = 0;
+    uint32_t pre_stride = 0;   // 32-bit words per point in `pre` (0: packed, 2 * WORDS).  G1: 32 = one 128-byte line per 96-byte point
 };
 extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b);   // no-op for tables under 4096 points
 int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b);             // only when ZK_PRECOMP=1 (off by default: see fixed_base.hip)
@@ -58,6 +59,7 @@ struct ZkMsmJob {
     uint32_t Wb = 0;                  // bucket sets: W, or 1 when the bases carry precomputed window multiples
     uint32_t log_nb = 0, nout = 0;    // reduce phase (msm_reduce.cuh): a bucket set of 2^log_nb buckets leaves nout = log_nb + 1 points for the host
     uint32_t n_tab = 0, tab_off = 0;  // merged mode: table stride and offset of this MSM's first base
+    uint32_t stride = 0;              // 32-bit words between consecutive points of bases_dev (the packed 2 * WORDS, or zk_bases::pre_stride)
     const uint32_t* bases_dev = nullptr;
     const void* scalars = nullptr;
     hipStream_t stream = nullptr;     // the stream the reduce phase (and the copy to hw) is on

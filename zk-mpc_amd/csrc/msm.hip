@@ -621,7 +621,9 @@ k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t
 template <class F>
 __global__ void __launch_bounds__(256, (F::WORDS == 12 ? ZK_ACCUM_WAVES_G1 : ZK_ACCUM_WAVES_G2))
 k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
-        const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums) {
+        const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums, uint32_t stride) {
+    // stride: words between consecutive points of `bases` (2 * WORDS packed; 32 for a G1 table of window multiples: one point per line)
+    auto point = [&](uint32_t e) { return aff_load16<F>(bases + (size_t)(e & 0x7fffffffu) * stride, 0); };
     const uint32_t S = ctr[2];
     const uint32_t G = gridDim.x * blockDim.x;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < S; t += G) {
@@ -632,16 +634,16 @@ k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
 #ifdef ZK_ACCUM_NO_PREFETCH
             for (uint32_t k = 0; k < d.len; k++) {
                 const uint32_t ce = srt[k];
-                Affine<F> cur = aff_load16<F>(bases, ce & 0x7fffffffu);
+                Affine<F> cur = point(ce);
 #else
             uint32_t e = srt[0];
-            Affine<F> p = aff_load16<F>(bases, e & 0x7fffffffu);
+            Affine<F> p = point(e);
             for (uint32_t k = 0; k < d.len; k++) {
                 Affine<F> cur = p;
                 const uint32_t ce = e;
                 if (k + 1 < d.len) {
                     e = srt[k + 1];
-                    p = aff_load16<F>(bases, e & 0x7fffffffu);
+                    p = point(e);
                 }
 #endif
                 // lazy domain (fp29.cuh / ec.cuh::xyzz_madd_lazy): the accumulator is a representative in [0, ~5 p], a negative
@@ -800,9 +802,11 @@ int msm_prepare_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base
         job->bases_dev = bases->pre;
         job->n_tab = (uint32_t)bases->n;
         job->tab_off = (uint32_t)base_offset;
+        job->stride = bases->pre_stride ? bases->pre_stride : 2 * F::WORDS;
     } else {
         job->Wb = p.W;
         job->bases_dev = bases->dev + base_offset * (2 * F::WORDS);
+        job->stride = 2 * F::WORDS;
     }
     // Segment length: long enough that a typical bucket (mean n/NB points) is one segment, short enough that
     // (a) there are at least as many segments as resident lanes (2 waves per SIMD) and (b) the longest serial
@@ -996,7 +1000,7 @@ int msm_enqueue_accum_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     // G2 runs on lane pairs (msm_g2pair.hip): the one-lane-per-addition form needs the whole register file and is slower
     if constexpr (F::WORDS == 12)
         hipLaunchKernelGGL(k_accum<F>, accum_blocks, 256, 0, st, job->bases_dev, job->sorted,
-                           (const SegDesc*)job->desc, job->order, job->ctr, b.sums);
+                           (const SegDesc*)job->desc, job->order, job->ctr, b.sums, job->stride);
     else
         zk_launch_accum_g2pair(st, job->max_segs, job->bases_dev, job->sorted, job->desc, job->order, job->ctr, b.sums);
     ZK_HIP(ctx, hipGetLastError());
