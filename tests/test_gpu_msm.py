@@ -167,6 +167,37 @@ def test_msm_large_discrete_log_check(ctx, log_n):
         prod.free()
 
 
+@pytest.mark.parametrize("group,logs", [(1, range(3, 20)), (2, range(3, 17))])
+def test_msm_every_window_width(ctx, group, logs):
+    """Every shape of the bucket grid of msm_reduce.cuh: n = 2^k - 1 walks the plan through c = 4 ... 16 (bucket sets of
+    2^3 ... 2^15: row / column splits with rl = cl and rl = cl + 1, one to 64 windows, K x TW partial counts from 1 to 4) and,
+    for tables that carry window multiples, through merged bucket sets up to 2^18; checked by the discrete-log identity."""
+    rs = np.random.RandomState(4242 + group)
+    top = 1 << (max(logs))
+    km = rs.randint(0, 1 << 62, size=(top, 4), dtype=np.uint64); km[:, 3] &= np.uint64((1 << 60) - 1)
+    sm = rs.randint(0, 1 << 62, size=(top, 4), dtype=np.uint64); sm[:, 3] &= np.uint64((1 << 60) - 1)
+    dk, ds = ctx.upload(km), ctx.upload(sm)
+    prod = ctx.alloc(top * 32)
+    ctx.fr_vec_op_dev(0, dk.ptr, ds.ptr, prod.ptr, top)
+    pr = ctx.download(prod, (top, 4))
+    one = cv.fr_to_mont([1])[0]
+    bases = ctx.fixed_base(dk.ptr, top, group, one)
+    to_aff = cv.g1_projective_to_affine if group == 1 else cv.g2_projective_to_affine
+    mul = (lambda e: O.g1_mul(O.G1_GEN, e)) if group == 1 else (lambda e: O.g2_mul(O.G2_GEN, e))
+
+    def want(m):
+        tot = sum(int(pr[:m, j].astype(object).sum()) << (64 * j) for j in range(4))
+        return mul(cv.fr_from_mont(cv.fr_raw([tot % O.R_MOD]))[0])
+    for k in logs:
+        m = (1 << k) - 1
+        assert to_aff(ctx.msm_dev(bases, 0, ds.ptr, m)) == want(m), (group, k)
+    bases.precompute()                                   # one merged bucket set from here on (n >= 4096)
+    for k in [x for x in logs if x >= 12]:
+        m = (1 << k) - 1
+        assert to_aff(ctx.msm_dev(bases, 0, ds.ptr, m)) == want(m), (group, k, "window multiples")
+    bases.free(); prod.free(); dk.free(); ds.free()
+
+
 @pytest.mark.parametrize("group,n,part", [(1, 5000, 0), (1, 1 << 16, 0), (2, 6000, 0), (1, 5000, 1), (1, (1 << 16) + 77, 1)])
 def test_msm_precomputed_window_multiples(ctx, group, n, part, monkeypatch):
     """Resident bases with precomputed 2^(c w) multiples (one bucket set for all windows): random scalars,
