@@ -521,6 +521,19 @@ class Party:
             return out
         return self._early(finish) if lazy else finish()
 
+    def close(self):
+        """Release the host helper threads (the pool of _early)."""
+        pool = getattr(self, "_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=True)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _early(self, fn, *args):
         """fn(*args) on a host thread: a future.  For host-side group algebra that need not wait for the device."""
         pool = getattr(self, "_pool", None)
