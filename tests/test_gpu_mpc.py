@@ -675,9 +675,28 @@ def _marlin_proc_worker(rank, world, port, spdz, q):
             proof = party.marlin_prove_full_spdz(keys, (up(zs[rank]), up(zm[rank])), Rng.from_seed(seed, 20))
         else:
             proof = party.marlin_prove_full(keys, up(zs[rank]), Rng.from_seed(seed, 20))
+        # the one-call collaborative Groth16 provers over the same transport: the library calls back into gloo for its two small
+        # exchanges and (staged through host memory) for the vector opens
+        gr = O.Prng(9900 + world)
+        g_r1cs, g_z = O.mul_chain_r1cs(50, gr.fr(), gr.fr())
+        td = O.Trapdoor(gr.fr(), gr.fr(), gr.fr(), gr.fr(), gr.fr(), gr.fr(), gr.fr())
+        rr, ss = gr.fr(), gr.fr()
+        gzs = additive_shares(g_z, world, gr, public_prefix=2)
+        gzm = additive_shares(g_z, world, gr, public_prefix=2)
+        rsh, ssh = O.additive_share(rr, world, gr), O.additive_share(ss, world, gr)
+        rm, sm = O.additive_share(rr, world, gr), O.additive_share(ss, world, gr)
+        tdm = td_mont(td)
+        dr = ctx.r1cs_mul_chain(50)
+        pk = ctx.groth16_setup(dr, *[tdm[i] for i in range(7)])
+        dzs_, dzm_ = up(gzs[rank]), up(gzm[rank])          # (kept alive: a DevBuf frees its memory when it is collected)
+        if spdz:
+            g16 = party.create_proof_shared_spdz_native(pk, dr, (dzs_.ptr, dzm_.ptr), (mont1(rsh[rank]), mont1(rm[rank])),
+                                                        (mont1(ssh[rank]), mont1(sm[rank])))
+        else:
+            g16 = party.create_proof_shared_native(pk, dr, dzs_.ptr, mont1(rsh[rank]), mont1(ssh[rank]))
         q.put((rank, proof.serialize(ctx), proof.evaluations,
                [[(cc.comm_aff, cc.shifted_aff, cc.shifted is not None) for cc in rnd] for rnd in proof.commitments],
-               [(cv.g1_projective_to_affine(w), rv) for w, rv in proof.pc_proof], srs.max_degree, int(party.bytes_sent)))
+               [(cv.g1_projective_to_affine(w), rv) for w, rv in proof.pc_proof], srs.max_degree, int(party.bytes_sent), g16))
     except Exception as e:  # pragma: no cover
         import traceback
         q.put((rank, "ERROR %s\n%s" % (e, traceback.format_exc())))
@@ -721,3 +740,10 @@ def test_collaborative_marlin_across_os_processes(world, spdz):
     assert MF.verify(okeys, pub, as_oracle)
     assert not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], as_oracle)
     assert all(r[6] > 0 for r in res)
+    # the Groth16 proof of zk_groth16_prove_shared[_spdz] across the same processes: the local proof on the summed inputs
+    gr = O.Prng(9900 + world)
+    g_r1cs, g_z = O.mul_chain_r1cs(50, gr.fr(), gr.fr())
+    td = O.Trapdoor(gr.fr(), gr.fr(), gr.fr(), gr.fr(), gr.fr(), gr.fr(), gr.fr())
+    rr, ss = gr.fr(), gr.fr()
+    want = O.proof_serialize(*O.predict_proof(g_r1cs, O.ProvingKeyScalars(g_r1cs, td), g_z, rr, ss))
+    assert all(r[7] == want for r in res)
