@@ -783,6 +783,9 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
     static const bool in_order = getenv("ZK_BATCH_IN_ORDER") != nullptr;      // experiment: submission order
     if (!in_order) std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
     std::vector<ZkMsmJob> jobs(n_jobs);
+    std::vector<int> owner(n_jobs), sharer(n_jobs, -1);          // whose sort a job uses (itself unless it borrows), and who borrows a job's sort
+    for (size_t k = 0; k < n_jobs; k++) owner[k] = (int)k;
+    static const bool share_sorts = !(getenv("ZK_BATCH_SHARE_SORT") && atoi(getenv("ZK_BATCH_SHARE_SORT")) == 0);
     int rc = ZK_OK;
     static const bool red_on_main = !(getenv("ZK_BATCH_REDUCE_STREAM") && !strcmp(getenv("ZK_BATCH_REDUCE_STREAM"), "sort"));
     for (size_t k = 0; k < n_jobs && rc == ZK_OK; k++) {
@@ -792,7 +795,20 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
         // the slot's previous user must be through its reduce chain (k_fold reads the sort scratch, the chain the sums) before
         // this job's sort rewrites the slot; that job's accumulate kernel is then done as well
         if (rc == ZK_OK && k >= SLOTS && jobs[k - SLOTS].reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(s_sort, jobs[k - SLOTS].reduce_done, 0));
-        if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[k], s_sort, nullptr);
+        // ... and so must a job that borrowed that user's sort (its accumulate kernel reads the sorted entries, its k_fold the
+        // segment tables of the slot)
+        if (rc == ZK_OK && k >= SLOTS && sharer[k - SLOTS] >= 0 && jobs[sharer[k - SLOTS]].reduce_done)
+            ZK_HIP(ctx, hipStreamWaitEvent(s_sort, jobs[sharer[k - SLOTS]].reduce_done, 0));
+        // the same scalar vector as the previous job of the batch (a degree-bounded oracle's commitment and its shifted copy):
+        // one sort for both
+        const ZkMsmJob* share = nullptr;
+        if (rc == ZK_OK && k > 0 && share_sorts && scalars_dev[j] == scalars_dev[perm[k - 1]] && lens[j] == lens[perm[k - 1]] &&
+            owner[k - 1] == (int)(k - 1)) {
+            share = &jobs[k - 1];
+            owner[k] = (int)(k - 1);
+            sharer[k - 1] = (int)k;
+        }
+        if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[k], s_sort, share);
         if (rc == ZK_OK) rc = zk_msm_enqueue_accum(ctx, &jobs[k], s_acc);
         // reduces on the context stream (idle here), not behind the sorts: on the sort stream the sort of job k+2 queued
         // behind the reduce of job k, i.e. behind the accumulate of job k, and the accumulate stream then waited for it

@@ -859,9 +859,14 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     if (job->n == 0) return ZK_OK;
     const bool g1 = F::WORDS == 12;
     const size_t n = job->n;
+    const bool share_merged = share && share->Wb == 1 && share->W > 1;       // entries are table indices w * n_tab + tab_off + i
     if (share && share->n == n && share->scalars == job->scalars && share->sorted && share->Wb == job->Wb &&
-        share->n_tab == job->n_tab && share->tab_off == job->tab_off && share->c == job->c) {
-        // same scalar vector as an earlier job (A, B-in-G1 and B-in-G2 all use z[1..]): reuse its sort
+        share->n_tab == job->n_tab && (share->tab_off == job->tab_off || share_merged) && share->c == job->c) {
+        // same scalar vector as an earlier job (A, B-in-G1 and B-in-G2 all use z[1..]): reuse its sort.  A different offset into a
+        // table of window multiples (a polynomial's commitment over the shifted powers: marlin_pc/mod.rs:172-243) folds into
+        // the base pointer -- the entries index the table linearly
+        if (share->tab_off != job->tab_off)
+            job->bases_dev = job->bases_dev + ((ptrdiff_t)job->tab_off - (ptrdiff_t)share->tab_off) * (ptrdiff_t)job->stride;
         job->sorted = share->sorted; job->desc = share->desc; job->order = share->order; job->ctr = share->ctr; job->heavy = share->heavy;
         ZK_HIP(ctx, hipEventCreateWithFlags(&job->sort_done, hipEventDisableTiming));
         ZK_HIP(ctx, hipStreamWaitEvent(st, share->sort_done, 0));
