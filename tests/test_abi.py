@@ -481,6 +481,22 @@ def test_fr_lazy_primitives_against_big_integers():
         assert _val(r) % RR == a * w * inv % RR and _val(r) * RI9 < RR * (RI9 + a) and all(x <= M29 for x in r)
 
 
+def test_fr_mul32_against_big_integers():
+    """frlazy.cuh::fr_mul32 (the 2^5 fix-up of a product of two elements in the reference's form, replacing a second Montgomery
+    product in k_vec_op / k_beaver): 32 v mod r, fully reduced, for every v below 2^256 -- the reciprocal it estimates the
+    quotient with is exact for every numerator it can meet, and the remainder it leaves needs one subtraction."""
+    import random
+    rnd = random.Random(32)
+    d = (RR >> 240) + 1
+    M = (1 << 32) // d + 1
+    assert all((n * M) >> 32 == n // d for n in range(1 << 21))                 # t >> 240 < 2^21 for any v < 2^256
+    ends = [0, 1, RR - 1, RR, RR + 1, (RR - 1) // 32, RR // 32 + 1, 2 * RR, (1 << 256) - 1, (1 << 253), (1 << 240) - 1, 1 << 240]
+    ends += [k * RR // 32 + e for k in range(1, 33) for e in (-1, 0, 1)]        # the quotient boundaries
+    for v in ends + [rnd.randrange(RR) for _ in range(3000)] + [rnd.randrange(1 << 256) for _ in range(500)]:
+        (r,) = _fr_lazy(10, _l9(v))
+        assert _val(r) == 32 * v % RR and all(x <= M29 for x in r), hex(v)
+
+
 def test_fr_lazy_butterflies():
     """frl_radix4 / frl_radix2 (the sequences ntt.hip runs) against the two DIF levels of radix2/fft.rs:185-307 computed with
     Python integers; inputs anywhere in the stage-input range (< 2.1 r), outputs back inside it."""

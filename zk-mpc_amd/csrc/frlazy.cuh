@@ -113,4 +113,29 @@ ZK_HD void frl_radix2(Fr& x0, Fr& x1, const Fr& w) {
     x0 = frl_reduce(s);
 }
 
+// 32 v mod r for ANY v below 2^256 with limbs below 2^29: the fix-up of a product of two elements in the reference's form.  The
+// device's Montgomery product divides by RI = 2^261, so mmul(a 2^256, b 2^256) = a b 2^251; the missing 2^5 used to be a second
+// Montgomery product (153 multiply-adds) and is ~90 plain instructions here: t = v << 5, q = floor((t >> 240) / ((r >> 240) + 1))
+// by a reciprocal (exact for every 21-bit numerator: tests/test_abi.py), so q <= t / r < q + 1.01 and t - q r < 1.01 r, then
+// one conditional subtraction.  Fully reduced result.
+ZK_HD Fr fr_mul32(const Fr& v) {
+    constexpr int L = FrParams::L;
+    static_assert(L == 9, "nine 29-bit limbs");
+    uint32_t t[L], s[L];
+    t[0] = (v.l[0] << 5) & MASK29;
+#pragma unroll
+    for (int i = 1; i < L - 1; i++) t[i] = ((v.l[i] << 5) | (v.l[i - 1] >> 24)) & MASK29;
+    t[L - 1] = (v.l[L - 1] << 5) | (v.l[L - 2] >> 24);                   // bits 232 .. 260 of t
+    constexpr uint32_t R_HI = (FrParams::P[L - 1] >> 8) + 1;             // (r >> 240) + 1
+    constexpr uint32_t M = (uint32_t)((1ull << 32) / R_HI) + 1;
+    const uint32_t q = (uint32_t)(((uint64_t)(t[L - 1] >> 8) * M) >> 32);
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        const int64_t x = (int64_t)t[i] - (int64_t)((uint64_t)q * FrParams::P[i]) + c;
+        if (i < L - 1) { s[i] = (uint32_t)x & MASK29; c = x >> 29; } else { s[i] = (uint32_t)x; }
+    }
+    return fp_reduce_once<FrParams>(s);
+}
+
 }  // namespace zk

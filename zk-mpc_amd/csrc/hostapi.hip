@@ -274,6 +274,7 @@ extern "C" int zk_fr_lazy_raw(int op, const uint32_t* in, uint32_t* out) {
             st(0, x0); st(1, x1);
             break;
         }
+        case 10: st(0, fr_mul32(ld(0))); break;
         default: return ZK_ERR_ARG;
     }
     return ZK_OK;

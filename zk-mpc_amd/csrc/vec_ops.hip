@@ -7,6 +7,7 @@
 // HBM-bound: 96 B of traffic per element for a binary op (2 x 32 B in, 32 B out).
 #include "../../include/zkmpc_hip.h"
 #include "devutil.cuh"
+#include "frlazy.cuh"
 #include "internal.hpp"
 
 using namespace zk;
@@ -24,10 +25,9 @@ __device__ __forceinline__ Fr frk(const FrK& k) {
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_vec_op(const void* a, const void* b, void* out, size_t n) {
-    const Fr fix = fp_const<FrParams>(FrParams::EXT_TO_INT);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         Fr x = fr_load(a, i), y = fr_load(b, i), z;
-        if (OP == ZK_OP_MUL) z = fr_mul(fr_mul(x, y), fix);  // ext*ext -> ext needs one fix-up product
+        if (OP == ZK_OP_MUL) z = fr_mul32(fr_mul(x, y));     // ext * ext = a b 2^251: times 2^5 (frlazy.cuh), not a second product
         else if (OP == ZK_OP_ADD) z = fr_add(x, y);
         else z = fr_sub(x, y);
         fr_store(out, i, z);
@@ -59,24 +59,27 @@ __global__ void __launch_bounds__(256) k_sum_parties(const void* g, size_t np, s
 template <bool DUMMY>
 __global__ void __launch_bounds__(256) k_beaver(const void* sx, const void* oy, const void* tx, const void* ty,
                                                 const void* tz, void* out, size_t n, int leader) {
-    const Fr fix = fp_const<FrParams>(FrParams::EXT_TO_INT);
     // 1 in external form = 2^256 mod r = mmul(ONE_internal, INT_TO_EXT)
     const Fr one_ext = fr_mul(fp_one<FrParams>(), fp_const<FrParams>(FrParams::INT_TO_EXT));
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        Fr a = fr_load(sx, i), b = fr_load(oy, i), z;
+        const Fr a = fr_load(sx, i), b = fr_load(oy, i);
+        // the 2^5 that a product of two elements in the reference's form lacks goes in ONCE per opened value (fr_mul32), not
+        // as a second Montgomery product behind each of the three products
+        const Fr a32 = fr_mul32(a);
+        Fr z;
         if (DUMMY) {
             if (leader) {
                 // 1 - a - b + ab
-                z = fr_add(fr_sub(fr_sub(one_ext, a), b), fr_mul(fr_mul(a, b), fix));
+                z = fr_add(fr_sub(fr_sub(one_ext, a), b), fr_mul(a32, b));
             } else {
                 z = fp_zero<FrParams>();
             }
         } else {
-            Fr x = fr_load(tx, i), y = fr_load(ty, i);
+            const Fr x = fr_load(tx, i), y = fr_load(ty, i);
             z = fr_load(tz, i);
-            z = fr_sub(z, fr_mul(fr_mul(a, y), fix));
-            z = fr_sub(z, fr_mul(fr_mul(b, x), fix));
-            if (leader) z = fr_add(z, fr_mul(fr_mul(a, b), fix));
+            z = fr_sub(z, fr_mul(a32, y));
+            z = fr_sub(z, fr_mul(fr_mul32(b), x));
+            if (leader) z = fr_add(z, fr_mul(a32, b));
         }
         fr_store(out, i, z);
     }
