@@ -33,8 +33,11 @@ struct GridGeom {
     uint32_t row_blocks, col_blocks;
 };
 
-static inline void grid_split(uint32_t D, uint32_t& K, uint32_t& TW, uint32_t& P) {
-    K = D < 8 ? D : 8;
+// kmax: serial additions per lane.  8 when there are buckets enough to fill the chip (2^19 buckets / 8 = 2 waves per SIMD); a
+// small bucket set leaves most lanes idle and is bound by the chain's LATENCY: shorter serial runs, deeper trees (a 2^14-scalar
+// MSM: 26 windows of 512 buckets, 7 + 2 dependent additions with K = 8, 1 + 4 with K = 2)
+static inline void grid_split(uint32_t D, uint32_t kmax, uint32_t& K, uint32_t& TW, uint32_t& P) {
+    K = D < kmax ? D : kmax;
     TW = D / K < 32 ? D / K : 32;
     P = D / (K * TW);
 }
@@ -44,8 +47,10 @@ static inline GridGeom make_grid_geom(uint32_t log_nb, uint32_t n_win, uint32_t 
     g.cl = log_nb / 2;
     g.rl = log_nb - g.cl;
     g.n_win = n_win;
-    grid_split(1u << g.cl, g.Kr, g.TWr, g.Pr);
-    grid_split(1u << g.rl, g.Kc, g.TWc, g.Pc);
+    const uint64_t buckets = (uint64_t)n_win << log_nb;
+    const uint32_t kmax = buckets <= (1u << 15) ? 2u : buckets <= (1u << 17) ? 4u : 8u;
+    grid_split(1u << g.cl, kmax, g.Kr, g.TWr, g.Pr);
+    grid_split(1u << g.rl, kmax, g.Kc, g.TWc, g.Pc);
     g.lgPr = 0;
     while ((1u << g.lgPr) < g.Pr) g.lgPr++;
     const size_t row_groups = ((size_t)n_win << g.rl) * g.Pr, col_groups = ((size_t)n_win << g.cl) * g.Pc;
@@ -149,8 +154,10 @@ k_grid_bits(const uint32_t* __restrict__ rowP, const uint32_t* __restrict__ colP
     else { src = colP; T = g.Pc << g.cl; pos = j - g.rl; all = pos == g.cl; }
     const uint32_t nsel = all ? T : T >> 1, low = (1u << pos) - 1;
     const uint32_t nser = (nsel + P::PTS - 1) / P::PTS;
+    // tree over the lanes that hold something: lanes >= nsel carry infinity (a small window selects a handful of partials)
+    const uint32_t span = nsel < (uint32_t)P::PTS ? (nsel > 1 ? nsel : 2) : (uint32_t)P::PTS;
     uint32_t nlev = 0;
-    while ((1u << nlev) < (uint32_t)P::PTS) nlev++;
+    while ((1u << nlev) < span) nlev++;
     X acc = P::inf();
     for (uint32_t it = 0; it < nser + nlev; it++) {
         X v = P::inf();
@@ -163,7 +170,7 @@ k_grid_bits(const uint32_t* __restrict__ rowP, const uint32_t* __restrict__ colP
         } else {
             if (it == nser) P::lds_put(grid_lds, pt, P::pack(acc));
             __syncthreads();
-            const uint32_t d = (uint32_t)P::PTS >> (it - nser + 1);
+            const uint32_t d = (1u << nlev) >> (it - nser + 1);
             act = pt < d;
             if (act) {
                 acc = P::lds_get(grid_lds, pt);
