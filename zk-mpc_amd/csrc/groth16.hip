@@ -16,6 +16,7 @@
 #include "hostgroup.hpp"
 #include "hostfield64.hpp"
 #include "internal.hpp"
+#include "sharednet.hpp"
 #include <chrono>
 #include <cstring>
 #include <functional>
@@ -1085,35 +1086,6 @@ __global__ void __launch_bounds__(256) k_vec_add_const(const void* a, FrK k, voi
         fr_store(out, i, fr_add(fr_load(a, i), kk));
 }
 
-struct SharedNet {
-    zk_ctx* ctx;
-    const zk_net_vtable* vt;
-    size_t bytes = 0;
-    int parties() const { return ctx->n_parties; }
-    // out[p * len ..] = party p's bytes (MpcNet::broadcast_bytes); a single party needs no transport
-    int gather(const uint8_t* mine, size_t len, std::vector<uint8_t>& all) {
-        all.resize((size_t)parties() * len);
-        bytes += len;
-        if (parties() == 1) { memcpy(all.data(), mine, len); return ZK_OK; }
-        if (!vt || !vt->all_gather_bytes) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_groth16_prove_shared: several parties need zk_net_vtable::all_gather_bytes");
-        if (vt->all_gather_bytes(vt->user, mine, len, all.data()) != 0) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_groth16_prove_shared: all_gather_bytes failed");
-        return ZK_OK;
-    }
-    int open_vec(const void* v, size_t n, void* out) {
-        bytes += n * 32;
-        if (vt && vt->open_sum_fr_dev) {
-            ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));             // the callback may use its own stream
-            if (vt->open_sum_fr_dev(vt->user, v, n, out) != 0) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_groth16_prove_shared: open_sum_fr_dev callback failed");
-            return ZK_OK;
-        }
-        if (parties() == 1) {
-            if (out != v) ZK_HIP(ctx, hipMemcpyAsync(out, v, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
-            return ZK_OK;
-        }
-        return zk_open_sum_fr_dev(ctx, v, n, out);
-    }
-};
-
 }  // namespace
 
 namespace {
@@ -1123,14 +1095,9 @@ __global__ void __launch_bounds__(256) k_vec_neg(const void* a, void* out, size_
         fr_store(out, i, fr_sub(fp_zero<FrParams>(), fr_load(a, i)));
 }
 
-using SH1 = Fq64Field;
-using SH2 = Fq264Field;
-using SX1 = XYZZ<SH1>;
-using SX2 = XYZZ<SH2>;
+}  // namespace
 
-// SpdzFieldShare::batch_open on a device vector (mpc-algebra/src/share/spdz.rs:177-196, key alpha = 1 held by the leader):
-// x = open(share lane); then every party publishes [leader ? x : 0] - mac and the sum must vanish element by element.
-int spdz_open_vec(SharedNet& nt, const void* sh, const void* mac, size_t n, void* out, void* dx) {
+int zk_shared_spdz_open_vec(ZkSharedNet& nt, const void* sh, const void* mac, size_t n, void* out, void* dx) {
     zk_ctx* ctx = nt.ctx;
     ZK_TRY(nt.open_vec(sh, n, out));
     if (ctx->party_id == 0) {
@@ -1146,6 +1113,52 @@ int spdz_open_vec(SharedNet& nt, const void* sh, const void* mac, size_t n, void
     return ZK_OK;
 }
 
+int zk_shared_beaver_mul(ZkSharedNet& nt, int lanes, const void* const x[2], const void* const y[2], void* const out[2], size_t n,
+                         const void* const tx[2], const void* const ty[2], const void* const tz[2], const char* tag) {
+    zk_ctx* ctx = nt.ctx;
+    const bool dummy = !tx[0] && !ty[0] && !tz[0];
+    for (int l = 0; l < lanes; l++)
+        if (dummy ? (tx[l] || ty[l] || tz[l]) : (!tx[l] || !ty[l] || !tz[l])) ZK_FAIL(ctx, ZK_ERR_ARG, "batch_mul: give a whole Beaver triple (every lane) or none");
+    void *sxl[2], *oyl[2], *sx, *oy, *dx;
+    char nm[64];
+    auto buf = [&](const char* what, int l, void** p) { snprintf(nm, sizeof nm, "%s.%s%d", tag, what, l); return zk_scratch(ctx, nm, n * 32, p); };
+    for (int l = 0; l < lanes; l++) { ZK_TRY(buf("sxl", l, &sxl[l])); ZK_TRY(buf("oyl", l, &oyl[l])); }
+    ZK_TRY(buf("sx", 0, &sx)); ZK_TRY(buf("oy", 0, &oy)); ZK_TRY(buf("dx", 0, &dx));
+    const Fr one_ext = fp_mul<FrParams>(fp_one<FrParams>(), fp_const<FrParams>(FrParams::INT_TO_EXT));
+    for (int l = 0; l < lanes; l++) {
+        if (dummy) {                                      // DummyFieldTripleSource: the leader holds 1 (in both lanes), the rest 0 (wire/field.rs:49-63)
+            if (nt.leader()) {
+                hipLaunchKernelGGL(k_vec_add_const, zk_grid(n, 256), 256, 0, ctx->stream, x[l], to_frk(one_ext), sxl[l], n);
+                hipLaunchKernelGGL(k_vec_add_const, zk_grid(n, 256), 256, 0, ctx->stream, y[l], to_frk(one_ext), oyl[l], n);
+                ZK_HIP(ctx, hipGetLastError());
+            } else {
+                ZK_HIP(ctx, hipMemcpyAsync(sxl[l], x[l], n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+                ZK_HIP(ctx, hipMemcpyAsync(oyl[l], y[l], n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        } else {
+            ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_ADD, x[l], tx[l], sxl[l], n));
+            ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_ADD, y[l], ty[l], oyl[l], n));
+        }
+    }
+    if (lanes == 1) {
+        ZK_TRY(nt.open_vec(sxl[0], n, sx));               // open(s + x), open(o + y)
+        ZK_TRY(nt.open_vec(oyl[0], n, oy));
+    } else {
+        ZK_TRY(zk_shared_spdz_open_vec(nt, sxl[0], sxl[1], n, sx, dx));
+        ZK_TRY(zk_shared_spdz_open_vec(nt, oyl[0], oyl[1], n, oy, dx));
+    }
+    // the local tail; the shift of sx * oy lands on the leader in BOTH lanes (mac_share = 1 there)
+    for (int l = 0; l < lanes; l++) ZK_TRY(zk_beaver_combine_dev(ctx, sx, oy, tx[l], ty[l], tz[l], out[l], n));
+    return ZK_OK;
+}
+
+namespace {
+
+using SH1 = Fq64Field;
+using SH2 = Fq264Field;
+using SX1 = XYZZ<SH1>;
+using SX2 = XYZZ<SH2>;
+
 // LANES = 1: additive shares (AdditiveFieldShare / AdditiveGroupShare); LANES = 2: SPDZ (share lane, MAC lane), every open
 // MAC-checked.  z / rs / ss / tx..tz are indexed by lane.
 template <int LANES>
@@ -1157,7 +1170,7 @@ int prove_shared_impl(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void
         if (dummy ? (tx[l] || ty[l] || tz[l]) : (!tx[l] || !ty[l] || !tz[l])) ZK_FAIL(ctx, ZK_ERR_ARG, "prove_shared: give a whole Beaver triple (every lane) or none");
     const bool leader = ctx->party_id == 0;
     const size_t D = (size_t)1 << r->log_d;
-    SharedNet nt{ctx, net};
+    ZkSharedNet nt{ctx, net};
     uint32_t rw[2][8], sw[2][8];
     for (int l = 0; l < LANES; l++) { fr_abi_to_canon_words(rs[l]->l, rw[l]); fr_abi_to_canon_words(ss[l]->l, sw[l]); }
     const SX1 delta1 = xyzz_from_affine<SH1>(aff_to_host64<G1Field>(pk->delta_g1));
@@ -1174,46 +1187,25 @@ int prove_shared_impl(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void
         f_s_g1[l] = zk_async([&, l] { return host64_scalar_mul<SH1>(delta1, sw[l]); });
         f_s_g2[l] = zk_async([&, l] { return host64_scalar_mul<SH2>(delta2, sw[l]); });
     }
-    void *a[2], *b[2], *c[2], *sxl[2], *oyl[2], *sx, *oy, *dx;
+    void *a[2], *b[2], *c[2];
     char nm[32];
     for (int l = 0; l < LANES; l++) {
-        const char* names[5] = {"shared_a%d", "shared_b%d", "shared_c%d", "shared_sxl%d", "shared_oyl%d"};
-        void** dst[5] = {&a[l], &b[l], &c[l], &sxl[l], &oyl[l]};
-        for (int k = 0; k < 5; k++) { snprintf(nm, sizeof nm, names[k], l); ZK_TRY(zk_scratch(ctx, nm, D * 32, dst[k])); }
+        const char* names[3] = {"shared_a%d", "shared_b%d", "shared_c%d"};
+        void** dst[3] = {&a[l], &b[l], &c[l]};
+        for (int k = 0; k < 3; k++) { snprintf(nm, sizeof nm, names[k], l); ZK_TRY(zk_scratch(ctx, nm, D * 32, dst[k])); }
     }
-    ZK_TRY(zk_scratch(ctx, "shared_sx", D * 32, &sx));
-    ZK_TRY(zk_scratch(ctx, "shared_oy", D * 32, &oy));
-    ZK_TRY(zk_scratch(ctx, "shared_dx", D * 32, &dx));
     for (int l = 0; l < LANES; l++) ZK_TRY(zk_groth16_witness_map_pre_dev(ctx, r, z[l], 1, a[l], b[l], c[l]));     // local: linear in the shares
     ZK_TRY(zk_groth16_msms_begin_dev(ctx, pk, r, z[0]));                          // the share lane's four MSMs over z run under the opens
-    // FieldShare::batch_mul (share/field.rs:97-129): open(s + x), open(o + y), then the local tail -- per lane
-    const Fr one_ext = fp_mul<FrParams>(fp_one<FrParams>(), fp_const<FrParams>(FrParams::INT_TO_EXT));
-    for (int l = 0; l < LANES; l++) {
-        if (dummy) {                                      // DummyFieldTripleSource: the leader holds 1 (in both lanes), the rest 0 (wire/field.rs:49-63)
-            if (leader) {
-                hipLaunchKernelGGL(k_vec_add_const, zk_grid(D, 256), 256, 0, ctx->stream, (const void*)a[l], to_frk(one_ext), sxl[l], D);
-                hipLaunchKernelGGL(k_vec_add_const, zk_grid(D, 256), 256, 0, ctx->stream, (const void*)b[l], to_frk(one_ext), oyl[l], D);
-                ZK_HIP(ctx, hipGetLastError());
-            } else {
-                ZK_HIP(ctx, hipMemcpyAsync(sxl[l], a[l], D * 32, hipMemcpyDeviceToDevice, ctx->stream));
-                ZK_HIP(ctx, hipMemcpyAsync(oyl[l], b[l], D * 32, hipMemcpyDeviceToDevice, ctx->stream));
-            }
-        } else {
-            ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_ADD, a[l], tx[l], sxl[l], D));
-            ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_ADD, b[l], ty[l], oyl[l], D));
-        }
-    }
-    if (LANES == 1) {
-        ZK_TRY(nt.open_vec(sxl[0], D, sx));
-        ZK_TRY(nt.open_vec(oyl[0], D, oy));
-    } else {
-        ZK_TRY(spdz_open_vec(nt, sxl[0], sxl[1], D, sx, dx));
-        ZK_TRY(spdz_open_vec(nt, oyl[0], oyl[1], D, oy, dx));
+    // FieldShare::batch_mul of the D-element product (share/field.rs:97-129): open(s + x), open(o + y), the local tail -- per lane
+    {
+        const void* xa[2] = {a[0], LANES == 2 ? a[1] : nullptr};
+        const void* yb[2] = {b[0], LANES == 2 ? b[1] : nullptr};
+        void* oa[2] = {a[0], LANES == 2 ? a[1] : nullptr};
+        ZK_TRY(zk_shared_beaver_mul(nt, LANES, xa, yb, oa, D, tx, ty, tz, "shared_bv"));
     }
     zk_g1_projective m1[2][4];
     zk_g2_projective m2[2];
-    for (int l = 0; l < LANES; l++) {                     // the shift of sx * oy lands on the leader in BOTH lanes (mac_share = 1 there)
-        ZK_TRY(zk_beaver_combine_dev(ctx, sx, oy, tx[l], ty[l], tz[l], a[l], D));
+    for (int l = 0; l < LANES; l++) {
         ZK_TRY(zk_groth16_witness_map_post_dev(ctx, r, a[l], c[l]));                    // h shares in a[l]
         ZK_TRY(zk_groth16_msms_dev(ctx, pk, r, z[l], a[l], m1[l], &m2[l]));            // party-local MSMs (multi_scale_pub_group; spdz.rs:482-488: twice)
     }
@@ -1234,7 +1226,7 @@ int prove_shared_impl(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void
     // first exchange: open(o + y) for o = s, r (y = the leader's 1: the dummy group triple; from_add_shared: mac = share), open(s + x)
     // for the three scaled points (x = 0) and the reveal of B.  SPDZ: a second exchange of [leader ? opened : 0] - mac, all zero.
     constexpr size_t MW = 2 * 4 + 3 * 18 + 36;
-    const Fr y = leader ? one_ext : fp_zero<FrParams>();
+    const Fr y = leader ? fp_mul<FrParams>(fp_one<FrParams>(), fp_const<FrParams>(FrParams::INT_TO_EXT)) : fp_zero<FrParams>();
     auto pack = [&](int l, uint64_t* msg) {
         host_store_ext<FrParams>(msg, fp_add<FrParams>(host_load_ext<FrParams>(ss[l]->l), y));
         host_store_ext<FrParams>(msg + 4, fp_add<FrParams>(host_load_ext<FrParams>(rs[l]->l), y));
