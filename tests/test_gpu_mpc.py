@@ -617,6 +617,12 @@ def test_collaborative_marlin_full_proof(n_parties, n, spdz, mask_dev):
             proof = party.marlin_prove_full_spdz(keys, (up(zs[p]), up(zm[p])), Rng.from_seed(seeds[p], 20), mask_on_device=mask_dev)
         else:
             proof = party.marlin_prove_full(keys, up(zs[p]), Rng.from_seed(seeds[p], 20), mask_on_device=mask_dev)
+        # the same proof as ONE library call (zk_marlin_prove_shared[_spdz]) under the same seeds: byte for byte
+        if spdz:
+            native = party.marlin_prove_shared_spdz_native(keys, (up(zs[p]), up(zm[p])), Rng.from_seed(seeds[p], 20), mask_on_device=mask_dev)
+        else:
+            native = party.marlin_prove_shared_native(keys, up(zs[p]), Rng.from_seed(seeds[p], 20), mask_on_device=mask_dev)
+        assert native == proof.serialize(ctx)
         return proof.serialize(ctx), proof.evaluations, [[(cc.comm_aff, cc.shifted_aff, cc.shifted is not None) for cc in rnd] for rnd in proof.commitments], \
             [(cv.g1_projective_to_affine(w), rv) for w, rv in proof.pc_proof]
 
@@ -637,6 +643,65 @@ def test_collaborative_marlin_full_proof(n_parties, n, spdz, mask_dev):
         assert not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], as_oracle)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("spdz", [False, True])
+def test_native_collaborative_marlin_with_real_triples_and_tampering(spdz):
+    """zk_marlin_prove_shared[_spdz] with REAL Beaver triples for the round-2 product (the dummy source is the reference's
+    default; a deployment brings triples from the preprocessing phase): the proof verifies in the oracle.  Under SPDZ a
+    party that lies about one MAC share of its assignment makes every party's call fail with MacCheckError."""
+    import marlin_full_ref as MF
+    import marlin_ref as M
+    from zk_mpc_amd import marlin as DM
+    from zk_mpc_amd.api import Rng
+    n_parties, n = 3, 11
+    rng = O.Prng(4242 + spdz)
+    r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
+    sq, zz = M.pad_and_square(r1cs, z)
+    zs = additive_shares(zz, n_parties, rng, public_prefix=sq.num_instance)
+    zm = additive_shares(zz, n_parties, rng, public_prefix=sq.num_instance)
+    beta_srs, g_k, gg_k, h_k = rng.fr(), rng.fr(), rng.fr(), rng.fr()
+    seeds = [bytes((23 * p + i) & 0xff for i in range(32)) for p in range(n_parties)]
+    a, b, c = DM.Csr.from_rows(sq.a), DM.Csr.from_rows(sq.b), DM.Csr.from_rows(sq.c)
+    n_h = len(zz)
+    n_mul = 1 << (3 * n_h + 1 - 1).bit_length()                 # the multiplication domain of round 2
+    ta = [rng.fr() for _ in range(n_mul)]
+    tb = [rng.fr() for _ in range(n_mul)]
+    tc = [x * y % O.R_MOD for x, y in zip(ta, tb)]
+    tr = {k: (additive_shares(v, n_parties, rng), additive_shares(v, n_parties, rng)) for k, v in (("a", ta), ("b", tb), ("c", tc))}
+
+    def setup(ctx):
+        index = DM.Index(ctx, sq.num_instance, sq.num_witness, a, b, c)
+        srs = DM.UniversalSrs(ctx, DM.ahp_max_degree(index) + 3, beta_srs, g_k, gg_k)
+        return DM.IndexKeys(index, srs)
+
+    def fn(p, ctx, net, tamper=False):
+        party = (mpc.SpdzParty if spdz else mpc.Party)(ctx, net=net)
+        keys = setup(ctx)
+        up = lambda v: ctx.upload(cv.fr_to_mont(v))
+        bufs = {(k, lane): up(tr[k][lane][p]) for k in "abc" for lane in (0, 1)}
+        mac = list(zm[p])
+        if tamper and p == 1:
+            mac[sq.num_instance + 2] = (mac[sq.num_instance + 2] + 1) % O.R_MOD
+        if spdz:
+            triple = tuple((bufs[(k, 0)].ptr, bufs[(k, 1)].ptr) for k in "abc")
+            try:
+                return party.marlin_prove_shared_spdz_native(keys, (up(zs[p]), up(mac)), Rng.from_seed(seeds[p], 20), triple=triple)
+            except mpc.MacCheckError:
+                return "mac"
+        return party.marlin_prove_shared_native(keys, up(zs[p]), Rng.from_seed(seeds[p], 20), triple=tuple(bufs[(k, 0)].ptr for k in "abc"))
+
+    res = run_parties(n_parties, fn)
+    assert all(r == res[0] for r in res) and isinstance(res[0], bytes) and len(res[0]) > 900
+    ctx = Z.Context(0)
+    try:
+        keys = setup(ctx)
+        local = DM.prove(keys, ctx.upload(cv.fr_to_mont(zz)), _SumRng(seeds))     # triples do not change the opened values
+        assert local.serialize(ctx) == res[0]
+    finally:
+        ctx.close()
+    if spdz:
+        assert run_parties(n_parties, lambda p, ctx, net: fn(p, ctx, net, tamper=True)) == ["mac"] * n_parties
 
 
 # ---- several OS processes, one GPU, host-staged transport (gloo) ---------------------------------------------------------------
@@ -675,6 +740,11 @@ def _marlin_proc_worker(rank, world, port, spdz, q):
             proof = party.marlin_prove_full_spdz(keys, (up(zs[rank]), up(zm[rank])), Rng.from_seed(seed, 20))
         else:
             proof = party.marlin_prove_full(keys, up(zs[rank]), Rng.from_seed(seed, 20))
+        if spdz:                                                # the one-call provers over the same transport: the same bytes
+            native = party.marlin_prove_shared_spdz_native(keys, (up(zs[rank]), up(zm[rank])), Rng.from_seed(seed, 20))
+        else:
+            native = party.marlin_prove_shared_native(keys, up(zs[rank]), Rng.from_seed(seed, 20))
+        assert native == proof.serialize(ctx)
         # the one-call collaborative Groth16 provers over the same transport: the library calls back into gloo for its two small
         # exchanges and (staged through host memory) for the vector opens
         gr = O.Prng(9900 + world)

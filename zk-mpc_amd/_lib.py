@@ -204,6 +204,8 @@ PROTOTYPES = {
     "zk_marlin_round3_ab_evals_dev": (_I, [_P, _P, _SZ, _P, _P, _P, _P, _P, _P]),
     "zk_marlin_proof_max_size": (_SZ, []),
     "zk_marlin_prove": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _SZ, _P]),
+    "zk_marlin_prove_shared": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _SZ, _P, _P]),
+    "zk_marlin_prove_shared_spdz": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "zk_she_vec_op_dev": (_I, [_P, _I, _P, _P, _P, _SZ]),
     "zk_she_vec_scale_dev": (_I, [_P, _P, _P, _P, _SZ]),
     "zk_she_negacyclic_mul_dev": (_I, [_P, _P, _P, _P, _SZ, _SZ]),

@@ -14,6 +14,8 @@
 #include "devutil.cuh"
 #include "hostgroup.hpp"
 #include "internal.hpp"
+#include "sharednet.hpp"
+#include "hostfield64.hpp"
 #include <algorithm>
 #include <chrono>
 #include <future>
@@ -82,6 +84,7 @@ struct Prover {
     const zk_bases *pg, *pgg;
     size_t max_degree;
     zk_rng* rng;
+    int lane = 0;                      // 0: the share lane (or the plain prover); 1: the MAC lane of a SPDZ prover -- own scratch names
     int rc = ZK_OK;
     std::map<std::string, Poly> polys;
     std::map<std::string, std::pair<std::vector<HF>, std::vector<HF>>> rands;   // label -> (blind, shifted blind)
@@ -90,7 +93,7 @@ struct Prover {
 
     char* dev(const std::string& name, size_t elems) {
         void* p = nullptr;
-        if (rc == ZK_OK) rc = zk_scratch(ctx, ("mp." + name).c_str(), std::max<size_t>(elems, 1) * 32, &p);
+        if (rc == ZK_OK) rc = zk_scratch(ctx, ((lane ? "mp1." : "mp.") + name).c_str(), std::max<size_t>(elems, 1) * 32, &p);
         return (char*)p;
     }
     void ck(int r) { if (rc == ZK_OK) rc = r; }
@@ -177,10 +180,91 @@ struct Term { HF c; const char* label; };      // label = nullptr: the constant 
 
 extern "C" size_t zk_marlin_proof_max_size(void) { return 8 + 3 * 8 + 9 * 49 + 2 * 48 + 8 + 7 * 32 + 8 + 3 + 8 + 2 * (49 + 32) + 1; }
 
-extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
-                               const void* z_dev, zk_rng* zk_rng_, int mask_on_device, uint8_t* proof_out, size_t cap, size_t* proof_len) {
-    ZK_API_BEGIN(ctx)
-    if (!ctx || !ix || !powers_g || !powers_gamma_g || !z_dev || !zk_rng_ || !proof_out || !proof_len) return ZK_ERR_ARG;
+namespace {
+
+bool fr_words_valid_abi(const uint64_t l[4]) {       // < r (is_valid, ff/src/fields/macros.rs:255-260): what arrives from a peer
+    Fr m;
+    for (int i = 0; i < 9; i++) m.l[i] = FrParams::P[i];
+    uint64_t pm[4];
+    host_store_ext<FrParams>(pm, m);
+    for (int i = 3; i >= 0; i--) {
+        if (l[i] < pm[i]) return true;
+        if (l[i] > pm[i]) return false;
+    }
+    return false;
+}
+
+// Opens of O(1) values on the caller's transport, batched into ONE exchange: scalars and G1 points of this party's share lane
+// (AdditiveFieldShare / AdditiveGroupShare::open: the sum over parties).  LANES = 2 (SPDZ): frs[1] / g1s[1] are the MAC shares;
+// a second exchange publishes [leader ? opened : 0] - mac for every item and every sum must vanish (SpdzFieldShare::batch_open,
+// SpdzGroupShare::open: share/spdz.rs:177-196,312-336, key alpha = 1 held by the leader) -- otherwise ZK_ERR_MAC.
+template <int LANES>
+int open_small(ZkSharedNet& nt, const std::vector<HF> frs[2], const std::vector<zk_g1_projective> g1s[2], std::vector<HF>& out_fr,
+               std::vector<zk_g1_projective>& out_g1) {
+    using H1 = Fq64Field;
+    using X1 = XYZZ<H1>;
+    zk_ctx* ctx = nt.ctx;
+    const size_t nf = frs[0].size(), ng = g1s[0].size(), words = 4 * nf + 18 * ng;
+    out_fr.assign(nf, HF::zero());
+    out_g1.resize(ng);
+    if (!words) return ZK_OK;
+    std::vector<uint64_t> msg(words);
+    std::vector<uint8_t> all;
+    std::vector<X1> og(ng);
+    auto exchange = [&](std::vector<HF>& f, std::vector<X1>& g) -> int {
+        ZK_TRY(nt.gather((const uint8_t*)msg.data(), words * 8, all));
+        f.assign(nf, HF::zero());
+        g.assign(ng, xyzz_inf<H1>());
+        std::vector<uint64_t> w(words);
+        for (int p = 0; p < nt.parties(); p++) {
+            memcpy(w.data(), all.data() + (size_t)p * words * 8, words * 8);
+            for (size_t i = 0; i < nf; i++) {
+                if (!fr_words_valid_abi(&w[4 * i])) ZK_FAIL(ctx, ZK_ERR_STATE, "collaborative prover: a party sent a non-canonical field element");
+                zk_fr a;
+                memcpy(a.l, &w[4 * i], 32);
+                f[i] = f[i] + HF::from_abi(a);
+            }
+            for (size_t i = 0; i < ng; i++) g[i] = xyzz_add<H1>(g[i], host64_proj_from_abi<H1>(&w[4 * nf + 18 * i]));
+        }
+        return ZK_OK;
+    };
+    for (size_t i = 0; i < nf; i++) { zk_fr a = frs[0][i].abi(); memcpy(&msg[4 * i], a.l, 32); }
+    for (size_t i = 0; i < ng; i++) memcpy(&msg[4 * nf + 18 * i], &g1s[0][i], 144);
+    ZK_TRY(exchange(out_fr, og));
+    if (LANES == 2) {
+        const bool leader = nt.leader();
+        for (size_t i = 0; i < nf; i++) { zk_fr a = ((leader ? out_fr[i] : HF::zero()) - frs[1][i]).abi(); memcpy(&msg[4 * i], a.l, 32); }
+        for (size_t i = 0; i < ng; i++) {
+            const X1 d = xyzz_add<H1>(leader ? og[i] : xyzz_inf<H1>(), xyzz_neg<H1>(host64_proj_from_abi<H1>((const uint64_t*)&g1s[1][i])));
+            host64_write_projective<H1>(xyzz_to_affine<H1>(d), &msg[4 * nf + 18 * i]);
+        }
+        std::vector<HF> cf;
+        std::vector<X1> cg;
+        ZK_TRY(exchange(cf, cg));
+        bool ok = true;
+        for (auto& v : cf) ok = ok && v.is_zero();
+        for (auto& v : cg) ok = ok && xyzz_is_inf<H1>(v);
+        if (!ok) ZK_FAIL(ctx, ZK_ERR_MAC, "SPDZ MAC check failed on an opened commitment / evaluation / witness");
+    }
+    for (size_t i = 0; i < ng; i++) host64_write_projective<H1>(xyzz_to_affine<H1>(og[i]), (uint64_t*)&out_g1[i]);
+    return ZK_OK;
+}
+
+bool label_shared(const char* l) {           // the witness-dependent oracles (mpc.py: Party.SHARED_POLYS); t, g_2, h_2 and the index are public
+    return !strcmp(l, "w") || !strcmp(l, "z_a") || !strcmp(l, "z_b") || !strcmp(l, "mask_poly") || !strcmp(l, "g_1") || !strcmp(l, "h_1");
+}
+
+// Marlin::prove, plain (shared = false, LANES = 1: zk_marlin_prove) or over this party's shares (zk_marlin_prove_shared[_spdz]):
+// MpcMarlin::prove, src/marlin.rs:56 / arkworks/marlin/src/lib.rs:152-319 with F = MpcField.  Every step of the rounds is linear
+// in the witness except z_A * z_B in round 2 (FieldShare::batch_mul over the 4|H| multiplication domain) and the zero test of the
+// outer sum-check (an open); commitments / evaluations / opening witnesses of witness-dependent oracles are computed on the
+// shares and opened (`publicize()`, lib.rs:171-228,296); public oracles enter a shared combination on the leader only (shift()).
+// LANES = 2: everything linear runs on the share lane and on the MAC lane, every open is MAC-checked; the MAC lane of this
+// party's fresh randomness is the share itself (from_add_shared with key 1).
+template <int LANES>
+int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g, const zk_bases* powers_gamma_g, const void* const z_lanes[2],
+                zk_rng* zk_rng_, int mask_on_device, bool shared, const void* const tx[2], const void* const ty[2], const void* const tz[2],
+                const zk_net_vtable* net, uint8_t* proof_out, size_t cap, size_t* proof_len, uint64_t* bytes_sent) {
     if (powers_g->group != 1 || powers_gamma_g->group != 1 || powers_gamma_g->n < 3) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: SRS tables");
     if (cap < zk_marlin_proof_max_size()) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: output buffer smaller than zk_marlin_proof_max_size()");
     if (ix->num_constraints != ix->num_variables) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: NonSquareMatrix");
@@ -200,7 +284,12 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         }
         ~Laps() { if (on) fprintf(stderr, "zk_marlin_prove ms:%s | total %.2f\n", line.c_str(), std::chrono::duration<double, std::milli>(t - t0).count()); }
     } laps;
-    Prover P{ctx, ix, powers_g, powers_gamma_g, powers_g->n - 1, zk_rng_};
+    ZkSharedNet nt{ctx, net};
+    const bool leader = nt.leader();
+    Prover PL[2] = {Prover{ctx, ix, powers_g, powers_gamma_g, powers_g->n - 1, zk_rng_}, Prover{ctx, ix, powers_g, powers_gamma_g, powers_g->n - 1, zk_rng_}};
+    PL[1].lane = 1;
+    Prover& P = PL[0];                            // lane 0 also carries everything public: blinds, commitments, bounds, public oracles
+    auto lanes_rc = [&]() { for (int l = 0; l < LANES; l++) if (PL[l].rc != ZK_OK) return PL[l].rc; return (int)ZK_OK; };
     const Dom H(ix->num_constraints), K(ix->num_non_zero), X(ix->num_instance), B(3 * Dom(ix->num_non_zero).size - 3);
     const size_t n = H.size, ni = ix->num_instance;
     {   // AHPForR1CS::max_degree (ahp/mod.rs:75-97)
@@ -210,14 +299,13 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     if (B.size < 4 * K.size - 3) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: |K| < 4 is not supported by this entry point");
     P.bounds["g_1"] = n - 2;
     P.bounds["g_2"] = K.size - 2;
-    const char* zb = (const char*)z_dev;
-    for (int i = 0; i < 12; i++) {
-        P.polys[INDEX_LABELS[i]] = Poly{(char*)ix->index_polys[i].ptr, ix->index_polys[i].n};
-        P.rands[INDEX_LABELS[i]] = {};
-    }
+    const char* zb[2] = {(const char*)z_lanes[0], LANES == 2 ? (const char*)z_lanes[1] : nullptr};
+    for (int l = 0; l < LANES; l++)
+        for (int i = 0; i < 12; i++) PL[l].polys[INDEX_LABELS[i]] = Poly{(char*)ix->index_polys[i].ptr, ix->index_polys[i].n};
+    for (int i = 0; i < 12; i++) P.rands[INDEX_LABELS[i]] = {};
 
     // ZK_MARLIN_SYNC_BLINDS=1 (experiment): the host-side blinding terms inline instead of on host threads
-    const bool blind_deferred = getenv("ZK_MARLIN_SYNC_BLINDS") != nullptr;     // experiment: the blinding terms in line
+    const bool blind_deferred = getenv("ZK_MARLIN_SYNC_BLINDS") != nullptr;
     zk_g1_projective gamma_pts[3];
     {
         zk_g1_affine a[3];
@@ -225,11 +313,20 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
         for (int i = 0; i < 3; i++) zk_g1_from_affine(&a[i], &gamma_pts[i]);
     }
 
-    // ---- transcript seed: PROTOCOL_NAME | index_vk | public_input (lib.rs:161-164) ----
+    // ---- transcript seed: PROTOCOL_NAME | index_vk | public_input (lib.rs:161-164).  Over shares the instance part of the
+    // assignment is shared like the rest (from_public: the leader holds it) and opened here ----
     std::vector<HF> pub(ni - 1);
     {
         std::vector<zk_fr> tmp(ni);
-        ZK_TRY(zk_memcpy_d2h(ctx, tmp.data(), zb, ni * 32));
+        if (shared) {
+            char* po = P.dev("pub_open", ni); char* pd = P.dev("pub_dx", ni);
+            ZK_TRY(P.rc);
+            if (LANES == 2) ZK_TRY(zk_shared_spdz_open_vec(nt, zb[0], zb[1], ni, po, pd));
+            else ZK_TRY(nt.open_vec(zb[0], ni, po));
+            ZK_TRY(zk_memcpy_d2h(ctx, tmp.data(), po, ni * 32));
+        } else {
+            ZK_TRY(zk_memcpy_d2h(ctx, tmp.data(), zb[0], ni * 32));
+        }
         for (size_t i = 1; i < ni; i++) pub[i - 1] = HF::from_abi(tmp[i]);
     }
     std::vector<uint8_t> seed;
@@ -243,11 +340,12 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     auto sample_outside = [&](const Dom& d) { HF t = P.next_fr(fs); while (d.vanishing(t).is_zero()) t = P.next_fr(fs); return t; };
 
     // MarlinKZG10::commit for one round (marlin_pc/mod.rs:172-243): blinding polynomials in the reference's rng order, all MSMs
-    // of the round as one pipelined batch; then the round's bytes into the transcript
+    // of the round (every lane) as one pipelined batch; shared oracles' commitments opened; then the round's bytes into the transcript
     auto commit_round = [&](std::initializer_list<const char*> labels) -> int {
         std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
-        std::vector<std::pair<std::string, int>> slot;                          // (label, 0 = comm / 1 = shifted)
-        std::map<std::string, zk_g1_projective> acc[2];
+        struct Slot { std::string label; int which, lane; };
+        std::vector<Slot> slot;                                                  // which: 0 = comm / 1 = shifted
+        std::map<std::string, zk_g1_projective> acc[2][2];                       // [lane][which]
         // the blinding terms (three host scalar multiplications each, ~1.2 ms) run on host threads under the device batch
         std::vector<std::pair<std::pair<int, std::string>, std::future<zk_g1_projective>>> blinds;
         auto blind_async = [&](int which, const char* l, const std::vector<HF>& c) {
@@ -260,34 +358,56 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
             if (hiding) for (int i = 0; i < 3; i++) blind.push_back(P.next_fr(P.rng));
             if (hiding && bounded) for (int i = 0; i < 3; i++) sblind.push_back(P.next_fr(P.rng));
             P.rands[l] = {blind, sblind};
-            const Poly& p = P.polys[l];
-            jb.push_back(P.pg); joff.push_back(0); jsc.push_back(p.p); jlen.push_back(p.n); slot.push_back({l, 0});
-            if (hiding) blind_async(0, l, blind);
-            if (bounded) {
-                if (p.n - 1 > P.bounds[l]) { ctx->last_error = std::string("zk_marlin_prove: ") + l + " exceeds its degree bound"; return ZK_ERR_STATE; }
-                jb.push_back(P.pg); joff.push_back(P.max_degree - P.bounds[l]); jsc.push_back(p.p); jlen.push_back(p.n); slot.push_back({l, 1});
-                if (hiding) blind_async(1, l, sblind);
+            for (int lane = 0; lane < LANES; lane++) {
+                if (lane == 1 && !label_shared(l)) continue;                     // public oracles are the same on every lane: committed once
+                const Poly& p = PL[lane].polys[l];
+                jb.push_back(P.pg); joff.push_back(0); jsc.push_back(p.p); jlen.push_back(p.n); slot.push_back({l, 0, lane});
+                if (bounded) {
+                    if (p.n - 1 > P.bounds[l]) { ctx->last_error = std::string("zk_marlin_prove: ") + l + " exceeds its degree bound"; return ZK_ERR_STATE; }
+                    jb.push_back(P.pg); joff.push_back(P.max_degree - P.bounds[l]); jsc.push_back(p.p); jlen.push_back(p.n); slot.push_back({l, 1, lane});
+                }
             }
+            if (hiding) blind_async(0, l, blind);
+            if (hiding && bounded) blind_async(1, l, sblind);
         }
-        ZK_TRY(P.rc);
+        ZK_TRY(lanes_rc());
         std::vector<zk_g1_projective> outs(jb.size());
         std::vector<void*> outp(jb.size());
         for (size_t i = 0; i < jb.size(); i++) outp[i] = &outs[i];
         const int brc = zk_msm_batch_dev(ctx, jb.size(), jb.data(), joff.data(), jsc.data(), jlen.data(), outp.data());
-        for (auto& b : blinds) acc[b.first.first][b.first.second] = b.second.get();      // joined before any return
+        std::vector<std::pair<std::pair<int, std::string>, zk_g1_projective>> bl;
+        for (auto& b : blinds) bl.push_back({b.first, b.second.get()});          // joined before any return
         ZK_TRY(brc);
-        for (size_t i = 0; i < jb.size(); i++) {
-            auto& m = acc[slot[i].second];
-            auto it = m.find(slot[i].first);
-            if (it == m.end()) m[slot[i].first] = outs[i];
-            else { zk_g1_projective t; zk_g1_add(&it->second, &outs[i], &t); it->second = t; }
+        for (size_t i = 0; i < jb.size(); i++) acc[slot[i].lane][slot[i].which][slot[i].label] = outs[i];
+        for (auto& b : bl)                                                       // the MAC lane of this party's fresh blinds is the share itself
+            for (int lane = 0; lane < LANES; lane++) {
+                auto it = acc[lane][b.first.first].find(b.first.second);
+                if (it == acc[lane][b.first.first].end()) continue;
+                zk_g1_projective t;
+                zk_g1_add(&it->second, &b.second, &t);
+                it->second = t;
+            }
+        if (shared) {                                                            // first_comms.publicize() (lib.rs:180,205,228)
+            std::vector<HF> nofr[2], ofr;
+            std::vector<zk_g1_projective> pts[2], opened;
+            std::vector<std::pair<std::string, int>> what;
+            for (const char* l : labels) {
+                if (!label_shared(l)) continue;
+                for (int which = 0; which < 2; which++) {
+                    if (!acc[0][which].count(l)) continue;
+                    for (int lane = 0; lane < LANES; lane++) pts[lane].push_back(acc[lane][which][l]);
+                    what.push_back({l, which});
+                }
+            }
+            ZK_TRY(open_small<LANES>(nt, nofr, pts, ofr, opened));
+            for (size_t i = 0; i < what.size(); i++) acc[0][what[i].second][what[i].first] = opened[i];
         }
         std::vector<uint8_t> bytes;
         for (const char* l : labels) {
             Comm c;
-            c.c = proj_to_aff(acc[0][l]);
-            c.has_shift = acc[1].count(l) != 0;
-            c.s = c.has_shift ? proj_to_aff(acc[1][l]) : aff_inf<G1Field>();
+            c.c = proj_to_aff(acc[0][0][l]);
+            c.has_shift = acc[0][1].count(l) != 0;
+            c.s = c.has_shift ? proj_to_aff(acc[0][1][l]) : aff_inf<G1Field>();
             P.comms[l] = c;
             comm_tobytes(c, bytes);
         }
@@ -295,13 +415,9 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     };
 
     laps.lap("setup");
-    // =========================== round 1 (prover.rs:216-404) ===========================
-    char* z_a = P.dev("z_a", n); char* z_b = P.dev("z_b", n);
-    ZK_TRY(P.rc);
-    ZK_TRY(zk_r1cs_matvec_dev(ctx, ix->r1cs, 0, z_dev, z_a, n));
-    ZK_TRY(zk_r1cs_matvec_dev(ctx, ix->r1cs, 1, z_dev, z_b, n));
+    // =========================== round 1 (prover.rs:216-404), every lane ===========================
     const size_t md = 3 * n + 2 - 3;                                             // mask polynomial degree, zk_bound = 1
-    char* rnd = P.dev("rnd", 3 + md + 1);
+    char* rnd = P.dev("rnd", 3 + md + 1);                                        // this party's (share of the) prover randomness: both lanes read it
     ZK_TRY(P.rc);
     {
         const size_t host_n = mask_on_device ? 3 : 3 + md + 1;
@@ -314,36 +430,48 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
             ZK_TRY(zk_fr_random_dev(ctx, key, 0, rnd + 96, md + 1));
         }
     }
-    char* xb = P.dev("x_poly", X.size);
-    P.d2d(xb, zb, X.size);
-    P.ntt(xb, X, 1);
-    const Poly x_poly{xb, X.size};
-    char* x_evals = P.fft(H, x_poly, "x_evals");
-    char* w_evals = P.dev("w_evals", n); char* tmp = P.dev("tmp_h", n);
-    ZK_TRY(P.rc);
-    ZK_TRY(zk_fr_gather_dev(ctx, zb, ix->w_idx, n, w_evals));
-    ZK_TRY(zk_fr_gather_dev(ctx, x_evals, ix->x_idx, n, tmp));
-    P.op(ZK_OP_SUB, w_evals, tmp, w_evals, n);
-    P.ntt(w_evals, H, 1);
-    const Poly w_h = P.blind(w_evals, n, rnd, "w_h");
     const size_t nwq = n + 1 - X.size;
-    char* wq = P.dev("w_poly", nwq); char* wr = P.dev("w_rem", X.size);
-    ZK_TRY(P.rc);
-    ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, w_h.p, n + 1, X.log, wq, wr));
-    if (!P.is_zero(wr, X.size)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: w polynomial is not divisible by v_X");
-    P.polys["w"] = Poly{wq, nwq};
-    char* za = P.dev("za_c", n); char* zbb = P.dev("zb_c", n);
-    P.d2d(za, z_a, n); P.d2d(zbb, z_b, n);
-    P.ntt(za, H, 1); P.ntt(zbb, H, 1);
-    P.polys["z_a"] = P.blind(za, n, rnd + 32, "z_a_poly");
-    P.polys["z_b"] = P.blind(zbb, n, rnd + 64, "z_b_poly");
-    char* mask = P.dev("mask", md + 1); char* mq = P.dev("mask_q", md + 1); char* mr = P.dev("mask_r", n);
-    P.d2d(mask, rnd + 96, md + 1);
-    ZK_TRY(P.rc);
-    ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, mask, md + 1, H.log, mq, mr));
-    P.op(ZK_OP_SUB, mask, mr, mask, 1);                                          // the sum over H becomes zero
-    P.polys["mask_poly"] = Poly{mask, md + 1};
-    ZK_TRY(P.rc);
+    char *z_a[2], *z_b[2], *xb[2], *wq[2], *mask[2], *tmp[2];
+    for (int l = 0; l < LANES; l++) {
+        Prover& Q = PL[l];
+        z_a[l] = Q.dev("z_a", n); z_b[l] = Q.dev("z_b", n);
+        ZK_TRY(Q.rc);
+        ZK_TRY(zk_r1cs_matvec_dev(ctx, ix->r1cs, 0, zb[l], z_a[l], n));
+        ZK_TRY(zk_r1cs_matvec_dev(ctx, ix->r1cs, 1, zb[l], z_b[l], n));
+        xb[l] = Q.dev("x_poly", X.size);
+        Q.d2d(xb[l], zb[l], X.size);
+        Q.ntt(xb[l], X, 1);
+        const Poly x_poly{xb[l], X.size};
+        char* x_evals = Q.fft(H, x_poly, "x_evals");
+        char* w_evals = Q.dev("w_evals", n);
+        tmp[l] = Q.dev("tmp_h", n);
+        ZK_TRY(Q.rc);
+        ZK_TRY(zk_fr_gather_dev(ctx, zb[l], ix->w_idx, n, w_evals));
+        ZK_TRY(zk_fr_gather_dev(ctx, x_evals, ix->x_idx, n, tmp[l]));
+        Q.op(ZK_OP_SUB, w_evals, tmp[l], w_evals, n);
+        Q.ntt(w_evals, H, 1);
+        const Poly w_h = Q.blind(w_evals, n, rnd, "w_h");
+        wq[l] = Q.dev("w_poly", nwq);
+        char* wr = Q.dev("w_rem", X.size);
+        ZK_TRY(Q.rc);
+        ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, w_h.p, n + 1, X.log, wq[l], wr));
+        // (over shares the remainder is a share of zero: the reference's assert!(remainder.is_zero()) cannot be evaluated locally)
+        if (!shared && !Q.is_zero(wr, X.size)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: w polynomial is not divisible by v_X");
+        Q.polys["w"] = Poly{wq[l], nwq};
+        char* za = Q.dev("za_c", n); char* zbb = Q.dev("zb_c", n);
+        Q.d2d(za, z_a[l], n); Q.d2d(zbb, z_b[l], n);
+        Q.ntt(za, H, 1); Q.ntt(zbb, H, 1);
+        Q.polys["z_a"] = Q.blind(za, n, rnd + 32, "z_a_poly");
+        Q.polys["z_b"] = Q.blind(zbb, n, rnd + 64, "z_b_poly");
+        mask[l] = Q.dev("mask", md + 1);
+        char* mq = Q.dev("mask_q", md + 1); char* mr = Q.dev("mask_r", n);
+        Q.d2d(mask[l], rnd + 96, md + 1);
+        ZK_TRY(Q.rc);
+        ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, mask[l], md + 1, H.log, mq, mr));
+        Q.op(ZK_OP_SUB, mask[l], mr, mask[l], 1);                                // the sum over H becomes zero
+        Q.polys["mask_poly"] = Poly{mask[l], md + 1};
+        ZK_TRY(Q.rc);
+    }
     laps.lap("polys");
     ZK_TRY(commit_round({"w", "z_a", "z_b", "mask_poly"}));
     laps.lap("commit");
@@ -351,6 +479,7 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
 
     laps.lap("round1");
     // =========================== round 2 (prover.rs:438-565) ===========================
+    // public: r(alpha, X) on H, t = sum_M eta_M M^T r, their evaluations over the multiplication domain (computed once)
     const HF v_h_alpha = H.vanishing(alpha), one = HF::one();
     char* elems = P.dev("h_elems", n);
     char* ra = P.dev("r_alpha", n);
@@ -366,48 +495,74 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     const HF etas[3] = {eta_a, eta_b, eta_c};
     for (int which = 0; which < 3; which++) {                                    // calculate_t on the transposed matrices
         ZK_TRY(P.rc);
-        ZK_TRY(zk_r1cs_matvec_dev(ctx, ix->r1cs_t, which, ra, which == 0 ? t_ev : tmp, n));
+        ZK_TRY(zk_r1cs_matvec_dev(ctx, ix->r1cs_t, which, ra, which == 0 ? t_ev : tmp[0], n));
         if (which == 0) P.scale(t_ev, etas[0], t_ev, n);
-        else { P.scale(tmp, etas[which], tmp, n); P.op(ZK_OP_ADD, t_ev, tmp, t_ev, n); }
+        else { P.scale(tmp[0], etas[which], tmp[0], n); P.op(ZK_OP_ADD, t_ev, tmp[0], t_ev, n); }
     }
     P.ntt(t_ev, H, 1);
-    P.polys["t"] = Poly{t_ev, n};
+    for (int l = 0; l < LANES; l++) PL[l].polys["t"] = Poly{t_ev, n};
     P.ntt(ra, H, 1);
     const Poly r_alpha_poly{ra, n};
-    char* zp = P.dev("z_poly", n + 1);                                           // z = w v_X + x
-    P.zero(zp, n + 1);
-    P.d2d(zp + 32 * X.size, wq, nwq);
-    P.op(ZK_OP_SUB, zp, wq, zp, nwq);
-    P.op(ZK_OP_ADD, zp, xb, zp, X.size);
-    const Poly z_poly{zp, n + 1};
     const Dom MUL(std::max(std::max(md + 1, n + 2 * n + 1), n + n + 1));
-    char* e_a = P.fft(MUL, P.polys["z_a"], "e_a"); char* e_b = P.fft(MUL, P.polys["z_b"], "e_b");
-    char* e_s = P.dev("e_s", MUL.size);
-    P.op(ZK_OP_MUL, e_a, e_b, e_s, MUL.size);                                    // z_a z_b: the one product of two witness vectors
-    P.scale(e_s, eta_c, e_s, MUL.size);
-    P.scale(e_a, eta_a, e_a, MUL.size);
-    P.op(ZK_OP_ADD, e_s, e_a, e_s, MUL.size);
-    P.scale(e_b, eta_b, e_b, MUL.size);
-    P.op(ZK_OP_ADD, e_s, e_b, e_s, MUL.size);
-    char* e_r = P.fft(MUL, r_alpha_poly, "e_r"); char* e_z = P.fft(MUL, z_poly, "e_z"); char* e_t = P.fft(MUL, P.polys["t"], "e_t");
-    P.op(ZK_OP_MUL, e_r, e_s, e_r, MUL.size);
-    P.op(ZK_OP_MUL, e_z, e_t, e_z, MUL.size);
-    P.op(ZK_OP_SUB, e_r, e_z, e_r, MUL.size);
-    P.ntt(e_r, MUL, 1);                                                          // q_1 (prover.rs:517-541)
-    P.op(ZK_OP_ADD, e_r, mask, e_r, md + 1);
-    char* hq = P.dev("h1_q", MUL.size - n); char* hr = P.dev("h1_r", n);
-    ZK_TRY(P.rc);
-    ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, e_r, MUL.size, H.log, hq, hr));
-    if (!P.is_zero(hr, 1)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: outer sum-check: the sum over H is not zero (unsatisfied constraint system)");
-    P.polys["g_1"] = Poly{hr + 32, n - 1};
-    P.polys["h_1"] = Poly{hq, std::min(MUL.size - n, 2 * n + 2 - 1)};
+    char* e_rp = P.fft(MUL, r_alpha_poly, "e_r"); char* e_tp = P.fft(MUL, P.polys["t"], "e_t");
+    char *e_a[2], *e_b[2], *e_s[2], *e_z[2];
+    for (int l = 0; l < LANES; l++) {
+        Prover& Q = PL[l];
+        char* zp = Q.dev("z_poly", n + 1);                                       // z = w v_X + x
+        Q.zero(zp, n + 1);
+        Q.d2d(zp + 32 * X.size, wq[l], nwq);
+        Q.op(ZK_OP_SUB, zp, wq[l], zp, nwq);
+        Q.op(ZK_OP_ADD, zp, xb[l], zp, X.size);
+        const Poly z_poly{zp, n + 1};
+        e_a[l] = Q.fft(MUL, Q.polys["z_a"], "e_a"); e_b[l] = Q.fft(MUL, Q.polys["z_b"], "e_b");
+        e_s[l] = Q.dev("e_s", MUL.size);
+        e_z[l] = Q.fft(MUL, z_poly, "e_z");
+        ZK_TRY(Q.rc);
+    }
+    // z_a z_b: the one product of two witness vectors (`DensePolynomial::mul` on MpcField = FieldShare::batch_mul)
+    if (!shared) P.op(ZK_OP_MUL, e_a[0], e_b[0], e_s[0], MUL.size);
+    else ZK_TRY(zk_shared_beaver_mul(nt, LANES, (const void* const*)e_a, (const void* const*)e_b, (void* const*)e_s, MUL.size, tx, ty, tz, "mp_bv"));
+    char *hq[2], *hr[2];
+    for (int l = 0; l < LANES; l++) {
+        Prover& Q = PL[l];
+        Q.scale(e_s[l], eta_c, e_s[l], MUL.size);
+        Q.scale(e_a[l], eta_a, e_a[l], MUL.size);
+        Q.op(ZK_OP_ADD, e_s[l], e_a[l], e_s[l], MUL.size);
+        Q.scale(e_b[l], eta_b, e_b[l], MUL.size);
+        Q.op(ZK_OP_ADD, e_s[l], e_b[l], e_s[l], MUL.size);
+        Q.op(ZK_OP_MUL, e_rp, e_s[l], e_s[l], MUL.size);                         // public * own value: local
+        Q.op(ZK_OP_MUL, e_z[l], e_tp, e_z[l], MUL.size);
+        Q.op(ZK_OP_SUB, e_s[l], e_z[l], e_s[l], MUL.size);
+        Q.ntt(e_s[l], MUL, 1);                                                   // q_1 (prover.rs:517-541)
+        Q.op(ZK_OP_ADD, e_s[l], mask[l], e_s[l], md + 1);
+        hq[l] = Q.dev("h1_q", MUL.size - n); hr[l] = Q.dev("h1_r", n);
+        ZK_TRY(Q.rc);
+        ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, e_s[l], MUL.size, H.log, hq[l], hr[l]));
+    }
+    {   // the outer sum-check's zero test (prover.rs:547-550): over shares the constant term is opened
+        bool zero_sum;
+        if (!shared) zero_sum = P.is_zero(hr[0], 1);
+        else {
+            char* zo = P.dev("zero_open", 1); char* zd = P.dev("zero_dx", 1);
+            ZK_TRY(P.rc);
+            if (LANES == 2) ZK_TRY(zk_shared_spdz_open_vec(nt, hr[0], hr[1], 1, zo, zd));
+            else ZK_TRY(nt.open_vec(hr[0], 1, zo));
+            zero_sum = P.is_zero(zo, 1);
+        }
+        ZK_TRY(P.rc);
+        if (!zero_sum) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: outer sum-check: the sum over H is not zero (unsatisfied constraint system)");
+    }
+    for (int l = 0; l < LANES; l++) {
+        PL[l].polys["g_1"] = Poly{hr[l] + 32, n - 1};
+        PL[l].polys["h_1"] = Poly{hq[l], std::min(MUL.size - n, 2 * n + 2 - 1)};
+    }
     laps.lap("polys");
     ZK_TRY(commit_round({"t", "g_1", "h_1"}));
     laps.lap("commit");
     const HF beta = sample_outside(H);
 
     laps.lap("round2");
-    // =========================== round 3 (prover.rs:583-716) ===========================
+    // =========================== round 3 (prover.rs:583-716): public values only ===========================
     const HF vv = v_h_alpha * H.vanishing(beta);
     char* f_ev = P.dev("f_ev", K.size);
     char* a_ev = P.dev("a_ev", B.size); char* b_ev = P.dev("b_ev", B.size);
@@ -417,7 +572,6 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
       ZK_TRY(zk_marlin_round3_ab_evals_dev(ctx, ix->on_b, B.size, &al, &be, et, &v, a_ev, b_ev)); }
     P.ntt(f_ev, K, 1);
     const Poly f{f_ev, K.size};
-    P.polys["g_2"] = Poly{f_ev + 32, K.size - 1};
     char* f_on_b = P.fft(B, f, "f_on_b");                                       // a - b f on B itself (degree <= 4|K| - 4 < |B|)
     P.op(ZK_OP_MUL, b_ev, f_on_b, b_ev, B.size);
     P.op(ZK_OP_SUB, a_ev, b_ev, a_ev, B.size);
@@ -426,7 +580,10 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     ZK_TRY(P.rc);
     ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, a_ev, B.size, K.log, h2q, h2r));
     if (!P.is_zero(h2r, K.size)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: inner sum-check: a - b f is not divisible by v_K");
-    P.polys["h_2"] = Poly{h2q, B.size - K.size};
+    for (int l = 0; l < LANES; l++) {
+        PL[l].polys["g_2"] = Poly{f_ev + 32, K.size - 1};
+        PL[l].polys["h_2"] = Poly{h2q, B.size - K.size};
+    }
     laps.lap("polys");
     ZK_TRY(commit_round({"g_2", "h_2"}));
     laps.lap("commit");
@@ -435,20 +592,32 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     laps.lap("round3");
     // =========================== evaluations and linear combinations ===========================
     std::map<std::string, HF> single;
-    {   // the thirteen evaluations of the query set in one batch (two launches, one copy back)
+    {   // the evaluations of the query set in one batch (two launches, one copy back); z_b and g_1 are shared: every lane's
+        // evaluation, opened (`evaluations.publicize()`, lib.rs:296)
         std::vector<std::pair<std::string, HF>> want = {{"z_b", beta}, {"g_1", beta}, {"t", beta}, {"g_2", gamma}};
         for (const char* m : {"a", "b", "c"})
             for (const char* part : {"_row", "_col", "_row_col"}) want.push_back({std::string(m) + part, gamma});
         std::vector<zk_poly_ref> refs;
-        std::vector<zk_fr> pts(want.size()), vals(want.size());
+        std::vector<zk_fr> pts;
         for (size_t i = 0; i < want.size(); i++) {
             const Poly& p = P.polys[want[i].first];
             refs.push_back(zk_poly_ref{p.p, p.n});
-            pts[i] = want[i].second.abi();
+            pts.push_back(want[i].second.abi());
         }
-        ZK_TRY(zk_poly_evaluate_batch_dev(ctx, refs.data(), pts.data(), want.size(), vals.data()));
+        if (LANES == 2)
+            for (const char* l : {"z_b", "g_1"}) { const Poly& p = PL[1].polys[l]; refs.push_back(zk_poly_ref{p.p, p.n}); pts.push_back(beta.abi()); }
+        std::vector<zk_fr> vals(refs.size());
+        ZK_TRY(zk_poly_evaluate_batch_dev(ctx, refs.data(), pts.data(), refs.size(), vals.data()));
         std::map<std::string, HF> at;
         for (size_t i = 0; i < want.size(); i++) at[want[i].first] = HF::from_abi(vals[i]);
+        if (shared) {
+            std::vector<HF> frs[2] = {{at["z_b"], at["g_1"]}, {}}, ofr;
+            if (LANES == 2) frs[1] = {HF::from_abi(vals[want.size()]), HF::from_abi(vals[want.size() + 1])};
+            std::vector<zk_g1_projective> nog[2], og;
+            ZK_TRY(open_small<LANES>(nt, frs, nog, ofr, og));
+            at["z_b"] = ofr[0];
+            at["g_1"] = ofr[1];
+        }
         for (const char* l : {"z_b", "g_1", "t", "g_2"}) single[l] = at[l];
         const HF ba0 = beta * alpha;
         for (const char* m : {"a", "b", "c"}) {
@@ -501,13 +670,16 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
 
     laps.lap("evals+lc");
     // =========================== open_combinations (marlin/mod.rs:213-306, marlin_pc/mod.rs:245-340) ===========================
+    // Over shares: the witness of a share combination is a share of the witness.  A combination with a shared oracle in it runs on
+    // every lane, public oracles entering it on the leader only (shift(): in both lanes, mac_share = 1 there), and its witness
+    // (and random_v) is opened; a combination of public oracles only (the query point gamma) is computed alike by every party.
     const std::vector<std::string> QUERY[2] = {{"g_1", "outer_sumcheck", "t", "z_b"}, {"a_denom", "b_denom", "c_denom", "g_2", "inner_sumcheck"}};
     const HF points[2] = {beta, gamma};
     std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
-    size_t counts[2] = {0, 0};
+    size_t counts[2][2] = {{0, 0}, {0, 0}};                                      // [query point][lane]
     std::vector<std::future<zk_g1_projective>> extra[2];                         // the blinding witnesses: host threads, joined after the batch
     auto small_async = [&](const std::vector<HF>& c) { return (blind_deferred ? std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); }) : zk_async([&gamma_pts, c] { return small_msm(gamma_pts, c); })); };
-    bool has_rv[2] = {false, false};
+    bool has_rv[2] = {false, false}, q_shared[2] = {false, false};
     HF rvs[2];
     for (int q = 0; q < 2; q++) {
         const HF z = points[q];
@@ -533,16 +705,38 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
                 acc_scaled(sr, P.rands[ps[0].label].second, c1);
             }
         }
+        bool any_shared = false;
+        for (auto& t : terms) any_shared = any_shared || (shared && label_shared(t.first.c_str()));
+        q_shared[q] = any_shared;
         size_t cn = 0;
         for (auto& t : terms) cn = std::max(cn, P.polys[t.first].n);
-        char* comb = P.dev("comb" + std::to_string(q), cn); char* ctmp = P.dev("combtmp", cn);
-        P.zero(comb, cn);
-        for (auto& t : terms) { const Poly& p = P.polys[t.first]; P.scale(p.p, t.second, ctmp, p.n); P.op(ZK_OP_ADD, comb, ctmp, comb, p.n); }
-        char* quo = P.dev("quo" + std::to_string(q), cn);
-        ZK_TRY(P.rc);
-        { zk_fr zz = z.abi(); ZK_TRY(zk_poly_divide_by_linear_dev(ctx, comb, cn, &zz, quo, nullptr)); }
-        const size_t first_job = jb.size();
-        jb.push_back(P.pg); joff.push_back(0); jsc.push_back(quo); jlen.push_back(cn - 1);
+        for (int l = 0; l < (any_shared ? LANES : 1); l++) {
+            Prover& Q = PL[l];
+            char* comb = Q.dev("comb" + std::to_string(q), cn); char* ctmp = Q.dev("combtmp", cn);
+            Q.zero(comb, cn);
+            for (auto& t : terms) {
+                if (any_shared && !label_shared(t.first.c_str()) && !leader) continue;   // a public oracle in a shared combination: the leader's
+                const Poly& p = Q.polys[t.first];
+                Q.scale(p.p, t.second, ctmp, p.n);
+                Q.op(ZK_OP_ADD, comb, ctmp, comb, p.n);
+            }
+            char* quo = Q.dev("quo" + std::to_string(q), cn);
+            ZK_TRY(Q.rc);
+            { zk_fr zz = z.abi(); ZK_TRY(zk_poly_divide_by_linear_dev(ctx, comb, cn, &zz, quo, nullptr)); }
+            const size_t first_job = jb.size();
+            jb.push_back(P.pg); joff.push_back(0); jsc.push_back(quo); jlen.push_back(cn - 1);
+            int si = 0;
+            for (auto& sh : shifted) {
+                if (any_shared && !label_shared(sh.first.c_str()) && !leader) continue;
+                const Poly& p = Q.polys[sh.first];
+                char* wq2 = Q.dev("swit" + std::to_string(q) + "_" + std::to_string(si++), p.n);
+                ZK_TRY(Q.rc);
+                { zk_fr zz = z.abi(); ZK_TRY(zk_poly_divide_by_linear_dev(ctx, p.p, p.n, &zz, wq2, nullptr)); }
+                Q.scale(wq2, sh.second, wq2, p.n - 1);
+                jb.push_back(P.pg); joff.push_back(P.max_degree - P.bounds[sh.first]); jsc.push_back(wq2); jlen.push_back(p.n - 1);
+            }
+            counts[q][l] = jb.size() - first_job;
+        }
         bool hiding = false;
         for (auto& v : r_comb) hiding = hiding || !v.is_zero();
         if (hiding) {
@@ -550,22 +744,14 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
             has_rv[q] = true;
             rvs[q] = host_eval(r_comb, z);
         }
-        int si = 0;
         for (auto& sh : shifted) {
-            const Poly& p = P.polys[sh.first];
-            char* wq2 = P.dev("swit" + std::to_string(q) + "_" + std::to_string(si++), p.n);
-            ZK_TRY(P.rc);
-            { zk_fr zz = z.abi(); ZK_TRY(zk_poly_divide_by_linear_dev(ctx, p.p, p.n, &zz, wq2, nullptr)); }
-            P.scale(wq2, sh.second, wq2, p.n - 1);
-            jb.push_back(P.pg); joff.push_back(P.max_degree - P.bounds[sh.first]); jsc.push_back(wq2); jlen.push_back(p.n - 1);
             const std::vector<HF>& sb = P.rands[sh.first].second;
             if (!sb.empty()) acc_scaled(srw, host_div_linear(sb, z), sh.second);
         }
         if (!srw.empty()) extra[q].push_back(small_async(srw));
         if (!shifted.empty() && has_rv[q]) rvs[q] = rvs[q] + host_eval(sr, z);
-        counts[q] = jb.size() - first_job;
     }
-    ZK_TRY(P.rc);
+    ZK_TRY(lanes_rc());
     std::vector<zk_g1_projective> outs(jb.size());
     std::vector<void*> outp(jb.size());
     for (size_t i = 0; i < jb.size(); i++) outp[i] = &outs[i];
@@ -577,11 +763,24 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     {
         size_t k = 0;
         for (int q = 0; q < 2; q++) {
-            zk_g1_projective w = outs[k];
-            for (size_t i = 1; i < counts[q]; i++) { zk_g1_projective t; zk_g1_add(&w, &outs[k + i], &t); w = t; }
-            for (auto& e : extra_pts[q]) { zk_g1_projective t; zk_g1_add(&w, &e, &t); w = t; }
-            k += counts[q];
-            wit[q] = proj_to_aff(w);
+            zk_g1_projective wl[2];
+            const int nl = q_shared[q] ? LANES : 1;
+            for (int l = 0; l < nl; l++) {
+                zk_g1_projective w = outs[k];
+                for (size_t i = 1; i < counts[q][l]; i++) { zk_g1_projective t; zk_g1_add(&w, &outs[k + i], &t); w = t; }
+                for (auto& e : extra_pts[q]) { zk_g1_projective t; zk_g1_add(&w, &e, &t); w = t; }    // own randomness: the same on the MAC lane
+                k += counts[q][l];
+                wl[l] = w;
+            }
+            if (q_shared[q]) {                                                  // the witness (and random_v) of a shared combination: opened
+                std::vector<HF> frs[2], ofr;
+                std::vector<zk_g1_projective> pts[2], og;
+                for (int l = 0; l < LANES; l++) { pts[l].push_back(wl[l]); if (has_rv[q]) frs[l].push_back(rvs[q]); }
+                ZK_TRY(open_small<LANES>(nt, frs, pts, ofr, og));
+                wl[0] = og[0];
+                if (has_rv[q]) rvs[q] = ofr[0];
+            }
+            wit[q] = proj_to_aff(wl[0]);
         }
     }
 
@@ -614,6 +813,49 @@ extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_
     if (out.size() > cap) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: output buffer too small");
     memcpy(proof_out, out.data(), out.size());
     *proof_len = out.size();
+    if (bytes_sent) *bytes_sent = nt.bytes;
     return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
+                               const void* z_dev, zk_rng* zk_rng_, int mask_on_device, uint8_t* proof_out, size_t cap, size_t* proof_len) {
+    ZK_API_BEGIN(ctx)
+    if (!ctx || !ix || !powers_g || !powers_gamma_g || !z_dev || !zk_rng_ || !proof_out || !proof_len) return ZK_ERR_ARG;
+    const void* z[2] = {z_dev, nullptr};
+    const void* none[2] = {nullptr, nullptr};
+    return marlin_impl<1>(ctx, ix, powers_g, powers_gamma_g, z, zk_rng_, mask_on_device, false, none, none, none, nullptr, proof_out, cap,
+                          proof_len, nullptr);
+    ZK_API_END
+}
+
+// MpcMarlin::prove over additive shares (src/marlin.rs:56): z_share_dev = this party's share of the padded assignment, zk_rng =
+// this party's own generator (its share of the prover's randomness); tx / ty / tz = Beaver triple shares for the one product of
+// round 2 (4|H| elements... the multiplication domain) or NULL for DummyFieldTripleSource.  Every party returns the same bytes.
+extern "C" int zk_marlin_prove_shared(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
+                                      const void* z_share_dev, zk_rng* zk_rng_, int mask_on_device, const void* tx, const void* ty,
+                                      const void* tz, const zk_net_vtable* net, uint8_t* proof_out, size_t cap, size_t* proof_len,
+                                      uint64_t* bytes_sent) {
+    ZK_API_BEGIN(ctx)
+    if (!ctx || !ix || !powers_g || !powers_gamma_g || !z_share_dev || !zk_rng_ || !proof_out || !proof_len) return ZK_ERR_ARG;
+    const void* z[2] = {z_share_dev, nullptr};
+    const void *txs[2] = {tx, nullptr}, *tys[2] = {ty, nullptr}, *tzs[2] = {tz, nullptr};
+    return marlin_impl<1>(ctx, ix, powers_g, powers_gamma_g, z, zk_rng_, mask_on_device, true, txs, tys, tzs, net, proof_out, cap, proof_len,
+                          bytes_sent);
+    ZK_API_END
+}
+
+// ... over SPDZ shares (the `malicious` feature; BASELINE config 5's prover): lanes [0] = share, [1] = MAC share.
+extern "C" int zk_marlin_prove_shared_spdz(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
+                                           const void* const z_lanes_dev[2], zk_rng* zk_rng_, int mask_on_device,
+                                           const void* const tx_lanes[2], const void* const ty_lanes[2], const void* const tz_lanes[2],
+                                           const zk_net_vtable* net, uint8_t* proof_out, size_t cap, size_t* proof_len, uint64_t* bytes_sent) {
+    ZK_API_BEGIN(ctx)
+    if (!ctx || !ix || !powers_g || !powers_gamma_g || !z_lanes_dev || !z_lanes_dev[0] || !z_lanes_dev[1] || !zk_rng_ || !proof_out || !proof_len)
+        return ZK_ERR_ARG;
+    const void* none[2] = {nullptr, nullptr};
+    return marlin_impl<2>(ctx, ix, powers_g, powers_gamma_g, z_lanes_dev, zk_rng_, mask_on_device, true, tx_lanes ? tx_lanes : none,
+                          ty_lanes ? ty_lanes : none, tz_lanes ? tz_lanes : none, net, proof_out, cap, proof_len, bytes_sent);
     ZK_API_END
 }

@@ -914,12 +914,9 @@ def prove(keys: IndexKeys, assignment_dev: DevBuf, zk_rng, mask_on_device: bool 
     return MarlinProof([[comms[l] for l in rnd] for rnd in ROUND_LABELS], evaluations, pc_proof, ch)
 
 
-def prove_native(keys: IndexKeys, assignment_dev: DevBuf, zk_rng, mask_on_device: bool = False) -> bytes:
-    """Marlin::prove through the library's single entry point zk_marlin_prove (csrc/marlin_prove.hip): the same sequence as
-    `prove` above, on the host in C++.  Returns the CanonicalSerialize bytes of the proof."""
-    import ctypes as C
-    index, srs = keys.index, keys.srs
-    ctx = index.ctx
+def native_index(keys: IndexKeys):
+    """The index as the C ABI's zk_marlin_index (include/zkmpc_hip.h): (struct, objects that must outlive the call)."""
+    index = keys.index
     d = _lib.MarlinIndex()
     d.num_constraints, d.num_variables = index.num_constraints, index.num_variables
     d.num_non_zero, d.num_instance = index.num_non_zero, index.num_instance
@@ -935,6 +932,16 @@ def prove_native(keys: IndexKeys, assignment_dev: DevBuf, zk_rng, mask_on_device
     d.w_idx, d.x_idx = d_iw.ptr, d_ix.ptr
     ivk = keys.ivk_bytes()
     d.ivk_bytes, d.ivk_len = ivk, len(ivk)
+    return d, (polys, d_iw, d_ix, ivk)
+
+
+def prove_native(keys: IndexKeys, assignment_dev: DevBuf, zk_rng, mask_on_device: bool = False) -> bytes:
+    """Marlin::prove through the library's single entry point zk_marlin_prove (csrc/marlin_prove.hip): the same sequence as
+    `prove` above, on the host in C++.  Returns the CanonicalSerialize bytes of the proof."""
+    import ctypes as C
+    srs = keys.srs
+    ctx = keys.index.ctx
+    d, _keep = native_index(keys)
     cap = ctx.lib.zk_marlin_proof_max_size()
     out = (C.c_uint8 * cap)()
     n = C.c_size_t()

@@ -744,6 +744,13 @@ class Party:
         proof on the summed inputs and summed randomness."""
         return _marlin_prove_full(self, keys, [z_share], zk_rng, triple_fn, spdz=False, mask_on_device=mask_on_device)
 
+    def marlin_prove_shared_native(self, keys, z_share, zk_rng, triple=None, mask_on_device=False) -> bytes:
+        """MpcMarlin::prove over additive shares as ONE library call (zk_marlin_prove_shared): what a Rust host would bind.
+        Arguments as marlin_prove_full (triple: three device pointers of |MUL| Beaver shares, or None for dummy triples);
+        returns Proof::serialize's bytes -- the same bytes as marlin_prove_full(...).to_bytes(), which stays the second
+        implementation the tests compare with."""
+        return _marlin_prove_native(self, keys, [z_share], zk_rng, triple, mask_on_device)
+
 # ------------------------------------------------------------------------------------------------
 # SPDZ (malicious-majority backend): every share carries a MAC share; opens are MAC-checked
 # ------------------------------------------------------------------------------------------------
@@ -1010,6 +1017,43 @@ class SpdzParty(Party):
         open MAC-checked.  The MAC lane of this party's fresh randomness is the share itself (key alpha = 1 on the leader:
         sum of MAC shares = sum of shares), as the reference's from_add_shared does."""
         return _marlin_prove_full(self, keys, list(z_share), zk_rng, triple_fn, spdz=True, mask_on_device=mask_on_device)
+
+
+    def marlin_prove_shared_spdz_native(self, keys, z_share, zk_rng, triple=None, mask_on_device=False) -> bytes:
+        """The same over SPDZ shares (zk_marlin_prove_shared_spdz): z_share = (share, MAC) DevBufs, triple = ((x, x_mac), (y, y_mac),
+        (z, z_mac)) device pointers or None.  A failed MAC check raises MacCheckError."""
+        return _marlin_prove_native(self, keys, list(z_share), zk_rng, triple, mask_on_device)
+
+
+def _marlin_prove_native(party, keys, z_lanes, zk_rng, triple, mask_on_device):
+    import ctypes as C
+    from . import marlin as DM
+    ctx = party.be.ctx
+    srs = keys.srs
+    d, _keep_index = DM.native_index(keys)
+    vt, errors, _keep = party._net_vtable()
+    net = C.byref(vt) if party.net.n > 1 else None
+    cap = ctx.lib.zk_marlin_proof_max_size()
+    out = (C.c_uint8 * cap)()
+    n, sent = C.c_size_t(), C.c_uint64(0)
+    ptr = lambda v: int(getattr(v, "ptr", v))
+    if len(z_lanes) == 1:
+        t = [C.c_void_p(ptr(x)) for x in triple] if triple is not None else [None, None, None]
+        rc = ctx.lib.zk_marlin_prove_shared(ctx.h, C.byref(d), srs.powers_g.h, srs.powers_gamma_g.h, C.c_void_p(ptr(z_lanes[0])), zk_rng.h,
+                                            int(mask_on_device), t[0], t[1], t[2], net, out, cap, C.byref(n), C.byref(sent))
+    else:
+        P2 = C.c_void_p * 2
+        lanes = lambda v: P2(ptr(v[0]), ptr(v[1]))
+        t = [lanes(triple[k]) for k in range(3)] if triple is not None else [None, None, None]
+        rc = ctx.lib.zk_marlin_prove_shared_spdz(ctx.h, C.byref(d), srs.powers_g.h, srs.powers_gamma_g.h, lanes(z_lanes), zk_rng.h,
+                                                 int(mask_on_device), t[0], t[1], t[2], net, out, cap, C.byref(n), C.byref(sent))
+    if errors:
+        raise errors[0]
+    if rc == -5:
+        raise MacCheckError((ctx.lib.zk_last_error(ctx.h) or b"").decode())
+    ctx._ck(rc)
+    party.bytes_sent += int(sent.value)
+    return bytes(out[:n.value])
 
 
 def _marlin_prove_full(party, keys, z_lanes, zk_rng, triple_fn, spdz: bool, mask_on_device: bool = False):
