@@ -371,10 +371,16 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
             keep.append(party._keep)
         zb = [types.SimpleNamespace(ptr=p) for p in zl]
 
-        def step():
+        def python_step():
             if args.spdz:
                 return party.marlin_prove_full_spdz(keys, (zb[0], zb[1]), Rng.from_seed(seed, 20), mask_on_device=True)
             return party.marlin_prove_full(keys, zb[0], Rng.from_seed(seed, 20), mask_on_device=True)
+
+        def native_step():      # one library call per proof (zk_marlin_prove_shared[_spdz]); --python-mpc times the mpc.py sequence
+            if args.spdz:
+                return party.marlin_prove_shared_spdz_native(keys, (zb[0], zb[1]), Rng.from_seed(seed, 20), mask_on_device=True)
+            return party.marlin_prove_shared_native(keys, zb[0], Rng.from_seed(seed, 20), mask_on_device=True)
+        step = python_step if args.python_mpc else native_step
 
     def barrier():
         if dist is not None:
@@ -398,15 +404,16 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if dist is not None:        # (every rank: the Python sequence is a collective too) the parsed proof for the oracle's verifier
+        obj = proof if args.python_mpc else python_step()
+        proof_bytes = proof.serialize(ctx) if args.python_mpc else proof
+        same = None if args.python_mpc else bool(obj.serialize(ctx) == proof_bytes)
     if rank != 0:
         return
     if dist is None:
         obj = DM.prove(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
         same = obj.serialize(ctx) == proof
         proof_bytes = proof
-    else:
-        obj, same = proof, None
-        proof_bytes = proof.serialize(ctx)
     verdict = {}
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -445,6 +452,7 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
         out["bytes_sent_per_party_per_proof"] = int(sent_timed // max(K, 1))
         out["aggregate_constraint_shares_per_s"] = round(n * K / dt * world, 1)
         out["opens_in_timed_proofs"] = opens_timed
+        out["prover_entry"] = "mpc.py sequence" if args.python_mpc else ("zk_marlin_prove_shared_spdz" if args.spdz else "zk_marlin_prove_shared")
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
