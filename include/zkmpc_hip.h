@@ -363,25 +363,6 @@ typedef struct {
 size_t zk_marlin_proof_max_size(void);
 int zk_marlin_prove(zk_ctx* ctx, const zk_marlin_index* index, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
                     const void* z_dev, zk_rng* zk_rng, int mask_on_device, uint8_t* proof_out, size_t cap, size_t* proof_len);
-/* The collaborative Marlin prover as one call: MpcMarlin::prove (src/marlin.rs:56; arkworks/marlin/src/lib.rs:152-319 with
- * F = MpcField<Fr>) over this party's ADDITIVE shares.  z_share_dev = the party's share of the padded assignment (instance part
- * included: shared as from_public, opened for the transcript), zk_rng = the party's own generator (its draws are its shares of the
- * prover's randomness, in Marlin::prove's order); tx / ty / tz = device vectors of Beaver triple shares for the ONE product of two
- * witness vectors (z_A z_B over the multiplication domain: the power of two >= 3|H|), or all NULL for DummyFieldTripleSource
- * (mpc-algebra/src/share/additive.rs:352-375).  `net` as in zk_groth16_prove_shared.  Opens per proof: the public input, the
- * masked Beaver operands (2 x |MUL| elements), one element for the outer sum-check's zero test, the round commitments of the
- * witness-dependent oracles (w, z_a, z_b, mask_poly | g_1, h_1), the evaluations z_b(beta), g_1(beta), and the opening witness
- * and random_v at beta.  Every party writes the same proof bytes (Proof::serialize). */
-int zk_marlin_prove_shared(zk_ctx* ctx, const zk_marlin_index* index, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
-                           const void* z_share_dev, zk_rng* zk_rng, int mask_on_device, const void* tx, const void* ty, const void* tz,
-                           const zk_net_vtable* net, uint8_t* proof_out, size_t cap, size_t* proof_len, uint64_t* bytes_sent);
-/* ... over SPDZ shares (the `malicious` feature, mpc-algebra/src/share/spdz.rs; BASELINE config 5's prover): every *_lanes[2] is
- * {share, MAC share}.  Everything linear runs on both lanes; every open is MAC-checked (a failure returns ZK_ERR_MAC and no
- * proof).  The MAC lane of this party's fresh randomness is the share itself (from_add_shared, MAC key 1 held by the leader). */
-int zk_marlin_prove_shared_spdz(zk_ctx* ctx, const zk_marlin_index* index, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
-                                const void* const z_lanes_dev[2], zk_rng* zk_rng, int mask_on_device, const void* const tx_lanes[2],
-                                const void* const ty_lanes[2], const void* const tz_lanes[2], const zk_net_vtable* net,
-                                uint8_t* proof_out, size_t cap, size_t* proof_len, uint64_t* bytes_sent);
 
 /* ---- SHE ring arithmetic of the preprocessing phase (row a15) ----
  * Elements are ark_mnt4_753::Fq = Fp768 (12 x u64 little-endian, Montgomery R = 2^768), the `Fq` of src/she.rs:17.
@@ -456,6 +437,26 @@ int zk_groth16_prove_shared_spdz(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1
                                  const zk_fr r_lanes[2], const zk_fr s_lanes[2], const void* const tx_lanes_dev[2],
                                  const void* const ty_lanes_dev[2], const void* const tz_lanes_dev[2], const zk_net_vtable* net,
                                  uint8_t proof[192], uint64_t* bytes_sent);
+
+/* The collaborative Marlin prover as one call: MpcMarlin::prove (src/marlin.rs:56; arkworks/marlin/src/lib.rs:152-319 with
+ * F = MpcField<Fr>) over this party's ADDITIVE shares.  z_share_dev = the party's share of the padded assignment (instance part
+ * included: shared as from_public, opened for the transcript), zk_rng = the party's own generator (its draws are its shares of the
+ * prover's randomness, in Marlin::prove's order); tx / ty / tz = device vectors of Beaver triple shares for the ONE product of two
+ * witness vectors (z_A z_B over the multiplication domain: the power of two >= 3|H|), or all NULL for DummyFieldTripleSource
+ * (mpc-algebra/src/share/additive.rs:352-375).  `net` as in zk_groth16_prove_shared.  Opens per proof: the public input, the
+ * masked Beaver operands (2 x |MUL| elements), one element for the outer sum-check's zero test, the round commitments of the
+ * witness-dependent oracles (w, z_a, z_b, mask_poly | g_1, h_1), the evaluations z_b(beta), g_1(beta), and the opening witness
+ * and random_v at beta.  Every party writes the same proof bytes (Proof::serialize). */
+int zk_marlin_prove_shared(zk_ctx* ctx, const zk_marlin_index* index, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
+                           const void* z_share_dev, zk_rng* zk_rng, int mask_on_device, const void* tx, const void* ty, const void* tz,
+                           const zk_net_vtable* net, uint8_t* proof_out, size_t cap, size_t* proof_len, uint64_t* bytes_sent);
+/* ... over SPDZ shares (the `malicious` feature, mpc-algebra/src/share/spdz.rs; BASELINE config 5's prover): every *_lanes[2] is
+ * {share, MAC share}.  Everything linear runs on both lanes; every open is MAC-checked (a failure returns ZK_ERR_MAC and no
+ * proof).  The MAC lane of this party's fresh randomness is the share itself (from_add_shared, MAC key 1 held by the leader). */
+int zk_marlin_prove_shared_spdz(zk_ctx* ctx, const zk_marlin_index* index, const zk_bases* powers_g, const zk_bases* powers_gamma_g,
+                                const void* const z_lanes_dev[2], zk_rng* zk_rng, int mask_on_device, const void* const tx_lanes[2],
+                                const void* const ty_lanes[2], const void* const tz_lanes[2], const zk_net_vtable* net,
+                                uint8_t* proof_out, size_t cap, size_t* proof_len, uint64_t* bytes_sent);
 
 /* ---- share algebra on device vectors (rows a11, a13) ------------------------------------- */
 /* out[i] = sum_p gathered[p*n + i] mod r: the receive side of AdditiveFieldShare::batch_open

@@ -29,6 +29,18 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_lib.PROTOTYPES) == syms
 
 
+def test_header_is_plain_c():
+    """include/zkmpc_hip.h is the boundary a cgo / Rust-bindgen / ctypes host reads: it must parse as C99 on its own (every type
+    declared before its first use, no C++ in the signatures)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    r = subprocess.run(["gcc", "-x", "c", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", os.path.join(ROOT, "include", "zkmpc_hip.h")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
