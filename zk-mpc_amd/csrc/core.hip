@@ -13,7 +13,22 @@ extern "C" int zk_selftest_exception_barrier(int kind) {
     if (kind == 1) throw std::runtime_error("selftest");
     if (kind == 2) throw 42;
     if (kind == 3) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
-    if (kind == 4) return zk_async([] { return 7; }).get() == 7 ? ZK_OK : ZK_ERR_STATE;
+    if (kind == 4) {       // the helper pool: nested waits (a task that waits for tasks) finish, results and exceptions arrive
+        ZkHostPool pool;
+        auto outer = pool.submit([&] {
+            int s = 0;
+            std::vector<std::future<int>> in;
+            for (int i = 0; i < 8; i++) in.push_back(pool.submit([i] { return i; }));
+            for (auto& f : in) s += f.get();
+            return s;
+        });
+        auto bad = pool.submit([]() -> int { throw std::runtime_error("task"); });
+        if (outer.get() != 28) return ZK_ERR_STATE;
+        try { (void)bad.get(); return ZK_ERR_STATE; } catch (const std::runtime_error&) {}
+        const size_t after_first = pool.threads();
+        for (int r = 0; r < 4; r++) if (pool.submit([r] { return r; }).get() != r) return ZK_ERR_STATE;
+        return pool.threads() == after_first ? ZK_OK : ZK_ERR_STATE;      // steady state: no new threads
+    }
     return ZK_ERR_ARG;
     ZK_API_END
 }

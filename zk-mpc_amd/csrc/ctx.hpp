@@ -6,13 +6,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <condition_variable>
+#include <deque>
 #include <exception>
+#include <functional>
 #include <future>
+#include <memory>
 #include <map>
 #include <mutex>
 #include <new>
 #include <string>
 #include <system_error>
+#include <thread>
 #include <vector>
 
 #define ZK_OK 0
@@ -23,6 +28,72 @@
 #define ZK_ERR_MAC -5
 
 struct zk_domain;  // ntt.hip
+
+// The context's host helper threads (window Horner chains, the O(1) scalar multiplications of a proof, Marlin's blinding
+// terms: ~20 short tasks per proof).  Workers are created on demand and then kept: a task is queued only when an idle worker
+// will take it, otherwise a new worker is started first -- so a task that waits for other tasks can never starve them -- and
+// if the system refuses another thread the task runs in the caller.  After the first proof no thread is created any more.
+class ZkHostPool {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    std::vector<std::thread> workers;
+    size_t idle = 0;
+    bool stop = false;
+
+    void run() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            idle++;
+            cv.wait(lk, [&] { return stop || !q.empty(); });
+            idle--;
+            if (q.empty()) return;                  // stop, and nothing left to do
+            std::function<void()> job = std::move(q.front());
+            q.pop_front();
+            lk.unlock();
+            job();                                  // (a packaged_task: exceptions land in its future)
+            lk.lock();
+        }
+    }
+
+   public:
+    ZkHostPool() = default;
+    ZkHostPool(const ZkHostPool&) = delete;
+    ZkHostPool& operator=(const ZkHostPool&) = delete;
+    ~ZkHostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : workers) t.join();
+    }
+    size_t threads() {
+        std::lock_guard<std::mutex> lk(m);
+        return workers.size();
+    }
+    template <class Fn>
+    auto submit(Fn&& fn) -> std::future<decltype(fn())> {
+        using R = decltype(fn());
+        auto task = std::make_shared<std::packaged_task<R()>>(std::forward<Fn>(fn));
+        std::future<R> fut = task->get_future();
+        bool inline_run = false;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (q.size() + 1 > idle) {              // every queued task has an idle worker of its own, or gets a new one
+                try {
+                    workers.emplace_back([this] { run(); });
+                } catch (const std::system_error&) {
+                    inline_run = true;              // thread exhaustion must not fail a proof
+                }
+            }
+            if (!inline_run) q.emplace_back([task] { (*task)(); });
+        }
+        if (inline_run) (*task)();
+        else cv.notify_one();
+        return fut;
+    }
+};
 
 struct zk_ctx {
     int device = 0;
@@ -57,6 +128,7 @@ struct zk_ctx {
     struct Timer { float ms = 0; int count = 0; };
     std::map<std::string, Timer> timers;
     bool profiling = false;
+    ZkHostPool pool;                // host helper threads (last member: joined first when the context goes)
 };
 
 #define ZK_HIP(ctx, expr)                                                                         \
@@ -120,15 +192,10 @@ static inline int zk_api_guarded(zk_ctx* ctx, Fn&& body) noexcept {
         return ZK_ERR_STATE;
     }
 }
-// A host-side helper task (window Horner chains, the O(1) scalar multiplications of a proof, Marlin's blinding terms): on its
-// own thread when one can be had, otherwise run by whoever waits for it -- thread exhaustion must not fail a proof.
+// A host-side helper task on the context's worker pool.
 template <class Fn>
-static inline auto zk_async(Fn&& fn) -> std::future<decltype(fn())> {
-    try {
-        return std::async(std::launch::async, fn);
-    } catch (const std::system_error&) {
-        return std::async(std::launch::deferred, fn);
-    }
+static inline auto zk_async(zk_ctx* ctx, Fn&& fn) -> std::future<decltype(fn())> {
+    return ctx->pool.submit(std::forward<Fn>(fn));
 }
 
 #define ZK_API_BEGIN(ctx) return zk_api_guarded((zk_ctx*)(ctx), [&]() -> int {

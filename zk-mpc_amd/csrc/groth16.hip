@@ -283,11 +283,8 @@ extern "C" int zk_groth16_witness_map_pre_dev(zk_ctx* ctx, const zk_r1cs* r, con
     ZK_TRY(spmv(ctx, r, 1, z, 0, b));
     ZK_TRY(spmv(ctx, r, 2, z, 0, c));
     void* v[3] = {a, b, c};
-    for (int k = 0; k < 3; k++) {
-        ZK_TRY(zk_ntt_launch(ctx, v[k], r->log_d, 1, 0));  // ifft          (:278-279,295)
-        ZK_TRY(zk_ntt_launch(ctx, v[k], r->log_d, 0, 1));  // coset_fft     (:281-282,296)
-    }
-    return ZK_OK;
+    ZK_TRY(zk_ntt_launch_batch(ctx, v, 3, r->log_d, 1, 0));    // ifft of a, b, c       (:278-279,295), one launch per pass
+    return zk_ntt_launch_batch(ctx, v, 3, r->log_d, 0, 1);     // coset_fft of a, b, c  (:281-282,296)
     ZK_API_END
 }
 
@@ -948,18 +945,18 @@ extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs*
         const X1 b1_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[3]);
         const X2 b2_acc = host64_proj_from_abi<H2>((const uint64_t*)&m2);
         // calculate_coeff (src/groth16.rs:185-201): initial + query[0] + acc + vk_param
-        chain_a = zk_async([&, a_acc] {
+        chain_a = zk_async(ctx, [&, a_acc] {
             const X1 r_g1 = host64_scalar_mul<H1>(delta1, rw);
             r_s_delta = host64_scalar_mul<H1>(r_g1, sw);                                                     // :115
             g_a = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(r_g1, a0), a_acc), alpha);
             s_g_a = host64_scalar_mul<H1>(g_a, sw);                                                           // :140
         });
-        chain_b = zk_async([&, b1_acc] {
+        chain_b = zk_async(ctx, [&, b1_acc] {
             const X1 s_g1 = host64_scalar_mul<H1>(delta1, sw);
             const X1 g1_b = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(s_g1, b0), b1_acc), beta1);
             r_g1_b = host64_scalar_mul<H1>(g1_b, rw);                                                         // :161
         });
-        chain_g2 = zk_async([&, b2_acc] {
+        chain_g2 = zk_async(ctx, [&, b2_acc] {
             const X2 s_g2 = host64_scalar_mul<H2>(delta2, sw);
             const X2 g2_b = xyzz_madd<H2>(xyzz_add<H2>(xyzz_madd<H2>(s_g2, b02), b2_acc), beta2);
             b_aff = xyzz_to_affine<H2>(g2_b);
@@ -1183,9 +1180,9 @@ int prove_shared_impl(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void
         ~Join() { for (int l = 0; l < 2; l++) { if (a[l].valid()) a[l].wait(); if (b[l].valid()) b[l].wait(); if (c[l].valid()) c[l].wait(); } }
     } join{f_r_g1, f_s_g1, f_s_g2};
     for (int l = 0; l < LANES; l++) {
-        f_r_g1[l] = zk_async([&, l] { return host64_scalar_mul<SH1>(delta1, rw[l]); });
-        f_s_g1[l] = zk_async([&, l] { return host64_scalar_mul<SH1>(delta1, sw[l]); });
-        f_s_g2[l] = zk_async([&, l] { return host64_scalar_mul<SH2>(delta2, sw[l]); });
+        f_r_g1[l] = zk_async(ctx, [&, l] { return host64_scalar_mul<SH1>(delta1, rw[l]); });
+        f_s_g1[l] = zk_async(ctx, [&, l] { return host64_scalar_mul<SH1>(delta1, sw[l]); });
+        f_s_g2[l] = zk_async(ctx, [&, l] { return host64_scalar_mul<SH2>(delta2, sw[l]); });
     }
     void *a[2], *b[2], *c[2];
     char nm[32];
@@ -1286,8 +1283,8 @@ int prove_shared_impl(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void
         fr_abi_to_canon_words(l4, kw);
         return xyzz_add<SH1>(host64_scalar_mul<SH1>(sxp, kw), xyzz_neg<SH1>(sxp));
     };
-    auto p0 = zk_async([&] { return scale_finish(sx_rd, oy_s); });       // r s delta            (:115)
-    auto p1 = zk_async([&] { return scale_finish(sx_a, oy_s); });        // s A                  (:140)
+    auto p0 = zk_async(ctx, [&] { return scale_finish(sx_rd, oy_s); });       // r s delta            (:115)
+    auto p1 = zk_async(ctx, [&] { return scale_finish(sx_a, oy_s); });        // s A                  (:140)
     const SX1 part2 = scale_finish(sx_b, oy_r);                          // r B1                 (:161)
     SX1 t = xyzz_add<SH1>(p1.get(), part2);
     t = xyzz_add<SH1>(t, xyzz_neg<SH1>(p0.get()));

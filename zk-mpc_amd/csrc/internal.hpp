@@ -10,6 +10,7 @@ void zk_presort_free(zk_ctx* ctx);   // groth16.hip: drop a pending zk_groth16_m
 extern "C" int zk_comm_destroy(zk_ctx* ctx);
 extern "C" int zk_fr_sum_parties_dev(zk_ctx* ctx, const void* gathered_dev, size_t n_parties, size_t n, void* out_dev);
 int zk_ntt_launch(zk_ctx* ctx, void* buf_dev, uint32_t log_n, int inverse, int coset);
+int zk_ntt_launch_batch(zk_ctx* ctx, void* const* bufs_dev, int count, uint32_t log_n, int inverse, int coset);   // count <= 4, same size and kind, one launch per pass
 int zk_ntt_vanishing_inv(zk_ctx* ctx, uint32_t log_n, uint32_t out9[9]);  // 1/(g^N - 1), internal form
 
 // vec_ops.hip

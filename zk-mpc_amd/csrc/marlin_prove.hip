@@ -102,11 +102,20 @@ struct Prover {
     void op(int o, const void* a, const void* b, void* out, size_t n) { if (n) ck(zk_fr_vec_op_dev(ctx, o, a, b, out, n)); }
     void scale(const void* a, const HF& k, void* out, size_t n) { zk_fr kk = k.abi(); if (n) ck(zk_fr_vec_scale_dev(ctx, a, &kk, out, n)); }
     void ntt(void* buf, const Dom& d, int inverse) { ck(zk_fr_ntt_dev(ctx, buf, d.log, inverse, 0)); }
-    char* fft(const Dom& d, const Poly& p, const std::string& name) {     // evaluate_over_domain: zero-pad, forward transform
+    // up to four transforms of one size and kind as one launch per pass (ntt.hip::zk_ntt_launch_batch)
+    void ntt_batch(std::initializer_list<void*> bufs, const Dom& d, int inverse) {
+        std::vector<void*> v(bufs);
+        if (rc == ZK_OK) ck(zk_ntt_launch_batch(ctx, v.data(), (int)v.size(), d.log, inverse, 0));
+    }
+    char* padded(const Dom& d, const Poly& p, const std::string& name) {  // the zero-padded copy evaluate_over_domain transforms
         char* out = dev(name, d.size);
         if (rc != ZK_OK) return out;
         if (p.n < d.size) zero(out + 32 * p.n, d.size - p.n);
         d2d(out, p.p, std::min(p.n, d.size));
+        return out;
+    }
+    char* fft(const Dom& d, const Poly& p, const std::string& name) {     // evaluate_over_domain: zero-pad, forward transform
+        char* out = padded(d, p, name);
         ntt(out, d, 0);
         return out;
     }
@@ -349,7 +358,7 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         // the blinding terms (three host scalar multiplications each, ~1.2 ms) run on host threads under the device batch
         std::vector<std::pair<std::pair<int, std::string>, std::future<zk_g1_projective>>> blinds;
         auto blind_async = [&](int which, const char* l, const std::vector<HF>& c) {
-            blinds.push_back({{which, l}, (blind_deferred ? std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); }) : zk_async([&gamma_pts, c] { return small_msm(gamma_pts, c); }))});
+            blinds.push_back({{which, l}, (blind_deferred ? std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); }) : zk_async(ctx, [&gamma_pts, c] { return small_msm(gamma_pts, c); }))});
         };
         for (const char* l : labels) {
             const bool hiding = !strcmp(l, "w") || !strcmp(l, "z_a") || !strcmp(l, "z_b") || !strcmp(l, "g_1");
@@ -449,7 +458,9 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         ZK_TRY(zk_fr_gather_dev(ctx, zb[l], ix->w_idx, n, w_evals));
         ZK_TRY(zk_fr_gather_dev(ctx, x_evals, ix->x_idx, n, tmp[l]));
         Q.op(ZK_OP_SUB, w_evals, tmp[l], w_evals, n);
-        Q.ntt(w_evals, H, 1);
+        char* za = Q.dev("za_c", n); char* zbb = Q.dev("zb_c", n);
+        Q.d2d(za, z_a[l], n); Q.d2d(zbb, z_b[l], n);
+        Q.ntt_batch({w_evals, za, zbb}, H, 1);                                   // the three interpolations of the round: one launch per pass
         const Poly w_h = Q.blind(w_evals, n, rnd, "w_h");
         wq[l] = Q.dev("w_poly", nwq);
         char* wr = Q.dev("w_rem", X.size);
@@ -458,9 +469,6 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         // (over shares the remainder is a share of zero: the reference's assert!(remainder.is_zero()) cannot be evaluated locally)
         if (!shared && !Q.is_zero(wr, X.size)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: w polynomial is not divisible by v_X");
         Q.polys["w"] = Poly{wq[l], nwq};
-        char* za = Q.dev("za_c", n); char* zbb = Q.dev("zb_c", n);
-        Q.d2d(za, z_a[l], n); Q.d2d(zbb, z_b[l], n);
-        Q.ntt(za, H, 1); Q.ntt(zbb, H, 1);
         Q.polys["z_a"] = Q.blind(za, n, rnd + 32, "z_a_poly");
         Q.polys["z_b"] = Q.blind(zbb, n, rnd + 64, "z_b_poly");
         mask[l] = Q.dev("mask", md + 1);
@@ -499,12 +507,12 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         if (which == 0) P.scale(t_ev, etas[0], t_ev, n);
         else { P.scale(tmp[0], etas[which], tmp[0], n); P.op(ZK_OP_ADD, t_ev, tmp[0], t_ev, n); }
     }
-    P.ntt(t_ev, H, 1);
+    P.ntt_batch({t_ev, ra}, H, 1);
     for (int l = 0; l < LANES; l++) PL[l].polys["t"] = Poly{t_ev, n};
-    P.ntt(ra, H, 1);
     const Poly r_alpha_poly{ra, n};
     const Dom MUL(std::max(std::max(md + 1, n + 2 * n + 1), n + n + 1));
-    char* e_rp = P.fft(MUL, r_alpha_poly, "e_r"); char* e_tp = P.fft(MUL, P.polys["t"], "e_t");
+    char* e_rp = P.padded(MUL, r_alpha_poly, "e_r"); char* e_tp = P.padded(MUL, P.polys["t"], "e_t");
+    P.ntt_batch({e_rp, e_tp}, MUL, 0);
     char *e_a[2], *e_b[2], *e_s[2], *e_z[2];
     for (int l = 0; l < LANES; l++) {
         Prover& Q = PL[l];
@@ -514,9 +522,10 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         Q.op(ZK_OP_SUB, zp, wq[l], zp, nwq);
         Q.op(ZK_OP_ADD, zp, xb[l], zp, X.size);
         const Poly z_poly{zp, n + 1};
-        e_a[l] = Q.fft(MUL, Q.polys["z_a"], "e_a"); e_b[l] = Q.fft(MUL, Q.polys["z_b"], "e_b");
+        e_a[l] = Q.padded(MUL, Q.polys["z_a"], "e_a"); e_b[l] = Q.padded(MUL, Q.polys["z_b"], "e_b");
         e_s[l] = Q.dev("e_s", MUL.size);
-        e_z[l] = Q.fft(MUL, z_poly, "e_z");
+        e_z[l] = Q.padded(MUL, z_poly, "e_z");
+        Q.ntt_batch({e_a[l], e_b[l], e_z[l]}, MUL, 0);
         ZK_TRY(Q.rc);
     }
     // z_a z_b: the one product of two witness vectors (`DensePolynomial::mul` on MpcField = FieldShare::batch_mul)
@@ -678,7 +687,7 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
     size_t counts[2][2] = {{0, 0}, {0, 0}};                                      // [query point][lane]
     std::vector<std::future<zk_g1_projective>> extra[2];                         // the blinding witnesses: host threads, joined after the batch
-    auto small_async = [&](const std::vector<HF>& c) { return (blind_deferred ? std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); }) : zk_async([&gamma_pts, c] { return small_msm(gamma_pts, c); })); };
+    auto small_async = [&](const std::vector<HF>& c) { return (blind_deferred ? std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); }) : zk_async(ctx, [&gamma_pts, c] { return small_msm(gamma_pts, c); })); };
     bool has_rv[2] = {false, false}, q_shared[2] = {false, false};
     HF rvs[2];
     for (int q = 0; q < 2; q++) {

@@ -1099,7 +1099,7 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
         const uint32_t nthreads = nwin >= 16 ? 8u : nwin >= 8 ? 4u : 1u;
         std::vector<std::future<void>> tasks;
         for (uint32_t t = 1; t < nthreads; t++)
-            tasks.push_back(zk_async([&, t] { for (uint32_t w = t; w < nwin; w += nthreads) wsum[w] = window_sum(w); }));
+            tasks.push_back(zk_async(ctx, [&, t] { for (uint32_t w = t; w < nwin; w += nthreads) wsum[w] = window_sum(w); }));
         for (uint32_t w = 0; w < nwin; w += nthreads) wsum[w] = window_sum(w);
         for (auto& f : tasks) f.get();
     }

@@ -207,12 +207,22 @@ __device__ __forceinline__ void radix4_item(const PassIO<POST>& io, const FrK& p
 // One DIF pass: logM levels of the size-M transforms of a tile, as radix-4 register butterflies in the lazy domain
 // (frlazy.cuh) with the tile in LDS between stages; one radix-2 level comes first when logM is odd.  Twiddle exponents in
 // units of w = w_N: level s of the size-M transform uses w_M^(jj 2^s) = w^((jj << s) << (log_n - logM)).
+// blockIdx.y picks one of up to NTT_BATCH same-size transforms: the witness map's three inverse and three coset transforms are
+// one launch per pass (a pass is one 147-KB tile per CU: the transforms of a batch follow each other on a CU without a launch
+// boundary, its drain and its ramp, between them).
+constexpr int NTT_BATCH = 4;
+struct NttBatch {
+    const uint32_t* src[NTT_BATCH];
+    uint32_t* dst[NTT_BATCH];
+};
 template <int POST>
 __global__ void __launch_bounds__(NTT_THREADS)
-k_ntt_pass(const uint32_t* data, uint32_t* out, const uint32_t* __restrict__ tw,
+k_ntt_pass(NttBatch nb, const uint32_t* __restrict__ tw,
            const uint32_t* __restrict__ pre, uint32_t log_n, uint32_t logS, uint32_t logM, uint32_t logC, int inverse,
            int final_rev, FrK post_k, const uint32_t* __restrict__ post) {
     extern __shared__ uint32_t lds[];
+    const uint32_t* data = nb.src[blockIdx.y];
+    uint32_t* out = nb.dst[blockIdx.y];
     const uint32_t C = 1u << logC, E = C << logM;
     const uint32_t N1 = (1u << log_n) - 1;
     const uint32_t tid = threadIdx.x, NT = blockDim.x;
@@ -347,22 +357,24 @@ void zk_domains_free(zk_ctx* ctx) {
     ctx->domains.clear();
 }
 
-int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset) {
+// `count` (<= NTT_BATCH) transforms of the same size and kind, in place on bufs[k], as one launch per pass.
+int zk_ntt_launch_batch(zk_ctx* ctx, void* const* bufs, int count, uint32_t log_n, int inverse, int coset) {
+    if (count < 1 || count > NTT_BATCH) ZK_FAIL(ctx, ZK_ERR_ARG, "ntt: batch of 1..4 transforms");
     zk_domain* d;
     ZK_TRY(get_domain(ctx, log_n, coset != 0, &d));
-    uint32_t* data = (uint32_t*)buf;
     FrK zero{};
     const int post_mode = !inverse ? 0 : (!coset ? 1 : 2);
     const FrK post_k = post_mode == 1 ? to_frk(d->size_inv) : zero;
     const uint32_t* post_tab = post_mode == 2 ? d->icos : nullptr;
-    auto launch = [&](const uint32_t* src, uint32_t* dst, uint32_t tiles, uint32_t nt, uint32_t E, const uint32_t* pre, uint32_t logS,
+    auto launch = [&](const NttBatch& nb, uint32_t tiles, uint32_t nt, uint32_t E, const uint32_t* pre, uint32_t logS,
                       uint32_t logM, uint32_t logC, int final_rev) {
+        const dim3 grid(tiles, (unsigned)count);
         if (post_mode == 0)
-            hipLaunchKernelGGL(k_ntt_pass<0>, tiles, nt, E * 36, ctx->stream, src, dst, d->tw, pre, log_n, logS, logM, logC, inverse, final_rev, post_k, post_tab);
+            hipLaunchKernelGGL(k_ntt_pass<0>, grid, nt, E * 36, ctx->stream, nb, d->tw, pre, log_n, logS, logM, logC, inverse, final_rev, post_k, post_tab);
         else if (post_mode == 1)
-            hipLaunchKernelGGL(k_ntt_pass<1>, tiles, nt, E * 36, ctx->stream, src, dst, d->tw, pre, log_n, logS, logM, logC, inverse, final_rev, post_k, post_tab);
+            hipLaunchKernelGGL(k_ntt_pass<1>, grid, nt, E * 36, ctx->stream, nb, d->tw, pre, log_n, logS, logM, logC, inverse, final_rev, post_k, post_tab);
         else
-            hipLaunchKernelGGL(k_ntt_pass<2>, tiles, nt, E * 36, ctx->stream, src, dst, d->tw, pre, log_n, logS, logM, logC, inverse, final_rev, post_k, post_tab);
+            hipLaunchKernelGGL(k_ntt_pass<2>, grid, nt, E * 36, ctx->stream, nb, d->tw, pre, log_n, logS, logM, logC, inverse, final_rev, post_k, post_tab);
     };
     bool permuted = false;      // the last pass already wrote the natural order (and the post-scale)
     if (log_n > 0) {
@@ -378,7 +390,8 @@ int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset
         // with two or more passes the first one writes a scratch buffer and the last one scatters from it back into the
         // caller's buffer in natural order; a single-pass transform (N <= 2^LOGM_MAX) keeps the separate permutation
         uint32_t* tmp = nullptr;
-        if (passes >= 2) ZK_TRY(zk_scratch(ctx, "ntt_tmp", ((size_t)1 << log_n) * 32, (void**)&tmp));
+        const size_t words = ((size_t)1 << log_n) * 8;
+        if (passes >= 2) ZK_TRY(zk_scratch(ctx, "ntt_tmp", (size_t)count * words * 4, (void**)&tmp));
         for (uint32_t p = 0; p < passes; p++) {
             uint32_t logM = base + (p < extra ? 1 : 0);
             uint32_t logS = remaining - logM;
@@ -398,10 +411,15 @@ int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset
             uint32_t nt = E / 4 > NTT_THREADS ? NTT_THREADS : (E / 4 < 64 ? 64 : E / 4);
             uint32_t tiles = 1u << (log_n - logE);
             const uint32_t* pre = (p == 0 && coset && !inverse) ? d->cos : nullptr;
-            const uint32_t* src = (tmp && p > 0) ? tmp : data;
             const bool last = p + 1 == passes;
-            uint32_t* dst = tmp ? (last ? data : tmp) : data;
-            launch(src, dst, tiles, nt, E, pre, logS, logM, logC, (tmp && last) ? 1 : 0);
+            NttBatch nb{};
+            for (int k = 0; k < count; k++) {
+                uint32_t* data = (uint32_t*)bufs[k];
+                uint32_t* t = tmp ? tmp + (size_t)k * words : nullptr;
+                nb.src[k] = (t && p > 0) ? t : data;
+                nb.dst[k] = t ? (last ? data : t) : data;
+            }
+            launch(nb, tiles, nt, E, pre, logS, logM, logC, (tmp && last) ? 1 : 0);
             ZK_HIP(ctx, hipGetLastError());
             remaining = logS;
         }
@@ -409,17 +427,22 @@ int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset
     }
     if (!permuted) {
         unsigned g = zk_grid((size_t)1 << log_n, 256);
-        if (!inverse) {
-            if (log_n > 1) hipLaunchKernelGGL(k_bitrev_scale<0>, g, 256, 0, ctx->stream, data, log_n, zero, nullptr);
-        } else if (!coset) {
-            hipLaunchKernelGGL(k_bitrev_scale<1>, g, 256, 0, ctx->stream, data, log_n, to_frk(d->size_inv), nullptr);
-        } else {
-            hipLaunchKernelGGL(k_bitrev_scale<2>, g, 256, 0, ctx->stream, data, log_n, zero, d->icos);
+        for (int k = 0; k < count; k++) {
+            uint32_t* data = (uint32_t*)bufs[k];
+            if (!inverse) {
+                if (log_n > 1) hipLaunchKernelGGL(k_bitrev_scale<0>, g, 256, 0, ctx->stream, data, log_n, zero, nullptr);
+            } else if (!coset) {
+                hipLaunchKernelGGL(k_bitrev_scale<1>, g, 256, 0, ctx->stream, data, log_n, to_frk(d->size_inv), nullptr);
+            } else {
+                hipLaunchKernelGGL(k_bitrev_scale<2>, g, 256, 0, ctx->stream, data, log_n, zero, d->icos);
+            }
         }
         ZK_HIP(ctx, hipGetLastError());
     }
     return ZK_OK;
 }
+
+int zk_ntt_launch(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset) { return zk_ntt_launch_batch(ctx, &buf, 1, log_n, inverse, coset); }
 
 extern "C" int zk_fr_ntt_dev(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse, int coset) {
     ZK_API_BEGIN(ctx)
