@@ -1,5 +1,6 @@
 """CPU: the C-ABI library loads and exports every symbol include/zkmpc_hip.h declares, the Python binding
 covers exactly that set, and the product fails loudly without a GPU."""
+import json
 import os
 import re
 
@@ -448,6 +449,84 @@ def test_fr_lazy_domain_column_bounds():
     # top limbs: the subtrahend's top limb never exceeds the offset's (b < 1.03 r / 2.1 r / 4.2 r respectively)
     assert c["OFF2"][8] >= (103 * RR // 100) >> 232 and c["OFF3"][8] >= (21 * RR // 10) >> 232 and c["OFF5"][8] >= (42 * RR // 10) >> 232
     assert sum(int(x) << (29 * i) for i, x in enumerate(c["RC"])) == RI9 - RR and c["MQ"] == (1 << 264) // RR
+
+
+def test_she_lazy_domain_bounds():
+    """The lazy domain of the SHE butterflies (she.hip: f7l_red / f7l_sub / f7l_mul over the MNT4-753 base field, 26 limbs of 29
+    bits, Montgomery radix 2^754), modelled on Python integers: the quotient estimate of f7l_red never exceeds a / q and leaves
+    less than 2.01 q for every input the butterflies can produce (worst-case limb spreads included); the ranges close -- a
+    product of anything below 2.26 q by a reduced twiddle is below 1.89 q, the forward and inverse butterflies map [0, 2.01 q)
+    to itself; the offsets of f7l_sub dominate the limbs they absorb; the worst product column stays below 2^64."""
+    import random
+    from fractions import Fraction
+    q = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_constants.json")))["mnt4_753_fq"]["MODULUS"]["value"]
+    q = int(q)
+    src = open(os.path.join(ROOT, "zk-mpc_amd", "csrc", "consts.cuh")).read()
+    body = src[src.index("struct Fq753Lazy"):]
+    body = body[:body.index("\n};")]
+    c = {m.group(1): [int(x.strip().rstrip("u"), 16) for x in m.group(2).split(",")] for m in re.finditer(r"(\w+)\[26\] = \{([^}]*)\}", body)}
+    mq = int(re.search(r"MQ = (\d+)u", body).group(1))
+    val = lambda limbs: sum(int(x) << (29 * i) for i, x in enumerate(limbs))
+    RI = 1 << 754
+    assert val(c["RC"]) == RI - q and mq == (1 << 56) // ((q >> 725) + 1)
+    for name, K in (("OFF2", 2), ("OFF3", 3)):
+        assert val(c[name]) == K * q and all(1 << 29 <= x < 1 << 30 for x in c[name][:25])
+    # f7l_sub: the subtrahend's limbs are below 2^29 and its top limb below the offset's (b < 1.89 q for K = 2, < 2.26 q for K = 3)
+    assert c["OFF2"][25] >= (189 * q // 100) >> 725 and c["OFF3"][25] >= (226 * q // 100) >> 725
+
+    def red(limbs):                                   # she.hip::f7l_red, instruction for instruction
+        t = (limbs[25] + (limbs[24] >> 29)) & 0xffffffff
+        k = (t * mq) >> 56
+        out, carry = [], 0
+        for i in range(26):
+            assert limbs[i] + carry < 1 << 32
+            acc = k * c["RC"][i] + limbs[i] + carry
+            out.append(acc & M29)
+            carry = acc >> 29
+        return k, out
+
+    def spread(v, rnd, wide):                         # v as 26 limbs, the lower ones pushed up to `wide` bits where v allows it
+        limbs = [(v >> (29 * i)) & M29 for i in range(25)] + [v >> 725]
+        for i in range(24, -1, -1):
+            room = min(((1 << wide) - 1 - limbs[i]) >> 29, limbs[i + 1])
+            if room > 0:
+                mv = rnd.randint(0, room)
+                limbs[i] += mv << 29
+                limbs[i + 1] -= mv
+        assert val(limbs) == v
+        return limbs
+
+    rnd = random.Random(753)
+    worst = Fraction(0)
+    cases = [0, 1, q - 1, q, 2 * q, 201 * q // 100, 3 * q - 1, 501 * q // 100, 56 * q // 10, 79 * q // 10 - 1]
+    cases += [k * q + d for k in range(8) for d in (-1, 0, 1) if k * q + d >= 0]
+    cases += [rnd.randrange(79 * q // 10) for _ in range(300)]
+    for v in cases:
+        for wide in (29, 30, 31):
+            limbs = spread(v, rnd, wide)
+            k, out = red(limbs)
+            r = val(out)
+            assert k * q <= v and r == v - k * q and all(x < 1 << 29 for x in out)
+            worst = max(worst, Fraction(r, q))
+    assert worst < Fraction(201, 100)
+    # the ranges close: product of x < 2.26 q by a reduced y is (x y + m q) / RI < x q / RI + q
+    B = Fraction(201, 100)
+    prod = lambda x: x * Fraction(q, RI) + 1          # in units of q
+    assert prod(Fraction(226, 100)) < Fraction(2) and prod(B) < Fraction(189, 100)
+    assert B + prod(B) < Fraction(79, 10) and B + 2 < Fraction(79, 10) and B + 3 < Fraction(79, 10)          # red's inputs
+    assert 2 * (B * B * Fraction(q, RI) + 1) < Fraction(79, 10)                                              # x0 y0 + x1 y1, lazy operands
+    assert (Fraction(226, 100) * q).__floor__() >> 725 < 1 << 29                                             # every limb of a legal operand < 2^29
+    # worst column of fp_mul_lazy<Fq753Params>: 26 operand products and 26 reduction products of 29 x 29 bits, plus the carry
+    carry = top = 0
+    pl = [(q >> (29 * i)) & M29 for i in range(26)]
+    for k in range(51):
+        col = carry
+        for i in range(26):
+            if 0 <= k - i < 26:
+                col += M29 * M29 + M29 * pl[k - i]
+        top = max(top, col)
+        carry = col >> 29
+    assert top < 1 << 64
 
 
 def _fr_consts():

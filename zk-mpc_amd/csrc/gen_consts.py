@@ -91,7 +91,7 @@ def sub_offset(p, L, K, j):
     assert t >= 0
     lo = [((t >> (B * i)) & ((1 << B) - 1)) + (j << B) for i in range(L - 1)]
     c = lo + [t >> (B * (L - 1))]
-    assert sum(v << (B * i) for i, v in enumerate(c)) == K * p and c[-1] < (1 << 29)
+    assert sum(v << (B * i) for i, v in enumerate(c)) == K * p and c[-1] < (1 << 31)
     return c
 
 
@@ -105,6 +105,22 @@ def fr_lazy():
         c = sub_offset(R_MOD, L, K, j)
         out.append("    static constexpr uint32_t %s[%d] = {%s};  // %d r, limbs 0..7 in [%d * 2^29, %d * 2^29)" % (
             name, L, ", ".join("0x%08xu" % v for v in c), K, j, j + 1))
+    out.append("};")
+    return "\n".join(out)
+
+
+def fq753_lazy():
+    """Constants of the lazy domain of the SHE butterflies (she.hip): 26 limbs hold 754 bits, q = 0.4427 * 2^754, so values below
+    2.2 q keep every limb below 2^29 and a Montgomery product (RI = 2^754) of x < 2.2 q by y < q lands below 0.4427 x + q < 2 q."""
+    L, q = 26, Q753_MOD
+    out = ["struct Fq753Lazy {"]
+    out.append(arr("RC", (1 << (B * L)) - q, L, "2^754 - q: a + k RC = (a - k q) + k 2^754"))
+    d = (q >> (B * (L - 1))) + 1
+    out.append("    static constexpr uint32_t MQ = %du;      // floor(2^56 / ((q >> 725) + 1)): k = (top limb * MQ) >> 56 <= floor(a / q)" % ((1 << 56) // d))
+    for name, K in (("OFF2", 2), ("OFF3", 3)):
+        c = sub_offset(q, L, K, 1)
+        out.append("    static constexpr uint32_t %s[%d] = {%s};  // %d q, limbs 0..24 in [2^29, 2^30)" % (
+            name, L, ", ".join("0x%08xu" % v for v in c), K))
     out.append("};")
     return "\n".join(out)
 
@@ -151,6 +167,7 @@ def main():
         ("MOD_FR", Q753_MOD % R_MOD),                      # q mod p, subtracted from the upper half (ibid.)
     ]))
     print("static constexpr int FQ753_TWO_ADICITY = %d;" % Q753_TWO_ADICITY)
+    print(fq753_lazy())
     # Fr constants that fold a 26-limb canonical integer into Fr: K[i] = 2^(29 i) * RE * RI mod r (RAW operands),
     # so that sum_i mmul(limb_i, K[i]) is the value mod r in external form.
     RI, RE = 1 << (B * 9), 1 << 256

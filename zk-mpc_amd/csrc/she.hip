@@ -61,6 +61,52 @@ __device__ __forceinline__ F7 f7_mul(const F7& a, const F7& b) { return fp_mul<F
 __device__ __forceinline__ F7 f7_add(const F7& a, const F7& b) { return fp_add<Fq753Params>(a, b); }
 __device__ __forceinline__ F7 f7_sub(const F7& a, const F7& b) { return fp_sub<Fq753Params>(a, b); }
 
+// ---- the lazy domain of the transform butterflies ---------------------------------------------------------------------------
+// 26 limbs of 29 bits hold 754 bits and q = 0.4427 * 2^754: a value below 2.26 q keeps EVERY limb below 2^29, so it is a legal
+// operand of the product-scanning Montgomery product (fp29.cuh: 52 * 2^58 < 2^64 per column) without being reduced, and that
+// product (RI = 2^754) of x < 2.26 q by y < q lands below 0.4427 x + q < 2 q by itself: no conditional subtraction anywhere.
+//   f7l_red(a)      any a < 7.9 q with u32 limbs -> a - k q in [0, 2.01 q), limbs < 2^29: k = floor(top * MQ / 2^56) <= a / q
+//                   estimated from the top limb (k >= a / q - 2), the subtraction folded into the carry pass as a + k (2^754 - q)
+//   f7l_sub<K>(a,b) a + K q - b limb by limb, no borrow (OFF<K>: K q written with limbs 0..24 in [2^29, 2^30)): b's limbs < 2^29,
+//                   b < 1.89 q for K = 2 (a product), b < 2.26 q for K = 3
+// Forward (Cooley-Tukey):   V = x[j+t] S < 1.89 q;  x[j] = red(U + V),  x[j+t] = red(U + 2q - V)          (inputs < 2.01 q)
+// Inverse (Gentleman-Sande): x[j] = red(U + X),  x[j+t] = red(U + 3q - X) S < 1.89 q
+// Bounds and the worst product column are recomputed by tests/test_abi.py::test_she_lazy_domain_bounds.
+using LZ7 = Fq753Lazy;
+__device__ __forceinline__ F7 f7l_add(const F7& a, const F7& b) {
+    F7 r;
+#pragma unroll
+    for (int i = 0; i < L7; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+template <int K>
+__device__ __forceinline__ F7 f7l_sub(const F7& a, const F7& b) {
+    static_assert(K == 2 || K == 3, "offsets generated: 2 q, 3 q");
+    F7 r;
+#pragma unroll
+    for (int i = 0; i < L7; i++) r.l[i] = a.l[i] + (K == 2 ? LZ7::OFF2[i] : LZ7::OFF3[i]) - b.l[i];
+    return r;
+}
+__device__ __forceinline__ F7 f7l_red(const F7& a) {
+    const uint32_t t = a.l[L7 - 1] + (a.l[L7 - 2] >> 29);
+    const uint32_t k = (uint32_t)(((uint64_t)t * LZ7::MQ) >> 56);
+    F7 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L7; i++) {
+        const uint64_t acc = (uint64_t)k * LZ7::RC[i] + (uint64_t)(a.l[i] + c);     // a.l[i] + c < 2^32: limbs < 2^31, c < 2^7
+        r.l[i] = (uint32_t)acc & MASK29;             // (the top limb too: k 2^754 drops off)
+        c = (uint32_t)(acc >> 29);
+    }
+    return r;
+}
+__device__ __forceinline__ F7 f7l_mul(const F7& a, const F7& b) { return fp_mul_lazy<Fq753Params>(a, b); }
+// a < 2.01 q, limbs < 2^29 -> a mod q
+__device__ __forceinline__ F7 f7l_canon(const F7& a) {
+    const F7 t = fp_reduce_once<Fq753Params>(a.l);
+    return fp_reduce_once<Fq753Params>(t.l);
+}
+
 // limb-major table of n elements (internal form)
 __device__ __forceinline__ F7 tab_load(const uint32_t* tab, uint32_t n, uint32_t i) {
     F7 r;
@@ -139,17 +185,19 @@ __global__ void __launch_bounds__(256) k_she_fwd_global(void* data, const uint32
         uint32_t i = b >> log_t, off = b & (t - 1);
         size_t j = (size_t)row * n + 2 * (size_t)i * t + off;
         F7 S = tab_load(psi, n, m + i);
-        F7 U = f7_load(data, j), V = f7_mul(f7_load(data, j + t), S);
-        f7_store(data, j, f7_add(U, V));
-        f7_store(data, j + t, f7_sub(U, V));
+        F7 U = f7_load(data, j), V = f7l_mul(f7_load(data, j + t), S);
+        f7_store(data, j, f7l_red(f7l_add(U, V)));
+        f7_store(data, j + t, f7l_red(f7l_sub<2>(U, V)));
     }
 }
 
 // Forward LDS pass: levels t = min(n, TILE)/2 ... 1 on one tile.  FIRST: read through the row map (n <= TILE), else
 // read dst in place (the global levels already copied).
+// The transform-domain values it writes are lazy representatives (< 2.01 q, limbs < 2^29: they fit the 768-bit words) unless
+// `canon` asks for reduced ones (a consumer outside the transform kernels: the s * s of decrypt).
 template <bool FIRST>
 __global__ void __launch_bounds__(TILE_THREADS) k_she_fwd_tile(RowMap src, void* dst, const uint32_t* psi, uint32_t log_n,
-                                                      uint64_t n_elems) {
+                                                      uint64_t n_elems, int canon) {
     extern __shared__ uint32_t lds[];
     uint32_t n = 1u << log_n;
     uint64_t e0 = (uint64_t)blockIdx.x * TILE;
@@ -172,15 +220,15 @@ __global__ void __launch_bounds__(TILE_THREADS) k_she_fwd_tile(RowMap src, void*
             uint32_t i = b >> log_t, off = b & (t - 1);
             uint32_t j = (uint32_t)(row * n + 2 * (uint64_t)i * t + off - e0);
             F7 S = tab_load(psi, n, m + i);
-            F7 U = lds_get(lds, j), V = f7_mul(lds_get(lds, j + t), S);
-            lds_put(lds, j, f7_add(U, V));
-            lds_put(lds, j + t, f7_sub(U, V));
+            F7 U = lds_get(lds, j), V = f7l_mul(lds_get(lds, j + t), S);
+            lds_put(lds, j, f7l_red(f7l_add(U, V)));
+            lds_put(lds, j + t, f7l_red(f7l_sub<2>(U, V)));
         }
         __syncthreads();
     }
     for (uint32_t l = threadIdx.x; l < TILE; l += TILE_THREADS) {
         uint64_t e = e0 + l;
-        if (e < n_elems) f7_store(dst, e, lds_get(lds, l));
+        if (e < n_elems) f7_store(dst, e, canon ? f7l_canon(lds_get(lds, l)) : lds_get(lds, l));
     }
 }
 
@@ -204,10 +252,12 @@ __global__ void __launch_bounds__(TILE_THREADS) k_she_inv_tile(InvArgs a, const 
         if (e < n_elems) {
             uint64_t row = e >> log_n;
             uint32_t j = (uint32_t)(e & (n - 1));
-            F7 v = f7_mul(f7_load(a.x0.base, row_elem(a.x0, n, row, j)), f7_load(a.y0.base, row_elem(a.y0, n, row, j)));
+            // operands < 2.01 q: each product < 2.79 q, their sum < 5.6 q
+            F7 v = f7l_mul(f7_load(a.x0.base, row_elem(a.x0, n, row, j)), f7_load(a.y0.base, row_elem(a.y0, n, row, j)));
             if (a.x1.base)
-                v = f7_add(v, f7_mul(f7_load(a.x1.base, row_elem(a.x1, n, row, j)), f7_load(a.y1.base, row_elem(a.y1, n, row, j))));
-            if (a.negate) v = fp_neg<Fq753Params>(v);
+                v = f7l_add(v, f7l_mul(f7_load(a.x1.base, row_elem(a.x1, n, row, j)), f7_load(a.y1.base, row_elem(a.y1, n, row, j))));
+            v = f7l_red(v);
+            if (a.negate) v = f7l_red(f7l_sub<3>(fp_zero<Fq753Params>(), v));
             lds_put(lds, l, v);
         }
     }
@@ -224,8 +274,8 @@ __global__ void __launch_bounds__(TILE_THREADS) k_she_inv_tile(InvArgs a, const 
             uint32_t j = (uint32_t)(row * n + 2 * (uint64_t)i * t + off - e0);
             F7 S = tab_load(psi_inv, n, h + i);
             F7 U = lds_get(lds, j), V = lds_get(lds, j + t);
-            lds_put(lds, j, f7_add(U, V));
-            lds_put(lds, j + t, f7_mul(f7_sub(U, V), S));
+            lds_put(lds, j, f7l_red(f7l_add(U, V)));
+            lds_put(lds, j + t, f7l_mul(f7l_red(f7l_sub<3>(U, V)), S));
         }
         __syncthreads();
     }
@@ -264,7 +314,7 @@ __global__ void __launch_bounds__(256) k_she_inv_global(void* work, RowMap out, 
         size_t j = (size_t)row * n + jj;
         F7 S = tab_load(psi_inv, n, h + i);
         F7 U = f7_load(work, j), V = f7_load(work, j + t);
-        F7 lo = f7_add(U, V), hi = f7_mul(f7_sub(U, V), S);
+        F7 lo = f7l_red(f7l_add(U, V)), hi = f7l_mul(f7l_red(f7l_sub<3>(U, V)), S);      // lazy: < 2.01 q; f7_mul by sc reduces
         if (LAST) {
             f7_store(const_cast<void*>(out.base), row_elem(out, n, row, jj), f7_mul(lo, sc));
             f7_store(const_cast<void*>(out.base), row_elem(out, n, row, jj + t), f7_mul(hi, sc));
@@ -442,19 +492,19 @@ int she_lds_attr(zk_ctx* ctx) {
 }
 
 // dst (packed rows) <- forward negacyclic NTT of `rows` polynomials read through src.
-int she_forward(zk_ctx* ctx, const SheTables& tb, RowMap src, void* dst, uint32_t log_n, uint64_t rows) {
+int she_forward(zk_ctx* ctx, const SheTables& tb, RowMap src, void* dst, uint32_t log_n, uint64_t rows, int canon = 0) {
     uint32_t n = 1u << log_n;
     uint64_t n_elems = rows * n;
     unsigned tiles = (unsigned)((n_elems + TILE - 1) / TILE);
     ZK_TRY(she_lds_attr(ctx));
     if (log_n <= LOG_TILE) {
-        hipLaunchKernelGGL(k_she_fwd_tile<true>, tiles, TILE_THREADS, LDS_BYTES, ctx->stream, src, dst, tb.psi, log_n, n_elems);
+        hipLaunchKernelGGL(k_she_fwd_tile<true>, tiles, TILE_THREADS, LDS_BYTES, ctx->stream, src, dst, tb.psi, log_n, n_elems, canon);
     } else {
         hipLaunchKernelGGL(k_she_gather, zk_grid(n_elems, 256), 256, 0, ctx->stream, src, dst, n, n_elems);
         for (int log_t = (int)log_n - 1; log_t >= LOG_TILE; log_t--)
             hipLaunchKernelGGL(k_she_fwd_global, zk_grid(n_elems / 2, 256), 256, 0, ctx->stream, dst, tb.psi, log_n, (uint32_t)log_t,
                                n_elems / 2);
-        hipLaunchKernelGGL(k_she_fwd_tile<false>, tiles, TILE_THREADS, LDS_BYTES, ctx->stream, src, dst, tb.psi, log_n, n_elems);
+        hipLaunchKernelGGL(k_she_fwd_tile<false>, tiles, TILE_THREADS, LDS_BYTES, ctx->stream, src, dst, tb.psi, log_n, n_elems, canon);
     }
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
@@ -646,7 +696,7 @@ extern "C" int zk_she_decrypt_dev(zk_ctx* ctx, const void* ct, const void* sk, v
         ZK_TRY(zk_scratch(ctx, "she_fa", batch * 2 * poly, (void**)&fc));
         ZK_TRY(zk_scratch(ctx, "she_fb", 2 * poly, (void**)&fs));
         ZK_TRY(she_forward(ctx, tb, rows_of(cb + poly, 2, 3 * n), fc, log_n, 2 * batch));
-        ZK_TRY(she_forward(ctx, tb, rows_of(sk, 1, n), fs, log_n, 1));
+        ZK_TRY(she_forward(ctx, tb, rows_of(sk, 1, n), fs, log_n, 1, 1));       // reduced: k_she_vec_op multiplies it by itself
         hipLaunchKernelGGL(k_she_vec_op, zk_grid(n, 256), 256, 0, ctx->stream, (int)SHE_MUL, (const void*)fs, (const void*)fs, (void*)(fs + poly), n);
         ZK_TRY(she_inverse(ctx, tb,
                            InvArgs{rows_of(fs, 1, 0), rows_of(fc, 1, 2 * n), rows_of(fs + poly, 1, 0), rows_of(fc + poly, 1, 2 * n),
