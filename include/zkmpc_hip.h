@@ -253,8 +253,11 @@ int zk_pk_vk_g2(const zk_pk* pk, int which, zk_g2_affine* out);
 int zk_groth16_witness_map_dev(zk_ctx* ctx, const zk_r1cs* r1cs, const void* z_dev, void* h_dev);
 uint32_t zk_r1cs_domain_log(const zk_r1cs* r1cs);
 /* Collaborative form, split at the one shared x shared product (src/groth16.rs:285):
- *  pre : a,b,c <- coset_fft(ifft(M z))                    (local: linear in the shares)
- *  post: h <- coset_ifft((ab - c) / Z(g)), ab supplied by the caller (Beaver batch_mul). */
+ *  pre : a,b <- coset_fft(ifft(M z)), c <- ifft(C z)      (local: linear in the shares)
+ *  post: h <- (coset_ifft(ab) - c) / Z(g), ab supplied by the caller (Beaver batch_mul).
+ * c is an opaque value between the two calls: it stays in coefficient form, because the reference's
+ * coset_ifft((ab - c) / Z(g)) over coset evaluations equals coset_ifft(ab) - c over coefficients (interpolation is linear)
+ * -- the same h, one transform less. */
 int zk_groth16_witness_map_pre_dev(zk_ctx* ctx, const zk_r1cs* r1cs, const void* z_dev,
                                    int include_instance, void* a_dev, void* b_dev, void* c_dev);
 int zk_groth16_witness_map_post_dev(zk_ctx* ctx, const zk_r1cs* r1cs, void* ab_dev, const void* c_dev);

@@ -284,7 +284,10 @@ extern "C" int zk_groth16_witness_map_pre_dev(zk_ctx* ctx, const zk_r1cs* r, con
     ZK_TRY(spmv(ctx, r, 2, z, 0, c));
     void* v[3] = {a, b, c};
     ZK_TRY(zk_ntt_launch_batch(ctx, v, 3, r->log_d, 1, 0));    // ifft of a, b, c       (:278-279,295), one launch per pass
-    return zk_ntt_launch_batch(ctx, v, 3, r->log_d, 0, 1);     // coset_fft of a, b, c  (:281-282,296)
+    // coset_fft of a and b (:281-282).  c stays in coefficient form: the reference's coset_ifft((ab - c) / Z(g)) on coset
+    // evaluations (:296-303) is, interpolation being linear, coset_ifft(ab) - c on coefficients -- the same field elements with
+    // one transform less (witness_map_post subtracts there)
+    return zk_ntt_launch_batch(ctx, v, 2, r->log_d, 0, 1);
     ZK_API_END
 }
 
@@ -293,8 +296,8 @@ extern "C" int zk_groth16_witness_map_post_dev(zk_ctx* ctx, const zk_r1cs* r, vo
     if (!ctx || !r || !ab || !c) return ZK_ERR_ARG;
     uint32_t zinv[9];
     ZK_TRY(zk_ntt_vanishing_inv(ctx, r->log_d, zinv));
-    ZK_TRY(zk_vec_sub_scale_launch(ctx, ab, c, zinv, ab, (size_t)1 << r->log_d));  // (ab - c) / Z(g)   (:298-302)
-    return zk_ntt_launch(ctx, ab, r->log_d, 1, 1);                                   // coset_ifft        (:303)
+    ZK_TRY(zk_ntt_launch(ctx, ab, r->log_d, 1, 1));                                  // coset_ifft of ab  (:303)
+    return zk_vec_sub_scale_launch(ctx, ab, c, zinv, ab, (size_t)1 << r->log_d);    // (. - c) / Z(g), c in coefficient form (:298-302)
     ZK_API_END
 }
 
