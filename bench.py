@@ -401,7 +401,7 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
     opens_timed = party.be.open_stats(args.steps) if dist is not None else None
     sent_timed = (int(party.bytes_sent) - sent0) if dist is not None else 0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if args.transport == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if dist is not None:        # (every rank: the Python sequence is a collective too) the parsed proof for the oracle's verifier
@@ -453,6 +453,8 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
         out["aggregate_constraint_shares_per_s"] = round(n * K / dt * world, 1)
         out["opens_in_timed_proofs"] = opens_timed
         out["prover_entry"] = "mpc.py sequence" if args.python_mpc else ("zk_marlin_prove_shared_spdz" if args.spdz else "zk_marlin_prove_shared")
+        out["transport"] = ("RCCL (torch.distributed nccl)" if args.transport == "nccl" else
+                            "gloo, opens staged through host memory" + (", every party on cuda:0 (functional run, not a measurement)" if args.one_gpu else ""))
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
@@ -485,6 +487,11 @@ def main():
     ap.add_argument("--natural-domain", action="store_true",
                     help="n = 2^L constraints, so that the QAP domain is 2^(L+1) (the reference's natural sizing, src/groth16.rs:256-257)")
     ap.add_argument("--spdz", action="store_true", help="N > 1: SPDZ (malicious) shares instead of additive ones")
+    ap.add_argument("--transport", choices=["nccl", "gloo"], default="nccl",
+                    help="N > 1: torch.distributed backend of the parties' opens (nccl = RCCL over xGMI, the default; gloo = staged through host memory)")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="N > 1: every rank on cuda:0 (a functional run of the N-party path on a one-GPU box; needs --transport gloo: RCCL "
+                         "refuses two ranks on one device)")
     ap.add_argument("--python-mpc", action="store_true", help="additive collaborative prover: the Python sequence instead of zk_groth16_prove_shared")
     ap.add_argument("--marlin", action="store_true",
                     help="prove with Marlin/KZG instead of Groth16 (BASELINE configs 4 and 5: --gpus 1, or --gpus 8 --spdz --log-constraints 22)")
@@ -510,6 +517,10 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libzkmpc_hip has no CPU path")
+    if args.one_gpu:
+        if world > 1 and args.transport == "nccl":
+            sys.exit("bench.py --one-gpu needs --transport gloo (RCCL refuses two ranks on one device)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_mpc:
@@ -517,7 +528,10 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.transport == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     if args.marlin:
         ctx = Z.Context(local_rank, rank, world)
@@ -661,7 +675,7 @@ def main():
             host_leg = {"error": repr(e)}
     open_probe = None
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if args.transport == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # every rank must hold the same revealed proof
@@ -804,6 +818,8 @@ def main():
             out["prover_entry"] = ("mpc.py sequence" if args.python_mpc else
                                    "zk_groth16_prove_shared%s (one C-ABI call per proof)" % ("_spdz" if args.spdz else ""))
             out["open_probe"] = open_probe
+            out["transport"] = ("RCCL (torch.distributed nccl), one GPU per party" if args.transport == "nccl" else
+                                "gloo, opens staged through host memory" + (", every party on cuda:0 (functional run, not a measurement)" if args.one_gpu else ""))
             out["bytes_sent_per_party"] = int(party.bytes_sent)
         if dist is None:
             # second half of the headline metric: standalone variable-base MSM throughput (resident bases = the
