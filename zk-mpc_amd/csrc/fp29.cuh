@@ -147,6 +147,31 @@ ZK_HD Fp<P> fp_neg_lazy(const Fp<P>& a) {
     return r;
 }
 
+// The tail of one reduction column of the Montgomery products below: returns the digit m = -acc / p mod 2^29 and leaves
+// acc <- (acc + m p_0) >> 29, the carry into the next column.
+// p_0 = 1 (BLS12-377's Fr and Fq are 1 mod 2^46): m = -acc mod 2^29, and acc + m is simply the next multiple of 2^29, so the
+// shift is a rounding-up division: (acc + m) >> 29 == (acc + 2^29 - 1) >> 29.  The constant 2^29 - 1 enters at the START of a
+// column (fp_round0 for the first one, `more` for the following ones), where it is the free addend of the column's first
+// multiply-add instead of a 64-bit addition of m at its end; with it already inside, m = ~acc mod 2^29 (one v_bfi).  The
+// integers are the same as with the textbook tail: nothing about ranges or column bounds changes (the constant is < 2^29).
+template <class P>
+ZK_HD constexpr uint64_t fp_round0() { return P::P[0] == 1 ? (uint64_t)MASK29 : 0; }
+// acc = carry from the column before + this column's sum `col` (which started from fp_round0)
+template <class P>
+ZK_HD uint32_t fp_redc_column(uint64_t& acc, uint64_t col) {
+    acc += col;
+    if constexpr (P::P[0] == 1) {
+        const uint32_t m = ~(uint32_t)acc & MASK29;
+        acc >>= 29;
+        return m;
+    } else {
+        const uint32_t m = ((uint32_t)acc * P::INV) & MASK29;
+        acc += (uint64_t)m * P::P[0];
+        acc >>= 29;
+        return m;
+    }
+}
+
 // ---- Montgomery products, product scanning with ONE 64-bit accumulator -----------------------------------------------------
 // LR = P::LR Montgomery digits (radix RI = 2^(29 LR)), L = P::L operand limbs.  The *_lazy forms return the value before any
 // final subtraction:  (a b + m p) / RI  <  a b / RI + p.
@@ -164,13 +189,12 @@ ZK_HD Fp<P> fp_mul_lazy(const Fp<P>& a, const Fp<P>& b) {
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < LR; k++) {
+        uint64_t col = fp_round0<P>();
 #pragma unroll
-        for (int i = (k >= L ? k - L + 1 : 0); i <= (k < L ? k : L - 1); i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+        for (int i = (k >= L ? k - L + 1 : 0); i <= (k < L ? k : L - 1); i++) col += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-        for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
-        m[k] = ((uint32_t)acc * P::INV) & MASK29;
-        acc += (uint64_t)m[k] * P::P[0];
-        acc >>= 29;
+        for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) col += (uint64_t)m[i] * P::P[k - i];
+        m[k] = fp_redc_column<P>(acc, col);
     }
 #pragma unroll
     for (int k = LR; k < LR + L - 1; k++) {
@@ -209,16 +233,15 @@ ZK_HD Fp<P> fp_mul2_lazy(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const F
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < LR; k++) {
+        uint64_t col = fp_round0<P>();
 #pragma unroll
         for (int i = (k >= L ? k - L + 1 : 0); i <= (k < L ? k : L - 1); i++) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            acc += (uint64_t)c.l[i] * d.l[k - i];
+            col += (uint64_t)a.l[i] * b.l[k - i];
+            col += (uint64_t)c.l[i] * d.l[k - i];
         }
 #pragma unroll
-        for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
-        m[k] = ((uint32_t)acc * P::INV) & MASK29;
-        acc += (uint64_t)m[k] * P::P[0];
-        acc >>= 29;
+        for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) col += (uint64_t)m[i] * P::P[k - i];
+        m[k] = fp_redc_column<P>(acc, col);
     }
 #pragma unroll
     for (int k = LR; k < LR + L - 1; k++) {
@@ -309,22 +332,23 @@ ZK_HD Fp<P> fp_sqr_lazy(const Fp<P>& a) {
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < LR + L - 1; k++) {
+        uint64_t col = k < LR ? fp_round0<P>() : 0;
         if (k <= 2 * L - 2) {
 #pragma unroll
-            for (int i = (k >= L ? k - L + 1 : 0); 2 * i < k; i++) acc += (uint64_t)a2[i] * a.l[k - i];    // i < j = k - i
-            if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+            for (int i = (k >= L ? k - L + 1 : 0); 2 * i < k; i++) col += (uint64_t)a2[i] * a.l[k - i];    // i < j = k - i
+            if ((k & 1) == 0) col += (uint64_t)a.l[k / 2] * a.l[k / 2];
         }
         if (k < LR) {
 #pragma unroll
-            for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) acc += (uint64_t)m[i] * P::P[k - i];
-            m[k] = ((uint32_t)acc * P::INV) & MASK29;
-            acc += (uint64_t)m[k] * P::P[0];
+            for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) col += (uint64_t)m[i] * P::P[k - i];
+            m[k] = fp_redc_column<P>(acc, col);
         } else {
+            acc += col;
 #pragma unroll
             for (int i = k - L + 1; i < LR; i++) acc += (uint64_t)m[i] * P::P[k - i];
             r[k - LR] = (uint32_t)acc & MASK29;
+            acc >>= 29;
         }
-        acc >>= 29;
     }
     r[L - 1] = (uint32_t)acc;
     Fp<P> o;
