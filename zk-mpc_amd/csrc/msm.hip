@@ -623,7 +623,24 @@ __global__ void __launch_bounds__(256, (F::WORDS == 12 ? ZK_ACCUM_WAVES_G1 : ZK_
 k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
         const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums, uint32_t stride) {
     // stride: words between consecutive points of `bases` (2 * WORDS packed; 32 for a G1 table of window multiples: one point per line)
-    auto point = [&](uint32_t e) { return aff_load16<F>(bases + (size_t)(e & 0x7fffffffu) * stride, 0); };
+    // The NEXT point is fetched as raw words while the current one is added and unpacked into limbs only when its turn comes: the
+    // wait for the gather then sits behind a whole mixed addition.  (Fetching it in unpacked form put the wait, and the unpacking,
+    // in front of the addition: the loads had nothing to hide behind but the other wave.)
+    constexpr int NW = 2 * F::WORDS / 4;
+    struct Raw { uint4 v[NW]; };
+    auto fetch = [&](uint32_t e) {
+        const uint4* w = reinterpret_cast<const uint4*>(bases + (size_t)(e & 0x7fffffffu) * stride);
+        Raw r;
+#pragma unroll
+        for (int i = 0; i < NW; i++) r.v[i] = w[i];
+        return r;
+    };
+    auto unpack = [&](const Raw& r) {
+        uint32_t t[2 * F::WORDS];
+#pragma unroll
+        for (int i = 0; i < NW; i++) { t[4 * i] = r.v[i].x; t[4 * i + 1] = r.v[i].y; t[4 * i + 2] = r.v[i].z; t[4 * i + 3] = r.v[i].w; }
+        return Affine<F>{F::load(t), F::load(t + F::WORDS)};
+    };
     const uint32_t S = ctr[2];
     const uint32_t G = gridDim.x * blockDim.x;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < S; t += G) {
@@ -631,21 +648,16 @@ k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
         XYZZ<F> acc = xyzz_inf<F>();
         if (d.len) {
             const uint32_t* srt = sorted + d.start;
-#ifdef ZK_ACCUM_NO_PREFETCH
+            uint32_t e = srt[0], e1 = d.len > 1 ? srt[1] : 0;         // the sorted entries run one step further ahead still
+            Raw nxt = fetch(e);
             for (uint32_t k = 0; k < d.len; k++) {
-                const uint32_t ce = srt[k];
-                Affine<F> cur = point(ce);
-#else
-            uint32_t e = srt[0];
-            Affine<F> p = point(e);
-            for (uint32_t k = 0; k < d.len; k++) {
-                Affine<F> cur = p;
+                Affine<F> cur = unpack(nxt);
                 const uint32_t ce = e;
                 if (k + 1 < d.len) {
-                    e = srt[k + 1];
-                    p = point(e);
+                    e = e1;
+                    nxt = fetch(e);
+                    if (k + 2 < d.len) e1 = srt[k + 2];
                 }
-#endif
                 // lazy domain (fp29.cuh / ec.cuh::xyzz_madd_lazy): the accumulator is a representative in [0, ~5 p], a negative
                 // digit takes p - y in one carry pass; nothing is compared or selected until the segment is through
                 const bool inf = aff_is_inf<F>(cur);

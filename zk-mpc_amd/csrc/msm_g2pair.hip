@@ -156,6 +156,24 @@ __device__ __forceinline__ AffP aff_load_p(const uint32_t* bases, size_t i, uint
     return AffP{fq_load16(w), fq_load16(w + 2 * FW)};
 }
 
+struct RawP { uint4 x[FW / 4], y[FW / 4]; };
+__device__ __forceinline__ RawP fetch_p(const uint32_t* bases, size_t i, uint32_t odd) {
+    const uint4* w = reinterpret_cast<const uint4*>(bases + i * (4 * FW) + odd * FW);
+    RawP r;
+#pragma unroll
+    for (int k = 0; k < FW / 4; k++) { r.x[k] = w[k]; r.y[k] = w[2 * FW / 4 + k]; }
+    return r;
+}
+__device__ __forceinline__ AffP unpack_p(const RawP& r) {
+    uint32_t tx[FW], ty[FW];
+#pragma unroll
+    for (int k = 0; k < FW / 4; k++) {
+        tx[4 * k] = r.x[k].x; tx[4 * k + 1] = r.x[k].y; tx[4 * k + 2] = r.x[k].z; tx[4 * k + 3] = r.x[k].w;
+        ty[4 * k] = r.y[k].x; ty[4 * k + 1] = r.y[k].y; ty[4 * k + 2] = r.y[k].z; ty[4 * k + 3] = r.y[k].w;
+    }
+    return AffP{B::load(tx), B::load(ty)};
+}
+
 // MODE 2 (the product): 256 registers, two waves per SIMD, no spills.  MODE 0 (experiment, ZK_G2PAIR_WAVES=0): one wave per
 // SIMD AND 192 registers per lane left free -- the clobber of a63 makes the kernel own 256 + 64 registers -- so that kernels
 // of other streams find room on every SIMD beside it instead of waiting for a block of this kernel to retire; measured
@@ -174,14 +192,16 @@ k_accum_g2pair(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ 
         XyzzP acc{B::zero(), B::zero(), B::zero(), B::zero()};
         if (d.len) {
             const uint32_t* srt = sorted + d.start;
-            uint32_t e = srt[0];
-            AffP p = aff_load_p(bases, e & 0x7fffffffu, oddw);
+            // the next point travels as raw words under the current addition and is unpacked when its turn comes (msm.hip::k_accum)
+            uint32_t e = srt[0], e1 = d.len > 1 ? srt[1] : 0;
+            RawP nxt = fetch_p(bases, e & 0x7fffffffu, oddw);
             for (uint32_t k = 0; k < d.len; k++) {
-                AffP cur = p;
+                AffP cur = unpack_p(nxt);
                 const uint32_t ce = e;
                 if (k + 1 < d.len) {
-                    e = srt[k + 1];
-                    p = aff_load_p(bases, e & 0x7fffffffu, oddw);
+                    e = e1;
+                    nxt = fetch_p(bases, e & 0x7fffffffu, oddw);
+                    if (k + 2 < d.len) e1 = srt[k + 2];
                 }
                 // lazy domain: see msm.hip::k_accum
                 const bool inf = pair_zero(limbs_or(cur.x) | limbs_or(cur.y));
