@@ -327,7 +327,9 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     std::vector<HF> pub(ni - 1);
     {
         std::vector<zk_fr> tmp(ni);
-        if (shared) {
+        if (shared && ni == 1) {
+            // no public input beside the constant 1: nothing to open
+        } else if (shared) {
             char* po = P.dev("pub_open", ni); char* pd = P.dev("pub_dx", ni);
             ZK_TRY(P.rc);
             if (LANES == 2) ZK_TRY(zk_shared_spdz_open_vec(nt, zb[0], zb[1], ni, po, pd));
