@@ -764,9 +764,10 @@ def main():
                                 "unit": "T v_mad_u64_u32 lane-ops/s", "frac": round(mads / avg_s / INT_MAD_PEAK, 4),
                                 "mads_per_mixed_add": mads_per_madd}}
             try:  # instruction mix of the kernel's main path (static, from the ISA: tools/isa_hist.py) -> mix-weighted ceiling
-                ih = json.load(open(os.path.join(ROOT, "profiles", "r2_isa_k_accum_g1.json")))
+                isa = "r3_isa_k_accum_g1.json" if os.path.exists(os.path.join(ROOT, "profiles", "r3_isa_k_accum_g1.json")) else "r2_isa_k_accum_g1.json"
+                ih = json.load(open(os.path.join(ROOT, "profiles", isa)))
                 roof["int_alu"]["mix_weighted_ceiling"] = {
-                    "source": "profiles/r2_isa_k_accum_g1.json (tools/isa_hist.py over hipcc -S; priced with profiles/r1_ubench_int.txt: "
+                    "source": "profiles/" + isa + " (tools/isa_hist.py over hipcc -S; priced with profiles/r1_ubench_int.txt: "
                               "v_mad_u64_u32 and the other ~35 T/s classes = 1 issue slot, the ~67 T/s classes = 0.5)",
                     "mad_share_of_issue_slots": round(ih["main_path"]["mix_ceiling"], 4)}
             except Exception:
