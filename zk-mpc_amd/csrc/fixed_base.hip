@@ -142,6 +142,28 @@ __global__ void __launch_bounds__(256) k_repack(const uint32_t* in, uint32_t* ou
     }
 }
 
+// packed G1 points -> the accumulate kernel's own form, 64 words (two 128-byte lines) per point:
+//   line 0: x as 13 limbs of 29 bits, y as 13 limbs  (what fp_unpack would produce: msm.hip::k_accum takes them as they are)
+//   line 1: x, p - y                                   (the point of a NEGATIVE digit: the sign bit of a sorted entry picks the line)
+// Infinity stays all-zero words in both lines.  An entry still costs one line of traffic; the kernel loses the unpacking (~55
+// instructions per addition) and the conditional negation (~55): memory traded for instructions, 256 B per table point.
+template <class F>
+__global__ void __launch_bounds__(256) k_repack_limbs(const uint32_t* in, uint32_t* out, size_t n) {
+    constexpr int L = sizeof(typename F::T) / sizeof(uint32_t);
+    static_assert(2 * L <= 32, "x and y limbs fit one 128-byte line");
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const Affine<F> p = aff_load16<F>(in, i);
+        const bool inf = aff_is_inf<F>(p);
+        const typename F::T ny = inf ? p.y : F::neg(p.y);
+        uint32_t* d = out + i * 64;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            d[k] = k < L ? p.x.l[k] : (k < 2 * L ? p.y.l[k - L] : 0u);
+            d[32 + k] = k < L ? p.x.l[k] : (k < 2 * L ? ny.l[k - L] : 0u);
+        }
+    }
+}
+
 template <class F>
 int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W) {
     const size_t n = b->n, PW = 2 * F::WORDS;
@@ -173,6 +195,23 @@ int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W) {
     // multiples -- read once per digit, at random -- are re-laid one point per line: a third more memory, half the traffic.
     // (ZK_PRE_PAD=0 keeps the packed table.)  G2's 192-byte points take two lines either way.
     static const bool pad = !(getenv("ZK_PRE_PAD") && atoi(getenv("ZK_PRE_PAD")) == 0);
+    // ZK_PRE_LIMBS=0 keeps the packed one-line form below; default: limbs, both signs (k_repack_limbs)
+    static const bool limbs = !(getenv("ZK_PRE_LIMBS") && atoi(getenv("ZK_PRE_LIMBS")) == 0);
+    if constexpr (F::WORDS == 12) {
+        if (pad && limbs && (size_t)W * n * 64 * 4 <= mem_free / 3) {
+            uint32_t* wide = nullptr;
+            if (hipMalloc((void**)&wide, (size_t)W * n * 64 * 4) == hipSuccess) {
+                hipLaunchKernelGGL(k_repack_limbs<F>, zk_grid((size_t)W * n, 256), 256, 0, ctx->stream, (const uint32_t*)b->pre, wide, (size_t)W * n);
+                ZK_HIP(ctx, hipGetLastError());
+                ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                (void)hipFree(b->pre);
+                b->pre = wide;
+                b->pre_stride = 64;
+                return ZK_OK;
+            }
+            (void)hipGetLastError();
+        }
+    }
     if (pad && F::WORDS == 12 && (size_t)W * n * 32 * 4 <= mem_free / 3) {
         uint32_t* padded = nullptr;
         if (hipMalloc((void**)&padded, (size_t)W * n * 32 * 4) == hipSuccess) {

@@ -28,7 +28,8 @@ struct zk_bases {
     // With them every window of an MSM drops into ONE bucket set (fixed_base.hip: zk_bases_precompute).
     uint32_t* pre = nullptr;
     uint32_t c_pre = 0, W_pre = 0;
-    uint32_t pre_stride = 0;   // 32-bit words per point in `pre` (0: packed, 2 * WORDS).  G1: 32 = one 128-byte line per 96-byte point
+    uint32_t pre_stride = 0;   // 32-bit words per point in `pre` (0: packed, 2 * WORDS).  G1: 32 = one 128-byte line per 96-byte point;
+                               // 64 = limb form, line 0 the point, line 1 its negative (fixed_base.hip::k_repack_limbs)
 };
 extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b);   // no-op for tables under 4096 points
 int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b);             // only when ZK_PRECOMP=1 (off by default: see fixed_base.hip)

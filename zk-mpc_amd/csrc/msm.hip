@@ -618,7 +618,7 @@ k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t
 #ifndef ZK_ACCUM_WAVES_G2
 #define ZK_ACCUM_WAVES_G2 1
 #endif
-template <class F>
+template <class F, bool LIMB_TABLE = false>
 __global__ void __launch_bounds__(256, (F::WORDS == 12 ? ZK_ACCUM_WAVES_G1 : ZK_ACCUM_WAVES_G2))
 k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
         const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums, uint32_t stride) {
@@ -626,20 +626,30 @@ k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
     // The NEXT point is fetched as raw words while the current one is added and unpacked into limbs only when its turn comes: the
     // wait for the gather then sits behind a whole mixed addition.  (Fetching it in unpacked form put the wait, and the unpacking,
     // in front of the addition: the loads had nothing to hide behind but the other wave.)
-    constexpr int NW = 2 * F::WORDS / 4;
+    // stride 64 (G1 window multiples, fixed_base.hip::k_repack_limbs): the table holds limbs, and the negative of every point in
+    // the second line of its slot -- the entry's sign bit picks the line; nothing is unpacked or negated here.
+    constexpr int LIMBS = sizeof(typename F::T) / sizeof(uint32_t);
+    constexpr int NW = LIMB_TABLE ? (2 * LIMBS + 3) / 4 : 2 * F::WORDS / 4;
     struct Raw { uint4 v[NW]; };
     auto fetch = [&](uint32_t e) {
-        const uint4* w = reinterpret_cast<const uint4*>(bases + (size_t)(e & 0x7fffffffu) * stride);
+        const uint4* w = reinterpret_cast<const uint4*>(bases + (size_t)(e & 0x7fffffffu) * stride + (LIMB_TABLE ? (e >> 31) * 32u : 0u));
         Raw r;
 #pragma unroll
         for (int i = 0; i < NW; i++) r.v[i] = w[i];
         return r;
     };
     auto unpack = [&](const Raw& r) {
-        uint32_t t[2 * F::WORDS];
+        uint32_t t[4 * NW];
 #pragma unroll
         for (int i = 0; i < NW; i++) { t[4 * i] = r.v[i].x; t[4 * i + 1] = r.v[i].y; t[4 * i + 2] = r.v[i].z; t[4 * i + 3] = r.v[i].w; }
-        return Affine<F>{F::load(t), F::load(t + F::WORDS)};
+        if constexpr (LIMB_TABLE) {
+            Affine<F> a;
+#pragma unroll
+            for (int i = 0; i < LIMBS; i++) { a.x.l[i] = t[i]; a.y.l[i] = t[LIMBS + i]; }
+            return a;
+        } else {
+            return Affine<F>{F::load(t), F::load(t + F::WORDS)};
+        }
     };
     const uint32_t S = ctr[2];
     const uint32_t G = gridDim.x * blockDim.x;
@@ -661,7 +671,7 @@ k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                 // lazy domain (fp29.cuh / ec.cuh::xyzz_madd_lazy): the accumulator is a representative in [0, ~5 p], a negative
                 // digit takes p - y in one carry pass; nothing is compared or selected until the segment is through
                 const bool inf = aff_is_inf<F>(cur);
-                if (ce >> 31) cur.y = F::template kp_minus<1>(cur.y);
+                if (!LIMB_TABLE && (ce >> 31)) cur.y = F::template kp_minus<1>(cur.y);
                 if (!inf) acc = xyzz_madd_lazy<F>(acc, cur);
             }
             acc = xyzz_canon_lazy<F>(acc);
@@ -1015,9 +1025,14 @@ int msm_enqueue_accum_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     const size_t full_grid = (job->max_segs + 255) / 256;
     const unsigned accum_blocks = (unsigned)(bpc > 0 ? std::min<size_t>(full_grid, (size_t)ctx->n_cu * bpc) : full_grid);
     // G2 runs on lane pairs (msm_g2pair.hip): the one-lane-per-addition form needs the whole register file and is slower
-    if constexpr (F::WORDS == 12)
-        hipLaunchKernelGGL(k_accum<F>, accum_blocks, 256, 0, st, job->bases_dev, job->sorted,
-                           (const SegDesc*)job->desc, job->order, job->ctr, b.sums, job->stride);
+    if constexpr (F::WORDS == 12) {
+        if (job->stride == 64)      // limb-form table with both signs (fixed_base.hip::k_repack_limbs)
+            hipLaunchKernelGGL((k_accum<F, true>), accum_blocks, 256, 0, st, job->bases_dev, job->sorted,
+                               (const SegDesc*)job->desc, job->order, job->ctr, b.sums, job->stride);
+        else
+            hipLaunchKernelGGL((k_accum<F, false>), accum_blocks, 256, 0, st, job->bases_dev, job->sorted,
+                               (const SegDesc*)job->desc, job->order, job->ctr, b.sums, job->stride);
+    }
     else
         zk_launch_accum_g2pair(st, job->max_segs, job->bases_dev, job->sorted, job->desc, job->order, job->ctr, b.sums);
     ZK_HIP(ctx, hipGetLastError());
