@@ -747,7 +747,8 @@ def main():
                 for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
                     pth = os.path.join(ROOT, "profiles", f)
                     if os.path.exists(pth) and args.log_constraints == 20 and not args.natural_domain:
-                        traffic = json.load(open(pth))["kernels"]["k_accum<G1>"]["hbm_bytes"]
+                        ks = json.load(open(pth))["kernels"]
+                        traffic = (ks.get("k_accum<G1, true>") or ks["k_accum<G1>"])["hbm_bytes"]      # (limb-form tables: the <F, true> instance)
                         traffic_src = "profiles/" + f
                         break
             except Exception:
