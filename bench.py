@@ -71,24 +71,35 @@ def cpu_baseline(ctx, td, sample_log: int, threads: int, full_log: int = 20):
                pk.download("b_g1_query"), pk.download("b_g2_query"), pk.download("h_query"), pk.download("l_query"))
     t_all, proof_all, ph = OC.bench_mul_chain_prove(n, w0, w1, hp, r_, s_, threads)
     ok = proof_all == gpu_proof
-    t_one, proof_one, _ = OC.bench_mul_chain_prove(n, w0, w1, hp, r_, s_, 1)
-    ok = ok and proof_one == gpu_proof
     for o in (z, ):
         o.free()
     pk.free(); r1cs.free()
+    # single thread (the reference's actual build has no rayon feature) on a BOUNDED sample: 2^17 - 2 constraints is ~11 s of one
+    # core (the full 2^20 would be ~90 s); its own device proof is the check
+    one_log = min(sample_log, 17)
+    n1 = (1 << one_log) - 2
+    r1 = ctx.r1cs_mul_chain(n1)
+    pk1 = ctx.groth16_setup(r1, *td)
+    z1 = ctx.mul_chain_assignment_dev(n1, w0, w1)
+    gpu1 = ctx.create_proof_dev(pk1, r1, z1.ptr, r_, s_)
+    hp1 = OC.Pk(pk1.vk_g1(0), pk1.vk_g1(1), pk1.vk_g1(2), pk1.vk_g2(0), pk1.vk_g2(1), pk1.download("a_query"),
+                pk1.download("b_g1_query"), pk1.download("b_g2_query"), pk1.download("h_query"), pk1.download("l_query"))
+    t_one, proof_one, _ = OC.bench_mul_chain_prove(n1, w0, w1, hp1, r_, s_, 1)
+    ok = ok and proof_one == gpu1
+    z1.free(); pk1.free(); r1.free()
     c_ref = max(3, int(__import__("math").log(max(n, 2))) + 2)        # arkworks' window: ln(n) + 2 (msm/variable_base.rs:22-26)
     windows = (253 + c_ref - 1) // c_ref
     return {"value": round(n / t_all, 1), "unit": "constraints/s", "cores": threads, "kind": "port",
             "sample": "mul-chain prove, n=2^%d-2 constraints (%s), device's proving key; %.2f s with %d threads requested "
-                      "(witness map %.2f s, MSMs %.2f s); single thread (the reference's actual build: no rayon feature): "
-                      "%.2f s = %.0f constraints/s" % (
+                      "(17-way: one thread per Pippenger window; witness map %.2f s, MSMs %.2f s); single thread (the reference's "
+                      "actual build: no rayon feature) on the bounded sample n=2^%d-2: %.2f s = %.0f constraints/s" % (
                           sample_log, "the benched configuration itself" if sample_log == full_log else
-                          "bounded sample of the 2^%d workload" % full_log, t_all, threads, ph[0], ph[1], t_one, n / t_one),
+                          "bounded sample of the 2^%d workload" % full_log, t_all, threads, ph[0], ph[1], one_log, t_one, n1 / t_one),
             "effective_parallel_width": {"msm": min(threads, windows), "fft": min(threads, 32),
                                          "note": "the port parallelises where arkworks' `parallel` feature does: over the %d Pippenger "
                                                  "windows of an MSM (c = %d) and over butterfly chunks; the five MSMs run one after the "
                                                  "other as in the reference" % (windows, c_ref)},
-            "single_thread_value": round(n / t_one, 1), "proof_matches_device": bool(ok)}
+            "single_thread_value": round(n1 / t_one, 1), "single_thread_sample_log": one_log, "proof_matches_device": bool(ok)}
 
 
 def pk_bases(ctx, pk, which):
@@ -389,6 +400,10 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
         torch.cuda.synchronize()
     for _ in range(2 + args.warmup):
         proof = step()
+    preflight = ranks_seen = None
+    if dist is not None and world > 1:
+        preflight = preflight_opens(ctx, dist, party, torch, args.transport)
+        ranks_seen = comm_report(ctx, dist, party, torch)
     sent0 = int(party.bytes_sent) if dist is not None else 0
     if dist is not None:
         party.be.open_stats()
@@ -453,6 +468,13 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
         out["aggregate_constraint_shares_per_s"] = round(n * K / dt * world, 1)
         out["opens_in_timed_proofs"] = opens_timed
         out["prover_entry"] = "mpc.py sequence" if args.python_mpc else ("zk_marlin_prove_shared_spdz" if args.spdz else "zk_marlin_prove_shared")
+        out["preflight_opens"] = preflight
+        out["ranks"] = ranks_seen
+        out["rccl_ranks_seen"] = None if ranks_seen is None else {
+            "torch_distributed": dist.get_world_size() if args.transport == "nccl" else 0,
+            "zk_comm": max([r.get("zk_comm", {}).get("n_ranks", 0) for r in ranks_seen] +
+                           [q["zk_comm"].get("n_ranks", 0) for q in (preflight or []) if "zk_comm" in q]),
+            "devices": sorted(set((r.get("device_uuid") or r["device"]) for r in ranks_seen))}
         out["transport"] = ("RCCL (torch.distributed nccl)" if args.transport == "nccl" else
                             "gloo, opens staged through host memory" + (", every party on cuda:0 (functional run, not a measurement)" if args.one_gpu else ""))
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
@@ -467,6 +489,129 @@ def hbm_in_use_gb():
         return round((total - free) / 1e9, 2)
     except Exception:
         return None
+
+
+def launch_ranks(n: int, real_stdout: int) -> int:
+    """Start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process (the launch line
+    the driver uses for N > 1), relay the one JSON line rank 0 prints, return the launcher's exit code.  The rendezvous is on
+    127.0.0.1 at a port the kernel has just handed out."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this pool's driver only supports dmabuf IPC (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env)
+    out, _ = proc.communicate()
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if lines:
+        try:
+            rec = json.loads(lines[-1])
+            rec["launched_by"] = "bench.py itself (child torch.distributed.run, %d ranks, 127.0.0.1:%d)" % (n, port)
+            os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+        except ValueError:
+            os.write(real_stdout, (lines[-1] + "\n").encode())
+    elif proc.returncode == 0:
+        sys.stderr.write("bench.py: the %d-rank child printed no JSON line\n" % n)
+        return 1
+    return proc.returncode
+
+
+def comm_report(ctx, dist, party, torch):
+    """What actually carried the ranks of an N > 1 run, gathered over the process group: one entry per rank with its device and
+    -- when the library's own communicator is up (ZK_TRANSPORT=native) -- the rank count RCCL itself reports."""
+    info = {"rank": dist.get_rank(), "device": int(ctx.device), "dist_world_size": dist.get_world_size(),
+            "dist_backend": dist.get_backend()}
+    try:
+        if torch.cuda.is_available():
+            info["device_name"] = torch.cuda.get_device_name(ctx.device)
+            info["device_uuid"] = str(getattr(torch.cuda.get_device_properties(ctx.device), "uuid", ""))
+    except Exception:
+        pass
+    if getattr(party.be, "native_open", False):
+        try:
+            info["zk_comm"] = ctx.comm_info()
+        except Exception as e:
+            info["zk_comm"] = {"error": repr(e)}
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, info)
+    return box
+
+
+def preflight_opens(ctx, dist, party, torch, transport: str):
+    """Before the timed loop of an N > 1 run: tiny opens through every transport this launch can use, each compared with the
+    host-side sum mod r of the vectors every rank is known to hold.  Sizes: 1 (fewer elements than parties: padding only), a
+    size not divisible by the party count, and 4096.  Raises with rank, transport, pattern and size on the first difference --
+    a wrong collective must not become a timed number.  mpc-net/src/multi.rs:469-525 semantics: every party ends up with all
+    payloads in party order; here already summed."""
+    import zk_mpc_amd.convert as cv
+    rank, P = dist.get_rank(), dist.get_world_size()
+    report = []
+
+    def vec(p, n):        # party p's vector: canonical residues p * 2^200 + i * (p + 3) + 1, in the library's Montgomery form
+        return cv.fr_to_mont([((p << 200) + i * (p + 3) + 1) % cv.R_MOD for i in range(n)]) if n else np.zeros((0, 4), np.uint64)
+
+    def check(label, pattern, n, fn):
+        mine = ctx.upload(np.ascontiguousarray(vec(rank, n)))
+        out = ctx.alloc(max(n, 1) * 32)
+        fn(mine.ptr, out.ptr, n)
+        ctx.sync()
+        got = cv.fr_from_mont(ctx.download(out, (n, 4)))
+        want = [sum(((p << 200) + i * (p + 3) + 1) for p in range(P)) % cv.R_MOD for i in range(n)]
+        mine.free(); out.free()
+        if list(got) != want:
+            bad = next(i for i in range(n) if got[i] != want[i])
+            raise RuntimeError("pre-flight open FAILED on rank %d: transport %s, pattern %s, n = %d, first wrong element %d"
+                               % (rank, label, pattern, n, bad))
+        report.append({"transport": label, "pattern": pattern, "n": n, "ok": True})
+
+    sizes = (1, 1000 + 1, 4096)
+    be = party.be
+    native = getattr(be, "native_open", False)
+    # (a) the transport the timed proofs will use
+    for n in sizes:
+        check("native (zk_open_sum_fr_dev, RCCL inside the library)" if native else "torch.distributed/%s" % transport,
+              "by party count", n, lambda v, o, m: be._open_vec(v, o, m))
+    if transport == "nccl":
+        # (b) the other RCCL path, so that both have carried P ranks before either is trusted: DistNet's collectives when the
+        # timed path is native, the library's own communicator when it is DistNet's
+        if native:
+            be.native_open = False
+            try:
+                for n in sizes:
+                    check("torch.distributed/nccl", "by party count", n, lambda v, o, m: be._open_vec(v, o, m))
+            finally:
+                be.native_open = True
+        else:
+            box = [ctx.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(box[0], rank, P)
+            try:
+                for pat, name in ((0, "by party count"), (1, "all-gather"), (2, "all-to-all of slices")):
+                    ctx.comm_set_open_pattern(pat)
+                    for n in sizes:
+                        check("native (zk_open_sum_fr_dev, RCCL inside the library)", name, n,
+                              lambda v, o, m: (ctx.open_sum_fr_dev(v, m, o), ctx.sync()))
+                report.append({"zk_comm": ctx.comm_info()})
+            finally:
+                ctx.comm_destroy()
+        # (c) both exchange patterns of DistNet, whatever the party count picks by default
+        keep = party.net.open_pattern
+        native_keep = getattr(be, "native_open", False)
+        be.native_open = False
+        try:
+            for pat in ("allgather", "a2a"):
+                party.net.open_pattern = pat
+                for n in sizes:
+                    check("torch.distributed/nccl", pat, n, lambda v, o, m: be._open_vec(v, o, m))
+        finally:
+            party.net.open_pattern = keep
+            be.native_open = native_keep
+    dist.barrier()
+    return report
 
 
 def main():
@@ -506,9 +651,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has not touched the GPU (no
+        # torch import, no HIP call so far) and never will: the ranks are CHILD processes of torch.distributed.run, rank 0's one
+        # JSON line is relayed, the exit code is the launcher's.
+        sys.exit(launch_ranks(args.gpus, real_stdout))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+        sys.exit("bench.py --gpus %d inside a launch of WORLD_SIZE=%d: the two must agree" % (args.gpus, world))
 
     import hashlib
     import torch
@@ -611,16 +760,26 @@ def main():
     ctx.set_profiling(True)
     if dist is not None:
         party.be.open_stats()                 # reset the per-open wall-time counters
+    preflight = None
+    ranks_seen = None
+    if dist is not None and world > 1:
+        # N > 1: both transports carry a tiny open and are checked against the host-side sum before anything is timed
+        preflight = preflight_opens(ctx, dist, party, torch, args.transport)
+        ranks_seen = comm_report(ctx, dist, party, torch)
     barrier()
+    step_s = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         proof = step(it); it += 1
+        step_s.append(time.perf_counter() - ts)          # (a proof call returns with the proof's bytes: no extra synchronisation)
     barrier()
     dt = time.perf_counter() - t0
     timers = ctx.timers()
     ctx.set_profiling(False)
     opens_timed = party.be.open_stats(args.steps) if dist is not None else None
     isolated_ms = None
+    isolated_all = None
     host_leg = None
     if dist is None:
         ctx.groth16_hint_next_dev(None)
@@ -628,11 +787,14 @@ def main():
             # the same proofs without the announcement (latency of one isolated proof), outside the timed region
             ctx.create_proof_dev(pk, r1cs, zs[0].ptr, *rs[0])
             barrier()
-            t1 = time.perf_counter()
-            for i in range(3):
+            iso = []
+            for i in range(7):
+                t1 = time.perf_counter()
                 ctx.create_proof_dev(pk, r1cs, zs[i % Q].ptr, *rs[i % Q])
-            barrier()
-            isolated_ms = (time.perf_counter() - t1) / 3 * 1e3
+                ctx.sync()
+                iso.append((time.perf_counter() - t1) * 1e3)
+            isolated_ms = float(np.median(iso))
+            isolated_all = [round(x, 3) for x in iso]
         # second leg, SURVEY 8(d)'s definition of t: "from witness vector on host to 192 proof bytes on host", through the
         # host-slice entry point (zk_groth16_prove_queued; the assignments sit in page-locked host memory from zk_host_alloc)
         try:
@@ -649,25 +811,32 @@ def main():
                     host_ok = False
             barrier()
             t1 = time.perf_counter()
-            Kh = max(args.steps, 4)
+            Kh = max(args.steps, 5)
+            hq = []
             for i in range(2, 2 + Kh):
+                ts = time.perf_counter()
                 p = ctx.create_proof_queued(pk, r1cs, hz[i % Q], *rs[i % Q], z_next_host=hz[(i + 1) % Q])
+                hq.append(time.perf_counter() - ts)
                 if (i % Q) in last_proof and p != last_proof[i % Q]:
                     host_ok = False
             barrier()
             th = (time.perf_counter() - t1) / Kh
-            # one isolated host proof (no announcement): upload + proof + bytes back
+            # isolated host proofs (no announcement): upload + proof + bytes back, each on its own
             ctx.create_proof_queued(pk, r1cs, hz[0], *rs[0])
             barrier()
-            t1 = time.perf_counter()
-            for i in range(3):
+            hi_ = []
+            for i in range(5):
+                t1 = time.perf_counter()
                 ctx.create_proof_queued(pk, r1cs, hz[i % Q], *rs[i % Q])
-            barrier()
-            th_iso = (time.perf_counter() - t1) / 3
+                ctx.sync()
+                hi_.append(time.perf_counter() - t1)
+            th_iso = float(np.median(hi_))
             host_leg = {"entry_point": "zk_groth16_prove_queued (host assignment in page-locked memory -> 192 proof bytes on the host; "
                                        "the next assignment announced and uploaded on a copy stream under the current proof)",
                         "ms_per_proof": round(th * 1e3, 3), "constraints_per_s": round(n / th, 1),
+                        "median_ms_per_proof": round(float(np.median(hq)) * 1e3, 3), "max_ms_per_proof": round(max(hq) * 1e3, 3),
                         "isolated_ms_per_proof": round(th_iso * 1e3, 3), "isolated_constraints_per_s": round(n / th_iso, 1),
+                        "isolated_ms_all": [round(x * 1e3, 3) for x in hi_], "statistic": "mean over the queue; median of 5 isolated",
                         "proofs_equal_device_leg": bool(host_ok), "steps": Kh}
             for pb in pinned:
                 pb.free()
@@ -744,7 +913,7 @@ def main():
             mads = madds * mads_per_madd
             traffic, traffic_src = None, None
             try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), not measured live
-                for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+                for f in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
                     pth = os.path.join(ROOT, "profiles", f)
                     if os.path.exists(pth) and args.log_constraints == 20 and not args.natural_domain:
                         ks = json.load(open(pth))["kernels"]
@@ -753,19 +922,34 @@ def main():
                         break
             except Exception:
                 pass
-            roof = {"bound": "hbm", "kernel": "k_accum<G1> (MSM bucket accumulation)", "achieved": round(achieved, 2),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            # the roof that binds: SURVEY 8(d) prices an MSM kernel against the v_mad_u64_u32 issue rate, measured on THIS device in
+            # THIS run (zk_diag_int_mad_peak: 12 launches of a pure multiply-add kernel after the timed loop; median launch = the roof)
+            peak, peak_src = INT_MAD_PEAK, "constant from profiles/r1_ubench_int.txt (the live measurement failed)"
+            try:
+                pk_meas = ctx.int_mad_peak(12)
+                peak = pk_meas["median"]
+                peak_src = ("measured in this run: zk_diag_int_mad_peak, median of %d launches of ~4.5 ms each, ~50 ms in all (the sustained "
+                            "rate; fastest launch %.2f T/s)" % (pk_meas["launches"], pk_meas["best"] / 1e12))
+            except Exception as e:
+                peak_src += ": %r" % (e,)
+            roof = {"bound": "int_alu", "kernel": "k_accum<G1> (MSM bucket accumulation), 4 launches per proof",
+                    "achieved": round(mads / avg_s / 1e12, 3), "peak": round(peak / 1e12, 3), "unit": "T v_mad_u64_u32 lane-ops/s",
+                    "frac": round(mads / avg_s / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                    "peak_source": peak_src, "avg_launch_ms": round(avg_s * 1e3, 3), "launches": acc_cnt,
+                    "work_per_launch": {"mixed_additions": madds, "mads_per_mixed_add": mads_per_madd, "terms": n_msm, "digits_per_scalar": W,
+                                        "window_bits": c},
                     "traffic_source": traffic_src,
-                    "traffic_note": "bytes/launch, 2*FETCH_SIZE+WRITE_SIZE from a SEPARATE rocprofv3 --pmc run committed under profiles/ "
-                                    "(not measured in this run); ~25x the 128 B/term algorithmic figure because the bucket method "
-                                    "reads every base once per digit (13x) in 128-B lines (96-B points); the kernel is ALU-bound",
-                    "avg_launch_ms": round(avg_s * 1e3, 3), "launches": acc_cnt,
-                    "note": "kernel is integer-ALU bound, not HBM bound (SURVEY 8d); see int_alu",
-                    "int_alu": {"achieved": round(mads / avg_s / 1e12, 3), "peak": round(INT_MAD_PEAK / 1e12, 2),
-                                "unit": "T v_mad_u64_u32 lane-ops/s", "frac": round(mads / avg_s / INT_MAD_PEAK, 4),
-                                "mads_per_mixed_add": mads_per_madd}}
+                    "traffic_note": "2*FETCH_SIZE+WRITE_SIZE from a SEPARATE rocprofv3 --pmc run committed under profiles/ (not measured in "
+                                    "this run); above the 128 B/term algorithmic figure because the bucket method reads every base once per "
+                                    "digit in 128-B lines; the kernel is ALU-bound, the HBM view is nested under `hbm`",
+                    "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                            "algorithmic_bytes_per_launch": alg_bytes,
+                            "note": "128 B/term (32 B scalar + 96 B base) over the kernel's launch time: not the binding roof"}}
+            roof["int_alu"] = {"achieved": roof["achieved"], "peak": roof["peak"], "unit": roof["unit"], "frac": roof["frac"],
+                               "mads_per_mixed_add": mads_per_madd}          # (the place earlier rounds' parsers looked)
             try:  # instruction mix of the kernel's main path (static, from the ISA: tools/isa_hist.py) -> mix-weighted ceiling
-                isa = "r3_isa_k_accum_g1.json" if os.path.exists(os.path.join(ROOT, "profiles", "r3_isa_k_accum_g1.json")) else "r2_isa_k_accum_g1.json"
+                isa = next(f for f in ("r4_isa_k_accum_g1.json", "r3_isa_k_accum_g1.json", "r2_isa_k_accum_g1.json")
+                           if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 ih = json.load(open(os.path.join(ROOT, "profiles", isa)))
                 roof["int_alu"]["mix_weighted_ceiling"] = {
                     "source": "profiles/" + isa + " (tools/isa_hist.py over hipcc -S; priced with profiles/r1_ubench_int.txt: "
@@ -780,8 +964,8 @@ def main():
                 g2_s = g2_ms / g2_cnt * 1e-3
                 roof["g2_accum"] = {"kernel": "k_accum_g2pair (B-in-G2 bucket accumulation, two lanes per addition)",
                                     "avg_launch_ms": round(g2_s * 1e3, 3), "launches": g2_cnt,
-                                    "int_alu": {"achieved": round(madds * MADS_PER_MADD_G2 / g2_s / 1e12, 3), "peak": round(INT_MAD_PEAK / 1e12, 2),
-                                                "unit": "T v_mad_u64_u32 lane-ops/s", "frac": round(madds * MADS_PER_MADD_G2 / g2_s / INT_MAD_PEAK, 4)}}
+                                    "int_alu": {"achieved": round(madds * MADS_PER_MADD_G2 / g2_s / 1e12, 3), "peak": round(peak / 1e12, 3),
+                                                "unit": "T v_mad_u64_u32 lane-ops/s", "frac": round(madds * MADS_PER_MADD_G2 / g2_s / peak, 4)}}
         share_kind = "SPDZ (share + MAC lanes, MAC-checked opens)" if args.spdz else "additive-share"
         out = {
             "metric": "R1CS constraints/sec (prove), Groth16 BLS12-377",
@@ -801,7 +985,9 @@ def main():
             "proof_constraints_per_s": round(per_proof, 1),
             "proof_matches_prediction": pred.get("ok"),
             "prediction_check": pred,
+            "ms_per_step_median": round(float(np.median(step_s)) * 1e3, 3), "ms_per_step_max": round(max(step_s) * 1e3, 3),
             "isolated_proof_ms": None if isolated_ms is None else round(isolated_ms, 3),
+            "isolated_proof_ms_all": isolated_all,
             "host_witness_leg": host_leg,
             "phases_ms_per_proof": {k: round(v[0] / K, 3) for k, v in sorted(timers.items())},
             "setup_s": round(t_setup, 2),
@@ -820,6 +1006,13 @@ def main():
             out["prover_entry"] = ("mpc.py sequence" if args.python_mpc else
                                    "zk_groth16_prove_shared%s (one C-ABI call per proof)" % ("_spdz" if args.spdz else ""))
             out["open_probe"] = open_probe
+            out["preflight_opens"] = preflight
+            out["ranks"] = ranks_seen
+            out["rccl_ranks_seen"] = None if ranks_seen is None else {
+                "torch_distributed": dist.get_world_size() if args.transport == "nccl" else 0,
+                "zk_comm": max([r.get("zk_comm", {}).get("n_ranks", 0) for r in ranks_seen] +
+                               [p["zk_comm"].get("n_ranks", 0) for p in (preflight or []) if "zk_comm" in p]),
+                "devices": sorted(set((r.get("device_uuid") or r["device"]) for r in ranks_seen))}
             out["transport"] = ("RCCL (torch.distributed nccl), one GPU per party" if args.transport == "nccl" else
                                 "gloo, opens staged through host memory" + (", every party on cuda:0 (functional run, not a measurement)" if args.one_gpu else ""))
             out["bytes_sent_per_party"] = int(party.bytes_sent)
@@ -829,15 +1022,22 @@ def main():
             msm = {}
             for name, q, grp in (("g1", pk_bases(ctx, pk, "a"), 1), ("g2", pk_bases(ctx, pk, "b_g2"), 2)):
                 m = n                       # terms
-                ctx.msm_dev(q, 1, zs[0].ptr + 32, m)
-                ctx.sync()
-                t1 = time.perf_counter()
-                reps = 5
-                for _ in range(reps):
+                warm = []
+                for _ in range(2):          # the first calls of a new shape after the proofs (reported, not part of the median)
+                    t1 = time.perf_counter()
                     ctx.msm_dev(q, 1, zs[0].ptr + 32, m)
+                    warm.append(time.perf_counter() - t1)
                 ctx.sync()
-                msm[name] = round(m * reps / (time.perf_counter() - t1) / 1e6, 1)
-            out["msm_mscalar_per_s"] = dict(msm, n=n, note="single MSM per call incl. host round trip, bases resident")
+                reps = []
+                for _ in range(9):
+                    t1 = time.perf_counter()
+                    ctx.msm_dev(q, 1, zs[0].ptr + 32, m)      # returns with the result on the host
+                    reps.append(time.perf_counter() - t1)
+                med = float(np.median(reps))
+                msm[name] = round(m / med / 1e6, 1)
+                msm[name + "_ms"] = {"median": round(med * 1e3, 3), "min": round(min(reps) * 1e3, 3), "max": round(max(reps) * 1e3, 3),
+                                     "all": [round(x * 1e3, 3) for x in reps], "first_two_calls": [round(x * 1e3, 3) for x in warm]}
+            out["msm_mscalar_per_s"] = dict(msm, n=n, note="single MSM per call incl. host round trip, bases resident (window multiples); median of 9 calls")
         if dist is None and not args.no_extras:
             out["other_workloads"] = other_workloads(ctx, min(args.log_constraints, 20))
         if dist is None and not args.no_micro and not args.no_extras:

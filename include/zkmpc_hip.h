@@ -396,10 +396,14 @@ int zk_she_decode_dev(zk_ctx* ctx, const void* enc_dev, void* out_fr_dev, size_t
 /* ---- transport of the vector opens inside the library (row a13): RCCL over xGMI, one communicator per context ----
  * The leader calls zk_comm_unique_id and ships the 128 bytes to the other parties over the channel it already has (the
  * reference's TCP mesh); then every party calls zk_comm_init(ctx, id, party_id, n_parties).  RCCL is dlopen'ed on first
- * use (ZK_RCCL_LIB overrides the library name). */
+ * use: ZK_RCCL_LIB if set, else the copy ALREADY mapped in the process (a host with PyTorch has one), else librccl.so.1 by
+ * name -- never a second copy beside a mapped one. */
 int zk_comm_unique_id(uint8_t out[128]);
 int zk_comm_init(zk_ctx* ctx, const uint8_t id[128], int rank, int n_parties);
 int zk_comm_destroy(zk_ctx* ctx);             /* also done by zk_ctx_destroy */
+/* Diagnostics: rank count and rank as the communicator reports them (ncclCommCount / ncclCommUserRank; 0 / -1 without one), the
+ * context's device, RCCL's version code, the path of the RCCL copy that was bound.  Out pointers may be NULL. */
+int zk_comm_info(zk_ctx* ctx, int* n_ranks, int* rank, int* device, int* rccl_version, char* lib_path, size_t lib_path_cap);
 /* Exchange pattern of zk_open_sum_fr_dev: 0 = by party count (default), 1 = all-gather + sum, 2 = all-to-all of slices +
  * sum + all-gather.  A property of the communicator: every party must make the same call (it is not read from the
  * environment, where parties could disagree and wait for each other in different collectives). */
@@ -511,6 +515,10 @@ int zk_chacha_block(const uint8_t key[32], const uint32_t words12_15[4], int rou
  * `name_stride` bytes apart; returns the number of entries written. */
 int zk_set_profiling(zk_ctx* ctx, int on);
 int zk_last_timers(zk_ctx* ctx, char* names, size_t name_stride, float* ms, int* counts, int max_entries);
+/* Diagnostic (no reference counterpart): the issue rate of v_mad_u64_u32 on this device in lane multiply-adds per second, measured
+ * now with `launches` timed launches of a pure multiply-add kernel (~4.4 ms each) on the context stream: best and median launch.
+ * This is the integer-ALU roof the MSM kernels are priced against. */
+int zk_diag_int_mad_peak(zk_ctx* ctx, int launches, double* best_mads_per_s, double* median_mads_per_s);
 
 #ifdef __cplusplus
 }

@@ -192,6 +192,7 @@ PROTOTYPES = {
     "zk_comm_unique_id": (_I, [_P]),
     "zk_comm_init": (_I, [_P, _P, _I, _I]),
     "zk_comm_destroy": (_I, [_P]),
+    "zk_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.c_char_p, _SZ]),
     "zk_comm_set_open_pattern": (_I, [_P, _I]),
     "zk_open_sum_fr_dev": (_I, [_P, _P, _SZ, _P]),
     "zk_memcpy_d2d": (_I, [_P, _P, _P, _SZ]),
@@ -231,6 +232,7 @@ PROTOTYPES = {
     "zk_chacha_block": (_I, [_P, _P, _I, _P]),
     "zk_set_profiling": (_I, [_P, _I]),
     "zk_last_timers": (_I, [_P, _P, _SZ, _P, _P, _I]),
+    "zk_diag_int_mad_peak": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

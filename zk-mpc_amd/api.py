@@ -209,6 +209,12 @@ class Context:
     def stream(self) -> int:
         return self.lib.zk_ctx_stream(self.h)
 
+    def int_mad_peak(self, launches: int = 12) -> dict:
+        """zk_diag_int_mad_peak: v_mad_u64_u32 lane-ops/s of this device, measured now (best and median launch)."""
+        best, med = C.c_double(0), C.c_double(0)
+        self._ck(self.lib.zk_diag_int_mad_peak(self.h, launches, C.byref(best), C.byref(med)))
+        return {"best": best.value, "median": med.value, "launches": launches}
+
     def set_profiling(self, on: bool):
         self._ck(self.lib.zk_set_profiling(self.h, int(on)))
 
@@ -460,6 +466,14 @@ class Context:
         buf = np.frombuffer(unique_id, dtype=np.uint8).copy()
         assert buf.size == 128
         self._ck(self.lib.zk_comm_init(self.h, _ptr(buf), rank, n_parties))
+
+    def comm_info(self) -> dict:
+        """zk_comm_info: what the context's RCCL communicator reports about itself (n_ranks 0 without one) and which RCCL copy
+        the library bound."""
+        n, r, d, v = C.c_int(0), C.c_int(-1), C.c_int(-1), C.c_int(0)
+        path = C.create_string_buffer(1024)
+        self._ck(self.lib.zk_comm_info(self.h, C.byref(n), C.byref(r), C.byref(d), C.byref(v), path, 1024))
+        return {"n_ranks": n.value, "rank": r.value, "device": d.value, "rccl_version": v.value, "library": path.value.decode()}
 
     def comm_set_open_pattern(self, pattern: int):
         """0: by party count, 1: all-gather, 2: all-to-all of slices (every party must choose the same)."""

@@ -32,21 +32,33 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
 };
 
 // Loaded once per process, by whichever thread comes first (a function-local static is initialised exactly once even when
 // several parties' threads arrive together, the LocalTestNet shape of mpc-net/src/multi.rs:419-443); immutable afterwards.
+// WHICH copy: a process that hosts PyTorch already has one mapped (torch/lib/librccl.so, soname librccl.so.1) and a second
+// one (/opt/rocm/lib) would bring its own bootstrap threads, IPC handle caches and a second set of kernels for the same
+// devices.  So the rule is "exactly one RCCL per process": ZK_RCCL_LIB if set; otherwise the copy that is ALREADY mapped
+// (RTLD_NOLOAD by soname, which matches torch's whatever its path); only when none is mapped is one loaded by name.
+// zk_comm_info reports the path that was bound.
 Rccl load_rccl() {
     Rccl r;
-    const char* names[] = {getenv("ZK_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char* nm : names) {
-        if (!nm) continue;
-        if ((r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    if (const char* forced = getenv("ZK_RCCL_LIB")) r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    if (!r.lib) {
+        for (const char* nm : {"librccl.so.1", "librccl.so"})
+            if ((r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
+    }
+    if (!r.lib) {
+        for (const char* nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"})
+            if ((r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
     }
     if (r.lib) {
 #define ZK_SYM(f) *(void**)(&r.f) = dlsym(r.lib, "nccl" #f)
         ZK_SYM(GetUniqueId); ZK_SYM(CommInitRank); ZK_SYM(CommDestroy); ZK_SYM(AllGather); ZK_SYM(Send); ZK_SYM(Recv);
-        ZK_SYM(GroupStart); ZK_SYM(GroupEnd); ZK_SYM(GetErrorString);
+        ZK_SYM(GroupStart); ZK_SYM(GroupEnd); ZK_SYM(GetErrorString); ZK_SYM(CommCount); ZK_SYM(CommUserRank); ZK_SYM(GetVersion);
 #undef ZK_SYM
     }
     return r;
@@ -119,6 +131,35 @@ extern "C" int zk_comm_destroy(zk_ctx* ctx) {
     if (R && R->CommDestroy && c->comm) (void)R->CommDestroy(c->comm);
     delete c;
     ctx->comm = nullptr;
+    return ZK_OK;
+    ZK_API_END
+}
+
+// What the communicator itself says (ncclCommCount / ncclCommUserRank, not the arguments of zk_comm_init), the device it lives
+// on, RCCL's version code and the path of the library copy that was bound (dladdr of ncclGetUniqueId).  Any out pointer may be
+// NULL.  Without a communicator: n_ranks = 0, rank = -1, and the library fields are still filled in when RCCL can be loaded.
+extern "C" int zk_comm_info(zk_ctx* ctx, int* n_ranks, int* rank, int* device, int* rccl_version, char* lib_path, size_t lib_path_cap) {
+    ZK_API_BEGIN(ctx)
+    if (!ctx) return ZK_ERR_ARG;
+    if (n_ranks) *n_ranks = 0;
+    if (rank) *rank = -1;
+    if (device) *device = ctx->device;
+    if (rccl_version) *rccl_version = 0;
+    if (lib_path && lib_path_cap) lib_path[0] = 0;
+    const Rccl* R = rccl(&ctx->last_error);
+    if (!R) return ZK_ERR_STATE;
+    if (rccl_version && R->GetVersion) (void)R->GetVersion(rccl_version);
+    if (lib_path && lib_path_cap) {
+        Dl_info di;
+        if (dladdr((void*)R->GetUniqueId, &di) && di.dli_fname) { strncpy(lib_path, di.dli_fname, lib_path_cap - 1); lib_path[lib_path_cap - 1] = 0; }
+    }
+    if (ctx->comm) {
+        Comm* c = (Comm*)ctx->comm;
+        int v = c->n;
+        if (n_ranks) { if (R->CommCount) ZK_NCCL(ctx, R, R->CommCount(c->comm, &v)); *n_ranks = v; }
+        v = c->rank;
+        if (rank) { if (R->CommUserRank) ZK_NCCL(ctx, R, R->CommUserRank(c->comm, &v)); *rank = v; }
+    }
     return ZK_OK;
     ZK_API_END
 }

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <exception>
@@ -166,8 +167,13 @@ hipError_t zk_stream_create(hipStream_t* st, bool high_priority);   // core.hip
 struct ZkDeviceGuard {
     int prev = -1;
     bool switched = false;
+    hipError_t err = hipSuccess;           // a failing hipGetDevice / hipSetDevice: the body must NOT run on whatever device the thread holds
     explicit ZkDeviceGuard(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev && hipSetDevice(dev) == hipSuccess) switched = true;
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
     }
     ~ZkDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
     ZkDeviceGuard(const ZkDeviceGuard&) = delete;
@@ -180,6 +186,11 @@ static inline int zk_api_guarded(zk_ctx* ctx, Fn&& body) noexcept {
     try {
         if (!ctx) return body();
         ZkDeviceGuard guard(ctx->device);
+        if (guard.err != hipSuccess) {
+            // another party's GPU would take this context's pointers: silent corruption instead of an error code
+            ctx->last_error = std::string("cannot make device ") + std::to_string(ctx->device) + " current: " + hipGetErrorString(guard.err);
+            return ZK_ERR_HIP;
+        }
         return body();
     } catch (const std::bad_alloc&) {
         try { if (ctx) ctx->last_error = "out of host memory (std::bad_alloc)"; } catch (...) {}
@@ -192,10 +203,41 @@ static inline int zk_api_guarded(zk_ctx* ctx, Fn&& body) noexcept {
         return ZK_ERR_STATE;
     }
 }
+// The handle of a host-side helper task: a future that JOINS in its destructor, as std::async's does and a packaged_task's does
+// not.  The tasks capture their frame by reference (window sums, the host chains of a proof, Marlin's blinding terms), so a
+// frame left early -- a ZK_TRY return, an exception on its way to the C-ABI barrier -- must not be unwound under a running
+// task.  Declare a ZkTask AFTER everything its task references: locals are destroyed in reverse order.  (A deferred std::async
+// future is not run by the destructor: nothing of it is in flight.)
+template <class R>
+class ZkTask {
+    std::future<R> f;
+    void join() noexcept {
+        if (!f.valid()) return;
+        try {
+            if (f.wait_for(std::chrono::seconds(0)) != std::future_status::deferred) f.wait();
+        } catch (...) {}
+    }
+
+   public:
+    ZkTask() = default;
+    ZkTask(std::future<R>&& x) : f(std::move(x)) {}          // (implicit: zk_async and std::async results both land here)
+    ZkTask(ZkTask&& o) noexcept : f(std::move(o.f)) {}
+    ZkTask& operator=(ZkTask&& o) noexcept {
+        if (this != &o) { join(); f = std::move(o.f); }
+        return *this;
+    }
+    ZkTask(const ZkTask&) = delete;
+    ZkTask& operator=(const ZkTask&) = delete;
+    ~ZkTask() { join(); }
+    bool valid() const { return f.valid(); }
+    void wait() { f.wait(); }
+    R get() { return f.get(); }
+};
+
 // A host-side helper task on the context's worker pool.
 template <class Fn>
-static inline auto zk_async(zk_ctx* ctx, Fn&& fn) -> std::future<decltype(fn())> {
-    return ctx->pool.submit(std::forward<Fn>(fn));
+static inline auto zk_async(zk_ctx* ctx, Fn&& fn) -> ZkTask<decltype(fn())> {
+    return ZkTask<decltype(fn())>(ctx->pool.submit(std::forward<Fn>(fn)));
 }
 
 #define ZK_API_BEGIN(ctx) return zk_api_guarded((zk_ctx*)(ctx), [&]() -> int {

@@ -941,7 +941,7 @@ extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs*
     const Affine<H2> b02 = aff_to_host64<G2Field>(pk->b0_g2), beta2 = aff_to_host64<G2Field>(pk->beta_g2);
     X1 g_a, s_g_a, r_s_delta, r_g1_b;
     Affine<H2> b_aff;
-    std::future<void> chain_a, chain_b, chain_g2;
+    ZkTask<void> chain_a, chain_b, chain_g2;         // (declared after everything the chains write: joined before those go)
     std::chrono::steady_clock::time_point t_tail;
     auto after_abc = [&]() {
         const X1 a_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[2]);
@@ -1176,12 +1176,8 @@ int prove_shared_impl(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void
     const SX1 delta1 = xyzz_from_affine<SH1>(aff_to_host64<G1Field>(pk->delta_g1));
     const SX2 delta2 = xyzz_from_affine<SH2>(aff_to_host64<G2Field>(pk->delta_g2));
     // public point x shared scalar: local host arithmetic (scale_pub_group, share/additive.rs:502-508), under the device work
-    std::future<SX1> f_r_g1[2], f_s_g1[2];
-    std::future<SX2> f_s_g2[2];
-    struct Join {                                        // the helper tasks reference this frame: never leave it before they are done
-        std::future<SX1>*a, *b; std::future<SX2>* c;
-        ~Join() { for (int l = 0; l < 2; l++) { if (a[l].valid()) a[l].wait(); if (b[l].valid()) b[l].wait(); if (c[l].valid()) c[l].wait(); } }
-    } join{f_r_g1, f_s_g1, f_s_g2};
+    ZkTask<SX1> f_r_g1[2], f_s_g1[2];                  // (joining handles: the tasks reference this frame and are waited for when it is left)
+    ZkTask<SX2> f_s_g2[2];
     for (int l = 0; l < LANES; l++) {
         f_r_g1[l] = zk_async(ctx, [&, l] { return host64_scalar_mul<SH1>(delta1, rw[l]); });
         f_s_g1[l] = zk_async(ctx, [&, l] { return host64_scalar_mul<SH1>(delta1, sw[l]); });
@@ -1247,8 +1243,14 @@ int prove_shared_impl(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void
                 if (!fr_abi_valid(w + 4 * k)) ZK_FAIL(ctx, ZK_ERR_STATE, "prove_shared: a party sent a non-canonical field element");
                 o.f[k] = fp_add<FrParams>(o.f[k], host_load_ext<FrParams>(w + 4 * k));
             }
-            for (int k = 0; k < 3; k++) o.g[k] = xyzz_add<SH1>(o.g[k], host64_proj_from_abi<SH1>(w + 8 + 18 * k));
-            o.B = xyzz_add<SH2>(o.B, host64_proj_from_abi<SH2>(w + 62));
+            // points from a peer: canonical coordinates, on the curve; the malicious-security prover also checks the subgroup
+            // (GroupAffine::deserialize behind MpcSerNet::broadcast, channel.rs:12-28).  A party's own message is its own output.
+            bool pts_ok = true;
+            const bool peer = p != ctx->party_id;
+            for (int k = 0; k < 3; k++)
+                o.g[k] = xyzz_add<SH1>(o.g[k], peer ? host64_peer_point<SH1>(w + 8 + 18 * k, LANES == 2, pts_ok) : host64_proj_from_abi<SH1>(w + 8 + 18 * k));
+            o.B = xyzz_add<SH2>(o.B, peer ? host64_peer_point<SH2>(w + 62, LANES == 2, pts_ok) : host64_proj_from_abi<SH2>(w + 62));
+            if (!pts_ok) ZK_FAIL(ctx, ZK_ERR_STATE, "prove_shared: a party sent a point that is not a valid group element");
         }
         return ZK_OK;
     };
@@ -1296,20 +1298,24 @@ int prove_shared_impl(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void
     uint64_t cmsg[18];
     host64_write_projective<SH1>(xyzz_to_affine<SH1>(g_c[0]), cmsg);
     ZK_TRY(nt.gather((const uint8_t*)cmsg, sizeof cmsg, all));          // Proof::reveal of C (A and B were opened above)
+    bool c_ok = true;
     auto sum_g1 = [&](const std::vector<uint8_t>& v) {
         SX1 acc = xyzz_inf<SH1>();
         for (int p = 0; p < nt.parties(); p++) {
             uint64_t w[18];
             memcpy(w, v.data() + (size_t)p * sizeof w, sizeof w);
-            acc = xyzz_add<SH1>(acc, host64_proj_from_abi<SH1>(w));
+            acc = xyzz_add<SH1>(acc, p != ctx->party_id ? host64_peer_point<SH1>(w, LANES == 2, c_ok) : host64_proj_from_abi<SH1>(w));
         }
         return acc;
     };
     const SX1 C = sum_g1(all);
+    if (!c_ok) ZK_FAIL(ctx, ZK_ERR_STATE, "prove_shared: a party sent a point that is not a valid group element");
     if (LANES == 2) {
         host64_write_projective<SH1>(xyzz_to_affine<SH1>(xyzz_add<SH1>(leader ? C : xyzz_inf<SH1>(), xyzz_neg<SH1>(g_c[1]))), cmsg);
         ZK_TRY(nt.gather((const uint8_t*)cmsg, sizeof cmsg, all));
-        if (!xyzz_is_inf<SH1>(sum_g1(all))) ZK_FAIL(ctx, ZK_ERR_MAC, "SPDZ MAC check failed on the reveal of C");
+        const SX1 dsum = sum_g1(all);
+        if (!c_ok) ZK_FAIL(ctx, ZK_ERR_STATE, "prove_shared: a party sent a point that is not a valid group element");
+        if (!xyzz_is_inf<SH1>(dsum)) ZK_FAIL(ctx, ZK_ERR_MAC, "SPDZ MAC check failed on the reveal of C");
     }
     g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<SH1>(sx_a)), proof);
     g2_serialize(aff_from_host64<G2Field>(xyzz_to_affine<SH2>(op.B)), proof + 48);

@@ -215,6 +215,54 @@ inline XYZZ<H> host64_proj_from_abi(const uint64_t* p) {
     return XYZZ<H>{get(p), get(p + FE), zz, H::mul(zz, z)};
 }
 
+// ---- a point that arrives from a PEER (the collaborative provers' small opens) ---------------------------------------------
+// The reference's MpcSerNet::broadcast deserialises every payload and unwraps (mpc-algebra/src/channel.rs:12-28); for a
+// point that is GroupAffine::deserialize: coordinates canonical, on the curve, in the prime-order subgroup
+// (short_weierstrass_jacobian.rs:888-905, :171-183).  The wire form here is the C-ABI Jacobian a party's own
+// host64_write_projective produces: Z = 0 with X = Y = 1 (infinity) or Z = 1.  host64_peer_point accepts exactly that:
+//   every coordinate word below q;  Z = 0 or Z = 1 (Montgomery one);  Z = 1: y^2 = x^3 + b;
+//   `subgroup` (the malicious-security entry points): r P = O, one 253-bit scalar multiplication on the host.
+// On failure `ok` is cleared and infinity returned; the caller turns that into ZK_ERR_STATE like a non-canonical scalar.
+template <class H> struct Host64Curve;
+template <> struct Host64Curve<Fq64Field> {
+    static Fq64 b() { return Fq64Field::one(); }                                  // y^2 = x^3 + 1 (curves/g1.rs:22-25)
+    static bool words_valid(const uint64_t* w) { return host64::cmp(w, host64::P) < 0; }
+};
+template <> struct Host64Curve<Fq264Field> {
+    static Fq264 b() { return Fq264{Fq64Field::zero(), Fq64Field::from_dev(fp_const<FqParams>(FqParams::G2_B_C1))}; }   // b' = 1/u (curves/g2.rs:28-35)
+    static bool words_valid(const uint64_t* w) { return host64::cmp(w, host64::P) < 0 && host64::cmp(w + 6, host64::P) < 0; }
+};
+
+template <class H>
+inline XYZZ<H> host64_peer_point(const uint64_t* p, bool subgroup, bool& ok) {
+    constexpr int FE = H::WORDS / 2;
+    uint32_t w[H::WORDS];
+    auto get = [&](const uint64_t* src) {
+        for (int i = 0; i < FE; i++) { w[2 * i] = (uint32_t)src[i]; w[2 * i + 1] = (uint32_t)(src[i] >> 32); }
+        return H::load(w);
+    };
+    if (!Host64Curve<H>::words_valid(p) || !Host64Curve<H>::words_valid(p + FE) || !Host64Curve<H>::words_valid(p + 2 * FE)) { ok = false; return xyzz_inf<H>(); }
+    const typename H::T z = get(p + 2 * FE);
+    if (H::is_zero(z)) return xyzz_inf<H>();
+    if (!H::eq(z, H::one())) { ok = false; return xyzz_inf<H>(); }
+    const typename H::T x = get(p), y = get(p + FE);
+    if (!H::eq(H::sqr(y), H::add(H::mul(H::sqr(x), x), Host64Curve<H>::b()))) { ok = false; return xyzz_inf<H>(); }
+    const XYZZ<H> pt{x, y, H::one(), H::one()};
+    if (subgroup) {
+        uint32_t HOST64_R_WORDS[8];                                               // r, from the generated constants (fr.rs:45-52)
+        fp_pack<FrParams>(HOST64_R_WORDS, fp_const<FrParams>(FrParams::P));
+        XYZZ<H> r = xyzz_inf<H>();
+        bool started = false;
+        for (int i = 7; i >= 0; i--)
+            for (int b = 31; b >= 0; b--) {
+                if (started) r = xyzz_dbl<H>(r);
+                if ((HOST64_R_WORDS[i] >> b) & 1) { r = xyzz_add<H>(r, pt); started = true; }
+            }
+        if (!xyzz_is_inf<H>(r)) { ok = false; return xyzz_inf<H>(); }
+    }
+    return pt;
+}
+
 template <class H>
 inline XYZZ<H> host64_scalar_mul(const XYZZ<H>& p, const uint32_t k[8]) {
     XYZZ<H> r = xyzz_inf<H>();

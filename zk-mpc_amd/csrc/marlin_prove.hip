@@ -233,7 +233,11 @@ int open_small(ZkSharedNet& nt, const std::vector<HF> frs[2], const std::vector<
                 memcpy(a.l, &w[4 * i], 32);
                 f[i] = f[i] + HF::from_abi(a);
             }
-            for (size_t i = 0; i < ng; i++) g[i] = xyzz_add<H1>(g[i], host64_proj_from_abi<H1>(&w[4 * nf + 18 * i]));
+            bool pts_ok = true;                      // a peer's points: canonical, on the curve, (malicious prover) in the subgroup
+            const bool peer = p != ctx->party_id;
+            for (size_t i = 0; i < ng; i++)
+                g[i] = xyzz_add<H1>(g[i], peer ? host64_peer_point<H1>(&w[4 * nf + 18 * i], LANES == 2, pts_ok) : host64_proj_from_abi<H1>(&w[4 * nf + 18 * i]));
+            if (!pts_ok) ZK_FAIL(ctx, ZK_ERR_STATE, "collaborative prover: a party sent a point that is not a valid group element");
         }
         return ZK_OK;
     };
@@ -358,9 +362,9 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         std::vector<Slot> slot;                                                  // which: 0 = comm / 1 = shifted
         std::map<std::string, zk_g1_projective> acc[2][2];                       // [lane][which]
         // the blinding terms (three host scalar multiplications each, ~1.2 ms) run on host threads under the device batch
-        std::vector<std::pair<std::pair<int, std::string>, std::future<zk_g1_projective>>> blinds;
+        std::vector<std::pair<std::pair<int, std::string>, ZkTask<zk_g1_projective>>> blinds;
         auto blind_async = [&](int which, const char* l, const std::vector<HF>& c) {
-            blinds.push_back({{which, l}, (blind_deferred ? std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); }) : zk_async(ctx, [&gamma_pts, c] { return small_msm(gamma_pts, c); }))});
+            blinds.push_back({{which, l}, (blind_deferred ? ZkTask<zk_g1_projective>(std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); })) : zk_async(ctx, [&gamma_pts, c] { return small_msm(gamma_pts, c); }))});
         };
         for (const char* l : labels) {
             const bool hiding = !strcmp(l, "w") || !strcmp(l, "z_a") || !strcmp(l, "z_b") || !strcmp(l, "g_1");
@@ -688,8 +692,8 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     const HF points[2] = {beta, gamma};
     std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
     size_t counts[2][2] = {{0, 0}, {0, 0}};                                      // [query point][lane]
-    std::vector<std::future<zk_g1_projective>> extra[2];                         // the blinding witnesses: host threads, joined after the batch
-    auto small_async = [&](const std::vector<HF>& c) { return (blind_deferred ? std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); }) : zk_async(ctx, [&gamma_pts, c] { return small_msm(gamma_pts, c); })); };
+    std::vector<ZkTask<zk_g1_projective>> extra[2];                         // the blinding witnesses: host threads, joined after the batch
+    auto small_async = [&](const std::vector<HF>& c) { return (blind_deferred ? ZkTask<zk_g1_projective>(std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); })) : zk_async(ctx, [&gamma_pts, c] { return small_msm(gamma_pts, c); })); };
     bool has_rv[2] = {false, false}, q_shared[2] = {false, false};
     HF rvs[2];
     for (int q = 0; q < 2; q++) {

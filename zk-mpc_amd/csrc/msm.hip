@@ -1124,7 +1124,7 @@ int msm_finish_t(zk_ctx* ctx, ZkMsmJob* job, void* out_host) {
     {
         // (a window is log2(NB) + 1 points: ~16 doublings and additions of ~1 us each; 32 windows of a small MSM on eight threads)
         const uint32_t nthreads = nwin >= 16 ? 8u : nwin >= 8 ? 4u : 1u;
-        std::vector<std::future<void>> tasks;
+        std::vector<ZkTask<void>> tasks;                 // joining handles, declared after wsum: a throw below cannot free it under a task
         for (uint32_t t = 1; t < nthreads; t++)
             tasks.push_back(zk_async(ctx, [&, t] { for (uint32_t w = t; w < nwin; w += nthreads) wsum[w] = window_sum(w); }));
         for (uint32_t w = 0; w < nwin; w += nthreads) wsum[w] = window_sum(w);
