@@ -76,3 +76,45 @@ def test_bench_rejects_mismatched_launch():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=ROOT, capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "must agree" in r.stderr
+
+
+# ---- the BASELINE configurations at their OWN sizes (the small-size parity of every one of them is in the other test files) ----
+def _own_size(cmd, timeout=1100):
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py"] + cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout,
+                       env=dict(env_clean, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_config3_three_party_groth16_at_2p18():
+    """BASELINE config 3 at its own size: 3 parties (three OS processes, here sharing cuda:0 with the opens over gloo), additive
+    shares, n = 2^18 - 2: the revealed proof equals the known-trapdoor prediction on the summed shares, on every rank
+    (src/groth16.rs:68-183 over MpcField; reveal = sum, share/additive.rs:81-83)."""
+    d = _own_size(["--gpus", "3", "--transport", "gloo", "--one-gpu", "--log-constraints", "18", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 3 and d["config"]["constraints"] == (1 << 18) - 2 and d["config"]["parties"] == 3
+    assert d["proof_matches_prediction"] is True and d["same_proof_on_all_ranks"] is True
+    assert d["opens_in_timed_proofs"]["elements_per_open"] == 1 << 18 and d["opens_in_timed_proofs"]["opens_per_proof"] == 2
+    assert all(x["ok"] for x in d["preflight_opens"] if "ok" in x)
+
+
+def test_config4_marlin_at_2p20():
+    """BASELINE config 4 at its own size: Marlin::prove (arkworks/marlin/src/lib.rs:152-319) with |H| = |K| = 2^20 through
+    zk_marlin_prove; the oracle's Marlin::verify accepts the proof and rejects a wrong public input."""
+    d = _own_size(["--marlin", "--log-constraints", "20", "--steps", "2", "--warmup", "1"])
+    assert d["config"]["constraints"] == (1 << 20) - 3 and d["n_gpus"] == 1
+    assert d["oracle_verifier_accepts"] is True and d["oracle_verifier_rejects_wrong_input"] is True
+    assert d["equals_python_sequence"] is True and d["proof_bytes"] > 900
+
+
+def test_config5_spdz_marlin_at_2p22():
+    """BASELINE config 5's per-party workload at its own size: SPDZ (malicious-backend) collaborative Marlin, |H| = |K| = 2^22,
+    through zk_marlin_prove_shared_spdz -- two parties here (two OS processes on cuda:0, 2 x 64 GB of HBM, opens of 2^23 elements
+    over gloo; eight parties of this size need eight GPUs), MAC-checked opens, the oracle's verifier accepts."""
+    d = _own_size(["--gpus", "2", "--transport", "gloo", "--one-gpu", "--marlin", "--spdz", "--log-constraints", "22", "--steps", "1",
+                   "--warmup", "0"])
+    assert d["config"]["constraints"] == (1 << 22) - 3 and d["n_gpus"] == 2 and "SPDZ" in d["config"]["workload"]
+    assert d["oracle_verifier_accepts"] is True and d["oracle_verifier_rejects_wrong_input"] is True
+    assert d["prover_entry"] == "zk_marlin_prove_shared_spdz" and d["opens_in_timed_proofs"]["opens_per_proof"] >= 8

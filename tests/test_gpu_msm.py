@@ -307,3 +307,93 @@ def test_msm_batch_over_window_multiples_with_offsets(ctx):
     want = ctx.msm_batch_dev([(plain, off, vecs[v].ptr, m) for off, m, v in spec])
     for g, w in zip(got, want):
         assert cv.g1_projective_to_affine(g) == cv.g1_projective_to_affine(w)
+
+
+def _mont_inner_product(ctx, dk, ds, m):
+    """sum_i k_i s_i mod r (canonical integer) of two device vectors of Montgomery residues: the products on the device, the sum
+    exact on the host in 32-bit halves (2^24 terms of < 2^32 stay below 2^56)."""
+    prod = ctx.alloc(m * 32)
+    ctx.fr_vec_op_dev(0, dk, ds, prod.ptr, m)
+    pr = ctx.download(prod, (m, 4))
+    prod.free()
+    tot = 0
+    for j in range(4):
+        lo = int((pr[:, j] & np.uint64(0xFFFFFFFF)).sum(dtype=np.uint64))
+        hi = int((pr[:, j] >> np.uint64(32)).sum(dtype=np.uint64))
+        tot += (lo + (hi << 32)) << (64 * j)
+    return cv.fr_from_mont(cv.fr_raw([tot % O.R_MOD]))[0]
+
+
+@pytest.mark.parametrize("group,log_n", [(1, 22), (1, 24), (2, 22)])
+def test_msm_benched_sizes_discrete_log_check(ctx, group, log_n):
+    """The sizes bench.py's `micro` rows time (G1 2^22 / 2^24, G2 2^22), checked: over the plain table and over the same table
+    with window multiples, bases = k_i G, sum s_i (k_i G) == (sum s_i k_i) G.  Also a base offset and a ragged length."""
+    n = 1 << log_n
+    rs = np.random.RandomState(70 + log_n + group)
+
+    def rand_mont(m):
+        a = rs.randint(0, 1 << 62, size=(m, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+    km, sm = rand_mont(n), rand_mont(n)
+    dk, ds = ctx.upload(km), ctx.upload(sm)
+    del km, sm
+    one = cv.fr_to_mont([1])[0]
+    to_aff = cv.g1_projective_to_affine if group == 1 else cv.g2_projective_to_affine
+    mul = (lambda e: O.g1_mul(O.G1_GEN, e)) if group == 1 else (lambda e: O.g2_mul(O.G2_GEN, e))
+    bases = ctx.fixed_base(dk.ptr, n, group, one)
+    want = mul(_mont_inner_product(ctx, dk.ptr, ds.ptr, n))
+    assert to_aff(ctx.msm_dev(bases, 0, ds.ptr, n)) == want, "plain table"
+    m = n - 12345                                        # ragged length behind an offset: bases[5 ...] x scalars[0 ...]
+    want_off = mul(_mont_inner_product(ctx, dk.ptr + 5 * 32, ds.ptr, m))
+    assert to_aff(ctx.msm_dev(bases, 5, ds.ptr, m)) == want_off, "plain table, offset"
+    bases.precompute()
+    assert ctx.lib.zk_bases_window_bits(bases.h) >= 13, "this device holds the window multiples of a 2^%d table" % log_n
+    assert to_aff(ctx.msm_dev(bases, 0, ds.ptr, n)) == want, "window multiples"
+    assert to_aff(ctx.msm_dev(bases, 5, ds.ptr, m)) == want_off, "window multiples, offset"
+    bases.free(); dk.free(); ds.free()
+
+
+def _adversarial_sets(rs, n):
+    """The scalar sets of bench.py's adversarial rows (SURVEY 8d 'MSM micro'), plus small range-checked values."""
+    a = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    one = cv.fr_to_mont([1])[0]
+    pick = rs.rand(n)
+    z01 = a.copy()
+    z01[pick < 0.45] = 0
+    z01[(pick >= 0.45) & (pick < 0.9)] = one
+    small = cv.fr_to_mont([int(v) for v in rs.randint(0, 1 << 16, size=4096)])
+    sv = small[rs.randint(0, 4096, size=n)]
+    sv[pick >= 0.9] = a[pick >= 0.9]
+    minus_one = cv.fr_to_mont([O.R_MOD - 1])[0]
+    pm = np.tile(one, (n, 1))
+    pm[pick < 0.5] = minus_one                               # +1 / -1: both signs of one bucket
+    return {"uniform": a, "all_zero": np.zeros((n, 4), dtype=np.uint64), "all_equal": np.tile(a[12345:12346], (n, 1)),
+            "all_one": np.tile(one, (n, 1)), "plus_minus_one": pm, "zero_one_heavy": z01, "small_values": np.ascontiguousarray(sv)}
+
+
+@pytest.mark.parametrize("group,log_n", [(1, 20), (2, 18), (1, 12)])
+def test_msm_adversarial_scalar_sets(ctx, group, log_n):
+    """Witness-shaped scalar vectors (the reference's circuits are boolean-heavy: docs/benchmark.md:45-58; arkworks keeps a
+    unit-scalar fast path for them, ec/src/msm/variable_base.rs:45-49): all zero, all one, +-1, all equal, 90 % zeros and ones,
+    small range-checked values -- every one through the plain table and through window multiples, against the discrete-log
+    identity.  These are the rows bench.py times."""
+    n = 1 << log_n
+    rs = np.random.RandomState(900 + log_n)
+    km = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    km[:, 3] &= np.uint64((1 << 60) - 1)
+    dk = ctx.upload(km)
+    one = cv.fr_to_mont([1])[0]
+    to_aff = cv.g1_projective_to_affine if group == 1 else cv.g2_projective_to_affine
+    mul = (lambda e: O.g1_mul(O.G1_GEN, e)) if group == 1 else (lambda e: O.g2_mul(O.G2_GEN, e))
+    plain = ctx.fixed_base(dk.ptr, n, group, one)
+    pre = ctx.fixed_base(dk.ptr, n, group, one)
+    pre.precompute()
+    for name, arr in _adversarial_sets(rs, n).items():
+        ds = ctx.upload(np.ascontiguousarray(arr))
+        want = mul(_mont_inner_product(ctx, dk.ptr, ds.ptr, n))
+        assert to_aff(ctx.msm_dev(plain, 0, ds.ptr, n)) == want, (name, "plain table")
+        assert to_aff(ctx.msm_dev(pre, 0, ds.ptr, n)) == want, (name, "window multiples")
+        ds.free()
+    plain.free(); pre.free(); dk.free()
