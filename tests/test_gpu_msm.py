@@ -198,14 +198,12 @@ def test_msm_every_window_width(ctx, group, logs):
     bases.free(); prod.free(); dk.free(); ds.free()
 
 
-@pytest.mark.parametrize("group,n,part", [(1, 5000, 0), (1, 1 << 16, 0), (2, 6000, 0), (1, 5000, 1), (1, (1 << 16) + 77, 1)])
-def test_msm_precomputed_window_multiples(ctx, group, n, part, monkeypatch):
+@pytest.mark.parametrize("group,n", [(1, 5000), (1, 1 << 16), (2, 6000), (1, (1 << 16) + 77), (2, (1 << 14) + 5)])
+def test_msm_precomputed_window_multiples(ctx, group, n):
     """Resident bases with precomputed 2^(c w) multiples (one bucket set for all windows): random scalars,
     witness-like 0/1-heavy scalars, all-equal scalars (every point in one bucket per window), extreme scalars and
-    an offset sub-range must give the same group element as the discrete-log identity.  part = 1: through the partition sort
-    (ZK_SORT_PART, an experiment kept behind its switch) instead of the radix sort."""
-    if part:
-        monkeypatch.setenv("ZK_SORT_PART", "1")
+    an offset sub-range must give the same group element as the discrete-log identity.  The sizes sit on both sides of the
+    2^16-digit line between the counting sort of small MSMs and the bucket sort of msm_sort.hip."""
     rs = np.random.RandomState(group * 100 + (n & 0xff))
     km = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64)
     km[:, 3] &= np.uint64((1 << 60) - 1)

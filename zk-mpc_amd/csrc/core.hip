@@ -188,6 +188,17 @@ int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out) {
     return ZK_OK;
 }
 
+int zk_scratch_zeroed(zk_ctx* ctx, const char* name, size_t bytes, void** out) {
+    const auto it = ctx->slots.find(name);
+    const void* before = it == ctx->slots.end() ? nullptr : it->second.p;
+    ZK_TRY(zk_scratch(ctx, name, bytes, out));
+    if (*out != before) {
+        ZK_HIP(ctx, hipMemsetAsync(*out, 0, ctx->slots[name].bytes, ctx->stream));
+        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ZK_OK;
+}
+
 extern "C" int zk_set_profiling(zk_ctx* ctx, int on) {
     ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;

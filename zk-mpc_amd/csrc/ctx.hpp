@@ -246,6 +246,8 @@ static inline auto zk_async(zk_ctx* ctx, Fn&& fn) -> ZkTask<decltype(fn())> {
 
 // Returns a device buffer of at least `bytes` bound to `name`; contents are unspecified.
 int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out);
+// The same for a buffer whose users leave it all-zero behind them: it is zeroed when it is (re)allocated, never afterwards.
+int zk_scratch_zeroed(zk_ctx* ctx, const char* name, size_t bytes, void** out);
 
 static inline unsigned zk_grid(size_t work, unsigned block, unsigned cap = 256 * 16) {
     size_t g = (work + block - 1) / block;

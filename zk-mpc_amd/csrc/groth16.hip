@@ -641,7 +641,6 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
     const void* h = h_in;
     ZkPhaseTimer tm(ctx);
     static const bool gate = !(getenv("ZK_WM_GATE") && atoi(getenv("ZK_WM_GATE")) == 0);
-    static const bool h_counting = getenv("ZK_H_SORT_ATOMIC") && atoi(getenv("ZK_H_SORT_ATOMIC")) != 0;
     if (fronted) {
         // witness map and H's sort were enqueued with the previous proof (enqueue_front below)
         h = h_scratch;
@@ -658,7 +657,6 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
         if (rc == ZK_OK) {
             ZK_HIP(ctx, hipEventRecord(e1, ctx->stream));
             if (gate) ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e1, 0));
-            J[4]->counting_sort = h_counting ? 1 : 0;
             rc = zk_msm_enqueue_sort(ctx, J[4], ctx->stream, nullptr);
         }
     }
@@ -726,7 +724,6 @@ int run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, cons
             // H's own chain (slot 5: k_fold reads ctr / heavy there) may be on the other stream
             if (J[4]->reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, J[4]->reduce_done, 0));
             rc = zk_msm_prepare(ctx, &nf->jobh, pk->h, 0, h_scratch, std::min(pk->h->n, D), 5);
-            nf->jobh.counting_sort = h_counting ? 1 : 0;
             if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &nf->jobh, ctx->stream, nullptr);
         }
         if (rc == ZK_OK) { ctx->presort = nf.release(); front_enqueued = true; }

@@ -54,7 +54,6 @@ struct ZkPhaseTimer {
 struct ZkMsmJob {
     int group = 1, slot = 0;
     int pin_key = -1;                 // pinned result buffer (ctx->pinned key); -1: the slot's.  Jobs enqueued without a host wait in between need their own
-    int counting_sort = 0;            // 1: take the atomic counting sort even for a merged bucket set (its small kernels co-run with an accumulate kernel)
     size_t n = 0, max_segs = 0, max_heavy = 0;
     uint32_t c = 0, W = 0, NB = 0, seg = 0;
     uint16_t off[65] = {0};           // window w covers scalar bits [off[w], off[w+1])
@@ -71,7 +70,8 @@ struct ZkMsmJob {
     uint32_t* hw = nullptr;           // partial window sums (XYZZ, internal form) in pinned host memory
     // the sort products, so that a later job over the same scalar vector can reuse them
     uint32_t *sorted = nullptr, *order = nullptr, *ctr = nullptr;
-    void *desc = nullptr, *heavy = nullptr;
+    void *desc = nullptr, *heavy = nullptr, *heavy2 = nullptr;
+    size_t max_heavy2 = 0, max_heavy_segs = 0, max_groups = 0;
     std::vector<ZkPhaseTimer*> timers;
     ~ZkMsmJob();
 };
@@ -81,16 +81,13 @@ int zk_msm_enqueue_accum(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st);
 int zk_msm_enqueue_reduce(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st);
 int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out_host_projective);
 
-// msm_sort.hip: rocPRIM radix sort of (bucket, table index) pairs for the merged bucket set
-size_t zk_sort_pairs_temp_bytes(size_t n, unsigned key_bits);
-int zk_sort_pairs(hipStream_t st, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                  const uint32_t* vals_in, uint32_t* vals_out, size_t n, unsigned key_bits);
+// msm_sort.hip: the bucket sort (msm_digits.cuh declares its interface)
 
 // msm_g2pair.hip: the G2 accumulate kernel with two lanes per point addition
 void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bases, const uint32_t* sorted, const void* desc,
                             const uint32_t* order, const uint32_t* ctr, uint32_t* sums);
 struct ZkG2PairReduce {   // the arguments of msm.hip's reduce chain
-    const void* heavy; const uint32_t* ctr;
+    const void *heavy, *heavy2; const uint32_t* ctr; uint32_t* done;
     uint32_t *sums, *rowP, *colP, *bits;
     uint32_t log_nb, n_win, light_blocks, heavy_blocks;
 };

@@ -31,6 +31,7 @@
 #include "hostfield64.hpp"
 #include "internal.hpp"
 #include "msm_reduce.cuh"
+#include "msm_digits.cuh"
 #include <algorithm>
 #include <future>
 #include <vector>
@@ -83,10 +84,6 @@ MsmPlan make_plan(size_t n, uint32_t forced_c = 0) {
     return p;
 }
 
-struct WinOff { uint16_t off[66]; };
-
-struct Bias { uint32_t w[9]; };
-
 // dig[w*n + i] = |d| | (d<0 ? 1<<31 : 0), and counts[w*NB + |d| - 1]++ for |d| > 0.
 __global__ void __launch_bounds__(256)
 k_digits(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, uint32_t* dig, uint32_t* counts, int merged) {
@@ -95,23 +92,15 @@ k_digits(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, Bias
     for (size_t i0 = blockIdx.x * (size_t)256; i0 < n; i0 += (size_t)gridDim.x * 256) {
         size_t i = i0 + tid;
         if (i < n) {
-            Fr s = fp_ext_to_canon<FrParams>(fr_load(scalars, i));
-            uint32_t w8[8];
-            fp_pack<FrParams>(w8, s);
-            uint32_t carry = 0;
+            uint32_t w9[9];
+            scalar_biased_words(scalars, i, bias, w9);
 #pragma unroll
-            for (int k = 0; k < 9; k++) {
-                uint64_t t = (uint64_t)(k < 8 ? w8[k] : 0u) + bias.w[k] + carry;
-                kw[k][tid] = (uint32_t)t;
-                carry = (uint32_t)(t >> 32);
-            }
+            for (int k = 0; k < 9; k++) kw[k][tid] = w9[k];
             for (uint32_t w = 0; w < W; w++) {
-                const uint32_t bit = wo.off[w], cw = wo.off[w + 1] - bit;
-                const uint32_t half = 1u << (cw - 1), mask = (1u << cw) - 1;
-                const uint32_t wi = bit >> 5, sh = bit & 31;
+                const uint32_t bit = wo.off[w], wi = bit >> 5;
                 uint64_t two = kw[wi][tid];
                 if (wi + 1 < 9) two |= (uint64_t)kw[wi + 1][tid] << 32;
-                int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (int32_t)half;
+                const int32_t d = signed_digit(two, bit, wo.off[w + 1] - bit);
                 uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
                 dig[(size_t)w * n + i] = mag | (d < 0 ? 0x80000000u : 0u);
                 if (mag) atomicAdd(&counts[(merged ? 0 : (size_t)w * NB) + mag - 1], 1u);
@@ -141,259 +130,6 @@ k_scatter(const uint32_t* dig, size_t n, uint32_t W, uint32_t NB, const uint32_t
     }
 }
 
-// ---- sort by key instead of counting with atomics (msm_sort.hip) ------------------------------------------------
-// key[w*n + i] = the bucket of digit w of scalar i, or `none` for a zero digit (sorts behind every bucket and is never
-// read); val[w*n + i] = entry | sign, what k_accum reads.
-// merged: one bucket set, the entry is the table index of the window multiple.  Otherwise window w owns the buckets
-// [w*NB, (w+1)*NB) and the entry is the index of the base; `none` (the key of a zero digit) is the total bucket count.
-__global__ void __launch_bounds__(256)
-k_digit_keys(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, uint32_t* key, uint32_t* val,
-             int merged, uint32_t none, uint32_t n_tab, uint32_t tab_off) {
-    __shared__ uint32_t kw[9][256];
-    const uint32_t tid = threadIdx.x;
-    for (size_t i0 = blockIdx.x * (size_t)256; i0 < n; i0 += (size_t)gridDim.x * 256) {
-        size_t i = i0 + tid;
-        if (i < n) {
-            Fr s = fp_ext_to_canon<FrParams>(fr_load(scalars, i));
-            uint32_t w8[8];
-            fp_pack<FrParams>(w8, s);
-            uint32_t carry = 0;
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                uint64_t t = (uint64_t)(k < 8 ? w8[k] : 0u) + bias.w[k] + carry;
-                kw[k][tid] = (uint32_t)t;
-                carry = (uint32_t)(t >> 32);
-            }
-            for (uint32_t w = 0; w < W; w++) {
-                const uint32_t bit = wo.off[w], cw = wo.off[w + 1] - bit;
-                const uint32_t half = 1u << (cw - 1), mask = (1u << cw) - 1;
-                const uint32_t wi = bit >> 5, sh = bit & 31;
-                uint64_t two = kw[wi][tid];
-                if (wi + 1 < 9) two |= (uint64_t)kw[wi + 1][tid] << 32;
-                int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (int32_t)half;
-                uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-                key[(size_t)w * n + i] = mag ? (merged ? 0u : w * NB) + mag - 1 : none;
-                val[(size_t)w * n + i] = (merged ? (uint32_t)(w * n_tab + tab_off + i) : (uint32_t)i) | (d < 0 ? 0x80000000u : 0u);
-            }
-        }
-    }
-}
-
-// ---- partition sort (experiment, ZK_SORT_PART=1): the same grouping in ~270 MB of traffic instead of the radix sort's ~900 MB ----
-// Only the grouping by bucket matters (the order inside a bucket does not: the group is commutative, outputs are canonical), and
-// the pairs need not exist before they are grouped.  Buckets are cut into bins of 2^PART_F = 1024 consecutive bucket ids:
-//   k_part_hist    bin sizes: the digits are computed from the scalars, counted per block in LDS, one global add per (block, bin)
-//   k_part_scan    exclusive scan of the (<= 4096) bin sizes
-//   k_part_scatter the digits are computed AGAIN (cheaper than keeping 13 pairs per scalar); a block of 1024 lanes takes 2048
-//                  scalars, reserves one run per bin with one global atomic, and writes (low key bits, entry) into its runs
-//   k_part_bins    one block per bin: 1024-counter histogram of the low key bits in LDS, scan -> the bucket offsets of the bin
-//                  (written straight to offs: no pass over sorted keys), then the entries go to their bucket's range
-// Zero digits produce no pair at all.  Heavy buckets (0/1 witnesses, repeated scalars) make a bin long, not the method slow: a
-// bin is streamed, never staged.
-constexpr uint32_t PART_F = 10;           // low key bits sorted inside a bin: bins of 1024 bucket ids (runs of ~50 pairs per block and bin)
-constexpr uint32_t PART_BIN = 1u << PART_F;
-constexpr uint32_t PART_TILE = 2048;      // scalars per block step (1024 lanes x 2)
-
-// words of (canonical scalar + bias) of scalar i into column `col` of kw (9 x PART_TILE words)
-__device__ __forceinline__ void part_load_scalar(const void* scalars, size_t i, const Bias& bias, uint32_t (*kw)[PART_TILE], uint32_t col) {
-    Fr s = fp_ext_to_canon<FrParams>(fr_load(scalars, i));
-    uint32_t w8[8];
-    fp_pack<FrParams>(w8, s);
-    uint32_t carry = 0;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        uint64_t t = (uint64_t)(k < 8 ? w8[k] : 0u) + bias.w[k] + carry;
-        kw[k][col] = (uint32_t)t;
-        carry = (uint32_t)(t >> 32);
-    }
-}
-// digit w of the scalar in column col: false for a zero digit; bucket = its id in the ONE sorted bucket space, neg = its sign
-__device__ __forceinline__ bool part_digit(const uint32_t (*kw)[PART_TILE], uint32_t col, const WinOff& wo, uint32_t w, uint32_t NB, int merged,
-                                           uint32_t& bucket, uint32_t& neg) {
-    const uint32_t bit = wo.off[w], cw = wo.off[w + 1] - bit;
-    const uint32_t half = 1u << (cw - 1), mask = (1u << cw) - 1;
-    const uint32_t wi = bit >> 5, sh = bit & 31;
-    uint64_t two = kw[wi][col];
-    if (wi + 1 < 9) two |= (uint64_t)kw[wi + 1][col] << 32;
-    const int32_t d = (int32_t)((uint32_t)(two >> sh) & mask) - (int32_t)half;
-    if (d == 0) return false;
-    const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
-    bucket = (merged ? 0u : w * NB) + mag - 1;
-    neg = d < 0 ? 0x80000000u : 0u;
-    return true;
-}
-
-__global__ void __launch_bounds__(1024)
-k_part_hist(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, int merged, uint32_t NC, uint32_t* bin_count) {
-    extern __shared__ uint32_t part_lds[];
-    uint32_t (*kw)[PART_TILE] = reinterpret_cast<uint32_t (*)[PART_TILE]>(part_lds);
-    uint32_t* cnt = part_lds + 9 * PART_TILE;
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t b = tid; b < NC; b += 1024) cnt[b] = 0;
-    __syncthreads();
-    for (size_t t0 = (size_t)blockIdx.x * PART_TILE; t0 < n; t0 += (size_t)gridDim.x * PART_TILE) {
-        for (uint32_t k = 0; k < 2; k++) {
-            const uint32_t col = tid + k * 1024;
-            const size_t i = t0 + col;
-            if (i >= n) continue;
-            part_load_scalar(scalars, i, bias, kw, col);
-            for (uint32_t w = 0; w < W; w++) {
-                uint32_t bucket, neg;
-                if (part_digit(kw, col, wo, w, NB, merged, bucket, neg)) atomicAdd(&cnt[bucket >> PART_F], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    for (uint32_t b = tid; b < NC; b += 1024)
-        if (cnt[b]) atomicAdd(&bin_count[b], cnt[b]);
-}
-
-// bin_start[b] = sum of the sizes of the bins before b (b <= NC), cursor = a copy the scatter consumes.  One block, NC <= 4096.
-__global__ void __launch_bounds__(1024) k_part_scan(const uint32_t* bin_count, uint32_t NC, uint32_t* bin_start, uint32_t* cursor) {
-    __shared__ uint32_t part[1024];
-    const uint32_t tid = threadIdx.x;
-    uint32_t v[4], s = 0;
-    for (uint32_t k = 0; k < 4; k++) { const uint32_t b = tid * 4 + k; v[k] = b < NC ? bin_count[b] : 0; s += v[k]; }
-    part[tid] = s;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint32_t x = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += x;
-        __syncthreads();
-    }
-    uint32_t run = part[tid] - s;
-    for (uint32_t k = 0; k < 4; k++) {
-        const uint32_t b = tid * 4 + k;
-        if (b <= NC) { bin_start[b] = run; if (b < NC) cursor[b] = run; }
-        run += v[k];
-    }
-}
-
-__global__ void __launch_bounds__(1024)
-k_part_scatter(const void* scalars, size_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, int merged, uint32_t NC, uint32_t n_tab,
-               uint32_t tab_off, uint32_t* cursor, uint16_t* key8, uint32_t* val) {
-    extern __shared__ uint32_t part_lds[];
-    uint32_t (*kw)[PART_TILE] = reinterpret_cast<uint32_t (*)[PART_TILE]>(part_lds);
-    uint32_t* cnt = part_lds + 9 * PART_TILE;
-    uint32_t* base = cnt + NC;
-    const uint32_t tid = threadIdx.x;
-    for (size_t t0 = (size_t)blockIdx.x * PART_TILE; t0 < n; t0 += (size_t)gridDim.x * PART_TILE) {
-        for (uint32_t b = tid; b < NC; b += 1024) cnt[b] = 0;
-        __syncthreads();
-        for (uint32_t k = 0; k < 2; k++) {
-            const uint32_t col = tid + k * 1024;
-            const size_t i = t0 + col;
-            if (i >= n) continue;
-            part_load_scalar(scalars, i, bias, kw, col);
-            for (uint32_t w = 0; w < W; w++) {
-                uint32_t bucket, neg;
-                if (part_digit(kw, col, wo, w, NB, merged, bucket, neg)) atomicAdd(&cnt[bucket >> PART_F], 1u);
-            }
-        }
-        __syncthreads();
-        for (uint32_t b = tid; b < NC; b += 1024) {
-            const uint32_t c = cnt[b];
-            if (c) base[b] = atomicAdd(&cursor[b], c);        // this block's run inside bin b
-            cnt[b] = 0;
-        }
-        __syncthreads();
-        for (uint32_t k = 0; k < 2; k++) {
-            const uint32_t col = tid + k * 1024;
-            const size_t i = t0 + col;
-            if (i >= n) continue;
-            for (uint32_t w = 0; w < W; w++) {
-                uint32_t bucket, neg;
-                if (!part_digit(kw, col, wo, w, NB, merged, bucket, neg)) continue;
-                const uint32_t bin = bucket >> PART_F;
-                const uint32_t pos = base[bin] + atomicAdd(&cnt[bin], 1u);
-                key8[pos] = (uint16_t)(bucket & (PART_BIN - 1));
-                val[pos] = (merged ? (uint32_t)(w * n_tab + tab_off + i) : (uint32_t)i) | neg;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// One block per bin: offs[bucket] for the bin's buckets, and its entries moved to their bucket's range of `sorted`.  A bin that
-// fits (PART_STAGE entries: all but the bins of heavy buckets) is put in order in LDS and leaves as one contiguous copy --
-// scattered 4-byte stores cost a 64-byte L2 transaction each; a longer bin scatters straight to memory.
-constexpr uint32_t PART_STAGE = 28672;          // x 4 B = 112 KiB of LDS
-__global__ void __launch_bounds__(PART_BIN)
-k_part_bins(const uint16_t* __restrict__ key8, const uint32_t* __restrict__ val, const uint32_t* __restrict__ bin_start, uint32_t NC,
-            uint32_t NBt, uint32_t* __restrict__ sorted, uint32_t* __restrict__ offs) {
-    extern __shared__ uint32_t part_lds[];
-    uint32_t* hist = part_lds;                   // PART_BIN counters, later cursors
-    uint32_t* wsum = part_lds + PART_BIN;        // one total per wave (16)
-    uint32_t* stage = part_lds + PART_BIN + 64;
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t lo = bin_start[b], hi = bin_start[b + 1], cnt = hi - lo;
-    hist[tid] = 0;
-    __syncthreads();
-    for (uint32_t i0 = lo + tid; i0 < hi; i0 += 4 * PART_BIN) {       // four loads in flight per lane
-        uint32_t k[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) k[u] = i0 + u * PART_BIN < hi ? key8[i0 + u * PART_BIN] : 0xffffffffu;
-#pragma unroll
-        for (int u = 0; u < 4; u++) if (k[u] != 0xffffffffu) atomicAdd(&hist[k[u]], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of the PART_BIN counters: inside a wave by shuffles, across the 16 waves through LDS
-    const uint32_t mine = hist[tid];
-    uint32_t inc = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t x = __shfl_up(inc, d, 64);
-        if ((tid & 63) >= (uint32_t)d) inc += x;
-    }
-    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < (tid >> 6); w++) before += wsum[w];
-    const uint32_t off = before + inc - mine;              // exclusive
-    const uint32_t id = (b << PART_F) + tid;
-    if (id <= NBt) offs[id] = lo + off;
-    if (b == NC - 1 && tid == PART_BIN - 1 && ((NC << PART_F) == NBt)) offs[NBt] = hi;       // the end marker when the last bin is full
-    __syncthreads();
-    hist[tid] = off;                                       // now the cursors
-    __syncthreads();
-    const bool staged = cnt <= PART_STAGE;
-    for (uint32_t i0 = lo + tid; i0 < hi; i0 += 4 * PART_BIN) {
-        uint32_t k[4], v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const bool in = i0 + u * PART_BIN < hi;
-            k[u] = in ? key8[i0 + u * PART_BIN] : 0xffffffffu;
-            v[u] = in ? val[i0 + u * PART_BIN] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (k[u] == 0xffffffffu) continue;
-            const uint32_t p = atomicAdd(&hist[k[u]], 1u);
-            if (staged) stage[p] = v[u]; else sorted[lo + p] = v[u];
-        }
-    }
-    if (staged) {
-        __syncthreads();
-        for (uint32_t i = tid; i < cnt; i += PART_BIN) sorted[lo + i] = stage[i];
-    }
-}
-
-// offs[b] = first position of bucket b in the sorted keys, for every b <= NB (empty buckets get the next bucket's start;
-// offs[NB] = number of non-zero digits: the key of a zero digit is NB).  One binary search per bucket: 2^19 x 24 reads whatever
-// the keys are.  (The first form walked the gaps between neighbouring keys from the keys' side: with all scalars zero, or all
-// equal, one thread filled 2^19 offsets by itself -- 7 ms.)
-__global__ void __launch_bounds__(256)
-k_offs_from_sorted(const uint32_t* __restrict__ skey, size_t total, uint32_t NB, uint32_t* __restrict__ offs) {
-    for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b <= NB; b += (size_t)gridDim.x * blockDim.x) {
-        size_t lo = 0, hi = total;                       // first t with skey[t] >= b
-        while (lo < hi) {
-            const size_t mid = (lo + hi) >> 1;
-            if (skey[mid] < (uint32_t)b) lo = mid + 1; else hi = mid;
-        }
-        offs[b] = (uint32_t)lo;
-    }
-}
 __global__ void __launch_bounds__(256) k_counts_from_offs(const uint32_t* __restrict__ offs, uint32_t NB, uint32_t* __restrict__ counts) {
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < NB; b += gridDim.x * blockDim.x) counts[b] = offs[b + 1] - offs[b];
 }
@@ -405,12 +141,15 @@ __global__ void __launch_bounds__(256) k_counts_from_offs(const uint32_t* __rest
 // for uniformly random scalars no bucket is split; splitting is what keeps 0/1-heavy witness
 // vectors, repeated scalars and a nearly empty top window from serialising on one thread.
 struct SegDesc { uint32_t start, len, dst; };
-struct HeavyDesc { uint32_t key, first, nseg; };
+// parent: HEAVY_NONE, or -- for the group of a bucket that is folded in two levels -- the index of its second-level entry
+struct HeavyDesc { uint32_t key, first, nseg, parent; };
+constexpr uint32_t HEAVY_NONE = 0xffffffffu;
 
 // One block per window: exclusive scans of counts (-> offs) and of the per-bucket segment counts.
 __global__ void __launch_bounds__(1024)
-k_scan(const uint32_t* counts, uint32_t* offs, uint32_t* seg_local, uint32_t* win_segs, uint32_t NB, uint32_t seg) {
+k_scan(const uint32_t* counts, uint32_t* offs, uint32_t* seg_local, uint32_t* win_segs, uint32_t NB, const uint32_t* segp) {
     __shared__ uint32_t part[1024], part2[1024];
+    const uint32_t seg = *segp;
     const uint32_t w = blockIdx.x, tid = threadIdx.x;
     const uint32_t per = (NB + 1023) / 1024;
     const uint32_t lo = tid * per, hi = min(lo + per, NB);
@@ -465,8 +204,9 @@ __device__ __forceinline__ void block_scan2(uint32_t* part, uint32_t* part2, uin
 }
 
 __global__ void __launch_bounds__(SCAN_T)
-k_scan_sums(const uint32_t* counts, uint32_t NB, uint32_t seg, uint32_t nchunks, uint32_t* sums) {
+k_scan_sums(const uint32_t* counts, uint32_t NB, const uint32_t* segp, uint32_t nchunks, uint32_t* sums) {
     __shared__ uint32_t part[SCAN_T], part2[SCAN_T];
+    const uint32_t seg = *segp;
     const uint32_t w = blockIdx.x / nchunks, ch = blockIdx.x % nchunks, tid = threadIdx.x;
     uint32_t s = 0, s2 = 0;
     for (uint32_t k = 0; k < 8; k++) {
@@ -492,8 +232,9 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_tops(uint32_t* sums, uint32_t n
 
 __global__ void __launch_bounds__(SCAN_T)
 k_scan_fill(const uint32_t* counts, const uint32_t* sums, uint32_t* offs, uint32_t* seg_local, uint32_t* win_segs, uint32_t NB,
-            uint32_t seg, uint32_t nchunks) {
+            const uint32_t* segp, uint32_t nchunks) {
     __shared__ uint32_t part[SCAN_T], part2[SCAN_T];
+    const uint32_t seg = *segp;
     const uint32_t w = blockIdx.x / nchunks, ch = blockIdx.x % nchunks, tid = threadIdx.x;
     const uint32_t lo = ch * SCAN_CHUNK + tid * 8;
     uint32_t c[8], s = 0, s2 = 0;
@@ -522,12 +263,27 @@ k_scan_fill(const uint32_t* counts, const uint32_t* sums, uint32_t* offs, uint32
     }
 }
 
-// ctr[0] = heavy buckets, ctr[1] = heavy segments, ctr[2] = total segments; hist[len] = #segments of that length
+// ctr[0] = entries of the heavy list, ctr[1] = heavy segments, ctr[2] = total segments, ctr[3] = the segment length (written by the
+// sort: msm_sort.hip::k_scan_bins, or copied from the host's plan), ctr[4] = non-zero digits, ctr[5] = entries of the second-level
+// heavy list, ctr[6] = group slots handed out; hist[len] = #segments of that length.
+// A split bucket's segment sums are folded back by k_fold.  A bucket cut into more than FOLD_GROUP segments (the "1" bucket of a
+// boolean witness: hundreds of thousands of points) is folded in two levels: its segments in groups of FOLD_GROUP, one heavy-list
+// entry per group writing a group sum (slots from grp_base on), and one second-level entry that adds the group sums up -- so that
+// no block walks more than FOLD_GROUP partial sums.  The descriptors of a split bucket are written by the whole block (a lane
+// that met a 15 000-segment bucket used to write them alone: 0.3 ms).
+constexpr uint32_t FOLD_GROUP = 256;
+constexpr uint32_t FOLD_LIGHT = 8;      // up to this many partial sums: one lane adds them; more: a 64-lane block (strided sums + an LDS tree)
+struct HeavyFill { uint32_t base, start, cnt, dst0; };
+
 __global__ void __launch_bounds__(256)
 k_build_segs(const uint32_t* offs, const uint32_t* seg_local, const uint32_t* win_segs, size_t n, uint32_t W, uint32_t NB,
-             uint32_t seg, SegDesc* desc, HeavyDesc* heavy, uint32_t* ctr, uint32_t* hist) {
+             SegDesc* desc, HeavyDesc* heavy, HeavyDesc* heavy2, uint32_t* ctr, uint32_t* hist, uint32_t grp_base) {
     extern __shared__ uint32_t lh[];  // seg + 1 bins
+    __shared__ HeavyFill q[64];
+    __shared__ uint32_t qn;
+    const uint32_t seg = ctr[3];
     for (uint32_t i = threadIdx.x; i <= seg; i += blockDim.x) lh[i] = 0;
+    if (threadIdx.x == 0) qn = 0;
     __syncthreads();
     const size_t total = (size_t)W * NB;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -541,25 +297,42 @@ k_build_segs(const uint32_t* offs, const uint32_t* seg_local, const uint32_t* wi
             desc[base] = SegDesc{start, cnt, (uint32_t)t};
             atomicAdd(&lh[cnt], 1u);
         } else {
-            uint32_t ns = (cnt + seg - 1) / seg;
-            uint32_t first = atomicAdd(&ctr[1], ns);
-            heavy[atomicAdd(&ctr[0], 1u)] = HeavyDesc{(uint32_t)t, (uint32_t)total + first, ns};
-            for (uint32_t j = 0; j < ns; j++) {
-                uint32_t l = min(seg, cnt - j * seg);
-                desc[base + j] = SegDesc{start + j * seg, l, (uint32_t)total + first + j};
-                atomicAdd(&lh[l], 1u);
+            const uint32_t ns = (cnt + seg - 1) / seg;
+            const uint32_t dst0 = (uint32_t)total + atomicAdd(&ctr[1], ns);
+            if (ns <= FOLD_GROUP) {
+                heavy[atomicAdd(&ctr[0], 1u)] = HeavyDesc{(uint32_t)t, dst0, ns, HEAVY_NONE};
+            } else {
+                const uint32_t ng = (ns + FOLD_GROUP - 1) / FOLD_GROUP;
+                const uint32_t g0 = grp_base + atomicAdd(&ctr[6], ng), h0 = atomicAdd(&ctr[0], ng), up = atomicAdd(&ctr[5], 1u);
+                for (uint32_t j = 0; j < ng; j++) heavy[h0 + j] = HeavyDesc{g0 + j, dst0 + j * FOLD_GROUP, min(FOLD_GROUP, ns - j * FOLD_GROUP), up};
+                heavy2[up] = HeavyDesc{(uint32_t)t, g0, ng, HEAVY_NONE};
+            }
+            atomicAdd(&lh[seg], ns - 1);
+            atomicAdd(&lh[cnt - (ns - 1) * seg], 1u);
+            const uint32_t slot = atomicAdd(&qn, 1u);
+            if (slot < 64) {
+                q[slot] = HeavyFill{base, start, cnt, dst0};
+            } else {                     // more split buckets than the block's queue holds: this lane writes its own
+                for (uint32_t j = 0; j < ns; j++) desc[base + j] = SegDesc{start + j * seg, min(seg, cnt - j * seg), dst0 + j};
             }
         }
         if (t == total - 1) ctr[2] = base + (cnt <= seg ? 1 : (cnt + seg - 1) / seg);
     }
     __syncthreads();
+    const uint32_t nq = min(qn, 64u);
+    for (uint32_t e = 0; e < nq; e++) {
+        const HeavyFill f = q[e];
+        const uint32_t ns = (f.cnt + seg - 1) / seg;
+        for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x) desc[f.base + j] = SegDesc{f.start + j * seg, min(seg, f.cnt - j * seg), f.dst0 + j};
+    }
     for (uint32_t i = threadIdx.x; i <= seg; i += blockDim.x)
         if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
 // bin_start[len] for a DESCENDING order by length (longest segments first); one block.
-__global__ void __launch_bounds__(512) k_len_scan(const uint32_t* hist, uint32_t* bin_start, uint32_t* bin_cursor, uint32_t seg) {
+__global__ void __launch_bounds__(512) k_len_scan(const uint32_t* hist, uint32_t* bin_start, uint32_t* bin_cursor, const uint32_t* ctr) {
     __shared__ uint32_t part[512];
+    const uint32_t seg = ctr[3];
     const uint32_t tid = threadIdx.x, nb = seg + 1;
     const uint32_t per = (nb + 511) / 512;
     // position p = seg - len  (p = 0 is the longest)
@@ -583,9 +356,9 @@ __global__ void __launch_bounds__(512) k_len_scan(const uint32_t* hist, uint32_t
 
 // order[pos] = segment id, grouped by length (descending).  Per-block LDS counting, one global atomic per (block, bin).
 __global__ void __launch_bounds__(256)
-k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t seg, uint32_t* order) {
+k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t* order) {
     extern __shared__ uint32_t lh[];  // [0..seg]: counts then base
-    const uint32_t S = ctr[2];
+    const uint32_t S = ctr[2], seg = ctr[3];
     const uint32_t per_block = (S + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = blockIdx.x * per_block, hi = min(lo + per_block, S);
     for (uint32_t i = threadIdx.x; i <= seg; i += blockDim.x) lh[i] = 0;
@@ -719,19 +492,35 @@ __device__ __forceinline__ XYZZ<F> rcanon(const XYZZ<F>& a) {
 
 // Split buckets are folded back into one sum per bucket by ONE launch (every launch of a reduce chain waits for a free
 // slot beside the running accumulate kernel, so fewer launches is a shorter chain): the first `light_blocks` blocks take
-// buckets with few segments, one thread per bucket adding them up serially; the remaining blocks take the very heavy
-// ones (repeated scalars, 0/1 witnesses), one 64-lane block per bucket: strided partial sums, then an LDS tree.
+// buckets with few segments, one thread per bucket adding them up serially; the remaining blocks take the heavy
+// ones (repeated scalars, 0/1 witnesses), one 64-lane block per entry: strided partial sums, then an LDS tree.
+// A bucket folded in two levels (k_build_segs) has one entry per group of FOLD_GROUP segments; the block that finishes the LAST
+// group of a bucket (a counter per second-level entry in `done`, which it leaves at zero again) adds the group sums up.
+template <class F>
+__device__ __forceinline__ void fold_block(uint32_t* lds, uint32_t* sums, uint32_t first, uint32_t nseg, uint32_t key, uint32_t tid) {
+    XYZZ<F> acc = xyzz_inf<F>();
+    for (uint32_t j = tid; j < nseg; j += 64) acc = radd<F>(acc, xyzz_load16<F>(sums, (size_t)first + j));
+    lds_put_xyzz<F, 64>(lds, tid, rpack<F>(acc));
+    __syncthreads();
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+        if (tid < d) lds_put_xyzz<F, 64>(lds, tid, rpack<F>(radd<F>(lds_get_xyzz<F, 64>(lds, tid), lds_get_xyzz<F, 64>(lds, tid + d))));
+        __syncthreads();
+    }
+    if (tid == 0) xyzz_store16<F>(sums, key, rcanon<F>(lds_get_xyzz<F, 64>(lds, 0)));
+    __syncthreads();
+}
+
 template <class F>
 __global__ void __launch_bounds__(64)
-k_fold(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint32_t light_blocks) {
-    constexpr int XW = 4 * F::WORDS;
+k_fold(const HeavyDesc* heavy, const HeavyDesc* heavy2, const uint32_t* ctr, uint32_t* done, uint32_t* sums, uint32_t light_blocks) {
     extern __shared__ uint32_t lds[];  // 64 * XW words (heavy blocks only)
+    __shared__ uint32_t last_flag;
     const uint32_t nheavy = ctr[0];
     const uint32_t tid = threadIdx.x;
     if (blockIdx.x < light_blocks) {
         for (uint32_t hb = blockIdx.x * 64 + tid; hb < nheavy; hb += light_blocks * 64) {
             const HeavyDesc h = heavy[hb];
-            if (h.nseg > 32) continue;
+            if (h.nseg > FOLD_LIGHT || h.parent != HEAVY_NONE) continue;
             XYZZ<F> acc = xyzz_load16<F>(sums, (size_t)h.first);
             for (uint32_t j = 1; j < h.nseg; j++) acc = radd<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
             xyzz_store16<F>(sums, h.key, rcanon<F>(acc));
@@ -740,16 +529,21 @@ k_fold(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint32_t lig
     }
     for (uint32_t hb = blockIdx.x - light_blocks; hb < nheavy; hb += gridDim.x - light_blocks) {
         const HeavyDesc h = heavy[hb];
-        if (h.nseg <= 32) continue;
-        XYZZ<F> acc = xyzz_inf<F>();
-        for (uint32_t j = tid; j < h.nseg; j += 64) acc = radd<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
-        lds_put_xyzz<F, 64>(lds, tid, rpack<F>(acc));
-        __syncthreads();
-        for (uint32_t d = 32; d >= 1; d >>= 1) {
-            if (tid < d) lds_put_xyzz<F, 64>(lds, tid, rpack<F>(radd<F>(lds_get_xyzz<F, 64>(lds, tid), lds_get_xyzz<F, 64>(lds, tid + d))));
-            __syncthreads();
+        if (h.nseg <= FOLD_LIGHT && h.parent == HEAVY_NONE) continue;
+        fold_block<F>(lds, sums, h.first, h.nseg, h.key, tid);
+        if (h.parent == HEAVY_NONE) continue;
+        const HeavyDesc up = heavy2[h.parent];
+        if (tid == 0) {
+            __threadfence();                                       // the group sum above is visible before the count is
+            const uint32_t before = atomicAdd(&done[h.parent], 1u);
+            last_flag = before + 1 == up.nseg ? 1u : 0u;
+            if (last_flag) done[h.parent] = 0;                     // (ready for the next MSM that uses this slot)
         }
-        if (tid == 0) xyzz_store16<F>(sums, h.key, rcanon<F>(lds_get_xyzz<F, 64>(lds, 0)));
+        __syncthreads();
+        if (last_flag) {
+            __threadfence();
+            fold_block<F>(lds, sums, up.first, up.nseg, up.key, tid);
+        }
         __syncthreads();
     }
 }
@@ -799,9 +593,9 @@ __global__ void __launch_bounds__(256) k_bases_export(const uint32_t* in, uint32
 // and reduce phases of the neighbouring jobs run beside them on other streams.
 template <class F>
 struct MsmBufs {
-    uint32_t *dig, *sorted, *counts, *offs, *seg_local, *small, *order, *sums, *rowP, *colP, *bits;
+    uint32_t *dig, *sorted, *counts, *offs, *seg_local, *small, *order, *sums, *rowP, *colP, *bits, *fold_done;
     SegDesc* desc;
-    HeavyDesc* heavy;
+    HeavyDesc *heavy, *heavy2;
 };
 
 template <class F>
@@ -851,9 +645,15 @@ int msm_bufs_t(zk_ctx* ctx, ZkMsmJob* job, MsmBufs<F>& b, bool need_sort) {
     constexpr size_t XW = 4 * F::WORDS;
     const size_t n = job->n, W = job->W, NB = job->NB, seg = job->seg, Wb = job->Wb;
     const size_t nbuck = Wb * NB;
-    job->max_segs = nbuck + W * n / seg + W;                  // every bucket >= 1 segment
-    const size_t max_heavy_segs = 2 * (W * n / seg) + W;      // segments of split buckets
-    job->max_heavy = W * n / seg + 1;
+    // The segment length is settled on the device, per input, anywhere in [32, seg] (msm_sort.hip::k_scan_bins): T non-zero digits
+    // are cut into segments of at least T / lanes, so an input never has more than max(W n / seg, lanes) full segments.
+    const size_t lanes = (size_t)ctx->n_cu * 4 * 64 * 2;
+    const size_t cap_segs = std::max(W * n / seg, lanes);
+    job->max_segs = nbuck + cap_segs + W;                     // every bucket >= 1 segment
+    job->max_heavy_segs = 2 * cap_segs + W;                   // segments of split buckets (a split bucket of cnt points has <= 2 cnt / seg)
+    job->max_heavy2 = job->max_heavy_segs / FOLD_GROUP + 2;   // buckets folded in two levels
+    job->max_groups = job->max_heavy_segs / FOLD_GROUP + job->max_heavy2 + 2;
+    job->max_heavy = cap_segs + job->max_groups + 1;          // heavy-list entries: split buckets and groups
     char nm[64];
     auto slotname = [&](const char* base) { snprintf(nm, sizeof nm, "%s.%d", base, job->slot); return nm; };
     if (need_sort) {
@@ -862,13 +662,15 @@ int msm_bufs_t(zk_ctx* ctx, ZkMsmJob* job, MsmBufs<F>& b, bool need_sort) {
         ZK_TRY(zk_scratch(ctx, slotname("msm_counts"), nbuck * 4, (void**)&b.counts));
         ZK_TRY(zk_scratch(ctx, slotname("msm_offs"), Wb * (NB + 1) * 4, (void**)&b.offs));
         ZK_TRY(zk_scratch(ctx, slotname("msm_segl"), nbuck * 4, (void**)&b.seg_local));
-        // small: win_segs[64] | ctr[4] | hist[seg+1] | bin_start[seg+1] | bin_cursor[seg+1]
-        ZK_TRY(zk_scratch(ctx, slotname("msm_small"), (64 + 4 + 3 * (seg + 1)) * 4, (void**)&b.small));
+        // small: win_segs[64] | ctr[8] | hist[seg+1] | bin_start[seg+1] | bin_cursor[seg+1]
+        ZK_TRY(zk_scratch(ctx, slotname("msm_small"), (64 + 8 + 3 * (seg + 1)) * 4, (void**)&b.small));
         ZK_TRY(zk_scratch(ctx, slotname("msm_desc"), job->max_segs * sizeof(SegDesc), (void**)&b.desc));
         ZK_TRY(zk_scratch(ctx, slotname("msm_heavy"), job->max_heavy * sizeof(HeavyDesc), (void**)&b.heavy));
+        ZK_TRY(zk_scratch(ctx, slotname("msm_heavy2"), job->max_heavy2 * sizeof(HeavyDesc), (void**)&b.heavy2));
         ZK_TRY(zk_scratch(ctx, slotname("msm_order"), job->max_segs * 4, (void**)&b.order));
     }
-    ZK_TRY(zk_scratch(ctx, slotname("msm_sums"), (nbuck + max_heavy_segs) * XW * 4, (void**)&b.sums));
+    ZK_TRY(zk_scratch(ctx, slotname("msm_sums"), (nbuck + job->max_heavy_segs + job->max_groups) * XW * 4, (void**)&b.sums));
+    ZK_TRY(zk_scratch_zeroed(ctx, slotname("msm_fold_done"), job->max_heavy2 * 4, (void**)&b.fold_done));
     const GridGeom gg = make_grid_geom(job->log_nb, (uint32_t)Wb, 256);     // the partial counts do not depend on the block size
     ZK_TRY(zk_scratch(ctx, slotname("msm_rowP"), grid_row_points(gg) * XW * 4, (void**)&b.rowP));
     ZK_TRY(zk_scratch(ctx, slotname("msm_colP"), grid_col_points(gg) * XW * 4, (void**)&b.colP));
@@ -890,6 +692,7 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
         if (share->tab_off != job->tab_off)
             job->bases_dev = job->bases_dev + ((ptrdiff_t)job->tab_off - (ptrdiff_t)share->tab_off) * (ptrdiff_t)job->stride;
         job->sorted = share->sorted; job->desc = share->desc; job->order = share->order; job->ctr = share->ctr; job->heavy = share->heavy;
+        job->heavy2 = share->heavy2;
         ZK_HIP(ctx, hipEventCreateWithFlags(&job->sort_done, hipEventDisableTiming));
         ZK_HIP(ctx, hipStreamWaitEvent(st, share->sort_done, 0));
         ZK_HIP(ctx, hipEventRecord(job->sort_done, st));
@@ -908,23 +711,17 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     for (int i = 0; i < 9; i++) bias.w[i] = p.bias[i];
     uint32_t* win_segs = b.small;
     uint32_t* ctr = b.small + 64;
-    uint32_t* hist = b.small + 68;
+    uint32_t* hist = b.small + 72;
     uint32_t* bin_start = hist + (seg + 1);
     uint32_t* bin_cursor = bin_start + (seg + 1);
     ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
     job->timers.push_back(tm);
     tm->begin(g1 ? "msm_g1.sort" : "msm_g2.sort");
-    ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 4 + 3 * (size_t)(seg + 1)) * 4, st));
-    // merged bucket set: radix sort of (bucket, entry) pairs, no global atomics (msm_sort.hip); ZK_SORT_ATOMIC=1 keeps the
-    // counting sort.  Per-window bucket sets (tables without window multiples) always take the counting sort.
-    static const bool radix = !(getenv("ZK_SORT_ATOMIC") && atoi(getenv("ZK_SORT_ATOMIC")) != 0);
-    // Radix sort of (bucket, entry) pairs, no global atomics (msm_sort.hip), for every MSM with at least 2^16 digits; the sort
-    // then sees ONE set of Wb*NB buckets (bucket ids w*NB + b, as the reduce phase numbers them).  Small MSMs keep the
-    // counting sort with per-window offsets.  ZK_SORT_ATOMIC=1 forces the counting sort.
-    const bool use_radix = radix && !job->counting_sort && (size_t)W * n >= 65536;
+    ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 8 + 3 * (size_t)(seg + 1)) * 4, st));
+    const uint32_t grp_base = (uint32_t)(nbuck + job->max_heavy_segs);       // where the group sums of two-level buckets live in `sums`
     auto scans = [&](uint32_t Wx, uint32_t NBx) -> int {
         if (NBx <= 65536) {
-            hipLaunchKernelGGL(k_scan, Wx, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NBx, seg);
+            hipLaunchKernelGGL(k_scan, Wx, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NBx, (const uint32_t*)(ctr + 3));
         } else {
             const uint32_t nchunks = (uint32_t)((NBx + SCAN_CHUNK - 1) / SCAN_CHUNK);
             if (nchunks > SCAN_T) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: bucket set too large for the two-level scan");
@@ -932,79 +729,43 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
             char nm2[64];
             snprintf(nm2, sizeof nm2, "msm_scan_sums.%d", job->slot);
             ZK_TRY(zk_scratch(ctx, nm2, (size_t)Wx * nchunks * 8, (void**)&sums));
-            hipLaunchKernelGGL(k_scan_sums, Wx * nchunks, SCAN_T, 0, st, b.counts, NBx, seg, nchunks, sums);
+            hipLaunchKernelGGL(k_scan_sums, Wx * nchunks, SCAN_T, 0, st, b.counts, NBx, (const uint32_t*)(ctr + 3), nchunks, sums);
             hipLaunchKernelGGL(k_scan_tops, Wx, SCAN_T, 0, st, sums, nchunks);
             hipLaunchKernelGGL(k_scan_fill, Wx * nchunks, SCAN_T, 0, st, b.counts, (const uint32_t*)sums, b.offs, b.seg_local, win_segs,
-                               NBx, seg, nchunks);
+                               NBx, (const uint32_t*)(ctr + 3), nchunks);
         }
         return ZK_OK;
     };
-    if (use_radix) {
-        const size_t total = (size_t)W * n;
-        const uint32_t NBt = (uint32_t)nbuck;                  // all buckets as one set; a zero digit gets the key NBt
-        unsigned key_bits = 1;
-        while (((uint64_t)1 << key_bits) <= NBt) key_bits++;
-        uint32_t *vals, *skey;
-        void* tmp;
-        char nm2[64];
-        snprintf(nm2, sizeof nm2, "msm_vals.%d", job->slot);
-        ZK_TRY(zk_scratch(ctx, nm2, total * 4, (void**)&vals));
-        snprintf(nm2, sizeof nm2, "msm_skey.%d", job->slot);
-        ZK_TRY(zk_scratch(ctx, nm2, total * 4, (void**)&skey));
-        const size_t tmp_bytes = zk_sort_pairs_temp_bytes(total, key_bits);
-        snprintf(nm2, sizeof nm2, "msm_sorttmp.%d", job->slot);
-        ZK_TRY(zk_scratch(ctx, nm2, tmp_bytes, &tmp));
-        // ZK_SORT_PART=1 (experiment, read per call so that a test can switch it): the partition sort above instead of rocPRIM's
-        // radix sort of materialised pairs.  A third of the traffic, yet not faster: 0.59 ms alone against 0.54 (the pairs leave
-        // k_part_scatter as ~50-entry runs from 512 blocks, 64-byte L2 transactions for 6-byte payloads; the bins kernel is bound
-        // by its 27 M returning LDS atomics), and no difference in the pipelines (Groth16 18.0 / 18.0 ms, Marlin 82.3 / 81.7 ms).
-        const bool part = getenv("ZK_SORT_PART") && atoi(getenv("ZK_SORT_PART")) != 0;
-        const uint32_t NC = (NBt + PART_BIN - 1) >> PART_F;
-        if (part && NC <= 4096) {
-            uint32_t* bins;
-            snprintf(nm2, sizeof nm2, "msm_bins.%d", job->slot);
-            ZK_TRY(zk_scratch(ctx, nm2, (size_t)(3 * (NC + 1)) * 4, (void**)&bins));
-            uint32_t *bin_count = bins, *bin_start = bins + (NC + 1), *cursor = bins + 2 * (NC + 1);
-            if (!ctx->flags["part_lds"]) {
-                ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_part_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (9 * PART_TILE + 4096) * 4));
-                ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_part_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (9 * PART_TILE + 2 * 4096) * 4));
-                ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_part_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (PART_BIN + 64 + PART_STAGE) * 4));
-                ctx->flags["part_lds"] = 1;
-            }
-            ZK_HIP(ctx, hipMemsetAsync(bin_count, 0, (size_t)(NC + 1) * 4, st));
-            const unsigned tiles = (unsigned)((n + PART_TILE - 1) / PART_TILE);
-            const unsigned pg = tiles < 512 ? tiles : 512;
-            hipLaunchKernelGGL(k_part_hist, pg, 1024, (9 * PART_TILE + NC) * 4, st, job->scalars, n, wo, W, NB, bias, merged, NC, bin_count);
-            hipLaunchKernelGGL(k_part_scan, 1, 1024, 0, st, (const uint32_t*)bin_count, NC, bin_start, cursor);
-            hipLaunchKernelGGL(k_part_scatter, pg, 1024, (9 * PART_TILE + 2 * NC) * 4, st, job->scalars, n, wo, W, NB, bias, merged, NC,
-                               job->n_tab, job->tab_off, cursor, (uint16_t*)b.dig, vals);
-            hipLaunchKernelGGL(k_part_bins, NC, PART_BIN, (PART_BIN + 64 + PART_STAGE) * 4, st, (const uint16_t*)b.dig, (const uint32_t*)vals, (const uint32_t*)bin_start, NC, NBt,
-                               b.sorted, b.offs);
-        } else {
-            hipLaunchKernelGGL(k_digit_keys, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, vals, merged, NBt,
-                               job->n_tab, job->tab_off);
-            if (zk_sort_pairs(st, tmp, tmp_bytes, b.dig, skey, vals, b.sorted, total, key_bits) != 0)
-                ZK_FAIL(ctx, ZK_ERR_HIP, "msm: radix sort failed");
-            hipLaunchKernelGGL(k_offs_from_sorted, zk_grid((size_t)NBt + 1, 256), 256, 0, st, (const uint32_t*)skey, total, NBt, b.offs);
-        }
+    // The bucket sort (msm_sort.hip: no global atomics per digit, zero digits dropped, the segment length fitted to the input) for
+    // every MSM with at least 2^16 digits; it sees ONE set of Wb*NB buckets (bucket ids w*NB + b, as the reduce phase numbers
+    // them).  Small MSMs keep the counting sort with per-window offsets: a handful of short kernels.
+    ZkGroupArgs ga;
+    ga.scalars = job->scalars; ga.n = n; ga.wo = wo; ga.bias = bias; ga.W = W; ga.NB = NB; ga.merged = merged != 0;
+    ga.n_tab = job->n_tab; ga.tab_off = job->tab_off; ga.NBt = (uint32_t)nbuck;
+    ga.lanes = (uint32_t)ctx->n_cu * 4 * 64 * 2; ga.seg_max = seg;
+    ga.sorted = b.sorted; ga.offs = b.offs; ga.ctr = ctr;
+    if ((size_t)W * n >= 65536 && zk_msm_group_supported(ga)) {
+        const uint32_t NBt = (uint32_t)nbuck;
+        ZK_TRY(zk_msm_group(ctx, st, job->slot, ga));
         hipLaunchKernelGGL(k_counts_from_offs, zk_grid(NBt, 256), 256, 0, st, (const uint32_t*)b.offs, NBt, b.counts);
         ZK_TRY(scans(1, NBt));                                 // rewrites offs (same values) and produces the segment counts
         hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
-                           (size_t)0, 1u, NBt, seg, b.desc, b.heavy, ctr, hist);
+                           (size_t)0, 1u, NBt, b.desc, b.heavy, b.heavy2, ctr, hist, grp_base);
     } else {
         ZK_HIP(ctx, hipMemsetAsync(b.counts, 0, nbuck * 4, st));
+        ZK_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctr + 3), (int)seg, 1, st));             // the host's plan is the segment length
         hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, b.counts, merged);
         ZK_TRY(scans(Wb, NB));
         hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted, merged,
                            job->n_tab, job->tab_off);
         hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
-                           merged ? (size_t)0 : n, Wb, NB, seg, b.desc, b.heavy, ctr, hist);
+                           merged ? (size_t)0 : n, Wb, NB, b.desc, b.heavy, b.heavy2, ctr, hist, grp_base);
     }
-    hipLaunchKernelGGL(k_len_scan, 1, 512, 0, st, hist, bin_start, bin_cursor, seg);
-    hipLaunchKernelGGL(k_order, 512, 256, (seg + 1) * 4, st, b.desc, ctr, bin_cursor, seg, b.order);
+    hipLaunchKernelGGL(k_len_scan, 1, 512, 0, st, hist, bin_start, bin_cursor, (const uint32_t*)ctr);
+    hipLaunchKernelGGL(k_order, 512, 256, (seg + 1) * 4, st, b.desc, ctr, bin_cursor, b.order);
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
-    job->sorted = b.sorted; job->desc = b.desc; job->order = b.order; job->ctr = ctr; job->heavy = b.heavy;
+    job->sorted = b.sorted; job->desc = b.desc; job->order = b.order; job->ctr = ctr; job->heavy = b.heavy; job->heavy2 = b.heavy2;
     ZK_HIP(ctx, hipEventCreateWithFlags(&job->sort_done, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventRecord(job->sort_done, st));
     return ZK_OK;
@@ -1058,11 +819,11 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     const unsigned heavy_blocks = (unsigned)std::min<size_t>(job->max_heavy, 1024);
     if constexpr (F::WORDS != 12) {
         // G2: the same chain on lane pairs (msm_g2pair.hip)
-        ZkG2PairReduce a{job->heavy, job->ctr, b.sums, b.rowP, b.colP, b.bits, job->log_nb, job->Wb, 2 * light_blocks, heavy_blocks};
+        ZkG2PairReduce a{job->heavy, job->heavy2, job->ctr, b.fold_done, b.sums, b.rowP, b.colP, b.bits, job->log_nb, job->Wb, 2 * light_blocks, heavy_blocks};
         ZK_TRY(zk_launch_reduce_g2pair(ctx, st, a));
     } else {
-        hipLaunchKernelGGL(k_fold<F>, light_blocks + heavy_blocks, 64, 64 * XW * 4, st, (const HeavyDesc*)job->heavy, job->ctr, b.sums,
-                           light_blocks);
+        hipLaunchKernelGGL(k_fold<F>, light_blocks + heavy_blocks, 64, 64 * XW * 4, st, (const HeavyDesc*)job->heavy, (const HeavyDesc*)job->heavy2,
+                           (const uint32_t*)job->ctr, b.fold_done, b.sums, light_blocks);
         const GridGeom gg = make_grid_geom(job->log_nb, job->Wb, RedG1::PTS);
         hipLaunchKernelGGL(k_grid_l1<RedG1>, gg.row_blocks + gg.col_blocks, RedG1::NT, RedG1::PTS * XW * 4, st, (const uint32_t*)b.sums,
                            b.rowP, b.colP, gg);

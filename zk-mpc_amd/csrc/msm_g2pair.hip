@@ -272,18 +272,36 @@ __device__ __forceinline__ XP lds_get_pair(const uint32_t* lds, uint32_t tid) {
     return xyzz_load<FP>(w);
 }
 
-struct HeavyDesc { uint32_t key, first, nseg; };   // msm.hip
+struct HeavyDesc { uint32_t key, first, nseg, parent; };   // msm.hip
+constexpr uint32_t HEAVY_NONE = 0xffffffffu;
+constexpr uint32_t FOLD_LIGHT = 8;
 
-// msm.hip::k_fold on pairs: 32 buckets (light part) or one bucket (heavy part) per 64-lane block
+// the 32 lane pairs of a block add nseg partial sums (strided, then an LDS tree) into sums[key]
+__device__ __forceinline__ void fold_block_pair(uint32_t* lds, uint32_t* sums, uint32_t first, uint32_t nseg, uint32_t key, uint32_t tid) {
+    const uint32_t lt = tid >> 1, odd = tid & 1u;
+    XP acc = xyzz_inf<FP>();
+    for (uint32_t j = lt; j < nseg; j += 32) acc = xyzz_add<FP>(acc, xyzz_load_pair(sums, (size_t)first + j, odd));
+    lds_put_pair<64>(lds, tid, acc);
+    __syncthreads();
+    for (uint32_t d = 16; d >= 1; d >>= 1) {
+        if (lt < d) lds_put_pair<64>(lds, tid, xyzz_add<FP>(lds_get_pair<64>(lds, tid), lds_get_pair<64>(lds, tid + 2 * d)));
+        __syncthreads();
+    }
+    if (lt == 0) xyzz_store_pair(sums, key, odd, lds_get_pair<64>(lds, tid));
+    __syncthreads();
+}
+
+// msm.hip::k_fold on pairs: 32 buckets (light part) or one entry (heavy part) per 64-lane block; two-level buckets as there
 __global__ void __launch_bounds__(64)
-k_fold_g2pair(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint32_t light_blocks) {
+k_fold_g2pair(const HeavyDesc* heavy, const HeavyDesc* heavy2, const uint32_t* ctr, uint32_t* done, uint32_t* sums, uint32_t light_blocks) {
     extern __shared__ uint32_t lds[];  // 64 * 48 words (heavy blocks only)
+    __shared__ uint32_t last_flag;
     const uint32_t nheavy = ctr[0];
     const uint32_t tid = threadIdx.x, lt = tid >> 1, odd = tid & 1u;
     if (blockIdx.x < light_blocks) {
         for (uint32_t hb = blockIdx.x * 32 + lt; hb < nheavy; hb += light_blocks * 32) {
             const HeavyDesc h = heavy[hb];
-            if (h.nseg > 32) continue;
+            if (h.nseg > FOLD_LIGHT || h.parent != HEAVY_NONE) continue;
             XP acc = xyzz_load_pair(sums, (size_t)h.first, odd);
             for (uint32_t j = 1; j < h.nseg; j++) acc = xyzz_add<FP>(acc, xyzz_load_pair(sums, (size_t)h.first + j, odd));
             xyzz_store_pair(sums, h.key, odd, acc);
@@ -292,16 +310,22 @@ k_fold_g2pair(const HeavyDesc* heavy, const uint32_t* ctr, uint32_t* sums, uint3
     }
     for (uint32_t hb = blockIdx.x - light_blocks; hb < nheavy; hb += gridDim.x - light_blocks) {
         const HeavyDesc h = heavy[hb];
-        if (h.nseg <= 32) continue;
-        XP acc = xyzz_inf<FP>();
-        for (uint32_t j = lt; j < h.nseg; j += 32) acc = xyzz_add<FP>(acc, xyzz_load_pair(sums, (size_t)h.first + j, odd));
-        lds_put_pair<64>(lds, tid, acc);
+        if (h.nseg <= FOLD_LIGHT && h.parent == HEAVY_NONE) continue;
+        fold_block_pair(lds, sums, h.first, h.nseg, h.key, tid);
+        if (h.parent == HEAVY_NONE) continue;
+        const HeavyDesc up = heavy2[h.parent];
+        __threadfence();                                           // both lanes of pair 0 stored a half of the group sum
         __syncthreads();
-        for (uint32_t d = 16; d >= 1; d >>= 1) {
-            if (lt < d) lds_put_pair<64>(lds, tid, xyzz_add<FP>(lds_get_pair<64>(lds, tid), lds_get_pair<64>(lds, tid + 2 * d)));
-            __syncthreads();
+        if (tid == 0) {
+            const uint32_t before = atomicAdd(&done[h.parent], 1u);
+            last_flag = before + 1 == up.nseg ? 1u : 0u;
+            if (last_flag) done[h.parent] = 0;
         }
-        if (lt == 0) xyzz_store_pair(sums, h.key, odd, lds_get_pair<64>(lds, tid));
+        __syncthreads();
+        if (last_flag) {
+            __threadfence();
+            fold_block_pair(lds, sums, up.first, up.nseg, up.key, tid);
+        }
         __syncthreads();
     }
 }
@@ -372,8 +396,8 @@ void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bas
 
 // The G2 reduce chain of msm.hip::msm_enqueue_reduce_t, same buffers and geometry, on lane pairs.
 int zk_launch_reduce_g2pair(zk_ctx* ctx, hipStream_t st, const ZkG2PairReduce& a) {
-    hipLaunchKernelGGL(k_fold_g2pair, a.light_blocks + a.heavy_blocks, 64, 64 * 4 * FW * 4, st, (const HeavyDesc*)a.heavy, a.ctr, a.sums,
-                       a.light_blocks);
+    hipLaunchKernelGGL(k_fold_g2pair, a.light_blocks + a.heavy_blocks, 64, 64 * 4 * FW * 4, st, (const HeavyDesc*)a.heavy, (const HeavyDesc*)a.heavy2,
+                       a.ctr, a.done, a.sums, a.light_blocks);
     const GridGeom gg = make_grid_geom(a.log_nb, a.n_win, RedG2Pair::PTS);
     const size_t lds = (size_t)RedG2Pair::NT * 4 * FW * 4;            // 48 KiB
     hipLaunchKernelGGL(k_grid_l1<RedG2Pair>, gg.row_blocks + gg.col_blocks, RedG2Pair::NT, lds, st, (const uint32_t*)a.sums, a.rowP, a.colP, gg);
