@@ -177,6 +177,10 @@ def micro_sweeps(ctx, max_log=24, budget_s=45.0):
             z01[pick < 0.45] = 0
             z01[(pick >= 0.45) & (pick < 0.9)] = one
             sets["zero_one_heavy"] = z01                      # 90 % of the scalars 0 or 1, like a real witness
+            small = cv2.fr_to_mont([int(v) for v in rs.randint(0, 1 << 16, size=4096)])
+            sv = small[rs.randint(0, 4096, size=n)]
+            sv[pick >= 0.9] = a[:n][pick >= 0.9]
+            sets["small_values"] = np.ascontiguousarray(sv)   # 16-bit range-checked values with a uniform tenth
             for name, arr in sets.items():
                 dd = ctx.upload(np.ascontiguousarray(arr))
                 dt = timed(lambda: ctx.msm_dev(bases, 0, dd.ptr, n), 3)
@@ -221,6 +225,93 @@ def natural_domain_leg(ctx, log_constraints, td, threads):
            "isolated_ms": round(t_iso * 1e3, 3), "proof_matches_prediction": None if want is None else bool(want == proof and iso == proof)}
     if want is None:
         out["note"] = note
+    for z in zs:
+        z.free()
+    pk.free(); r1cs.free()
+    return out
+
+
+def bool_chain_system(n: int, seed: int, frac_bool: float = 0.9):
+    """A witness shaped like the reference's circuits (boolean-heavy: BitDecomposition / SmallerThan / Pedersen gadgets,
+    docs/benchmark.md:45-58): the variable layout of the mul-chain system (z = [1, public, w_0 .. w_n]), but the first 90 % of the rows
+    are booleanity checks w_j * w_j = w_j over random bits and only the tail is a multiplication chain over uniform field
+    elements, w_j * w_{j+1} = w_{j+2}, ending in the public input.  Returns (CSR a, b, c; the assignment in the reference's
+    Montgomery form) -- plain data for zk_r1cs_upload on one side and the oracle on the other."""
+    import zk_mpc_amd.convert as cv
+    nb = int(n * frac_bool)
+    one = cv.fr_to_mont([1])[0]
+    rs = np.random.RandomState(seed)
+    bits = rs.randint(0, 2, size=nb)
+    w = [0] * (n + 2)
+    w[nb], w[nb + 1] = seeded_fr(seed * 2 + 1), seeded_fr(seed * 2 + 2)
+    for j in range(nb, n):
+        w[j + 2] = w[j] * w[j + 1] % cv.R_MOD
+    z = np.zeros((n + 3, 4), dtype=np.uint64)
+    z[0] = one
+    z[2:2 + nb][bits == 1] = one
+    tail = cv.fr_to_mont(w[nb:n + 2])
+    z[2 + nb:2 + n + 1] = tail[:n + 1 - nb]
+    z[1] = tail[n + 1 - nb]                                   # the public input w_{n+1}
+    rp = np.arange(n + 1, dtype=np.uint32)
+    j = np.arange(n, dtype=np.int64)
+    idx = lambda v: np.where(v <= n, 2 + v, 1).astype(np.uint32)
+    ones = np.tile(one, (n, 1))
+    a = (rp, idx(j), ones)
+    b = (rp, idx(np.where(j < nb, j, j + 1)), ones)
+    c = (rp, idx(np.where(j < nb, j, j + 2)), ones)
+    return a, b, c, z, nb
+
+
+def boolean_heavy_leg(ctx, log_constraints, td, threads):
+    """The same prover on a boolean-heavy assignment (bool_chain_system: 90 % of the variables are 0 or 1), beside the uniform
+    headline: arkworks keeps a unit-scalar fast path for exactly this (ec/src/msm/variable_base.rs:45-49).  Proofs back to back
+    over two different assignments, the last one checked against the known-trapdoor prediction."""
+    n = (1 << log_constraints) - 2
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    systems = [bool_chain_system(n, 7000 + q) for q in range(2)]
+    a, b, c = systems[0][:3]
+    r1cs = ctx.r1cs_upload(2, n + 1, a, b, c)
+    pk = ctx.groth16_setup(r1cs, *td)
+    import zk_mpc_amd.convert as cv2
+    mont = lambda v: cv2.fr_to_mont([v])[0]
+    zs = [ctx.upload(sy[3]) for sy in systems]
+    r_, s_ = mont(seeded_fr(420)), mont(seeded_fr(421))
+    for i in range(3):
+        ctx.groth16_hint_next_dev(zs[(i + 1) % 2].ptr)
+        ctx.create_proof_dev(pk, r1cs, zs[i % 2].ptr, r_, s_)
+    ctx.sync()
+    K = 8
+    per = []
+    proof = None
+    t0 = time.perf_counter()
+    for i in range(K):
+        ts = time.perf_counter()
+        ctx.groth16_hint_next_dev(zs[(i + 1) % 2].ptr)
+        proof = ctx.create_proof_dev(pk, r1cs, zs[i % 2].ptr, r_, s_)
+        per.append(time.perf_counter() - ts)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / K
+    ctx.groth16_hint_next_dev(None)
+    iso = []
+    for i in range(5):
+        t1 = time.perf_counter()
+        p_iso = ctx.create_proof_dev(pk, r1cs, zs[(K - 1) % 2].ptr, r_, s_)
+        ctx.sync()
+        iso.append(time.perf_counter() - t1)
+    out = {"workload": "bool-chain R1CS: %d booleanity rows b*b = b over random bits + a %d-row multiplication chain over uniform "
+                       "elements; n=2^%d-2 constraints, QAP domain 2^%d" % (systems[0][4], n - systems[0][4], log_constraints, r1cs.domain_log),
+           "constraints": n, "boolean_fraction_of_assignment": round(systems[0][4] / (n + 3), 3),
+           "ms_per_proof": round(dt * 1e3, 3), "median_ms_per_proof": round(float(np.median(per)) * 1e3, 3),
+           "constraints_per_s": round(n / dt, 1), "isolated_ms": round(float(np.median(iso)) * 1e3, 3)}
+    try:
+        import zkref_c as OC
+        cr = OC.R1cs(2, n + 1, a, b, c)
+        zarr = systems[(K - 1) % 2][3]
+        want = OC.groth16_predict(cr, np.stack(td), zarr, OC.witness_map(cr, zarr, threads), r_, s_)
+        out["proof_matches_prediction"] = bool(want == proof and p_iso == proof)
+    except Exception as e:
+        out["proof_matches_prediction"] = None
+        out["note"] = "oracle unavailable: %r" % (e,)
     for z in zs:
         z.free()
     pk.free(); r1cs.free()
@@ -1046,6 +1137,10 @@ def main():
                 out["micro"] = micro_sweeps(ctx)
             except Exception as e:
                 out["micro"] = {"error": repr(e)}
+            try:
+                out["boolean_heavy"] = boolean_heavy_leg(ctx, args.log_constraints, td, os.cpu_count() or 1)
+            except Exception as e:
+                out["boolean_heavy"] = {"error": repr(e)}
             try:
                 if not args.natural_domain and args.log_constraints <= 20:
                     out["natural_domain"] = natural_domain_leg(ctx, args.log_constraints, td, os.cpu_count() or 1)

@@ -390,3 +390,41 @@ def test_msms_begin_then_finish_and_its_misuse(ctx):
     assert same(ctx.groth16_msms_dev(pk, dr, z1.ptr, h1.ptr), want1)
     ctx.groth16_msms_begin_dev(pk, dr, z1.ptr)           # begun and never finished: the key goes first
     pk.free()
+
+
+@pytest.mark.parametrize("log_n", [10, 16, 20])
+def test_boolean_heavy_assignment_matches_prediction(ctx, log_n):
+    """A witness shaped like the reference's circuits (90 % of the variables are bits: bench.py::bool_chain_system; the reference:
+    docs/benchmark.md:45-58 and arkworks' unit-scalar fast path, ec/src/msm/variable_base.rs:45-49): heavy "0" and "1" digits in
+    every z-MSM (dropped zero digits, one bucket with 45 % of all points, folded in two levels), proof bytes against the
+    known-trapdoor prediction -- isolated, over an announced queue, and through the host-slice entry."""
+    import importlib.util
+    import os
+    import zkref_c as OC
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = (1 << log_n) - 2
+    rng = O.Prng(5150 + log_n)
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    td = [mont(rng.fr()) for _ in range(7)]
+    systems = [bench.bool_chain_system(n, 40 + q + log_n) for q in range(2)]
+    a, b, c = systems[0][:3]
+    dr = ctx.r1cs_upload(2, n + 1, a, b, c)
+    pk = ctx.groth16_setup(dr, *td)
+    cr = OC.R1cs(2, n + 1, a, b, c)
+    rs = [(mont(rng.fr()), mont(rng.fr())) for _ in range(2)]
+    want = [OC.groth16_predict(cr, np.stack(td), sy[3], OC.witness_map(cr, sy[3], OC.num_threads()), r, s) for sy, (r, s) in zip(systems, rs)]
+    assert want[0] != want[1]
+    zs = [ctx.upload(sy[3]) for sy in systems]
+    assert [ctx.create_proof_dev(pk, dr, z.ptr, r, s) for z, (r, s) in zip(zs, rs)] == want
+    got = []
+    for k in (0, 1, 0, 1):
+        ctx.groth16_hint_next_dev(zs[1 - k].ptr)
+        got.append(ctx.create_proof_dev(pk, dr, zs[k].ptr, *rs[k]))
+    ctx.groth16_hint_next_dev(None)
+    assert got == [want[0], want[1], want[0], want[1]]
+    assert ctx.create_proof(pk, dr, systems[1][3], *rs[1]) == want[1]
+    pk.free(); dr.free()
+    for z in zs:
+        z.free()
