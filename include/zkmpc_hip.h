@@ -121,6 +121,14 @@ int zk_bases_free(zk_ctx* ctx, zk_bases* b);
  * of 16.  No-op for tables under 4096 points.  zk_pk_upload / zk_groth16_setup apply it to proving-key queries of
  * >= 2^16 points unless ZK_PRECOMP=0 (measured at 2^20: 35.9 -> 32.4 ms per proof). */
 int zk_bases_precompute(zk_ctx* ctx, zk_bases* b);
+/* The same with the table's memory layout chosen by the caller instead of by the memory budget (tests, diagnostics): 0 = as
+ * zk_bases_precompute; 1 = packed; 2 = one 96-byte point per 128-byte line (G1); 3 = 29-bit limbs with both signs, 256 bytes per
+ * point (G1: what the accumulate kernel reads without unpacking).  A forced layout that does not fit a third of the free device
+ * memory fails with ZK_ERR_NOMEM; zk_bases_precompute never fails for lack of memory: it keeps the plain table. */
+int zk_bases_precompute_as(zk_ctx* ctx, zk_bases* b, int layout);
+/* Which layout the table's window multiples have, or -- when zk_bases_precompute skipped them -- why (also left in
+ * zk_last_error): a table without them runs 16 digits per scalar over 16 bucket sets instead of 13 over one.  "" = never asked. */
+const char* zk_bases_precompute_note(const zk_bases* b);
 /* Window width of the table's precomputed multiples (0: none): MSMs over it use ceil(255 / c) digits per scalar. */
 uint32_t zk_bases_window_bits(const zk_bases* b);
 size_t zk_bases_len(const zk_bases* b);

@@ -395,3 +395,32 @@ def test_msm_adversarial_scalar_sets(ctx, group, log_n):
         assert to_aff(ctx.msm_dev(pre, 0, ds.ptr, n)) == want, (name, "window multiples")
         ds.free()
     plain.free(); pre.free(); dk.free()
+
+
+@pytest.mark.parametrize("group,layout,note", [(1, 1, "packed"), (1, 2, "128-byte line"), (1, 3, "limbs"), (2, 1, "packed"), (1, 0, "limbs"),
+                                               (2, 0, "packed")])
+def test_window_multiple_layouts(ctx, group, layout, note):
+    """The three memory layouts of a table's window multiples (zk_bases_precompute_as): packed, one 96-byte point per 128-byte
+    line, and -- what the memory budget picks for G1 on this device -- 29-bit limbs with both signs, read by the accumulate
+    kernel without unpacking or negation.  The same MSM through each, both signs of every digit, an offset sub-range."""
+    n = (1 << 14) + 3
+    rs = np.random.RandomState(31 + layout + 10 * group)
+    km = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64); km[:, 3] &= np.uint64((1 << 60) - 1)
+    sm = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64); sm[:, 3] &= np.uint64((1 << 60) - 1)
+    dk, ds = ctx.upload(km), ctx.upload(sm)
+    bases = ctx.fixed_base(dk.ptr, n, group, cv.fr_to_mont([1])[0])
+    assert bases.precompute_note() == ""
+    bases.precompute(layout)
+    assert note in bases.precompute_note() and ctx.lib.zk_bases_window_bits(bases.h) >= 12
+    to_aff = cv.g1_projective_to_affine if group == 1 else cv.g2_projective_to_affine
+    mul = (lambda e: O.g1_mul(O.G1_GEN, e)) if group == 1 else (lambda e: O.g2_mul(O.G2_GEN, e))
+    assert to_aff(ctx.msm_dev(bases, 0, ds.ptr, n)) == mul(_mont_inner_product(ctx, dk.ptr, ds.ptr, n))
+    assert to_aff(ctx.msm_dev(bases, 9, ds.ptr, n - 9)) == mul(_mont_inner_product(ctx, dk.ptr + 9 * 32, ds.ptr, n - 9))
+    if group == 2:
+        with pytest.raises(Exception):
+            other = ctx.fixed_base(dk.ptr, n, 2, cv.fr_to_mont([1])[0])
+            try:
+                other.precompute(3)                       # a G1 form
+            finally:
+                other.free()
+    bases.free(); dk.free(); ds.free()

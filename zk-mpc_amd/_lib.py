@@ -111,6 +111,8 @@ PROTOTYPES = {
     "zk_bases_upload_g2": (_I, [_P, _P, _SZ, C.POINTER(_P)]),
     "zk_bases_free": (_I, [_P, _P]),
     "zk_bases_precompute": (_I, [_P, _P]),
+    "zk_bases_precompute_as": (_I, [_P, _P, _I]),
+    "zk_bases_precompute_note": (C.c_char_p, [_P]),
     "zk_bases_len": (_SZ, [_P]),
     "zk_bases_window_bits": (_U32, [_P]),
     "zk_msm_g1_dev": (_I, [_P, _P, _SZ, _P, _SZ, _P]),

@@ -694,9 +694,17 @@ class Bases:
     def __len__(self):
         return self.ctx.lib.zk_bases_len(self.h)
 
-    def precompute(self):
-        """Store the window multiples of this resident table (16x memory, one bucket set per MSM)."""
-        self.ctx._ck(self.ctx.lib.zk_bases_precompute(self.ctx.h, self.h))
+    def precompute(self, layout: int = 0):
+        """Store the window multiples of this resident table (13x memory at 2^20, one bucket set per MSM).  layout: 0 = chosen by
+        the memory budget, 1 = packed, 2 = one point per 128-byte line, 3 = limbs with both signs (zk_bases_precompute_as)."""
+        if layout:
+            self.ctx._ck(self.ctx.lib.zk_bases_precompute_as(self.ctx.h, self.h, layout))
+        else:
+            self.ctx._ck(self.ctx.lib.zk_bases_precompute(self.ctx.h, self.h))
+
+    def precompute_note(self) -> str:
+        """The layout of the window multiples, or why they were skipped (zk_bases_precompute_note)."""
+        return (self.ctx.lib.zk_bases_precompute_note(self.h) or b"").decode()
 
     def download(self, offset: int = 0, n: int = None) -> np.ndarray:
         n = len(self) - offset if n is None else n

@@ -33,18 +33,9 @@ extern "C" int zk_selftest_exception_barrier(int kind) {
     ZK_API_END
 }
 
-// Stream priorities (experiment, off unless ZK_STREAM_PRIO=1): accumulate stream lowest, every other stream highest, in
-// the hope that the dispatcher hands freed slots to the short sort / reduce / witness-map kernels instead of to the
-// accumulate kernel's own backlog (a co-running kernel only gets slots at accumulate-kernel boundaries: 2 ms of waiting
-// for 0.1 ms of work).  Measured on MI355X / ROCm 7: no effect (30.5 vs 30.0 ms per proof; an ungated witness map is
-// still starved to 17 ms), so equal priorities stay the default.
-hipError_t zk_stream_create(hipStream_t* st, bool high) {
-    static const bool prio = getenv("ZK_STREAM_PRIO") && atoi(getenv("ZK_STREAM_PRIO")) != 0;
-    int least = 0, greatest = 0;
-    if (!prio || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest)
-        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, high ? greatest : least);
-}
+// Equal stream priorities: giving the accumulate stream the lowest and every other stream the highest priority was measured on
+// MI355X / ROCm 7 and changes nothing (30.5 vs 30.0 ms per proof in round 1; an ungated witness map is still starved).
+hipError_t zk_stream_create(hipStream_t* st, bool) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); }
 
 extern "C" int zk_ctx_create(int device, int party_id, int n_parties, zk_ctx** out) {
     ZK_API_BEGIN_NOCTX

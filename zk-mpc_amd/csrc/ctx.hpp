@@ -112,9 +112,9 @@ struct zk_ctx {
     std::map<uint32_t, zk_domain*> domains;  // keyed by log2(size)
     std::map<std::string, int> flags;         // one-time per-context setup markers
     void* comm = nullptr;                     // RCCL communicator of this party (comm.hip), created by zk_comm_init
-    void* presort = nullptr;                  // groth16.hip: a sort of z[1..] enqueued ahead of zk_groth16_msms_dev (ZkPresort)
-    const void* next_z = nullptr;             // groth16.hip: zk_groth16_hint_next_dev
-    // groth16.hip: zk_groth16_hint_next (host-slice form): the announced assignment is uploaded on its own stream into the
+    void* presort = nullptr;                  // groth16_pipeline.hip: a sort of z[1..] enqueued ahead of zk_groth16_msms_dev (ZkPresort)
+    const void* next_z = nullptr;             // groth16_pipeline.hip: zk_groth16_hint_next_dev
+    // groth16_prove.hip: zk_groth16_hint_next (host-slice form): the announced assignment is uploaded on its own stream into the
     // idle one of two device slots while the current proof runs; next_z_ready is recorded behind that copy
     hipStream_t copy_stream = nullptr;
     hipEvent_t next_z_ready = nullptr;

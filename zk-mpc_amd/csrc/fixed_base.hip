@@ -164,66 +164,90 @@ __global__ void __launch_bounds__(256) k_repack_limbs(const uint32_t* in, uint32
     }
 }
 
+// layout: 0 = the best form that fits the memory budget; 1 = packed (2 * WORDS words per point); 2 = one point per 128-byte line
+// (G1); 3 = limbs with both signs, 256 bytes per point (G1).  A forced layout (tests, diagnostics) that does not fit fails.
+// The table is a trade of memory for work, never a reason to run out of memory later: whatever is allocated here -- the packed
+// table AND the re-laid copy that briefly lives beside it -- may take at most a third of what is free when the call starts (a
+// 2^24-point G2 query would ask for 40 GB).  When the table is skipped the MSM falls back to per-window bucket sets; the reason
+// is kept in zk_bases::pre_note (zk_bases_precompute_note) and in zk_last_error, although the call succeeds.
 template <class F>
-int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W) {
+int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W, int layout) {
     const size_t n = b->n, PW = 2 * F::WORDS;
     uint32_t *xy, *scr;
     ZK_TRY(zk_scratch(ctx, "fb_xyzz", n * 4 * F::WORDS * 4, (void**)&xy));
     ZK_TRY(zk_scratch(ctx, "fb_scr", n * F::WORDS * 4, (void**)&scr));
-    // the table is a trade of memory for work, never a reason to run out of memory later: it may take at most a third of
-    // what is free now (a 2^24-point G2 query would ask for 40 GB)
     size_t mem_free = 0, mem_total = 0;
-    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || (size_t)W * n * PW * 4 > mem_free / 3) return ZK_OK;
-    if (hipMalloc((void**)&b->pre, (size_t)W * n * PW * 4) != hipSuccess) {
+    const size_t packed_bytes = (size_t)W * n * PW * 4;
+    auto skip = [&](const char* why) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "window multiples skipped for a %zu-point G%d table (c = %u, W = %u: %.2f GB packed): %s; %.2f GB free",
+                 n, b->group, c, W, packed_bytes / 1e9, why, mem_free / 1e9);
+        b->pre_note = msg;
+        ctx->last_error = msg;
+        return layout ? ZK_ERR_NOMEM : ZK_OK;
+    };
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return skip("hipMemGetInfo failed");
+    const size_t budget = mem_free / 3;
+    if (packed_bytes > budget) return skip("more than a third of the free device memory");
+    if (hipMalloc((void**)&b->pre, packed_bytes) != hipSuccess) {
         b->pre = nullptr;
         (void)hipGetLastError();
-        return ZK_OK;   // not enough memory: keep the plain table, the MSM falls back to per-window bucket sets
+        return skip("hipMalloc failed");
     }
-    ZK_HIP(ctx, hipMemcpyAsync(b->pre, b->dev, n * PW * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    auto fail_free = [&](void* extra) {      // an error below must not leave a half-built table behind
+        if (extra) (void)hipFree(extra);
+        (void)hipFree(b->pre);
+        b->pre = nullptr;
+        b->c_pre = b->W_pre = b->pre_stride = 0;
+    };
+    hipError_t e = hipMemcpyAsync(b->pre, b->dev, n * PW * 4, hipMemcpyDeviceToDevice, ctx->stream);
     const size_t chunks = (n + NORM_CHUNK - 1) / NORM_CHUNK;
-    for (uint32_t w = 1; w < W; w++) {
+    for (uint32_t w = 1; w < W && e == hipSuccess; w++) {
         hipLaunchKernelGGL(k_dbl_c<F>, zk_grid(n, 256), 256, 0, ctx->stream, b->pre + (size_t)(w - 1) * n * PW, xy, n, c);
         hipLaunchKernelGGL(k_batch_affine<F>, (unsigned)((chunks + 63) / 64), 64, 0, ctx->stream, xy, b->pre + (size_t)w * n * PW, scr, n);
+        e = hipGetLastError();
     }
-    ZK_HIP(ctx, hipGetLastError());
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { fail_free(nullptr); ZK_HIP(ctx, e); }
     b->c_pre = c;
     b->W_pre = W;
     b->pre_stride = 0;
+    b->pre_note = "packed";
     // G1: a 96-byte point in a packed table straddles two 128-byte lines half of the time and the accumulate kernel's gather
     // then fetches 2.6x the bytes it uses (profiles/r2_pmc_traffic.json: 3.45 GB per launch for 1.31 GB of points).  The window
-    // multiples -- read once per digit, at random -- are re-laid one point per line: a third more memory, half the traffic.
-    // (ZK_PRE_PAD=0 keeps the packed table.)  G2's 192-byte points take two lines either way.
-    static const bool pad = !(getenv("ZK_PRE_PAD") && atoi(getenv("ZK_PRE_PAD")) == 0);
-    // ZK_PRE_LIMBS=0 keeps the packed one-line form below; default: limbs, both signs (k_repack_limbs)
-    static const bool limbs = !(getenv("ZK_PRE_LIMBS") && atoi(getenv("ZK_PRE_LIMBS")) == 0);
+    // multiples -- read once per digit, at random -- are re-laid one point per line (a third more memory, half the traffic), or,
+    // when that fits too, as limbs with the negative of every point in the second line of a 256-byte slot (k_repack_limbs:
+    // nothing to unpack or negate in the accumulate kernel).  G2's 192-byte points take two lines either way.
     if constexpr (F::WORDS == 12) {
-        if (pad && limbs && (size_t)W * n * 64 * 4 <= mem_free / 3) {
-            uint32_t* wide = nullptr;
-            if (hipMalloc((void**)&wide, (size_t)W * n * 64 * 4) == hipSuccess) {
-                hipLaunchKernelGGL(k_repack_limbs<F>, zk_grid((size_t)W * n, 256), 256, 0, ctx->stream, (const uint32_t*)b->pre, wide, (size_t)W * n);
-                ZK_HIP(ctx, hipGetLastError());
-                ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                (void)hipFree(b->pre);
-                b->pre = wide;
-                b->pre_stride = 64;
-                return ZK_OK;
+        for (int form : {3, 2}) {
+            if (layout && layout != form) continue;
+            if (!layout && b->pre_stride) break;
+            const size_t words = form == 3 ? 64 : 32, bytes = (size_t)W * n * words * 4;
+            if (packed_bytes + bytes > budget) {         // (the packed table is still alive while the copy is made)
+                if (layout) { fail_free(nullptr); return skip("the forced layout does not fit a third of the free device memory"); }
+                continue;
             }
-            (void)hipGetLastError();
-        }
-    }
-    if (pad && F::WORDS == 12 && (size_t)W * n * 32 * 4 <= mem_free / 3) {
-        uint32_t* padded = nullptr;
-        if (hipMalloc((void**)&padded, (size_t)W * n * 32 * 4) == hipSuccess) {
-            hipLaunchKernelGGL(k_repack<F>, zk_grid((size_t)W * n, 256), 256, 0, ctx->stream, (const uint32_t*)b->pre, padded, (size_t)W * n, 32u);
-            ZK_HIP(ctx, hipGetLastError());
-            ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            uint32_t* wide = nullptr;
+            if (hipMalloc((void**)&wide, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                if (layout) { fail_free(nullptr); return skip("hipMalloc of the forced layout failed"); }
+                continue;
+            }
+            if (form == 3)
+                hipLaunchKernelGGL(k_repack_limbs<F>, zk_grid((size_t)W * n, 256), 256, 0, ctx->stream, (const uint32_t*)b->pre, wide, (size_t)W * n);
+            else
+                hipLaunchKernelGGL(k_repack<F>, zk_grid((size_t)W * n, 256), 256, 0, ctx->stream, (const uint32_t*)b->pre, wide, (size_t)W * n, 32u);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { fail_free(wide); ZK_HIP(ctx, e); }
             (void)hipFree(b->pre);
-            b->pre = padded;
-            b->pre_stride = 32;
-        } else {
-            (void)hipGetLastError();
+            b->pre = wide;
+            b->pre_stride = (uint32_t)words;
+            b->pre_note = form == 3 ? "limbs, both signs (256 B per point)" : "one point per 128-byte line";
         }
+    } else if (layout > 1) {
+        fail_free(nullptr);
+        ZK_FAIL(ctx, ZK_ERR_ARG, "zk_bases_precompute_as: layouts 2 and 3 are G1 forms");
     }
     return ZK_OK;
 }
@@ -250,8 +274,6 @@ extern "C" int zk_fixed_base_g2_dev(zk_ctx* ctx, const zk_fr* gen_k, const void*
 // The top window must keep >= 10 significant bits: 255 - c (W - 1) of only 3 bits (c = 18, 21) sends every point into
 // <= 8 buckets and the sort's atomics serialise (65 ms instead of 32).
 static uint32_t precompute_window_bits(size_t n) {
-    static const int env_c = getenv("ZK_PRECOMP_C") ? atoi(getenv("ZK_PRECOMP_C")) : 0;   // experiments
-    if (env_c >= 8 && env_c <= 24) return (uint32_t)env_c;
     uint32_t lg = 0;                                   // round(log2 n): a 2^20 - 1 point query is a 2^20 one
     while (((size_t)3 << lg) <= 2 * n) lg++;
     int c0 = (int)lg - 1;      // measured on whole proofs: 2^16 -> 15, 2^18 -> 16/17, 2^20..2^22 -> 20 (22 loses: 4x the buckets)
@@ -278,15 +300,26 @@ int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b) {
 
 extern "C" uint32_t zk_bases_window_bits(const zk_bases* b) { return b ? b->c_pre : 0; }
 
+static int precompute_run(zk_ctx* ctx, zk_bases* b, int layout) {
+    if (!ctx || layout < 0 || layout > 3) return ZK_ERR_ARG;
+    if (!b || b->pre || b->n < 4096) return ZK_OK;
+    const uint32_t c = precompute_window_bits(b->n);
+    const uint32_t W = (255 + c - 1) / c;
+    if (b->group == 1) return precompute_t<G1Field>(ctx, b, c, W, layout);
+    return precompute_t<G2Field>(ctx, b, c, W, layout);
+}
+
 extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b) {
     ZK_API_BEGIN(ctx)
-    if (!ctx) return ZK_ERR_ARG;
-    if (!b || b->pre || b->n < 4096) return ZK_OK;
-    uint32_t c = precompute_window_bits(b->n);
-    static const int env_c2 = getenv("ZK_PRECOMP_C_G2") ? atoi(getenv("ZK_PRECOMP_C_G2")) : 0;   // experiments
-    if (b->group == 2 && env_c2 >= 8 && env_c2 <= 24) c = (uint32_t)env_c2;
-    const uint32_t W = (255 + c - 1) / c;
-    if (b->group == 1) return precompute_t<G1Field>(ctx, b, c, W);
-    return precompute_t<G2Field>(ctx, b, c, W);
+    return precompute_run(ctx, b, 0);
     ZK_API_END
 }
+
+extern "C" int zk_bases_precompute_as(zk_ctx* ctx, zk_bases* b, int layout) {
+    ZK_API_BEGIN(ctx)
+    return precompute_run(ctx, b, layout);
+    ZK_API_END
+}
+
+// "" when nothing was attempted; the layout that was built; or why the table was skipped
+extern "C" const char* zk_bases_precompute_note(const zk_bases* b) { return b ? b->pre_note.c_str() : ""; }

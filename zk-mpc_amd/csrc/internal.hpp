@@ -6,7 +6,7 @@
 
 // ntt.hip
 void zk_domains_free(zk_ctx* ctx);
-void zk_presort_free(zk_ctx* ctx);   // groth16.hip: drop a pending zk_groth16_msms_presort_dev
+void zk_presort_free(zk_ctx* ctx);   // groth16_pipeline.hip: drop a pending zk_groth16_msms_presort_dev
 extern "C" int zk_comm_destroy(zk_ctx* ctx);
 extern "C" int zk_fr_sum_parties_dev(zk_ctx* ctx, const void* gathered_dev, size_t n_parties, size_t n, void* out_dev);
 int zk_ntt_launch(zk_ctx* ctx, void* buf_dev, uint32_t log_n, int inverse, int coset);
@@ -30,6 +30,7 @@ struct zk_bases {
     uint32_t c_pre = 0, W_pre = 0;
     uint32_t pre_stride = 0;   // 32-bit words per point in `pre` (0: packed, 2 * WORDS).  G1: 32 = one 128-byte line per 96-byte point;
                                // 64 = limb form, line 0 the point, line 1 its negative (fixed_base.hip::k_repack_limbs)
+    std::string pre_note;      // which layout `pre` has, or why the window multiples were skipped (zk_bases_precompute_note)
 };
 extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b);   // no-op for tables under 4096 points
 int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b);             // only when ZK_PRECOMP=1 (off by default: see fixed_base.hip)

@@ -1,7 +1,7 @@
 // marlin.hip -- data-parallel pieces of the Marlin AHP prover that are not already an NTT, an MSM or a vector op.
 //
 // Replaces (reference, relative to /root/reference/arkworks/marlin/src/ahp):
-//   prover.rs:258-278        inner_prod_fn (z_A = A z, z_B = B z)            -> zk_r1cs_matvec_dev (groth16.hip's SpMV)
+//   prover.rs:258-278        inner_prod_fn (z_A = A z, z_B = B z)            -> zk_r1cs_matvec_dev (r1cs.hip's SpMV)
 //   prover.rs:406-423        calculate_t                                      -> the same SpMV on the transposed matrices
 //   prover.rs:335-353        w_poly_evals (index re-mapping of the witness)   -> zk_fr_gather_dev
 //   constraint_systems.rs:183-216  row / col / val vectors of M^*             -> zk_fr_gather_dev

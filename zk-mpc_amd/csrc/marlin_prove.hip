@@ -282,21 +282,22 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     if (cap < zk_marlin_proof_max_size()) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: output buffer smaller than zk_marlin_proof_max_size()");
     if (ix->num_constraints != ix->num_variables) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: NonSquareMatrix");
     if (ix->num_instance == 0 || (ix->num_instance & (ix->num_instance - 1))) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_marlin_prove: InvalidPublicInputLength");
-    // ZK_MARLIN_TIMING=1: host wall-clock laps of the phases on stderr (a lap includes whatever device work the host waited for)
+    // with zk_set_profiling(ctx, 1): host wall-clock laps of the phases land in the context's timers as "marlin.<phase>" (a lap
+    // includes whatever device work the host waited for)
     struct Laps {
-        bool on = getenv("ZK_MARLIN_TIMING") != nullptr;
-        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), t = t0;
-        std::string line;
+        zk_ctx* ctx;
+        bool on;
+        std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+        explicit Laps(zk_ctx* c) : ctx(c), on(c->profiling) {}
         void lap(const char* what) {
             if (!on) return;
             const auto now = std::chrono::steady_clock::now();
-            char b[64];
-            snprintf(b, sizeof b, " %s %.2f", what, std::chrono::duration<double, std::milli>(now - t).count());
-            line += b;
+            auto& tm = ctx->timers[std::string("marlin.") + what];
+            tm.ms += (float)std::chrono::duration<double, std::milli>(now - t).count();
+            tm.count += 1;
             t = now;
         }
-        ~Laps() { if (on) fprintf(stderr, "zk_marlin_prove ms:%s | total %.2f\n", line.c_str(), std::chrono::duration<double, std::milli>(t - t0).count()); }
-    } laps;
+    } laps(ctx);
     ZkSharedNet nt{ctx, net};
     const bool leader = nt.leader();
     Prover PL[2] = {Prover{ctx, ix, powers_g, powers_gamma_g, powers_g->n - 1, zk_rng_}, Prover{ctx, ix, powers_g, powers_gamma_g, powers_g->n - 1, zk_rng_}};
@@ -317,8 +318,6 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         for (int i = 0; i < 12; i++) PL[l].polys[INDEX_LABELS[i]] = Poly{(char*)ix->index_polys[i].ptr, ix->index_polys[i].n};
     for (int i = 0; i < 12; i++) P.rands[INDEX_LABELS[i]] = {};
 
-    // ZK_MARLIN_SYNC_BLINDS=1 (experiment): the host-side blinding terms inline instead of on host threads
-    const bool blind_deferred = getenv("ZK_MARLIN_SYNC_BLINDS") != nullptr;
     zk_g1_projective gamma_pts[3];
     {
         zk_g1_affine a[3];
@@ -364,7 +363,7 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         // the blinding terms (three host scalar multiplications each, ~1.2 ms) run on host threads under the device batch
         std::vector<std::pair<std::pair<int, std::string>, ZkTask<zk_g1_projective>>> blinds;
         auto blind_async = [&](int which, const char* l, const std::vector<HF>& c) {
-            blinds.push_back({{which, l}, (blind_deferred ? ZkTask<zk_g1_projective>(std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); })) : zk_async(ctx, [&gamma_pts, c] { return small_msm(gamma_pts, c); }))});
+            blinds.push_back({{which, l}, zk_async(ctx, [&gamma_pts, c] { return small_msm(gamma_pts, c); })});
         };
         for (const char* l : labels) {
             const bool hiding = !strcmp(l, "w") || !strcmp(l, "z_a") || !strcmp(l, "z_b") || !strcmp(l, "g_1");
@@ -693,7 +692,7 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     std::vector<const zk_bases*> jb; std::vector<size_t> joff, jlen; std::vector<const void*> jsc;
     size_t counts[2][2] = {{0, 0}, {0, 0}};                                      // [query point][lane]
     std::vector<ZkTask<zk_g1_projective>> extra[2];                         // the blinding witnesses: host threads, joined after the batch
-    auto small_async = [&](const std::vector<HF>& c) { return (blind_deferred ? ZkTask<zk_g1_projective>(std::async(std::launch::deferred, [&gamma_pts, c] { return small_msm(gamma_pts, c); })) : zk_async(ctx, [&gamma_pts, c] { return small_msm(gamma_pts, c); })); };
+    auto small_async = [&](const std::vector<HF>& c) { return zk_async(ctx, [&gamma_pts, c] { return small_msm(gamma_pts, c); }); };
     bool has_rv[2] = {false, false}, q_shared[2] = {false, false};
     HF rvs[2];
     for (int q = 0; q < 2; q++) {

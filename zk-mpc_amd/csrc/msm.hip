@@ -61,8 +61,6 @@ MsmPlan make_plan(size_t n, uint32_t forced_c = 0) {
     int c = (int)lg - 4;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
-    static const int env_c = getenv("ZK_MSM_C") ? atoi(getenv("ZK_MSM_C")) : 0;   // experiments: window bits for n >= 2^19
-    if (env_c >= 4 && env_c <= 20 && n >= ((size_t)1 << 19)) c = env_c;
     if (forced_c) c = (int)forced_c;
     p.W = (255 + (uint32_t)c - 1) / (uint32_t)c;
     for (int i = 0; i < 9; i++) p.bias[i] = 0;
@@ -781,10 +779,7 @@ int msm_enqueue_accum_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
     job->timers.push_back(tm);
     tm->begin(g1 ? "msm_g1.accum" : "msm_g2.accum");
-    // blocks per CU of the (grid-striding) accumulate kernel; 0 = one thread per segment.  Tunable for experiments.
-    static const int bpc = getenv("ZK_ACCUM_BPC") ? atoi(getenv("ZK_ACCUM_BPC")) : 0;
-    const size_t full_grid = (job->max_segs + 255) / 256;
-    const unsigned accum_blocks = (unsigned)(bpc > 0 ? std::min<size_t>(full_grid, (size_t)ctx->n_cu * bpc) : full_grid);
+    const unsigned accum_blocks = (unsigned)((job->max_segs + 255) / 256);      // one lane per segment (blocks beyond ctr[2] return at once)
     // G2 runs on lane pairs (msm_g2pair.hip): the one-lane-per-addition form needs the whole register file and is slower
     if constexpr (F::WORDS == 12) {
         if (job->stride == 64)      // limb-form table with both signs (fixed_base.hip::k_repack_limbs)
@@ -1037,7 +1032,7 @@ extern "C" int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* h, size_t n, 
 extern "C" int zk_bases_free(zk_ctx* ctx, zk_bases* b) {
     ZK_API_BEGIN(ctx)
     if (!b) return ZK_OK;
-    zk_presort_free(ctx);          // a pending presort's job points into b->dev / b->pre (groth16.hip: zk_pk_free)
+    zk_presort_free(ctx);          // a pending presort's job points into b->dev / b->pre (groth16_key.hip: zk_pk_free)
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     if (b->owned && b->dev) (void)hipFree(b->dev);
     if (b->pre) (void)hipFree(b->pre);

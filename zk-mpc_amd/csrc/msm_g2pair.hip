@@ -174,15 +174,11 @@ __device__ __forceinline__ AffP unpack_p(const RawP& r) {
     return AffP{B::load(tx), B::load(ty)};
 }
 
-// MODE 2 (the product): 256 registers, two waves per SIMD, no spills.  MODE 0 (experiment, ZK_G2PAIR_WAVES=0): one wave per
-// SIMD AND 192 registers per lane left free -- the clobber of a63 makes the kernel own 256 + 64 registers -- so that kernels
-// of other streams find room on every SIMD beside it instead of waiting for a block of this kernel to retire; measured
-// slower (7.7 vs 7.2 ms alone, 21.3 vs 20.8 ms per proof).
-template <int MODE>
-__global__ void __launch_bounds__(256, (MODE == 2 ? 2 : 1))
+// 256 registers, two waves per SIMD, no spills.  (One wave per SIMD with 192 registers per lane left free for the kernels of the
+// other streams was measured slower: 7.7 vs 7.2 ms alone, 21.3 vs 20.8 ms per proof in round 2.)
+__global__ void __launch_bounds__(256, 2)
 k_accum_g2pair(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
                const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums) {
-    if (MODE == 0) asm volatile("" ::: "a63");
     const uint32_t S = ctr[2];
     const uint32_t G = gridDim.x * (blockDim.x >> 1);
     const uint32_t oddw = threadIdx.x & 1u;
@@ -386,12 +382,8 @@ struct RedG2Pair {
 // One pair of lanes per segment: `segments` logical threads.
 void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bases, const uint32_t* sorted, const void* desc,
                             const uint32_t* order, const uint32_t* ctr, uint32_t* sums) {
-    static const int waves = getenv("ZK_G2PAIR_WAVES") ? atoi(getenv("ZK_G2PAIR_WAVES")) : 2;
     const unsigned blocks = (unsigned)((segments + 127) / 128);
-    if (waves == 0)
-        hipLaunchKernelGGL(k_accum_g2pair<0>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
-    else
-        hipLaunchKernelGGL(k_accum_g2pair<2>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
+    hipLaunchKernelGGL(k_accum_g2pair, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
 }
 
 // The G2 reduce chain of msm.hip::msm_enqueue_reduce_t, same buffers and geometry, on lane pairs.

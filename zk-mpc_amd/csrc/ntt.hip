@@ -476,7 +476,7 @@ extern "C" int zk_fr_divide_by_vanishing_on_coset_dev(zk_ctx* ctx, void* evals, 
     ZK_API_END
 }
 
-// used by groth16.hip: (ab - c) / Z(g) fused
+// used by r1cs.hip: (ab - c) / Z(g) fused
 int zk_ntt_vanishing_inv(zk_ctx* ctx, uint32_t log_n, uint32_t out9[9]) {
     zk_domain* d;
     ZK_TRY(get_domain(ctx, log_n, false, &d));

@@ -1,4 +1,4 @@
-// sharednet.hpp -- what the collaborative provers (groth16.hip: zk_groth16_prove_shared[_spdz]; marlin_prove.hip:
+// sharednet.hpp -- what the collaborative provers (groth16_shared.hip: zk_groth16_prove_shared[_spdz]; marlin_prove.hip:
 // zk_marlin_prove_shared[_spdz]) share: the party's transport behind zk_net_vtable, the MAC-checked vector open and the vector
 // Beaver product.  Replaces MpcSerNet::broadcast (mpc-algebra/src/channel.rs:12-28), AdditiveFieldShare / SpdzFieldShare::batch_open
 // (share/additive.rs:124-131, share/spdz.rs:177-196) and FieldShare::batch_mul (share/field.rs:97-129) on device vectors.
@@ -39,7 +39,7 @@ struct ZkSharedNet {
     }
 };
 
-// groth16.hip
+// groth16_shared.hip
 // SpdzFieldShare::batch_open on a device vector (key alpha = 1 held by the leader): out = open(share lane); then every party
 // publishes [leader ? out : 0] - mac (into dx, n elements of scratch) and the sum must vanish -- otherwise ZK_ERR_MAC.
 int zk_shared_spdz_open_vec(ZkSharedNet& nt, const void* sh, const void* mac, size_t n, void* out, void* dx);
