@@ -571,6 +571,81 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
+def one_prover_bench(args, real_stdout):
+    """--one-prover: ONE local prover whose five MSMs are spread over --gpus N devices (zk_groth16_prove_multi; SURVEY 8e, second
+    level), all inside this one process -- no process group, no collective: the assignment goes out by peer copies, partial sums
+    come back as points.  Total work is fixed as N grows ("strong").  --one-gpu puts every context on cuda:0 (a functional run)."""
+    import hashlib
+    import torch
+    import zk_mpc_amd as Z
+    import zk_mpc_amd.convert as cv
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: libzkmpc_hip has no CPU path")
+    N = args.gpus
+    ndev = torch.cuda.device_count()
+    if not args.one_gpu and ndev < N:
+        sys.exit("bench.py --one-prover --gpus %d: only %d device(s) visible (add --one-gpu for a functional run on one)" % (N, ndev))
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    n = (1 << args.log_constraints) - 2
+    ctxs = [Z.Context(0 if args.one_gpu else d) for d in range(N)]
+    td = [mont(seeded_fr(i)) for i in range(1, 8)]
+    t0 = time.time()
+    r1css = [c.r1cs_mul_chain(n) for c in ctxs]
+    pks = [c.groth16_setup(r, *td) for c, r in zip(ctxs, r1css)]
+    t_setup = time.time() - t0
+    Q = max(1, args.queue)
+    zs = [ctxs[0].mul_chain_assignment_dev(n, mont(seeded_fr(100 + 10 * q)), mont(seeded_fr(101 + 10 * q))) for q in range(Q)]
+    rs = [(mont(seeded_fr(200 + 10 * q)), mont(seeded_fr(201 + 10 * q))) for q in range(Q)]
+    last = {}
+
+    def step(i):
+        q = i % Q
+        last[q] = ctxs[0].create_proof_multi(ctxs[1:], pks, r1css, zs[q].ptr, *rs[q])
+        return last[q]
+    it = 0
+    for _ in range(2 + args.warmup):
+        step(it); it += 1
+    for c in ctxs:
+        c.sync()
+    torch.cuda.synchronize()
+    per = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        proof = step(it); it += 1
+        per.append(time.perf_counter() - ts)
+    for c in ctxs:
+        c.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    single = [ctxs[0].create_proof_dev(pks[0], r1css[0], zs[q].ptr, *rs[q]) for q in sorted(last)]
+    t1 = time.perf_counter()
+    for q in sorted(last):
+        ctxs[0].create_proof_dev(pks[0], r1css[0], zs[q].ptr, *rs[q])
+    ctxs[0].sync()
+    t_single = (time.perf_counter() - t1) / len(last)
+    pred = None
+    if not args.no_predict:
+        q = sorted(last)[-1]
+        want, note = predict_proof(ctxs[0], n, ctxs[0].download(zs[q], (n + 3, 4)), td, rs[q][0], rs[q][1], os.cpu_count() or 1)
+        pred = None if want is None else bool(want == last[q])
+    K = args.steps
+    out = {"metric": "R1CS constraints/sec (prove), Groth16 BLS12-377", "value": round(n * K / dt, 1), "unit": "constraints/s",
+           "n_gpus": N, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3),
+           "ms_per_step_median": round(float(np.median(per)) * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "u32x13 (29-bit limbs, int64 accumulate)", "data": "synthetic",
+           "config": {"workload": "mul-chain R1CS, n=2^%d-2 constraints, ONE local prover over %d contexts (zk_groth16_prove_multi)%s"
+                                  % (args.log_constraints, N, ", every context on cuda:0 (functional run, not a measurement)" if args.one_gpu else ""),
+                      "constraints": n, "parties": 1, "contexts": N},
+           "plan": ctxs[0].multi_plan(pks[0], r1css[0], N),
+           "plan_columns": ["context", "job (0 = B in G2, 1 = A, 2 = B in G1, 3 = L, 4 = H)", "first term", "terms"],
+           "equals_single_context_proof": bool(all(a == last[q] for a, q in zip(single, sorted(last)))),
+           "single_context_isolated_ms": round(t_single * 1e3, 3),
+           "proof_matches_prediction": pred, "setup_s": round(t_setup, 2), "proof_sha": hashlib.sha256(proof).hexdigest()[:16],
+           "devices": [int(c.device) for c in ctxs], "hbm_in_use_gb": hbm_in_use_gb()}
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
 def hbm_in_use_gb():
     """Device memory held by this process when the line is written.  Scratch arenas and key tables are grow-only, so this is the
     high-water mark of the run up to freed temporaries."""
@@ -729,6 +804,9 @@ def main():
                     help="N > 1: every rank on cuda:0 (a functional run of the N-party path on a one-GPU box; needs --transport gloo: RCCL "
                          "refuses two ranks on one device)")
     ap.add_argument("--python-mpc", action="store_true", help="additive collaborative prover: the Python sequence instead of zk_groth16_prove_shared")
+    ap.add_argument("--one-prover", action="store_true",
+                    help="--gpus N: ONE local prover whose MSMs are spread over N devices inside this process (zk_groth16_prove_multi), instead "
+                         "of N parties; total work fixed (strong scaling); add --one-gpu for a functional run on one device")
     ap.add_argument("--marlin", action="store_true",
                     help="prove with Marlin/KZG instead of Groth16 (BASELINE configs 4 and 5: --gpus 1, or --gpus 8 --spdz --log-constraints 22)")
     args = ap.parse_args()
@@ -742,6 +820,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.one_prover:
+        if rank == 0:                       # one process drives every device; under a launcher the other ranks have nothing to do
+            one_prover_bench(args, real_stdout)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has not touched the GPU (no
         # torch import, no HIP call so far) and never will: the ranks are CHILD processes of torch.distributed.run, rank 0's one

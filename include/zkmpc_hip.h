@@ -291,6 +291,16 @@ int zk_groth16_msms_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const
  * (non-shared) assignment resident on the device; proof = a||b||c compressed, 192 bytes. */
 int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const void* z_dev,
                          const zk_fr* r, const zk_fr* s, uint8_t proof_out[192]);
+/* The same proof with the five MSMs of src/groth16.rs:106,110,137,148,160 spread over n_ctx contexts -- one per GPU of a node; for a
+ * functional run several on one GPU -- each with ITS OWN copy of the proving key and the constraint system (pks[i], r1css[i]
+ * belong to ctxs[i]).  The work is cut by cost into base ranges (a G2 term weighs 2.7 G1 terms), a context holding a piece of H runs
+ * the witness map itself, the assignment (on ctxs[0]'s device) reaches the others by one peer copy, the partial sums are added
+ * on the host: same 192 bytes as zk_groth16_prove_dev.  Errors of another context are reported through ctxs[0]. */
+int zk_groth16_prove_multi(zk_ctx* const* ctxs, const zk_pk* const* pks, const zk_r1cs* const* r1css, int n_ctx, const void* z_dev0,
+                           const zk_fr* r, const zk_fr* s, uint8_t proof_out[192]);
+/* How that call deals a proof of this shape: one text line per piece, "ctx job lo n" with job 0 = B in G2, 1 = A, 2 = B in G1,
+ * 3 = L, 4 = H and [lo, lo + n) the job's terms.  Returns the bytes written (0: bad arguments). */
+size_t zk_groth16_multi_plan(const zk_pk* pk, const zk_r1cs* r1cs, int n_ctx, char* out, size_t cap);
 /* Same with the assignment in host memory (instance then witness): SURVEY 8(d)'s "witness vector on host to 192 proof
  * bytes on host". */
 int zk_groth16_prove(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const zk_fr* z_host,

@@ -118,3 +118,12 @@ def test_config5_spdz_marlin_at_2p22():
     assert d["config"]["constraints"] == (1 << 22) - 3 and d["n_gpus"] == 2 and "SPDZ" in d["config"]["workload"]
     assert d["oracle_verifier_accepts"] is True and d["oracle_verifier_rejects_wrong_input"] is True
     assert d["prover_entry"] == "zk_marlin_prove_shared_spdz" and d["opens_in_timed_proofs"]["opens_per_proof"] >= 8
+
+
+def test_one_prover_line_over_three_contexts():
+    """`bench.py --gpus 3 --one-prover --one-gpu`: one local prover over three contexts (here on one device), no launcher and no
+    process group; the line says so, carries the plan, and the proofs equal the single-context ones and the prediction."""
+    d = _own_size(["--gpus", "3", "--one-prover", "--one-gpu", "--log-constraints", "16", "--steps", "3", "--warmup", "1"], timeout=600)
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["contexts"] == 3 and d["value"] > 0
+    assert d["equals_single_context_proof"] is True and d["proof_matches_prediction"] is True
+    assert sorted(set(p[0] for p in d["plan"])) == [0, 1, 2]

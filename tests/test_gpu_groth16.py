@@ -428,3 +428,45 @@ def test_boolean_heavy_assignment_matches_prediction(ctx, log_n):
     pk.free(); dr.free()
     for z in zs:
         z.free()
+
+
+@pytest.mark.parametrize("n,n_ctx", [(300, 2), ((1 << 14) - 2, 2), ((1 << 16) - 2, 3), ((1 << 16) - 2, 4), ((1 << 18) - 2, 5)])
+def test_one_prover_over_several_contexts(ctx, n, n_ctx):
+    """zk_groth16_prove_multi (second level): the five MSMs of src/groth16.rs:106-160 cut by cost into base ranges
+    and dealt to n_ctx contexts -- here all on this one device, each with its own copy of the key and the constraint system --
+    the partial sums added on the host: the same 192 bytes as zk_groth16_prove_dev on one context, and as the prediction.  The
+    plan covers every term of every job exactly once."""
+    import zk_mpc_amd as Z
+    import zkref_c as OC
+    rng = O.Prng(8100 + n_ctx + (n & 0xff))
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    td = [mont(rng.fr()) for _ in range(7)]
+    others = [Z.Context(0) for _ in range(n_ctx - 1)]
+    ctxs = [ctx] + others
+    try:
+        drs = [c.r1cs_mul_chain(n) for c in ctxs]
+        pks = [c.groth16_setup(dr, *td) for c, dr in zip(ctxs, drs)]
+        z = ctx.mul_chain_assignment_dev(n, mont(rng.fr()), mont(rng.fr()))
+        r, s = mont(rng.fr()), mont(rng.fr())
+        single = ctx.create_proof_dev(pks[0], drs[0], z.ptr, r, s)
+        cr = OC.R1cs(2, n + 1, *OC.mul_chain_csr(n))
+        zarr = ctx.download(z, (n + 3, 4))
+        assert single == OC.groth16_predict(cr, np.stack(td), zarr, OC.witness_map(cr, zarr, OC.num_threads()), r, s)
+        for _ in range(2):                                   # (twice: scratch and key state survive a call)
+            assert ctx.create_proof_multi(others, pks, drs, z.ptr, r, s) == single
+        plan = ctx.multi_plan(pks[0], drs[0], n_ctx)
+        lens = {0: n + 2, 1: n + 2, 2: n + 2, 3: n + 1, 4: min(len(pks[0].query_bases("h_query")), 1 << drs[0].domain_log)}
+        for job in range(5):
+            pieces = sorted((lo, m) for (_, j, lo, m) in plan if j == job)
+            assert pieces[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(pieces, pieces[1:])) and sum(m for _, m in pieces) == lens[job]
+        if n >= 1 << 14:
+            assert len(set(c for c, _, _, _ in plan)) == n_ctx                  # every context got work
+        assert ctx.create_proof_dev(pks[0], drs[0], z.ptr, r, s) == single     # the single-context pipeline still works afterwards
+        for pk in pks:
+            pk.free()
+        for dr in drs:
+            dr.free()
+        z.free()
+    finally:
+        for c in others:
+            c.close()

@@ -678,6 +678,26 @@ class Context:
         self._ck(self.lib.zk_groth16_prove_dev(self.h, pk.h, r1cs.h, C.c_void_p(int(z_dev)), C.byref(r), C.byref(s), _ptr(out)))
         return out.tobytes()
 
+    def create_proof_multi(self, others, pks, r1css, z_dev, r_mont4, s_mont4) -> bytes:
+        """zk_groth16_prove_multi: this context plus `others` (one per further device), each with its own key and constraint
+        system (pks[i], r1css[i] belong to [self] + others [i]); z_dev lives on this context's device."""
+        ctxs = [self] + list(others)
+        n = len(ctxs)
+        assert len(pks) == n and len(r1css) == n
+        ca = (C.c_void_p * n)(*[c.h for c in ctxs])
+        pa = (C.c_void_p * n)(*[p.h for p in pks])
+        ra = (C.c_void_p * n)(*[r.h for r in r1css])
+        r, s = _fr_struct(r_mont4), _fr_struct(s_mont4)
+        out = np.zeros(192, dtype=np.uint8)
+        self._ck(self.lib.zk_groth16_prove_multi(ca, pa, ra, n, C.c_void_p(int(z_dev)), C.byref(r), C.byref(s), _ptr(out)))
+        return out.tobytes()
+
+    def multi_plan(self, pk: "ProvingKey", r1cs: "R1cs", n_ctx: int):
+        """[(ctx, job, lo, n)]: how zk_groth16_prove_multi deals this proof over n_ctx contexts."""
+        buf = C.create_string_buffer(1 << 16)
+        k = self.lib.zk_groth16_multi_plan(pk.h, r1cs.h, n_ctx, buf, len(buf))
+        return [tuple(int(x) for x in line.split()) for line in buf.raw[:k].decode().splitlines()]
+
     def create_proof(self, pk: "ProvingKey", r1cs: "R1cs", z_mont: np.ndarray, r_mont4, s_mont4) -> bytes:
         z = np.ascontiguousarray(z_mont, dtype=np.uint64)
         assert z.shape[0] == r1cs.num_instance + r1cs.num_witness

@@ -13,6 +13,7 @@
 #include "hostgroup.hpp"
 #include "hostfield64.hpp"
 #include "internal.hpp"
+#include "../../include/zkmpc_hip.h"
 #include <chrono>
 #include <cstring>
 #include <functional>
@@ -76,6 +77,30 @@ int zk_prover_streams(zk_ctx* ctx, size_t k);
 int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const void* h_in, void* h_scratch,
                         zk_g1_projective out_g1[4], zk_g2_projective* out_g2, const std::function<void()>& after_abc = nullptr);
 int zk_pk_make_l_pad(zk_ctx* ctx, zk_pk* pk);     // groth16_key.hip: see zk_pk::l_pad
+
+// The O(1) host tail of a proof (groth16_prove.hip).  The chains run on the context's helper threads and reference this object:
+// declare it after the MSM sums it reads; the destructor joins.
+class ZkProofTail {
+    using H1 = zk::Fq64Field;
+    using H2 = zk::Fq264Field;
+    using X1 = zk::XYZZ<H1>;
+    using X2 = zk::XYZZ<H2>;
+    zk_ctx* ctx;
+    uint32_t rw[8], sw[8];
+    X1 delta1;
+    X2 delta2;
+    zk::Affine<H1> a0, alpha, b0, beta1;
+    zk::Affine<H2> b02, beta2;
+    X1 g_a, s_g_a, r_s_delta, r_g1_b;
+    zk::Affine<H2> b_aff;
+    ZkTask<void> chain_a, chain_b, chain_g2;         // (last members: joined before the fields the chains write go)
+
+   public:
+    ZkProofTail(zk_ctx* c, const zk_pk* pk, const zk_fr* r_, const zk_fr* s_);
+    void abc_ready(const zk_g1_projective& a_sum, const zk_g1_projective& b1_sum, const zk_g2_projective& b2_sum);
+    void join();
+    void finish(const zk_g1_projective& h_sum, const zk_g1_projective& l_sum, uint8_t proof[192]);
+};
 
 namespace zk {
 template <class F>

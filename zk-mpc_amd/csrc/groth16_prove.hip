@@ -5,6 +5,61 @@
 
 using namespace zk;
 
+// The O(1) tail of create_proof on the host, 64-bit limbs (hostfield64.hpp): calculate_coeff (src/groth16.rs:185-201: initial +
+// query[0] + acc + vk_param) for A, B-in-G1 and B-in-G2, the r / s terms (:115, :140, :161), C (:169-174) and the 192 bytes.
+// Everything that depends only on the A, B-in-G1 and B-in-G2 sums (and on r, s, the key) starts -- on the context's helper
+// threads -- as soon as those three MSMs have delivered (abc_ready), while the devices still work on L and H.
+ZkProofTail::ZkProofTail(zk_ctx* c, const zk_pk* pk, const zk_fr* r_, const zk_fr* s_) : ctx(c) {
+    fr_abi_to_canon_words(r_->l, rw);
+    fr_abi_to_canon_words(s_->l, sw);
+    delta1 = xyzz_from_affine<H1>(aff_to_host64<G1Field>(pk->delta_g1));
+    delta2 = xyzz_from_affine<H2>(aff_to_host64<G2Field>(pk->delta_g2));
+    a0 = aff_to_host64<G1Field>(pk->a0); alpha = aff_to_host64<G1Field>(pk->alpha_g1);
+    b0 = aff_to_host64<G1Field>(pk->b0_g1); beta1 = aff_to_host64<G1Field>(pk->beta_g1);
+    b02 = aff_to_host64<G2Field>(pk->b0_g2); beta2 = aff_to_host64<G2Field>(pk->beta_g2);
+}
+
+void ZkProofTail::abc_ready(const zk_g1_projective& a_sum, const zk_g1_projective& b1_sum, const zk_g2_projective& b2_sum) {
+    const X1 a_acc = host64_proj_from_abi<H1>((const uint64_t*)&a_sum);
+    const X1 b1_acc = host64_proj_from_abi<H1>((const uint64_t*)&b1_sum);
+    const X2 b2_acc = host64_proj_from_abi<H2>((const uint64_t*)&b2_sum);
+    chain_a = zk_async(ctx, [this, a_acc] {
+        const X1 r_g1 = host64_scalar_mul<H1>(delta1, rw);
+        r_s_delta = host64_scalar_mul<H1>(r_g1, sw);                                                     // :115
+        g_a = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(r_g1, a0), a_acc), alpha);
+        s_g_a = host64_scalar_mul<H1>(g_a, sw);                                                           // :140
+    });
+    chain_b = zk_async(ctx, [this, b1_acc] {
+        const X1 s_g1 = host64_scalar_mul<H1>(delta1, sw);
+        const X1 g1_b = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(s_g1, b0), b1_acc), beta1);
+        r_g1_b = host64_scalar_mul<H1>(g1_b, rw);                                                         // :161
+    });
+    chain_g2 = zk_async(ctx, [this, b2_acc] {
+        const X2 s_g2 = host64_scalar_mul<H2>(delta2, sw);
+        const X2 g2_b = xyzz_madd<H2>(xyzz_add<H2>(xyzz_madd<H2>(s_g2, b02), b2_acc), beta2);
+        b_aff = xyzz_to_affine<H2>(g2_b);
+    });
+}
+
+void ZkProofTail::join() {
+    if (chain_a.valid()) chain_a.get();
+    if (chain_b.valid()) chain_b.get();
+    if (chain_g2.valid()) chain_g2.get();
+}
+
+void ZkProofTail::finish(const zk_g1_projective& h_sum, const zk_g1_projective& l_sum, uint8_t proof[192]) {
+    join();
+    const X1 h_acc = host64_proj_from_abi<H1>((const uint64_t*)&h_sum);
+    const X1 l_acc = host64_proj_from_abi<H1>((const uint64_t*)&l_sum);
+    X1 g_c = xyzz_add<H1>(s_g_a, r_g1_b);                                                                 // :169-174
+    g_c = xyzz_add<H1>(g_c, xyzz_neg<H1>(r_s_delta));
+    g_c = xyzz_add<H1>(g_c, l_acc);
+    g_c = xyzz_add<H1>(g_c, h_acc);
+    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<H1>(g_a)), proof);
+    g2_serialize(aff_from_host64<G2Field>(b_aff), proof + 48);
+    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<H1>(g_c)), proof + 144);
+}
+
 extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const void* z, const zk_fr* r_, const zk_fr* s_,
                                     uint8_t proof[192]) {
     ZK_API_BEGIN(ctx)
@@ -12,65 +67,14 @@ extern "C" int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs*
     const size_t D = (size_t)1 << r->log_d;
     void* h;
     ZK_TRY(zk_scratch(ctx, "prove_h", D * 32, &h));
-    zk_g1_projective m1[4];
+    zk_g1_projective m1[4];      // H, L, A, B-in-G1 (declared before the tail: its tasks are joined before these go)
     zk_g2_projective m2;
-
-    // ---- O(1) tail on the host, 64-bit limbs.  Everything that depends only on the A, B-in-G1 and B-in-G2 sums (and on
-    // r, s, the key) starts as soon as those three jobs have delivered, while the GPU still works on L and H ----
-    using H1 = Fq64Field;
-    using H2 = Fq264Field;
-    using X1 = XYZZ<H1>;
-    using X2 = XYZZ<H2>;
-    uint32_t rw[8], sw[8];
-    fr_abi_to_canon_words(r_->l, rw);
-    fr_abi_to_canon_words(s_->l, sw);
-    const X1 delta1 = xyzz_from_affine<H1>(aff_to_host64<G1Field>(pk->delta_g1));
-    const X2 delta2 = xyzz_from_affine<H2>(aff_to_host64<G2Field>(pk->delta_g2));
-    const Affine<H1> a0 = aff_to_host64<G1Field>(pk->a0), alpha = aff_to_host64<G1Field>(pk->alpha_g1);
-    const Affine<H1> b0 = aff_to_host64<G1Field>(pk->b0_g1), beta1 = aff_to_host64<G1Field>(pk->beta_g1);
-    const Affine<H2> b02 = aff_to_host64<G2Field>(pk->b0_g2), beta2 = aff_to_host64<G2Field>(pk->beta_g2);
-    X1 g_a, s_g_a, r_s_delta, r_g1_b;
-    Affine<H2> b_aff;
-    ZkTask<void> chain_a, chain_b, chain_g2;         // (declared after everything the chains write: joined before those go)
-    std::chrono::steady_clock::time_point t_tail;
-    auto after_abc = [&]() {
-        const X1 a_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[2]);
-        const X1 b1_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[3]);
-        const X2 b2_acc = host64_proj_from_abi<H2>((const uint64_t*)&m2);
-        // calculate_coeff (src/groth16.rs:185-201): initial + query[0] + acc + vk_param
-        chain_a = zk_async(ctx, [&, a_acc] {
-            const X1 r_g1 = host64_scalar_mul<H1>(delta1, rw);
-            r_s_delta = host64_scalar_mul<H1>(r_g1, sw);                                                     // :115
-            g_a = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(r_g1, a0), a_acc), alpha);
-            s_g_a = host64_scalar_mul<H1>(g_a, sw);                                                           // :140
-        });
-        chain_b = zk_async(ctx, [&, b1_acc] {
-            const X1 s_g1 = host64_scalar_mul<H1>(delta1, sw);
-            const X1 g1_b = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(s_g1, b0), b1_acc), beta1);
-            r_g1_b = host64_scalar_mul<H1>(g1_b, rw);                                                         // :161
-        });
-        chain_g2 = zk_async(ctx, [&, b2_acc] {
-            const X2 s_g2 = host64_scalar_mul<H2>(delta2, sw);
-            const X2 g2_b = xyzz_madd<H2>(xyzz_add<H2>(xyzz_madd<H2>(s_g2, b02), b2_acc), beta2);
-            b_aff = xyzz_to_affine<H2>(g2_b);
-        });
-    };
-    int rc_msm = zk_groth16_run_msms(ctx, pk, r, z, nullptr, h, m1, &m2, after_abc);
-    t_tail = std::chrono::steady_clock::now();      // what is left of the host work once the GPU is done
-    if (chain_a.valid()) chain_a.get();
-    if (chain_b.valid()) chain_b.get();
-    if (chain_g2.valid()) chain_g2.get();
+    ZkProofTail tail(ctx, pk, r_, s_);
+    const int rc_msm = zk_groth16_run_msms(ctx, pk, r, z, nullptr, h, m1, &m2, [&] { tail.abc_ready(m1[2], m1[3], m2); });
+    const auto t_tail = std::chrono::steady_clock::now();      // what is left of the host work once the GPU is done
+    tail.join();
     ZK_TRY(rc_msm);
-    const X1 h_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[0]);
-    const X1 l_acc = host64_proj_from_abi<H1>((const uint64_t*)&m1[1]);
-    X1 g_c = xyzz_add<H1>(s_g_a, r_g1_b);                                                                 // :169-174
-    g_c = xyzz_add<H1>(g_c, xyzz_neg<H1>(r_s_delta));
-    g_c = xyzz_add<H1>(g_c, l_acc);
-    g_c = xyzz_add<H1>(g_c, h_acc);
-
-    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<H1>(g_a)), proof);
-    g2_serialize(aff_from_host64<G2Field>(b_aff), proof + 48);
-    g1_serialize(aff_from_host64<G1Field>(xyzz_to_affine<H1>(g_c)), proof + 144);
+    tail.finish(m1[0], m1[1], proof);
     if (ctx->profiling) {
         auto& t = ctx->timers["host.tail"];
         t.ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_tail).count();
