@@ -653,3 +653,87 @@ def test_lazy_add_matches_the_group_law():
         acc = out[:4]
         assert _val(acc[0]) < 5 * Q + EPS and all(_val(c) < Q + EPS for c in acc[1:])
         assert affine_of(out[4:]) == acc_pt
+
+
+# ---- the Rust side of the boundary (bindings/, generated by tools/gen_rust_ffi.py; no Rust toolchain here: kept from rotting) ----
+def _rust_prototypes():
+    text = open(os.path.join(ROOT, "bindings", "hip_ffi.rs")).read()
+    protos = {}
+    for m in re.finditer(r"pub fn (zk_\w+)\((.*)\)( -> ([^;]+))?;", text):
+        args = re.sub(r"/\*.*?\*/", "", m.group(2)).strip()
+        protos[m.group(1)] = ([a.split(":", 1)[1].strip() for a in args.split(", ")] if args else [], (m.group(4) or "").strip())
+    return protos
+
+
+def _split_args(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def test_generated_rust_bindings_match_header_library_and_ctypes():
+    """bindings/hip_ffi.rs is what tools/gen_rust_ffi.py makes of include/zkmpc_hip.h TODAY (--check), and agrees symbol for symbol,
+    arity for arity and return kind for return kind with the header's declarations and with the ctypes table the test-suite
+    drives the library through (zk-mpc_amd/_lib.py::PROTOTYPES).  What it must override in the reference:
+    ec/src/lib.rs:305-318, poly/src/domain/mod.rs:78-190, ff/src/fields/mod.rs:216-220, mpc-net/src/lib.rs:60-64."""
+    import ctypes as C
+    import subprocess
+    import sys
+    from zk_mpc_amd import _lib
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rust = _rust_prototypes()
+    assert sorted(rust) == declared_symbols() == sorted(_lib.PROTOTYPES)
+    kinds = {"i32": C.c_int, "usize": C.c_size_t, "u32": C.c_uint32, "*const c_char": C.c_char_p, "*mut c_void": C.c_void_p}
+    for name, (args, ret) in rust.items():
+        restype, argtypes = _lib.PROTOTYPES[name]
+        assert len(args) == len(argtypes), name
+        if ret.startswith("*") and ret not in kinds:           # a typed handle (zk_pk_query_bases): any pointer-sized restype
+            assert restype in (C.c_void_p, C.c_char_p), (name, ret, restype)
+        else:
+            assert kinds[ret] is restype, (name, ret, restype)
+        for a, ct in zip(args, argtypes):                       # pointers stay pointers, integers keep their width class
+            is_ptr = a.startswith("*")
+            ct_ptr = ct in (C.c_void_p, C.c_char_p) or hasattr(ct, "contents") or (isinstance(ct, type) and issubclass(ct, C._Pointer))
+            assert is_ptr == ct_ptr, (name, a, ct)
+            if not is_ptr:
+                assert {"i32": C.c_int, "u32": C.c_uint32, "usize": C.c_size_t, "u64": C.c_uint64}[a] is ct, (name, a, ct)
+    text = open(os.path.join(ROOT, "bindings", "hip_ffi.rs")).read()
+    for const in ("ZK_OK", "ZK_ERR_HIP", "ZK_ERR_ARG", "ZK_ERR_NOMEM", "ZK_ERR_STATE", "ZK_ERR_MAC"):
+        assert re.search(r"pub const %s: i32 = " % const, text)
+    for struct, size in (("ZkFr", "[u64; 4]"), ("ZkFq", "[u64; 6]"), ("ZkFq753", "[u64; 12]")):
+        assert re.search(r"pub struct %s \{[^}]*pub l: %s" % (struct, re.escape(size)), text)
+
+
+def test_rust_overrides_call_the_abi_with_the_declared_arity():
+    """bindings/overrides.rs (the trait overrides of INTEGRATION.md section 2 as source): every zk_* call names a declared entry
+    point and passes as many arguments as the header declares; the four dispatch points of SURVEY 8(b) are all there."""
+    rust = _rust_prototypes()
+    src = open(os.path.join(ROOT, "bindings", "overrides.rs")).read()
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    calls = 0
+    for m in re.finditer(r"\b(zk_\w+)\(", src):
+        name = m.group(1)
+        assert name in rust, name
+        depth, i = 1, m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        assert len(_split_args(src[m.end():i - 1])) == len(rust[name][0]), name
+        calls += 1
+    assert calls >= 10
+    for needed in ("zk_msm_g1", "zk_msm_g2", "zk_fr_fft_in_place", "zk_fr_divide_by_vanishing_on_coset_dev", "zk_fr_batch_product_in_place",
+                   "zk_comm_init", "zk_open_sum_fr_dev", "zk_groth16_prove_shared", "all_gather_bytes"):
+        assert needed in src, needed

@@ -235,3 +235,58 @@ def test_device_against_reference_vectors(ctx, kats):
     o = ctx.alloc(n * 96)
     ctx.encodedtext_mul_dev(x.ptr, y.ptr, o.ptr, n)
     assert cv.fq753_from_mont(ctx.download(o, (n, 12))) == [le(v) for v in s["xy"]]
+
+
+def test_groth16_proving_key_bytes_oracle(kats):
+    """ProvingKey::serialize / serialize_uncompressed of the reference (arkworks/groth16/src/data_structures.rs:133-151) against
+    the oracle's framing (zkref.pk_serialize): field order and the u64 Vec prefixes are choices, not mathematics."""
+    g = kats["groth16_simple"]
+    if "pk" not in g:
+        pytest.skip("ref_kats.json predates the proving-key dump: regenerate it with the current tools/ref_vectors/dump_kats.rs")
+    r1cs, z, td = _simple_circuit(g)
+    pk = O.ProvingKey(O.ProvingKeyScalars(r1cs, td))
+    assert O.pk_serialize(pk, True).hex() == g["pk"]
+    assert O.pk_serialize(pk, False).hex() == g["pk_uncompressed"]
+    assert O.vk_serialize(pk, True).hex() == g["vk"]
+
+
+def _marlin_pc_case(kats):
+    m = kats.get("marlin_pc_commit")
+    if m is None:
+        pytest.skip("ref_kats.json predates the MarlinKZG10::commit dump: regenerate it with the current tools/ref_vectors/dump_kats.rs")
+    return m
+
+
+def test_marlin_pc_commit_rng_draw_order_oracle(kats):
+    """MarlinKZG10::commit (poly-commit/src/marlin/marlin_pc/mod.rs:172-243) with Some(rng): per polynomial the blinding
+    polynomial of the commitment (hiding bound 1: three coefficients), then -- for a degree-bounded one -- the blinding polynomial
+    of the SHIFTED commitment; nothing for a non-hiding polynomial.  The reference's rng was a fresh test_rng(): replayed here,
+    the draws must BE the dumped blinding coefficients, the generator must end where the reference's did, and commitment =
+    MSM(powers, p) + MSM(powers_of_gamma_g, blind) (shifted: over shifted_powers from max_degree - bound on) must give the bytes."""
+    m = _marlin_pc_case(kats)
+    rng = FR.test_rng()
+    powers = [g1_unc(h) for h in m["powers"]]
+    shifted = [g1_unc(h) for h in m["shifted_powers"]]
+    gamma = [g1_unc(h) for h in m["powers_of_gamma_g"]]
+    bound = 8
+    for p in m["polys"]:
+        coeffs = [le(c) for c in p["coeffs"]]
+        hiding = p["label"] in ("hb", "h")
+        blind = [rng.next_fr() for _ in range(3)] if hiding else []
+        assert blind == [le(c) for c in p["blind"]], p["label"]
+        comm = O.msm_naive(powers, coeffs, O.FqOps)
+        if blind:
+            comm = O.g1_add(comm, O.msm_naive(gamma, blind, O.FqOps))
+        want = O.g1_serialize(comm)
+        if p["label"] == "hb":
+            sblind = [rng.next_fr() for _ in range(3)]
+            assert sblind == [le(c) for c in p["shifted_blind"]]
+            # shifted_powers holds the powers from max_degree - (largest enforced bound) on: with one bound, from its start
+            sc = O.g1_add(O.msm_naive(shifted[:len(coeffs)], coeffs, O.FqOps), O.msm_naive(gamma, sblind, O.FqOps))
+            want += b"\x01" + O.g1_serialize(sc)                # Option<Commitment>: a presence byte, then the point
+            assert len(shifted) == bound + 1
+        else:
+            assert p["shifted_blind"] is None
+            want += b"\x00"
+        assert want.hex() == p["commitment"], p["label"]
+    assert rng.next_u64() == m["rng_next_u64_after"]

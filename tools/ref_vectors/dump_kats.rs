@@ -133,9 +133,12 @@ fn main() {
         let proof: Proof<Bls12_377> = create_proof(MySimpleCircuit { a: Some(a), b: Some(b) }, &pk, r, s).unwrap();
         let tau = Fr::rand(&mut test_rng());
         writeln!(j, "\"groth16_simple\": {{\"alpha\": \"{}\", \"beta\": \"{}\", \"gamma\": \"{}\", \"delta\": \"{}\", \"g1_k\": \"{}\", \"g2_k\": \"{}\", \
-                     \"tau\": \"{}\", \"a\": \"{}\", \"b\": \"{}\", \"r\": \"{}\", \"s\": \"{}\", \"proof\": \"{}\", \"vk\": \"{}\", \"pk_sha_len\": {}}},",
+                     \"tau\": \"{}\", \"a\": \"{}\", \"b\": \"{}\", \"r\": \"{}\", \"s\": \"{}\", \"proof\": \"{}\", \"vk\": \"{}\", \"pk_sha_len\": {}, \"pk\": \"{}\", \"pk_uncompressed\": \"{}\"}},",
                  fr_hex(&alpha), fr_hex(&beta), fr_hex(&gamma), fr_hex(&delta), fr_hex(&k1), fr_hex(&k2), fr_hex(&tau),
-                 fr_hex(&a), fr_hex(&b), fr_hex(&r), fr_hex(&s), ser(&proof), ser(&pk.vk), ser(&pk).len() / 2).unwrap();
+                 fr_hex(&a), fr_hex(&b), fr_hex(&r), fr_hex(&s), ser(&proof), ser(&pk.vk), ser(&pk).len() / 2,
+                 // the whole ProvingKey in both forms (arkworks/groth16/src/data_structures.rs:133-151: vk, beta_g1, delta_g1, a_query,
+                 // b_g1_query, b_g2_query, h_query, l_query -- the FRAMING is a choice, not mathematics: field order, u64 Vec prefixes)
+                 ser(&pk), ser_unc(&pk)).unwrap();
     }
 
     // (7) SHE: Encodedtext * Encodedtext in F_q[X]/(X^N + 1), N = 4 (src/she/encodedtext.rs:115-134), q = MNT4-753 base field
@@ -190,10 +193,54 @@ fn main() {
         let gamma = Fr::rand(&mut fs);
         writeln!(j, "\"marlin_simple\": {{\"a\": \"{}\", \"b\": \"{}\", \"public_input\": {}, \"seed\": \"{}\", \"absorb\": {}, \
                      \"alpha\": \"{}\", \"eta_a\": \"{}\", \"eta_b\": \"{}\", \"eta_c\": \"{}\", \"beta\": \"{}\", \"gamma\": \"{}\", \
-                     \"proof\": \"{}\", \"ivk\": \"{}\", \"srs\": \"{}\"}}",
+                     \"proof\": \"{}\", \"ivk\": \"{}\", \"srs\": \"{}\"}},",
                  fr_hex(&a), fr_hex(&b), list(public_input.iter().map(fr_hex).collect()), hex::encode(&seed),
                  list(ab.iter().map(hex::encode).collect()), fr_hex(&m1.alpha), fr_hex(&m1.eta_a), fr_hex(&m1.eta_b), fr_hex(&m1.eta_c),
                  fr_hex(&m2.beta), fr_hex(&gamma), ser(&proof), ser(&ivk), ser(&srs)).unwrap();
+    }
+    // (9) MarlinKZG10::commit (poly-commit/src/marlin/marlin_pc/mod.rs:172-243): the ORDER in which a hiding commitment draws from
+    //     the prover's rng -- per polynomial: the blinding polynomial of the commitment (kzg10::Randomness::rand -> P::rand(
+    //     hiding_bound + 1 coefficients... calculate_hiding_polynomial_degree, kzg10/data_structures.rs:447-483), then, if the
+    //     polynomial has a degree bound, the blinding polynomial of the SHIFTED commitment -- and what a commitment with and without
+    //     a degree bound / hiding bound looks like in bytes.  Three labelled polynomials of degree 5 over an SRS of degree 16:
+    //       "hb"  degree bound 8, hiding bound 1      "h" hiding bound 1      "plain" neither
+    //     PolynomialCommitment::{setup(max_degree, None, rng) (:72-78), trim(pp, supported_degree, supported_hiding_bound,
+    //     enforced_degree_bounds) (:80-85), commit(ck, polys, Some(rng)) (:172-176)}; LabeledPolynomial::new(label, poly, degree_bound,
+    //     hiding_bound) (poly-commit/src/data_structures.rs:140-153); Randomness { rand, shifted_rand } with
+    //     rand.blinding_polynomial (marlin_pc/data_structures.rs:336-343, kzg10/data_structures.rs:447-452).
+    //     Draw order: the SRS from a fresh test_rng(); the three polynomials' 6 coefficients each from `rng` (in label order); the
+    //     commit rng is a fresh test_rng(), so its draws are the generator's first words: the consumer replays them.
+    {
+        use ark_poly::{univariate::DensePolynomial, UVPolynomial};
+        use ark_poly_commit::{marlin_pc::MarlinKZG10, LabeledPolynomial, PolynomialCommitment};
+        use ark_std::rand::RngCore;
+        type PC = MarlinKZG10<Bls12_377, DensePolynomial<Fr>>;
+        let pp = PC::setup(16, None, &mut test_rng()).unwrap();
+        let (ck, _vk) = PC::trim(&pp, 16, 1, Some(&[8])).unwrap();
+        let coeffs: Vec<Vec<Fr>> = (0..3).map(|_| (0..6).map(|_| Fr::rand(rng)).collect()).collect();
+        let polys = vec![
+            LabeledPolynomial::new("hb".to_string(), DensePolynomial::from_coefficients_vec(coeffs[0].clone()), Some(8), Some(1)),
+            LabeledPolynomial::new("h".to_string(), DensePolynomial::from_coefficients_vec(coeffs[1].clone()), None, Some(1)),
+            LabeledPolynomial::new("plain".to_string(), DensePolynomial::from_coefficients_vec(coeffs[2].clone()), None, None),
+        ];
+        let mut commit_rng = test_rng();
+        let (comms, rands) = PC::commit(&ck, &polys, Some(&mut commit_rng)).unwrap();
+        let next_after = commit_rng.next_u64();          // how far the commit advanced the generator
+        let fr_list = |v: &Vec<Fr>| list(v.iter().map(fr_hex).collect());
+        let blind = |r: &ark_poly_commit::kzg10::Randomness<Fr, DensePolynomial<Fr>>| fr_list(&r.blinding_polynomial.coeffs);
+        let mut items = Vec::new();
+        for (i, (c, r)) in comms.iter().zip(rands.iter()).enumerate() {
+            let shifted = match &r.shifted_rand { Some(sr) => blind(sr), None => "null".to_string() };
+            items.push(format!("{{\"label\": \"{}\", \"coeffs\": {}, \"commitment\": \"{}\", \"blind\": {}, \"shifted_blind\": {}}}",
+                               c.label(), fr_list(&coeffs[i]), ser(c.commitment()), blind(&r.rand), shifted));
+        }
+        // the committer key's tables (pub fields, marlin_pc/data_structures.rs:25-43) so that the consumer needs no replay of
+        // KZG10::setup (whose g, gamma_g, h are rejection-sampled curve points): powers = beta^i g, shifted_powers = the powers from
+        // max_degree - (largest bound) on, powers_of_gamma_g = beta^i gamma_g
+        let pts = |v: &Vec<G1Affine>| list(v.iter().map(ser_unc).collect());
+        writeln!(j, "\"marlin_pc_commit\": {{\"polys\": [{}], \"rng_next_u64_after\": {}, \"max_degree\": {}, \"powers\": {},                      \"shifted_powers\": {}, \"powers_of_gamma_g\": {}}}",
+                 items.join(","), next_after, ck.max_degree, pts(&ck.powers), pts(ck.shifted_powers.as_ref().unwrap()),
+                 pts(&ck.powers_of_gamma_g)).unwrap();
     }
     j.push_str("}\n");
     std::fs::write(&out_path, j).unwrap();
