@@ -69,7 +69,8 @@ def main():
     proof = O.proof_serialize(*O.predict_proof(r1cs, pks, z, rr, ss_))
     out["groth16_simple"] = dict(alpha=hx(alpha, 32), beta=hx(beta, 32), gamma=hx(gamma, 32), delta=hx(delta, 32), g1_k=hx(g1k, 32),
                                  g2_k=hx(g2k, 32), tau=hx(tau, 32), a=hx(a, 32), b=hx(b, 32), r=hx(rr, 32), s=hx(ss_, 32),
-                                 proof=proof.hex(), vk="", pk_sha_len=0)
+                                 proof=proof.hex(), vk=O.vk_serialize(O.ProvingKey(pks), True).hex(), pk_sha_len=0,
+                                 pk=O.pk_serialize(O.ProvingKey(pks), True).hex(), pk_uncompressed=O.pk_serialize(O.ProvingKey(pks), False).hex())
     N = 4
     x = [fq_rand(r, O.Q753, 12, 15) for _ in range(N)]
     y = [fq_rand(r, O.Q753, 12, 15) for _ in range(N)]
@@ -94,6 +95,27 @@ def main():
                                 alpha=hx(ch["alpha"], 32), eta_a=hx(ch["eta_a"], 32), eta_b=hx(ch["eta_b"], 32), eta_c=hx(ch["eta_c"], 32),
                                 beta=hx(ch["beta"], 32), gamma=hx(ch["gamma"], 32), proof=proof.serialize().hex(), ivk="", srs="",
                                 domain_h=index.dom_h.size)
+    # (9) MarlinKZG10::commit's draw order: three polynomials of 6 coefficients from r; the commit rng is a fresh test_rng()
+    coeffs = [[r.next_fr() for _ in range(6)] for _ in range(3)]
+    pp9 = O.KzgParams(16, 0x1234567, g_k=3, gg_k=7, h_k=5)
+    crng = FR.test_rng()
+    items = []
+    for label, c, bound, hiding in (("hb", coeffs[0], 8, True), ("h", coeffs[1], None, True), ("plain", coeffs[2], None, False)):
+        blind = [crng.next_fr() for _ in range(3)] if hiding else []
+        comm = O.kzg_commit(pp9, c, blind or None)
+        ser = O.g1_serialize(comm)
+        sblind = None
+        if bound is not None:
+            sblind = [crng.next_fr() for _ in range(3)]
+            sc = O.g1_add(O.msm_naive(pp9.powers_of_g[16 - bound:], c, O.FqOps), O.msm_naive(pp9.powers_of_gamma_g, sblind, O.FqOps))
+            ser += b"\x01" + O.g1_serialize(sc)
+        else:
+            ser += b"\x00"
+        items.append(dict(label=label, coeffs=[hx(v, 32) for v in c], commitment=ser.hex(), blind=[hx(v, 32) for v in blind],
+                          shifted_blind=None if sblind is None else [hx(v, 32) for v in sblind]))
+    out["marlin_pc_commit"] = dict(polys=items, rng_next_u64_after=crng.next_u64(), max_degree=16,
+                                   powers=[u1(x).hex() for x in pp9.powers_of_g], shifted_powers=[u1(x).hex() for x in pp9.powers_of_g[8:]],
+                                   powers_of_gamma_g=[u1(x).hex() for x in pp9.powers_of_gamma_g[:3]])
     json.dump(out, open(sys.argv[1], "w"))
 
 
