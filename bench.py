@@ -353,47 +353,14 @@ def other_workloads(ctx, log_h=20):
             proof_bytes = DM.prove_native(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
         ctx.sync()
         dt = (time.perf_counter() - t0) / reps
-        # the same proof through the Python sequence of the C-ABI pieces (what the collaborative provers build on): equal bytes,
-        # and an object the oracle's verifier can take apart
-        proof = DM.prove(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
-        same = proof.serialize(ctx) == proof_bytes
         ctx.pooling = False
         ctx.drop_pool()
         out["marlin"] = {"workload": "Marlin::prove (AHP rounds + MarlinKZG10 commitments with hiding and degree bounds + Fiat-Shamir "
                                      "transcript + open_combinations), mul-chain R1CS, |H| = |K| = 2^%d, index key and SRS resident, "
                                      "prover randomness from a ChaCha20 rng (the mask polynomial sampled on the device)" % log_h,
                          "constraints": n, "ms_per_proof": round(dt * 1e3, 2), "constraints_per_s": round(n / dt, 1),
-                         "entry_point": "zk_marlin_prove", "proof_bytes": len(proof_bytes),
-                         "equals_python_sequence": bool(same)}
-        # checker (outside the timing): the oracle's Marlin::verify re-derives the transcript from the proof and checks the two
-        # sum-check combinations and one KZG pairing equation per query point; a wrong public input must be rejected
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import marlin_full_ref as MF
-            import marlin_ref as MR
-            import zkref as O
-
-            class PP:
-                pass
-            pp = PP()
-            pp.beta = beta_srs
-            pp.g, pp.gamma_g, pp.h = O.g1_mul(O.G1_GEN, g_k), O.g1_mul(O.G1_GEN, gg_k), O.g2_mul(O.G2_GEN, h_k)
-            pp.beta_h = O.g2_mul(pp.h, beta_srs)
-            info = MR.IndexInfo(index.num_constraints, index.num_non_zero, index.num_instance)
-            info.num_variables, info.num_constraints, info.num_non_zero = index.num_variables, index.num_constraints, index.num_non_zero
-            okeys = MF.Keys(info, pp, max_degree=srs.max_degree, index_comms={l: keys.index_comms[l].comm_aff for l in MF.INDEX_LABELS})
-            as_oracle = MF.Proof([[(cc.comm_aff, cc.shifted_aff, cc.shifted is not None) for cc in rnd] for rnd in proof.commitments],
-                                 proof.evaluations, [(cv2.g1_projective_to_affine(w), rv) for w, rv in proof.pc_proof])
-            pub = cv2.fr_from_mont(ctx.download(z.ptr + 32, (index.num_instance - 1, 4)))
-            t1 = time.time()
-            ok = MF.verify(okeys, pub, as_oracle)
-            rej = not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], as_oracle)
-            out["marlin"]["oracle_verifier_accepts"] = bool(ok)
-            out["marlin"]["oracle_verifier_rejects_wrong_input"] = bool(rej)
-            out["marlin"]["verify_seconds"] = round(time.time() - t1, 1)
-        except Exception as e:
-            out["marlin"]["oracle_verifier_accepts"] = None
-            out["marlin"]["verifier_error"] = repr(e)
+                         "entry_point": "zk_marlin_prove", "proof_bytes": len(proof_bytes)}
+        out["marlin"].update(marlin_oracle_verdict(ctx, index, keys, srs, z, proof_bytes, beta_srs, g_k, gg_k, h_k))
         del index, srs, keys, z
     except Exception as e:  # the headline line must not depend on this leg
         ctx.pooling = False
@@ -437,6 +404,37 @@ def predict_proof(ctx, n, zarr, td, r_, s_, threads):
     return OC.groth16_predict(cr, np.stack(td), zarr, h, r_, s_), "ok"
 
 
+def marlin_oracle_verdict(ctx, index, keys, srs, z, proof_bytes, beta_srs, g_k, gg_k, h_k):
+    """Checker (outside every timed region): the oracle's Marlin::verify on the BYTES the prover emitted -- CanonicalDeserialize of
+    the proof (points through GroupAffine::deserialize: on the curve, in the subgroup), the transcript re-derived, the two
+    sum-check combinations and one KZG pairing equation per query point; a wrong public input must be rejected."""
+    import zk_mpc_amd.convert as cv
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import marlin_full_ref as MF
+        import marlin_ref as MR
+        import zkref as O
+
+        class PP:
+            pass
+        pp = PP()
+        pp.beta = beta_srs
+        pp.g, pp.gamma_g, pp.h = O.g1_mul(O.G1_GEN, g_k), O.g1_mul(O.G1_GEN, gg_k), O.g2_mul(O.G2_GEN, h_k)
+        pp.beta_h = O.g2_mul(pp.h, beta_srs)
+        info = MR.IndexInfo(index.num_constraints, index.num_non_zero, index.num_instance)
+        info.num_variables, info.num_constraints, info.num_non_zero = index.num_variables, index.num_constraints, index.num_non_zero
+        okeys = MF.Keys(info, pp, max_degree=srs.max_degree, index_comms={l: keys.index_comms[l].comm_aff for l in MF.INDEX_LABELS})
+        t1 = time.time()
+        as_oracle = MF.proof_deserialize(proof_bytes)
+        assert as_oracle.serialize() == proof_bytes
+        pub = cv.fr_from_mont(ctx.download(z.ptr + 32, (index.num_instance - 1, 4)))
+        return {"oracle_verifier_accepts": bool(MF.verify(okeys, pub, as_oracle)),
+                "oracle_verifier_rejects_wrong_input": bool(not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], as_oracle)),
+                "verified": "the emitted bytes, deserialised by the oracle", "verify_seconds": round(time.time() - t1, 1)}
+    except Exception as e:
+        return {"oracle_verifier_accepts": None, "verifier_error": repr(e)}
+
+
 def marlin_bench(args, ctx, dist, rank, world, real_stdout):
     """--marlin: Marlin::prove on the mul-chain system with |H| = |K| = 2^L (BASELINE config 4: one GPU, zk_marlin_prove;
     config 5's shape with --gpus N [--spdz]: the N-party collaborative prover, every party the full-size rounds and MSMs on its
@@ -473,16 +471,10 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
             keep.append(party._keep)
         zb = [types.SimpleNamespace(ptr=p) for p in zl]
 
-        def python_step():
-            if args.spdz:
-                return party.marlin_prove_full_spdz(keys, (zb[0], zb[1]), Rng.from_seed(seed, 20), mask_on_device=True)
-            return party.marlin_prove_full(keys, zb[0], Rng.from_seed(seed, 20), mask_on_device=True)
-
-        def native_step():      # one library call per proof (zk_marlin_prove_shared[_spdz]); --python-mpc times the mpc.py sequence
+        def step():      # one library call per proof (zk_marlin_prove_shared[_spdz])
             if args.spdz:
                 return party.marlin_prove_shared_spdz_native(keys, (zb[0], zb[1]), Rng.from_seed(seed, 20), mask_on_device=True)
             return party.marlin_prove_shared_native(keys, zb[0], Rng.from_seed(seed, 20), mask_on_device=True)
-        step = python_step if args.python_mpc else native_step
 
     def barrier():
         if dist is not None:
@@ -510,39 +502,10 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
         t = torch.tensor([dt], device="cuda" if args.transport == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if dist is not None:        # (every rank: the Python sequence is a collective too) the parsed proof for the oracle's verifier
-        obj = proof if args.python_mpc else python_step()
-        proof_bytes = proof.serialize(ctx) if args.python_mpc else proof
-        same = None if args.python_mpc else bool(obj.serialize(ctx) == proof_bytes)
     if rank != 0:
         return
-    if dist is None:
-        obj = DM.prove(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
-        same = obj.serialize(ctx) == proof
-        proof_bytes = proof
-    verdict = {}
-    try:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import marlin_full_ref as MF
-        import marlin_ref as MR
-        import zkref as O
-
-        class PP:
-            pass
-        pp = PP()
-        pp.beta = beta_srs
-        pp.g, pp.gamma_g, pp.h = O.g1_mul(O.G1_GEN, g_k), O.g1_mul(O.G1_GEN, gg_k), O.g2_mul(O.G2_GEN, h_k)
-        pp.beta_h = O.g2_mul(pp.h, beta_srs)
-        info = MR.IndexInfo(index.num_constraints, index.num_non_zero, index.num_instance)
-        info.num_variables, info.num_constraints, info.num_non_zero = index.num_variables, index.num_constraints, index.num_non_zero
-        okeys = MF.Keys(info, pp, max_degree=srs.max_degree, index_comms={l: keys.index_comms[l].comm_aff for l in MF.INDEX_LABELS})
-        as_oracle = MF.Proof([[(cc.comm_aff, cc.shifted_aff, cc.shifted is not None) for cc in rnd] for rnd in obj.commitments],
-                             obj.evaluations, [(cv.g1_projective_to_affine(w), rv) for w, rv in obj.pc_proof])
-        pub = cv.fr_from_mont(ctx.download(z.ptr + 32, (index.num_instance - 1, 4)))
-        verdict = {"oracle_verifier_accepts": bool(MF.verify(okeys, pub, as_oracle)),
-                   "oracle_verifier_rejects_wrong_input": bool(not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], as_oracle))}
-    except Exception as e:
-        verdict = {"oracle_verifier_accepts": None, "verifier_error": repr(e)}
+    proof_bytes = proof
+    verdict = marlin_oracle_verdict(ctx, index, keys, srs, z, proof_bytes, beta_srs, g_k, gg_k, h_k)
     K = args.steps
     out = {"metric": "R1CS constraints/sec (prove), Marlin/KZG10 BLS12-377", "value": round(n * K / dt, 1), "unit": "constraints/s",
            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True,
@@ -550,7 +513,7 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
            "config": {"workload": "Marlin::prove, mul-chain R1CS, |H| = |K| = 2^%d, %s" % (
                args.log_constraints, "local prove (zk_marlin_prove)" if dist is None else "%d-party %s collaborative prove" % (
                    world, "SPDZ" if args.spdz else "additive-share")), "constraints": n, "parties": world},
-           "proof_constraints_per_s": round(n * K / dt, 1), "proof_bytes": len(proof_bytes), "equals_python_sequence": same,
+           "proof_constraints_per_s": round(n * K / dt, 1), "proof_bytes": len(proof_bytes),
            "setup_s": round(t_setup, 2), "proof_sha": __import__("hashlib").sha256(proof_bytes).hexdigest()[:16], **verdict}
     out["hbm_in_use_gb"] = hbm_in_use_gb()
     if dist is not None:
@@ -558,7 +521,7 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
         out["bytes_sent_per_party_per_proof"] = int(sent_timed // max(K, 1))
         out["aggregate_constraint_shares_per_s"] = round(n * K / dt * world, 1)
         out["opens_in_timed_proofs"] = opens_timed
-        out["prover_entry"] = "mpc.py sequence" if args.python_mpc else ("zk_marlin_prove_shared_spdz" if args.spdz else "zk_marlin_prove_shared")
+        out["prover_entry"] = "zk_marlin_prove_shared_spdz" if args.spdz else "zk_marlin_prove_shared"
         out["preflight_opens"] = preflight
         out["ranks"] = ranks_seen
         out["rccl_ranks_seen"] = None if ranks_seen is None else {
@@ -803,7 +766,6 @@ def main():
     ap.add_argument("--one-gpu", action="store_true",
                     help="N > 1: every rank on cuda:0 (a functional run of the N-party path on a one-GPU box; needs --transport gloo: RCCL "
                          "refuses two ranks on one device)")
-    ap.add_argument("--python-mpc", action="store_true", help="additive collaborative prover: the Python sequence instead of zk_groth16_prove_shared")
     ap.add_argument("--one-prover", action="store_true",
                     help="--gpus N: ONE local prover whose MSMs are spread over N devices inside this process (zk_groth16_prove_multi), instead "
                          "of N parties; total work fixed (strong scaling); add --one-gpu for a functional run on one device")
@@ -901,18 +863,15 @@ def main():
             rsh, ssh = (ra[0], rb[0]), (ra[1], rb[1])
 
             def step(i):
-                fn = party.create_proof_shared_spdz if args.python_mpc else party.create_proof_shared_spdz_native
-                last_proof[0] = fn(pk, r1cs, zshare, rsh, ssh)
+                last_proof[0] = party.create_proof_shared_spdz_native(pk, r1cs, zshare, rsh, ssh)
                 return last_proof[0]
         else:
             zshare = party.share_assignment_dev(zs[0], r1cs, seed=1234)
             sc = party.share_scalars([r_plain, s_plain], seed=99)
 
             def step(i):
-                # one library call per proof (zk_groth16_prove_shared; the transport reached through callbacks): --python-mpc
-                # keeps the Python sequence of the same calls
-                fn = party.create_proof_shared if args.python_mpc else party.create_proof_shared_native
-                last_proof[0] = fn(pk, r1cs, zshare, sc[0], sc[1])
+                # one library call per proof (zk_groth16_prove_shared; the transport reached through callbacks)
+                last_proof[0] = party.create_proof_shared_native(pk, r1cs, zshare, sc[0], sc[1])
                 return last_proof[0]
 
     def barrier():
@@ -1176,8 +1135,7 @@ def main():
             out["aggregate_constraint_shares_per_s"] = round(per_proof * world, 1)
             out["opens_in_timed_proofs"] = opens_timed
             out["same_proof_on_all_ranks"] = bool(same_on_all_ranks)
-            out["prover_entry"] = ("mpc.py sequence" if args.python_mpc else
-                                   "zk_groth16_prove_shared%s (one C-ABI call per proof)" % ("_spdz" if args.spdz else ""))
+            out["prover_entry"] = "zk_groth16_prove_shared%s (one C-ABI call per proof)" % ("_spdz" if args.spdz else "")
             out["open_probe"] = open_probe
             out["preflight_opens"] = preflight
             out["ranks"] = ranks_seen

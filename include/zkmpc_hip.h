@@ -299,8 +299,8 @@ int zk_groth16_prove_dev(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, cons
 int zk_groth16_prove_multi(zk_ctx* const* ctxs, const zk_pk* const* pks, const zk_r1cs* const* r1css, int n_ctx, const void* z_dev0,
                            const zk_fr* r, const zk_fr* s, uint8_t proof_out[192]);
 /* How that call deals a proof of this shape: one text line per piece, "ctx job lo n" with job 0 = B in G2, 1 = A, 2 = B in G1,
- * 3 = L, 4 = H and [lo, lo + n) the job's terms.  Returns the bytes written (0: bad arguments). */
-size_t zk_groth16_multi_plan(const zk_pk* pk, const zk_r1cs* r1cs, int n_ctx, char* out, size_t cap);
+ * 3 = L, 4 = H and [lo, lo + n) the job's terms; *written = the bytes put into out (ZK_ERR_ARG when cap is too small). */
+int zk_groth16_multi_plan(const zk_pk* pk, const zk_r1cs* r1cs, int n_ctx, char* out, size_t cap, size_t* written);
 /* Same with the assignment in host memory (instance then witness): SURVEY 8(d)'s "witness vector on host to 192 proof
  * bytes on host". */
 int zk_groth16_prove(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r1cs, const zk_fr* z_host,

@@ -188,6 +188,47 @@ class Proof:
         return out + b"\x00"                                                  # BatchLCProof.evals = None
 
 
+def proof_deserialize(data: bytes) -> Proof:
+    """CanonicalDeserialize of marlin::Proof (data_structures.rs:99-110; the inverse of Proof.serialize above): what a verifier on
+    the other side of the wire does with the prover's bytes.  Points go through GroupAffine::deserialize (curve and subgroup
+    checked), scalars must be canonical, nothing may trail."""
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        assert pos + n <= len(data), "truncated proof"
+        out = data[pos:pos + n]
+        pos += n
+        return out
+
+    def u64():
+        return int.from_bytes(take(8), "little")
+
+    def fr():
+        v = int.from_bytes(take(32), "little")
+        assert v < P, "non-canonical scalar"
+        return v
+    commitments = []
+    for _ in range(u64()):
+        rnd = []
+        for _ in range(u64()):
+            comm = O.g1_deserialize(take(48))
+            has = take(1)[0]
+            assert has in (0, 1)
+            rnd.append((comm, O.g1_deserialize(take(48)) if has else None, bool(has)))
+        commitments.append(rnd)
+    evaluations = [fr() for _ in range(u64())]
+    assert u64() == 3 and take(3) == b"\x00" * 3                   # three EmptyMessage
+    pc_proof = []
+    for _ in range(u64()):
+        w = O.g1_deserialize(take(48))
+        has = take(1)[0]
+        assert has in (0, 1)
+        pc_proof.append((w, fr() if has else None))
+    assert take(1) == b"\x00" and pos == len(data)                 # BatchLCProof.evals = None, then the end
+    return Proof(commitments, evaluations, pc_proof)
+
+
 def transcript_challenges(keys_ivk_bytes: bytes, index, public_input, commitments, evaluations=None):
     """The verifier's side of the Fiat-Shamir transcript; returns (challenges, fs) with fs positioned after gamma (the caller
     absorbs the evaluations and draws the opening challenge)."""

@@ -312,6 +312,51 @@ def g1_serialize(P) -> bytes:
     return fq_serialize(P[0], SW_POSITIVE_Y if _fq_gt_neg(P[1]) else 0)
 
 
+def fq_sqrt(a: int):
+    """A square root of a in Fq, or None (Tonelli-Shanks: q - 1 = 2^46 t; ff/src/fields/macros.rs:389-443 `sqrt` has the same
+    structure).  Either root: the caller picks by the sign flag."""
+    a %= Q_MOD
+    if a == 0:
+        return 0
+    if pow(a, (Q_MOD - 1) // 2, Q_MOD) != 1:
+        return None
+    s, t = 0, Q_MOD - 1
+    while t % 2 == 0:
+        s, t = s + 1, t // 2
+    z = 2
+    while pow(z, (Q_MOD - 1) // 2, Q_MOD) == 1:
+        z += 1
+    c, x, b, m = pow(z, t, Q_MOD), pow(a, (t + 1) // 2, Q_MOD), pow(a, t, Q_MOD), s
+    while b != 1:
+        i, bb = 0, b
+        while bb != 1:
+            bb, i = bb * bb % Q_MOD, i + 1
+        g = pow(c, 1 << (m - i - 1), Q_MOD)
+        x, c = x * g % Q_MOD, g * g % Q_MOD
+        b, m = b * c % Q_MOD, i
+    return x
+
+
+def g1_deserialize(b: bytes):
+    """GroupAffine::deserialize of a compressed G1 point (short_weierstrass_jacobian.rs:888-905 -> get_point_from_x, :171-183):
+    x in the low 377 bits, bit 7 of the last byte = "y is the greater root", bit 6 = infinity.  Raises on a non-canonical x, an x
+    off the curve or a point outside the prime-order subgroup, as the reference's Result does."""
+    assert len(b) == 48
+    flags = b[47] & (SW_INFINITY | SW_POSITIVE_Y)
+    if flags & SW_INFINITY:
+        assert flags == SW_INFINITY and not any(b[:47]) and not (b[47] & 0x3F), "infinity with a non-zero x"
+        return None
+    x = int.from_bytes(bytes(b[:47]) + bytes([b[47] & 0x3F]), "little")
+    assert x < Q_MOD, "non-canonical x"
+    y = fq_sqrt((x * x % Q_MOD * x + 1) % Q_MOD)              # y^2 = x^3 + 1 (curves/g1.rs:22-25)
+    assert y is not None, "x is not on the curve"
+    if _fq_gt_neg(y) != bool(flags & SW_POSITIVE_Y):
+        y = (Q_MOD - y) % Q_MOD
+    P = (x, y)
+    assert g1_mul(P, R_MOD) is None, "not in the prime-order subgroup"
+    return P
+
+
 def g2_serialize(P) -> bytes:
     """Compressed 96 B: c0 || c1-with-flags (quadratic_extension.rs:659-669)."""
     if P is None:

@@ -7,7 +7,7 @@ import pytest
 import marlin_ref as M
 import zkref as O
 import zk_mpc_amd.convert as cv
-from zk_mpc_amd import marlin as DM
+import pyseq.marlin_seq as DM
 from helpers import mont1
 
 pytestmark = pytest.mark.gpu

@@ -10,7 +10,7 @@ import zkref as O
 import zkref_c as OC
 import zk_mpc_amd as Z
 import zk_mpc_amd.convert as cv
-from zk_mpc_amd import mpc
+import pyseq.mpc_seq as mpc
 from helpers import td_mont, mont1
 from oracle_backend import additive_shares
 
@@ -270,7 +270,7 @@ def test_collaborative_marlin(n_parties, n):
     and opening witnesses equal the single-prover run on the summed witness and summed randomness; the opened evaluations
     satisfy the verifier's sum-check equations."""
     import marlin_ref as M
-    from zk_mpc_amd import marlin as DM
+    import pyseq.marlin_seq as DM
     rng = O.Prng(1100 + n)
     r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
     sq, zz = M.pad_and_square(r1cs, z)
@@ -338,7 +338,7 @@ def test_collaborative_marlin_spdz(n_parties, n):
     """Marlin over SPDZ shares (two lanes, MAC-checked opens): the same revealed outputs as the additive run above on the
     same inputs, and a corrupted MAC share of the witness is detected."""
     import marlin_ref as M
-    from zk_mpc_amd import marlin as DM
+    import pyseq.marlin_seq as DM
     rng = O.Prng(1200 + n)
     r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
     sq, zz = M.pad_and_square(r1cs, z)
@@ -593,7 +593,7 @@ def test_collaborative_marlin_full_proof(n_parties, n, spdz, mask_dev):
     inputs with the summed randomness; the oracle's Marlin::verify accepts them and rejects a wrong public input."""
     import marlin_full_ref as MF
     import marlin_ref as M
-    from zk_mpc_amd import marlin as DM
+    import pyseq.marlin_seq as DM
     from zk_mpc_amd.api import Rng
     rng = O.Prng(7700 + n + n_parties)
     r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
@@ -652,7 +652,7 @@ def test_native_collaborative_marlin_with_real_triples_and_tampering(spdz):
     party that lies about one MAC share of its assignment makes every party's call fail with MacCheckError."""
     import marlin_full_ref as MF
     import marlin_ref as M
-    from zk_mpc_amd import marlin as DM
+    import pyseq.marlin_seq as DM
     from zk_mpc_amd.api import Rng
     n_parties, n = 3, 11
     rng = O.Prng(4242 + spdz)
@@ -714,7 +714,7 @@ def _marlin_proc_worker(rank, world, port, spdz, q):
             sys.path.insert(0, p)
     import torch.distributed as dist
     import marlin_ref as M
-    from zk_mpc_amd import marlin as DM
+    import pyseq.marlin_seq as DM
     from zk_mpc_amd.api import Rng
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

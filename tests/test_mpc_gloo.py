@@ -28,7 +28,7 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     import zkref as O
     import zk_mpc_amd.convert as cv
-    from zk_mpc_amd import mpc
+    import pyseq.mpc_seq as mpc
     from oracle_backend import OracleBackend, OraclePk, additive_shares
 
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)

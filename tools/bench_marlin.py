@@ -13,7 +13,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from zk_mpc_amd import marlin as DM  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import pyseq.marlin_seq as DM  # noqa: E402  (the round-by-round Python sequence: test infrastructure)
 from zk_mpc_amd.api import Context  # noqa: E402
 from zk_mpc_amd.marlin import HostField  # noqa: E402
 

@@ -11,7 +11,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 import zk_mpc_amd as Z  # noqa: E402
 import zk_mpc_amd.convert as cv  # noqa: E402
-from zk_mpc_amd import mpc  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import pyseq.mpc_seq as mpc  # noqa: E402  (the Python sequences: test infrastructure)
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29544")

@@ -166,7 +166,7 @@ PROTOTYPES = {
     "zk_groth16_hint_next_dev": (_I, [_P, _P]),
     "zk_groth16_prove_dev": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "zk_groth16_prove_multi": (_I, [_P, _P, _P, _I, _P, _P, _P, _P]),
-    "zk_groth16_multi_plan": (_SZ, [_P, _P, _I, C.c_char_p, _SZ]),
+    "zk_groth16_multi_plan": (_I, [_P, _P, _I, C.c_char_p, _SZ, C.POINTER(_SZ)]),
     "zk_groth16_prove": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "zk_groth16_prove_queued": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "zk_host_alloc": (_I, [_P, _SZ, C.POINTER(_P)]),

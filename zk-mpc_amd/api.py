@@ -695,8 +695,9 @@ class Context:
     def multi_plan(self, pk: "ProvingKey", r1cs: "R1cs", n_ctx: int):
         """[(ctx, job, lo, n)]: how zk_groth16_prove_multi deals this proof over n_ctx contexts."""
         buf = C.create_string_buffer(1 << 16)
-        k = self.lib.zk_groth16_multi_plan(pk.h, r1cs.h, n_ctx, buf, len(buf))
-        return [tuple(int(x) for x in line.split()) for line in buf.raw[:k].decode().splitlines()]
+        k = C.c_size_t(0)
+        self._ck(self.lib.zk_groth16_multi_plan(pk.h, r1cs.h, n_ctx, buf, len(buf), C.byref(k)))
+        return [tuple(int(x) for x in line.split()) for line in buf.raw[:k.value].decode().splitlines()]
 
     def create_proof(self, pk: "ProvingKey", r1cs: "R1cs", z_mont: np.ndarray, r_mont4, s_mont4) -> bytes:
         z = np.ascontiguousarray(z_mont, dtype=np.uint64)

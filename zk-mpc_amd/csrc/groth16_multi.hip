@@ -56,11 +56,8 @@ std::vector<std::vector<Piece>> deal(const size_t len[5], int n_ctx) {
 
 }  // namespace
 
-extern "C" int zk_groth16_prove_multi(zk_ctx* const* ctxs, const zk_pk* const* pks, const zk_r1cs* const* rs, int n_ctx, const void* z_dev0,
-                                      const zk_fr* r_, const zk_fr* s_, uint8_t proof[192]) {
-    zk_ctx* ctx0 = (ctxs && n_ctx > 0) ? ctxs[0] : nullptr;
-    ZK_API_BEGIN(ctx0)
-    if (!ctxs || !pks || !rs || n_ctx < 1 || n_ctx > 64 || !z_dev0 || !r_ || !s_ || !proof) return ZK_ERR_ARG;
+static int prove_multi(zk_ctx* ctx0, zk_ctx* const* ctxs, const zk_pk* const* pks, const zk_r1cs* const* rs, int n_ctx, const void* z_dev0,
+                       const zk_fr* r_, const zk_fr* s_, uint8_t proof[192]) {
     for (int d = 0; d < n_ctx; d++) {
         if (!ctxs[d] || !pks[d] || !rs[d]) return ZK_ERR_ARG;
         for (int e = 0; e < d; e++)
@@ -126,11 +123,19 @@ extern "C" int zk_groth16_prove_multi(zk_ctx* const* ctxs, const zk_pk* const* p
     };
     {
         std::vector<std::thread> th;
-        for (int d = 1; d < n_ctx; d++)
-            th.emplace_back([&, d] {
-                try { rc[d] = run(d); } catch (...) { rc[d] = ZK_ERR_STATE; ctxs[d]->last_error = "zk_groth16_prove_multi: exception on a helper thread"; }
-            });
+        th.reserve(n_ctx);
+        for (int d = 1; d < n_ctx; d++) {
+            try {
+                th.emplace_back([&, d] {
+                    try { rc[d] = run(d); } catch (...) { rc[d] = ZK_ERR_STATE; ctxs[d]->last_error = "zk_groth16_prove_multi: exception on a helper thread"; }
+                });
+            } catch (...) {                      // no thread to be had: this context's share runs here, after context 0's
+                rc[d] = -1000;
+            }
+        }
         try { rc[0] = run(0); } catch (...) { rc[0] = ZK_ERR_STATE; }
+        for (int d = 1; d < n_ctx; d++)
+            if (rc[d] == -1000) { try { rc[d] = run(d); } catch (...) { rc[d] = ZK_ERR_STATE; } }
         for (auto& t : th) t.join();
     }
     for (int d = 0; d < n_ctx; d++)
@@ -162,23 +167,32 @@ extern "C" int zk_groth16_prove_multi(zk_ctx* const* ctxs, const zk_pk* const* p
     tail.abc_ready(a_sum, b1_sum, b2_sum);
     tail.finish(h_sum, l_sum, proof);
     return ZK_OK;
+}
+
+extern "C" int zk_groth16_prove_multi(zk_ctx* const* ctxs, const zk_pk* const* pks, const zk_r1cs* const* rs, int n_ctx, const void* z_dev0,
+                                      const zk_fr* r_, const zk_fr* s_, uint8_t proof[192]) {
+    ZK_API_BEGIN_NOCTX
+    if (!ctxs || !pks || !rs || n_ctx < 1 || n_ctx > 64 || !ctxs[0] || !z_dev0 || !r_ || !s_ || !proof) return ZK_ERR_ARG;
+    // the body runs under context 0's guard: its device current, its error string, the exception barrier
+    return zk_api_guarded(ctxs[0], [&]() -> int { return prove_multi(ctxs[0], ctxs, pks, rs, n_ctx, z_dev0, r_, s_, proof); });
     ZK_API_END
 }
 
 // How zk_groth16_prove_multi would deal a proof of this shape over n_ctx contexts: one line per piece, "ctx job lo n" (job 0 = B in
-// G2, 1 = A, 2 = B in G1, 3 = L, 4 = H).  Diagnostics / tests; returns the number of bytes written (excluding the terminator).
-extern "C" size_t zk_groth16_multi_plan(const zk_pk* pk, const zk_r1cs* r, int n_ctx, char* out, size_t cap) {
-    if (!pk || !r || n_ctx < 1 || n_ctx > 64 || !out || !cap) return 0;
+// G2, 1 = A, 2 = B in G1, 3 = L, 4 = H).  Diagnostics / tests; *written = the bytes put into out (excluding the terminator).
+extern "C" int zk_groth16_multi_plan(const zk_pk* pk, const zk_r1cs* r, int n_ctx, char* out, size_t cap, size_t* written) {
+    ZK_API_BEGIN_NOCTX
+    if (!pk || !r || n_ctx < 1 || n_ctx > 64 || !out || !cap || !written) return ZK_ERR_ARG;
     const size_t D = (size_t)1 << r->log_d, nvars = (r->ni - 1) + r->nw;
     const size_t len[5] = {nvars, nvars, nvars, r->nw, std::min(pk->h->n, D)};
     std::string s;
-    try {
-        const auto plan = deal(len, n_ctx);
-        for (int d = 0; d < n_ctx; d++)
-            for (const Piece& p : plan[d]) s += std::to_string(d) + " " + std::to_string(p.job) + " " + std::to_string(p.lo) + " " + std::to_string(p.n) + "\n";
-    } catch (...) { return 0; }
-    const size_t n = std::min(s.size(), cap - 1);
-    memcpy(out, s.data(), n);
-    out[n] = 0;
-    return n;
+    const auto plan = deal(len, n_ctx);
+    for (int d = 0; d < n_ctx; d++)
+        for (const Piece& p : plan[d]) s += std::to_string(d) + " " + std::to_string(p.job) + " " + std::to_string(p.lo) + " " + std::to_string(p.n) + "\n";
+    if (s.size() + 1 > cap) return ZK_ERR_ARG;
+    memcpy(out, s.data(), s.size());
+    out[s.size()] = 0;
+    *written = s.size();
+    return ZK_OK;
+    ZK_API_END
 }
