@@ -16,6 +16,7 @@ from zk_mpc_amd import convert as cv
 from zk_mpc_amd.api import Context, DevBuf
 from zk_mpc_amd.marlin import *          # noqa: F401,F403
 from zk_mpc_amd.marlin import (_fr_bytes, _g1_to_bytes, _log2, _next_pow2)      # noqa: F401
+from zk_mpc_amd.marlin import _FR_TWO_ADICITY, _FR_TWO_ADIC_ROOT_MONT      # noqa: F401
 
 
 class ProverState:
@@ -438,7 +439,7 @@ def prove(keys: IndexKeys, assignment_dev: DevBuf, zk_rng, mask_on_device: bool 
     randomness; drawn one by one from a host generator they cost more than the whole proof at 2^20 (0.4 s of scalar ChaCha).
     With this flag they are sampled on the device (zk_fr_random_dev, ChaCha20 under a 32-byte key taken from zk_rng): the
     same distribution, not the same stream -- proofs then differ from a reference run with the same seed, and verify alike."""
-    from .api import Rng
+    from zk_mpc_amd.api import Rng
     index, srs = keys.index, keys.srs
     ctx = index.ctx
     m, ival = HostField.m, HostField.i
