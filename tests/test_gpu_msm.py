@@ -367,7 +367,7 @@ def _adversarial_sets(rs, n):
     minus_one = cv.fr_to_mont([O.R_MOD - 1])[0]
     pm = np.tile(one, (n, 1))
     pm[pick < 0.5] = minus_one                               # +1 / -1: both signs of one bucket
-    return {"uniform": a, "all_zero": np.zeros((n, 4), dtype=np.uint64), "all_equal": np.tile(a[12345:12346], (n, 1)),
+    return {"uniform": a, "all_zero": np.zeros((n, 4), dtype=np.uint64), "all_equal": np.tile(a[12345 % n:12345 % n + 1], (n, 1)),
             "all_one": np.tile(one, (n, 1)), "plus_minus_one": pm, "zero_one_heavy": z01, "small_values": np.ascontiguousarray(sv)}
 
 
@@ -389,6 +389,7 @@ def test_msm_adversarial_scalar_sets(ctx, group, log_n):
     pre = ctx.fixed_base(dk.ptr, n, group, one)
     pre.precompute()
     for name, arr in _adversarial_sets(rs, n).items():
+        assert arr.shape == (n, 4), name
         ds = ctx.upload(np.ascontiguousarray(arr))
         want = mul(_mont_inner_product(ctx, dk.ptr, ds.ptr, n))
         assert to_aff(ctx.msm_dev(plain, 0, ds.ptr, n)) == want, (name, "plain table")

@@ -14,9 +14,8 @@
 //   3. k_scatter  : counting sort of (point index, sign) by bucket.  Order inside a bucket is
 //                   whatever the atomics give: the group is commutative and the result is reduced
 //                   to its canonical affine form, so the output bits do not depend on it.
-//   1-3 for a table with window multiples (ONE bucket set for all digits): k_digit_keys writes (bucket, entry)
-//                   pairs, rocPRIM's radix sort orders them (msm_sort.hip), k_offs_from_sorted reads the
-//                   bucket boundaries off the sorted keys -- no global atomics at all.
+//   1-3 for MSMs of >= 2^16 digits: the bucket sort of msm_sort.hip (bins, then per-bin LDS counting; zero digits never become
+//                   pairs; no global atomics per digit) over ONE set of all buckets; the segment length is fitted to the input.
 //   4. k_accum    : one thread per bucket: gather its points (96 B / 192 B random reads), mixed
 //                   XYZZ additions (8M+2S in Fq / Fq2).  This is the dominant kernel; it is bound by
 //                   the integer ALU (v_mad_u64_u32), not by HBM.
@@ -128,9 +127,6 @@ k_scatter(const uint32_t* dig, size_t n, uint32_t W, uint32_t NB, const uint32_t
     }
 }
 
-__global__ void __launch_bounds__(256) k_counts_from_offs(const uint32_t* __restrict__ offs, uint32_t NB, uint32_t* __restrict__ counts) {
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < NB; b += gridDim.x * blockDim.x) counts[b] = offs[b + 1] - offs[b];
-}
 
 // ---- segments -------------------------------------------------------------------------------
 // A bucket with cnt points is cut into max(1, ceil(cnt / SEG)) segments.  Single-segment buckets
@@ -181,86 +177,6 @@ k_scan(const uint32_t* counts, uint32_t* offs, uint32_t* seg_local, uint32_t* wi
     }
 }
 
-// The same scan for a big bucket set (merged mode: one window of 2^19 buckets), over several blocks: chunk totals,
-// a scan of the totals, then the scan inside each chunk.  One 1024-thread block walking 2^19 counters alone took
-// 1.2 ms, on the critical path in front of the first accumulate kernel.
-constexpr uint32_t SCAN_T = 512;                 // threads per block of the multi-block scan
-constexpr uint32_t SCAN_CHUNK = SCAN_T * 8;      // 8 consecutive counters per thread
-
-__device__ __forceinline__ uint32_t segs_of(uint32_t c, uint32_t seg) { return c ? (c + seg - 1) / seg : 1; }
-
-// block-wide inclusive scan of one value pair per thread (SCAN_T threads)
-__device__ __forceinline__ void block_scan2(uint32_t* part, uint32_t* part2, uint32_t tid) {
-    __syncthreads();
-    for (uint32_t d = 1; d < SCAN_T; d <<= 1) {
-        uint32_t v = tid >= d ? part[tid - d] : 0, v2 = tid >= d ? part2[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        part2[tid] += v2;
-        __syncthreads();
-    }
-}
-
-__global__ void __launch_bounds__(SCAN_T)
-k_scan_sums(const uint32_t* counts, uint32_t NB, const uint32_t* segp, uint32_t nchunks, uint32_t* sums) {
-    __shared__ uint32_t part[SCAN_T], part2[SCAN_T];
-    const uint32_t seg = *segp;
-    const uint32_t w = blockIdx.x / nchunks, ch = blockIdx.x % nchunks, tid = threadIdx.x;
-    uint32_t s = 0, s2 = 0;
-    for (uint32_t k = 0; k < 8; k++) {
-        uint32_t b = ch * SCAN_CHUNK + k * SCAN_T + tid;           // totals only: any order, so read coalesced
-        if (b < NB) { uint32_t c = counts[(size_t)w * NB + b]; s += c; s2 += segs_of(c, seg); }
-    }
-    part[tid] = s;
-    part2[tid] = s2;
-    block_scan2(part, part2, tid);
-    if (tid == SCAN_T - 1) { sums[2 * blockIdx.x] = part[SCAN_T - 1]; sums[2 * blockIdx.x + 1] = part2[SCAN_T - 1]; }
-}
-
-// one block per window: exclusive scan of the chunk totals in place (nchunks <= SCAN_T)
-__global__ void __launch_bounds__(SCAN_T) k_scan_tops(uint32_t* sums, uint32_t nchunks) {
-    __shared__ uint32_t part[SCAN_T], part2[SCAN_T];
-    const uint32_t w = blockIdx.x, tid = threadIdx.x;
-    uint32_t v = tid < nchunks ? sums[2 * ((size_t)w * nchunks + tid)] : 0, v2 = tid < nchunks ? sums[2 * ((size_t)w * nchunks + tid) + 1] : 0;
-    part[tid] = v;
-    part2[tid] = v2;
-    block_scan2(part, part2, tid);
-    if (tid < nchunks) { sums[2 * ((size_t)w * nchunks + tid)] = part[tid] - v; sums[2 * ((size_t)w * nchunks + tid) + 1] = part2[tid] - v2; }
-}
-
-__global__ void __launch_bounds__(SCAN_T)
-k_scan_fill(const uint32_t* counts, const uint32_t* sums, uint32_t* offs, uint32_t* seg_local, uint32_t* win_segs, uint32_t NB,
-            const uint32_t* segp, uint32_t nchunks) {
-    __shared__ uint32_t part[SCAN_T], part2[SCAN_T];
-    const uint32_t seg = *segp;
-    const uint32_t w = blockIdx.x / nchunks, ch = blockIdx.x % nchunks, tid = threadIdx.x;
-    const uint32_t lo = ch * SCAN_CHUNK + tid * 8;
-    uint32_t c[8], s = 0, s2 = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        c[k] = lo + k < NB ? counts[(size_t)w * NB + lo + k] : 0;
-        s += c[k];
-        s2 += lo + k < NB ? segs_of(c[k], seg) : 0;
-    }
-    part[tid] = s;
-    part2[tid] = s2;
-    block_scan2(part, part2, tid);
-    uint32_t run = sums[2 * blockIdx.x] + part[tid] - s, run2 = sums[2 * blockIdx.x + 1] + part2[tid] - s2;
-#pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        if (lo + k < NB) {
-            offs[(size_t)w * (NB + 1) + lo + k] = run;
-            seg_local[(size_t)w * NB + lo + k] = run2;
-            run += c[k];
-            run2 += segs_of(c[k], seg);
-        }
-    }
-    if (ch == nchunks - 1 && tid == SCAN_T - 1) {
-        offs[(size_t)w * (NB + 1) + NB] = sums[2 * blockIdx.x] + part[SCAN_T - 1];
-        win_segs[w] = sums[2 * blockIdx.x + 1] + part2[SCAN_T - 1];
-    }
-}
-
 // ctr[0] = entries of the heavy list, ctr[1] = heavy segments, ctr[2] = total segments, ctr[3] = the segment length (written by the
 // sort: msm_sort.hip::k_scan_bins, or copied from the host's plan), ctr[4] = non-zero digits, ctr[5] = entries of the second-level
 // heavy list, ctr[6] = group slots handed out; hist[len] = #segments of that length.
@@ -271,7 +187,7 @@ k_scan_fill(const uint32_t* counts, const uint32_t* sums, uint32_t* offs, uint32
 // that met a 15 000-segment bucket used to write them alone: 0.3 ms).
 constexpr uint32_t FOLD_GROUP = 256;
 constexpr uint32_t FOLD_LIGHT = 8;      // up to this many partial sums: one lane adds them; more: a 64-lane block (strided sums + an LDS tree)
-struct HeavyFill { uint32_t base, start, cnt, dst0; };
+struct HeavyFill { uint32_t base, rest, start, cnt, dst0; };      // segment 0 at desc[base], segments 1.. at desc[rest ...]
 
 __global__ void __launch_bounds__(256)
 k_build_segs(const uint32_t* offs, const uint32_t* seg_local, const uint32_t* win_segs, size_t n, uint32_t W, uint32_t NB,
@@ -280,15 +196,21 @@ k_build_segs(const uint32_t* offs, const uint32_t* seg_local, const uint32_t* wi
     __shared__ HeavyFill q[64];
     __shared__ uint32_t qn;
     const uint32_t seg = ctr[3];
+    // seg_local == NULL (one bucket set, after the bucket sort): no scan of segment counts at all -- bucket t's first segment is
+    // descriptor t, the further segments of a split bucket are appended behind the last bucket (ctr[7] hands out the places), and
+    // k_len_scan closes the count.  Four kernels fewer on the sort's chain, the front of every proof.
+    const bool flat = seg_local == nullptr;
     for (uint32_t i = threadIdx.x; i <= seg; i += blockDim.x) lh[i] = 0;
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
     const size_t total = (size_t)W * NB;
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         uint32_t w = (uint32_t)(t / NB), b = (uint32_t)(t - (size_t)w * NB);
-        uint32_t base = 0;
-        for (uint32_t k = 0; k < w; k++) base += win_segs[k];
-        base += seg_local[t];
+        uint32_t base = (uint32_t)t;
+        if (!flat) {
+            base = seg_local[t];
+            for (uint32_t k = 0; k < w; k++) base += win_segs[k];
+        }
         uint32_t lo = offs[(size_t)w * (NB + 1) + b], hi = offs[(size_t)w * (NB + 1) + b + 1];
         uint32_t cnt = hi - lo, start = (uint32_t)(w * n) + lo;
         if (cnt <= seg) {
@@ -307,30 +229,34 @@ k_build_segs(const uint32_t* offs, const uint32_t* seg_local, const uint32_t* wi
             }
             atomicAdd(&lh[seg], ns - 1);
             atomicAdd(&lh[cnt - (ns - 1) * seg], 1u);
+            const uint32_t rest = flat ? (uint32_t)total + atomicAdd(&ctr[7], ns - 1) : base + 1;
             const uint32_t slot = atomicAdd(&qn, 1u);
             if (slot < 64) {
-                q[slot] = HeavyFill{base, start, cnt, dst0};
+                q[slot] = HeavyFill{base, rest, start, cnt, dst0};
             } else {                     // more split buckets than the block's queue holds: this lane writes its own
-                for (uint32_t j = 0; j < ns; j++) desc[base + j] = SegDesc{start + j * seg, min(seg, cnt - j * seg), dst0 + j};
+                for (uint32_t j = 0; j < ns; j++) desc[j ? rest + j - 1 : base] = SegDesc{start + j * seg, min(seg, cnt - j * seg), dst0 + j};
             }
         }
-        if (t == total - 1) ctr[2] = base + (cnt <= seg ? 1 : (cnt + seg - 1) / seg);
+        if (!flat && t == total - 1) ctr[2] = base + (cnt <= seg ? 1 : (cnt + seg - 1) / seg);
     }
     __syncthreads();
     const uint32_t nq = min(qn, 64u);
     for (uint32_t e = 0; e < nq; e++) {
         const HeavyFill f = q[e];
         const uint32_t ns = (f.cnt + seg - 1) / seg;
-        for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x) desc[f.base + j] = SegDesc{f.start + j * seg, min(seg, f.cnt - j * seg), f.dst0 + j};
+        for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x)
+            desc[j ? f.rest + j - 1 : f.base] = SegDesc{f.start + j * seg, min(seg, f.cnt - j * seg), f.dst0 + j};
     }
     for (uint32_t i = threadIdx.x; i <= seg; i += blockDim.x)
         if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
 // bin_start[len] for a DESCENDING order by length (longest segments first); one block.
-__global__ void __launch_bounds__(512) k_len_scan(const uint32_t* hist, uint32_t* bin_start, uint32_t* bin_cursor, const uint32_t* ctr) {
+// flat_buckets != 0 (k_build_segs' flat mode): the segment count is closed here, buckets + appended segments.
+__global__ void __launch_bounds__(512) k_len_scan(const uint32_t* hist, uint32_t* bin_start, uint32_t* bin_cursor, uint32_t* ctr, uint32_t flat_buckets) {
     __shared__ uint32_t part[512];
     const uint32_t seg = ctr[3];
+    if (flat_buckets && threadIdx.x == 0) ctr[2] = flat_buckets + ctr[7];
     const uint32_t tid = threadIdx.x, nb = seg + 1;
     const uint32_t per = (nb + 511) / 512;
     // position p = seg - len  (p = 0 is the longest)
@@ -717,26 +643,15 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     tm->begin(g1 ? "msm_g1.sort" : "msm_g2.sort");
     ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 8 + 3 * (size_t)(seg + 1)) * 4, st));
     const uint32_t grp_base = (uint32_t)(nbuck + job->max_heavy_segs);       // where the group sums of two-level buckets live in `sums`
-    auto scans = [&](uint32_t Wx, uint32_t NBx) -> int {
-        if (NBx <= 65536) {
-            hipLaunchKernelGGL(k_scan, Wx, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NBx, (const uint32_t*)(ctr + 3));
-        } else {
-            const uint32_t nchunks = (uint32_t)((NBx + SCAN_CHUNK - 1) / SCAN_CHUNK);
-            if (nchunks > SCAN_T) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: bucket set too large for the two-level scan");
-            uint32_t* sums;
-            char nm2[64];
-            snprintf(nm2, sizeof nm2, "msm_scan_sums.%d", job->slot);
-            ZK_TRY(zk_scratch(ctx, nm2, (size_t)Wx * nchunks * 8, (void**)&sums));
-            hipLaunchKernelGGL(k_scan_sums, Wx * nchunks, SCAN_T, 0, st, b.counts, NBx, (const uint32_t*)(ctr + 3), nchunks, sums);
-            hipLaunchKernelGGL(k_scan_tops, Wx, SCAN_T, 0, st, sums, nchunks);
-            hipLaunchKernelGGL(k_scan_fill, Wx * nchunks, SCAN_T, 0, st, b.counts, (const uint32_t*)sums, b.offs, b.seg_local, win_segs,
-                               NBx, (const uint32_t*)(ctr + 3), nchunks);
-        }
+    auto scans = [&](uint32_t Wx, uint32_t NBx) -> int {      // counting-sort path only: one block per window
+        if (NBx > 65536) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: a bucket set of more than 2^16 buckets needs the bucket sort (>= 2^16 digits)");
+        hipLaunchKernelGGL(k_scan, Wx, 1024, 0, st, b.counts, b.offs, b.seg_local, win_segs, NBx, (const uint32_t*)(ctr + 3));
         return ZK_OK;
     };
     // The bucket sort (msm_sort.hip: no global atomics per digit, zero digits dropped, the segment length fitted to the input) for
     // every MSM with at least 2^16 digits; it sees ONE set of Wb*NB buckets (bucket ids w*NB + b, as the reduce phase numbers
     // them).  Small MSMs keep the counting sort with per-window offsets: a handful of short kernels.
+    uint32_t flat_buckets = 0;
     ZkGroupArgs ga;
     ga.scalars = job->scalars; ga.n = n; ga.wo = wo; ga.bias = bias; ga.W = W; ga.NB = NB; ga.merged = merged != 0;
     ga.n_tab = job->n_tab; ga.tab_off = job->tab_off; ga.NBt = (uint32_t)nbuck;
@@ -745,10 +660,9 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     if ((size_t)W * n >= 65536 && zk_msm_group_supported(ga)) {
         const uint32_t NBt = (uint32_t)nbuck;
         ZK_TRY(zk_msm_group(ctx, st, job->slot, ga));
-        hipLaunchKernelGGL(k_counts_from_offs, zk_grid(NBt, 256), 256, 0, st, (const uint32_t*)b.offs, NBt, b.counts);
-        ZK_TRY(scans(1, NBt));                                 // rewrites offs (same values) and produces the segment counts
-        hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
+        hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, (const uint32_t*)nullptr, win_segs,
                            (size_t)0, 1u, NBt, b.desc, b.heavy, b.heavy2, ctr, hist, grp_base);
+        flat_buckets = NBt;
     } else {
         ZK_HIP(ctx, hipMemsetAsync(b.counts, 0, nbuck * 4, st));
         ZK_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctr + 3), (int)seg, 1, st));             // the host's plan is the segment length
@@ -759,7 +673,7 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
         hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
                            merged ? (size_t)0 : n, Wb, NB, b.desc, b.heavy, b.heavy2, ctr, hist, grp_base);
     }
-    hipLaunchKernelGGL(k_len_scan, 1, 512, 0, st, hist, bin_start, bin_cursor, (const uint32_t*)ctr);
+    hipLaunchKernelGGL(k_len_scan, 1, 512, 0, st, hist, bin_start, bin_cursor, ctr, flat_buckets);
     hipLaunchKernelGGL(k_order, 512, 256, (seg + 1) * 4, st, b.desc, ctr, bin_cursor, b.order);
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
@@ -810,8 +724,10 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
     job->timers.push_back(tm);
     tm->begin(g1 ? "msm_g1.reduce" : "msm_g2.reduce");
-    const unsigned light_blocks = (unsigned)std::min<size_t>((job->max_heavy + 63) / 64, 512);
-    const unsigned heavy_blocks = (unsigned)std::min<size_t>(job->max_heavy, 1024);
+    // (a small grid: every block of the chain waits for a wave slot beside the running accumulate kernel, and a uniform input has
+    // nothing to fold at all; the blocks stride over the heavy list)
+    const unsigned light_blocks = (unsigned)std::min<size_t>((job->max_heavy + 63) / 64, 128);
+    const unsigned heavy_blocks = (unsigned)std::min<size_t>(job->max_heavy, 256);
     if constexpr (F::WORDS != 12) {
         // G2: the same chain on lane pairs (msm_g2pair.hip)
         ZkG2PairReduce a{job->heavy, job->heavy2, job->ctr, b.fold_done, b.sums, b.rowP, b.colP, b.bits, job->log_nb, job->Wb, 2 * light_blocks, heavy_blocks};
