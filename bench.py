@@ -6,11 +6,14 @@
 N = 1: local (non-MPC) prove of the SURVEY 8(d) config-2 workload: mul-chain R1CS with
        n = 2^20 - 2 constraints (QAP domain 2^20), proving key resident on the device,
        witness resident on the device when the timed region starts.
-N > 1: N-party collaborative prove (additive shares, honest backend), one party per GPU,
-       launched by torch.distributed.run; the two Beaver opens are all-gathers over RCCL.
-       Per-GPU work is fixed (every party runs the full-size NTTs/MSMs on its shares), so
-       scaling is "weak": value = N * n * K / T (constraint-shares proved per second);
-       `proof_constraints_per_s` = n * K / T is the per-proof rate.
+N > 1: N-party collaborative prove (additive shares, honest backend; --spdz: the malicious one), one
+       party per GPU, one process per party.  Launched by torch.distributed.run -- or by nobody: without
+       a launcher this script starts the N ranks itself as a child process.  The two Beaver opens are
+       collectives over RCCL.  Per-GPU work is fixed (every party runs the full-size NTTs / MSMs on its
+       shares: "weak"); the parties jointly produce ONE proof, so value = n * K / T.  Before anything is
+       timed both transports carry tiny opens that are checked against the host-side sum.
+--one-prover: ONE local prover whose five MSMs are spread over N devices inside this process
+       (zk_groth16_prove_multi): total work fixed, "strong".
 
 A step = one proof.  Timing: W untimed proofs, then exactly K proofs bracketed by barrier +
 device synchronisation; max over ranks.  One JSON line on rank 0.
@@ -1127,6 +1130,14 @@ def main():
             "roofline": roof,
             "hbm_in_use_gb": hbm_in_use_gb(),
         }
+        try:      # which tables carry window multiples, in which layout -- or why not (a skipped table costs 16 digits per scalar instead of 13)
+            wm = {}
+            for which in ("a", "b_g1", "b_g2", "h", "l"):
+                qb = pk_bases(ctx, pk, which)
+                wm[which] = {"window_bits": int(ctx.lib.zk_bases_window_bits(qb.h)), "layout_or_reason": qb.precompute_note()}
+            out["window_multiples"] = wm
+        except Exception as e:
+            out["window_multiples"] = {"error": repr(e)}
         if dist is not None:
             out["value_note"] = ("value = constraints of ONE proof x proofs / time: the N parties jointly produce one proof, so the job's "
                                  "output does not grow with N although every party runs the full-size prover on its shares (per-GPU work "

@@ -84,14 +84,16 @@ def field(struct, p, L, W, internal=(), raw=(), LR=None):
     return "\n".join(out)
 
 
-def sub_offset(p, L, K, j):
+def sub_offset(p, L, K, j, top_bits=29):
     """K p written with limbs 0..L-2 in [j 2^29, (j + 1) 2^29) and whatever is left in the top limb: a + offset - b needs no
-    borrow for any b whose limbs 0..L-2 are below j 2^29 (and whose top limb is below the offset's)."""
+    borrow for any b whose limbs 0..L-2 are below j 2^29 (and whose top limb is below the offset's).  top_bits: the width the
+    caller's arithmetic allows the top limb (29 for the Fr butterflies; 31 only where the caller has shown its sums keep inside
+    32 bits: OFF3 of the 753-bit field)."""
     t = K * p - sum((j << B) << (B * i) for i in range(L - 1))
     assert t >= 0
     lo = [((t >> (B * i)) & ((1 << B) - 1)) + (j << B) for i in range(L - 1)]
     c = lo + [t >> (B * (L - 1))]
-    assert sum(v << (B * i) for i, v in enumerate(c)) == K * p and c[-1] < (1 << 31)
+    assert sum(v << (B * i) for i, v in enumerate(c)) == K * p and c[-1] < (1 << top_bits), (K, hex(c[-1]))
     return c
 
 
@@ -118,7 +120,7 @@ def fq753_lazy():
     d = (q >> (B * (L - 1))) + 1
     out.append("    static constexpr uint32_t MQ = %du;      // floor(2^56 / ((q >> 725) + 1)): k = (top limb * MQ) >> 56 <= floor(a / q)" % ((1 << 56) // d))
     for name, K in (("OFF2", 2), ("OFF3", 3)):
-        c = sub_offset(q, L, K, 1)
+        c = sub_offset(q, L, K, 1, top_bits=31)
         out.append("    static constexpr uint32_t %s[%d] = {%s};  // %d q, limbs 0..24 in [2^29, 2^30)" % (
             name, L, ", ".join("0x%08xu" % v for v in c), K))
     out.append("};")
