@@ -676,60 +676,93 @@ def comm_report(ctx, dist, party, torch):
 def preflight_opens(ctx, dist, party, torch, transport: str):
     """Before the timed loop of an N > 1 run: tiny opens through every transport this launch can use, each compared with the
     host-side sum mod r of the vectors every rank is known to hold.  Sizes: 1 (fewer elements than parties: padding only), a
-    size not divisible by the party count, and 4096.  Raises with rank, transport, pattern and size on the first difference --
-    a wrong collective must not become a timed number.  mpc-net/src/multi.rs:469-525 semantics: every party ends up with all
-    payloads in party order; here already summed."""
+    size not divisible by the party count, and 4096.  mpc-net/src/multi.rs:469-525 semantics: every party ends up with all
+    payloads in party order; here already summed.
+    The ranks AGREE on every verdict (one small all-reduce per check) so that nobody leaves a collective sequence alone.  A wrong
+    result on the transport the timed proofs use raises on every rank -- a wrong collective must not become a timed number; a
+    failure of the OTHER transport (the one this run does not time) is recorded in the line with rank, pattern and size, and the
+    run goes on: the first multi-GPU run must not lose its number to a path it does not measure."""
     import zk_mpc_amd.convert as cv
     rank, P = dist.get_rank(), dist.get_world_size()
     report = []
+    dev = "cuda" if transport == "nccl" else "cpu"
+
+    def agree(ok: bool) -> bool:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
 
     def vec(p, n):        # party p's vector: canonical residues p * 2^200 + i * (p + 3) + 1, in the library's Montgomery form
         return cv.fr_to_mont([((p << 200) + i * (p + 3) + 1) % cv.R_MOD for i in range(n)]) if n else np.zeros((0, 4), np.uint64)
 
     def check(label, pattern, n, fn):
-        mine = ctx.upload(np.ascontiguousarray(vec(rank, n)))
-        out = ctx.alloc(max(n, 1) * 32)
-        fn(mine.ptr, out.ptr, n)
-        ctx.sync()
-        got = cv.fr_from_mont(ctx.download(out, (n, 4)))
-        want = [sum(((p << 200) + i * (p + 3) + 1) for p in range(P)) % cv.R_MOD for i in range(n)]
-        mine.free(); out.free()
-        if list(got) != want:
-            bad = next(i for i in range(n) if got[i] != want[i])
-            raise RuntimeError("pre-flight open FAILED on rank %d: transport %s, pattern %s, n = %d, first wrong element %d"
-                               % (rank, label, pattern, n, bad))
-        report.append({"transport": label, "pattern": pattern, "n": n, "ok": True})
+        err = None
+        try:
+            mine = ctx.upload(np.ascontiguousarray(vec(rank, n)))
+            out = ctx.alloc(max(n, 1) * 32)
+            fn(mine.ptr, out.ptr, n)
+            ctx.sync()
+            got = cv.fr_from_mont(ctx.download(out, (n, 4)))
+            want = [sum(((p << 200) + i * (p + 3) + 1) for p in range(P)) % cv.R_MOD for i in range(n)]
+            mine.free(); out.free()
+            if list(got) != want:
+                err = "wrong sum on rank %d, first wrong element %d" % (rank, next(i for i in range(n) if got[i] != want[i]))
+        except Exception as e:               # (an error code from the library: the collective itself returned on every rank)
+            err = "rank %d: %r" % (rank, e)
+        ok = agree(err is None)
+        entry = {"transport": label, "pattern": pattern, "n": n, "ok": ok}
+        if not ok:
+            entry["error"] = err or "another rank failed this check"
+        report.append(entry)
+        return ok, entry
+
+    def section(label, pattern, fn, fatal):
+        for n in sizes:
+            ok, entry = check(label, pattern, n, fn)
+            if not ok:
+                if fatal:
+                    raise RuntimeError("pre-flight open FAILED: transport %s, pattern %s, n = %d: %s" % (label, pattern, n, entry["error"]))
+                return False                  # skip the rest of a section that does not work (every rank takes this branch)
+        return True
 
     sizes = (1, 1000 + 1, 4096)
     be = party.be
     native = getattr(be, "native_open", False)
-    # (a) the transport the timed proofs will use
-    for n in sizes:
-        check("native (zk_open_sum_fr_dev, RCCL inside the library)" if native else "torch.distributed/%s" % transport,
-              "by party count", n, lambda v, o, m: be._open_vec(v, o, m))
+    native_label = "native (zk_open_sum_fr_dev, RCCL inside the library)"
+    # (a) the transport the timed proofs will use: fatal
+    section(native_label if native else "torch.distributed/%s" % transport, "by party count", lambda v, o, m: be._open_vec(v, o, m), True)
     if transport == "nccl":
         # (b) the other RCCL path, so that both have carried P ranks before either is trusted: DistNet's collectives when the
-        # timed path is native, the library's own communicator when it is DistNet's
+        # timed path is native, the library's own communicator when it is DistNet's.  Recorded, not fatal.
         if native:
             be.native_open = False
             try:
-                for n in sizes:
-                    check("torch.distributed/nccl", "by party count", n, lambda v, o, m: be._open_vec(v, o, m))
+                section("torch.distributed/nccl", "by party count", lambda v, o, m: be._open_vec(v, o, m), False)
             finally:
                 be.native_open = True
         else:
-            box = [ctx.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            ctx.comm_init(box[0], rank, P)
+            up = None
             try:
-                for pat, name in ((0, "by party count"), (1, "all-gather"), (2, "all-to-all of slices")):
-                    ctx.comm_set_open_pattern(pat)
-                    for n in sizes:
-                        check("native (zk_open_sum_fr_dev, RCCL inside the library)", name, n,
-                              lambda v, o, m: (ctx.open_sum_fr_dev(v, m, o), ctx.sync()))
-                report.append({"zk_comm": ctx.comm_info()})
-            finally:
-                ctx.comm_destroy()
+                box = [ctx.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                ctx.comm_init(box[0], rank, P)
+            except Exception as e:
+                up = "rank %d: zk_comm_init: %r" % (rank, e)
+            if agree(up is None):
+                try:
+                    for pat, name in ((0, "by party count"), (1, "all-gather"), (2, "all-to-all of slices")):
+                        ctx.comm_set_open_pattern(pat)
+                        if not section(native_label, name, lambda v, o, m: (ctx.open_sum_fr_dev(v, m, o), ctx.sync()), False):
+                            break
+                    report.append({"zk_comm": ctx.comm_info()})
+                finally:
+                    ctx.comm_destroy()
+            else:
+                report.append({"transport": native_label, "ok": False, "error": up or "zk_comm_init failed on another rank"})
+                try:
+                    ctx.comm_destroy()
+                except Exception:
+                    pass
         # (c) both exchange patterns of DistNet, whatever the party count picks by default
         keep = party.net.open_pattern
         native_keep = getattr(be, "native_open", False)
@@ -737,8 +770,7 @@ def preflight_opens(ctx, dist, party, torch, transport: str):
         try:
             for pat in ("allgather", "a2a"):
                 party.net.open_pattern = pat
-                for n in sizes:
-                    check("torch.distributed/nccl", pat, n, lambda v, o, m: be._open_vec(v, o, m))
+                section("torch.distributed/nccl", pat, lambda v, o, m: be._open_vec(v, o, m), not native_keep and (pat == ("allgather" if P < 3 else "a2a")))
         finally:
             party.net.open_pattern = keep
             be.native_open = native_keep
