@@ -147,32 +147,7 @@ ZK_HD Fp<P> fp_neg_lazy(const Fp<P>& a) {
     return r;
 }
 
-// The tail of one reduction column of the Montgomery products below: returns the digit m = -acc / p mod 2^29 and leaves
-// acc <- (acc + m p_0) >> 29, the carry into the next column.
-// p_0 = 1 (BLS12-377's Fr and Fq are 1 mod 2^46): m = -acc mod 2^29, and acc + m is simply the next multiple of 2^29, so the
-// shift is a rounding-up division: (acc + m) >> 29 == (acc + 2^29 - 1) >> 29.  The constant 2^29 - 1 enters at the START of a
-// column (fp_round0 for the first one, `more` for the following ones), where it is the free addend of the column's first
-// multiply-add instead of a 64-bit addition of m at its end; with it already inside, m = ~acc mod 2^29 (one v_bfi).  The
-// integers are the same as with the textbook tail: nothing about ranges or column bounds changes (the constant is < 2^29).
-template <class P>
-ZK_HD constexpr uint64_t fp_round0() { return P::P[0] == 1 ? (uint64_t)MASK29 : 0; }
-// acc = carry from the column before + this column's sum `col` (which started from fp_round0)
-template <class P>
-ZK_HD uint32_t fp_redc_column(uint64_t& acc, uint64_t col) {
-    acc += col;
-    if constexpr (P::P[0] == 1) {
-        const uint32_t m = ~(uint32_t)acc & MASK29;
-        acc >>= 29;
-        return m;
-    } else {
-        const uint32_t m = ((uint32_t)acc * P::INV) & MASK29;
-        acc += (uint64_t)m * P::P[0];
-        acc >>= 29;
-        return m;
-    }
-}
-
-// ---- Montgomery products, product scanning with ONE 64-bit accumulator -----------------------------------------------------
+// ---- Montgomery products, product scanning with ONE 64-bit accumulator that is never left -------------------------------------
 // LR = P::LR Montgomery digits (radix RI = 2^(29 LR)), L = P::L operand limbs.  The *_lazy forms return the value before any
 // final subtraction:  (a b + m p) / RI  <  a b / RI + p.
 //   LR = L  (Fr, the 753-bit field): operands < p give a result < 2p; fp_mul subtracts p once.
@@ -182,28 +157,71 @@ ZK_HD uint32_t fp_redc_column(uint64_t& acc, uint64_t col) {
 // Column sums: a column holds at most L products a_i b_j and L products m_i p_j of 29 x 29 bits (2 L * 2^58) plus, for
 // unnormalised operands, two products with one wide top limb and (top column only) one with two; for the operand bounds of
 // the lazy domain the worst column is < 2^63.8 (tests/test_abi.py::test_lazy_domain_column_bounds recomputes it).
+//
+// Instruction shape.  Every limb product is one v_mad_u64_u32 whose addend is the running accumulator: a column STARTS from the
+// carry of the column before it, so a reduction column costs its products + 3 instructions (digit, shift, rounding constant)
+// and a result column its products + 2 (mask, shift).  Left alone, LLVM's reassociation orders a column's sum by operand rank:
+// the carry, computed last, is added last, i.e. every column becomes a chain from zero plus a 64-bit join (and the rounding
+// constant a second one): 22-33 more instructions per product.  ZK_PIN gives each partial sum a second use (an empty asm that
+// only READS it), which is what makes the pass leave the chain in source order; it emits nothing.  (An asm that also WRITES the
+// value would do, but gfx950's hazard recogniser puts an s_nop behind every register an asm defines.)
+// PIN is a template argument of the lazy products: the bucket-accumulation loops set it (two waves per SIMD at ~200 registers:
+// the instruction count is what they pay for).  Everything else keeps the compiler's order -- under a 128-register budget (the
+// transforms) the pinned order costs spills (k_ntt_pass: 3-7 -> 61-65 spilled registers, measured slower).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZK_PIN(x) do { if constexpr (PIN) asm volatile("" ::"v"(x)); } while (0)
+#else
+#define ZK_PIN(x) ((void)0)
+#endif
+
+// The end of one reduction column: acc holds carry + products (+ the rounding constant, see below).  Returns the digit
+// m = -acc / p mod 2^29 and leaves acc <- (acc + m p_0) >> 29 (+ the next column's rounding constant if `more`).
+// p_0 = 1 (BLS12-377's Fr and Fq are 1 mod 2^46): m = -acc mod 2^29, and acc + m is simply the next multiple of 2^29, so the
+// shift is a rounding-up division: (acc + m) >> 29 == (acc + 2^29 - 1) >> 29.  The constant 2^29 - 1 is in the accumulator
+// BEFORE the column's products arrive (fp_round0 for the first column, `more` for the following ones); with it inside,
+// m = ~acc mod 2^29 (one v_bitop3).  The integers are the same as with the textbook tail: nothing about ranges or column
+// bounds changes (the constant is < 2^29).
 template <class P>
+ZK_HD constexpr uint64_t fp_round0() { return P::P[0] == 1 ? (uint64_t)MASK29 : 0; }
+template <class P, bool PIN>
+ZK_HD uint32_t fp_redc_column(uint64_t& acc, bool more) {
+    uint32_t m;
+    if constexpr (P::P[0] == 1) {
+        m = ~(uint32_t)acc & MASK29;
+        acc >>= 29;
+        if (more) acc += MASK29;
+    } else {
+        m = ((uint32_t)acc * P::INV) & MASK29;
+        acc += (uint64_t)m * P::P[0];
+        acc >>= 29;
+    }
+    ZK_PIN(acc);
+    return m;
+}
+#define ZK_MAD(acc, x, y) do { (acc) += (uint64_t)(x) * (y); ZK_PIN(acc); } while (0)
+
+template <class P, bool PIN = false>
 ZK_HD Fp<P> fp_mul_lazy(const Fp<P>& a, const Fp<P>& b) {
     constexpr int L = P::L, LR = P::LR;
     uint32_t m[LR], r[L];
-    uint64_t acc = 0;
+    uint64_t acc = fp_round0<P>();
 #pragma unroll
     for (int k = 0; k < LR; k++) {
-        uint64_t col = fp_round0<P>();
 #pragma unroll
-        for (int i = (k >= L ? k - L + 1 : 0); i <= (k < L ? k : L - 1); i++) col += (uint64_t)a.l[i] * b.l[k - i];
+        for (int i = (k >= L ? k - L + 1 : 0); i <= (k < L ? k : L - 1); i++) ZK_MAD(acc, a.l[i], b.l[k - i]);
 #pragma unroll
-        for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) col += (uint64_t)m[i] * P::P[k - i];
-        m[k] = fp_redc_column<P>(acc, col);
+        for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) ZK_MAD(acc, m[i], P::P[k - i]);
+        m[k] = fp_redc_column<P, PIN>(acc, k + 1 < LR);
     }
 #pragma unroll
     for (int k = LR; k < LR + L - 1; k++) {
 #pragma unroll
-        for (int i = k - L + 1; i < L; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+        for (int i = k - L + 1; i < L; i++) ZK_MAD(acc, a.l[i], b.l[k - i]);
 #pragma unroll
-        for (int i = k - L + 1; i < LR; i++) acc += (uint64_t)m[i] * P::P[k - i];
+        for (int i = k - L + 1; i < LR; i++) ZK_MAD(acc, m[i], P::P[k - i]);
         r[k - LR] = (uint32_t)acc & MASK29;
         acc >>= 29;
+        ZK_PIN(acc);
     }
     r[L - 1] = (uint32_t)acc;
     Fp<P> o;
@@ -225,42 +243,42 @@ ZK_HD Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
 // TOPSPLIT: all four operands may have wide top limbs (up to 7 p each: the odd lane of an Fq2 squaring, a0 a1 + a1 a0).  Then
 // the top column alone -- a_top b_top + c_top d_top, 2 * 5.9^2 * 2^58 -- would pass 2^64, so the second of those products is
 // entered in two parts, its low 29 bits in that column and the rest one column up (every other column stays below 2^63.8).
-template <class P, bool TOPSPLIT = false>
+template <class P, bool TOPSPLIT = false, bool PIN = false>
 ZK_HD Fp<P> fp_mul2_lazy(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d) {
     constexpr int L = P::L, LR = P::LR;
     static_assert(!TOPSPLIT || LR > L, "the split top column is a column of the result part");
     uint32_t m[LR], r[L];
-    uint64_t acc = 0;
+    uint64_t acc = fp_round0<P>();
 #pragma unroll
     for (int k = 0; k < LR; k++) {
-        uint64_t col = fp_round0<P>();
 #pragma unroll
         for (int i = (k >= L ? k - L + 1 : 0); i <= (k < L ? k : L - 1); i++) {
-            col += (uint64_t)a.l[i] * b.l[k - i];
-            col += (uint64_t)c.l[i] * d.l[k - i];
+            ZK_MAD(acc, a.l[i], b.l[k - i]);
+            ZK_MAD(acc, c.l[i], d.l[k - i]);
         }
 #pragma unroll
-        for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) col += (uint64_t)m[i] * P::P[k - i];
-        m[k] = fp_redc_column<P>(acc, col);
+        for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) ZK_MAD(acc, m[i], P::P[k - i]);
+        m[k] = fp_redc_column<P, PIN>(acc, k + 1 < LR);
     }
 #pragma unroll
     for (int k = LR; k < LR + L - 1; k++) {
         uint64_t up = 0;
 #pragma unroll
         for (int i = k - L + 1; i < L; i++) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
+            ZK_MAD(acc, a.l[i], b.l[k - i]);
             if (TOPSPLIT && k == 2 * L - 2) {
                 const uint64_t t = (uint64_t)c.l[i] * d.l[k - i];
                 acc += t & MASK29;
                 up = t >> 29;
             } else {
-                acc += (uint64_t)c.l[i] * d.l[k - i];
+                ZK_MAD(acc, c.l[i], d.l[k - i]);
             }
         }
 #pragma unroll
-        for (int i = k - L + 1; i < LR; i++) acc += (uint64_t)m[i] * P::P[k - i];
+        for (int i = k - L + 1; i < LR; i++) ZK_MAD(acc, m[i], P::P[k - i]);
         r[k - LR] = (uint32_t)acc & MASK29;
         acc = (acc >> 29) + up;
+        ZK_PIN(acc);
     }
     r[L - 1] = (uint32_t)acc;
     Fp<P> o;
@@ -271,10 +289,10 @@ ZK_HD Fp<P> fp_mul2_lazy(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const F
 
 // exact form: fully reduced.  LR = L: the value before the subtractions is < (2 p^2 + RI p) / RI < 2.68 p for a 0.84 * 2^(29 L)
 // modulus (two conditional subtractions); LR > L: < p + 2^(29 (L - 1) + 7) (one).
-template <class P>
+template <class P, bool PIN = false>
 ZK_HD Fp<P> fp_mul2(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d) {
     constexpr int L = P::L;
-    const Fp<P> t = fp_mul2_lazy<P>(a, b, c, d);
+    const Fp<P> t = fp_mul2_lazy<P, false, PIN>(a, b, c, d);
     if constexpr (P::LR > P::L) {
         return fp_reduce_once<P>(t.l);
     } else {
@@ -323,31 +341,30 @@ ZK_HD Fp<P> fp_neg5_almost(const Fp<P>& a) {
 
 // Montgomery square: cross products taken once, against the doubled LOWER-index limb (that one is always < 2^29, so the
 // doubling cannot overflow even when the operand's top limb is wide).
-template <class P>
+template <class P, bool PIN = false>
 ZK_HD Fp<P> fp_sqr_lazy(const Fp<P>& a) {
     constexpr int L = P::L, LR = P::LR;
     uint32_t m[LR], r[L], a2[L];
 #pragma unroll
     for (int i = 0; i < L; i++) a2[i] = a.l[i] << 1;
-    uint64_t acc = 0;
+    uint64_t acc = fp_round0<P>();
 #pragma unroll
     for (int k = 0; k < LR + L - 1; k++) {
-        uint64_t col = k < LR ? fp_round0<P>() : 0;
         if (k <= 2 * L - 2) {
 #pragma unroll
-            for (int i = (k >= L ? k - L + 1 : 0); 2 * i < k; i++) col += (uint64_t)a2[i] * a.l[k - i];    // i < j = k - i
-            if ((k & 1) == 0) col += (uint64_t)a.l[k / 2] * a.l[k / 2];
+            for (int i = (k >= L ? k - L + 1 : 0); 2 * i < k; i++) ZK_MAD(acc, a2[i], a.l[k - i]);    // i < j = k - i
+            if ((k & 1) == 0) ZK_MAD(acc, a.l[k / 2], a.l[k / 2]);
         }
         if (k < LR) {
 #pragma unroll
-            for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) col += (uint64_t)m[i] * P::P[k - i];
-            m[k] = fp_redc_column<P>(acc, col);
+            for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) ZK_MAD(acc, m[i], P::P[k - i]);
+            m[k] = fp_redc_column<P, PIN>(acc, k + 1 < LR);
         } else {
-            acc += col;
 #pragma unroll
-            for (int i = k - L + 1; i < LR; i++) acc += (uint64_t)m[i] * P::P[k - i];
+            for (int i = k - L + 1; i < LR; i++) ZK_MAD(acc, m[i], P::P[k - i]);
             r[k - LR] = (uint32_t)acc & MASK29;
             acc >>= 29;
+            ZK_PIN(acc);
         }
     }
     r[L - 1] = (uint32_t)acc;
@@ -520,14 +537,14 @@ struct FqField {
     static ZK_HD bool is_zero(const T& a) { return fp_is_zero<FqParams>(a); }
     static ZK_HD bool eq(const T& a, const T& b) { return fp_eq<FqParams>(a, b); }
     // ---- lazy domain (see fp29.cuh "the lazy domain"): representatives in [0, ~7 p], no conditional subtractions ----
-    static ZK_HD T mul_l(const T& a, const T& b) { return fp_mul_lazy<FqParams>(a, b); }
-    static ZK_HD T sqr_l(const T& a) { return fp_sqr_lazy<FqParams>(a); }
+    static ZK_HD T mul_l(const T& a, const T& b) { return fp_mul_lazy<FqParams, true>(a, b); }
+    static ZK_HD T sqr_l(const T& a) { return fp_sqr_lazy<FqParams, true>(a); }
     template <int K> static ZK_HD T sub_kp(const T& a, const T& b) { return fp_sub_kp<FqParams, K>(a, b); }       // a + K p - b
     template <int K> static ZK_HD T kp_minus(const T& b) { return fp_sub_kp<FqParams, K>(fp_zero<FqParams>(), b); }   // K p - b
     static ZK_HD T x3_l(const T& rr, const T& ppp, const T& qq) { return fp_x3_lazy<FqParams>(rr, ppp, qq); }
     // r t - ppp y with one Montgomery reduction; ppp enters as 2 p - ppp in (p - eps, 2 p]
     static ZK_HD T mulsub_l(const T& r, const T& t, const T& ppp, const T& y) {
-        return fp_mul2_lazy<FqParams>(r, t, fp_sub_kp<FqParams, 2>(fp_zero<FqParams>(), ppp), y);
+        return fp_mul2_lazy<FqParams, false, true>(r, t, fp_sub_kp<FqParams, 2>(fp_zero<FqParams>(), ppp), y);
     }
     static ZK_HD T canon(const T& a) { return fp_canon<FqParams>(a); }                    // a < 8 p -> a mod p
     static ZK_HD T canon1(const T& a) { return fp_cond_sub_kp<FqParams, 1>(a); }          // a < 2 p -> a mod p

@@ -67,12 +67,12 @@ __device__ __forceinline__ Left prep(const Fq& a, bool odd) {
 }
 __device__ __forceinline__ Fq mulp(const Left& A, const Fq& b, bool odd) {
     (void)odd;
-    return fp_mul2<FqParams>(A.p, b, A.q, xchg(b));
+    return fp_mul2<FqParams, true>(A.p, b, A.q, xchg(b));
 }
 
 template <bool TOPSPLIT = false>
 __device__ __forceinline__ Fq mulp_l(const Left& A, const Fq& b) {     // lazy domain: no final subtraction, result < p + eps
-    return fp_mul2_lazy<FqParams, TOPSPLIT>(A.p, b, A.q, xchg(b));
+    return fp_mul2_lazy<FqParams, TOPSPLIT, true>(A.p, b, A.q, xchg(b));
 }
 
 struct AffP { Fq x, y; };
