@@ -265,7 +265,8 @@ def _normalised(a, top_bits=29):
 
 def _worst_columns(tops, split_top=False):
     """Worst-case column sums (in the order the kernels accumulate them) of the product scanning with every low limb at
-    2^29 - 1, the given top limbs per operand ((a, b) or (a, b, c, d)) and every Montgomery digit at its maximum."""
+    2^29 - 1, the given top limbs per operand ((a, b) or (a, b, c, d)) and every Montgomery digit at its maximum (2^29 for the
+    first one, fp29.cuh::fp_redc_column).  The m_i p_0 terms stand for the "+ 1" carries the kernels never add: an upper bound."""
     L, LR = 13, 14
     pl = [(Q >> (29 * i)) & ((1 << 29) - 1) for i in range(13)]
     mmax = (1 << 29) - 1
@@ -286,7 +287,7 @@ def _worst_columns(tops, split_top=False):
                         col += t
         for i in range(LR):
             if 0 <= k - i < L:
-                col += mmax * pl[k - i]
+                col += (mmax + 1 if i == 0 else mmax) * pl[k - i]
         cols.append(col)
         carry = (col >> 29) + up
     return cols
@@ -437,7 +438,7 @@ def test_fr_lazy_domain_column_bounds():
         col = carry
         for i in range(9):
             if 0 <= k - i < 9:
-                col += worst_a * M29 + M29 * pl[k - i]
+                col += worst_a * M29 + (M29 + 1 if i == 0 else M29) * pl[k - i]      # digit 0 may be 2^29 (fp_redc_column)
         top = max(top, col)
         carry = col >> 29
     assert top < (1 << 64)
@@ -569,7 +570,7 @@ def test_fr_lazy_primitives_against_big_integers():
         a = rnd.choice([92 * RR // 10 - 1, RI9 - 1, rnd.randrange(RI9), rnd.randrange(10 * RR)])
         w = rnd.choice([RR - 1, 1, rnd.randrange(RR)])
         (r,) = _fr_lazy(5, _spread(a, rnd, int(2 ** 31.33)), _l9(w))
-        assert _val(r) % RR == a * w * inv % RR and _val(r) * RI9 < RR * (RI9 + a) and all(x <= M29 for x in r)
+        assert _val(r) % RR == a * w * inv % RR and _val(r) * RI9 <= RR * (RI9 + a) and all(x <= M29 for x in r)
 
 
 def test_fr_mul32_against_big_integers():

@@ -159,10 +159,9 @@ ZK_HD Fp<P> fp_neg_lazy(const Fp<P>& a) {
 // the lazy domain the worst column is < 2^63.8 (tests/test_abi.py::test_lazy_domain_column_bounds recomputes it).
 //
 // Instruction shape.  Every limb product is one v_mad_u64_u32 whose addend is the running accumulator: a column STARTS from the
-// carry of the column before it, so a reduction column costs its products + 3 instructions (digit, shift, rounding constant)
-// and a result column its products + 2 (mask, shift).  Left alone, LLVM's reassociation orders a column's sum by operand rank:
-// the carry, computed last, is added last, i.e. every column becomes a chain from zero plus a 64-bit join (and the rounding
-// constant a second one): 22-33 more instructions per product.  ZK_PIN gives each partial sum a second use (an empty asm that
+// carry of the column before it, so a column costs its products + 2 instructions (digit or mask, shift).  Left alone, LLVM's reassociation orders a column's sum by operand rank:
+// the carry, computed last, is added last, i.e. every column becomes a chain from zero plus a 64-bit join: 22-33 more
+// instructions per product.  ZK_PIN gives each partial sum a second use (an empty asm that
 // only READS it), which is what makes the pass leave the chain in source order; it emits nothing.  (An asm that also WRITES the
 // value would do, but gfx950's hazard recogniser puts an s_nop behind every register an asm defines.)
 // PIN is a template argument of the lazy products: the bucket-accumulation loops set it (two waves per SIMD at ~200 registers:
@@ -174,22 +173,28 @@ ZK_HD Fp<P> fp_neg_lazy(const Fp<P>& a) {
 #define ZK_PIN(x) ((void)0)
 #endif
 
-// The end of one reduction column: acc holds carry + products (+ the rounding constant, see below).  Returns the digit
-// m = -acc / p mod 2^29 and leaves acc <- (acc + m p_0) >> 29 (+ the next column's rounding constant if `more`).
-// p_0 = 1 (BLS12-377's Fr and Fq are 1 mod 2^46): m = -acc mod 2^29, and acc + m is simply the next multiple of 2^29, so the
-// shift is a rounding-up division: (acc + m) >> 29 == (acc + 2^29 - 1) >> 29.  The constant 2^29 - 1 is in the accumulator
-// BEFORE the column's products arrive (fp_round0 for the first column, `more` for the following ones); with it inside,
-// m = ~acc mod 2^29 (one v_bitop3).  The integers are the same as with the textbook tail: nothing about ranges or column
-// bounds changes (the constant is < 2^29).
-template <class P>
-ZK_HD constexpr uint64_t fp_round0() { return P::P[0] == 1 ? (uint64_t)MASK29 : 0; }
+// The end of reduction column k: returns the digit m_k (the multiple of p that clears the column) and leaves the start of
+// column k + 1 in acc.
+// p_0 = 1 (BLS12-377's Fr and Fq are 1 mod 2^46), so with S_k the column's true sum (carry in + products) the digit is any m
+// with S_k + m = 0 mod 2^29 and the carry out is (S_k + m) >> 29.  No constant is ever added to a column:
+//   k = 0: acc = S_0.  m_0 = 2^29 - (S_0 mod 2^29), in [1, 2^29] (2^29, not 0, for a column that is already clear), so that
+//          S_0 + m_0 = ((S_0 >> 29) + 1) 2^29: the carry out is (acc >> 29) + 1, at least 1.
+//   k > 0: acc = S_k - 1 (the "+ 1" of the carry is what is NOT in acc; S_k >= 1 because every carry is).  m_k = -S_k mod
+//          2^29 = ~acc mod 2^29 (one v_bitop3; -(x + 1) = ~x), in [0, 2^29), and S_k + m_k = acc + 1 + (2^29 - 1 - acc mod
+//          2^29) = ((acc >> 29) + 1) 2^29: the carry out is again (acc >> 29) + 1.
+// Either way the next column starts from the plain shift, acc >> 29 = S_(k+1) - 1 once its products are in: the first
+// multiply-add of a column takes the shifted accumulator as its addend and the "+ 1" is owed until the LAST reduction column,
+// where it is paid once (`last`).  (Rounds 3-4 added 2^29 - 1 to every column instead: 13 64-bit additions per product.)
+// Digits: m_0 <= 2^29, the others < 2^29; sum m_k 2^(29 k) <= RI, so the lazy result is <= a b / RI + p (p, not 0, for
+// a b = 0: congruent, inside every range below, and fp_reduce_once maps it to 0).  Column sums are those of the textbook
+// tail minus one.
 template <class P, bool PIN>
-ZK_HD uint32_t fp_redc_column(uint64_t& acc, bool more) {
+ZK_HD uint32_t fp_redc_column(uint64_t& acc, bool first, bool last) {
     uint32_t m;
     if constexpr (P::P[0] == 1) {
-        m = ~(uint32_t)acc & MASK29;
+        m = first ? (1u << 29) - ((uint32_t)acc & MASK29) : ~(uint32_t)acc & MASK29;
         acc >>= 29;
-        if (more) acc += MASK29;
+        if (last) acc += 1;
     } else {
         m = ((uint32_t)acc * P::INV) & MASK29;
         acc += (uint64_t)m * P::P[0];
@@ -204,14 +209,14 @@ template <class P, bool PIN = false>
 ZK_HD Fp<P> fp_mul_lazy(const Fp<P>& a, const Fp<P>& b) {
     constexpr int L = P::L, LR = P::LR;
     uint32_t m[LR], r[L];
-    uint64_t acc = fp_round0<P>();
+    uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < LR; k++) {
 #pragma unroll
         for (int i = (k >= L ? k - L + 1 : 0); i <= (k < L ? k : L - 1); i++) ZK_MAD(acc, a.l[i], b.l[k - i]);
 #pragma unroll
         for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) ZK_MAD(acc, m[i], P::P[k - i]);
-        m[k] = fp_redc_column<P, PIN>(acc, k + 1 < LR);
+        m[k] = fp_redc_column<P, PIN>(acc, k == 0, k + 1 == LR);
     }
 #pragma unroll
     for (int k = LR; k < LR + L - 1; k++) {
@@ -248,7 +253,7 @@ ZK_HD Fp<P> fp_mul2_lazy(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const F
     constexpr int L = P::L, LR = P::LR;
     static_assert(!TOPSPLIT || LR > L, "the split top column is a column of the result part");
     uint32_t m[LR], r[L];
-    uint64_t acc = fp_round0<P>();
+    uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < LR; k++) {
 #pragma unroll
@@ -258,7 +263,7 @@ ZK_HD Fp<P> fp_mul2_lazy(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const F
         }
 #pragma unroll
         for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) ZK_MAD(acc, m[i], P::P[k - i]);
-        m[k] = fp_redc_column<P, PIN>(acc, k + 1 < LR);
+        m[k] = fp_redc_column<P, PIN>(acc, k == 0, k + 1 == LR);
     }
 #pragma unroll
     for (int k = LR; k < LR + L - 1; k++) {
@@ -347,7 +352,7 @@ ZK_HD Fp<P> fp_sqr_lazy(const Fp<P>& a) {
     uint32_t m[LR], r[L], a2[L];
 #pragma unroll
     for (int i = 0; i < L; i++) a2[i] = a.l[i] << 1;
-    uint64_t acc = fp_round0<P>();
+    uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < LR + L - 1; k++) {
         if (k <= 2 * L - 2) {
@@ -358,7 +363,7 @@ ZK_HD Fp<P> fp_sqr_lazy(const Fp<P>& a) {
         if (k < LR) {
 #pragma unroll
             for (int i = (k >= L ? k - L + 1 : 0); i < k; i++) ZK_MAD(acc, m[i], P::P[k - i]);
-            m[k] = fp_redc_column<P, PIN>(acc, k + 1 < LR);
+            m[k] = fp_redc_column<P, PIN>(acc, k == 0, k + 1 == LR);
         } else {
 #pragma unroll
             for (int i = k - L + 1; i < LR; i++) ZK_MAD(acc, m[i], P::P[k - i]);
