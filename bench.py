@@ -464,7 +464,7 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
             return DM.prove_native(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
     else:
         from zk_mpc_amd import mpc
-        party = (mpc.SpdzParty if args.spdz else mpc.Party)(ctx, dist)
+        party = make_party(mpc.SpdzParty if args.spdz else mpc.Party, mpc, ctx, dist, torch, getattr(args, 'data_group', None))
         shape = types.SimpleNamespace(num_instance=ni, num_witness=nw)
         z0 = party.share_assignment_dev(z, shape, seed=1234)
         keep = [party._keep]
@@ -484,12 +484,12 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
             dist.barrier()
         ctx.sync()
         torch.cuda.synchronize()
-    for _ in range(2 + args.warmup):
-        proof = step()
     preflight = ranks_seen = None
     if dist is not None and world > 1:
         preflight = preflight_opens(ctx, dist, party, torch, args.transport)
         ranks_seen = comm_report(ctx, dist, party, torch)
+    for _ in range(2 + args.warmup):
+        proof = step()
     sent0 = int(party.bytes_sent) if dist is not None else 0
     if dist is not None:
         party.be.open_stats()
@@ -502,7 +502,7 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
     opens_timed = party.be.open_stats(args.steps) if dist is not None else None
     sent_timed = (int(party.bytes_sent) - sent0) if dist is not None else 0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda" if args.transport == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64)          # over the control plane (gloo)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
@@ -534,6 +534,7 @@ def marlin_bench(args, ctx, dist, rank, world, real_stdout):
             "devices": sorted(set((r.get("device_uuid") or r["device"]) for r in ranks_seen))}
         out["transport"] = ("RCCL (torch.distributed nccl)" if args.transport == "nccl" else
                             "gloo, opens staged through host memory" + (", every party on cuda:0 (functional run, not a measurement)" if args.one_gpu else ""))
+        out["transport_fallback"] = getattr(args, "transport_fallback", None)
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
@@ -652,11 +653,51 @@ def launch_ranks(n: int, real_stdout: int) -> int:
     return proc.returncode
 
 
+def open_transport(args, torch, dist, rank, world, local_rank):
+    """Process groups of an N-party run.  The DEFAULT group is always gloo: the control plane (barriers, the agreement on
+    verdicts, object broadcasts, the max over ranks of the timed region).  With --transport nccl the share vectors travel over a
+    second group on RCCL; it is created and made to carry one all-reduce HERE, before anything else, and the ranks agree on the
+    outcome over gloo: if RCCL does not come up on every rank (an exception, a wrong sum), the run goes on with the gloo group
+    as its data plane too and says so in its line (`transport_fallback`) instead of ending without a number.  A rank that HANGS
+    inside RCCL cannot be rescued from in here: the group's timeout ends the job.
+    Returns (data_group or None, reason or None); sets args.transport to what is actually used."""
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.transport != "nccl":
+        return None, None
+    err, grp = None, None
+    try:
+        grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180), device_id=torch.device("cuda", local_rank))
+        t = torch.full((4,), float(rank + 1), device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, group=grp)
+        torch.cuda.synchronize()
+        if float(t[0].item()) != world * (world + 1) / 2:
+            err = "RCCL all-reduce over %d ranks returned %r on rank %d" % (world, float(t[0].item()), rank)
+    except Exception as e:
+        err = "rank %d: %r" % (rank, e)
+    box = [None] * world
+    dist.all_gather_object(box, err)
+    bad = [e for e in box if e]
+    if not bad:
+        return grp, None
+    args.transport = "gloo"
+    sys.stderr.write("bench.py: RCCL did not come up (%s): continuing over gloo\n" % bad[0])
+    return None, "RCCL group failed on %d of %d ranks (first: %s); the opens are staged through host memory over gloo" % (len(bad), world, bad[0][:300])
+
+
+def make_party(cls, mpc, ctx, dist, torch, data_group):
+    """The party over the run's data plane: RCCL group (device buffers) when there is one, else the gloo default group."""
+    if data_group is not None:
+        return cls(ctx, net=mpc.DistNet(dist, torch.device("cuda", ctx.device), group=data_group))
+    return cls(ctx, dist)
+
+
 def comm_report(ctx, dist, party, torch):
     """What actually carried the ranks of an N > 1 run, gathered over the process group: one entry per rank with its device and
     -- when the library's own communicator is up (ZK_TRANSPORT=native) -- the rank count RCCL itself reports."""
-    info = {"rank": dist.get_rank(), "device": int(ctx.device), "dist_world_size": dist.get_world_size(),
-            "dist_backend": dist.get_backend()}
+    grp = getattr(party.net, "group", None)
+    info = {"rank": dist.get_rank(), "device": int(ctx.device), "dist_world_size": dist.get_world_size(grp),
+            "dist_backend": dist.get_backend(grp), "control_plane": dist.get_backend()}
     try:
         if torch.cuda.is_available():
             info["device_name"] = torch.cuda.get_device_name(ctx.device)
@@ -685,10 +726,8 @@ def preflight_opens(ctx, dist, party, torch, transport: str):
     import zk_mpc_amd.convert as cv
     rank, P = dist.get_rank(), dist.get_world_size()
     report = []
-    dev = "cuda" if transport == "nccl" else "cpu"
-
     def agree(ok: bool) -> bool:
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)      # over the control plane (gloo)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t.item()))
 
@@ -837,9 +876,7 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libzkmpc_hip has no CPU path")
     if args.one_gpu:
-        if world > 1 and args.transport == "nccl":
-            sys.exit("bench.py --one-gpu needs --transport gloo (RCCL refuses two ranks on one device)")
-        local_rank = 0
+        local_rank = 0          # (with --transport nccl RCCL refuses two ranks on one device: the run falls back to gloo and says so)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_mpc:
@@ -847,10 +884,7 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if args.transport == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        args.data_group, args.transport_fallback = open_transport(args, torch, dist, rank, world, local_rank)
 
     if args.marlin:
         ctx = Z.Context(local_rank, rank, world)
@@ -885,7 +919,7 @@ def main():
             return last_proof[q]
     else:
         from zk_mpc_amd import mpc
-        party = (mpc.SpdzParty if args.spdz else mpc.Party)(ctx, dist)
+        party = make_party(mpc.SpdzParty if args.spdz else mpc.Party, mpc, ctx, dist, torch, getattr(args, 'data_group', None))
         r_plain, s_plain = seeded_fr(200), seeded_fr(201)
         if args.spdz:
             # SPDZ shares: (share, mac) lanes, MAC key alpha = 1 held by the leader (share/spdz.rs:31-37): the mac lane is an
@@ -919,6 +953,12 @@ def main():
     # priming, part of set-up like the key generation above: the first few proofs of a process pay one-off costs (pinned
     # staging buffers, scratch arenas growing to their final size, RCCL's lazy channel set-up: the 3rd collaborative proof
     # of a process takes 65 ms instead of 28) that must not land in the timed region when the caller asks for W < 3
+    preflight = None
+    ranks_seen = None
+    if dist is not None and world > 1:
+        # N > 1: both transports carry tiny opens and are checked against the host-side sum before the first proof
+        preflight = preflight_opens(ctx, dist, party, torch, args.transport)
+        ranks_seen = comm_report(ctx, dist, party, torch)
     it = 0
     for _ in range(4 if dist is not None else 2):
         step(it); it += 1
@@ -927,12 +967,6 @@ def main():
     ctx.set_profiling(True)
     if dist is not None:
         party.be.open_stats()                 # reset the per-open wall-time counters
-    preflight = None
-    ranks_seen = None
-    if dist is not None and world > 1:
-        # N > 1: both transports carry a tiny open and are checked against the host-side sum before anything is timed
-        preflight = preflight_opens(ctx, dist, party, torch, args.transport)
-        ranks_seen = comm_report(ctx, dist, party, torch)
     barrier()
     step_s = []
     t0 = time.perf_counter()
@@ -1011,7 +1045,7 @@ def main():
             host_leg = {"error": repr(e)}
     open_probe = None
     if dist is not None:
-        t = torch.tensor([dt], device="cuda" if args.transport == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64)          # over the control plane (gloo)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # every rank must hold the same revealed proof
@@ -1189,6 +1223,7 @@ def main():
                 "devices": sorted(set((r.get("device_uuid") or r["device"]) for r in ranks_seen))}
             out["transport"] = ("RCCL (torch.distributed nccl), one GPU per party" if args.transport == "nccl" else
                                 "gloo, opens staged through host memory" + (", every party on cuda:0 (functional run, not a measurement)" if args.one_gpu else ""))
+            out["transport_fallback"] = getattr(args, "transport_fallback", None)
             out["bytes_sent_per_party"] = int(party.bytes_sent)
         if dist is None:
             # second half of the headline metric: standalone variable-base MSM throughput (resident bases = the

@@ -72,6 +72,28 @@ def test_bench_starts_its_own_ranks(extra):
     assert d["rccl_ranks_seen"]["torch_distributed"] == 0          # gloo on one GPU: no RCCL rank, and the line says so
 
 
+def test_rccl_that_does_not_come_up_falls_back_to_gloo_and_says_so():
+    """Two ranks asked to run over RCCL on ONE device: RCCL refuses the duplicate device, the ranks agree on that over the gloo
+    control plane, the run goes on with the opens staged through host memory and the line carries the reason -- the same path a
+    multi-GPU box takes if its RCCL group fails to come up."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-constraints", "12",
+                        "--transport", "nccl", "--one-gpu"], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=dict(env_clean, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["same_proof_on_all_ranks"] is True and d["proof_matches_prediction"] is True
+    assert d["transport_fallback"] and "RCCL" in d["transport_fallback"] and d["transport"].startswith("gloo")
+    assert d["rccl_ranks_seen"]["torch_distributed"] == 0
+
+
+def test_one_rccl_rank_carries_the_data_plane_beside_a_gloo_control_plane():
+    """--force-mpc with one rank over --transport nccl: the RCCL group (one rank) is the data plane, gloo the control plane."""
+    d = _line([sys.executable, "bench.py", "--gpus", "1", "--force-mpc", "--steps", "2", "--warmup", "1", "--log-constraints", "12",
+               "--transport", "nccl", "--no-cpu-baseline"])
+    assert d["value"] > 0 and d["transport_fallback"] is None and d["transport"].startswith("RCCL")
+
+
 def test_bench_rejects_mismatched_launch():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=ROOT, capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))

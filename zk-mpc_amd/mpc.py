@@ -40,18 +40,21 @@ import numpy as np
 class DistNet:
     """torch.distributed transport: backend "nccl" (= RCCL) for device buffers, "gloo" on CPU."""
 
-    def __init__(self, dist, device=None, open_pattern=None):
+    def __init__(self, dist, device=None, open_pattern=None, group=None):
         """open_pattern: None = by party count (all-gather for two parties, all-to-all of slices for three or more),
         "allgather" or "a2a" to force one; a constructor argument, not an environment variable: every party of a run
-        must make the same choice, or the parties wait for each other in different collectives."""
+        must make the same choice, or the parties wait for each other in different collectives.
+        group: the process group that carries the collectives (None = the default group), e.g. an RCCL group beside a gloo
+        default group that stays the control plane."""
         import torch
         self.torch = torch
         self.dist = dist
         if open_pattern not in (None, "allgather", "a2a"):
             raise ValueError("open_pattern must be None, 'allgather' or 'a2a'")
         self.open_pattern = open_pattern
-        self.rank = dist.get_rank()
-        self.n = dist.get_world_size()
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.n = dist.get_world_size(group)
         self.device = device if device is not None else torch.device("cpu")
 
     def is_leader(self) -> bool:
@@ -64,7 +67,7 @@ class DistNet:
 
     def all_gather(self, send_tensor, recv_tensor):
         """recv = concat over parties (ordered by party id) of send  (MpcNet::broadcast_bytes)."""
-        self.dist.all_gather_into_tensor(recv_tensor, send_tensor)
+        self.dist.all_gather_into_tensor(recv_tensor, send_tensor, group=self.group)
         if self.device.type == "cuda":
             self.torch.cuda.current_stream().synchronize()
 
@@ -81,7 +84,7 @@ class DistNet:
         words = 4 * n
         if (N < 3 and self.open_pattern != "a2a") or self.open_pattern == "allgather":
             recv = buffer("open_recv", N * n * 32)
-            self.dist.all_gather_into_tensor(recv, send[:words])
+            self.dist.all_gather_into_tensor(recv, send[:words], group=self.group)
             out = buffer("open_out", n * 32)
             self._sync()
             sum_parties(recv, N, n, out)
@@ -93,12 +96,12 @@ class DistNet:
             padded[words:] = 0
             send = padded
         recv = buffer("open_recv", N * chunk * 32)
-        self.dist.all_to_all_single(recv, send[:N * chunk * 4])          # recv[p] = slice `rank` of party p
+        self.dist.all_to_all_single(recv, send[:N * chunk * 4], group=self.group)          # recv[p] = slice `rank` of party p
         part = buffer("open_part", chunk * 32)
         self._sync()
         sum_parties(recv, N, chunk, part)
         full = buffer("open_full", N * chunk * 32)
-        self.dist.all_gather_into_tensor(full, part)
+        self.dist.all_gather_into_tensor(full, part, group=self.group)
         self._sync()
         return full[:words]
 
@@ -107,7 +110,7 @@ class DistNet:
         (MpcNet::worker_receive_or_leader_send_element, used by king_share: mpc-algebra/src/share/additive.rs:98-107).
         parts: list of N int64 tensors of nbytes / 8 words on the leader, None elsewhere."""
         recv = self.torch.empty(nbytes // 8, dtype=self.torch.int64, device=self.device)
-        self.dist.scatter(recv, scatter_list=[p.reshape(-1) for p in parts] if self.rank == 0 else None, src=0)
+        self.dist.scatter(recv, scatter_list=[p.reshape(-1) for p in parts] if self.rank == 0 else None, src=0, group=self.group)
         self._sync()
         return recv
 
@@ -118,12 +121,12 @@ class DistNet:
     def all_gather_small(self, arr: np.ndarray) -> list:
         t = self.torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).reshape(-1).copy()).to(self.device)
         out = self.torch.empty(self.n * t.numel(), dtype=self.torch.int64, device=self.device)
-        self.dist.all_gather_into_tensor(out, t)
+        self.dist.all_gather_into_tensor(out, t, group=self.group)
         res = out.cpu().numpy().view(arr.dtype).reshape((self.n,) + arr.shape)
         return [res[p] for p in range(self.n)]
 
     def barrier(self):
-        self.dist.barrier()
+        self.dist.barrier(group=self.group)
 
 
 class LocalNet:
