@@ -327,6 +327,17 @@ def test_lazy_domain_primitives_against_big_integers():
         assert (_val(v) + 5 * a) % Q == 0 and 0 < _val(v) <= Q + (Q >> 22) and _normalised(v)
         (c,) = _lazy(7, a)
         assert _val(c) == a % Q and _normalised(c)
+    # operands whose low limbs are zero: the first column(s) of the product are already clear, the first Montgomery digit is
+    # 2^29 (fp29.cuh::fp_redc_column: never 0, so that every carry is at least 1) and the following columns start from a bare 1
+    sparse = [1 << (29 * k) for k in (1, 2, 5, 12)] + [3 << 87, (Q >> 58) << 58, ((7 * Q) >> 29) << 29, 1 << 376]
+    for a in sparse + [0]:
+        for b in sparse + [0, 1, Q, rnd.randrange(7 * Q)]:
+            (r,) = _lazy(0, a, b)
+            assert _val(r) % Q == a * b * inv % Q and _val(r) <= Q + EPS and _normalised(r)
+            (r,) = _lazy(11 if min(a, b) > 3 * Q else 2, a, b, b, a)          # (four wide operands: the split top column)
+            assert _val(r) % Q == 2 * a * b * inv % Q and _val(r) < Q + 2 * EPS and _normalised(r)
+        (r,) = _lazy(1, a)
+        assert _val(r) % Q == a * a * inv % Q and _val(r) <= Q + EPS and _normalised(r)
     for _ in range(300):
         a, b, c, d = [rnd.choice(wide) for _ in range(4)]
         (r,) = _lazy(2, a, b, c, d)
