@@ -609,3 +609,6 @@ struct Fq2Field {
 };
 
 }  // namespace zk
+
+#undef ZK_MAD
+#undef ZK_PIN
