@@ -1158,6 +1158,23 @@ def main():
                     "mad_share_of_issue_slots": round(ih["main_path"]["mix_ceiling"], 4)}
             except Exception:
                 pass
+            try:  # the instruction-issue view: VALU wave-instructions per launch (SQ_INSTS_VALU, a separate --pmc run) over the
+                # launch time, against the issue rate of the pure multiply-add kernel measured in this run (lane-ops / 64)
+                if args.log_constraints != 20 or args.natural_domain:
+                    raise KeyError("the committed counter run is of the 2^20 workload")
+                pv = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_valu.json")))["kernels"]
+                kk = next(k for k in pv if k.startswith("k_accum<G1"))
+                insts = float(pv[kk]["SQ_INSTS_VALU"])
+                peak_insts = roof["peak"] * 1e12 / 64
+                roof["int_alu"]["issue"] = {
+                    "valu_wave_insts_per_launch": insts, "achieved_wave_insts_per_s": round(insts / avg_s, 1),
+                    "peak_wave_insts_per_s": round(peak_insts, 1), "frac": round(insts / avg_s / peak_insts, 4),
+                    "source": "profiles/r4_pmc_valu.json (SQ_INSTS_VALU per launch of %s, not measured in this run; the count does "
+                              "not depend on what runs beside the kernel)" % kk,
+                    "note": "every VALU instruction priced as a multiply-add slot: the share of the chip's issue rate this kernel "
+                            "takes while it shares the chip with the other jobs' reduce chains, sorts and transforms"}
+            except Exception:
+                pass
             # the single longest kernel: the G2 accumulate on lane pairs (one launch per proof); every one of its 10 Fq2
             # products per mixed addition is two fused double products
             g2_ms, g2_cnt = timers.get("msm_g2.accum", (0.0, 0))
