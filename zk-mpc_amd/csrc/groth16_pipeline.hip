@@ -119,8 +119,15 @@ int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const vo
     }
     // accumulate order (job numbers: 0 = B in G2, 1 = A, 2 = B in G1, 3 = L, 4 = H; H's scalars arrive last)
     const int ord[5] = {0, 1, 2, 3, 4};
+    // A job of up to 2^16 terms occupies a tenth of the chip for the length of its longest bucket (~0.3 ms): five of them one
+    // behind the other on the accumulate stream are most of a small proof.  There every job's accumulate kernel goes on the stream
+    // of its own reduce chain instead (G2 alone on the accumulate stream, the G1 jobs alternating between the sort stream and the
+    // context stream): the kernels overlap, the chain follows its kernel without an event.  (Ordering against the next proof's
+    // front does not lean on the accumulate stream: that front waits for every job's reduce_done / accum_done event.)
+    const bool small_jobs = !begun && D <= ((size_t)1 << 16);
+    auto job_stream = [&](int k) -> hipStream_t { return k == 0 ? s_acc : ((k & 1) ? s_sort : ctx->stream); };
     for (int k = 0; k < 5 && rc == ZK_OK; k++)
-        if (!begun || ord[k] == 4) rc = zk_msm_enqueue_accum(ctx, J[ord[k]], s_acc);
+        if (!begun || ord[k] == 4) rc = zk_msm_enqueue_accum(ctx, J[ord[k]], small_jobs ? job_stream(ord[k]) : s_acc);
     // B-in-G2's reduce chain (the long one) stays on the sort stream; the four G1 reduces go to the main stream, idle by
     // then, so that each runs right behind its own accumulate kernel instead of queueing behind the G2 chain (that
     // queueing left 4 x 0.7 ms of reduces after the last accumulate).
@@ -128,7 +135,7 @@ int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const vo
     // through): on one stream the last job's chain queued behind its predecessor's, which was still waiting for slots
     // beside the last accumulate kernel, and ~0.6 ms of it ran after the GPU had otherwise gone idle.
     for (int k = 0; k < 5 && rc == ZK_OK; k++) {
-        hipStream_t rs = (ord[k] == 0 || (k & 1) == 0) ? s_red : ctx->stream;
+        hipStream_t rs = small_jobs ? job_stream(ord[k]) : ((ord[k] == 0 || (k & 1) == 0) ? s_red : ctx->stream);
         if (begun && ord[k] == 0) continue;                 // B in G2's chain went out with zk_groth16_msms_begin_dev
         rc = zk_msm_enqueue_reduce(ctx, J[ord[k]], rs);
     }
