@@ -184,12 +184,13 @@ def test_many_public_inputs_with_window_multiples(ctx):
     pk.free()
 
 
-def test_hint_next_front_prefetch(ctx):
+@pytest.mark.parametrize("n", [(1 << 16) + 50, (1 << 15) + 7])
+def test_hint_next_front_prefetch(ctx, n):
     """zk_groth16_hint_next_dev: a proof enqueues the announced next proof's front (z-sort, witness map, H-sort) behind its
     own kernels.  Proof bytes must not change: a queue of three different assignments proved with hints equals the same
     queue without; a hint that does not come true (another assignment follows) is dropped; a hint followed by a batch MSM
-    on the same context is dropped too."""
-    n = (1 << 16) + 50
+    on the same context is dropped too.  D = 2^17: the accumulate kernels queue on the accumulate stream; D = 2^16: every job's
+    kernel runs on the stream of its own reduce chain (groth16_pipeline.hip: small_jobs) and the front's ordering rests on events."""
     rng = O.Prng(4711)
     mont = lambda v: cv.fr_to_mont([v])[0]
     td = [mont(rng.fr()) for _ in range(7)]
