@@ -36,15 +36,17 @@ constexpr uint32_t G_NONE = 0xffffffffu;
 
 struct GroupGeom { uint32_t W, NB, merged, n_tab, tab_off, NBt, F, NC; };
 
-// words of (canonical scalar + bias) of scalar i into column `col` of kw (9 x G_TILE words)
-__device__ __forceinline__ void load_scalar_words(const void* scalars, size_t i, const Bias& bias, uint32_t (*kw)[G_TILE], uint32_t col) {
+// words of (canonical scalar + bias) of scalar i into column `col` of kw (9 x TW words)
+template <uint32_t TW>
+__device__ __forceinline__ void load_scalar_words(const void* scalars, size_t i, const Bias& bias, uint32_t (*kw)[TW], uint32_t col) {
     uint32_t w9[9];
     scalar_biased_words(scalars, i, bias, w9);
 #pragma unroll
     for (int k = 0; k < 9; k++) kw[k][col] = w9[k];
 }
 // digit w of the scalar in column col: false for a zero digit; bucket = its id among all NBt buckets, neg = the sign bit of the entry
-__device__ __forceinline__ bool tile_digit(const uint32_t (*kw)[G_TILE], uint32_t col, const WinOff& wo, uint32_t w, const GroupGeom& g,
+template <uint32_t TW>
+__device__ __forceinline__ bool tile_digit(const uint32_t (*kw)[TW], uint32_t col, const WinOff& wo, uint32_t w, const GroupGeom& g,
                                            uint32_t& bucket, uint32_t& neg) {
     const uint32_t bit = wo.off[w], wi = bit >> 5;
     uint64_t two = kw[wi][col];
@@ -70,10 +72,10 @@ k_hist(const void* scalars, size_t n, WinOff wo, Bias bias, GroupGeom g, uint32_
             const uint32_t col = tid + k * G_NT;
             const size_t i = t0 + col;
             if (i >= n) continue;
-            load_scalar_words(scalars, i, bias, kw, col);
+            load_scalar_words<G_TILE>(scalars, i, bias, kw, col);
             for (uint32_t w = 0; w < g.W; w++) {
                 uint32_t bucket, neg;
-                if (tile_digit(kw, col, wo, w, g, bucket, neg)) atomicAdd(&cnt[bucket >> g.F], 1u);
+                if (tile_digit<G_TILE>(kw, col, wo, w, g, bucket, neg)) atomicAdd(&cnt[bucket >> g.F], 1u);
             }
         }
     }
@@ -139,47 +141,96 @@ k_scan_bins(const uint32_t* bin_count, GroupGeom g, uint32_t lanes, uint32_t seg
     }
 }
 
+// exclusive scan over the 1024 lanes of `mine` (lanes >= 2^F pass 0); wsum = 16 words of LDS
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t* wsum, uint32_t tid) {
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x = __shfl_up(inc, d, 64);
+        if ((tid & 63) >= (uint32_t)d) inc += x;
+    }
+    __syncthreads();
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (tid >> 6); w++) before += wsum[w];
+    return before + inc - mine;
+}
+
+// The scatter, staged: a block takes S_TILE scalars at a time and a group of windows whose pairs fit the LDS stage; it counts the
+// group's pairs per bin, reserves one run per bin with one global atomic, ORDERS the pairs by bin in LDS and copies the stage out
+// linearly -- consecutive lanes write consecutive words of a run, a wave's store touches a handful of lines instead of 64.
+// (Round 4's first version stored every pair straight from its lane: 13.6 M pairs x two scattered stores were 114 of the
+// kernel's 167 us at 2^20, and in the pipeline they competed with the accumulate kernel's gathers.)
+constexpr uint32_t S_TILE = 1024;        // scalars per pass of k_scatter_bins (one per lane)
+constexpr uint32_t S_WG = 8;             // windows per pass: S_TILE * S_WG pairs at most in the stage
+constexpr uint32_t S_CAP = S_TILE * S_WG;
+// LDS words: kw[9][S_TILE] | cursor[NC] | delta[NC] | wsum[16] | stage_val[S_CAP] | stage_key+bin[S_CAP] (two 16-bit halves)
+static size_t scatter_lds_bytes(uint32_t NC) { return (size_t)(9 * S_TILE + 2 * NC + 16 + 2 * S_CAP) * 4; }
+
 __global__ void __launch_bounds__(G_NT)
 k_scatter_bins(const void* scalars, size_t n, WinOff wo, Bias bias, GroupGeom g, uint32_t* cursor, uint16_t* key_lo, uint32_t* val) {
     extern __shared__ uint32_t g_lds[];
-    uint32_t (*kw)[G_TILE] = reinterpret_cast<uint32_t (*)[G_TILE]>(g_lds);
-    uint32_t* cnt = g_lds + 9 * G_TILE;
-    uint32_t* base = cnt + g.NC;
+    uint32_t (*kw)[S_TILE] = reinterpret_cast<uint32_t (*)[S_TILE]>(g_lds);
+    uint32_t* cur = g_lds + 9 * S_TILE;            // per bin: count, then the bin's cursor inside the stage
+    uint32_t* delta = cur + g.NC;                  // per bin: (start of this block's run in the bin) - (start of the bin in the stage)
+    uint32_t* wsum = delta + g.NC;
+    uint32_t* st_val = wsum + 16;
+    uint32_t* st_kb = st_val + S_CAP;              // low half: the key inside the bin, high half: the bin
     const uint32_t tid = threadIdx.x, fmask = (1u << g.F) - 1;
-    for (size_t t0 = (size_t)blockIdx.x * G_TILE; t0 < n; t0 += (size_t)gridDim.x * G_TILE) {
-        for (uint32_t b = tid; b < g.NC; b += G_NT) cnt[b] = 0;
-        __syncthreads();
-        for (uint32_t k = 0; k < 2; k++) {
-            const uint32_t col = tid + k * G_NT;
-            const size_t i = t0 + col;
-            if (i >= n) continue;
-            load_scalar_words(scalars, i, bias, kw, col);
-            for (uint32_t w = 0; w < g.W; w++) {
-                uint32_t bucket, neg;
-                if (tile_digit(kw, col, wo, w, g, bucket, neg)) atomicAdd(&cnt[bucket >> g.F], 1u);
+    const uint32_t per = (g.NC + G_NT - 1) / G_NT; // bins per lane in the scan (<= 4)
+    for (size_t t0 = (size_t)blockIdx.x * S_TILE; t0 < n; t0 += (size_t)gridDim.x * S_TILE) {
+        const size_t i = t0 + tid;
+        const bool have = i < n;
+        __syncthreads();                           // the previous tile's last pass is through with kw
+        if (have) load_scalar_words<S_TILE>(scalars, i, bias, kw, tid);
+        for (uint32_t w0 = 0; w0 < g.W; w0 += S_WG) {
+            const uint32_t w1 = min(w0 + S_WG, g.W);
+            for (uint32_t b = tid; b < g.NC; b += G_NT) cur[b] = 0;
+            __syncthreads();
+            if (have)
+                for (uint32_t w = w0; w < w1; w++) {
+                    uint32_t bucket, neg;
+                    if (tile_digit<S_TILE>(kw, tid, wo, w, g, bucket, neg)) atomicAdd(&cur[bucket >> g.F], 1u);
+                }
+            __syncthreads();
+            // exclusive scan of the counts over the bins (lane t owns bins t*per .. t*per+per-1), one global reservation per bin
+            uint32_t c[4], mine = 0;
+            for (uint32_t k = 0; k < per; k++) {
+                const uint32_t b = tid * per + k;
+                c[k] = b < g.NC ? cur[b] : 0;
+                mine += c[k];
+            }
+            uint32_t off = block_excl_scan(mine, wsum, tid);
+            __syncthreads();
+            for (uint32_t k = 0; k < per; k++) {
+                const uint32_t b = tid * per + k;
+                if (b < g.NC) {
+                    cur[b] = off;
+                    if (c[k]) delta[b] = atomicAdd(&cursor[b], c[k]) - off;
+                    off += c[k];
+                }
+            }
+            __syncthreads();
+            if (have)
+                for (uint32_t w = w0; w < w1; w++) {
+                    uint32_t bucket, neg;
+                    if (!tile_digit<S_TILE>(kw, tid, wo, w, g, bucket, neg)) continue;
+                    const uint32_t bin = bucket >> g.F;
+                    const uint32_t p = atomicAdd(&cur[bin], 1u);
+                    st_val[p] = (g.merged ? (uint32_t)(w * g.n_tab + g.tab_off + i) : (uint32_t)i) | neg;
+                    st_kb[p] = (bucket & fmask) | (bin << 16);
+                }
+            __syncthreads();
+            uint32_t cnt_all = 0;                  // block_excl_scan left the sixteen wave totals in wsum
+            for (uint32_t k = 0; k < 16; k++) cnt_all += wsum[k];
+            for (uint32_t j = tid; j < cnt_all; j += G_NT) {
+                const uint32_t kb = st_kb[j];
+                const uint32_t gp = j + delta[kb >> 16];
+                key_lo[gp] = (uint16_t)kb;
+                val[gp] = st_val[j];
             }
         }
-        __syncthreads();
-        for (uint32_t b = tid; b < g.NC; b += G_NT) {
-            const uint32_t c = cnt[b];
-            if (c) base[b] = atomicAdd(&cursor[b], c);        // this block's run inside bin b
-            cnt[b] = 0;
-        }
-        __syncthreads();
-        for (uint32_t k = 0; k < 2; k++) {
-            const uint32_t col = tid + k * G_NT;
-            const size_t i = t0 + col;
-            if (i >= n) continue;
-            for (uint32_t w = 0; w < g.W; w++) {
-                uint32_t bucket, neg;
-                if (!tile_digit(kw, col, wo, w, g, bucket, neg)) continue;
-                const uint32_t bin = bucket >> g.F;
-                const uint32_t pos = base[bin] + atomicAdd(&cnt[bin], 1u);
-                key_lo[pos] = (uint16_t)(bucket & fmask);
-                val[pos] = (g.merged ? (uint32_t)(w * g.n_tab + g.tab_off + i) : (uint32_t)i) | neg;
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -204,22 +255,6 @@ __device__ __forceinline__ uint32_t lds_inc_agg(uint32_t* arr, uint32_t key) {
 
 // LDS of the bin kernels: hist / cursors [1024] | per-wave totals [64] | bucket offsets of a long bin [1024] | stage [G_CH]
 constexpr uint32_t BINS_LDS_WORDS = 1024 + 64 + 1024 + G_CH;
-
-// exclusive scan over the 1024 lanes of `mine` (lanes >= 2^F pass 0); wsum = 16 words of LDS
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t mine, uint32_t* wsum, uint32_t tid) {
-    uint32_t inc = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t x = __shfl_up(inc, d, 64);
-        if ((tid & 63) >= (uint32_t)d) inc += x;
-    }
-    __syncthreads();
-    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < (tid >> 6); w++) before += wsum[w];
-    return before + inc - mine;
-}
 
 __global__ void __launch_bounds__(G_NT)
 k_bins_pre(const uint16_t* __restrict__ key_lo, const uint32_t* __restrict__ bin_start, const uint2* __restrict__ items,
@@ -363,7 +398,7 @@ int zk_msm_group(zk_ctx* ctx, hipStream_t st, int slot, const ZkGroupArgs& a) {
              *hdr = bins + 4 * (g.NC + 1);
     if (!ctx->flags["group_lds"]) {
         ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (9 * G_TILE + G_MAXNC) * 4));
-        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_scatter_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (9 * G_TILE + 2 * G_MAXNC) * 4));
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_scatter_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds_bytes(G_MAXNC)));
         ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_bins, hipFuncAttributeMaxDynamicSharedMemorySize, BINS_LDS_WORDS * 4));
         ctx->flags["group_lds"] = 1;
     }
@@ -374,7 +409,7 @@ int zk_msm_group(zk_ctx* ctx, hipStream_t st, int slot, const ZkGroupArgs& a) {
     hipLaunchKernelGGL(k_hist, pg, G_NT, (9 * G_TILE + g.NC) * 4, st, a.scalars, a.n, a.wo, a.bias, g, bin_count);
     hipLaunchKernelGGL(k_scan_bins, 1, G_NT, 0, st, (const uint32_t*)bin_count, g, a.lanes, a.seg_max, bin_start, cursor, items, bin_long, hdr,
                        a.ctr);
-    hipLaunchKernelGGL(k_scatter_bins, pg, G_NT, (9 * G_TILE + 2 * g.NC) * 4, st, a.scalars, a.n, a.wo, a.bias, g, cursor, key_lo, val);
+    hipLaunchKernelGGL(k_scatter_bins, pg, G_NT, scatter_lds_bytes(g.NC), st, a.scalars, a.n, a.wo, a.bias, g, cursor, key_lo, val);
     hipLaunchKernelGGL(k_bins_pre, (unsigned)max_items, G_NT, 0, st, (const uint16_t*)key_lo, (const uint32_t*)bin_start, (const uint2*)items,
                        (const uint32_t*)bin_long, (const uint32_t*)hdr, ghist);
     hipLaunchKernelGGL(k_bins, (unsigned)max_items, G_NT, BINS_LDS_WORDS * 4, st, (const uint16_t*)key_lo, (const uint32_t*)val,
