@@ -117,11 +117,12 @@ MADS_PER_BUTTERFLY = 153          # v_mad_u64_u32 per radix-2 butterfly equivale
 
 
 def msm_plan_windows(n: int) -> int:
-    """Digits per scalar of an MSM over a PLAIN table (msm.hip::make_plan): c = round(log2 n) - 4 in [4, 16], W = ceil(255 / c)."""
+    """Digits per scalar of an MSM over a PLAIN table (msm.hip::make_plan): c = round(log2 n) - 4 (- 2 up to 2^15 terms) in
+    [4, 16], W = ceil(255 / c)."""
     lg = 0
     while (3 << lg) <= 2 * n:
         lg += 1
-    c = min(16, max(4, lg - 4))
+    c = min(16, max(4, lg - (2 if lg <= 15 else 4)))
     return (255 + c - 1) // c
 
 
@@ -1107,8 +1108,8 @@ def main():
             n_msm = n  # every G1 MSM of this workload has ~n terms (h: D-1, l: n+1, a/b: n+2)
             alg_bytes = 128.0 * n_msm            # 32 B scalar + 96 B base per term
             achieved = alg_bytes / avg_s / 1e9
-            c = ctx.lib.zk_bases_window_bits(pk_bases(ctx, pk, "a").h) or max(4, min(16, n_msm.bit_length() - 1 - 4))
-            W = (255 + c - 1) // c                # digits per scalar (13 with the key's precomputed window multiples, c = 20)
+            c = ctx.lib.zk_bases_window_bits(pk_bases(ctx, pk, "a").h)
+            W = (255 + c - 1) // c if c else msm_plan_windows(n_msm)      # digits per scalar (13 with the key's window multiples, c = 20)
             madds = n_msm * W                     # mixed additions in the accumulate kernel
             mads_per_madd = MADS_PER_MADD_G1
             mads = madds * mads_per_madd

@@ -57,7 +57,10 @@ MsmPlan make_plan(size_t n, uint32_t forced_c = 0) {
     MsmPlan p;
     uint32_t lg = 0;                                   // round(log2 n)
     while (((size_t)3 << lg) <= 2 * n) lg++;           // 1.5 * 2^lg <= n  ->  round up
-    int c = (int)lg - 4;
+    // plain tables (no window multiples): up to 2^15 terms a job is a chain of latencies -- its accumulate kernel lasts as long as
+    // its fullest bucket -- and wider windows (fewer terms per bucket, more buckets for the tree-shaped reduce) shorten it:
+    // measured on whole proofs, c = lg - 2 against lg - 4: 2^10 2.24 -> 2.15 ms, 2^12 2.45 -> 2.22, 2^14 2.64 -> 2.43
+    int c = (int)lg - (lg <= 15 ? 2 : 4);
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     if (forced_c) c = (int)forced_c;
