@@ -395,6 +395,46 @@ def other_workloads(ctx, log_h=20):
     return out
 
 
+def trait_path_leg(log_d: int, resident_ms: float, proofs: int = 7):
+    """The reference-shaped boundary, composed and timed (outside the timed region): examples/host_trait_groth16.cpp is
+    src/groth16.rs:68-183,240-306 over the trait-shaped entry points only -- zk_fr_fft_in_place x7, zk_fr_batch_product_in_place,
+    zk_fr_divide_by_vanishing_on_coset_in_place, zk_msm_g1 x4, zk_msm_g2 x1, host group helpers -- with the proving key in HOST
+    vectors and freshly allocated host Vecs per proof.  A child process with its own context (this process keeps its key resident:
+    the two do not share anything but the device).  `lib` = time inside library calls; `total` adds the caller's own single-thread
+    scalar loops (evaluate_constraint, ab -= c), as the reference runs them.  First proof: every base table crosses PCIe once;
+    second: the cache builds the window multiples; from the third on: steady state.  The proofs' bytes are checked against the
+    prediction by tests/test_gpu_trait_path.py (2^10, 2^16, 2^20); here they must agree with each other."""
+    import hashlib
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "_bin", "host_trait_groth16")
+    if not os.path.exists(exe):
+        return {"error": "examples/_bin/host_trait_groth16 not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    out = {"entry_points": "zk_fr_fft_in_place x7, zk_fr_batch_product_in_place, zk_fr_divide_by_vanishing_on_coset_in_place, zk_msm_g1 x4, zk_msm_g2 x1",
+           "log_domain": log_d, "resident_api_ms": round(resident_ms, 3)}
+    for mode in (("cache", "packed"), ("cache", "strided"), ("nocache", "packed")):
+        try:
+            r = subprocess.run([exe, str(log_d), str(proofs if mode[0] == "cache" else 3), *mode], capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                out["_".join(mode)] = {"error": r.stderr[-400:]}
+                continue
+            lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+            pr, last = lines[:-1], lines[-1]
+            steady = pr[2:] if len(pr) > 3 else pr[-1:]
+            med = lambda k: round(float(np.median([p["ms"][k] for p in steady])), 3)
+            rec = {"first_call_ms": pr[0]["ms"], "second_call_ms": {k: pr[1]["ms"][k] for k in ("total", "lib")} if len(pr) > 1 else None,
+                   "steady_state_ms": {k: med(k) for k in pr[0]["ms"]}, "steady_state_over": len(steady),
+                   "same_bytes_every_proof": len(set(p["proof"] for p in pr)) == 1, "proof_sha": hashlib.sha256(bytes.fromhex(pr[0]["proof"])).hexdigest()[:16],
+                   "cache": last["cache"]}
+            rec["lib_vs_resident_api"] = round(rec["steady_state_ms"]["lib"] / resident_ms, 2) if resident_ms else None
+            out["_".join(mode)] = rec
+        except Exception as e:
+            out["_".join(mode)] = {"error": repr(e)}
+    # bytes the trait shape moves per proof (host slices in and out): 7 transforms + divide in place, the product's 2 in / 1 out, 5 scalar vectors
+    D = 1 << log_d
+    out["pcie_bytes_per_proof"] = {"fft_and_divide": 8 * 64 * D, "batch_product": 96 * D, "msm_scalars": 5 * 32 * D, "total": (8 * 64 + 96 + 160) * D}
+    return out
+
+
 def predict_proof(ctx, n, zarr, td, r_, s_, threads):
     """The oracle's known-trapdoor prediction of the 192 proof bytes for the mul-chain system (checker only: never in the
     timed region).  Returns (bytes or None, note)."""
@@ -1282,6 +1322,11 @@ def main():
                     out["natural_domain"] = natural_domain_leg(ctx, args.log_constraints, td, os.cpu_count() or 1)
             except Exception as e:
                 out["natural_domain"] = {"error": repr(e)}
+        if dist is None and not args.no_extras and not args.natural_domain:
+            try:
+                out["trait_path"] = trait_path_leg(r1cs.domain_log, dt / K * 1e3)
+            except Exception as e:
+                out["trait_path"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             sample_log = args.cpu_sample_log if args.cpu_sample_log is not None else args.log_constraints
             out["cpu_baseline"] = cpu_baseline(ctx, td, sample_log, os.cpu_count() or 1, args.log_constraints)

@@ -103,6 +103,8 @@ int zk_fr_ntt_dev(zk_ctx* ctx, void* buf_dev, uint32_t log_n, int inverse, int c
 int zk_fr_fft_in_place(zk_ctx* ctx, zk_fr* vec_host, size_t n, uint32_t log_n, int inverse, int coset);
 /* EvaluationDomain::divide_by_vanishing_poly_on_coset_in_place (domain/mod.rs:183-190). */
 int zk_fr_divide_by_vanishing_on_coset_dev(zk_ctx* ctx, void* evals_dev, uint32_t log_n);
+/* Host-slice form (the trait method takes &mut [F]): 2^log_n elements in place. */
+int zk_fr_divide_by_vanishing_on_coset_in_place(zk_ctx* ctx, zk_fr* evals_host, uint32_t log_n);
 
 /* ---- variable-base MSM (rows a5, a6) ---------------------------------------------------- */
 /* AffineCurve::multi_scalar_mul(bases, scalars) (ec/src/lib.rs:305-314) for G1 / G2:
@@ -112,6 +114,30 @@ int zk_msm_g1(zk_ctx* ctx, const zk_g1_affine* bases_host, size_t n_bases,
               const zk_fr* scalars_host, size_t n_scalars, zk_g1_projective* out_host);
 int zk_msm_g2(zk_ctx* ctx, const zk_g2_affine* bases_host, size_t n_bases,
               const zk_fr* scalars_host, size_t n_scalars, zk_g2_projective* out_host);
+/* The same on a table in the CALLER'S OWN struct layout -- arkworks' GroupAffine<P> is {x, y, infinity: bool} laid out by rustc
+ * (104 / 200 bytes per point), so a binding that wants the repr(C) form above has to copy the whole slice on every call.  Here it
+ * passes the address of the slice and where the fields sit: stride = size_of::<GroupAffine<P>>(), off_x / off_y = the byte
+ * offsets of the coordinates (Montgomery words as above; G2: c0 then c1 at off_x, off_y), off_infinity = the byte offset of the
+ * flag (non-zero = infinity) or SIZE_MAX when there is none (then all-zero coordinates mean infinity). */
+typedef struct { size_t stride, off_x, off_y, off_infinity; } zk_affine_layout;
+int zk_msm_g1_strided(zk_ctx* ctx, const void* bases_host, size_t n_bases, const zk_affine_layout* layout,
+                      const zk_fr* scalars_host, size_t n_scalars, zk_g1_projective* out_host);
+int zk_msm_g2_strided(zk_ctx* ctx, const void* bases_host, size_t n_bases, const zk_affine_layout* layout,
+                      const zk_fr* scalars_host, size_t n_scalars, zk_g2_projective* out_host);
+/* The four entry points above keep what they are shown: a base slice of >= 256 points stays resident in HBM, keyed by (group,
+ * host address, length, layout) and a 64-bit fingerprint of 64 points spread over the slice, so that the next call with the same
+ * slice -- the queries of a ProvingKey proof after proof (src/groth16.rs:106,110,193), the powers of an SRS -- reads 64 points
+ * from the host instead of uploading 96 / 192 bytes per point; from its `precompute_after`-th re-use on (default 1) a slice of
+ * >= 2^16 points also carries window multiples (zk_bases_precompute).  Base tables are key material and immutable for those
+ * callers; a host that rewrites a table IN PLACE without touching any sampled point must call zk_bases_cache_drop.
+ *   zk_bases_cache_config  budget_bytes: HBM the cache may hold, least recently used out first (default: a quarter of the device
+ *                          memory; 0 switches the cache off and frees it); precompute_after: 0 = never build window multiples
+ *   zk_bases_cache_drop    forget every table (frees the HBM)
+ *   zk_bases_cache_stats   out[0..9] = hits, misses, evictions, replaced (same address, new content), uncached uploads,
+ *                          entries, entries with window multiples, resident bytes, bytes uploaded in all, budget */
+int zk_bases_cache_config(zk_ctx* ctx, size_t budget_bytes, int precompute_after);
+int zk_bases_cache_drop(zk_ctx* ctx);
+int zk_bases_cache_stats(zk_ctx* ctx, uint64_t out[10]);
 /* Resident bases: upload once (proving-key queries), then MSM against device scalars. */
 int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* bases_host, size_t n, zk_bases** out);
 int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* bases_host, size_t n, zk_bases** out);
@@ -537,6 +563,13 @@ int zk_last_timers(zk_ctx* ctx, char* names, size_t name_stride, float* ms, int*
  * now with `launches` timed launches of a pure multiply-add kernel (~4.4 ms each) on the context stream: best and median launch.
  * This is the integer-ALU roof the MSM kernels are priced against. */
 int zk_diag_int_mad_peak(zk_ctx* ctx, int launches, double* best_mads_per_s, double* median_mads_per_s);
+/* Diagnostic: Field::pow (ff/src/fields/mod.rs: square-and-multiply from the top bit) as ONE chain of dependent DEVICE products through
+ * the field templates the kernels run -- lazy = 0: fully reduced products; lazy = 1: the lazy domain of the accumulate kernels (Fq) /
+ * of the NTT butterflies (Fr), canonicalised once at the end.  Values in the reference's Montgomery form, exponent little-endian
+ * u64 limbs.  This is how the reference's own long-chain known answers run on the GPU: Fq::multiplicative_generator().pow(T) ==
+ * two_adic_root_of_unity() (arkworks/curves/bls12_377/src/fields/tests.rs:352-370) and the same relation of fr.rs's constants. */
+int zk_diag_fq_pow_dev(zk_ctx* ctx, const zk_fq* base, const uint64_t exp[6], int lazy, zk_fq* out);
+int zk_diag_fr_pow_dev(zk_ctx* ctx, const zk_fr* base, const uint64_t exp[4], int lazy, zk_fr* out);
 
 #ifdef __cplusplus
 }

@@ -198,6 +198,27 @@ def test_msm_every_window_width(ctx, group, logs):
     bases.free(); prod.free(); dk.free(); ds.free()
 
 
+def test_short_msm_over_a_large_table_of_window_multiples(ctx):
+    """A 2^20-point table gets c = 20 (2^19 buckets, 13 windows); an MSM of 4096 .. 5041 terms over it has fewer than 2^16 digits
+    and used to fall to the counting sort, whose one-block scan cannot take more than 2^16 buckets (ZK_ERR_ARG: ADVICE round 4).
+    Sub-ranges of a resident key, Marlin commitments of a |H| = 4096 circuit over a large SRS and the crumbs of
+    zk_groth16_prove_multi all land there.  Discrete-log identity, with and without an offset."""
+    n = 1 << 20
+    rs = np.random.RandomState(9090)
+    km = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64); km[:, 3] &= np.uint64((1 << 60) - 1)
+    sm = rs.randint(0, 1 << 62, size=(8192, 4), dtype=np.uint64); sm[:, 3] &= np.uint64((1 << 60) - 1)
+    dk, ds = ctx.upload(km), ctx.upload(sm)
+    one = cv.fr_to_mont([1])[0]
+    bases = ctx.fixed_base(dk.ptr, n, 1, one)
+    bases.precompute()
+    assert ctx.lib.zk_bases_window_bits(bases.h) == 20
+    ks, sc = cv.fr_from_mont(km[:1 << 16]), cv.fr_from_mont(sm)
+    for m, off in [(4096, 0), (4097, 0), (4097, 12345), (5041, 7), (5042, 1), (6000, 31)]:
+        e = sum(s * k for s, k in zip(sc[:m], ks[off:off + m])) % O.R_MOD
+        assert cv.g1_projective_to_affine(ctx.msm_dev(bases, off, ds.ptr, m)) == O.g1_mul(O.G1_GEN, e), (m, off)
+    bases.free(); dk.free(); ds.free()
+
+
 @pytest.mark.parametrize("group,n", [(1, 5000), (1, 1 << 16), (2, 6000), (1, (1 << 16) + 77), (2, (1 << 14) + 5)])
 def test_msm_precomputed_window_multiples(ctx, group, n):
     """Resident bases with precomputed 2^(c w) multiples (one bucket set for all windows): random scalars,

@@ -124,6 +124,20 @@ def collect():
     c["serialize_sw_flags"] = {"INFINITY_BIT": {"value": inf.group(1), "at": fl.where(off + inf.start())},
                                "POSITIVE_Y_BIT": {"value": pos.group(1), "at": fl.where(off + pos.start())},
                                "BIT_SIZE": {"value": bs.group(1), "at": fl.where(off + bs.start())}}
+    # known answers the reference's OWN tests hold for long arithmetic chains (not parameters: expected outputs)
+    ft = Src("curves/bls12_377/src/fields/tests.rs")
+    m = re.search(r"fn test_fq_root_of_unity\(\).*?multiplicative_generator\(\)\s*\.pow\(\[(.*?)\]\)", ft.text, re.S)
+    assert m
+    limbs = [_int(t) for t in re.sub(r"//[^\n]*", "", m.group(1)).split(",") if t.strip()]
+    ct = Src("curves/bls12_377/src/curves/tests.rs")
+    g = re.search(r"fn test_g1_generator_raw\(\).*?assert_eq!\(i,\s*(\d+)\)", ct.text, re.S)
+    assert g
+    c["bls12_377_tests"] = {
+        "FQ_ROOT_OF_UNITY_EXPONENT": {"limbs": ["0x%016x" % l for l in limbs], "value": str(sum(l << (64 * i) for i, l in enumerate(limbs))),
+                                      "at": ft.where(m.start(1)), "claim": "Fq::multiplicative_generator().pow(this) == Fq::two_adic_root_of_unity()"},
+        "G1_GENERATOR_RAW_X": {"value": g.group(1), "at": ct.where(g.start(1)),
+                               "claim": "the point with this x and the smaller y (y < -y), scaled by the cofactor, is G1Affine::prime_subgroup_generator(); "
+                                        "every smaller x gives a point that the cofactor sends to zero"}}
     return c
 
 

@@ -107,6 +107,12 @@ PROTOTYPES = {
     "zk_fr_divide_by_vanishing_on_coset_dev": (_I, [_P, _P, _U32]),
     "zk_msm_g1": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
     "zk_msm_g2": (_I, [_P, _P, _SZ, _P, _SZ, _P]),
+    "zk_msm_g1_strided": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
+    "zk_msm_g2_strided": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
+    "zk_bases_cache_config": (_I, [_P, _SZ, _I]),
+    "zk_bases_cache_drop": (_I, [_P]),
+    "zk_bases_cache_stats": (_I, [_P, _P]),
+    "zk_fr_divide_by_vanishing_on_coset_in_place": (_I, [_P, _P, _U32]),
     "zk_bases_upload_g1": (_I, [_P, _P, _SZ, C.POINTER(_P)]),
     "zk_bases_upload_g2": (_I, [_P, _P, _SZ, C.POINTER(_P)]),
     "zk_bases_free": (_I, [_P, _P]),
@@ -237,6 +243,8 @@ PROTOTYPES = {
     "zk_set_profiling": (_I, [_P, _I]),
     "zk_last_timers": (_I, [_P, _P, _SZ, _P, _P, _I]),
     "zk_diag_int_mad_peak": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "zk_diag_fq_pow_dev": (_I, [_P, _P, _P, _I, _P]),
+    "zk_diag_fr_pow_dev": (_I, [_P, _P, _P, _I, _P]),
 }
 
 _lib = None

@@ -69,6 +69,8 @@ extern "C" int zk_ctx_destroy(zk_ctx* ctx) {
     for (auto& kv : ctx->pinned)
         if (kv.second.p) (void)hipHostFree(kv.second.p);
     zk_presort_free(ctx);
+    zk_bases_cache_free(ctx);
+    zk_xfer_free(ctx);
     zk_domains_free(ctx);
     for (auto st : ctx->aux) (void)hipStreamDestroy(st);
     if (ctx->acc_stream) (void)hipStreamDestroy(ctx->acc_stream);
@@ -131,7 +133,7 @@ extern "C" int zk_host_free(zk_ctx* ctx, void* host) {
 extern "C" int zk_memcpy_h2d(zk_ctx* ctx, void* dev, const void* host, size_t bytes) {
     ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
-    ZK_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZK_TRY(zk_xfer_h2d(ctx, dev, host, bytes, zk_host_is_pinned(host)));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZK_OK;
     ZK_API_END
@@ -140,7 +142,7 @@ extern "C" int zk_memcpy_h2d(zk_ctx* ctx, void* dev, const void* host, size_t by
 extern "C" int zk_memcpy_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes) {
     ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
-    ZK_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_TRY(zk_xfer_d2h(ctx, host, dev, bytes, zk_host_is_pinned(host)));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZK_OK;
     ZK_API_END
@@ -180,10 +182,11 @@ int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out) {
 }
 
 int zk_scratch_zeroed(zk_ctx* ctx, const char* name, size_t bytes, void** out) {
+    // (by size, not by address: a slot that grows is freed and allocated again, and the allocator may hand the old address back)
     const auto it = ctx->slots.find(name);
-    const void* before = it == ctx->slots.end() ? nullptr : it->second.p;
+    const size_t before = it == ctx->slots.end() ? 0 : it->second.bytes;
     ZK_TRY(zk_scratch(ctx, name, bytes, out));
-    if (*out != before) {
+    if (ctx->slots[name].bytes != before) {
         ZK_HIP(ctx, hipMemsetAsync(*out, 0, ctx->slots[name].bytes, ctx->stream));
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }

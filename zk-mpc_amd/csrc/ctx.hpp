@@ -112,6 +112,8 @@ struct zk_ctx {
     std::map<uint32_t, zk_domain*> domains;  // keyed by log2(size)
     std::map<std::string, int> flags;         // one-time per-context setup markers
     void* comm = nullptr;                     // RCCL communicator of this party (comm.hip), created by zk_comm_init
+    void* xfer = nullptr;                     // hostxfer.hip: the page-locked ring host slices travel through (ZkXfer)
+    void* bases_cache = nullptr;              // bases_cache.hip: resident copies of host base slices seen by zk_msm_g1 / _g2 (ZkBasesCache)
     void* presort = nullptr;                  // groth16_pipeline.hip: a sort of z[1..] enqueued ahead of zk_groth16_msms_dev (ZkPresort)
     const void* next_z = nullptr;             // groth16_pipeline.hip: zk_groth16_hint_next_dev
     // groth16_prove.hip: zk_groth16_hint_next (host-slice form): the announced assignment is uploaded on its own stream into the

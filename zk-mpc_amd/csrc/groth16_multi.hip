@@ -75,6 +75,23 @@ static int prove_multi(zk_ctx* ctx0, zk_ctx* const* ctxs, const zk_pk* const* pk
 
     // the assignment was produced on context 0's stream
     ZK_HIP(ctx0, hipStreamSynchronize(ctx0->stream));
+    // a context whose device has no peer access to context 0's gets the assignment through page-locked host memory instead
+    void* z_stage = nullptr;
+    for (int d = 1; d < n_ctx && !z_stage; d++) {
+        int peer = 1;
+        if (ctxs[d]->device != ctx0->device && (hipDeviceCanAccessPeer(&peer, ctxs[d]->device, ctx0->device) != hipSuccess || !peer)) {
+            auto& pin = ctx0->pinned[-2];
+            if (pin.bytes < m * 32) {
+                if (pin.p) (void)hipHostFree(pin.p);
+                pin.p = nullptr; pin.bytes = 0;
+                ZK_HIP(ctx0, hipHostMalloc(&pin.p, m * 32, hipHostMallocPortable));
+                pin.bytes = m * 32;
+            }
+            z_stage = pin.p;
+            ZK_HIP(ctx0, hipMemcpyAsync(z_stage, z_dev0, m * 32, hipMemcpyDeviceToHost, ctx0->stream));
+            ZK_HIP(ctx0, hipStreamSynchronize(ctx0->stream));
+        }
+    }
     std::vector<int> rc(n_ctx, ZK_OK);
     std::vector<std::vector<zk_g1_projective>> part1(n_ctx);
     std::vector<std::vector<zk_g2_projective>> part2(n_ctx);
@@ -88,7 +105,14 @@ static int prove_multi(zk_ctx* ctx0, zk_ctx* const* ctxs, const zk_pk* const* pk
         if (d > 0) {
             void* zc;
             ZK_TRY(zk_scratch(c, "multi_z", m * 32, &zc));
-            ZK_HIP(c, hipMemcpyPeerAsync(zc, c->device, z_dev0, ctx0->device, m * 32, c->stream));     // (a plain copy when both contexts share a device)
+            int peer = 1;
+            if (c->device != ctx0->device && hipDeviceCanAccessPeer(&peer, c->device, ctx0->device) != hipSuccess) peer = 0;
+            if (peer) {
+                ZK_HIP(c, hipMemcpyPeerAsync(zc, c->device, z_dev0, ctx0->device, m * 32, c->stream));     // (a plain copy when both contexts share a device)
+            } else {
+                // no peer path between the two devices: through the host copy made once below (z_stage)
+                ZK_HIP(c, hipMemcpyAsync(zc, z_stage, m * 32, hipMemcpyHostToDevice, c->stream));
+            }
             z = zc;
         }
         const char* zb = (const char*)z;

@@ -108,7 +108,9 @@ extern "C" int zk_groth16_prove_queued(zk_ctx* ctx, const zk_pk* pk, const zk_r1
         zk_presort_free(ctx);
         if (ctx->copy_stream) ZK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
         ZK_TRY(zk_scratch(ctx, ctx->z_slot ? "prove_z1" : "prove_z0", m * 32, &z));
-        ZK_HIP(ctx, hipMemcpyAsync(z, z_host, m * 32, hipMemcpyHostToDevice, ctx->stream));
+        // page-locked memory (zk_host_alloc) goes to the DMA engine as it is; anything else through the context's ring, so that
+        // the runtime never pins memory the caller is about to free (hostxfer.hip)
+        ZK_TRY(zk_xfer_h2d(ctx, z, z_host, m * 32, zk_host_is_pinned(z_host)));
     }
     ctx->next_z_host = nullptr;
     ctx->next_z_dev = nullptr;
@@ -121,8 +123,13 @@ extern "C" int zk_groth16_prove_queued(zk_ctx* ctx, const zk_pk* pk, const zk_r1
         void* zn;
         // the other slot: its last reader was the previous proof, which has delivered its bytes
         ZK_TRY(zk_scratch(ctx, ctx->z_slot ? "prove_z0" : "prove_z1", m * 32, &zn));
-        ZK_HIP(ctx, hipMemcpyAsync(zn, z_next_host, m * 32, hipMemcpyHostToDevice, ctx->copy_stream));
-        ZK_HIP(ctx, hipEventRecord(ctx->next_z_ready, ctx->copy_stream));
+        if (zk_host_is_pinned(z_next_host)) {
+            ZK_HIP(ctx, hipMemcpyAsync(zn, z_next_host, m * 32, hipMemcpyHostToDevice, ctx->copy_stream));
+            ZK_HIP(ctx, hipEventRecord(ctx->next_z_ready, ctx->copy_stream));
+        } else {                                             // pageable: staged now (the call returns behind the host copy), the DMA still overlaps
+            ZK_TRY(zk_xfer_h2d(ctx, zn, z_next_host, m * 32));
+            ZK_HIP(ctx, hipEventRecord(ctx->next_z_ready, ctx->stream));
+        }
         ctx->next_z_host = z_next_host;
         ctx->next_z_dev = zn;
         ctx->next_z = zn;

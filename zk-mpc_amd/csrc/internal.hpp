@@ -32,6 +32,21 @@ struct zk_bases {
                                // 64 = limb form, line 0 the point, line 1 its negative (fixed_base.hip::k_repack_limbs)
     std::string pre_note;      // which layout `pre` has, or why the window multiples were skipped (zk_bases_precompute_note)
 };
+// hostxfer.hip: caller-owned (pageable) host memory <-> device through the context's page-locked ring; h2d returns once the host
+// buffer has been read (the context stream waits for the DMA), d2h once the host buffer is complete
+// pinned = the caller's own page-locked memory (zk_host_alloc): one DMA on the context stream, in place
+int zk_xfer_h2d(zk_ctx* ctx, void* dev, const void* host, size_t bytes, bool pinned = false);
+int zk_xfer_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes, bool pinned = false);
+void zk_xfer_free(zk_ctx* ctx);
+bool zk_host_is_pinned(const void* host);      // page-locked by HIP (hipHostMalloc / hipHostRegister): safe to hand to hipMemcpyAsync
+// a host table in the caller's own struct layout (zk_affine_layout of the ABI); off_inf == SIZE_MAX: no flag, all-zero bytes = infinity
+struct ZkAffineLayout { size_t stride, off_x, off_y, off_inf; };
+int zk_bases_upload_host(zk_ctx* ctx, int group, const void* host, size_t n, const ZkAffineLayout* layout, zk_bases** out);   // msm.hip
+// bases_cache.hip: the resident table for a host slice -- from the context's cache (then *temporary = false and the cache owns it)
+// or freshly uploaded for this call only (*temporary = true: the caller frees it)
+int zk_bases_cache_get(zk_ctx* ctx, int group, const void* host, size_t n, const ZkAffineLayout* layout, const zk_bases** out, bool* temporary);
+void zk_bases_cache_free(zk_ctx* ctx);
+extern "C" int zk_bases_free(zk_ctx* ctx, zk_bases* b);
 extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b);   // no-op for tables under 4096 points
 int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b);             // only when ZK_PRECOMP=1 (off by default: see fixed_base.hip)
 int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,

@@ -33,6 +33,8 @@
 #include "msm_digits.cuh"
 #include <algorithm>
 #include <future>
+#include <memory>
+#include <string.h>
 #include <vector>
 
 using namespace zk;
@@ -660,7 +662,9 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     ga.n_tab = job->n_tab; ga.tab_off = job->tab_off; ga.NBt = (uint32_t)nbuck;
     ga.lanes = (uint32_t)ctx->n_cu * 4 * 64 * 2; ga.seg_max = seg;
     ga.sorted = b.sorted; ga.offs = b.offs; ga.ctr = ctr;
-    if ((size_t)W * n >= 65536 && zk_msm_group_supported(ga)) {
+    // ... and for every bucket set the counting sort's one-block-per-window scan cannot take (a short MSM over a table of
+    // window multiples with c = 20: 2^19 buckets whatever n is -- the bucket sort is correct for any total)
+    if (((size_t)W * n >= 65536 || NB > 65536) && zk_msm_group_supported(ga)) {
         const uint32_t NBt = (uint32_t)nbuck;
         ZK_TRY(zk_msm_group(ctx, st, job->slot, ga));
         hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, (const uint32_t*)nullptr, win_segs,
@@ -825,23 +829,68 @@ int msm_run_t(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void
     return rc;
 }
 
+// A host table -> a resident one.  layout == NULL: the ABI's packed form (zk_g1_affine / zk_g2_affine, all-zero = infinity);
+// otherwise the caller's own struct layout (GroupAffine<P> {x, y, infinity} as rustc lays it out): the points are gathered into the
+// packed form in page-locked memory by the context's helper threads and copied from there.
 template <class F>
-int bases_upload_t(zk_ctx* ctx, const void* host, size_t n, int group, zk_bases** out) {
+int bases_upload_t(zk_ctx* ctx, const void* host, size_t n, int group, const ZkAffineLayout* layout, zk_bases** out) {
     if (!ctx || !out || (n && !host)) return ZK_ERR_ARG;
-    zk_bases* b = new zk_bases();
+    constexpr size_t FE = F::WORDS * 4;                       // bytes per coordinate (48 / 96)
+    const size_t bytes = n * 2 * FE;
+    std::unique_ptr<zk_bases> b(new zk_bases());             // (freed on every failing exit: ADVICE r4)
     b->group = group;
     b->n = n;
-    const size_t bytes = n * 2 * F::WORDS * 4;
     if (n) {
         void* stage;
         ZK_TRY(zk_scratch(ctx, "bases_stage", bytes, &stage));
-        if (hipMalloc((void**)&b->dev, bytes) != hipSuccess) { delete b; ZK_FAIL(ctx, ZK_ERR_NOMEM, "bases upload: hipMalloc failed"); }
-        ZK_HIP(ctx, hipMemcpyAsync(stage, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_bases_import<F>, zk_grid(n, 256), 256, 0, ctx->stream, (const uint32_t*)stage, b->dev, n);
-        ZK_HIP(ctx, hipGetLastError());
-        ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const void* src = host;
+        if (layout) {
+            if (layout->stride < 2 * FE || layout->off_x + FE > layout->stride || layout->off_y + FE > layout->stride ||
+                (layout->off_inf != SIZE_MAX && layout->off_inf >= layout->stride))
+                ZK_FAIL(ctx, ZK_ERR_ARG, "strided base table: the field offsets do not fit the stride");
+            auto& pin = ctx->pinned[-3];
+            if (pin.bytes < bytes) {
+                if (pin.p) (void)hipHostFree(pin.p);
+                pin.p = nullptr; pin.bytes = 0;
+                ZK_HIP(ctx, hipHostMalloc(&pin.p, bytes, hipHostMallocDefault));
+                pin.bytes = bytes;
+            }
+            char* dst = (char*)pin.p;
+            const ZkAffineLayout lay = *layout;
+            auto pack = [=](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; i++) {
+                    const char* p = (const char*)host + i * lay.stride;
+                    char* d = dst + i * 2 * FE;
+                    if (lay.off_inf != SIZE_MAX && p[lay.off_inf]) { memset(d, 0, 2 * FE); continue; }
+                    memcpy(d, p + lay.off_x, FE);
+                    memcpy(d + FE, p + lay.off_y, FE);
+                }
+            };
+            const size_t T = n >= 65536 ? 4 : 1, per = (n + T - 1) / T;
+            {
+                std::vector<ZkTask<void>> tasks;
+                for (size_t t = 1; t < T; t++) tasks.push_back(zk_async(ctx, [=] { pack(std::min(n, t * per), std::min(n, (t + 1) * per)); }));
+                pack(0, std::min(n, per));
+            }
+            src = dst;
+        }
+        uint32_t* dev = nullptr;
+        if (hipMalloc((void**)&dev, bytes) != hipSuccess) { (void)hipGetLastError(); ZK_FAIL(ctx, ZK_ERR_NOMEM, "bases upload: hipMalloc failed"); }
+        b->dev = dev;                                        // owned by *b from here: ~unique_ptr does not free device memory, so:
+        auto fail = [&](hipError_t e) { (void)hipFree(dev); b->dev = nullptr; return e; };
+        // (the packed table is the caller's memory -- possibly a temporary copy made for this call: through the ring; the gathered
+        // one already sits in page-locked memory)
+        hipError_t e = hipSuccess;
+        if (layout) e = hipMemcpyAsync(stage, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        else if (zk_xfer_h2d(ctx, stage, src, bytes) != ZK_OK) { (void)hipFree(dev); b->dev = nullptr; return ZK_ERR_HIP; }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_bases_import<F>, zk_grid(n, 256), 256, 0, ctx->stream, (const uint32_t*)stage, b->dev, n);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) ZK_HIP(ctx, fail(e));
     }
-    *out = b;
+    *out = b.release();
     return ZK_OK;
 }
 
@@ -860,21 +909,27 @@ int bases_download_t(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, vo
     return ZK_OK;
 }
 
+// AffineCurve::multi_scalar_mul on host slices.  The bases come through the context's table cache (bases_cache.hip): a slice the
+// context has seen before -- the queries of a proving key, the powers of an SRS -- is resident already, with window multiples
+// from its second use on; only the scalars cross PCIe.
 template <class F>
-int msm_host_t(zk_ctx* ctx, const void* bases_host, size_t nb, const zk_fr* scalars, size_t ns, int group, void* out) {
+int msm_host_t(zk_ctx* ctx, const void* bases_host, size_t nb, const ZkAffineLayout* layout, const zk_fr* scalars, size_t ns, int group, void* out) {
     if (!ctx || !out) return ZK_ERR_ARG;
-    size_t n = std::min(nb, ns);  // variable_base.rs:15-17
+    const size_t n = std::min(nb, ns);  // variable_base.rs:15-17
     if (n && (!bases_host || !scalars)) return ZK_ERR_ARG;
-    zk_bases* b = nullptr;
-    ZK_TRY(bases_upload_t<F>(ctx, bases_host, n, group, &b));
-    void* sdev = nullptr;
-    int rc = ZK_OK;
-    if (n) {
-        rc = zk_scratch(ctx, "msm_scalars_host", n * 32, &sdev);
-        if (rc == ZK_OK && hipMemcpyAsync(sdev, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = ZK_ERR_HIP;
+    if (n == 0) {
+        host_write_projective<F>(aff_inf<F>(), (uint64_t*)out);
+        return ZK_OK;
     }
+    const size_t nu = nb <= 2 * n ? nb : n;                  // the whole slice (it is the cache's key) unless most of it is unused
+    const zk_bases* b = nullptr;
+    bool temporary = false;
+    ZK_TRY(zk_bases_cache_get(ctx, group, bases_host, nu, layout, &b, &temporary));
+    void* sdev = nullptr;
+    int rc = zk_scratch(ctx, "msm_scalars_host", n * 32, &sdev);
+    if (rc == ZK_OK) rc = zk_xfer_h2d(ctx, sdev, scalars, n * 32);
     if (rc == ZK_OK) rc = msm_run_t<F>(ctx, b, 0, sdev, n, out);
-    zk_bases_free(ctx, b);
+    if (temporary) zk_bases_free(ctx, const_cast<zk_bases*>(b));
     return rc;
 }
 
@@ -946,8 +1001,12 @@ int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const voi
     return msm_run_t<G2Field>(ctx, bases, base_offset, scalars_dev, n, out);
 }
 
-extern "C" int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* h, size_t n, zk_bases** out) { ZK_API_BEGIN(ctx) return bases_upload_t<G1Field>(ctx, h, n, 1, out); ZK_API_END }
-extern "C" int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* h, size_t n, zk_bases** out) { ZK_API_BEGIN(ctx) return bases_upload_t<G2Field>(ctx, h, n, 2, out); ZK_API_END }
+int zk_bases_upload_host(zk_ctx* ctx, int group, const void* host, size_t n, const ZkAffineLayout* layout, zk_bases** out) {
+    if (group == 1) return bases_upload_t<G1Field>(ctx, host, n, 1, layout, out);
+    return bases_upload_t<G2Field>(ctx, host, n, 2, layout, out);
+}
+extern "C" int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* h, size_t n, zk_bases** out) { ZK_API_BEGIN(ctx) return bases_upload_t<G1Field>(ctx, h, n, 1, nullptr, out); ZK_API_END }
+extern "C" int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* h, size_t n, zk_bases** out) { ZK_API_BEGIN(ctx) return bases_upload_t<G2Field>(ctx, h, n, 2, nullptr, out); ZK_API_END }
 extern "C" int zk_bases_free(zk_ctx* ctx, zk_bases* b) {
     ZK_API_BEGIN(ctx)
     if (!b) return ZK_OK;
@@ -975,12 +1034,33 @@ extern "C" int zk_bases_download_g2(zk_ctx* ctx, const zk_bases* b, size_t off, 
 
 extern "C" int zk_msm_g1(zk_ctx* ctx, const zk_g1_affine* bases, size_t nb, const zk_fr* scalars, size_t ns, zk_g1_projective* out) {
     ZK_API_BEGIN(ctx)
-    return msm_host_t<G1Field>(ctx, bases, nb, scalars, ns, 1, out);
+    return msm_host_t<G1Field>(ctx, bases, nb, nullptr, scalars, ns, 1, out);
     ZK_API_END
 }
 extern "C" int zk_msm_g2(zk_ctx* ctx, const zk_g2_affine* bases, size_t nb, const zk_fr* scalars, size_t ns, zk_g2_projective* out) {
     ZK_API_BEGIN(ctx)
-    return msm_host_t<G2Field>(ctx, bases, nb, scalars, ns, 2, out);
+    return msm_host_t<G2Field>(ctx, bases, nb, nullptr, scalars, ns, 2, out);
+    ZK_API_END
+}
+static bool layout_from_abi(const zk_affine_layout* l, ZkAffineLayout* o) {
+    if (!l) return false;
+    o->stride = l->stride; o->off_x = l->off_x; o->off_y = l->off_y; o->off_inf = l->off_infinity;
+    return true;
+}
+extern "C" int zk_msm_g1_strided(zk_ctx* ctx, const void* bases, size_t nb, const zk_affine_layout* layout, const zk_fr* scalars, size_t ns,
+                                 zk_g1_projective* out) {
+    ZK_API_BEGIN(ctx)
+    ZkAffineLayout lay;
+    if (!layout_from_abi(layout, &lay)) return ZK_ERR_ARG;
+    return msm_host_t<G1Field>(ctx, bases, nb, &lay, scalars, ns, 1, out);
+    ZK_API_END
+}
+extern "C" int zk_msm_g2_strided(zk_ctx* ctx, const void* bases, size_t nb, const zk_affine_layout* layout, const zk_fr* scalars, size_t ns,
+                                 zk_g2_projective* out) {
+    ZK_API_BEGIN(ctx)
+    ZkAffineLayout lay;
+    if (!layout_from_abi(layout, &lay)) return ZK_ERR_ARG;
+    return msm_host_t<G2Field>(ctx, bases, nb, &lay, scalars, ns, 2, out);
     ZK_API_END
 }
 extern "C" int zk_msm_g1_dev(zk_ctx* ctx, const zk_bases* bases, size_t off, const void* scalars, size_t n, zk_g1_projective* out) {

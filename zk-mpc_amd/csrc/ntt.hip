@@ -458,11 +458,10 @@ extern "C" int zk_fr_fft_in_place(zk_ctx* ctx, zk_fr* vec, size_t n, uint32_t lo
     if (n > N) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_fr_fft_in_place: n exceeds the domain size");
     void* d;
     ZK_TRY(zk_scratch(ctx, "fft_host", N * 32, &d));
-    ZK_HIP(ctx, hipMemcpyAsync(d, vec, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_TRY(zk_xfer_h2d(ctx, d, vec, n * 32));
     if (N > n) ZK_HIP(ctx, hipMemsetAsync((char*)d + n * 32, 0, (N - n) * 32, ctx->stream));
     ZK_TRY(zk_ntt_launch(ctx, d, log_n, inverse, coset));
-    ZK_HIP(ctx, hipMemcpyAsync(vec, d, N * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_TRY(zk_xfer_d2h(ctx, vec, d, N * 32));
     return ZK_OK;
     ZK_API_END
 }
@@ -473,6 +472,21 @@ extern "C" int zk_fr_divide_by_vanishing_on_coset_dev(zk_ctx* ctx, void* evals, 
     zk_domain* d;
     ZK_TRY(get_domain(ctx, log_n, false, &d));
     return zk_vec_scale_launch(ctx, evals, d->zinv.l, evals, (size_t)1 << log_n);
+    ZK_API_END
+}
+
+extern "C" int zk_fr_divide_by_vanishing_on_coset_in_place(zk_ctx* ctx, zk_fr* evals, uint32_t log_n) {
+    ZK_API_BEGIN(ctx)
+    if (!ctx || !evals) return ZK_ERR_ARG;
+    const size_t N = (size_t)1 << log_n;
+    zk_domain* dom;
+    ZK_TRY(get_domain(ctx, log_n, false, &dom));
+    void* d;
+    ZK_TRY(zk_scratch(ctx, "fft_host", N * 32, &d));
+    ZK_TRY(zk_xfer_h2d(ctx, d, evals, N * 32));
+    ZK_TRY(zk_vec_scale_launch(ctx, d, dom->zinv.l, d, N));
+    ZK_TRY(zk_xfer_d2h(ctx, evals, d, N * 32));
+    return ZK_OK;
     ZK_API_END
 }
 

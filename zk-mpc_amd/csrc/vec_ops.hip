@@ -153,11 +153,10 @@ extern "C" int zk_fr_batch_product_in_place(zk_ctx* ctx, zk_fr* selfs, const zk_
     void *da, *db;
     ZK_TRY(zk_scratch(ctx, "bp_a", n * 32, &da));
     ZK_TRY(zk_scratch(ctx, "bp_b", n * 32, &db));
-    ZK_HIP(ctx, hipMemcpyAsync(da, selfs, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(ctx, hipMemcpyAsync(db, others, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZK_TRY(zk_xfer_h2d(ctx, da, selfs, n * 32));
+    ZK_TRY(zk_xfer_h2d(ctx, db, others, n * 32));
     ZK_TRY(zk_vec_op_launch(ctx, ZK_OP_MUL, da, db, da, n));
-    ZK_HIP(ctx, hipMemcpyAsync(selfs, da, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_TRY(zk_xfer_d2h(ctx, selfs, da, n * 32));
     return ZK_OK;
     ZK_API_END
 }
