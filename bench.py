@@ -370,6 +370,11 @@ def other_workloads(ctx, log_h=20):
         ctx.pooling = False
         out["marlin"] = {"error": repr(e)}
     try:
+        out["marlin_dense"] = marlin_dense_leg(ctx, min(log_h, 20) - 2)
+    except Exception as e:
+        ctx.pooling = False
+        out["marlin_dense"] = {"error": repr(e)}
+    try:
         N, batch = 1024, 2048
 
         def rnd753(k):
@@ -393,6 +398,47 @@ def other_workloads(ctx, log_h=20):
     except Exception as e:
         out["she"] = {"error": repr(e)}
     return out
+
+
+def marlin_dense_leg(ctx, log_h: int):
+    """Marlin::prove on a CIRCUIT-SHAPED system (tools/synth_r1cs.py): 3-5 / 1-2 / 2-4 terms per row of A / B / C, non-unit
+    coefficients, 7 public inputs, so that AHPForR1CS::index sizes K = 4 |H| (arkworks/marlin/src/ahp/indexer.rs:138-181) and the
+    round-3 interpolation domain is 16 |H| -- what the reference's circuits look like under Marlin, where the mul-chain row above has
+    |K| = |H|.  |H| = 2^log_h.  The emitted bytes go through the oracle's Marlin::verify."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth_r1cs as S
+    from zk_mpc_amd import marlin as DM
+    from zk_mpc_amd.api import Rng
+    import zk_mpc_amd.convert as cv2
+    t0 = time.time()
+    ni, nw, ra, rb, rc, zvals = S.sized_for_domain(log_h, 20260)
+    nv, nc = ni + nw, len(ra)
+    pad = [[]] * (nv - nc)                                     # make_matrices_square: dummy constraints 0 * 0 = 0
+    a, b, c = (DM.Csr.from_rows(m + pad) for m in (ra, rb, rc))
+    t_gen = time.time() - t0
+    index = DM.Index(ctx, ni, nw, a, b, c)
+    beta_srs, g_k, gg_k, h_k = 0x7654321, 3, 7, 5
+    srs = DM.UniversalSrs(ctx, DM.ahp_max_degree(index) + 5, beta_srs, g_k, gg_k)
+    keys = DM.IndexKeys(index, srs)
+    z = ctx.upload(cv2.fr_to_mont(zvals))
+    ctx.pooling = True
+    seed = bytes(range(32))
+    proof_bytes = DM.prove_native(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
+    ctx.sync()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        proof_bytes = DM.prove_native(keys, z, Rng.from_seed(seed, 20), mask_on_device=True)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    ctx.pooling = False
+    ctx.drop_pool()
+    rec = {"workload": "Marlin::prove, circuit-shaped R1CS (3-5 / 1-2 / 2-4 terms per row, non-unit coefficients, 7 public inputs): "
+                       "|H| = 2^%d, |K| = 2^%d, round-3 domain 2^%d" % (log_h, index.dom_k.log, index.dom_b.log),
+           "constraints": nc, "non_zero": [a.nnz, b.nnz, c.nnz], "ms_per_proof": round(dt * 1e3, 2), "constraints_per_s": round(nc / dt, 1),
+           "entry_point": "zk_marlin_prove", "proof_bytes": len(proof_bytes), "generate_system_s": round(t_gen, 1)}
+    rec.update(marlin_oracle_verdict(ctx, index, keys, srs, z, proof_bytes, beta_srs, g_k, gg_k, h_k))
+    return rec
 
 
 def trait_path_leg(log_d: int, resident_ms: float, proofs: int = 7):

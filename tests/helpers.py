@@ -52,3 +52,21 @@ def td_mont(td):
 
 def mont1(v):
     return cv.fr_to_mont([v])[0]
+
+
+def circuit_system(spec, seed):
+    """A circuit-shaped R1CS with its assignment (tools/synth_r1cs.py: 3-5 / 1-2 / 2-4 terms per row of A / B / C, non-unit
+    coefficients, several public inputs, |K| = 4 |H| under Marlin).  spec: log2 |H| of the padded system, or (rows, n_pub, n_free)."""
+    import synth_r1cs as S
+    ni, nw, a, b, c, z = S.sized_for_domain(spec, seed) if isinstance(spec, int) else S.circuit_shaped(*spec, seed)
+    return O.R1CS(ni, nw, a, b, c), z
+
+
+def marlin_test_system(n, rng):
+    """n: int -> the mul-chain of that many constraints; "dense<k>" -> a circuit-shaped system filling |H| = 2^k;
+    "tiny<r>" -> r circuit-shaped rows with 3 public inputs and 2 free witnesses."""
+    if isinstance(n, str) and n.startswith("dense"):
+        return circuit_system(int(n[5:]), rng.u64() & 0xffffffff)
+    if isinstance(n, str) and n.startswith("tiny"):
+        return circuit_system((int(n[4:]), 3, 2), rng.u64() & 0xffffffff)
+    return O.mul_chain_r1cs(n, rng.fr(), rng.fr())

@@ -8,7 +8,7 @@ import marlin_ref as M
 import zkref as O
 import zk_mpc_amd.convert as cv
 import pyseq.marlin_seq as DM
-from helpers import mont1
+from helpers import marlin_test_system, mont1
 
 pytestmark = pytest.mark.gpu
 
@@ -16,8 +16,10 @@ LABELS_INDEX = [m + s for m in "abc" for s in ("_row", "_col", "_val", "_row_col
 
 
 def build(ctx, n, seed):
+    """n: an int (the mul-chain of SURVEY 8d: one term per row, unit coefficients, |K| = |H|) or "dense<k>" / "tiny<r>" (circuit-shaped:
+    multi-term rows, non-unit coefficients, several public inputs, A / B / C of different density, |K| up to 4 |H|: helpers.py)."""
     rng = O.Prng(seed)
-    r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
+    r1cs, z = marlin_test_system(n, rng)
     sq, zz = M.pad_and_square(r1cs, z)
     dix = DM.Index(ctx, sq.num_instance, sq.num_witness, DM.Csr.from_rows(sq.a), DM.Csr.from_rows(sq.b), DM.Csr.from_rows(sq.c))
     return rng, r1cs, sq, zz, dix
@@ -32,9 +34,14 @@ def run_device(ctx, dix, zz, rnd, ch):
     return polys, st
 
 
-@pytest.mark.parametrize("n", [3, 6, 13, 40])
+@pytest.mark.parametrize("n", [3, 6, 13, 40, "tiny5", "tiny11", "dense5", "dense6"])
 def test_rounds_match_oracle(ctx, n):
-    rng, r1cs, sq, zz, dix = build(ctx, n, 800 + n)
+    """Index polynomials (row / col / val / row_col of A*, B*, C*) and the nine round polynomials, coefficient for coefficient."""
+    rng, r1cs, sq, zz, dix = build(ctx, n, 800 + (n if isinstance(n, int) else len(n) * 7 + int(n[-1])))
+    if not isinstance(n, int):
+        nnz = [sum(len(r) for r in m) for m in (sq.a, sq.b, sq.c)]
+        assert max(nnz) > min(nnz) and dix.dom_k.size >= 2 * dix.dom_h.size and sq.num_instance >= 4     # the shape the mul-chain never has
+        assert any(c not in (1,) for row in sq.a for c, _ in row)
     oix = M.Index(sq)
     for label, want in oix.polynomials().items():
         assert DM.download_poly(ctx, dix.polynomials()[label]) == want, label
@@ -60,10 +67,10 @@ def test_unsatisfied_system_is_rejected(ctx):
         run_device(ctx, dix, zz, rnd, ch)
 
 
-@pytest.mark.parametrize("n", [1000, 5000])
+@pytest.mark.parametrize("n", [1000, 5000, "dense10"])
 def test_sumcheck_equations_hold_at_size(ctx, n):
     """Beyond what the Python oracle proves in seconds: the device's polynomials satisfy the verifier's equations."""
-    rng, r1cs, sq, zz, dix = build(ctx, n, 820 + n)
+    rng, r1cs, sq, zz, dix = build(ctx, n, 820 + (n if isinstance(n, int) else 10))
     md = 3 * dix.dom_h.size - 1
     rnd = [rng.fr() for _ in range(3 + md + 1)]
     ch = {k: rng.fr() for k in ("alpha", "eta_a", "eta_b", "eta_c", "beta", "gamma")}
@@ -169,7 +176,7 @@ def _oracle_keys(oix, beta, g_k, gg_k, h_k, extra=3):
     return MF.Keys(oix, pp)
 
 
-@pytest.mark.parametrize("n", [3, 6, 13])
+@pytest.mark.parametrize("n", [3, 6, 13, "tiny7", "dense5"])
 def test_marlin_proof_bytes_equal_the_oracle_prover(ctx, n):
     """Marlin::prove on the device (marlin.py::prove: Fiat-Shamir through the library's FiatShamirRng<Blake2s>, MarlinKZG10
     commitments with hiding and degree bounds, open_combinations) against the oracle's Python prover from the same ChaCha20 prover
@@ -177,14 +184,14 @@ def test_marlin_proof_bytes_equal_the_oracle_prover(ctx, n):
     import fsrng_ref as FR
     import marlin_full_ref as MF
     from zk_mpc_amd.api import Rng
-    rng, r1cs, sq, zz, dix = build(ctx, n, 4000 + n)
+    rng, r1cs, sq, zz, dix = build(ctx, n, 4000 + (n if isinstance(n, int) else 90 + int(n[-1])))
     oix = M.Index(sq)
     beta, g_k, gg_k, h_k = rng.fr(), rng.fr(), rng.fr(), rng.fr()
     okeys = _oracle_keys(oix, beta, g_k, gg_k, h_k)
     srs = DM.UniversalSrs(ctx, okeys.max_degree, beta, g_k, gg_k)
     dkeys = DM.IndexKeys(dix, srs)
     assert dkeys.ivk_bytes() == okeys.ivk_bytes()
-    seed = bytes((7 * i + n) & 0xff for i in range(32))
+    seed = bytes((7 * i + (n if isinstance(n, int) else 5)) & 0xff for i in range(32))
     got = DM.prove(dkeys, ctx.upload(cv.fr_to_mont(zz)), Rng.from_seed(seed, 20))
     want = MF.prove(okeys, zz, FR.ChaChaRng(seed, 20))
     assert got.evaluations == want.evaluations
@@ -196,7 +203,7 @@ def test_marlin_proof_bytes_equal_the_oracle_prover(ctx, n):
     assert not MF.verify(okeys, [(pub[0] + 1) % O.R_MOD] + pub[1:], dev_as_oracle)
 
 
-@pytest.mark.parametrize("n", [1000, (1 << 14) - 3])
+@pytest.mark.parametrize("n", [1000, (1 << 14) - 3, "dense12", "dense16"])
 def test_marlin_proof_verifies_at_size(ctx, n):
     """Beyond what the Python prover does in seconds: the oracle's VERIFIER (transcript re-derived from the proof, the two
     sum-check combinations, degree-bound adjustments, one pairing equation per query point) accepts the device's proof, given
@@ -204,12 +211,16 @@ def test_marlin_proof_verifies_at_size(ctx, n):
     and a tampered evaluation."""
     import marlin_full_ref as MF
     from zk_mpc_amd.api import Rng
-    rng, r1cs, sq, zz, dix = build(ctx, n, 5000 + (n & 0xff))
+    rng, r1cs, sq, zz, dix = build(ctx, n, 5000 + ((n & 0xff) if isinstance(n, int) else int(n[5:])))
+    if not isinstance(n, int):
+        assert dix.dom_k.size == 4 * dix.dom_h.size == 4 << int(n[5:]) and dix.num_instance == 8
     beta, g_k, gg_k, h_k = rng.fr(), rng.fr(), rng.fr(), rng.fr()
     max_degree = DM.ahp_max_degree(dix) + 5
     srs = DM.UniversalSrs(ctx, max_degree, beta, g_k, gg_k)
     dkeys = DM.IndexKeys(dix, srs)
-    proof = DM.prove(dkeys, ctx.upload(cv.fr_to_mont(zz)), Rng.from_seed(bytes(range(32)), 20), mask_on_device=(n > 1000))
+    proof = DM.prove(dkeys, ctx.upload(cv.fr_to_mont(zz)), Rng.from_seed(bytes(range(32)), 20), mask_on_device=(not isinstance(n, int) or n > 1000))
+    if not isinstance(n, int):          # the one-call prover on the same index, same generator: the same bytes
+        assert DM.prove_native(dkeys, ctx.upload(cv.fr_to_mont(zz)), Rng.from_seed(bytes(range(32)), 20), mask_on_device=True) == proof.serialize(ctx)
 
     class PP:                                        # what the verifier key holds (kzg10::VerifierKey), from the toxic waste
         pass
@@ -231,13 +242,13 @@ def test_marlin_proof_verifies_at_size(ctx, n):
     assert len(proof.serialize(ctx)) == 8 + 3 * 8 + 9 * 49 + 2 * 48 + 8 + 7 * 32 + 8 + 3 + 8 + 2 * 49 + 32 + 1
 
 
-@pytest.mark.parametrize("n", [3, 13, 1000])
+@pytest.mark.parametrize("n", [3, 13, 1000, "tiny9", "dense8"])
 def test_native_marlin_prove_equals_the_python_sequence(ctx, n):
     """zk_marlin_prove (one C++ entry point) emits the bytes of marlin.py::prove (the ~200-call sequence the collaborative
     provers build on) from the same prover rng -- and, through it, of the oracle's prover at the small sizes -- for the
     host-drawn and the device-sampled mask polynomial; an unsatisfied system is refused."""
     from zk_mpc_amd.api import Rng
-    rng, r1cs, sq, zz, dix = build(ctx, n, 6000 + n)
+    rng, r1cs, sq, zz, dix = build(ctx, n, 6000 + (n if isinstance(n, int) else 77 + int(n[-1])))
     srs = DM.UniversalSrs(ctx, DM.ahp_max_degree(dix) + 2, rng.fr(), rng.fr(), rng.fr())
     keys = DM.IndexKeys(dix, srs)
     z = ctx.upload(cv.fr_to_mont(zz))

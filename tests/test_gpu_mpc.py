@@ -585,7 +585,8 @@ class _SumRng:
         return cv.fr_to_mont(tot) if n else np.zeros((0, 4), dtype=np.uint64)
 
 
-@pytest.mark.parametrize("n_parties,n,spdz,mask_dev", [(2, 6, False, False), (3, 40, False, True), (2, 13, True, True), (8, 21, True, False)])
+@pytest.mark.parametrize("n_parties,n,spdz,mask_dev", [(2, 6, False, False), (3, 40, False, True), (2, 13, True, True), (8, 21, True, False),
+                                                      (3, "dense5", False, False), (3, "dense6", True, False), (3, "tiny9", True, True)])
 def test_collaborative_marlin_full_proof(n_parties, n, spdz, mask_dev):
     """MpcMarlin::prove as a PROOF (src/marlin.rs:56): each party runs the rounds on its shares with its own generator, the
     witness-dependent commitments / evaluations / opening witnesses are revealed (MAC-checked under SPDZ), the transcript
@@ -595,8 +596,9 @@ def test_collaborative_marlin_full_proof(n_parties, n, spdz, mask_dev):
     import marlin_ref as M
     import pyseq.marlin_seq as DM
     from zk_mpc_amd.api import Rng
-    rng = O.Prng(7700 + n + n_parties)
-    r1cs, z = O.mul_chain_r1cs(n, rng.fr(), rng.fr())
+    from helpers import marlin_test_system
+    rng = O.Prng(7700 + (n if isinstance(n, int) else 50 + int(n[-1])) + n_parties)
+    r1cs, z = marlin_test_system(n, rng)          # an int: the mul-chain; "dense<k>" / "tiny<r>": circuit-shaped rows, |K| > |H|, several inputs
     sq, zz = M.pad_and_square(r1cs, z)
     zs = additive_shares(zz, n_parties, rng, public_prefix=sq.num_instance)
     zm = additive_shares(zz, n_parties, rng, public_prefix=sq.num_instance)
