@@ -1200,11 +1200,18 @@ def main():
             mads_per_madd = MADS_PER_MADD_G1
             mads = madds * mads_per_madd
             traffic, traffic_src = None, None
-            try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), not measured live
-                for f in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/), not measured live; a file collected on
+                # OTHER kernel sources than the ones this run executes is refused (tools/pmc_traffic.py records their hash)
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import pmc_traffic as PT
+                for f in ("r5_pmc_traffic.json", "r4_pmc_traffic.json"):
                     pth = os.path.join(ROOT, "profiles", f)
                     if os.path.exists(pth) and args.log_constraints == 20 and not args.natural_domain:
-                        ks = json.load(open(pth))["kernels"]
+                        doc = json.load(open(pth))
+                        if doc.get("kernel_sources_sha256") != PT.sources_sha256():
+                            traffic_src = "profiles/%s REFUSED: collected on other kernel sources than this run's (hash %s)" % (f, str(doc.get("kernel_sources_sha256"))[:12])
+                            continue
+                        ks = doc["kernels"]
                         traffic = (ks.get("k_accum<G1, true>") or ks["k_accum<G1>"])["hbm_bytes"]      # (limb-form tables: the <F, true> instance)
                         traffic_src = "profiles/" + f
                         break

@@ -471,3 +471,36 @@ def test_one_prover_over_several_contexts(ctx, n, n_ctx):
     finally:
         for c in others:
             c.close()
+
+
+def test_one_prover_deal_with_a_boundary_crumb_on_wide_window_tables(ctx):
+    """zk_groth16_prove_multi's deal leaves remainder pieces of 4096 .. 5041 terms; over a key of ~2^20 points (window
+    multiples with c = 20: 2^19 buckets) such a piece has fewer than 2^16 digits and used to fall to the counting sort, which cannot
+    scan more than 2^16 buckets (ZK_ERR_ARG).  n = 1 031 045 constraints over 5 contexts deals context 2 a 5 041-term tail of the
+    B-in-G2 job (found with a Python port of the deal; the library's own plan is asserted below).  Same bytes as one context."""
+    import zk_mpc_amd as Z
+    n, n_ctx = 1031045, 5
+    rng = O.Prng(8191)
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    td = [mont(rng.fr()) for _ in range(7)]
+    others = [Z.Context(0) for _ in range(n_ctx - 1)]
+    ctxs = [ctx] + others
+    try:
+        drs = [c.r1cs_mul_chain(n) for c in ctxs]
+        pks = [c.groth16_setup(dr, *td) for c, dr in zip(ctxs, drs)]
+        assert ctx.lib.zk_bases_window_bits(pks[0].query_bases("b_g2_query").h) == 20
+        plan = ctx.multi_plan(pks[0], drs[0], n_ctx)
+        crumbs = [(c, j, lo, m) for (c, j, lo, m) in plan if 4096 <= m <= 5041]
+        assert crumbs, plan
+        z = ctx.mul_chain_assignment_dev(n, mont(rng.fr()), mont(rng.fr()))
+        r, s = mont(rng.fr()), mont(rng.fr())
+        single = ctx.create_proof_dev(pks[0], drs[0], z.ptr, r, s)
+        assert ctx.create_proof_multi(others, pks, drs, z.ptr, r, s) == single
+        for pk in pks:
+            pk.free()
+        for dr in drs:
+            dr.free()
+        z.free()
+    finally:
+        for c in others:
+            c.close()

@@ -239,39 +239,52 @@ fn check(rc: i32) {
     }
 }
 
-// GroupAffine<P> is {x, y, infinity: bool} with Rust layout: copy into the #[repr(C)] form, infinity <-> all zero
-fn g1_repr(b: &[G1Affine]) -> Vec<ZkG1Affine> {
-    b.iter().map(|p| if p.infinity { ZkG1Affine { x: ZkFq { l: [0; 6] }, y: ZkFq { l: [0; 6] } } }
-                     else { ZkG1Affine { x: ZkFq { l: (p.x.0).0 }, y: ZkFq { l: (p.y.0).0 } } }).collect()
-}
-fn g2_repr(b: &[G2Affine]) -> Vec<ZkG2Affine> {
-    b.iter().map(|p| if p.infinity { ZkG2Affine { x: [ZkFq { l: [0; 6] }; 2], y: [ZkFq { l: [0; 6] }; 2] } }
-                     else { ZkG2Affine { x: [ZkFq { l: (p.x.c0.0).0 }, ZkFq { l: (p.x.c1.0).0 }], y: [ZkFq { l: (p.y.c0.0).0 }, ZkFq { l: (p.y.c1.0).0 }] } }).collect()
+// GroupAffine<P> is {x, y, infinity: bool} as rustc lays it out (104 / 200 bytes per point for BLS12-377): the library reads the
+// caller's slice IN PLACE -- stride and field offsets are taken off a value, whatever order rustc chose -- so nothing is copied per
+// call, and the slice's address keys the library's resident copy (zk_bases_cache_*): a proving key's queries cross PCIe once.
+fn layout_of<T, X, Y>(sample: &T, x: &X, y: &Y, infinity: &bool) -> ZkAffineLayout {
+    let base = sample as *const T as usize;
+    ZkAffineLayout { stride: std::mem::size_of::<T>(), off_x: x as *const X as usize - base, off_y: y as *const Y as usize - base,
+                     off_infinity: infinity as *const bool as usize - base }
 }
 
 // ---- 1. AffineCurve::multi_scalar_mul (arkworks/algebra/ec/src/lib.rs:305-318); min(len) rule inside (msm/variable_base.rs:15-17) ----
 pub fn multi_scalar_mul_g1(bases: &[G1Affine], scalars: &[Fr]) -> G1Projective {
-    let b = g1_repr(bases);
     let mut out = ZkG1Projective { x: ZkFq { l: [0; 6] }, y: ZkFq { l: [0; 6] }, z: ZkFq { l: [0; 6] } };
-    CTX.with(|c| check(unsafe { zk_msm_g1(*c, b.as_ptr(), b.len(), scalars.as_ptr() as *const ZkFr, scalars.len(), &mut out) }));
+    if let Some(p) = bases.first() {
+        let lay = layout_of(p, &p.x, &p.y, &p.infinity);
+        CTX.with(|c| check(unsafe { zk_msm_g1_strided(*c, bases.as_ptr() as *const c_void, bases.len(), &lay, scalars.as_ptr() as *const ZkFr, scalars.len(), &mut out) }));
+    } else {
+        CTX.with(|c| check(unsafe { zk_msm_g1(*c, std::ptr::null(), 0, scalars.as_ptr() as *const ZkFr, scalars.len(), &mut out) }));
+    }
     G1Projective::new(ark_ff::Fp384::new(ark_ff::BigInteger384(out.x.l)), ark_ff::Fp384::new(ark_ff::BigInteger384(out.y.l)),
                       ark_ff::Fp384::new(ark_ff::BigInteger384(out.z.l)))
 }
 pub fn multi_scalar_mul_g2(bases: &[G2Affine], scalars: &[Fr]) -> G2Projective {
-    let b = g2_repr(bases);
     let z6 = ZkFq { l: [0; 6] };
     let mut out = ZkG2Projective { x: [z6; 2], y: [z6; 2], z: [z6; 2] };
-    CTX.with(|c| check(unsafe { zk_msm_g2(*c, b.as_ptr(), b.len(), scalars.as_ptr() as *const ZkFr, scalars.len(), &mut out) }));
+    if let Some(p) = bases.first() {
+        let lay = layout_of(p, &p.x, &p.y, &p.infinity);          // Fq2 is {c0, c1}: c0 then c1 at off_x / off_y (quadratic_extension.rs)
+        CTX.with(|c| check(unsafe { zk_msm_g2_strided(*c, bases.as_ptr() as *const c_void, bases.len(), &lay, scalars.as_ptr() as *const ZkFr, scalars.len(), &mut out) }));
+    } else {
+        CTX.with(|c| check(unsafe { zk_msm_g2(*c, std::ptr::null(), 0, scalars.as_ptr() as *const ZkFr, scalars.len(), &mut out) }));
+    }
     let f = |a: &[ZkFq; 2]| ark_bls12_377::Fq2::new(ark_ff::Fp384::new(ark_ff::BigInteger384(a[0].l)), ark_ff::Fp384::new(ark_ff::BigInteger384(a[1].l)));
     G2Projective::new(f(&out.x), f(&out.y), f(&out.z))
 }
+// a host that rewrites a base table in place (never done by the reference: keys and SRS are immutable) says so
+pub fn bases_changed_in_place() { CTX.with(|c| check(unsafe { zk_bases_cache_drop(*c) })); }
 
 // ---- 2. EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place (poly/src/domain/mod.rs:78,89,138,154; radix2/mod.rs:98-114) ----
 pub fn fft_family_in_place(coeffs: &mut Vec<Fr>, size: usize, log_size: u32, inverse: bool, coset: bool) {
     coeffs.resize(size, Fr::zero());
     CTX.with(|c| check(unsafe { zk_fr_fft_in_place(*c, coeffs.as_mut_ptr() as *mut ZkFr, coeffs.len(), log_size, inverse as i32, coset as i32) }));
 }
-// EvaluationDomain::divide_by_vanishing_poly_on_coset_in_place (poly/src/domain/mod.rs:183-190): a device-resident vector
+// EvaluationDomain::divide_by_vanishing_poly_on_coset_in_place (poly/src/domain/mod.rs:183-190): the host slice, or a device-resident vector
+pub fn divide_by_vanishing_poly_on_coset_in_place(evals: &mut [Fr], log_size: u32) {
+    assert_eq!(evals.len(), 1usize << log_size);
+    CTX.with(|c| check(unsafe { zk_fr_divide_by_vanishing_on_coset_in_place(*c, evals.as_mut_ptr() as *mut ZkFr, log_size) }));
+}
 pub fn divide_by_vanishing_poly_on_coset_dev(evals_dev: *mut c_void, log_size: u32) {
     CTX.with(|c| check(unsafe { zk_fr_divide_by_vanishing_on_coset_dev(*c, evals_dev, log_size) }));
 }

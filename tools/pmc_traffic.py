@@ -7,10 +7,23 @@ on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane loads, so fetched b
 k_vec_op: 2 x 32 MiB read -> FETCH_SIZE 32 MiB).  hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE."""
 import csv
 import glob
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# what the accumulate kernels are made of: a traffic file belongs to ONE state of these sources (bench.py refuses another)
+KERNEL_SOURCES = ["msm.hip", "msm_sort.hip", "msm_g2pair.hip", "msm_reduce.cuh", "msm_digits.cuh", "fixed_base.hip", "ec.cuh", "fp29.cuh"]
+
+
+def sources_sha256():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "zk-mpc_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def short(name):
@@ -56,7 +69,8 @@ def main():
         wb = w / nw * 1024 if nw else 0.0
         kernels[k] = {"launches_sampled": nf or nw, "FETCH_SIZE_bytes": int(fb), "fetch_bytes_corrected": int(2 * fb),
                       "write_bytes": int(wb), "hbm_bytes": int(2 * fb + wb)}
-    json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes). " + note +
+    json.dump({"kernel_sources_sha256": sources_sha256(), "kernel_sources": KERNEL_SOURCES,
+               "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes). " + note +
                " Values are per-launch averages in bytes; fetch_bytes_corrected = 2 x FETCH_SIZE (gfx950 correction, "
                "MI355X_MICROARCH.md HBM section); hbm_bytes = fetch_bytes_corrected + write_bytes.", "kernels": kernels},
               open(out, "w"), indent=1)

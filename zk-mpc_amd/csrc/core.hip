@@ -53,6 +53,15 @@ extern "C" int zk_ctx_create(int device, int party_id, int n_parties, zk_ctx** o
     }
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+    // the bucket sort and the transforms stage up to 144 KiB per workgroup in LDS: CDNA4 (gfx950, 160 KiB).  On anything smaller
+    // every MSM of 2^16 digits and every transform would fail at its first launch; say so here instead
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0 && lds < 147456) {
+        fprintf(stderr, "libzkmpc_hip: device %d offers %d bytes of LDS per workgroup; this library is written for gfx950 (160 KiB)\n", device, lds);
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return ZK_ERR_HIP;
+    }
     *out = c;
     return ZK_OK;
     ZK_API_END
