@@ -128,7 +128,7 @@ int zk_msm_g2_strided(zk_ctx* ctx, const void* bases_host, size_t n_bases, const
  * host address, length, layout) and a 64-bit fingerprint of 64 points spread over the slice, so that the next call with the same
  * slice -- the queries of a ProvingKey proof after proof (src/groth16.rs:106,110,193), the powers of an SRS -- reads 64 points
  * from the host instead of uploading 96 / 192 bytes per point; from its `precompute_after`-th re-use on (default 1) a slice of
- * >= 2^16 points also carries window multiples (zk_bases_precompute).  Base tables are key material and immutable for those
+ * >= 256 points also carries window multiples (zk_bases_precompute).  Base tables are key material and immutable for those
  * callers; a host that rewrites a table IN PLACE without touching any sampled point must call zk_bases_cache_drop.
  *   zk_bases_cache_config  budget_bytes: HBM the cache may hold, least recently used out first (default: a quarter of the device
  *                          memory; 0 switches the cache off and frees it); precompute_after: 0 = never build window multiples
@@ -144,8 +144,8 @@ int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* bases_host, size_t n, zk
 int zk_bases_free(zk_ctx* ctx, zk_bases* b);
 /* Trade HBM for work on a resident table: store 2^(c w) * base_i for w < ceil(255 / c), c ~ log2(n) capped at 20
  * (13x the memory at 2^20), so that all digits of later MSMs share ONE bucket set and a scalar has 13 digits instead
- * of 16.  No-op for tables under 4096 points.  zk_pk_upload / zk_groth16_setup apply it to proving-key queries of
- * >= 2^16 points unless ZK_PRECOMP=0 (measured at 2^20: 35.9 -> 32.4 ms per proof). */
+ * of 16; small tables get windows of ~log2(n) + 2 bits: latency, not throughput).  No-op for tables under 256 points.
+ * zk_pk_upload / zk_groth16_setup apply it to proving-key queries of >= 256 points unless ZK_PRECOMP=0 (measured at 2^20: 35.9 -> 32.4 ms per proof). */
 int zk_bases_precompute(zk_ctx* ctx, zk_bases* b);
 /* The same with the table's memory layout chosen by the caller instead of by the memory budget (tests, diagnostics): 0 = as
  * zk_bases_precompute; 1 = packed; 2 = one 96-byte point per 128-byte line (G1); 3 = 29-bit limbs with both signs, 256 bytes per

@@ -198,6 +198,37 @@ def test_msm_every_window_width(ctx, group, logs):
     bases.free(); prod.free(); dk.free(); ds.free()
 
 
+@pytest.mark.parametrize("group,n", [(1, 256), (1, 300), (1, 1023), (1, 2047), (1, 4095), (2, 256), (2, 1000), (2, 3000)])
+def test_window_multiples_of_small_tables(ctx, group, n):
+    """Round 5: tables of 256 .. 4095 points carry window multiples too (windows of ~log2(n) + 2 bits, ONE bucket set: the host's
+    Horner chain over ~30 windows was a third of a small proof).  Uniform, 0/1-heavy, all-equal and extreme scalars, a sub-range
+    that still takes the merged path (>= n / 8 terms) and one that does not; discrete-log identity."""
+    rs = np.random.RandomState(group * 1000 + n)
+    km = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64); km[:, 3] &= np.uint64((1 << 60) - 1)
+    dk = ctx.upload(km)
+    one = cv.fr_to_mont([1])[0]
+    bases = ctx.fixed_base(dk.ptr, n, group, one)
+    bases.precompute()
+    c = ctx.lib.zk_bases_window_bits(bases.h)
+    assert 9 <= c <= 16, c
+    ks = cv.fr_from_mont(km)
+    r = O.R_MOD
+    gen_mul = (lambda e: O.g1_mul(O.G1_GEN, e)) if group == 1 else (lambda e: O.g2_mul(O.G2_GEN, e))
+    to_aff = cv.g1_projective_to_affine if group == 1 else cv.g2_projective_to_affine
+    sets = {"uniform": [int.from_bytes(rs.bytes(40), "little") % r for _ in range(n)],
+            "bits": [int(rs.randint(0, 2)) if i % 9 else int.from_bytes(rs.bytes(40), "little") % r for i in range(n)],
+            "equal": [12345678901234567890123] * n,
+            "extreme": [(r - 1 - i) if i % 2 else (1 << (i % 253)) for i in range(n)],
+            "zero": [0] * n}
+    for name, sc in sets.items():
+        ds = ctx.upload(cv.fr_to_mont(sc))
+        for off, m in ((0, n), (3, n - 3), (n // 2, n // 4), (5, 10)):
+            e = sum(s * k for s, k in zip(sc[:m], ks[off:off + m])) % r
+            assert to_aff(ctx.msm_dev(bases, off, ds.ptr, m)) == gen_mul(e), (name, off, m, c)
+        ds.free()
+    bases.free(); dk.free()
+
+
 def test_short_msm_over_a_large_table_of_window_multiples(ctx):
     """A 2^20-point table gets c = 20 (2^19 buckets, 13 windows); an MSM of 4096 .. 5041 terms over it has fewer than 2^16 digits
     and used to fall to the counting sort, whose one-block scan cannot take more than 2^16 buckets (ZK_ERR_ARG: ADVICE round 4).

@@ -52,8 +52,7 @@ def test_trait_path_proof_is_the_predicted_proof(tmp_path, log_d):
     c = last["cache"]
     # five slices: first proof 5 misses, then 15 hits; slices of >= 2^16 points got their window multiples on the first hit
     assert (c["misses"], c["hits"], c["entries"], c["replaced"], c["uncached"]) == (5, 15, 5, 0, 0)
-    # h_query and l_query have D - 1 points, the three `query[1..]` slices D: window multiples from 2^16 points on
-    assert c["with_window_multiples"] == {10: 0, 16: 3, 20: 5}[log_d]
+    assert c["with_window_multiples"] == 5            # (from 256 points on: small tables are where the host's Horner chain hurts most)
     D = 1 << log_d
     assert c["uploaded_bytes"] == 96 * (2 * (D - 1) + 2 * D) + 192 * D                  # every table crossed PCIe exactly once
     if log_d >= 16:

@@ -13,7 +13,7 @@
 //            as they were, must call zk_bases_cache_drop (or switch the cache off: zk_bases_cache_config(ctx, 0, 0)).
 //   budget   bytes of HBM the cache may hold (plain tables + window multiples), least recently used out first; a table larger
 //            than the budget is uploaded for its call only, as before.  Default: a quarter of the device memory.
-//   multiples  when a slice of >= 2^16 points is seen for the `precompute_after`-th time after its upload (default: the first hit)
+//   multiples  when a slice of >= 256 points is seen for the `precompute_after`-th time after its upload (default: the first hit)
 //            its window multiples are built (fixed_base.hip: 13x the memory at 2^20, one bucket set, 13 digits instead of 16):
 //            a key's queries are worth it from the second proof on, a one-off slice never pays for them.
 // Counters (hits, misses, evictions, bytes uploaded, ...) are read with zk_bases_cache_stats.
@@ -149,7 +149,7 @@ int zk_bases_cache_get(zk_ctx* ctx, int group, const void* host, size_t n, const
         x.hits++;
         x.last = ++c->tick;
         c->hits++;
-        if (c->precompute_after > 0 && !x.pre_tried && x.hits >= (uint32_t)c->precompute_after && n >= ((size_t)1 << 16)) {
+        if (c->precompute_after > 0 && !x.pre_tried && x.hits >= (uint32_t)c->precompute_after && n >= ZK_PRECOMP_MIN_POINTS) {
             x.pre_tried = true;                               // (one attempt: a table skipped for lack of memory stays plain)
             make_room(ctx, c, (group == 1 ? 50 : 14) * x.bytes, x.b);   // 13 window multiples: G1 in 256-byte limb slots (35x the plain table, the packed copy beside it while it is built), G2 packed
             ZK_TRY(zk_bases_precompute(ctx, x.b));

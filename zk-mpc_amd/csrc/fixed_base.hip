@@ -276,15 +276,23 @@ extern "C" int zk_fixed_base_g2_dev(zk_ctx* ctx, const zk_fr* gen_k, const void*
 static uint32_t precompute_window_bits(size_t n) {
     uint32_t lg = 0;                                   // round(log2 n): a 2^20 - 1 point query is a 2^20 one
     while (((size_t)3 << lg) <= 2 * n) lg++;
-    int c0 = (int)lg - 1;      // measured on whole proofs: 2^16 -> 15, 2^18 -> 16/17, 2^20..2^22 -> 20 (22 loses: 4x the buckets)
-    if (c0 < 13) c0 = 13;
-    if (c0 > 20) c0 = 20;
-    const int tries[6] = {0, -1, 1, -2, 2, -3};
+    // >= 2^16 points, measured on whole proofs: 2^16 -> 15, 2^18 -> 16/17, 2^20..2^22 -> 20 (22 loses: 4x the buckets).
+    // Smaller tables (round 5: the reference's own circuits are 2^2 .. 2^15 constraints) are latency, not throughput: a window
+    // of lg + 2 bits leaves ~W / 4 = 4-5 terms per bucket (the accumulate kernel lasts as long as its fullest bucket) and ONE
+    // bucket set means the host's Horner chain over ~30 windows -- 0.7 ms of a 2 ms proof at 2^10 -- shrinks to ~2 log2(NB) additions.
+    int c0 = lg >= 16 ? (int)lg - 1 : (int)lg + 2;
+    const int lo = lg >= 16 ? 13 : 9, hi = lg >= 16 ? 20 : 16;
+    if (c0 < lo) c0 = lo;
+    if (c0 > hi) c0 = hi;
+    // the top window must keep enough significant bits: 255 - c (W - 1) of only 3 bits (c = 18, 21) sends every point into <= 8
+    // buckets (2^20 points: the sort's atomics serialise, 65 ms instead of 32); for a small table 2^(top - 1) buckets >= n / 16 do
+    const int need = std::min(10, std::max(3, (int)lg - 3));
+    const int tries[9] = {0, -1, 1, -2, 2, -3, 3, 4, 5};
     for (int t : tries) {
         int c = c0 + t;
-        if (c < 12 || c > 20) continue;
+        if (c < lo - 1 || c > 20) continue;
         int W = (255 + c - 1) / c;
-        if (255 - c * (W - 1) >= 10) return (uint32_t)c;
+        if (255 - c * (W - 1) >= need) return (uint32_t)c;
     }
     return 16;
 }
@@ -295,14 +303,14 @@ static int precompute_enabled_by_default() {
 }
 // Resident proving-key queries get their window multiples at upload / setup time (ZK_PRECOMP=0 turns it off).
 int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b) {
-    return (precompute_enabled_by_default() && b && b->n >= ((size_t)1 << 16)) ? zk_bases_precompute(ctx, b) : ZK_OK;
+    return (precompute_enabled_by_default() && b && b->n >= ZK_PRECOMP_MIN_POINTS) ? zk_bases_precompute(ctx, b) : ZK_OK;
 }
 
 extern "C" uint32_t zk_bases_window_bits(const zk_bases* b) { return b ? b->c_pre : 0; }
 
 static int precompute_run(zk_ctx* ctx, zk_bases* b, int layout) {
     if (!ctx || layout < 0 || layout > 3) return ZK_ERR_ARG;
-    if (!b || b->pre || b->n < 4096) return ZK_OK;
+    if (!b || b->pre || b->n < ZK_PRECOMP_MIN_POINTS) return ZK_OK;
     const uint32_t c = precompute_window_bits(b->n);
     const uint32_t W = (255 + c - 1) / c;
     if (b->group == 1) return precompute_t<G1Field>(ctx, b, c, W, layout);

@@ -92,7 +92,10 @@ class ZkProofTail {
     zk::Affine<H1> a0, alpha, b0, beta1;
     zk::Affine<H2> b02, beta2;
     X1 g_a, s_g_a, r_s_delta, r_g1_b;
+    X1 r_g1, s_g1;                                   // delta r, delta s, delta_2 s: they depend on the key and on r, s only, and start
+    X2 s_g2;                                         // with the proof (pre_*), under the device's work, not behind it
     zk::Affine<H2> b_aff;
+    ZkTask<void> pre_a, pre_b, pre_2;                // (the chains wait for them; declared first = joined last)
     ZkTask<void> chain_a, chain_b, chain_g2;         // (last members: joined before the fields the chains write go)
 
    public:

@@ -537,7 +537,9 @@ int msm_prepare_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base
     if (n == 0) return ZK_OK;
     if (base_offset + n > bases->n) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: base range out of bounds");
     if (n >= ((size_t)1 << 27)) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: n must be < 2^27");
-    const bool merged = bases->pre != nullptr && n >= 4096;
+    // window multiples: one bucket set of 2^(c_pre - 1) buckets whatever n is -- worth it when this MSM uses a fair share of the
+    // table (a 100-term MSM over a 2^20-point table would reduce 2^19 buckets for nothing)
+    const bool merged = bases->pre != nullptr && (n >= 4096 || n * 8 >= bases->n);
     const MsmPlan p = make_plan(n, merged ? bases->c_pre : 0);
     job->c = p.c; job->W = p.W; job->NB = p.NB;
     for (int i = 0; i < 65; i++) job->off[i] = p.off[i];
