@@ -126,8 +126,16 @@ int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const vo
     // front does not lean on the accumulate stream: that front waits for every job's reduce_done / accum_done event.)
     const bool small_jobs = !begun && D <= ((size_t)1 << 16);
     auto job_stream = [&](int k) -> hipStream_t { return k == 0 ? s_acc : ((k & 1) ? s_sort : ctx->stream); };
-    for (int k = 0; k < 5 && rc == ZK_OK; k++)
+    // ... and where the four G1 jobs qualify (tables of window multiples with the same bucket count: every key of >= 256 points)
+    // they are ONE accumulate launch and one launch per level of the reduce chain, on the sort stream (round 5: two jobs per stream,
+    // one behind the other, were 2 x (0.26 + 0.2) ms of a 1.2 ms proof at 2^10)
+    ZkMsmJob* g1jobs[4] = {J[1], J[2], J[3], J[4]};
+    const bool grouped = small_jobs && rc == ZK_OK && zk_msm_group_ok(g1jobs, 4);
+    for (int k = 0; k < 5 && rc == ZK_OK; k++) {
+        if (grouped && ord[k] != 0) continue;
         if (!begun || ord[k] == 4) rc = zk_msm_enqueue_accum(ctx, J[ord[k]], small_jobs ? job_stream(ord[k]) : s_acc);
+    }
+    if (grouped && rc == ZK_OK) rc = zk_msm_enqueue_accum_group(ctx, g1jobs, 4, s_sort);
     // B-in-G2's reduce chain (the long one) stays on the sort stream; the four G1 reduces go to the main stream, idle by
     // then, so that each runs right behind its own accumulate kernel instead of queueing behind the G2 chain (that
     // queueing left 4 x 0.7 ms of reduces after the last accumulate).
@@ -137,8 +145,10 @@ int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const vo
     for (int k = 0; k < 5 && rc == ZK_OK; k++) {
         hipStream_t rs = small_jobs ? job_stream(ord[k]) : ((ord[k] == 0 || (k & 1) == 0) ? s_red : ctx->stream);
         if (begun && ord[k] == 0) continue;                 // B in G2's chain went out with zk_groth16_msms_begin_dev
+        if (grouped && ord[k] != 0) continue;
         rc = zk_msm_enqueue_reduce(ctx, J[ord[k]], rs);
     }
+    if (grouped && rc == ZK_OK) rc = zk_msm_enqueue_reduce_group(ctx, g1jobs, 4, s_sort);
     // The caller announced the next assignment (zk_groth16_hint_next_dev): enqueue that proof's front now, behind this
     // proof's kernels.  Its z-sort goes on the accumulate stream (in order behind the five accumulate kernels, the readers of
     // this proof's sort products; it also waits for the reduce chains, whose fold kernels read the segment tables), its

@@ -320,10 +320,9 @@ k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t
 #ifndef ZK_ACCUM_WAVES_G2
 #define ZK_ACCUM_WAVES_G2 1
 #endif
-template <class F, bool LIMB_TABLE = false>
-__global__ void __launch_bounds__(256, (F::WORDS == 12 ? ZK_ACCUM_WAVES_G1 : ZK_ACCUM_WAVES_G2))
-k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
-        const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums, uint32_t stride) {
+template <class F, bool LIMB_TABLE>
+__device__ __forceinline__ void accum_body(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
+                                           const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums, uint32_t stride) {
     // stride: words between consecutive points of `bases` (2 * WORDS packed; 32 for a G1 table of window multiples: one point per line)
     // The NEXT point is fetched as raw words while the current one is added and unpacked into limbs only when its turn comes: the
     // wait for the gather then sits behind a whole mixed addition.  (Fetching it in unpacked form put the wait, and the unpacking,
@@ -380,6 +379,22 @@ k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
         }
         xyzz_store16<F>(sums, d.dst, acc);
     }
+}
+template <class F, bool LIMB_TABLE = false>
+__global__ void __launch_bounds__(256, (F::WORDS == 12 ? ZK_ACCUM_WAVES_G1 : ZK_ACCUM_WAVES_G2))
+k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
+        const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums, uint32_t stride) {
+    accum_body<F, LIMB_TABLE>(bases, sorted, desc, order, ctr, sums, stride);
+}
+// A GROUP of small jobs as one launch (blockIdx.y = job): a job of 2^10 .. 2^15 terms fills a tenth of the chip for the length of
+// its longest segment; four of them one behind the other on a stream were most of a small proof's device time.
+constexpr int MSM_GROUP_MAX = GRID_SRC_MAX;
+struct AccumArgs { const uint32_t* bases; const uint32_t* sorted; const SegDesc* desc; const uint32_t* order; const uint32_t* ctr; uint32_t* sums; uint32_t stride; };
+struct AccumGroup { AccumArgs j[MSM_GROUP_MAX]; };
+template <class F, bool LIMB_TABLE>
+__global__ void __launch_bounds__(256, (F::WORDS == 12 ? ZK_ACCUM_WAVES_G1 : ZK_ACCUM_WAVES_G2)) k_accum_group(AccumGroup g) {
+    const AccumArgs& a = g.j[blockIdx.y];
+    accum_body<F, LIMB_TABLE>(a.bases, a.sorted, a.desc, a.order, a.ctr, a.sums, a.stride);
 }
 
 // LDS staging of one XYZZ point per lane, word-major (word k of lane t at lds[k * NT + t]): consecutive lanes hit
@@ -440,8 +455,7 @@ __device__ __forceinline__ void fold_block(uint32_t* lds, uint32_t* sums, uint32
 }
 
 template <class F>
-__global__ void __launch_bounds__(64)
-k_fold(const HeavyDesc* heavy, const HeavyDesc* heavy2, const uint32_t* ctr, uint32_t* done, uint32_t* sums, uint32_t light_blocks) {
+__device__ __forceinline__ void fold_body(const HeavyDesc* heavy, const HeavyDesc* heavy2, const uint32_t* ctr, uint32_t* done, uint32_t* sums, uint32_t light_blocks) {
     extern __shared__ uint32_t lds[];  // 64 * XW words (heavy blocks only)
     __shared__ uint32_t last_flag;
     const uint32_t nheavy = ctr[0];
@@ -475,6 +489,18 @@ k_fold(const HeavyDesc* heavy, const HeavyDesc* heavy2, const uint32_t* ctr, uin
         }
         __syncthreads();
     }
+}
+template <class F>
+__global__ void __launch_bounds__(64)
+k_fold(const HeavyDesc* heavy, const HeavyDesc* heavy2, const uint32_t* ctr, uint32_t* done, uint32_t* sums, uint32_t light_blocks) {
+    fold_body<F>(heavy, heavy2, ctr, done, sums, light_blocks);
+}
+struct FoldArgs { const HeavyDesc* heavy; const HeavyDesc* heavy2; const uint32_t* ctr; uint32_t* done; uint32_t* sums; };
+struct FoldGroup { FoldArgs j[MSM_GROUP_MAX]; };
+template <class F>
+__global__ void __launch_bounds__(64) k_fold_group(FoldGroup g, uint32_t light_blocks) {
+    const FoldArgs& a = g.j[blockIdx.y];
+    fold_body<F>(a.heavy, a.heavy2, a.ctr, a.done, a.sums, light_blocks);
 }
 
 // The bucket reduction proper is msm_reduce.cuh (row / column sums of the bucket grid, then bit sums); this is its point policy
@@ -560,7 +586,9 @@ int msm_prepare_t(zk_ctx* ctx, ZkMsmJob* job, const zk_bases* bases, size_t base
     // chain -- seg mixed additions by one lane, ~9 us each -- stays a small part of the kernel.
     const size_t lanes = (size_t)ctx->n_cu * 4 * 64 * 2;
     const size_t per_lane = ((size_t)n * p.W + lanes - 1) / lanes;
-    uint32_t seg = 32;
+    // (a small MSM is a chain of latencies: its accumulate kernel lasts as long as its longest segment -- 16 - 20 terms in the
+    // buckets of a 7-bit top window at 2^10, 0.25 ms -- so segments of 8; the halves of a split bucket meet in k_fold)
+    uint32_t seg = (size_t)n * p.W <= ((size_t)1 << 19) ? 8 : 32;
     while (seg < per_lane && seg < 4096) seg <<= 1;
     job->seg = seg;
     // Reduce phase geometry (msm_reduce.cuh): every bucket set is a grid of 2^rl x 2^cl buckets, rl + cl = log2(NB)
@@ -745,8 +773,8 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
         hipLaunchKernelGGL(k_fold<F>, light_blocks + heavy_blocks, 64, 64 * XW * 4, st, (const HeavyDesc*)job->heavy, (const HeavyDesc*)job->heavy2,
                            (const uint32_t*)job->ctr, b.fold_done, b.sums, light_blocks);
         const GridGeom gg = make_grid_geom(job->log_nb, job->Wb, RedG1::PTS);
-        hipLaunchKernelGGL(k_grid_l1<RedG1>, gg.row_blocks + gg.col_blocks, RedG1::NT, RedG1::PTS * XW * 4, st, (const uint32_t*)b.sums,
-                           b.rowP, b.colP, gg);
+        hipLaunchKernelGGL(k_grid_l1<RedG1>, gg.row_blocks + gg.col_blocks, RedG1::NT, RedG1::PTS * XW * 4, st,
+                           GridSrc{{(const uint32_t*)b.sums, nullptr, nullptr, nullptr}, 0u}, b.rowP, b.colP, gg);
         hipLaunchKernelGGL(k_grid_bits<RedG1>, gg.n_win * job->nout, RedG1::NT, RedG1::PTS * XW * 4, st, (const uint32_t*)b.rowP,
                            (const uint32_t*)b.colP, b.bits, gg);                                                      // 48 KiB of LDS each
     }
@@ -765,6 +793,103 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     // finish() waits for this event, not for the stream: later jobs' reduce phases may be queued behind on the same stream
     ZK_HIP(ctx, hipEventCreateWithFlags(&job->reduce_done, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventRecord(job->reduce_done, st));
+    return ZK_OK;
+}
+
+// ---- a group of small G1 jobs: one accumulate launch, one launch per level of the reduce chain ----------------------------------
+// Conditions (zk_msm_group_ok): G1, 2 .. MSM_GROUP_MAX jobs, every one sorted already, over tables of window multiples in the same
+// layout (one bucket set each, the same number of buckets).  The jobs keep their own sort products and bucket sums; row / column
+// partials and bit sums of the group live in the FIRST job's slot (sized for the group), and one copy brings all of them back.
+static bool msm_group_ok(ZkMsmJob* const* jobs, int count) {
+    if (count < 2 || count > MSM_GROUP_MAX) return false;
+    for (int k = 0; k < count; k++) {
+        const ZkMsmJob* j = jobs[k];
+        if (j->group != 1 || j->n == 0 || j->Wb != 1 || j->log_nb != jobs[0]->log_nb || (j->stride == 64) != (jobs[0]->stride == 64) || !j->sort_done) return false;
+        if ((size_t)j->n * j->W > ((size_t)1 << 21)) return false;       // (a job that fills the chip by itself gains nothing from company)
+    }
+    return true;
+}
+
+static int msm_enqueue_accum_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st) {
+    using F = G1Field;
+    AccumGroup g{};
+    size_t max_segs = 0;
+    for (int k = 0; k < count; k++) {
+        ZkMsmJob* job = jobs[k];
+        MsmBufs<F> b;
+        ZK_TRY(msm_bufs_t<F>(ctx, job, b, false));
+        ZK_HIP(ctx, hipStreamWaitEvent(st, job->sort_done, 0));
+        g.j[k] = AccumArgs{job->bases_dev, job->sorted, (const SegDesc*)job->desc, job->order, job->ctr, b.sums, job->stride};
+        max_segs = std::max(max_segs, job->max_segs);
+    }
+    for (int k = count; k < MSM_GROUP_MAX; k++) g.j[k] = g.j[0];
+    ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
+    jobs[0]->timers.push_back(tm);
+    tm->begin("msm_g1.accum");
+    const dim3 grid((unsigned)((max_segs + 255) / 256), (unsigned)count);
+    if (jobs[0]->stride == 64) hipLaunchKernelGGL((k_accum_group<F, true>), grid, 256, 0, st, g);
+    else hipLaunchKernelGGL((k_accum_group<F, false>), grid, 256, 0, st, g);
+    ZK_HIP(ctx, hipGetLastError());
+    tm->end();
+    for (int k = 0; k < count; k++) {
+        ZK_HIP(ctx, hipEventCreateWithFlags(&jobs[k]->accum_done, hipEventDisableTiming));
+        ZK_HIP(ctx, hipEventRecord(jobs[k]->accum_done, st));
+    }
+    return ZK_OK;
+}
+
+static int msm_enqueue_reduce_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st) {
+    using F = G1Field;
+    constexpr size_t XW = 4 * F::WORDS;
+    FoldGroup fg{};
+    GridSrc src{};
+    src.per_log = jobs[0]->log_nb;
+    size_t max_heavy = 0;
+    for (int k = 0; k < count; k++) {
+        ZkMsmJob* job = jobs[k];
+        job->stream = st;
+        MsmBufs<F> b;
+        ZK_TRY(msm_bufs_t<F>(ctx, job, b, false));
+        ZK_HIP(ctx, hipStreamWaitEvent(st, job->accum_done, 0));
+        fg.j[k] = FoldArgs{(const HeavyDesc*)job->heavy, (const HeavyDesc*)job->heavy2, (const uint32_t*)job->ctr, b.fold_done, b.sums};
+        src.p[k] = b.sums;
+        max_heavy = std::max(max_heavy, job->max_heavy);
+    }
+    for (int k = count; k < MSM_GROUP_MAX; k++) { fg.j[k] = fg.j[0]; src.p[k] = src.p[0]; }
+    const GridGeom gg = make_grid_geom(jobs[0]->log_nb, (uint32_t)count, RedG1::PTS);
+    const uint32_t nout = jobs[0]->nout;
+    char nm[64];
+    uint32_t *rowP, *colP, *bits;
+    snprintf(nm, sizeof nm, "msm_grp_rowP.%d", jobs[0]->slot);
+    ZK_TRY(zk_scratch(ctx, nm, grid_row_points(gg) * XW * 4, (void**)&rowP));
+    snprintf(nm, sizeof nm, "msm_grp_colP.%d", jobs[0]->slot);
+    ZK_TRY(zk_scratch(ctx, nm, grid_col_points(gg) * XW * 4, (void**)&colP));
+    snprintf(nm, sizeof nm, "msm_grp_bits.%d", jobs[0]->slot);
+    ZK_TRY(zk_scratch(ctx, nm, (size_t)count * nout * XW * 4, (void**)&bits));
+    ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
+    jobs[0]->timers.push_back(tm);
+    tm->begin("msm_g1.reduce");
+    const unsigned light_blocks = (unsigned)std::min<size_t>((max_heavy + 63) / 64, 128);
+    const unsigned heavy_blocks = (unsigned)std::min<size_t>(max_heavy, 256);
+    hipLaunchKernelGGL(k_fold_group<F>, dim3(light_blocks + heavy_blocks, (unsigned)count), 64, 64 * XW * 4, st, fg, light_blocks);
+    hipLaunchKernelGGL(k_grid_l1<RedG1>, gg.row_blocks + gg.col_blocks, RedG1::NT, RedG1::PTS * XW * 4, st, src, rowP, colP, gg);
+    hipLaunchKernelGGL(k_grid_bits<RedG1>, gg.n_win * nout, RedG1::NT, RedG1::PTS * XW * 4, st, (const uint32_t*)rowP, (const uint32_t*)colP, bits, gg);
+    ZK_HIP(ctx, hipGetLastError());
+    tm->end();
+    auto& pin = ctx->pinned[jobs[0]->pin_key >= 0 ? jobs[0]->pin_key : 32 + jobs[0]->slot];
+    const size_t bytes = (size_t)MSM_GROUP_MAX * 32 * XW * 4;
+    if (pin.bytes < bytes) {
+        if (pin.p) (void)hipHostFree(pin.p);
+        pin.p = nullptr; pin.bytes = 0;
+        ZK_HIP(ctx, hipHostMalloc(&pin.p, bytes, hipHostMallocDefault));
+        pin.bytes = bytes;
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(pin.p, bits, (size_t)count * nout * XW * 4, hipMemcpyDeviceToHost, st));
+    for (int k = 0; k < count; k++) {
+        jobs[k]->hw = (uint32_t*)pin.p + (size_t)k * nout * XW;
+        ZK_HIP(ctx, hipEventCreateWithFlags(&jobs[k]->reduce_done, hipEventDisableTiming));
+        ZK_HIP(ctx, hipEventRecord(jobs[k]->reduce_done, st));
+    }
     return ZK_OK;
 }
 
@@ -993,6 +1118,9 @@ int zk_msm_enqueue_reduce(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     if (job->group == 1) return msm_enqueue_reduce_t<G1Field>(ctx, job, st);
     return msm_enqueue_reduce_t<G2Field>(ctx, job, st);
 }
+bool zk_msm_group_ok(ZkMsmJob* const* jobs, int count) { return msm_group_ok(jobs, count); }
+int zk_msm_enqueue_accum_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st) { return msm_enqueue_accum_group(ctx, jobs, count, st); }
+int zk_msm_enqueue_reduce_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st) { return msm_enqueue_reduce_group(ctx, jobs, count, st); }
 int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out) {
     if (job->group == 1) return msm_finish_t<G1Field>(ctx, job, out);
     return msm_finish_t<G2Field>(ctx, job, out);

@@ -36,6 +36,48 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
     for (size_t k = 0; k < n_jobs; k++) perm[k] = k;
     std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
     std::vector<ZkMsmJob> jobs(n_jobs);
+    // Small G1 jobs over tables of window multiples (the commitments of a Marlin round at |H| <= 2^14: 4 - 7 jobs of 0.3 ms of
+    // latency each) go in GROUPS of up to four: sorts one behind the other, then one accumulate launch and one launch per level
+    // of the reduce chain for the group (msm.hip: zk_msm_enqueue_*_group).  Group position p uses scratch slot 1 + p; a slot's
+    // next user waits for its previous user's chain.
+    {
+        bool small = n_jobs >= 2;
+        for (size_t k = 0; k < n_jobs && small; k++) {
+            const zk_bases* b = bases[k];
+            small = b->group == 1 && b->pre && lens[k] > 0 && (lens[k] >= 4096 || lens[k] * 8 >= b->n) && b->c_pre == bases[0]->c_pre &&
+                    (b->pre_stride == 64) == (bases[0]->pre_stride == 64) && lens[k] * ((255 + b->c_pre - 1) / b->c_pre) <= ((size_t)1 << 21);
+        }
+        if (small) {
+            int rc = ZK_OK;
+            constexpr size_t GM = 4;
+            for (size_t g0 = 0; g0 < n_jobs && rc == ZK_OK; g0 += GM) {
+                const size_t cnt = std::min(GM, n_jobs - g0);
+                ZkMsmJob* grp[GM];
+                for (size_t p = 0; p < cnt && rc == ZK_OK; p++) {
+                    const size_t k = g0 + p, j = perm[k];
+                    grp[p] = &jobs[k];
+                    jobs[k].pin_key = 16 + (int)k;
+                    rc = zk_msm_prepare(ctx, &jobs[k], bases[j], base_offsets ? base_offsets[j] : 0, scalars_dev[j], lens[j], 1 + (int)p);
+                    if (rc == ZK_OK && g0 && jobs[k - GM].reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(s_sort, jobs[k - GM].reduce_done, 0));
+                    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[k], s_sort, nullptr);
+                }
+                if (rc != ZK_OK) break;
+                if (cnt >= 2 && zk_msm_group_ok(grp, (int)cnt)) {
+                    rc = zk_msm_enqueue_accum_group(ctx, grp, (int)cnt, s_sort);
+                    if (rc == ZK_OK) rc = zk_msm_enqueue_reduce_group(ctx, grp, (int)cnt, s_sort);
+                } else {
+                    for (size_t p = 0; p < cnt && rc == ZK_OK; p++) {
+                        rc = zk_msm_enqueue_accum(ctx, grp[p], s_sort);
+                        if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, grp[p], s_sort);
+                    }
+                }
+            }
+            for (size_t k = 0; k < n_jobs && rc == ZK_OK; k++) rc = zk_msm_finish(ctx, &jobs[k], outs[perm[k]]);
+            (void)hipStreamSynchronize(s_sort);
+            (void)hipEventDestroy(e0);
+            return rc;
+        }
+    }
     std::vector<int> owner(n_jobs), sharer(n_jobs, -1);          // whose sort a job uses (itself unless it borrows), and who borrows a job's sort
     for (size_t k = 0; k < n_jobs; k++) owner[k] = (int)k;
     int rc = ZK_OK;

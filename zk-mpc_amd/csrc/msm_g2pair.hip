@@ -392,7 +392,7 @@ int zk_launch_reduce_g2pair(zk_ctx* ctx, hipStream_t st, const ZkG2PairReduce& a
                        a.ctr, a.done, a.sums, a.light_blocks);
     const GridGeom gg = make_grid_geom(a.log_nb, a.n_win, RedG2Pair::PTS);
     const size_t lds = (size_t)RedG2Pair::NT * 4 * FW * 4;            // 48 KiB
-    hipLaunchKernelGGL(k_grid_l1<RedG2Pair>, gg.row_blocks + gg.col_blocks, RedG2Pair::NT, lds, st, (const uint32_t*)a.sums, a.rowP, a.colP, gg);
+    hipLaunchKernelGGL(k_grid_l1<RedG2Pair>, gg.row_blocks + gg.col_blocks, RedG2Pair::NT, lds, st, GridSrc{{(const uint32_t*)a.sums, nullptr, nullptr, nullptr}, 0u}, a.rowP, a.colP, gg);
     hipLaunchKernelGGL(k_grid_bits<RedG2Pair>, gg.n_win * grid_nout(gg), RedG2Pair::NT, lds, st, (const uint32_t*)a.rowP, (const uint32_t*)a.colP,
                        a.bits, gg);
     ZK_HIP(ctx, hipGetLastError());

@@ -63,7 +63,21 @@ static inline size_t grid_row_points(const GridGeom& g) { return ((size_t)g.n_wi
 static inline size_t grid_col_points(const GridGeom& g) { return ((size_t)g.n_win << g.cl) * g.Pc; }
 static inline uint32_t grid_nout(const GridGeom& g) { return g.rl + g.cl + 1; }
 
+// Where k_grid_l1 reads its bucket sums: one buffer (per_log = 0), or -- a group of small MSMs reduced by ONE launch per level, job w
+// as "window" w -- the buffers of up to four jobs of 2^per_log buckets each (msm.hip: zk_msm_enqueue_reduce_group).
+constexpr int GRID_SRC_MAX = 4;
+struct GridSrc {
+    const uint32_t* p[GRID_SRC_MAX];
+    uint32_t per_log;
+};
+
 #ifdef __HIPCC__
+__device__ __forceinline__ const uint32_t* grid_src(const GridSrc& s, size_t& idx) {
+    if (!s.per_log) return s.p[0];
+    const uint32_t w = (uint32_t)(idx >> s.per_log);
+    idx &= ((size_t)1 << s.per_log) - 1;
+    return s.p[w];
+}
 // Both kernels run ONE loop whose body holds the only call of P::add: the serial steps (operand from memory) and the tree
 // levels (both operands from LDS) are iterations of the same loop.  A point addition is ~7 k instructions (~55 KB): two or
 // three inlined copies do not fit the instruction cache a CU pair shares, beside an accumulate kernel's own 38 KB loop.
@@ -71,7 +85,7 @@ static inline uint32_t grid_nout(const GridGeom& g) { return g.rl + g.cl + 1; }
 // rowP[(w R + hi) Pr + part], colP[(w Pc + part) C + lo]: partial sums, packed form
 template <class P>
 __global__ void __launch_bounds__(P::NT, P::MINW)
-k_grid_l1(const uint32_t* __restrict__ sums, uint32_t* __restrict__ rowP, uint32_t* __restrict__ colP, GridGeom g) {
+k_grid_l1(GridSrc sums, uint32_t* __restrict__ rowP, uint32_t* __restrict__ colP, GridGeom g) {
     extern __shared__ uint32_t grid_lds[];
     using X = typename P::X;
     const uint32_t pt = P::pt();
@@ -114,7 +128,11 @@ k_grid_l1(const uint32_t* __restrict__ sums, uint32_t* __restrict__ rowP, uint32
         uint32_t qq = 0;
         if (it < K) {
             act = gg < n_groups;
-            if (act) v = P::load(sums, base + it * step);
+            if (act) {
+                size_t idx = base + it * step;
+                const uint32_t* src = grid_src(sums, idx);
+                v = P::load(src, idx);
+            }
         } else {
             if (it == K) P::lds_put(grid_lds, pt, P::pack(acc));
             __syncthreads();

@@ -134,7 +134,7 @@ k_scan_bins(const uint32_t* bin_count, GroupGeom g, uint32_t lanes, uint32_t seg
         bin_start[g.NC] = T;
         hdr[0] = part[1][G_NT - 1];
         hdr[1] = part[2][G_NT - 1];
-        uint32_t seg = 32;
+        uint32_t seg = seg_max < 32 ? seg_max : 32;
         while (seg < seg_max && (uint64_t)seg * lanes < T) seg <<= 1;
         ctr[3] = seg;
         ctr[4] = T;
