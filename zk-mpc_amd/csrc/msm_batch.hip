@@ -58,8 +58,10 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
                     grp[p] = &jobs[k];
                     jobs[k].pin_key = 16 + (int)k;
                     rc = zk_msm_prepare(ctx, &jobs[k], bases[j], base_offsets ? base_offsets[j] : 0, scalars_dev[j], lens[j], 1 + (int)p);
-                    if (rc == ZK_OK && g0 && jobs[k - GM].reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(s_sort, jobs[k - GM].reduce_done, 0));
-                    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[k], s_sort, nullptr);
+                    // the sorts of a group are independent chains of ~10 short launches: side by side on three streams
+                    hipStream_t ss = p % 3 == 0 ? s_sort : (p % 3 == 1 ? ctx->stream : s_acc);
+                    if (rc == ZK_OK && g0 && jobs[k - GM].reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(ss, jobs[k - GM].reduce_done, 0));
+                    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[k], ss, nullptr);
                 }
                 if (rc != ZK_OK) break;
                 if (cnt >= 2 && zk_msm_group_ok(grp, (int)cnt)) {
@@ -74,6 +76,8 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
             }
             for (size_t k = 0; k < n_jobs && rc == ZK_OK; k++) rc = zk_msm_finish(ctx, &jobs[k], outs[perm[k]]);
             (void)hipStreamSynchronize(s_sort);
+            (void)hipStreamSynchronize(s_acc);
+            (void)hipStreamSynchronize(ctx->stream);
             (void)hipEventDestroy(e0);
             return rc;
         }
