@@ -302,6 +302,112 @@ k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t
     for (uint32_t s = lo + threadIdx.x; s < hi; s += blockDim.x) order[atomicAdd(&lh[desc[s].len], 1u)] = s;
 }
 
+// The whole sort of a SMALL MSM over a table of window multiples (one bucket set, <= 2^17 digits, <= 2^15 buckets) as ONE block:
+// digits -> bucket counts in LDS -> offsets, segment descriptors and the heavy list -> entries to their buckets -> segments ordered by
+// length.  It replaces four memsets and six launches (k_digits, k_scan, k_scatter, k_build_segs, k_len_scan, k_order): a small MSM
+// is a chain of launch latencies, ~10 us apiece on the sort's critical path, and the commitments of a small Marlin proof are
+// fifteen of them.  Same products as those kernels (consecutive segment numbering, as their non-flat mode).
+constexpr uint32_t SS_NT = 1024;
+constexpr uint32_t SS_MAX_ENTRIES = 1u << 17, SS_MAX_NB = 1u << 15, SS_MAX_SEG = 64;
+__global__ void __launch_bounds__(SS_NT)
+k_sort_small(const void* scalars, uint32_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, uint32_t seg, uint32_t n_tab, uint32_t tab_off,
+             uint32_t grp_base, uint32_t* dig, uint32_t* sorted, SegDesc* desc, HeavyDesc* heavy, HeavyDesc* heavy2, uint32_t* order, uint32_t* ctr) {
+    extern __shared__ uint32_t ss_lds[];
+    uint32_t* cnt = ss_lds;                       // NB: counts, later cursors
+    uint32_t* part = cnt + NB;                    // 2 x SS_NT: the block scan
+    uint32_t* lh = part + 2 * SS_NT;              // seg + 1: segments per length, later their cursors
+    uint32_t* sc = lh + (SS_MAX_SEG + 1);         // [0] heavy entries [1] heavy segments [5] second-level entries [6] group slots
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b = tid; b < NB; b += SS_NT) cnt[b] = 0;
+    for (uint32_t i = tid; i <= seg; i += SS_NT) lh[i] = 0;
+    if (tid < 8) sc[tid] = 0;
+    __syncthreads();
+    // digits
+    for (uint32_t i = tid; i < n; i += SS_NT) {
+        uint32_t w9[9];
+        scalar_biased_words(scalars, i, bias, w9);
+        for (uint32_t w = 0; w < W; w++) {
+            const uint32_t bit = wo.off[w], wi = bit >> 5;
+            uint64_t two = w9[0];
+#pragma unroll
+            for (int k = 1; k < 9; k++) if (wi == (uint32_t)k) two = w9[k];
+            uint32_t hi = 0;
+#pragma unroll
+            for (int k = 1; k < 9; k++) if (wi + 1 == (uint32_t)k) hi = w9[k];
+            two |= (uint64_t)hi << 32;
+            const int32_t d = signed_digit(two, bit, wo.off[w + 1] - bit);
+            const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+            dig[(size_t)w * n + i] = mag | (d < 0 ? 0x80000000u : 0u);
+            if (mag) atomicAdd(&cnt[mag - 1], 1u);
+        }
+    }
+    __syncthreads();
+    // offsets and segment numbers: lane t owns buckets [t per, t per + per)
+    const uint32_t per = (NB + SS_NT - 1) / SS_NT;
+    const uint32_t lo = tid * per, hi = min(lo + per, NB);
+    uint32_t s = 0, s2 = 0;
+    for (uint32_t b = lo; b < hi; b++) {
+        const uint32_t c = cnt[b];
+        s += c;
+        s2 += c ? (c + seg - 1) / seg : 1;
+    }
+    part[tid] = s;
+    part[SS_NT + tid] = s2;
+    __syncthreads();
+    for (uint32_t d = 1; d < SS_NT; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0, v2 = tid >= d ? part[SS_NT + tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        part[SS_NT + tid] += v2;
+        __syncthreads();
+    }
+    const uint32_t S = part[2 * SS_NT - 1], T = part[SS_NT - 1];
+    uint32_t run = tid ? part[tid - 1] : 0, run2 = tid ? part[SS_NT + tid - 1] : 0;
+    for (uint32_t b = lo; b < hi; b++) {
+        const uint32_t c = cnt[b];
+        cnt[b] = run;                             // from here on: the bucket's cursor
+        if (c <= seg) {
+            desc[run2] = SegDesc{run, c, b};
+            atomicAdd(&lh[c], 1u);
+            run2 += 1;
+        } else {
+            const uint32_t ns = (c + seg - 1) / seg;
+            const uint32_t dst0 = NB + atomicAdd(&sc[1], ns);
+            if (ns <= FOLD_GROUP) {
+                heavy[atomicAdd(&sc[0], 1u)] = HeavyDesc{b, dst0, ns, HEAVY_NONE};
+            } else {
+                const uint32_t ng = (ns + FOLD_GROUP - 1) / FOLD_GROUP;
+                const uint32_t g0 = grp_base + atomicAdd(&sc[6], ng), h0 = atomicAdd(&sc[0], ng), up = atomicAdd(&sc[5], 1u);
+                for (uint32_t j = 0; j < ng; j++) heavy[h0 + j] = HeavyDesc{g0 + j, dst0 + j * FOLD_GROUP, min(FOLD_GROUP, ns - j * FOLD_GROUP), up};
+                heavy2[up] = HeavyDesc{b, g0, ng, HEAVY_NONE};
+            }
+            for (uint32_t j = 0; j < ns; j++) desc[run2 + j] = SegDesc{run + j * seg, min(seg, c - j * seg), dst0 + j};
+            atomicAdd(&lh[seg], ns - 1);
+            atomicAdd(&lh[c - (ns - 1) * seg], 1u);
+            run2 += ns;
+        }
+        run += c;
+    }
+    __syncthreads();
+    // the entries to their buckets (merged form: entry = the table index of the window multiple)
+    const size_t total = (size_t)W * n;
+    for (size_t t = tid; t < total; t += SS_NT) {
+        const uint32_t d = dig[t], mag = d & 0x7fffffffu;
+        if (!mag) continue;
+        const uint32_t w = (uint32_t)(t / n), i = (uint32_t)(t - (size_t)w * n);
+        sorted[atomicAdd(&cnt[mag - 1], 1u)] = (w * n_tab + tab_off + i) | (d & 0x80000000u);
+    }
+    // segments by length, longest first: lh[len] becomes the first position of that length
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t pos = 0;
+        for (uint32_t len = seg + 1; len-- > 0;) { const uint32_t c = lh[len]; lh[len] = pos; pos += c; }
+        ctr[0] = sc[0]; ctr[1] = sc[1]; ctr[2] = S; ctr[3] = seg; ctr[4] = T; ctr[5] = sc[5]; ctr[6] = sc[6]; ctr[7] = 0;
+    }
+    __syncthreads();
+    for (uint32_t q = tid; q < S; q += SS_NT) order[atomicAdd(&lh[desc[q].len], 1u)] = q;
+}
+
 // Persistent lanes over the length-sorted segment list: the grid is exactly 2 blocks per CU and thread g
 // takes segments g, g + G, g + 2G, ... (G = total threads).  Neighbouring lanes always hold segments of
 // (nearly) equal length, every thread gets the same long-to-short mix, and -- unlike a grid with one thread
@@ -676,7 +782,8 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
     job->timers.push_back(tm);
     tm->begin(g1 ? "msm_g1.sort" : "msm_g2.sort");
-    ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 8 + 3 * (size_t)(seg + 1)) * 4, st));
+    const bool one_block = merged && (size_t)W * n <= SS_MAX_ENTRIES && NB <= SS_MAX_NB && seg <= SS_MAX_SEG;      // k_sort_small: writes all of ctr itself
+    if (!one_block) ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 8 + 3 * (size_t)(seg + 1)) * 4, st));
     const uint32_t grp_base = (uint32_t)(nbuck + job->max_heavy_segs);       // where the group sums of two-level buckets live in `sums`
     auto scans = [&](uint32_t Wx, uint32_t NBx) -> int {      // counting-sort path only: one block per window
         if (NBx > 65536) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: a bucket set of more than 2^16 buckets needs the bucket sort (>= 2^16 digits)");
@@ -694,6 +801,22 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     ga.sorted = b.sorted; ga.offs = b.offs; ga.ctr = ctr;
     // ... and for every bucket set the counting sort's one-block-per-window scan cannot take (a short MSM over a table of
     // window multiples with c = 20: 2^19 buckets whatever n is -- the bucket sort is correct for any total)
+    if (one_block) {
+        // a small MSM over window multiples: the whole sort in one block (k_sort_small)
+        const size_t lds = ((size_t)NB + 2 * SS_NT + (SS_MAX_SEG + 1) + 8) * 4;
+        if (!ctx->flags["sort_small_lds"]) {
+            ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)SS_MAX_NB + 2 * SS_NT + (SS_MAX_SEG + 1) + 8) * 4)));
+            ctx->flags["sort_small_lds"] = 1;
+        }
+        hipLaunchKernelGGL(k_sort_small, 1, SS_NT, lds, st, job->scalars, (uint32_t)n, wo, W, NB, bias, seg, job->n_tab, job->tab_off, grp_base,
+                           b.dig, b.sorted, b.desc, b.heavy, b.heavy2, b.order, ctr);
+        ZK_HIP(ctx, hipGetLastError());
+        tm->end();
+        job->sorted = b.sorted; job->desc = b.desc; job->order = b.order; job->ctr = ctr; job->heavy = b.heavy; job->heavy2 = b.heavy2;
+        ZK_HIP(ctx, hipEventCreateWithFlags(&job->sort_done, hipEventDisableTiming));
+        ZK_HIP(ctx, hipEventRecord(job->sort_done, st));
+        return ZK_OK;
+    }
     if (((size_t)W * n >= 65536 || NB > 65536) && zk_msm_group_supported(ga)) {
         const uint32_t NBt = (uint32_t)nbuck;
         ZK_TRY(zk_msm_group(ctx, st, job->slot, ga));

@@ -37,7 +37,7 @@ struct zk_domain {
 namespace {
 
 constexpr int LOGM_MAX = 10;
-constexpr int NTT_THREADS = 1024;
+constexpr int NTT_THREADS = 1024;   // (512 / 256 threads per tile, two / four butterflies per lane and stage: 2^20 in 131 / 144 us against 126: round 5)
 constexpr int TILE_ELEMS = 4096;  // x 36 B = 144 KiB of LDS
 
 struct FrK { uint32_t l[9]; };
