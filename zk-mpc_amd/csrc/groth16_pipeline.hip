@@ -189,9 +189,19 @@ int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const vo
     // finish in completion order: the host-side Horner of an early job overlaps the GPU work of the later ones
     void* outs[5] = {out_g2, &out_g1[2], &out_g1[3], &out_g1[1], &out_g1[0]};
     int abc_left = 3;
-    for (int k = 0; k < 5 && rc == ZK_OK; k++) {
-        rc = zk_msm_finish(ctx, J[ord[k]], outs[ord[k]]);
-        if (ord[k] <= 2 && --abc_left == 0 && rc == ZK_OK && after_abc) after_abc();   // A, B1, B2 are in: the caller's host work overlaps the rest
+    if (grouped && rc == ZK_OK) {
+        // the four G1 jobs of a group become ready together: their host halves side by side, B in G2's on this thread
+        void* gouts[4] = {outs[1], outs[2], outs[3], outs[4]};
+        ZkTask<int> g1fin = zk_async(ctx, [&] { (void)hipSetDevice(ctx->device); return zk_msm_finish_many(ctx, g1jobs, gouts, 4); });
+        rc = zk_msm_finish(ctx, J[0], outs[0]);
+        const int rc1 = g1fin.get();
+        if (rc == ZK_OK) rc = rc1;
+        if (rc == ZK_OK && after_abc) after_abc();
+    } else {
+        for (int k = 0; k < 5 && rc == ZK_OK; k++) {
+            rc = zk_msm_finish(ctx, J[ord[k]], outs[ord[k]]);
+            if (ord[k] <= 2 && --abc_left == 0 && rc == ZK_OK && after_abc) after_abc();   // A, B1, B2 are in: the caller's host work overlaps the rest
+        }
     }
     if (!front_enqueued) {                         // (with a front in flight the streams carry the next proof's kernels)
         (void)hipStreamSynchronize(s_sort);

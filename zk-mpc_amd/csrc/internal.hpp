@@ -99,6 +99,7 @@ int zk_msm_enqueue_reduce(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st);
 int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out_host_projective);
 // Several SMALL G1 jobs (sorted already, tables of window multiples with the same bucket count) as one accumulate launch and one
 // launch per level of the reduce chain; zk_msm_group_ok says whether a set qualifies (else: the per-job calls above)
+int zk_msm_finish_many(zk_ctx* ctx, ZkMsmJob* const* jobs, void* const* outs, int count);      // the host halves side by side
 bool zk_msm_group_ok(ZkMsmJob* const* jobs, int count);
 int zk_msm_enqueue_accum_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st);
 int zk_msm_enqueue_reduce_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st);

@@ -390,12 +390,19 @@ k_sort_small(const void* scalars, uint32_t n, WinOff wo, uint32_t W, uint32_t NB
     }
     __syncthreads();
     // the entries to their buckets (merged form: entry = the table index of the window multiple)
-    const size_t total = (size_t)W * n;
-    for (size_t t = tid; t < total; t += SS_NT) {
-        const uint32_t d = dig[t], mag = d & 0x7fffffffu;
-        if (!mag) continue;
-        const uint32_t w = (uint32_t)(t / n), i = (uint32_t)(t - (size_t)w * n);
-        sorted[atomicAdd(&cnt[mag - 1], 1u)] = (w * n_tab + tab_off + i) | (d & 0x80000000u);
+    // (four digits in flight per lane: one block has sixteen waves to hide a global load behind, and 20 - 130 entries per lane)
+    const uint32_t total = W * n;
+    for (uint32_t t0 = tid; t0 < total; t0 += 4 * SS_NT) {
+        uint32_t d[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) d[u] = t0 + u * SS_NT < total ? dig[t0 + u * SS_NT] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t mag = d[u] & 0x7fffffffu;
+            if (!mag) continue;
+            const uint32_t t = t0 + u * SS_NT, w = t / n, i = t - w * n;
+            sorted[atomicAdd(&cnt[mag - 1], 1u)] = (w * n_tab + tab_off + i) | (d[u] & 0x80000000u);
+        }
     }
     // segments by length, longest first: lh[len] becomes the first position of that length
     __syncthreads();
@@ -405,7 +412,13 @@ k_sort_small(const void* scalars, uint32_t n, WinOff wo, uint32_t W, uint32_t NB
         ctr[0] = sc[0]; ctr[1] = sc[1]; ctr[2] = S; ctr[3] = seg; ctr[4] = T; ctr[5] = sc[5]; ctr[6] = sc[6]; ctr[7] = 0;
     }
     __syncthreads();
-    for (uint32_t q = tid; q < S; q += SS_NT) order[atomicAdd(&lh[desc[q].len], 1u)] = q;
+    for (uint32_t q0 = tid; q0 < S; q0 += 4 * SS_NT) {
+        uint32_t len[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) len[u] = q0 + u * SS_NT < S ? desc[q0 + u * SS_NT].len : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (len[u] != 0xffffffffu) order[atomicAdd(&lh[len[u]], 1u)] = q0 + u * SS_NT;
+    }
 }
 
 // Persistent lanes over the length-sorted segment list: the grid is exactly 2 blocks per CU and thread g
@@ -1212,6 +1225,7 @@ void ZkPhaseTimer::resolve() {
         float ms = 0;
         if (hipEventSynchronize(e.second.second) == hipSuccess &&
             hipEventElapsedTime(&ms, e.second.first, e.second.second) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(ctx->mu);           // (the host halves of a group's jobs resolve side by side)
             ctx->timers[e.first].ms += ms;
             ctx->timers[e.first].count += 1;
         }
@@ -1240,6 +1254,22 @@ int zk_msm_enqueue_accum(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
 int zk_msm_enqueue_reduce(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     if (job->group == 1) return msm_enqueue_reduce_t<G1Field>(ctx, job, st);
     return msm_enqueue_reduce_t<G2Field>(ctx, job, st);
+}
+// The host halves of several finished jobs (wait for the copy, Horner chain, one inversion: 30 - 60 us each) side by side on the
+// helper threads: behind a group launch they all become ready at once, and four in a row were a tenth of a small proof.
+int zk_msm_finish_many(zk_ctx* ctx, ZkMsmJob* const* jobs, void* const* outs, int count) {
+    if (count < 2) {
+        for (int k = 0; k < count; k++) ZK_TRY(zk_msm_finish(ctx, jobs[k], outs[k]));
+        return ZK_OK;
+    }
+    std::vector<int> rc((size_t)count, ZK_OK);
+    {
+        std::vector<ZkTask<void>> tasks;
+        for (int k = 1; k < count; k++) tasks.push_back(zk_async(ctx, [&, k] { (void)hipSetDevice(ctx->device); rc[(size_t)k] = zk_msm_finish(ctx, jobs[k], outs[k]); }));
+        rc[0] = zk_msm_finish(ctx, jobs[0], outs[0]);
+    }
+    for (int k = 0; k < count; k++) ZK_TRY(rc[(size_t)k]);
+    return ZK_OK;
 }
 bool zk_msm_group_ok(ZkMsmJob* const* jobs, int count) { return msm_group_ok(jobs, count); }
 int zk_msm_enqueue_accum_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st) { return msm_enqueue_accum_group(ctx, jobs, count, st); }

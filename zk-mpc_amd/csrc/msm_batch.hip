@@ -74,7 +74,12 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
                     }
                 }
             }
-            for (size_t k = 0; k < n_jobs && rc == ZK_OK; k++) rc = zk_msm_finish(ctx, &jobs[k], outs[perm[k]]);
+            if (rc == ZK_OK) {
+                std::vector<ZkMsmJob*> jp(n_jobs);
+                std::vector<void*> op(n_jobs);
+                for (size_t k = 0; k < n_jobs; k++) { jp[k] = &jobs[k]; op[k] = outs[perm[k]]; }
+                rc = zk_msm_finish_many(ctx, jp.data(), op.data(), (int)n_jobs);
+            }
             (void)hipStreamSynchronize(s_sort);
             (void)hipStreamSynchronize(s_acc);
             (void)hipStreamSynchronize(ctx->stream);
