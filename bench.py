@@ -1256,15 +1256,16 @@ def main():
                 # launch time, against the issue rate of the pure multiply-add kernel measured in this run (lane-ops / 64)
                 if args.log_constraints != 20 or args.natural_domain:
                     raise KeyError("the committed counter run is of the 2^20 workload")
-                pv = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_valu.json")))["kernels"]
+                pvf = next(f for f in ("r5_pmc_valu.json", "r4_pmc_valu.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                pv = json.load(open(os.path.join(ROOT, "profiles", pvf)))["kernels"]
                 kk = next(k for k in pv if k.startswith("k_accum<G1"))
                 insts = float(pv[kk]["SQ_INSTS_VALU"])
                 peak_insts = roof["peak"] * 1e12 / 64
                 roof["int_alu"]["issue"] = {
                     "valu_wave_insts_per_launch": insts, "achieved_wave_insts_per_s": round(insts / avg_s, 1),
                     "peak_wave_insts_per_s": round(peak_insts, 1), "frac": round(insts / avg_s / peak_insts, 4),
-                    "source": "profiles/r4_pmc_valu.json (SQ_INSTS_VALU per launch of %s, not measured in this run; the count does "
-                              "not depend on what runs beside the kernel)" % kk,
+                    "source": "profiles/%s (SQ_INSTS_VALU per launch of %s, not measured in this run; the count does "
+                              "not depend on what runs beside the kernel)" % (pvf, kk),
                     "note": "every VALU instruction priced as a multiply-add slot: the share of the chip's issue rate this kernel "
                             "takes while it shares the chip with the other jobs' reduce chains, sorts and transforms"}
             except Exception:

@@ -302,13 +302,13 @@ k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t
     for (uint32_t s = lo + threadIdx.x; s < hi; s += blockDim.x) order[atomicAdd(&lh[desc[s].len], 1u)] = s;
 }
 
-// The whole sort of a SMALL MSM over a table of window multiples (one bucket set, <= 2^17 digits, <= 2^15 buckets) as ONE block:
+// The whole sort of a SMALL MSM over a table of window multiples (one bucket set, <= 2^16 digits, <= 2^15 buckets) as ONE block:
 // digits -> bucket counts in LDS -> offsets, segment descriptors and the heavy list -> entries to their buckets -> segments ordered by
 // length.  It replaces four memsets and six launches (k_digits, k_scan, k_scatter, k_build_segs, k_len_scan, k_order): a small MSM
 // is a chain of launch latencies, ~10 us apiece on the sort's critical path, and the commitments of a small Marlin proof are
 // fifteen of them.  Same products as those kernels (consecutive segment numbering, as their non-flat mode).
 constexpr uint32_t SS_NT = 1024;
-constexpr uint32_t SS_MAX_ENTRIES = 1u << 17, SS_MAX_NB = 1u << 15, SS_MAX_SEG = 64;
+constexpr uint32_t SS_MAX_ENTRIES = 1u << 16, SS_MAX_NB = 1u << 15, SS_MAX_SEG = 64;   // (70 k entries in one block: 157 us against ~105 for the six launches)
 __global__ void __launch_bounds__(SS_NT)
 k_sort_small(const void* scalars, uint32_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, uint32_t seg, uint32_t n_tab, uint32_t tab_off,
              uint32_t grp_base, uint32_t* dig, uint32_t* sorted, SegDesc* desc, HeavyDesc* heavy, HeavyDesc* heavy2, uint32_t* order, uint32_t* ctr) {
