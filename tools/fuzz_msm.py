@@ -52,7 +52,41 @@ def main():
                 bad += 1
                 print("MISMATCH it=%d group=%d n=%d off=%d kind=%d table=%s" % (it, group, n, off, kind, name), flush=True)
         ds.free()
-    print("FUZZ %s: %d cases, %d mismatches, %.1f s" % ("FAILED" if bad else "ok", iters, bad, time.time() - t0))
+    # round 5: SMALL tables (256 .. 8192 points) with their own window multiples -- one bucket set, segments of 8, the single-block
+    # sort, and, through zk_msm_batch_dev, the group launches (2 .. 7 jobs over one table: one accumulate launch, one launch per
+    # reduce level) -- every job against the inner product, the batch against the single calls
+    small = 0
+    for it in range(max(iters // 3, 10)):
+        group = 1 if rs.rand() < 0.75 else 2
+        nt = int(rs.choice([256, 257, 1000, 1024, 3000, 4095, 4096, 8192, rs.randint(256, 8192)]))
+        off_t = int(rs.randint(0, 1000))
+        tb = ctx.fixed_base(dk.ptr + off_t * 32, nt, group, one)
+        tb.precompute()
+        to_aff = cv.g1_projective_to_affine if group == 1 else cv.g2_projective_to_affine
+        gen = (lambda e: O.g1_mul(O.G1_GEN, e)) if group == 1 else (lambda e: O.g2_mul(O.G2_GEN, e))
+        jobs, wants, keep = [], [], []
+        for j in range(int(rs.randint(1, 8))):
+            n = int(rs.choice([nt, nt - 1, max(1, nt // 2), max(1, nt // 8), int(rs.randint(1, nt + 1))]))
+            off = int(rs.randint(0, nt - n + 1))
+            a = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.uint64); a[:, 3] &= np.uint64((1 << 60) - 1)
+            kind = rs.randint(0, 5)
+            pick = rs.rand(n)
+            if kind == 1: a[pick < 0.9] = 0; a[(pick >= 0.45) & (pick < 0.9)] = one
+            elif kind == 2: a[:] = a[rs.randint(0, n)]
+            elif kind == 3: a[pick < 0.5] = one; a[pick >= 0.5] = minus_one
+            ds = ctx.upload(np.ascontiguousarray(a))
+            keep.append(ds)
+            jobs.append((tb, off, ds.ptr, n))
+            wants.append(gen(_mont_inner_product(ctx, dk.ptr + (off_t + off) * 32, ds.ptr, n)))
+        singles = [to_aff(ctx.msm_dev(*j)) for j in jobs]
+        batch = [to_aff(x) for x in ctx.msm_batch_dev(jobs)]
+        small += 1
+        if singles != wants or batch != wants:
+            bad += 1
+            print("MISMATCH small it=%d group=%d table=%d jobs=%s single_ok=%s batch_ok=%s" % (it, group, nt, [(j[1], j[3]) for j in jobs], singles == wants, batch == wants), flush=True)
+        for ds in keep: ds.free()
+        tb.free()
+    print("FUZZ %s: %d cases + %d small-table batches, %d mismatches, %.1f s" % ("FAILED" if bad else "ok", iters, small, bad, time.time() - t0))
     return 1 if bad else 0
 
 if __name__ == "__main__":
