@@ -30,12 +30,15 @@ def test_compiled_host_builds_and_fails_loudly_without_a_gpu(tmp_path):
     import torch
     exe = build(tmp_path)
     collab = build(tmp_path, "host_collab_groth16")
+    trait = build(tmp_path, "host_trait_groth16")          # create_proof over the trait-shaped entry points (tests/test_gpu_trait_path.py)
     if torch.cuda.is_available():
         pytest.skip("GPU present: the gpu tests run them")
     r = subprocess.run([exe, "4"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "proof" not in r.stdout and "zk_ctx_create" in r.stderr
     r = subprocess.run([collab, "2", "8"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "proof" not in r.stdout and "error" in r.stderr
+    r = subprocess.run([trait, "4", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "proof" not in r.stdout and "zk_ctx_create" in r.stderr
 
 
 @pytest.mark.gpu
