@@ -122,6 +122,16 @@ def test_cache_contract(ctx):
     assert msm(pts, n) == want(0, n) and msm(sub, 800) == want(100, 800) and msm(pts, n) == want(0, n)
     s3 = _stats(ctx)
     assert s3["entries"] == 1 and s3["evictions"] >= 2
+    # building the window multiples of one table pushes the other one out (the entry list shifts under the hit: ADVICE-style trap)
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    need = 20 * 900 * (256 + 96)                                                     # sub: 900 points, c = 13 -> 20 copies, limb slots + the packed copy
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, need + 900 * 96 + 50_000, 1))           # room for sub's multiples and sub -- not for pts beside them
+    assert msm(sub, 800) == want(100, 800) and msm(pts, n) == want(0, n)             # two plain tables resident (sub is the older one)
+    assert _stats(ctx)["entries"] == 2
+    assert msm(sub, 800) == want(100, 800)                                           # first hit on sub: its multiples need 6.3 MB -> pts goes
+    s4 = _stats(ctx)
+    assert s4["entries"] == 1 and s4["pre"] == 1
+    assert msm(sub, 800) == want(100, 800) and msm(pts, n) == want(0, n)             # sub from its multiples; pts uploaded again
     # smaller than any table: nothing is kept, everything still right
     ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 1024, 1))
     assert msm(pts, n) == want(0, n)
@@ -130,6 +140,7 @@ def test_cache_contract(ctx):
     ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 1 << 30, 1))
     assert msm(pts[:200], 200) == want(0, 200) and _stats(ctx)["entries"] == 0
     ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 64 << 30, 1))                        # (the session's context goes on with a roomy cache)
     tab.free(); dk.free()
 
 

@@ -149,13 +149,18 @@ int zk_bases_cache_get(zk_ctx* ctx, int group, const void* host, size_t n, const
         x.hits++;
         x.last = ++c->tick;
         c->hits++;
+        zk_bases* const xb = x.b;
         if (c->precompute_after > 0 && !x.pre_tried && x.hits >= (uint32_t)c->precompute_after && n >= ZK_PRECOMP_MIN_POINTS) {
-            x.pre_tried = true;                               // (one attempt: a table skipped for lack of memory stays plain)
-            make_room(ctx, c, (group == 1 ? 50 : 14) * x.bytes, x.b);   // 13 window multiples: G1 in 256-byte limb slots (35x the plain table, the packed copy beside it while it is built), G2 packed
-            ZK_TRY(zk_bases_precompute(ctx, x.b));
-            x.bytes = table_bytes(x.b);
+            x.pre_tried = true;                               // (one attempt: a table skipped for lack of room stays plain)
+            // W copies: G1 in 256-byte limb slots with the packed copy beside them while they are built, G2 packed
+            const size_t need = (size_t)zk_precompute_windows(n) * n * (group == 1 ? 256 + 96 : 192);
+            make_room(ctx, c, need, xb);                      // (may erase other entries: `x` is dead from here on)
+            if (resident(c) + need <= c->budget) {            // the budget holds for the multiples as well: else the table stays plain
+                ZK_TRY(zk_bases_precompute(ctx, xb));
+                for (auto& y : c->e) if (y.b == xb) y.bytes = table_bytes(xb);
+            }
         }
-        *out = x.b;
+        *out = xb;
         return ZK_OK;
     }
     c->misses++;

@@ -307,6 +307,8 @@ int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b) {
 }
 
 extern "C" uint32_t zk_bases_window_bits(const zk_bases* b) { return b ? b->c_pre : 0; }
+// how many copies (windows) the multiples of an n-point table have: what bases_cache.hip budgets for
+uint32_t zk_precompute_windows(size_t n) { const uint32_t c = precompute_window_bits(n); return (255 + c - 1) / c; }
 
 static int precompute_run(zk_ctx* ctx, zk_bases* b, int layout) {
     if (!ctx || layout < 0 || layout > 3) return ZK_ERR_ARG;

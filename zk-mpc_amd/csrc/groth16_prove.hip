@@ -48,12 +48,13 @@ void ZkProofTail::abc_ready(const zk_g1_projective& a_sum, const zk_g1_projectiv
 }
 
 void ZkProofTail::join() {
-    if (pre_a.valid()) pre_a.wait();
-    if (pre_b.valid()) pre_b.wait();
-    if (pre_2.valid()) pre_2.wait();
+    // the chains first: each waits for its own pre_* task, and a future is waited for by one thread at a time
     if (chain_a.valid()) chain_a.get();
     if (chain_b.valid()) chain_b.get();
     if (chain_g2.valid()) chain_g2.get();
+    if (pre_a.valid()) pre_a.wait();
+    if (pre_b.valid()) pre_b.wait();
+    if (pre_2.valid()) pre_2.wait();
 }
 
 void ZkProofTail::finish(const zk_g1_projective& h_sum, const zk_g1_projective& l_sum, uint8_t proof[192]) {

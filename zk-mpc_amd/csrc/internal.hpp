@@ -49,6 +49,7 @@ void zk_bases_cache_free(zk_ctx* ctx);
 extern "C" int zk_bases_free(zk_ctx* ctx, zk_bases* b);
 constexpr size_t ZK_PRECOMP_MIN_POINTS = 256;                    // tables below this keep the plain form (zk_bases_precompute is a no-op)
 extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b);
+uint32_t zk_precompute_windows(size_t n);                            // fixed_base.hip: copies a table of n points would get
 int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b);             // only when ZK_PRECOMP=1 (off by default: see fixed_base.hip)
 int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,
                void* out_host_projective);
