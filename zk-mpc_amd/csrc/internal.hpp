@@ -16,6 +16,14 @@ int zk_ntt_vanishing_inv(zk_ctx* ctx, uint32_t log_n, uint32_t out9[9]);  // 1/(
 // vec_ops.hip
 int zk_vec_op_launch(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n);
 int zk_vec_scale_launch(zk_ctx* ctx, const void* a, const uint32_t* k_int_form9, void* out, size_t n);
+// zk_fr_vec_is_zero_dev without the wait: *verdict points at a page-locked word that is 0 (all zero) or not once ctx->stream has
+// passed this point (slot 0..7: tests in flight)
+int zk_fr_vec_is_zero_launch(zk_ctx* ctx, const void* v, size_t n, int slot, const uint32_t** verdict);
+// out = rp (kc s + ka a + kb b) - z tp, element-wise (Marlin round 2); out may alias s
+int zk_fr_outer_q1_launch(zk_ctx* ctx, const void* s, const void* a, const void* b, const void* z, const void* rp, const void* tp,
+                          const uint32_t* ka_int9, const uint32_t* kb_int9, const uint32_t* kc_int9, void* out, size_t n);
+// out[i] = sum_t k_t p_t[i] (terms with i < ns[t]); constants in internal form; out may not alias a term
+int zk_fr_lincomb_launch(zk_ctx* ctx, int terms, const void* const* ps, const size_t* ns, const uint32_t (*k_int_form9)[9], void* out, size_t n_out);
 int zk_vec_sub_scale_launch(zk_ctx* ctx, const void* a, const void* b, const uint32_t* k_int_form9, void* out, size_t n);
 
 // msm.hip
@@ -102,6 +110,9 @@ int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out_host_projective);
 // launch per level of the reduce chain; zk_msm_group_ok says whether a set qualifies (else: the per-job calls above)
 int zk_msm_finish_many(zk_ctx* ctx, ZkMsmJob* const* jobs, void* const* outs, int count);      // the host halves side by side
 bool zk_msm_group_ok(ZkMsmJob* const* jobs, int count);
+// (the sorts of such a group as ONE launch, a block per job: every job a one-block sort -- prepared, not yet sorted)
+bool zk_msm_sort_group_ok(ZkMsmJob* const* jobs, int count);
+int zk_msm_enqueue_sort_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st);
 int zk_msm_enqueue_accum_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st);
 int zk_msm_enqueue_reduce_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st);
 
@@ -109,11 +120,12 @@ int zk_msm_enqueue_reduce_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, h
 
 // msm_g2pair.hip: the G2 accumulate kernel with two lanes per point addition
 void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bases, const uint32_t* sorted, const void* desc,
-                            const uint32_t* order, const uint32_t* ctr, uint32_t* sums);
+                            const uint32_t* order, const uint32_t* ctr, uint32_t* sums, bool quads);
 struct ZkG2PairReduce {   // the arguments of msm.hip's reduce chain
     const void *heavy, *heavy2; const uint32_t* ctr; uint32_t* done;
     uint32_t *sums, *rowP, *colP, *bits;
     uint32_t log_nb, n_win, light_blocks, heavy_blocks;
+    bool quads = false;          // a small job: the fold on lane quads (the grid kernels choose by the bucket count)
 };
 int zk_launch_reduce_g2pair(zk_ctx* ctx, hipStream_t st, const ZkG2PairReduce& a);
 constexpr uint32_t ZK_G2PAIR_RED_PTS = 128;   // points (lane pairs) per block of the G2 reduce kernels

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <future>
+#include <array>
 #include <map>
 #include <string>
 #include <vector>
@@ -150,6 +151,31 @@ void comm_tobytes(const Comm& c, std::vector<uint8_t>& out) {              // ma
     g1_tobytes(c.has_shift ? c.s : aff_inf<G1Field>(), out);
 }
 Affine<G1Field> proj_to_aff(const zk_g1_projective& p) { return xyzz_to_affine<G1Field>(host_proj_from_abi<G1Field>((const uint64_t*)&p)); }
+// ... of several points with ONE field inversion (the commitments of a round: 2 - 6 points, an inversion is ~400 products) in
+// the 64-bit host field
+std::vector<Affine<G1Field>> batch_to_aff(const std::vector<zk_g1_projective>& pts) {
+    using H = Fq64Field;
+    const size_t n = pts.size();
+    std::vector<XYZZ<H>> x(n);
+    std::vector<typename H::T> pre(n);
+    typename H::T acc = H::one();
+    for (size_t i = 0; i < n; i++) {
+        x[i] = host64_proj_from_abi<H>((const uint64_t*)&pts[i]);
+        if (xyzz_is_inf<H>(x[i])) continue;
+        pre[i] = acc;
+        acc = H::mul(acc, x[i].zzz);
+    }
+    typename H::T inv = H::inv(acc);
+    std::vector<Affine<G1Field>> out(n);
+    for (size_t i = n; i-- > 0;) {
+        if (xyzz_is_inf<H>(x[i])) { out[i] = aff_inf<G1Field>(); continue; }
+        const typename H::T zi3 = H::mul(inv, pre[i]);
+        inv = H::mul(inv, x[i].zzz);
+        const typename H::T zi = H::mul(zi3, x[i].zz), zi2 = H::sqr(zi);
+        out[i] = aff_from_host64<G1Field>(Affine<H>{H::mul(x[i].x, zi2), H::mul(x[i].y, zi3)});
+    }
+    return out;
+}
 
 HF host_eval(const std::vector<HF>& c, const HF& x) {
     HF acc = HF::zero();
@@ -315,6 +341,25 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         }
     } laps(ctx);
     ZkSharedNet nt{ctx, net};
+    // divisibility / zero-sum checks whose verdict nothing waits for: the test is enqueued, the round's commitments go out behind
+    // it, and the verdict is read once the batch has synchronised the streams (a wait here left the device idle for the whole of
+    // the host's preparation of the batch: 0.1 - 0.15 ms per round of a small proof)
+    struct Pending { const uint32_t* verdict; const char* msg; };
+    std::vector<Pending> pending;
+    auto check_later = [&](const void* v, size_t n, const char* msg) -> int {
+        const uint32_t* h = nullptr;
+        ZK_TRY(zk_fr_vec_is_zero_launch(ctx, v, n, (int)pending.size(), &h));
+        pending.push_back({h, msg});
+        return ZK_OK;
+    };
+    auto settle = [&]() -> int {
+        const char* failed = nullptr;
+        for (auto& c : pending)
+            if (!failed && *c.verdict != 0) failed = c.msg;
+        pending.clear();
+        if (failed) ZK_FAIL(ctx, ZK_ERR_STATE, failed);
+        return ZK_OK;
+    };
     const bool leader = nt.leader();
     Prover PL[2] = {Prover{ctx, ix, powers_g, powers_gamma_g, powers_g->n - 1, zk_rng_}, Prover{ctx, ix, powers_g, powers_gamma_g, powers_g->n - 1, zk_rng_}};
     PL[1].lane = 1;
@@ -404,9 +449,12 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         std::vector<zk_g1_projective> outs(jb.size());
         std::vector<void*> outp(jb.size());
         for (size_t i = 0; i < jb.size(); i++) outp[i] = &outs[i];
+        laps.lap("commit.prep");
         const int brc = zk_msm_batch_dev(ctx, jb.size(), jb.data(), joff.data(), jsc.data(), jlen.data(), outp.data());
+        laps.lap("commit.msm");
         std::vector<std::pair<std::pair<int, std::string>, zk_g1_projective>> bl;
         for (auto& b : blinds) bl.push_back({b.first, b.second.get()});          // joined before any return
+        laps.lap("commit.blinds");
         ZK_TRY(brc);
         for (size_t i = 0; i < jb.size(); i++) acc[slot[i].lane][slot[i].which][slot[i].label] = outs[i];
         for (auto& b : bl)                                                       // the MAC lane of this party's fresh blinds is the share itself
@@ -433,11 +481,18 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
             for (size_t i = 0; i < what.size(); i++) acc[0][what[i].second][what[i].first] = opened[i];
         }
         std::vector<uint8_t> bytes;
+        std::vector<zk_g1_projective> all;
+        for (const char* l : labels) {
+            all.push_back(acc[0][0][l]);
+            if (acc[0][1].count(l)) all.push_back(acc[0][1][l]);
+        }
+        const std::vector<Affine<G1Field>> aff = batch_to_aff(all);
+        size_t ai = 0;
         for (const char* l : labels) {
             Comm c;
-            c.c = proj_to_aff(acc[0][0][l]);
+            c.c = aff[ai++];
             c.has_shift = acc[0][1].count(l) != 0;
-            c.s = c.has_shift ? proj_to_aff(acc[0][1][l]) : aff_inf<G1Field>();
+            c.s = c.has_shift ? aff[ai++] : aff_inf<G1Field>();
             P.comms[l] = c;
             comm_tobytes(c, bytes);
         }
@@ -488,7 +543,7 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         ZK_TRY(Q.rc);
         ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, w_h.p, n + 1, X.log, wq[l], wr));
         // (over shares the remainder is a share of zero: the reference's assert!(remainder.is_zero()) cannot be evaluated locally)
-        if (!shared && !Q.is_zero(wr, X.size)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: w polynomial is not divisible by v_X");
+        if (!shared) ZK_TRY(check_later(wr, X.size, "zk_marlin_prove: w polynomial is not divisible by v_X"));
         Q.polys["w"] = Poly{wq[l], nwq};
         Q.polys["z_a"] = Q.blind(za, n, rnd + 32, "z_a_poly");
         Q.polys["z_b"] = Q.blind(zbb, n, rnd + 64, "z_b_poly");
@@ -503,6 +558,7 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     }
     laps.lap("polys");
     ZK_TRY(commit_round({"w", "z_a", "z_b", "mask_poly"}));
+    ZK_TRY(settle());
     laps.lap("commit");
     const HF alpha = sample_outside(H), eta_a = P.next_fr(fs), eta_b = P.next_fr(fs), eta_c = P.next_fr(fs);
 
@@ -555,14 +611,9 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     char *hq[2], *hr[2];
     for (int l = 0; l < LANES; l++) {
         Prover& Q = PL[l];
-        Q.scale(e_s[l], eta_c, e_s[l], MUL.size);
-        Q.scale(e_a[l], eta_a, e_a[l], MUL.size);
-        Q.op(ZK_OP_ADD, e_s[l], e_a[l], e_s[l], MUL.size);
-        Q.scale(e_b[l], eta_b, e_b[l], MUL.size);
-        Q.op(ZK_OP_ADD, e_s[l], e_b[l], e_s[l], MUL.size);
-        Q.op(ZK_OP_MUL, e_rp, e_s[l], e_s[l], MUL.size);                         // public * own value: local
-        Q.op(ZK_OP_MUL, e_z[l], e_tp, e_z[l], MUL.size);
-        Q.op(ZK_OP_SUB, e_s[l], e_z[l], e_s[l], MUL.size);
+        // r(alpha, X) (eta_c z_a z_b + eta_a z_a + eta_b z_b) - z t on the multiplication domain (public * own value: local): one pass
+        ZK_TRY(Q.rc);
+        ZK_TRY(zk_fr_outer_q1_launch(ctx, e_s[l], e_a[l], e_b[l], e_z[l], e_rp, e_tp, eta_a.v.l, eta_b.v.l, eta_c.v.l, e_s[l], MUL.size));
         Q.ntt(e_s[l], MUL, 1);                                                   // q_1 (prover.rs:517-541)
         Q.op(ZK_OP_ADD, e_s[l], mask[l], e_s[l], md + 1);
         hq[l] = Q.dev("h1_q", MUL.size - n); hr[l] = Q.dev("h1_r", n);
@@ -570,8 +621,8 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, e_s[l], MUL.size, H.log, hq[l], hr[l]));
     }
     {   // the outer sum-check's zero test (prover.rs:547-550): over shares the constant term is opened
-        bool zero_sum;
-        if (!shared) zero_sum = P.is_zero(hr[0], 1);
+        bool zero_sum = true;
+        if (!shared) ZK_TRY(check_later(hr[0], 1, "zk_marlin_prove: outer sum-check: the sum over H is not zero (unsatisfied constraint system)"));
         else {
             char* zo = P.dev("zero_open", 1); char* zd = P.dev("zero_dx", 1);
             ZK_TRY(P.rc);
@@ -588,6 +639,7 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     }
     laps.lap("polys");
     ZK_TRY(commit_round({"t", "g_1", "h_1"}));
+    ZK_TRY(settle());
     laps.lap("commit");
     const HF beta = sample_outside(H);
 
@@ -609,13 +661,14 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     char* h2q = P.dev("h2_q", B.size - K.size); char* h2r = P.dev("h2_r", K.size);
     ZK_TRY(P.rc);
     ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, a_ev, B.size, K.log, h2q, h2r));
-    if (!P.is_zero(h2r, K.size)) ZK_FAIL(ctx, ZK_ERR_STATE, "zk_marlin_prove: inner sum-check: a - b f is not divisible by v_K");
+    ZK_TRY(check_later(h2r, K.size, "zk_marlin_prove: inner sum-check: a - b f is not divisible by v_K"));
     for (int l = 0; l < LANES; l++) {
         PL[l].polys["g_2"] = Poly{f_ev + 32, K.size - 1};
         PL[l].polys["h_2"] = Poly{h2q, B.size - K.size};
     }
     laps.lap("polys");
     ZK_TRY(commit_round({"g_2", "h_2"}));
+    ZK_TRY(settle());
     laps.lap("commit");
     const HF gamma = P.next_fr(fs);
 
@@ -742,13 +795,19 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         for (auto& t : terms) cn = std::max(cn, P.polys[t.first].n);
         for (int l = 0; l < (any_shared ? LANES : 1); l++) {
             Prover& Q = PL[l];
-            char* comb = Q.dev("comb" + std::to_string(q), cn); char* ctmp = Q.dev("combtmp", cn);
-            Q.zero(comb, cn);
-            for (auto& t : terms) {
-                if (any_shared && !label_shared(t.first.c_str()) && !leader) continue;   // a public oracle in a shared combination: the leader's
-                const Poly& p = Q.polys[t.first];
-                Q.scale(p.p, t.second, ctmp, p.n);
-                Q.op(ZK_OP_ADD, comb, ctmp, comb, p.n);
+            char* comb = Q.dev("comb" + std::to_string(q), cn);
+            {   // one launch for the whole combination (vec_ops.hip::k_lincomb)
+                std::vector<const void*> tp; std::vector<size_t> tn; std::vector<std::array<uint32_t, 9>> tk;
+                for (auto& t : terms) {
+                    if (any_shared && !label_shared(t.first.c_str()) && !leader) continue;   // a public oracle in a shared combination: the leader's
+                    const Poly& p = Q.polys[t.first];
+                    tp.push_back(p.p); tn.push_back(p.n);
+                    std::array<uint32_t, 9> k;
+                    for (int i = 0; i < 9; i++) k[i] = t.second.v.l[i];
+                    tk.push_back(k);
+                }
+                ZK_TRY(Q.rc);
+                ZK_TRY(zk_fr_lincomb_launch(ctx, (int)tp.size(), tp.data(), tn.data(), (const uint32_t (*)[9])tk.data(), comb, cn));
             }
             char* quo = Q.dev("quo" + std::to_string(q), cn);
             ZK_TRY(Q.rc);
@@ -792,6 +851,7 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     Affine<G1Field> wit[2];
     {
         size_t k = 0;
+        std::vector<zk_g1_projective> wits;
         for (int q = 0; q < 2; q++) {
             zk_g1_projective wl[2];
             const int nl = q_shared[q] ? LANES : 1;
@@ -810,8 +870,11 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
                 wl[0] = og[0];
                 if (has_rv[q]) rvs[q] = ofr[0];
             }
-            wit[q] = proj_to_aff(wl[0]);
+            wits.push_back(wl[0]);
         }
+        const std::vector<Affine<G1Field>> wa = batch_to_aff(wits);
+        wit[0] = wa[0];
+        wit[1] = wa[1];
     }
 
     laps.lap("open");

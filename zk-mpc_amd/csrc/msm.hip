@@ -31,6 +31,7 @@
 #include "internal.hpp"
 #include "msm_reduce.cuh"
 #include "msm_digits.cuh"
+#include "ec_dual.cuh"
 #include <algorithm>
 #include <future>
 #include <memory>
@@ -309,9 +310,17 @@ k_order(const SegDesc* desc, const uint32_t* ctr, uint32_t* bin_cursor, uint32_t
 // fifteen of them.  Same products as those kernels (consecutive segment numbering, as their non-flat mode).
 constexpr uint32_t SS_NT = 1024;
 constexpr uint32_t SS_MAX_ENTRIES = 1u << 16, SS_MAX_NB = 1u << 15, SS_MAX_SEG = 64;   // (70 k entries in one block: 157 us against ~105 for the six launches)
-__global__ void __launch_bounds__(SS_NT)
-k_sort_small(const void* scalars, uint32_t n, WinOff wo, uint32_t W, uint32_t NB, Bias bias, uint32_t seg, uint32_t n_tab, uint32_t tab_off,
-             uint32_t grp_base, uint32_t* dig, uint32_t* sorted, SegDesc* desc, HeavyDesc* heavy, HeavyDesc* heavy2, uint32_t* order, uint32_t* ctr) {
+struct SortSmallArgs {
+    const void* scalars; uint32_t n; WinOff wo; uint32_t W, NB; Bias bias; uint32_t seg, n_tab, tab_off, grp_base;
+    uint32_t* dig; uint32_t* sorted; SegDesc* desc; HeavyDesc* heavy; HeavyDesc* heavy2; uint32_t* order; uint32_t* ctr;
+};
+__device__ __forceinline__ void sort_small_body(const SortSmallArgs& a) {
+    const void* scalars = a.scalars;
+    const uint32_t n = a.n, W = a.W, NB = a.NB, seg = a.seg, n_tab = a.n_tab, tab_off = a.tab_off, grp_base = a.grp_base;
+    const WinOff& wo = a.wo;
+    const Bias& bias = a.bias;
+    uint32_t* dig = a.dig; uint32_t* sorted = a.sorted; SegDesc* desc = a.desc; HeavyDesc* heavy = a.heavy; HeavyDesc* heavy2 = a.heavy2;
+    uint32_t* order = a.order; uint32_t* ctr = a.ctr;
     extern __shared__ uint32_t ss_lds[];
     uint32_t* cnt = ss_lds;                       // NB: counts, later cursors
     uint32_t* part = cnt + NB;                    // 2 x SS_NT: the block scan
@@ -420,6 +429,11 @@ k_sort_small(const void* scalars, uint32_t n, WinOff wo, uint32_t W, uint32_t NB
         for (int u = 0; u < 4; u++) if (len[u] != 0xffffffffu) order[atomicAdd(&lh[len[u]], 1u)] = q0 + u * SS_NT;
     }
 }
+__global__ void __launch_bounds__(SS_NT) k_sort_small(SortSmallArgs a) { sort_small_body(a); }
+// ... of a GROUP of small jobs: one block per job (the commitments of a small Marlin round: four sorts of 50 - 100 us, two of them
+// one behind the other on a stream, were a third of the round's device time)
+struct SortSmallGroup { SortSmallArgs j[GRID_SRC_MAX]; };
+__global__ void __launch_bounds__(SS_NT) k_sort_small_group(SortSmallGroup g) { sort_small_body(g.j[blockIdx.x]); }
 
 // Persistent lanes over the length-sorted segment list: the grid is exactly 2 blocks per CU and thread g
 // takes segments g, g + G, g + 2G, ... (G = total threads).  Neighbouring lanes always hold segments of
@@ -639,6 +653,48 @@ struct RedG1 {
     static __device__ __forceinline__ X lds_get(const uint32_t* lds, uint32_t slot) { return lds_get_xyzz<F, PTS>(lds, slot); }
 };
 
+// ... for a SMALL bucket set (a chain of dependent additions on waves that sit alone on their SIMD): every addition on a lane PAIR,
+// seven product times instead of fourteen (ec_dual.cuh).  Both lanes of a pair carry the whole point; the even one stores.
+struct G1DualOps {
+    using F = G1Field;
+    using T = typename F::T;
+    static __device__ __forceinline__ bool hi() { return (threadIdx.x & 1u) != 0; }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) { return F::mul_l(a, b); }
+    static __device__ __forceinline__ T swap(const T& a) {
+        T r;
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(T) / sizeof(uint32_t)); i++)
+            r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+        return r;
+    }
+    static __device__ __forceinline__ T zero() { return F::zero(); }
+    static __device__ __forceinline__ bool is_zero(const T& a) { return F::is_zero(a); }
+    static __device__ __forceinline__ bool maybe_multiple_of_p(const T& a) { return F::maybe_multiple_of_p(a); }
+    static __device__ __forceinline__ T select(bool c, const T& a, const T& b) { return F::select(c, a, b); }
+    template <int K> static __device__ __forceinline__ T sub_kp(const T& a, const T& b) { return F::template sub_kp<K>(a, b); }
+    static __device__ __forceinline__ T x3_l(const T& rr, const T& ppp, const T& qq) { return F::x3_l(rr, ppp, qq); }
+    static __device__ __forceinline__ T canon(const T& a) { return F::canon(a); }
+    static __device__ __forceinline__ T canon1(const T& a) { return F::canon1(a); }
+    static __device__ __forceinline__ XYZZ<F> dbl(const XYZZ<F>& a) { return xyzz_dbl<F>(a); }
+};
+struct RedG1Dual {
+    using F = G1Field;
+    using X = XYZZ<F>;
+    static constexpr int NT = 256, PTS = 128, MINW = 1;
+    static __device__ __forceinline__ uint32_t pt() { return threadIdx.x >> 1; }
+    static __device__ __forceinline__ X inf() { return xyzz_inf<F>(); }
+    static __device__ __forceinline__ X load(const uint32_t* base, size_t i) { return xyzz_load16<F>(base, i); }
+    static __device__ __forceinline__ void store(uint32_t* base, size_t i, const X& p) { if (!G1DualOps::hi()) xyzz_store16<F>(base, i, p); }
+    static __device__ __forceinline__ X add(const X& a, const X& b) { return xyzz_add_dual<G1DualOps, X>(a, b); }
+    // (y is a difference of two products here, < 3p + eps: brought below p with x wherever a sum is packed)
+    static __device__ __forceinline__ X pack(const X& a) { return X{F::canon(a.x), F::canon(a.y), a.zz, a.zzz}; }
+    static __device__ __forceinline__ X canon(const X& a) { return X{F::canon(a.x), F::canon(a.y), F::canon1(a.zz), F::canon1(a.zzz)}; }
+    static __device__ __forceinline__ void lds_put(uint32_t* lds, uint32_t slot, const X& p) { if (!G1DualOps::hi()) lds_put_xyzz<F, PTS>(lds, slot, p); }
+    static __device__ __forceinline__ X lds_get(const uint32_t* lds, uint32_t slot) { return lds_get_xyzz<F, PTS>(lds, slot); }
+};
+// bucket sets up to this size take the pair form (measured: 2^15 gains 20 - 25 % of the chain, 2^17 nothing -- the lanes are no longer alone)
+constexpr size_t RED_DUAL_MAX_BUCKETS = (size_t)1 << 16;
+
 // Arkworks-layout affine points (Montgomery R = 2^384) -> packed internal form.  all-zero = infinity stays zero.
 template <class F>
 __global__ void __launch_bounds__(256) k_bases_import(const uint32_t* in, uint32_t* out, size_t n) {
@@ -821,8 +877,8 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
             ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)SS_MAX_NB + 2 * SS_NT + (SS_MAX_SEG + 1) + 8) * 4)));
             ctx->flags["sort_small_lds"] = 1;
         }
-        hipLaunchKernelGGL(k_sort_small, 1, SS_NT, lds, st, job->scalars, (uint32_t)n, wo, W, NB, bias, seg, job->n_tab, job->tab_off, grp_base,
-                           b.dig, b.sorted, b.desc, b.heavy, b.heavy2, b.order, ctr);
+        hipLaunchKernelGGL(k_sort_small, 1, SS_NT, lds, st, SortSmallArgs{job->scalars, (uint32_t)n, wo, W, NB, bias, seg, job->n_tab, job->tab_off, grp_base,
+                           b.dig, b.sorted, b.desc, b.heavy, b.heavy2, b.order, ctr});
         ZK_HIP(ctx, hipGetLastError());
         tm->end();
         job->sorted = b.sorted; job->desc = b.desc; job->order = b.order; job->ctr = ctr; job->heavy = b.heavy; job->heavy2 = b.heavy2;
@@ -856,6 +912,10 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     return ZK_OK;
 }
 
+// A job whose accumulate kernel cannot give every SIMD a wave (<= 2^17 digits in segments of 8: <= 2^14 segments): its chains of
+// dependent additions run on twice the lanes per point (ec_dual.cuh)
+static bool msm_latency_bound(const ZkMsmJob* job) { return (size_t)job->n * job->W <= ((size_t)1 << 17); }
+
 template <class F>
 int msm_enqueue_accum_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     if (job->n == 0) return ZK_OK;
@@ -877,7 +937,7 @@ int msm_enqueue_accum_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
                                (const SegDesc*)job->desc, job->order, job->ctr, b.sums, job->stride);
     }
     else
-        zk_launch_accum_g2pair(st, job->max_segs, job->bases_dev, job->sorted, job->desc, job->order, job->ctr, b.sums);
+        zk_launch_accum_g2pair(st, job->max_segs, job->bases_dev, job->sorted, job->desc, job->order, job->ctr, b.sums, msm_latency_bound(job));
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
     ZK_HIP(ctx, hipEventCreateWithFlags(&job->accum_done, hipEventDisableTiming));
@@ -904,15 +964,23 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     if constexpr (F::WORDS != 12) {
         // G2: the same chain on lane pairs (msm_g2pair.hip)
         ZkG2PairReduce a{job->heavy, job->heavy2, job->ctr, b.fold_done, b.sums, b.rowP, b.colP, b.bits, job->log_nb, job->Wb, 2 * light_blocks, heavy_blocks};
+        a.quads = msm_latency_bound(job);
         ZK_TRY(zk_launch_reduce_g2pair(ctx, st, a));
     } else {
         hipLaunchKernelGGL(k_fold<F>, light_blocks + heavy_blocks, 64, 64 * XW * 4, st, (const HeavyDesc*)job->heavy, (const HeavyDesc*)job->heavy2,
                            (const uint32_t*)job->ctr, b.fold_done, b.sums, light_blocks);
-        const GridGeom gg = make_grid_geom(job->log_nb, job->Wb, RedG1::PTS);
-        hipLaunchKernelGGL(k_grid_l1<RedG1>, gg.row_blocks + gg.col_blocks, RedG1::NT, RedG1::PTS * XW * 4, st,
-                           GridSrc{{(const uint32_t*)b.sums, nullptr, nullptr, nullptr}, 0u}, b.rowP, b.colP, gg);
-        hipLaunchKernelGGL(k_grid_bits<RedG1>, gg.n_win * job->nout, RedG1::NT, RedG1::PTS * XW * 4, st, (const uint32_t*)b.rowP,
-                           (const uint32_t*)b.colP, b.bits, gg);                                                      // 48 KiB of LDS each
+        const GridSrc src{{(const uint32_t*)b.sums, nullptr, nullptr, nullptr}, 0u};
+        if (((size_t)job->Wb << job->log_nb) <= RED_DUAL_MAX_BUCKETS) {
+            const GridGeom gg = make_grid_geom(job->log_nb, job->Wb, RedG1Dual::PTS);
+            hipLaunchKernelGGL(k_grid_l1<RedG1Dual>, gg.row_blocks + gg.col_blocks, RedG1Dual::NT, RedG1Dual::PTS * XW * 4, st, src, b.rowP, b.colP, gg);
+            hipLaunchKernelGGL(k_grid_bits<RedG1Dual>, gg.n_win * job->nout, RedG1Dual::NT, RedG1Dual::PTS * XW * 4, st, (const uint32_t*)b.rowP,
+                               (const uint32_t*)b.colP, b.bits, gg);
+        } else {
+            const GridGeom gg = make_grid_geom(job->log_nb, job->Wb, RedG1::PTS);
+            hipLaunchKernelGGL(k_grid_l1<RedG1>, gg.row_blocks + gg.col_blocks, RedG1::NT, RedG1::PTS * XW * 4, st, src, b.rowP, b.colP, gg);
+            hipLaunchKernelGGL(k_grid_bits<RedG1>, gg.n_win * job->nout, RedG1::NT, RedG1::PTS * XW * 4, st, (const uint32_t*)b.rowP,
+                               (const uint32_t*)b.colP, b.bits, gg);                                                  // 48 KiB of LDS each
+        }
     }
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
@@ -932,7 +1000,56 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     return ZK_OK;
 }
 
-// ---- a group of small G1 jobs: one accumulate launch, one launch per level of the reduce chain ----------------------------------
+// ---- a group of small G1 jobs: one sort launch (a block per job), one accumulate launch, one launch per level of the reduce chain --
+// The sorts of a group: every job must qualify for the one-block sort (zk_msm_sort_group_ok; else the per-job calls).
+static bool sort_small_fits(const ZkMsmJob* j) {
+    const bool merged = j->Wb == 1 && j->W > 1;
+    return j->n > 0 && merged && (size_t)j->W * j->n <= SS_MAX_ENTRIES && j->NB <= SS_MAX_NB && j->seg <= SS_MAX_SEG;
+}
+static bool msm_sort_group_ok(ZkMsmJob* const* jobs, int count) {
+    if (count < 1 || count > MSM_GROUP_MAX) return false;
+    for (int k = 0; k < count; k++)
+        if (jobs[k]->group != 1 || !sort_small_fits(jobs[k])) return false;
+    return true;
+}
+static int msm_enqueue_sort_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st) {
+    using F = G1Field;
+    SortSmallGroup g{};
+    uint32_t nb_max = 0;
+    for (int k = 0; k < count; k++) {
+        ZkMsmJob* job = jobs[k];
+        MsmBufs<F> b;
+        ZK_TRY(msm_bufs_t<F>(ctx, job, b, true));
+        const MsmPlan p = make_plan(job->n, job->c);
+        SortSmallArgs& a = g.j[k];
+        a.scalars = job->scalars; a.n = (uint32_t)job->n; a.W = job->W; a.NB = job->NB; a.seg = job->seg;
+        for (int i = 0; i < 65; i++) a.wo.off[i] = job->off[i];
+        a.wo.off[65] = 0;
+        for (int i = 0; i < 9; i++) a.bias.w[i] = p.bias[i];
+        a.n_tab = job->n_tab; a.tab_off = job->tab_off;
+        a.grp_base = (uint32_t)((size_t)job->Wb * job->NB + job->max_heavy_segs);
+        a.dig = b.dig; a.sorted = b.sorted; a.desc = b.desc; a.heavy = b.heavy; a.heavy2 = b.heavy2; a.order = b.order; a.ctr = b.small + 64;
+        job->sorted = b.sorted; job->desc = b.desc; job->order = b.order; job->ctr = b.small + 64; job->heavy = b.heavy; job->heavy2 = b.heavy2;
+        nb_max = std::max(nb_max, job->NB);
+    }
+    ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
+    jobs[0]->timers.push_back(tm);
+    tm->begin("msm_g1.sort");
+    if (!ctx->flags["sort_small_group_lds"]) {
+        ZK_HIP(ctx, hipFuncSetAttribute((const void*)k_sort_small_group, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)SS_MAX_NB + 2 * SS_NT + (SS_MAX_SEG + 1) + 8) * 4)));
+        ctx->flags["sort_small_group_lds"] = 1;
+    }
+    const size_t lds = ((size_t)nb_max + 2 * SS_NT + (SS_MAX_SEG + 1) + 8) * 4;
+    hipLaunchKernelGGL(k_sort_small_group, count, SS_NT, lds, st, g);
+    ZK_HIP(ctx, hipGetLastError());
+    tm->end();
+    for (int k = 0; k < count; k++) {
+        ZK_HIP(ctx, hipEventCreateWithFlags(&jobs[k]->sort_done, hipEventDisableTiming));
+        ZK_HIP(ctx, hipEventRecord(jobs[k]->sort_done, st));
+    }
+    return ZK_OK;
+}
+
 // Conditions (zk_msm_group_ok): G1, 2 .. MSM_GROUP_MAX jobs, every one sorted already, over tables of window multiples in the same
 // layout (one bucket set each, the same number of buckets).  The jobs keep their own sort products and bucket sums; row / column
 // partials and bit sums of the group live in the FIRST job's slot (sized for the group), and one copy brings all of them back.
@@ -992,7 +1109,8 @@ static int msm_enqueue_reduce_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int coun
         max_heavy = std::max(max_heavy, job->max_heavy);
     }
     for (int k = count; k < MSM_GROUP_MAX; k++) { fg.j[k] = fg.j[0]; src.p[k] = src.p[0]; }
-    const GridGeom gg = make_grid_geom(jobs[0]->log_nb, (uint32_t)count, RedG1::PTS);
+    const bool dual = ((size_t)count << jobs[0]->log_nb) <= RED_DUAL_MAX_BUCKETS;
+    const GridGeom gg = make_grid_geom(jobs[0]->log_nb, (uint32_t)count, dual ? RedG1Dual::PTS : RedG1::PTS);
     const uint32_t nout = jobs[0]->nout;
     char nm[64];
     uint32_t *rowP, *colP, *bits;
@@ -1008,8 +1126,13 @@ static int msm_enqueue_reduce_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int coun
     const unsigned light_blocks = (unsigned)std::min<size_t>((max_heavy + 63) / 64, 128);
     const unsigned heavy_blocks = (unsigned)std::min<size_t>(max_heavy, 256);
     hipLaunchKernelGGL(k_fold_group<F>, dim3(light_blocks + heavy_blocks, (unsigned)count), 64, 64 * XW * 4, st, fg, light_blocks);
-    hipLaunchKernelGGL(k_grid_l1<RedG1>, gg.row_blocks + gg.col_blocks, RedG1::NT, RedG1::PTS * XW * 4, st, src, rowP, colP, gg);
-    hipLaunchKernelGGL(k_grid_bits<RedG1>, gg.n_win * nout, RedG1::NT, RedG1::PTS * XW * 4, st, (const uint32_t*)rowP, (const uint32_t*)colP, bits, gg);
+    if (dual) {
+        hipLaunchKernelGGL(k_grid_l1<RedG1Dual>, gg.row_blocks + gg.col_blocks, RedG1Dual::NT, RedG1Dual::PTS * XW * 4, st, src, rowP, colP, gg);
+        hipLaunchKernelGGL(k_grid_bits<RedG1Dual>, gg.n_win * nout, RedG1Dual::NT, RedG1Dual::PTS * XW * 4, st, (const uint32_t*)rowP, (const uint32_t*)colP, bits, gg);
+    } else {
+        hipLaunchKernelGGL(k_grid_l1<RedG1>, gg.row_blocks + gg.col_blocks, RedG1::NT, RedG1::PTS * XW * 4, st, src, rowP, colP, gg);
+        hipLaunchKernelGGL(k_grid_bits<RedG1>, gg.n_win * nout, RedG1::NT, RedG1::PTS * XW * 4, st, (const uint32_t*)rowP, (const uint32_t*)colP, bits, gg);
+    }
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
     auto& pin = ctx->pinned[jobs[0]->pin_key >= 0 ? jobs[0]->pin_key : 32 + jobs[0]->slot];
@@ -1272,6 +1395,8 @@ int zk_msm_finish_many(zk_ctx* ctx, ZkMsmJob* const* jobs, void* const* outs, in
     return ZK_OK;
 }
 bool zk_msm_group_ok(ZkMsmJob* const* jobs, int count) { return msm_group_ok(jobs, count); }
+bool zk_msm_sort_group_ok(ZkMsmJob* const* jobs, int count) { return msm_sort_group_ok(jobs, count); }
+int zk_msm_enqueue_sort_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st) { return msm_enqueue_sort_group(ctx, jobs, count, st); }
 int zk_msm_enqueue_accum_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st) { return msm_enqueue_accum_group(ctx, jobs, count, st); }
 int zk_msm_enqueue_reduce_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st) { return msm_enqueue_reduce_group(ctx, jobs, count, st); }
 int zk_msm_finish(zk_ctx* ctx, ZkMsmJob* job, void* out) {

@@ -2,6 +2,7 @@
 #include "../../include/zkmpc_hip.h"
 #include "groth16_int.hpp"
 #include <algorithm>
+#include <chrono>
 
 using namespace zk;
 
@@ -23,6 +24,10 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
         if (off + lens[k] > bases[k]->n) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_msm_batch_dev: a job reads past its base table");
     }
     if (n_jobs == 0) return ZK_OK;
+    static const bool trace = getenv("ZK_TRACE_BATCH") != nullptr;
+    const auto T0 = std::chrono::steady_clock::now();
+    auto lapus = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count(); };
+    double t_prep = 0, t_sort = 0, t_enq = 0, t_fin = 0;
     zk_presort_free(ctx);            // the batch rotates over the same scratch slots
     ZK_TRY(zk_prover_streams(ctx, 1));
     constexpr size_t SLOTS = 3;
@@ -58,12 +63,28 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
                     grp[p] = &jobs[k];
                     jobs[k].pin_key = 16 + (int)k;
                     rc = zk_msm_prepare(ctx, &jobs[k], bases[j], base_offsets ? base_offsets[j] : 0, scalars_dev[j], lens[j], 1 + (int)p);
-                    // the sorts of a group are independent chains of ~10 short launches: side by side on three streams
-                    hipStream_t ss = p % 3 == 0 ? s_sort : (p % 3 == 1 ? ctx->stream : s_acc);
-                    if (rc == ZK_OK && g0 && jobs[k - GM].reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(ss, jobs[k - GM].reduce_done, 0));
-                    if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &jobs[k], ss, nullptr);
                 }
                 if (rc != ZK_OK) break;
+                t_prep = lapus();
+                {
+                    // the jobs that take the one-block sort: one launch, a block per job (sort stream); the others (a job of more than
+                    // 2^16 digits: ~10 short launches each) side by side on the other two streams
+                    ZkMsmJob* fit[GM]; size_t nfit = 0, nother = 0;
+                    ZkMsmJob* one[1];
+                    for (size_t p = 0; p < cnt; p++) { one[0] = grp[p]; if (zk_msm_sort_group_ok(one, 1)) fit[nfit++] = grp[p]; }
+                    if (nfit < 2) nfit = 0;
+                    for (size_t p = 0; p < cnt && rc == ZK_OK; p++) {
+                        const size_t k = g0 + p;
+                        bool in_fit = false;
+                        for (size_t f = 0; f < nfit; f++) in_fit = in_fit || fit[f] == grp[p];
+                        hipStream_t ss = in_fit ? s_sort : (nother++ % 2 == 0 ? ctx->stream : s_acc);
+                        if (g0 && jobs[k - GM].reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(ss, jobs[k - GM].reduce_done, 0));
+                        if (!in_fit) rc = zk_msm_enqueue_sort(ctx, &jobs[k], ss, nullptr);
+                    }
+                    if (rc == ZK_OK && nfit) rc = zk_msm_enqueue_sort_group(ctx, fit, (int)nfit, s_sort);
+                }
+                if (rc != ZK_OK) break;
+                t_sort = lapus();
                 if (cnt >= 2 && zk_msm_group_ok(grp, (int)cnt)) {
                     rc = zk_msm_enqueue_accum_group(ctx, grp, (int)cnt, s_sort);
                     if (rc == ZK_OK) rc = zk_msm_enqueue_reduce_group(ctx, grp, (int)cnt, s_sort);
@@ -74,16 +95,19 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
                     }
                 }
             }
+            t_enq = lapus();
             if (rc == ZK_OK) {
                 std::vector<ZkMsmJob*> jp(n_jobs);
                 std::vector<void*> op(n_jobs);
                 for (size_t k = 0; k < n_jobs; k++) { jp[k] = &jobs[k]; op[k] = outs[perm[k]]; }
                 rc = zk_msm_finish_many(ctx, jp.data(), op.data(), (int)n_jobs);
             }
+            t_fin = lapus();
             (void)hipStreamSynchronize(s_sort);
             (void)hipStreamSynchronize(s_acc);
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipEventDestroy(e0);
+            if (trace) fprintf(stderr, "batch %zu jobs: prep %.0f sort %.0f enq %.0f finish %.0f sync %.0f us\n", n_jobs, t_prep, t_sort, t_enq, t_fin, lapus());
             return rc;
         }
     }

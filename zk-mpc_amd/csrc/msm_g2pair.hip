@@ -22,6 +22,7 @@
 #include "../../include/zkmpc_hip.h"
 #include "internal.hpp"
 #include "msm_reduce.cuh"
+#include "ec_dual.cuh"
 #include <stdlib.h>
 
 using namespace zk;
@@ -148,6 +149,38 @@ __device__ __forceinline__ XyzzP madd_p_lazy(const XyzzP& acc, const AffP& q, bo
     return XyzzP{x3, y3, mulp_l(PP, acc.zz), mulp_l(PPP, acc.zzz)};
 }
 
+// ---- lane QUADS for small jobs ---------------------------------------------------------------------------------------------------
+// A small MSM is a chain of dependent additions on waves that sit alone on their SIMD: there every addition
+// runs on two pairs, each taking one of the two independent Fq2 products of a step (ec_dual.cuh) -- seven product times instead of
+// fourteen for a full addition, five instead of ten for a mixed one.  Lane bit 0 = the Fq2 component as above, lane bit 1 = the
+// pair; both pairs carry the whole point, the first one stores.
+struct G2QuadBase {
+    using T = Fq;
+    static __device__ __forceinline__ bool odd() { return (threadIdx.x & 1u) != 0; }
+    static __device__ __forceinline__ bool hi() { return (threadIdx.x & 2u) != 0; }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) { return mulp_l(prep(a, odd()), b); }
+    static __device__ __forceinline__ T mul_wide(const T& a, const T& b) { return mulp_l<true>(prep(a, odd()), b); }
+    static __device__ __forceinline__ T swap(const T& a) {
+        T r;
+#pragma unroll
+        for (int i = 0; i < L; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true);
+        return r;
+    }
+    static __device__ __forceinline__ T zero() { return B::zero(); }
+    static __device__ __forceinline__ T one() { return one_p(odd()); }
+    static __device__ __forceinline__ bool is_zero(const T& a) { return pair_zero(limbs_or(a)); }
+    static __device__ __forceinline__ bool maybe_multiple_of_p(const T& a) {
+        const uint32_t m = B::maybe_multiple_of_p(a) ? 1u : 0u;
+        return (m & dpp_swap1(m)) != 0;
+    }
+    static __device__ __forceinline__ T select(bool c, const T& a, const T& b) { return sel(c, a, b); }
+    template <int K> static __device__ __forceinline__ T sub_kp(const T& a, const T& b) { return B::sub_kp<K>(a, b); }
+    static __device__ __forceinline__ T x3_l(const T& rr, const T& ppp, const T& qq) { return B::x3_l(rr, ppp, qq); }
+    static __device__ __forceinline__ T canon(const T& a) { return B::canon(a); }
+    static __device__ __forceinline__ T canon1(const T& a) { return B::canon1(a); }
+    static __device__ __forceinline__ XyzzP dbl_affine(const AffP& q) { return dbl_affine_p(q, odd()); }
+};
+
 __device__ __forceinline__ Fq fq_load16(const uint32_t* w) { return felt_load16<FqField>(w); }
 
 // this lane's components of affine point i: x.c[odd] at words [odd*12, +12), y.c[odd] at [24 + odd*12, +12)
@@ -176,14 +209,17 @@ __device__ __forceinline__ AffP unpack_p(const RawP& r) {
 
 // 256 registers, two waves per SIMD, no spills.  (One wave per SIMD with 192 registers per lane left free for the kernels of the
 // other streams was measured slower: 7.7 vs 7.2 ms alone, 21.3 vs 20.8 ms per proof in round 2.)
+// GL = 2: a lane pair per segment; GL = 4: a quad (small jobs, above).
+template <int GL>
 __global__ void __launch_bounds__(256, 2)
 k_accum_g2pair(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
                const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums) {
+    constexpr int SH = GL == 4 ? 2 : 1;
     const uint32_t S = ctr[2];
-    const uint32_t G = gridDim.x * (blockDim.x >> 1);
+    const uint32_t G = gridDim.x * (blockDim.x >> SH);
     const uint32_t oddw = threadIdx.x & 1u;
     const bool odd = oddw != 0;
-    for (uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 1; t < S; t += G) {
+    for (uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> SH; t < S; t += G) {
         const SegDesc d = desc[order[t]];
         XyzzP acc{B::zero(), B::zero(), B::zero(), B::zero()};
         if (d.len) {
@@ -202,10 +238,14 @@ k_accum_g2pair(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ 
                 // lazy domain: see msm.hip::k_accum
                 const bool inf = pair_zero(limbs_or(cur.x) | limbs_or(cur.y));
                 if (ce >> 31) cur.y = B::kp_minus<1>(cur.y);
-                if (!inf) acc = madd_p_lazy(acc, cur, odd);
+                if (!inf) {
+                    if constexpr (GL == 4) acc = xyzz_madd_dual<G2QuadBase, XyzzP, AffP>(acc, cur);
+                    else acc = madd_p_lazy(acc, cur, odd);
+                }
             }
             acc = XyzzP{B::canon(acc.x), B::canon(acc.y), B::canon1(acc.zz), B::canon1(acc.zzz)};
         }
+        if (GL == 4 && G2QuadBase::hi()) continue;
         // XYZZ over Fq2 in memory: x.c0 x.c1 y.c0 y.c1 zz.c0 zz.c1 zzz.c0 zzz.c1, 12 words each
         uint32_t* w = sums + (size_t)d.dst * (8 * FW) + oddw * FW;
         felt_store16<FqField>(w, acc.x);
@@ -272,42 +312,55 @@ struct HeavyDesc { uint32_t key, first, nseg, parent; };   // msm.hip
 constexpr uint32_t HEAVY_NONE = 0xffffffffu;
 constexpr uint32_t FOLD_LIGHT = 8;
 
-// the 32 lane pairs of a block add nseg partial sums (strided, then an LDS tree) into sums[key]
+// the 32 lane pairs (GL = 4: 16 quads) of a block add nseg partial sums (strided, then an LDS tree) into sums[key]
+template <int GL>
+__device__ __forceinline__ XP fold_add(const XP& a, const XP& b);
+template <int GL>
 __device__ __forceinline__ void fold_block_pair(uint32_t* lds, uint32_t* sums, uint32_t first, uint32_t nseg, uint32_t key, uint32_t tid) {
-    const uint32_t lt = tid >> 1, odd = tid & 1u;
+    constexpr uint32_t SH = GL == 4 ? 2 : 1, NG = 64 >> SH;
+    const uint32_t lt = tid >> SH, odd = tid & 1u;
+    const bool writer = GL == 2 || (tid & 2u) == 0;
+    const uint32_t slot = 2 * lt + odd;                              // a point's two halves in neighbouring LDS slots
     XP acc = xyzz_inf<FP>();
-    for (uint32_t j = lt; j < nseg; j += 32) acc = xyzz_add<FP>(acc, xyzz_load_pair(sums, (size_t)first + j, odd));
-    lds_put_pair<64>(lds, tid, acc);
+    for (uint32_t j = lt; j < nseg; j += NG) acc = fold_add<GL>(acc, xyzz_load_pair(sums, (size_t)first + j, odd));
+    if (writer) lds_put_pair<64>(lds, slot, acc);
     __syncthreads();
-    for (uint32_t d = 16; d >= 1; d >>= 1) {
-        if (lt < d) lds_put_pair<64>(lds, tid, xyzz_add<FP>(lds_get_pair<64>(lds, tid), lds_get_pair<64>(lds, tid + 2 * d)));
+    for (uint32_t d = NG / 2; d >= 1; d >>= 1) {
+        XP r = acc;
+        if (lt < d) r = fold_add<GL>(lds_get_pair<64>(lds, slot), lds_get_pair<64>(lds, slot + 2 * d));
+        __syncthreads();
+        if (lt < d && writer) lds_put_pair<64>(lds, slot, r);
         __syncthreads();
     }
-    if (lt == 0) xyzz_store_pair(sums, key, odd, lds_get_pair<64>(lds, tid));
+    if (lt == 0 && writer) xyzz_store_pair(sums, key, odd, lds_get_pair<64>(lds, slot));
     __syncthreads();
 }
 
-// msm.hip::k_fold on pairs: 32 buckets (light part) or one entry (heavy part) per 64-lane block; two-level buckets as there
+// msm.hip::k_fold on pairs: 32 buckets (light part) or one entry (heavy part) per 64-lane block; two-level buckets as there.
+// GL = 4: on quads (small jobs: 16 buckets per block).
+template <int GL>
 __global__ void __launch_bounds__(64)
 k_fold_g2pair(const HeavyDesc* heavy, const HeavyDesc* heavy2, const uint32_t* ctr, uint32_t* done, uint32_t* sums, uint32_t light_blocks) {
     extern __shared__ uint32_t lds[];  // 64 * 48 words (heavy blocks only)
     __shared__ uint32_t last_flag;
+    constexpr uint32_t SH = GL == 4 ? 2 : 1, NG = 64 >> SH;
     const uint32_t nheavy = ctr[0];
-    const uint32_t tid = threadIdx.x, lt = tid >> 1, odd = tid & 1u;
+    const uint32_t tid = threadIdx.x, lt = tid >> SH, odd = tid & 1u;
+    const bool writer = GL == 2 || (tid & 2u) == 0;
     if (blockIdx.x < light_blocks) {
-        for (uint32_t hb = blockIdx.x * 32 + lt; hb < nheavy; hb += light_blocks * 32) {
+        for (uint32_t hb = blockIdx.x * NG + lt; hb < nheavy; hb += light_blocks * NG) {
             const HeavyDesc h = heavy[hb];
             if (h.nseg > FOLD_LIGHT || h.parent != HEAVY_NONE) continue;
             XP acc = xyzz_load_pair(sums, (size_t)h.first, odd);
-            for (uint32_t j = 1; j < h.nseg; j++) acc = xyzz_add<FP>(acc, xyzz_load_pair(sums, (size_t)h.first + j, odd));
-            xyzz_store_pair(sums, h.key, odd, acc);
+            for (uint32_t j = 1; j < h.nseg; j++) acc = fold_add<GL>(acc, xyzz_load_pair(sums, (size_t)h.first + j, odd));
+            if (writer) xyzz_store_pair(sums, h.key, odd, acc);
         }
         return;
     }
     for (uint32_t hb = blockIdx.x - light_blocks; hb < nheavy; hb += gridDim.x - light_blocks) {
         const HeavyDesc h = heavy[hb];
         if (h.nseg <= FOLD_LIGHT && h.parent == HEAVY_NONE) continue;
-        fold_block_pair(lds, sums, h.first, h.nseg, h.key, tid);
+        fold_block_pair<GL>(lds, sums, h.first, h.nseg, h.key, tid);
         if (h.parent == HEAVY_NONE) continue;
         const HeavyDesc up = heavy2[h.parent];
         __threadfence();                                           // both lanes of pair 0 stored a half of the group sum
@@ -320,7 +373,7 @@ k_fold_g2pair(const HeavyDesc* heavy, const HeavyDesc* heavy2, const uint32_t* c
         __syncthreads();
         if (last_flag) {
             __threadfence();
-            fold_block_pair(lds, sums, up.first, up.nseg, up.key, tid);
+            fold_block_pair<GL>(lds, sums, up.first, up.nseg, up.key, tid);
         }
         __syncthreads();
     }
@@ -377,19 +430,63 @@ struct RedG2Pair {
     static __device__ __forceinline__ X lds_get(const uint32_t* lds, uint32_t slot) { return lds_get_pair<NT>(lds, 2 * slot + odd()); }
 };
 
+struct G2QuadOps : G2QuadBase {
+    static __device__ __forceinline__ XP dbl(const XP& a) { return xyzz_dbl<FP>(a); }
+};
+// the folds' addition: exact on pairs (as before); on quads the lazy form, brought back to reduced coordinates (the fold's sums are
+// read by both forms of the grid kernels and by the exact pair addition of a second-level fold)
+template <> __device__ __forceinline__ XP fold_add<2>(const XP& a, const XP& b) { return xyzz_add<FP>(a, b); }
+template <> __device__ __forceinline__ XP fold_add<4>(const XP& a, const XP& b) {
+    const XP r = xyzz_add_dual<G2QuadOps, XP>(a, b);
+    return XP{B::canon(r.x), B::canon(r.y), B::canon1(r.zz), B::canon1(r.zzz)};
+}
+struct RedG2Quad {
+    using X = XP;
+    static constexpr int NT = 256, PTS = 64, MINW = 1;
+    static __device__ __forceinline__ uint32_t pt() { return threadIdx.x >> 2; }
+    static __device__ __forceinline__ uint32_t odd() { return threadIdx.x & 1u; }
+    static __device__ __forceinline__ X inf() { return xyzz_inf<FP>(); }
+    static __device__ __forceinline__ X load(const uint32_t* base, size_t i) { return xyzz_load_pair(base, i, odd()); }
+    static __device__ __forceinline__ void store(uint32_t* base, size_t i, const X& p) { if (!G2QuadOps::hi()) xyzz_store_pair(base, i, odd(), p); }
+    static __device__ __forceinline__ X add(const X& a, const X& b) { return xyzz_add_dual<G2QuadOps, X>(a, b); }
+    static __device__ __forceinline__ X pack(const X& a) { return X{B::canon(a.x), B::canon(a.y), a.zz, a.zzz}; }
+    static __device__ __forceinline__ X canon(const X& a) { return X{B::canon(a.x), B::canon(a.y), B::canon1(a.zz), B::canon1(a.zzz)}; }
+    static __device__ __forceinline__ void lds_put(uint32_t* lds, uint32_t slot, const X& p) { if (!G2QuadOps::hi()) lds_put_pair<2 * PTS>(lds, 2 * slot + odd(), p); }
+    static __device__ __forceinline__ X lds_get(const uint32_t* lds, uint32_t slot) { return lds_get_pair<2 * PTS>(lds, 2 * slot + odd()); }
+};
+constexpr size_t RED_QUAD_MAX_BUCKETS = (size_t)1 << 15;
+
 }  // namespace
 
 // One pair of lanes per segment: `segments` logical threads.
 void zk_launch_accum_g2pair(hipStream_t st, size_t segments, const uint32_t* bases, const uint32_t* sorted, const void* desc,
-                            const uint32_t* order, const uint32_t* ctr, uint32_t* sums) {
+                            const uint32_t* order, const uint32_t* ctr, uint32_t* sums, bool quads) {
+    if (quads) {
+        const unsigned blocks = (unsigned)((segments + 63) / 64);
+        hipLaunchKernelGGL(k_accum_g2pair<4>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
+        return;
+    }
     const unsigned blocks = (unsigned)((segments + 127) / 128);
-    hipLaunchKernelGGL(k_accum_g2pair, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
+    hipLaunchKernelGGL(k_accum_g2pair<2>, blocks, 256, 0, st, bases, sorted, (const SegDesc*)desc, order, ctr, sums);
 }
 
 // The G2 reduce chain of msm.hip::msm_enqueue_reduce_t, same buffers and geometry, on lane pairs.
 int zk_launch_reduce_g2pair(zk_ctx* ctx, hipStream_t st, const ZkG2PairReduce& a) {
-    hipLaunchKernelGGL(k_fold_g2pair, a.light_blocks + a.heavy_blocks, 64, 64 * 4 * FW * 4, st, (const HeavyDesc*)a.heavy, (const HeavyDesc*)a.heavy2,
-                       a.ctr, a.done, a.sums, a.light_blocks);
+    if (a.quads)
+        hipLaunchKernelGGL(k_fold_g2pair<4>, 2 * a.light_blocks + a.heavy_blocks, 64, 64 * 4 * FW * 4, st, (const HeavyDesc*)a.heavy, (const HeavyDesc*)a.heavy2,
+                           a.ctr, a.done, a.sums, 2 * a.light_blocks);
+    else
+        hipLaunchKernelGGL(k_fold_g2pair<2>, a.light_blocks + a.heavy_blocks, 64, 64 * 4 * FW * 4, st, (const HeavyDesc*)a.heavy, (const HeavyDesc*)a.heavy2,
+                           a.ctr, a.done, a.sums, a.light_blocks);
+    if (((size_t)a.n_win << a.log_nb) <= RED_QUAD_MAX_BUCKETS) {
+        const GridGeom gg = make_grid_geom(a.log_nb, a.n_win, RedG2Quad::PTS);
+        const size_t lds = (size_t)2 * RedG2Quad::PTS * 4 * FW * 4;
+        hipLaunchKernelGGL(k_grid_l1<RedG2Quad>, gg.row_blocks + gg.col_blocks, RedG2Quad::NT, lds, st, GridSrc{{(const uint32_t*)a.sums, nullptr, nullptr, nullptr}, 0u}, a.rowP, a.colP, gg);
+        hipLaunchKernelGGL(k_grid_bits<RedG2Quad>, gg.n_win * grid_nout(gg), RedG2Quad::NT, lds, st, (const uint32_t*)a.rowP, (const uint32_t*)a.colP,
+                           a.bits, gg);
+        ZK_HIP(ctx, hipGetLastError());
+        return ZK_OK;
+    }
     const GridGeom gg = make_grid_geom(a.log_nb, a.n_win, RedG2Pair::PTS);
     const size_t lds = (size_t)RedG2Pair::NT * 4 * FW * 4;            // 48 KiB
     hipLaunchKernelGGL(k_grid_l1<RedG2Pair>, gg.row_blocks + gg.col_blocks, RedG2Pair::NT, lds, st, GridSrc{{(const uint32_t*)a.sums, nullptr, nullptr, nullptr}, 0u}, a.rowP, a.colP, gg);

@@ -9,6 +9,7 @@
 #include "devutil.cuh"
 #include "frlazy.cuh"
 #include "internal.hpp"
+#include <algorithm>
 
 using namespace zk;
 
@@ -38,6 +39,33 @@ __global__ void __launch_bounds__(256) k_vec_scale(const void* a, FrK k, void* o
     const Fr kk = frk(k);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         fr_store(out, i, fr_mul(fr_load(a, i), kk));
+}
+
+// out[i] = sum_t k_t * p_t[i] over the terms with i < n_t (a linear combination of polynomials of different lengths:
+// open_combinations, poly-commit/src/lib.rs:~390-460 / marlin_pc/mod.rs:245-340 builds it with one scaled addition per term --
+// two launches and five vector passes each; here one launch reads every term once)
+constexpr int LINCOMB_MAX = 16;
+struct LinComb { const void* p[LINCOMB_MAX]; size_t n[LINCOMB_MAX]; FrK k[LINCOMB_MAX]; int terms; };
+__global__ void __launch_bounds__(256) k_lincomb(LinComb c, void* out, size_t n_out, int accumulate) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_out; i += (size_t)gridDim.x * blockDim.x) {
+        Fr acc = accumulate ? fr_load(out, i) : fp_zero<FrParams>();
+        for (int t = 0; t < c.terms; t++)
+            if (i < c.n[t]) acc = fr_add(acc, fr_mul(fr_load(c.p[t], i), frk(c.k[t])));
+        fr_store(out, i, acc);
+    }
+}
+
+// out = rp * (kc s + ka a + kb b) - z * tp, element-wise (the outer sum-check's q_1 over the multiplication domain,
+// arkworks/marlin/src/ahp/prover.rs:517-541: eight launches and seventeen vector passes as separate operations)
+__global__ void __launch_bounds__(256) k_outer_q1(const void* s, const void* a, const void* b, const void* z, const void* rp, const void* tp,
+                                                  FrK ka, FrK kb, FrK kc, void* out, size_t n) {
+    const Fr fa = frk(ka), fb = frk(kb), fc = frk(kc);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr t = fr_add(fr_add(fr_mul(fr_load(s, i), fc), fr_mul(fr_load(a, i), fa)), fr_mul(fr_load(b, i), fb));
+        t = fr_mul32(fr_mul(fr_load(rp, i), t));
+        const Fr u = fr_mul32(fr_mul(fr_load(z, i), fr_load(tp, i)));
+        fr_store(out, i, fr_sub(t, u));
+    }
 }
 
 // out = (a - b) * k
@@ -124,6 +152,30 @@ int zk_vec_scale_launch(zk_ctx* ctx, const void* a, const uint32_t* k9, void* ou
     return ZK_OK;
 }
 
+int zk_fr_lincomb_launch(zk_ctx* ctx, int terms, const void* const* ps, const size_t* ns, const uint32_t (*k9)[9], void* out, size_t n_out) {
+    if (n_out == 0) return ZK_OK;
+    for (int t0 = 0; t0 < terms || t0 == 0; t0 += LINCOMB_MAX) {
+        LinComb c{};
+        c.terms = std::min(LINCOMB_MAX, terms - t0);
+        for (int t = 0; t < c.terms; t++) {
+            c.p[t] = ps[t0 + t];
+            c.n[t] = std::min(ns[t0 + t], n_out);
+            for (int i = 0; i < 9; i++) c.k[t].l[i] = k9[t0 + t][i];
+        }
+        hipLaunchKernelGGL(k_lincomb, zk_grid(n_out, 256), 256, 0, ctx->stream, c, out, n_out, t0 ? 1 : 0);
+        ZK_HIP(ctx, hipGetLastError());
+    }
+    return ZK_OK;
+}
+
+int zk_fr_outer_q1_launch(zk_ctx* ctx, const void* s, const void* a, const void* b, const void* z, const void* rp, const void* tp,
+                          const uint32_t* ka9, const uint32_t* kb9, const uint32_t* kc9, void* out, size_t n) {
+    if (n == 0) return ZK_OK;
+    hipLaunchKernelGGL(k_outer_q1, zk_grid(n, 256), 256, 0, ctx->stream, s, a, b, z, rp, tp, to_frk(ka9), to_frk(kb9), to_frk(kc9), out, n);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+
 int zk_vec_sub_scale_launch(zk_ctx* ctx, const void* a, const void* b, const uint32_t* k9, void* out, size_t n) {
     if (n == 0) return ZK_OK;
     hipLaunchKernelGGL(k_vec_sub_scale, zk_grid(n, 256), 256, 0, ctx->stream, a, b, to_frk(k9), out, n);
@@ -186,6 +238,28 @@ extern "C" int zk_beaver_combine_dev(zk_ctx* ctx, const void* sx, const void* oy
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
     ZK_API_END
+}
+
+// The same test without the wait: the verdict (0 = every element is zero) lands in a page-locked word once the context stream has
+// passed this point; up to 8 tests in flight (slot).  For a prover whose next step does not depend on the verdict (Marlin's
+// divisibility checks: the round's commitments are enqueued first, the verdict is read behind them).
+int zk_fr_vec_is_zero_launch(zk_ctx* ctx, const void* v, size_t n, int slot, const uint32_t** verdict) {
+    if (slot < 0 || slot >= 8) return ZK_ERR_ARG;
+    uint32_t* flag;
+    ZK_TRY(zk_scratch(ctx, "vec_flag_async", 8 * 16, (void**)&flag));
+    auto& pin = ctx->pinned[-5];
+    if (pin.bytes < 8 * 16) {
+        if (pin.p) (void)hipHostFree(pin.p);
+        pin.p = nullptr; pin.bytes = 0;
+        ZK_HIP(ctx, hipHostMalloc(&pin.p, 8 * 16, hipHostMallocDefault));
+        pin.bytes = 8 * 16;
+    }
+    uint32_t* h = (uint32_t*)pin.p + 4 * slot;
+    ZK_HIP(ctx, hipMemsetAsync(flag + 4 * slot, 0, 4, ctx->stream));
+    if (n) hipLaunchKernelGGL(k_any_nonzero, zk_grid(2 * n, 256), 256, 0, ctx->stream, v, n, flag + 4 * slot);
+    ZK_HIP(ctx, hipMemcpyAsync(h, flag + 4 * slot, 4, hipMemcpyDeviceToHost, ctx->stream));
+    *verdict = h;
+    return ZK_OK;
 }
 
 extern "C" int zk_fr_vec_is_zero_dev(zk_ctx* ctx, const void* v, size_t n, int* is_zero) {
