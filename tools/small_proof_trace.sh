@@ -15,7 +15,7 @@ try:
 except Exception as e: print(e)
 rows.sort()
 acc=[i for i,r in enumerate(rows) if r[2].startswith('k_accum') and r[2].endswith('.g2')]
-i0=acc[-3]
+i0=acc[8]
 t0=rows[i0][0]-600_000
 out=open('gpurun_out/r5_small_timeline.txt','w')
 for s,e,k,g,q in rows:

@@ -185,7 +185,6 @@ int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const vo
         }
         if (rc == ZK_OK) { ctx->presort = nf.release(); front_enqueued = true; }
     }
-    if (getenv("ZK_TRACE_FRONT")) fprintf(stderr, "front: presorted %d fronted %d begun %d l_shared %d next_z %p enqueued %d small %d grouped %d\n", (int)presorted, (int)fronted, (int)begun, (int)l_shared, ctx->next_z, (int)front_enqueued, (int)small_jobs, (int)grouped);
     ctx->next_z = nullptr;
     // finish in completion order: the host-side Horner of an early job overlaps the GPU work of the later ones
     void* outs[5] = {out_g2, &out_g1[2], &out_g1[3], &out_g1[1], &out_g1[0]};

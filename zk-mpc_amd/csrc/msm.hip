@@ -435,6 +435,34 @@ __global__ void __launch_bounds__(SS_NT) k_sort_small(SortSmallArgs a) { sort_sm
 struct SortSmallGroup { SortSmallArgs j[GRID_SRC_MAX]; };
 __global__ void __launch_bounds__(SS_NT) k_sort_small_group(SortSmallGroup g) { sort_small_body(g.j[blockIdx.x]); }
 
+// The operations of ec_dual.cuh for G1: a lane PAIR per point addition (small, latency-bound jobs: the accumulate kernel, the folds
+// and the grid reduce below).  Both lanes carry the whole point; the even one stores.
+struct G1DualOps {
+    using F = G1Field;
+    using T = typename F::T;
+    static __device__ __forceinline__ bool hi() { return (threadIdx.x & 1u) != 0; }
+    static __device__ __forceinline__ T mul(const T& a, const T& b) { return F::mul_l(a, b); }
+    static __device__ __forceinline__ T mul_wide(const T& a, const T& b) { return F::mul_l(a, b); }    // (any operands below ~7p)
+    static __device__ __forceinline__ T swap(const T& a) {
+        T r;
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(T) / sizeof(uint32_t)); i++)
+            r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+        return r;
+    }
+    static __device__ __forceinline__ T zero() { return F::zero(); }
+    static __device__ __forceinline__ T one() { return F::one(); }
+    static __device__ __forceinline__ XYZZ<F> dbl_affine(const Affine<F>& q) { return xyzz_dbl_affine<F>(q); }
+    static __device__ __forceinline__ bool is_zero(const T& a) { return F::is_zero(a); }
+    static __device__ __forceinline__ bool maybe_multiple_of_p(const T& a) { return F::maybe_multiple_of_p(a); }
+    static __device__ __forceinline__ T select(bool c, const T& a, const T& b) { return F::select(c, a, b); }
+    template <int K> static __device__ __forceinline__ T sub_kp(const T& a, const T& b) { return F::template sub_kp<K>(a, b); }
+    static __device__ __forceinline__ T x3_l(const T& rr, const T& ppp, const T& qq) { return F::x3_l(rr, ppp, qq); }
+    static __device__ __forceinline__ T canon(const T& a) { return F::canon(a); }
+    static __device__ __forceinline__ T canon1(const T& a) { return F::canon1(a); }
+    static __device__ __forceinline__ XYZZ<F> dbl(const XYZZ<F>& a) { return xyzz_dbl<F>(a); }
+};
+
 // Persistent lanes over the length-sorted segment list: the grid is exactly 2 blocks per CU and thread g
 // takes segments g, g + G, g + 2G, ... (G = total threads).  Neighbouring lanes always hold segments of
 // (nearly) equal length, every thread gets the same long-to-short mix, and -- unlike a grid with one thread
@@ -453,7 +481,7 @@ __global__ void __launch_bounds__(SS_NT) k_sort_small_group(SortSmallGroup g) { 
 #ifndef ZK_ACCUM_WAVES_G2
 #define ZK_ACCUM_WAVES_G2 1
 #endif
-template <class F, bool LIMB_TABLE>
+template <class F, bool LIMB_TABLE, bool DUAL = false>
 __device__ __forceinline__ void accum_body(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted, const SegDesc* __restrict__ desc,
                                            const uint32_t* __restrict__ order, const uint32_t* __restrict__ ctr, uint32_t* __restrict__ sums, uint32_t stride) {
     // stride: words between consecutive points of `bases` (2 * WORDS packed; 32 for a G1 table of window multiples: one point per line)
@@ -486,8 +514,8 @@ __device__ __forceinline__ void accum_body(const uint32_t* __restrict__ bases, c
         }
     };
     const uint32_t S = ctr[2];
-    const uint32_t G = gridDim.x * blockDim.x;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < S; t += G) {
+    const uint32_t G = (gridDim.x * blockDim.x) >> (DUAL ? 1 : 0);
+    for (uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> (DUAL ? 1 : 0); t < S; t += G) {
         const SegDesc d = desc[order[t]];
         XYZZ<F> acc = xyzz_inf<F>();
         if (d.len) {
@@ -506,10 +534,15 @@ __device__ __forceinline__ void accum_body(const uint32_t* __restrict__ bases, c
                 // digit takes p - y in one carry pass; nothing is compared or selected until the segment is through
                 const bool inf = aff_is_inf<F>(cur);
                 if (!LIMB_TABLE && (ce >> 31)) cur.y = F::template kp_minus<1>(cur.y);
-                if (!inf) acc = xyzz_madd_lazy<F>(acc, cur);
+                if (!inf) {
+                    if constexpr (DUAL) acc = xyzz_madd_dual<G1DualOps, XYZZ<F>, Affine<F>>(acc, cur);
+                    else acc = xyzz_madd_lazy<F>(acc, cur);
+                }
             }
-            acc = xyzz_canon_lazy<F>(acc);
+            if constexpr (DUAL) acc = XYZZ<F>{F::canon(acc.x), F::canon(acc.y), F::canon1(acc.zz), F::canon1(acc.zzz)};   // (y < 3p + eps there)
+            else acc = xyzz_canon_lazy<F>(acc);
         }
+        if (DUAL && G1DualOps::hi()) continue;
         xyzz_store16<F>(sums, d.dst, acc);
     }
 }
@@ -524,10 +557,10 @@ k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
 constexpr int MSM_GROUP_MAX = GRID_SRC_MAX;
 struct AccumArgs { const uint32_t* bases; const uint32_t* sorted; const SegDesc* desc; const uint32_t* order; const uint32_t* ctr; uint32_t* sums; uint32_t stride; };
 struct AccumGroup { AccumArgs j[MSM_GROUP_MAX]; };
-template <class F, bool LIMB_TABLE>
+template <class F, bool LIMB_TABLE, bool DUAL = false>
 __global__ void __launch_bounds__(256, (F::WORDS == 12 ? ZK_ACCUM_WAVES_G1 : ZK_ACCUM_WAVES_G2)) k_accum_group(AccumGroup g) {
     const AccumArgs& a = g.j[blockIdx.y];
-    accum_body<F, LIMB_TABLE>(a.bases, a.sorted, a.desc, a.order, a.ctr, a.sums, a.stride);
+    accum_body<F, LIMB_TABLE, DUAL>(a.bases, a.sorted, a.desc, a.order, a.ctr, a.sums, a.stride);
 }
 
 // LDS staging of one XYZZ point per lane, word-major (word k of lane t at lds[k * NT + t]): consecutive lanes hit
@@ -573,40 +606,65 @@ __device__ __forceinline__ XYZZ<F> rcanon(const XYZZ<F>& a) {
 // ones (repeated scalars, 0/1 witnesses), one 64-lane block per entry: strided partial sums, then an LDS tree.
 // A bucket folded in two levels (k_build_segs) has one entry per group of FOLD_GROUP segments; the block that finishes the LAST
 // group of a bucket (a counter per second-level entry in `done`, which it leaves at zero again) adds the group sums up.
-template <class F>
+// DUAL (small jobs, G1): every addition on a lane pair (ec_dual.cuh) -- 32 pairs per block instead of 64 lanes; sums are brought back
+// to reduced coordinates where they are stored (the exact and the lazy readers both take them).
+template <class F, bool DUAL>
+__device__ __forceinline__ XYZZ<F> fold_add(const XYZZ<F>& a, const XYZZ<F>& b) {
+    if constexpr (DUAL) return xyzz_add_dual<G1DualOps, XYZZ<F>>(a, b);
+    else return radd<F>(a, b);
+}
+template <class F, bool DUAL>
+__device__ __forceinline__ XYZZ<F> fold_pack(const XYZZ<F>& a) {
+    if constexpr (DUAL) return XYZZ<F>{F::canon(a.x), F::canon(a.y), a.zz, a.zzz};
+    else return rpack<F>(a);
+}
+template <class F, bool DUAL>
+__device__ __forceinline__ XYZZ<F> fold_canon(const XYZZ<F>& a) {
+    if constexpr (DUAL) return XYZZ<F>{F::canon(a.x), F::canon(a.y), F::canon1(a.zz), F::canon1(a.zzz)};
+    else return rcanon<F>(a);
+}
+template <class F, bool DUAL = false>
 __device__ __forceinline__ void fold_block(uint32_t* lds, uint32_t* sums, uint32_t first, uint32_t nseg, uint32_t key, uint32_t tid) {
+    constexpr uint32_t SH = DUAL ? 1 : 0, NG = 64 >> SH;
+    const uint32_t lt = tid >> SH;
+    const bool writer = !DUAL || (tid & 1u) == 0;
     XYZZ<F> acc = xyzz_inf<F>();
-    for (uint32_t j = tid; j < nseg; j += 64) acc = radd<F>(acc, xyzz_load16<F>(sums, (size_t)first + j));
-    lds_put_xyzz<F, 64>(lds, tid, rpack<F>(acc));
+    for (uint32_t j = lt; j < nseg; j += NG) acc = fold_add<F, DUAL>(acc, xyzz_load16<F>(sums, (size_t)first + j));
+    if (writer) lds_put_xyzz<F, 64>(lds, lt, fold_pack<F, DUAL>(acc));
     __syncthreads();
-    for (uint32_t d = 32; d >= 1; d >>= 1) {
-        if (tid < d) lds_put_xyzz<F, 64>(lds, tid, rpack<F>(radd<F>(lds_get_xyzz<F, 64>(lds, tid), lds_get_xyzz<F, 64>(lds, tid + d))));
+    for (uint32_t d = NG / 2; d >= 1; d >>= 1) {
+        XYZZ<F> r = acc;
+        if (lt < d) r = fold_pack<F, DUAL>(fold_add<F, DUAL>(lds_get_xyzz<F, 64>(lds, lt), lds_get_xyzz<F, 64>(lds, lt + d)));
+        __syncthreads();
+        if (lt < d && writer) lds_put_xyzz<F, 64>(lds, lt, r);
         __syncthreads();
     }
-    if (tid == 0) xyzz_store16<F>(sums, key, rcanon<F>(lds_get_xyzz<F, 64>(lds, 0)));
+    if (tid == 0) xyzz_store16<F>(sums, key, fold_canon<F, DUAL>(lds_get_xyzz<F, 64>(lds, 0)));
     __syncthreads();
 }
 
-template <class F>
+template <class F, bool DUAL = false>
 __device__ __forceinline__ void fold_body(const HeavyDesc* heavy, const HeavyDesc* heavy2, const uint32_t* ctr, uint32_t* done, uint32_t* sums, uint32_t light_blocks) {
     extern __shared__ uint32_t lds[];  // 64 * XW words (heavy blocks only)
     __shared__ uint32_t last_flag;
+    constexpr uint32_t SH = DUAL ? 1 : 0, NG = 64 >> SH;
     const uint32_t nheavy = ctr[0];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lt = tid >> SH;
+    const bool writer = !DUAL || (tid & 1u) == 0;
     if (blockIdx.x < light_blocks) {
-        for (uint32_t hb = blockIdx.x * 64 + tid; hb < nheavy; hb += light_blocks * 64) {
+        for (uint32_t hb = blockIdx.x * NG + lt; hb < nheavy; hb += light_blocks * NG) {
             const HeavyDesc h = heavy[hb];
             if (h.nseg > FOLD_LIGHT || h.parent != HEAVY_NONE) continue;
             XYZZ<F> acc = xyzz_load16<F>(sums, (size_t)h.first);
-            for (uint32_t j = 1; j < h.nseg; j++) acc = radd<F>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
-            xyzz_store16<F>(sums, h.key, rcanon<F>(acc));
+            for (uint32_t j = 1; j < h.nseg; j++) acc = fold_add<F, DUAL>(acc, xyzz_load16<F>(sums, (size_t)h.first + j));
+            if (writer) xyzz_store16<F>(sums, h.key, fold_canon<F, DUAL>(acc));
         }
         return;
     }
     for (uint32_t hb = blockIdx.x - light_blocks; hb < nheavy; hb += gridDim.x - light_blocks) {
         const HeavyDesc h = heavy[hb];
         if (h.nseg <= FOLD_LIGHT && h.parent == HEAVY_NONE) continue;
-        fold_block<F>(lds, sums, h.first, h.nseg, h.key, tid);
+        fold_block<F, DUAL>(lds, sums, h.first, h.nseg, h.key, tid);
         if (h.parent == HEAVY_NONE) continue;
         const HeavyDesc up = heavy2[h.parent];
         if (tid == 0) {
@@ -618,22 +676,21 @@ __device__ __forceinline__ void fold_body(const HeavyDesc* heavy, const HeavyDes
         __syncthreads();
         if (last_flag) {
             __threadfence();
-            fold_block<F>(lds, sums, up.first, up.nseg, up.key, tid);
+            fold_block<F, DUAL>(lds, sums, up.first, up.nseg, up.key, tid);
         }
         __syncthreads();
     }
 }
 template <class F>
-__global__ void __launch_bounds__(64)
-k_fold(const HeavyDesc* heavy, const HeavyDesc* heavy2, const uint32_t* ctr, uint32_t* done, uint32_t* sums, uint32_t light_blocks) {
+__global__ void __launch_bounds__(64) k_fold(const HeavyDesc* heavy, const HeavyDesc* heavy2, const uint32_t* ctr, uint32_t* done, uint32_t* sums, uint32_t light_blocks) {
     fold_body<F>(heavy, heavy2, ctr, done, sums, light_blocks);
 }
 struct FoldArgs { const HeavyDesc* heavy; const HeavyDesc* heavy2; const uint32_t* ctr; uint32_t* done; uint32_t* sums; };
 struct FoldGroup { FoldArgs j[MSM_GROUP_MAX]; };
-template <class F>
+template <class F, bool DUAL = false>
 __global__ void __launch_bounds__(64) k_fold_group(FoldGroup g, uint32_t light_blocks) {
     const FoldArgs& a = g.j[blockIdx.y];
-    fold_body<F>(a.heavy, a.heavy2, a.ctr, a.done, a.sums, light_blocks);
+    fold_body<F, DUAL>(a.heavy, a.heavy2, a.ctr, a.done, a.sums, light_blocks);
 }
 
 // The bucket reduction proper is msm_reduce.cuh (row / column sums of the bucket grid, then bit sums); this is its point policy
@@ -655,28 +712,6 @@ struct RedG1 {
 
 // ... for a SMALL bucket set (a chain of dependent additions on waves that sit alone on their SIMD): every addition on a lane PAIR,
 // seven product times instead of fourteen (ec_dual.cuh).  Both lanes of a pair carry the whole point; the even one stores.
-struct G1DualOps {
-    using F = G1Field;
-    using T = typename F::T;
-    static __device__ __forceinline__ bool hi() { return (threadIdx.x & 1u) != 0; }
-    static __device__ __forceinline__ T mul(const T& a, const T& b) { return F::mul_l(a, b); }
-    static __device__ __forceinline__ T swap(const T& a) {
-        T r;
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(T) / sizeof(uint32_t)); i++)
-            r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.l[i], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
-        return r;
-    }
-    static __device__ __forceinline__ T zero() { return F::zero(); }
-    static __device__ __forceinline__ bool is_zero(const T& a) { return F::is_zero(a); }
-    static __device__ __forceinline__ bool maybe_multiple_of_p(const T& a) { return F::maybe_multiple_of_p(a); }
-    static __device__ __forceinline__ T select(bool c, const T& a, const T& b) { return F::select(c, a, b); }
-    template <int K> static __device__ __forceinline__ T sub_kp(const T& a, const T& b) { return F::template sub_kp<K>(a, b); }
-    static __device__ __forceinline__ T x3_l(const T& rr, const T& ppp, const T& qq) { return F::x3_l(rr, ppp, qq); }
-    static __device__ __forceinline__ T canon(const T& a) { return F::canon(a); }
-    static __device__ __forceinline__ T canon1(const T& a) { return F::canon1(a); }
-    static __device__ __forceinline__ XYZZ<F> dbl(const XYZZ<F>& a) { return xyzz_dbl<F>(a); }
-};
 struct RedG1Dual {
     using F = G1Field;
     using X = XYZZ<F>;
@@ -1079,9 +1114,18 @@ static int msm_enqueue_accum_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count
     ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
     jobs[0]->timers.push_back(tm);
     tm->begin("msm_g1.accum");
-    const dim3 grid((unsigned)((max_segs + 255) / 256), (unsigned)count);
-    if (jobs[0]->stride == 64) hipLaunchKernelGGL((k_accum_group<F, true>), grid, 256, 0, st, g);
-    else hipLaunchKernelGGL((k_accum_group<F, false>), grid, 256, 0, st, g);
+    // a group that cannot give every SIMD a wave (<= 2^18 digits = 2^15 segments of 8 in all): a lane pair per segment (ec_dual.cuh)
+    size_t digits = 0;
+    for (int k = 0; k < count; k++) digits += (size_t)jobs[k]->n * jobs[k]->W;
+    const bool dual = digits <= ((size_t)1 << 18);
+    const dim3 grid((unsigned)((max_segs + (dual ? 127 : 255)) / (dual ? 128 : 256)), (unsigned)count);
+    if (jobs[0]->stride == 64) {
+        if (dual) hipLaunchKernelGGL((k_accum_group<F, true, true>), grid, 256, 0, st, g);
+        else hipLaunchKernelGGL((k_accum_group<F, true>), grid, 256, 0, st, g);
+    } else {
+        if (dual) hipLaunchKernelGGL((k_accum_group<F, false, true>), grid, 256, 0, st, g);
+        else hipLaunchKernelGGL((k_accum_group<F, false>), grid, 256, 0, st, g);
+    }
     ZK_HIP(ctx, hipGetLastError());
     tm->end();
     for (int k = 0; k < count; k++) {
@@ -1125,7 +1169,8 @@ static int msm_enqueue_reduce_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int coun
     tm->begin("msm_g1.reduce");
     const unsigned light_blocks = (unsigned)std::min<size_t>((max_heavy + 63) / 64, 128);
     const unsigned heavy_blocks = (unsigned)std::min<size_t>(max_heavy, 256);
-    hipLaunchKernelGGL(k_fold_group<F>, dim3(light_blocks + heavy_blocks, (unsigned)count), 64, 64 * XW * 4, st, fg, light_blocks);
+    if (dual) hipLaunchKernelGGL((k_fold_group<F, true>), dim3(2 * light_blocks + heavy_blocks, (unsigned)count), 64, 64 * XW * 4, st, fg, 2 * light_blocks);
+    else hipLaunchKernelGGL(k_fold_group<F>, dim3(light_blocks + heavy_blocks, (unsigned)count), 64, 64 * XW * 4, st, fg, light_blocks);
     if (dual) {
         hipLaunchKernelGGL(k_grid_l1<RedG1Dual>, gg.row_blocks + gg.col_blocks, RedG1Dual::NT, RedG1Dual::PTS * XW * 4, st, src, rowP, colP, gg);
         hipLaunchKernelGGL(k_grid_bits<RedG1Dual>, gg.n_win * nout, RedG1Dual::NT, RedG1Dual::PTS * XW * 4, st, (const uint32_t*)rowP, (const uint32_t*)colP, bits, gg);
