@@ -16,7 +16,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # what the accumulate kernels are made of: a traffic file belongs to ONE state of these sources (bench.py refuses another)
-KERNEL_SOURCES = ["msm.hip", "msm_sort.hip", "msm_g2pair.hip", "msm_reduce.cuh", "msm_digits.cuh", "fixed_base.hip", "ec.cuh", "fp29.cuh"]
+KERNEL_SOURCES = ["msm.hip", "msm_sort.hip", "msm_g2pair.hip", "msm_reduce.cuh", "msm_digits.cuh", "fixed_base.hip", "ec.cuh", "ec_dual.cuh", "fp29.cuh"]
 
 
 def sources_sha256():
