@@ -477,3 +477,55 @@ def test_window_multiple_layouts(ctx, group, layout, note):
             finally:
                 other.free()
     bases.free(); dk.free(); ds.free()
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_lane_group_additions_special_cases(ctx, group):
+    """Round 5: the additions of small (latency-bound) jobs run on two lane groups (ec_dual.cuh: G1 pairs in the group accumulate /
+    fold / grid reduce, G2 quads in the accumulate / fold / grid reduce).  Tables with REPEATED points and their negatives force the
+    branches random inputs never take: the same point twice in a bucket (mixed addition -> doubling), P and -P in a bucket
+    (-> infinity), equal and opposite bucket sums in the folds and trees; single jobs and a batch of three (the group path)."""
+    rng = O.Prng(900 + group)
+    n = 512
+    if group == 1:
+        pts, neg, mul, add, to_arr, to_aff = g1_points(rng, 4), O.g1_neg, O.g1_mul, O.g1_add, cv.g1_affine_to_array, cv.g1_projective_to_affine
+    else:
+        pts, neg, mul, add, to_arr, to_aff = g2_points(rng, 4), O.g2_neg, O.g2_mul, O.g2_add, cv.g2_affine_to_array, cv.g2_projective_to_affine
+    # base i: point (i % 4), negated when (i // 4) is odd; every 37th one is the point at infinity
+    kind = [(i % 4, (i // 4) & 1, i % 37 == 36) for i in range(n)]
+    table = [None if inf else (neg(pts[j]) if sgn else pts[j]) for j, sgn, inf in kind]
+    bases = ctx.bases_upload(to_arr(table), group)
+    bases.precompute()
+    assert ctx.lib.zk_bases_window_bits(bases.h) >= 9
+    r = O.R_MOD
+
+    def expect(sc, off, m):
+        tot = [0, 0, 0, 0]
+        for s, (j, sgn, inf) in zip(sc[:m], kind[off:off + m]):
+            if not inf:
+                tot[j] = (tot[j] + (r - s if sgn else s)) % r
+        acc = None
+        for j in range(4):
+            if tot[j]:
+                acc = add(acc, mul(pts[j], tot[j]))
+        return acc
+    sets = {"equal": [0x1234567] * n,                                        # the same digit for every base: doublings and cancellations
+            "pairs": [int(rng.fr()) if i % 8 < 4 else 0 for i in range(n)],   # P's scalar ...
+            "uniform": [int(rng.fr()) for _ in range(n)],
+            "small": [i % 3 for i in range(n)],
+            "same": [5 if i % 8 == 0 else 0 for i in range(n)],              # one bucket: P0, P0, P0, ... (P + P in the accumulate loop)
+            "cancel": [5 if i % 4 == 0 else 0 for i in range(n)]}            # one bucket: P0, -P0, P0, ... (-> infinity and back)
+    sets["pairs"] = [sets["pairs"][i - 4] if i % 8 >= 4 else sets["pairs"][i] for i in range(n)]     # ... and the same one for -P
+    dev = {k: ctx.upload(cv.fr_to_mont(v)) for k, v in sets.items()}
+    for name, sc in sets.items():
+        for off, m in ((0, n), (4, n - 4), (0, 300)):
+            assert to_aff(ctx.msm_dev(bases, off, dev[name].ptr, m)) == expect(sc, off, m), (name, off, m)
+    if group == 1:
+        names = ("equal", "pairs", "same", "cancel")
+        jobs = [(bases, 0, dev["equal"].ptr, n), (bases, 0, dev["pairs"].ptr, n), (bases, 0, dev["same"].ptr, n), (bases, 8, dev["cancel"].ptr, n - 8)]
+        got = ctx.msm_batch_dev(jobs)
+        for (b, off, _, m), g, name in zip(jobs, got, names):
+            assert to_aff(g) == expect(sets[name], off, m), ("batch", name)
+    for d in dev.values():
+        d.free()
+    bases.free()
