@@ -278,9 +278,11 @@ static uint32_t precompute_window_bits(size_t n) {
     while (((size_t)3 << lg) <= 2 * n) lg++;
     // >= 2^16 points, measured on whole proofs: 2^16 -> 15, 2^18 -> 16/17, 2^20..2^22 -> 20 (22 loses: 4x the buckets).
     // Smaller tables (round 5: the reference's own circuits are 2^2 .. 2^15 constraints) are latency, not throughput: a window
-    // of lg + 2 bits leaves ~W / 4 = 4-5 terms per bucket (the accumulate kernel lasts as long as its fullest bucket) and ONE
+    // of about lg + 2 bits leaves ~W / 4 = 4-5 terms per bucket (the accumulate kernel lasts as long as its fullest bucket) and ONE
     // bucket set means the host's Horner chain over ~30 windows -- 0.7 ms of a 2 ms proof at 2^10 -- shrinks to ~2 log2(NB) additions.
-    int c0 = lg >= 16 ? (int)lg - 1 : (int)lg + 2;
+    // (second half of round 5, with the reduce of small bucket sets on lane groups: lg + 1 from 2^13 up -- it only moves 2^14, 16 -> 15 bits:
+    // proof 1.11 -> 0.94 ms; the other sizes land on the same width through the top-window rule below)
+    int c0 = lg >= 16 ? (int)lg - 1 : (lg >= 13 ? (int)lg + 1 : (int)lg + 2);
     const int lo = lg >= 16 ? 13 : 9, hi = lg >= 16 ? 20 : 16;
     if (c0 < lo) c0 = lo;
     if (c0 > hi) c0 = hi;

@@ -89,8 +89,10 @@ int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const vo
                                              : zk_msm_prepare(ctx, J[3], pk->l, 0, zb + r->ni * 32, r->nw, 4);
     if (rc == ZK_OK && !presorted) rc = zk_msm_enqueue_sort(ctx, J[0], s_sort, nullptr);
     if (rc == ZK_OK && !begun) rc = zk_msm_enqueue_sort(ctx, J[1], s_sort, J[0]);
-    if (rc == ZK_OK && !begun) rc = zk_msm_enqueue_sort(ctx, J[2], s_sort, J[0]);
-    if (rc == ZK_OK && !begun && l_shared) rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, J[0]);
+    // (the G2 table may carry windows of another width than the G1 tables: then A sorts for itself and the other G1 jobs borrow A's)
+    const ZkMsmJob* lender = J[0]->c == J[1]->c ? J[0] : J[1];
+    if (rc == ZK_OK && !begun) rc = zk_msm_enqueue_sort(ctx, J[2], s_sort, lender);
+    if (rc == ZK_OK && !begun && l_shared) rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, lender);
     const void* h = h_in;
     ZkPhaseTimer tm(ctx);
     // the first accumulate kernel is gated on the witness map, which would otherwise be starved beside it (un-gating it: within

@@ -1037,9 +1037,11 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
 
 // ---- a group of small G1 jobs: one sort launch (a block per job), one accumulate launch, one launch per level of the reduce chain --
 // The sorts of a group: every job must qualify for the one-block sort (zk_msm_sort_group_ok; else the per-job calls).
+// (a block per job side by side: up to 2^17 digits each -- 160 us -- still beats ten launches per job one job behind the other)
+constexpr uint32_t SS_GROUP_MAX_ENTRIES = 1u << 17;
 static bool sort_small_fits(const ZkMsmJob* j) {
     const bool merged = j->Wb == 1 && j->W > 1;
-    return j->n > 0 && merged && (size_t)j->W * j->n <= SS_MAX_ENTRIES && j->NB <= SS_MAX_NB && j->seg <= SS_MAX_SEG;
+    return j->n > 0 && merged && (size_t)j->W * j->n <= SS_GROUP_MAX_ENTRIES && j->NB <= SS_MAX_NB && j->seg <= SS_MAX_SEG;
 }
 static bool msm_sort_group_ok(ZkMsmJob* const* jobs, int count) {
     if (count < 1 || count > MSM_GROUP_MAX) return false;
