@@ -570,6 +570,10 @@ int zk_diag_int_mad_peak(zk_ctx* ctx, int launches, double* best_mads_per_s, dou
  * two_adic_root_of_unity() (arkworks/curves/bls12_377/src/fields/tests.rs:352-370) and the same relation of fr.rs's constants. */
 int zk_diag_fq_pow_dev(zk_ctx* ctx, const zk_fq* base, const uint64_t exp[6], int lazy, zk_fq* out);
 int zk_diag_fr_pow_dev(zk_ctx* ctx, const zk_fr* base, const uint64_t exp[4], int lazy, zk_fr* out);
+/* Diagnostic: k * a in G1 through the curve's endomorphism (hostfield64.hpp: host64_scalar_mul_glv: k split at lambda = z^2 - 1, one
+ * joint chain) -- what the host tail of a Groth16 proof runs for keys made by zk_groth16_setup.  Equal to zk_g1_mul for every point of
+ * the prime-order subgroup; kept apart from it because ProjectiveCurve::mul (zk_g1_mul) is defined on the whole curve. */
+int zk_diag_g1_mul_glv(const zk_g1_projective* a, const zk_fr* k, zk_g1_projective* out);
 
 #ifdef __cplusplus
 }

@@ -110,6 +110,33 @@ class _Host(Z.Context):
         self.h = None
 
 
+def test_g1_scalar_mul_through_the_endomorphism():
+    """hostfield64.hpp::host64_scalar_mul_glv (the Groth16 tail's G1 scalar multiplications for keys made by zk_groth16_setup): k P by
+    k = k1 + k2 lambda and phi(x, y) = (beta x, y), against the oracle's double-and-add and the plain host chain -- random scalars,
+    the split's edges (0, 1, lambda - 1, lambda, lambda + 1, multiples of lambda, r - 1), the point at infinity."""
+    import ctypes as C
+    h = _Host()
+    rng = O.Prng(77)
+    z = 0x8508c00000000001
+    lam = z * z - 1
+    assert (lam * lam + lam + 1) % O.R_MOD == 0
+    P = O.g1_mul(O.G1_GEN, rng.fr())
+    pa = h.g1_from_affine(cv.g1_affine_to_array([P])[0])
+    ks = [0, 1, 2, 3, lam - 1, lam, lam + 1, 2 * lam, 3 * lam + 2, lam * lam % O.R_MOD, O.R_MOD - 1, O.R_MOD - lam, (1 << 252) + 5]
+    ks += [rng.fr() for _ in range(12)]
+    for k in ks:
+        km = np.ascontiguousarray(cv.fr_to_mont([k])[0])
+        out = np.zeros(18, dtype=np.uint64)
+        assert h.lib.zk_diag_g1_mul_glv(pa.ctypes.data_as(C.c_void_p), km.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+        assert cv.g1_projective_to_affine(out) == O.g1_mul(P, k), hex(k)
+        assert cv.g1_projective_to_affine(out) == cv.g1_projective_to_affine(h.g1_mul(pa, km))
+    inf = h.g1_from_affine(np.zeros(12, dtype=np.uint64))
+    out = np.ones(18, dtype=np.uint64)
+    km = np.ascontiguousarray(cv.fr_to_mont([12345])[0])
+    assert h.lib.zk_diag_g1_mul_glv(inf.ctypes.data_as(C.c_void_p), km.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)) == 0
+    assert cv.g1_projective_to_affine(out) is None
+
+
 def test_host_group_helpers_against_oracle():
     """The O(1)-per-proof host helpers of the C ABI (same field / curve templates as the kernels)."""
     h = _Host()

@@ -245,6 +245,7 @@ PROTOTYPES = {
     "zk_diag_int_mad_peak": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "zk_diag_fq_pow_dev": (_I, [_P, _P, _P, _I, _P]),
     "zk_diag_fr_pow_dev": (_I, [_P, _P, _P, _I, _P]),
+    "zk_diag_g1_mul_glv": (_I, [_P, _P, _P]),
 }
 
 _lib = None

@@ -113,6 +113,7 @@ struct zk_ctx {
     std::map<std::string, int> flags;         // one-time per-context setup markers
     void* comm = nullptr;                     // RCCL communicator of this party (comm.hip), created by zk_comm_init
     void* xfer = nullptr;                     // hostxfer.hip: the page-locked ring host slices travel through (ZkXfer)
+    void* xfer_small = nullptr;               // hostxfer.hip: rotating page-locked slots for transfers below 128 KiB
     void* bases_cache = nullptr;              // bases_cache.hip: resident copies of host base slices seen by zk_msm_g1 / _g2 (ZkBasesCache)
     void* presort = nullptr;                  // groth16_pipeline.hip: a sort of z[1..] enqueued ahead of zk_groth16_msms_dev (ZkPresort)
     const void* next_z = nullptr;             // groth16_pipeline.hip: zk_groth16_hint_next_dev

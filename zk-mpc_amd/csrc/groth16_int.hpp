@@ -41,6 +41,9 @@ struct zk_pk {
     // L job indexes its table by the position in z like A and B do and reuses their sort of z[1..]; the instance part adds
     // infinity, which the complete addition skips.  Only the prover's pipeline reads it.
     zk_bases* l_pad = nullptr;
+    // every point is a multiple of the generators (zk_groth16_setup): the proof tail may use the endomorphism (hostfield64.hpp:
+    // host64_scalar_mul_glv); a deserialised key is not checked for subgroup membership and keeps the plain scalar multiplication
+    bool points_in_subgroup = false;
     zk::Affine<zk::G1Field> alpha_g1, beta_g1, delta_g1, a0, b0_g1;
     zk::Affine<zk::G2Field> beta_g2, delta_g2, gamma_g2, b0_g2;
 };
@@ -86,7 +89,9 @@ class ZkProofTail {
     using X1 = zk::XYZZ<H1>;
     using X2 = zk::XYZZ<H2>;
     zk_ctx* ctx;
+    bool glv;                                        // the key's points are in the prime-order subgroup: G1 scalar multiplications through the endomorphism
     uint32_t rw[8], sw[8];
+    X1 mul1(const X1& p, const uint32_t* k) const { return glv ? zk::host64_scalar_mul_glv(p, k) : zk::host64_scalar_mul<H1>(p, k); }
     X1 delta1;
     X2 delta2;
     zk::Affine<H1> a0, alpha, b0, beta1;

@@ -245,6 +245,7 @@ extern "C" int zk_groth16_setup(zk_ctx* ctx, const zk_r1cs* r, const zk_fr* alph
         if (rc == ZK_OK) rc = zk_bases_precompute_auto(ctx, q);
     if (rc == ZK_OK) rc = zk_pk_make_l_pad(ctx, pk);
     if (rc != ZK_OK) { zk_pk_free(ctx, pk); return rc; }
+    pk->points_in_subgroup = true;            // every point of this key is a scalar multiple of a generator
 
     const Fr k1 = ld(g1_k), k2 = ld(g2_k);
     const Affine<G1Field> g1 = host_gen_mul<G1Field>(g1_gen(), k1);

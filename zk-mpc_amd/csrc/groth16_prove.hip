@@ -9,7 +9,7 @@ using namespace zk;
 // query[0] + acc + vk_param) for A, B-in-G1 and B-in-G2, the r / s terms (:115, :140, :161), C (:169-174) and the 192 bytes.
 // Everything that depends only on the A, B-in-G1 and B-in-G2 sums (and on r, s, the key) starts -- on the context's helper
 // threads -- as soon as those three MSMs have delivered (abc_ready), while the devices still work on L and H.
-ZkProofTail::ZkProofTail(zk_ctx* c, const zk_pk* pk, const zk_fr* r_, const zk_fr* s_) : ctx(c) {
+ZkProofTail::ZkProofTail(zk_ctx* c, const zk_pk* pk, const zk_fr* r_, const zk_fr* s_) : ctx(c), glv(pk->points_in_subgroup) {
     fr_abi_to_canon_words(r_->l, rw);
     fr_abi_to_canon_words(s_->l, sw);
     delta1 = xyzz_from_affine<H1>(aff_to_host64<G1Field>(pk->delta_g1));
@@ -19,10 +19,10 @@ ZkProofTail::ZkProofTail(zk_ctx* c, const zk_pk* pk, const zk_fr* r_, const zk_f
     b02 = aff_to_host64<G2Field>(pk->b0_g2); beta2 = aff_to_host64<G2Field>(pk->beta_g2);
     // the scalar multiplications that need no MSM result: four of the seven of a proof (0.2 - 0.7 ms each on one host thread)
     pre_a = zk_async(ctx, [this] {
-        r_g1 = host64_scalar_mul<H1>(delta1, rw);
-        r_s_delta = host64_scalar_mul<H1>(r_g1, sw);                                                     // :115
+        r_g1 = mul1(delta1, rw);
+        r_s_delta = mul1(r_g1, sw);                                                     // :115
     });
-    pre_b = zk_async(ctx, [this] { s_g1 = host64_scalar_mul<H1>(delta1, sw); });
+    pre_b = zk_async(ctx, [this] { s_g1 = mul1(delta1, sw); });
     pre_2 = zk_async(ctx, [this] { s_g2 = host64_scalar_mul<H2>(delta2, sw); });
 }
 
@@ -33,12 +33,12 @@ void ZkProofTail::abc_ready(const zk_g1_projective& a_sum, const zk_g1_projectiv
     chain_a = zk_async(ctx, [this, a_acc] {
         pre_a.wait();
         g_a = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(r_g1, a0), a_acc), alpha);
-        s_g_a = host64_scalar_mul<H1>(g_a, sw);                                                           // :140
+        s_g_a = mul1(g_a, sw);                                                           // :140
     });
     chain_b = zk_async(ctx, [this, b1_acc] {
         pre_b.wait();
         const X1 g1_b = xyzz_madd<H1>(xyzz_add<H1>(xyzz_madd<H1>(s_g1, b0), b1_acc), beta1);
-        r_g1_b = host64_scalar_mul<H1>(g1_b, rw);                                                         // :161
+        r_g1_b = mul1(g1_b, rw);                                                         // :161
     });
     chain_g2 = zk_async(ctx, [this, b2_acc] {
         pre_2.wait();

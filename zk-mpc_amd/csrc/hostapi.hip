@@ -71,6 +71,16 @@ extern "C" int zk_g1_mul(const zk_g1_projective* a, const zk_fr* k, zk_g1_projec
     return mul_t<Fq64Field>((const uint64_t*)a, k, (uint64_t*)out);
     ZK_API_END
 }
+extern "C" int zk_diag_g1_mul_glv(const zk_g1_projective* a, const zk_fr* k, zk_g1_projective* out) {
+    ZK_API_BEGIN_NOCTX
+    if (!a || !k || !out) return ZK_ERR_ARG;
+    using H = Fq64Field;
+    uint32_t kw[8];
+    fr_abi_to_canon_words(k->l, kw);
+    host64_write_projective<H>(xyzz_to_affine<H>(host64_scalar_mul_glv(host64_proj_from_abi<H>((const uint64_t*)a), kw)), (uint64_t*)out);
+    return ZK_OK;
+    ZK_API_END
+}
 extern "C" int zk_g2_mul(const zk_g2_projective* a, const zk_fr* k, zk_g2_projective* out) {
     ZK_API_BEGIN_NOCTX
     return mul_t<Fq264Field>((const uint64_t*)a, k, (uint64_t*)out);
