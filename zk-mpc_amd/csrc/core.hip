@@ -2,6 +2,7 @@
 #include "../../include/zkmpc_hip.h"
 #include "ctx.hpp"
 #include "internal.hpp"
+#include <functional>
 #include <stdexcept>
 #include <string.h>
 
@@ -79,6 +80,8 @@ extern "C" int zk_ctx_destroy(zk_ctx* ctx) {
         if (kv.second.p) (void)hipHostFree(kv.second.p);
     zk_presort_free(ctx);
     zk_bases_cache_free(ctx);
+    for (auto& kv : ctx->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    ctx->graphs.clear();
     zk_xfer_free(ctx);
     zk_domains_free(ctx);
     for (auto st : ctx->aux) (void)hipStreamDestroy(st);
@@ -185,8 +188,49 @@ int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out) {
         size_t want = bytes + bytes / 8 + 256;
         ZK_HIP(ctx, hipMalloc(&s.p, want));
         s.bytes = want;
+        ctx->scratch_gen++;                            // (captured graphs hold scratch addresses: zk_graph_run)
     }
     *out = s.p;
+    return ZK_OK;
+}
+
+// Run `enqueue` -- kernel launches and memsets on `st` ONLY: no allocation, no host wait, no other stream -- and from the third use
+// with the same key on replay it as ONE graph launch.  First use: plain (scratch slots and function attributes come into being);
+// second use: captured while it is enqueued; a key must cover every argument of every launch (ctx->scratch_gen covers the scratch
+// addresses).  With the phase timers on, or ZK_GRAPHS=0, always plain.  A sort of a 2^14-scalar MSM is 13 launches of 5 - 15 us
+// of device time each: the host's ~5 us per launch was what a small Marlin round waited for.
+int zk_graph_run(zk_ctx* ctx, const std::string& key, hipStream_t st, const std::function<int()>& enqueue) {
+    static const bool off = getenv("ZK_GRAPHS") && atoi(getenv("ZK_GRAPHS")) == 0;
+    if (off || ctx->profiling) return enqueue();
+    if (ctx->graphs.size() > 512) {                    // (keys that stopped matching: addresses moved, other sizes)
+        for (auto& kv : ctx->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        ctx->graphs.clear();
+    }
+    auto& e = ctx->graphs[key];
+    if (e.exec) {
+        ZK_HIP(ctx, hipGraphLaunch(e.exec, st));
+        return ZK_OK;
+    }
+    if (e.seen++ == 0) return enqueue();
+    const uint64_t gen = ctx->scratch_gen;
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return enqueue(); }
+    const int rc = enqueue();
+    hipGraph_t g = nullptr;
+    const hipError_t ce = hipStreamEndCapture(st, &g);
+    if (rc != ZK_OK || ce != hipSuccess || !g || gen != ctx->scratch_gen) {
+        // nothing ran (a capture only records): not capturable as it stands -- enqueue it for real and stop trying for this key
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        e.seen = -(1 << 30);
+        if (rc != ZK_OK) return rc;
+        return enqueue();
+    }
+    hipGraphExec_t x = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ie != hipSuccess || !x) { (void)hipGetLastError(); e.seen = -(1 << 30); return enqueue(); }
+    e.exec = x;
+    ZK_HIP(ctx, hipGraphLaunch(e.exec, st));
     return ZK_OK;
 }
 

@@ -111,6 +111,12 @@ struct zk_ctx {
     std::map<int, Slot> pinned;     // pinned host staging per MSM slot
     std::map<uint32_t, zk_domain*> domains;  // keyed by log2(size)
     std::map<std::string, int> flags;         // one-time per-context setup markers
+    // core.hip: zk_graph_run -- a launch-bound sequence (the ~13 launches of a bucket sort) replayed as one captured graph.  Key = a
+    // digest of everything the launches depend on, `scratch_gen` included (it moves whenever a scratch slot is allocated anew: every
+    // graph that baked the old addresses in stops matching).
+    struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; };
+    std::map<std::string, GraphEntry> graphs;
+    uint64_t scratch_gen = 0;
     void* comm = nullptr;                     // RCCL communicator of this party (comm.hip), created by zk_comm_init
     void* xfer = nullptr;                     // hostxfer.hip: the page-locked ring host slices travel through (ZkXfer)
     void* xfer_small = nullptr;               // hostxfer.hip: rotating page-locked slots for transfers below 128 KiB

@@ -3,6 +3,8 @@
 #include "ctx.hpp"
 #include <stddef.h>
 #include <stdint.h>
+#include <functional>
+#include <string>
 
 // ntt.hip
 void zk_domains_free(zk_ctx* ctx);
@@ -14,6 +16,8 @@ int zk_ntt_launch_batch(zk_ctx* ctx, void* const* bufs_dev, int count, uint32_t 
 int zk_ntt_vanishing_inv(zk_ctx* ctx, uint32_t log_n, uint32_t out9[9]);  // 1/(g^N - 1), internal form
 
 // vec_ops.hip
+// core.hip: a launch-bound sequence on ONE stream as a captured graph from its third use with the same key (see there)
+int zk_graph_run(zk_ctx* ctx, const std::string& key, hipStream_t st, const std::function<int()>& enqueue);
 int zk_vec_op_launch(zk_ctx* ctx, int op, const void* a, const void* b, void* out, size_t n);
 int zk_vec_scale_launch(zk_ctx* ctx, const void* a, const uint32_t* k_int_form9, void* out, size_t n);
 // zk_fr_vec_is_zero_dev without the wait: *verdict points at a page-locked word that is 0 (all zero) or not once ctx->stream has

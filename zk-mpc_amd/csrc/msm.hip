@@ -887,7 +887,6 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     job->timers.push_back(tm);
     tm->begin(g1 ? "msm_g1.sort" : "msm_g2.sort");
     const bool one_block = merged && (size_t)W * n <= SS_MAX_ENTRIES && NB <= SS_MAX_NB && seg <= SS_MAX_SEG;      // k_sort_small: writes all of ctr itself
-    if (!one_block) ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 8 + 3 * (size_t)(seg + 1)) * 4, st));
     const uint32_t grp_base = (uint32_t)(nbuck + job->max_heavy_segs);       // where the group sums of two-level buckets live in `sums`
     auto scans = [&](uint32_t Wx, uint32_t NBx) -> int {      // counting-sort path only: one block per window
         if (NBx > 65536) ZK_FAIL(ctx, ZK_ERR_ARG, "msm: a bucket set of more than 2^16 buckets needs the bucket sort (>= 2^16 digits)");
@@ -897,7 +896,6 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     // The bucket sort (msm_sort.hip: no global atomics per digit, zero digits dropped, the segment length fitted to the input) for
     // every MSM with at least 2^16 digits; it sees ONE set of Wb*NB buckets (bucket ids w*NB + b, as the reduce phase numbers
     // them).  Small MSMs keep the counting sort with per-window offsets: a handful of short kernels.
-    uint32_t flat_buckets = 0;
     ZkGroupArgs ga;
     ga.scalars = job->scalars; ga.n = n; ga.wo = wo; ga.bias = bias; ga.W = W; ga.NB = NB; ga.merged = merged != 0;
     ga.n_tab = job->n_tab; ga.tab_off = job->tab_off; ga.NBt = (uint32_t)nbuck;
@@ -921,25 +919,42 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
         ZK_HIP(ctx, hipEventRecord(job->sort_done, st));
         return ZK_OK;
     }
-    if (((size_t)W * n >= 65536 || NB > 65536) && zk_msm_group_supported(ga)) {
-        const uint32_t NBt = (uint32_t)nbuck;
-        ZK_TRY(zk_msm_group(ctx, st, job->slot, ga));
-        hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, (const uint32_t*)nullptr, win_segs,
-                           (size_t)0, 1u, NBt, b.desc, b.heavy, b.heavy2, ctr, hist, grp_base);
-        flat_buckets = NBt;
-    } else {
-        ZK_HIP(ctx, hipMemsetAsync(b.counts, 0, nbuck * 4, st));
-        ZK_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctr + 3), (int)seg, 1, st));             // the host's plan is the segment length
-        hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, b.counts, merged);
-        ZK_TRY(scans(Wb, NB));
-        hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted, merged,
-                           job->n_tab, job->tab_off);
-        hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
-                           merged ? (size_t)0 : n, Wb, NB, b.desc, b.heavy, b.heavy2, ctr, hist, grp_base);
+    // The ~13 launches of the sort as ONE graph launch from the third sort with the same arguments on (core.hip: zk_graph_run): a
+    // prover that works through proofs of one shape sorts the same buffers with the same geometry every time, and for jobs of
+    // 2^12 .. 2^16 scalars the host's launch rate, not the device, was the length of a sort (4 sorts of a Marlin round at 2^14:
+    // 0.5 ms one behind the other on three streams).
+    std::string gkey("sort");
+    {
+        auto put = [&](const void* p, size_t nbytes) { gkey.append((const char*)p, nbytes); };
+        const uint64_t words[] = {ctx->scratch_gen, (uint64_t)(uintptr_t)job->scalars, (uint64_t)n, W, NB, Wb, job->c, seg, (uint64_t)job->slot,
+                                  (uint64_t)merged, job->n_tab, job->tab_off, (uint64_t)job->max_segs, (uint64_t)job->max_heavy_segs, (uint64_t)g1};
+        put(words, sizeof words);
+        put(job->off, sizeof job->off);
     }
-    hipLaunchKernelGGL(k_len_scan, 1, 512, 0, st, hist, bin_start, bin_cursor, ctr, flat_buckets);
-    hipLaunchKernelGGL(k_order, 512, 256, (seg + 1) * 4, st, b.desc, ctr, bin_cursor, b.order);
-    ZK_HIP(ctx, hipGetLastError());
+    ZK_TRY(zk_graph_run(ctx, gkey, st, [&]() -> int {
+        uint32_t flat_buckets = 0;
+        if (!one_block) ZK_HIP(ctx, hipMemsetAsync(b.small, 0, (64 + 8 + 3 * (size_t)(seg + 1)) * 4, st));
+        if (((size_t)W * n >= 65536 || NB > 65536) && zk_msm_group_supported(ga)) {
+            const uint32_t NBt = (uint32_t)nbuck;
+            ZK_TRY(zk_msm_group(ctx, st, job->slot, ga));
+            hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, (const uint32_t*)nullptr, win_segs,
+                               (size_t)0, 1u, NBt, b.desc, b.heavy, b.heavy2, ctr, hist, grp_base);
+            flat_buckets = NBt;
+        } else {
+            ZK_HIP(ctx, hipMemsetAsync(b.counts, 0, nbuck * 4, st));
+            ZK_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctr + 3), (int)seg, 1, st));             // the host's plan is the segment length
+            hipLaunchKernelGGL(k_digits, zk_grid(n, 256), 256, 0, st, job->scalars, n, wo, W, NB, bias, b.dig, b.counts, merged);
+            ZK_TRY(scans(Wb, NB));
+            hipLaunchKernelGGL(k_scatter, zk_grid((size_t)W * n, 256), 256, 0, st, b.dig, n, W, NB, b.offs, b.counts, b.sorted, merged,
+                               job->n_tab, job->tab_off);
+            hipLaunchKernelGGL(k_build_segs, zk_grid(nbuck, 256, 512), 256, (seg + 1) * 4, st, b.offs, b.seg_local, win_segs,
+                               merged ? (size_t)0 : n, Wb, NB, b.desc, b.heavy, b.heavy2, ctr, hist, grp_base);
+        }
+        hipLaunchKernelGGL(k_len_scan, 1, 512, 0, st, hist, bin_start, bin_cursor, ctr, flat_buckets);
+        hipLaunchKernelGGL(k_order, 512, 256, (seg + 1) * 4, st, b.desc, ctr, bin_cursor, b.order);
+        ZK_HIP(ctx, hipGetLastError());
+        return ZK_OK;
+    }));
     tm->end();
     job->sorted = b.sorted; job->desc = b.desc; job->order = b.order; job->ctr = ctr; job->heavy = b.heavy; job->heavy2 = b.heavy2;
     ZK_HIP(ctx, hipEventCreateWithFlags(&job->sort_done, hipEventDisableTiming));
