@@ -110,9 +110,10 @@ __global__ void __launch_bounds__(64) k_batch_inverse(void* v, size_t n, uint32_
 // lane whatever the vector's length (the whole of k_batch_inverse at |K| = 2^10) and ~20 us on a host core.  k_inv_fwd leaves the
 // prefix products and every chunk's total; the host inverts the totals (Montgomery's trick over them, one inversion); k_inv_bwd
 // walks the chunks back.  totals[t] (internal form, 9 limbs) = product of the chunk's non-zero elements.
-__global__ void __launch_bounds__(64) k_inv_fwd(const void* v, size_t n, uint32_t* scratch, uint32_t* totals) {
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t * INV_CH < n; t += (size_t)gridDim.x * blockDim.x) {
-        size_t lo = t * INV_CH, hi = lo + INV_CH < n ? lo + INV_CH : n;
+// (ch: elements per lane -- the lanes' chains are what these two kernels last: 8 for vectors of up to 2^14, 32 at 2^16)
+__global__ void __launch_bounds__(64) k_inv_fwd(const void* v, size_t n, size_t ch, uint32_t* scratch, uint32_t* totals) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t * ch < n; t += (size_t)gridDim.x * blockDim.x) {
+        size_t lo = t * ch, hi = lo + ch < n ? lo + ch : n;
         Fr run = fp_one<FrParams>();
         for (size_t i = lo; i < hi; i++) {
             fr_store(scratch, i, run);
@@ -123,9 +124,9 @@ __global__ void __launch_bounds__(64) k_inv_fwd(const void* v, size_t n, uint32_
         for (int k = 0; k < 9; k++) totals[t * 9 + k] = run.l[k];
     }
 }
-__global__ void __launch_bounds__(64) k_inv_bwd(void* v, size_t n, const uint32_t* scratch, const uint32_t* inv_totals) {
-    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t * INV_CH < n; t += (size_t)gridDim.x * blockDim.x) {
-        size_t lo = t * INV_CH, hi = lo + INV_CH < n ? lo + INV_CH : n;
+__global__ void __launch_bounds__(64) k_inv_bwd(void* v, size_t n, size_t ch, const uint32_t* scratch, const uint32_t* inv_totals) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t * ch < n; t += (size_t)gridDim.x * blockDim.x) {
+        size_t lo = t * ch, hi = lo + ch < n ? lo + ch : n;
         Fr inv;
 #pragma unroll
         for (int k = 0; k < 9; k++) inv.l[k] = inv_totals[t * 9 + k];
@@ -140,10 +141,10 @@ __global__ void __launch_bounds__(64) k_inv_bwd(void* v, size_t n, const uint32_
 }
 
 // out[i] = start * base^i
-__global__ void __launch_bounds__(256) k_powers(void* out, FrK base_k, FrK start_k, size_t n) {
-    constexpr int PC = 32;
+// (PC powers per lane: 32, or 8 for vectors of up to 2^16 -- the lane's chain is what a short launch lasts)
+__global__ void __launch_bounds__(256) k_powers(void* out, FrK base_k, FrK start_k, size_t n, int PC) {
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    size_t i0 = t * PC;
+    size_t i0 = t * (size_t)PC;
     if (i0 >= n) return;
     const Fr base = frk(base_k);
     Fr p = fp_one<FrParams>();
@@ -274,13 +275,15 @@ __global__ void __launch_bounds__(256) k_span_carries(const EvalJob J, const voi
     }
     if (tid == 0 && rem) fr_store(rem, 0, c);
 }
-__global__ void __launch_bounds__(256) k_fill_spans(const EvalJob J, const void* carry, void* out, int shift) {
+// carry == nullptr: a polynomial of ONE span (<= 4 096 coefficients) -- its carry-in is zero and this launch is the whole division
+// (the remainder Q_0 goes to rem when asked for): one launch instead of three for the opening witnesses of a small Marlin proof.
+__global__ void __launch_bounds__(256) k_fill_spans(const EvalJob J, const void* carry, void* out, int shift, void* rem) {
     __shared__ uint32_t buf[2][9][256];
     const Fr z = limbs9(J.z);
     const uint32_t tid = threadIdx.x;
     const size_t lo = ((size_t)blockIdx.x * 256 + tid) * EV_CH;
     const size_t hi = lo + EV_CH < J.n ? lo + EV_CH : (lo < J.n ? J.n : lo);
-    const Fr cin = fr_load(carry, blockIdx.x);
+    const Fr cin = carry ? fr_load(carry, blockIdx.x) : fp_zero<FrParams>();
     Fr h = fp_zero<FrParams>();
     for (size_t i = hi; i > lo; i--) h = fr_add(fr_mul(h, z), fr_load(J.c, i - 1));
     if (tid == 255) h = fr_add(h, fr_mul(cin, limbs9(J.lvl1[0])));      // the span's carry-in enters behind its last chunk
@@ -295,6 +298,7 @@ __global__ void __launch_bounds__(256) k_fill_spans(const EvalJob J, const void*
         const long long o = (long long)(i - 1) + shift;
         if (o >= 0) fr_store(out, (size_t)o, acc);
     }
+    if (rem && blockIdx.x == 0 && tid == 0) fr_store(rem, 0, acc);         // Q_0 (an empty chunk 0 cannot occur: n >= 1)
 }
 
 }  // namespace
@@ -305,9 +309,10 @@ extern "C" int zk_fr_powers_dev(zk_ctx* ctx, const zk_fr* base, const zk_fr* sta
     if (!n) return ZK_OK;
     Fr b = host_int(base);
     Fr s_ext = host_load_ext<FrParams>(start->l);   // kept in ext form: multiplied in after the int->ext conversion of base^i0
-    size_t threads = (n + 31) / 32;
+    const int pc = n <= ((size_t)1 << 16) ? 8 : 32;
+    size_t threads = (n + pc - 1) / pc;
     hipLaunchKernelGGL(k_powers, (unsigned)((threads + 255) / 256), 256, 0, ctx->stream, out_dev, to_frk(b),
-                       to_frk(fp_ext_to_int<FrParams>(s_ext)), n);
+                       to_frk(fp_ext_to_int<FrParams>(s_ext)), n, pc);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
     ZK_API_END
@@ -319,7 +324,9 @@ extern "C" int zk_fr_batch_inverse_dev(zk_ctx* ctx, void* v_dev, size_t n) {
     if (!n) return ZK_OK;
     uint32_t* scr;
     ZK_TRY(zk_scratch(ctx, "poly_inv", n * 32 + 32, (void**)&scr));
-    size_t chunks = (n + INV_CH - 1) / INV_CH;
+    size_t ch = 8;                                      // the shortest chunk that leaves <= 2048 totals for the host
+    while (ch < (size_t)INV_CH && (n + ch - 1) / ch > 2048) ch *= 2;
+    size_t chunks = (n + ch - 1) / ch;
     if (chunks <= 2048) {
         // short vector: the one inversion on the host (see k_inv_fwd)
         uint32_t* tot;
@@ -332,7 +339,7 @@ extern "C" int zk_fr_batch_inverse_dev(zk_ctx* ctx, void* v_dev, size_t n) {
             pin.bytes = 2048 * 36 * 2;
         }
         uint32_t* h = (uint32_t*)pin.p;
-        hipLaunchKernelGGL(k_inv_fwd, zk_grid(chunks, 64, 8192), 64, 0, ctx->stream, (const void*)v_dev, n, scr, tot);
+        hipLaunchKernelGGL(k_inv_fwd, zk_grid(chunks, 64, 8192), 64, 0, ctx->stream, (const void*)v_dev, n, ch, scr, tot);
         ZK_HIP(ctx, hipGetLastError());
         ZK_HIP(ctx, hipMemcpyAsync(h, tot, chunks * 36, hipMemcpyDeviceToHost, ctx->stream));
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -349,10 +356,11 @@ extern "C" int zk_fr_batch_inverse_dev(zk_ctx* ctx, void* v_dev, size_t n) {
             for (int k = 0; k < 9; k++) hi[t * 9 + k] = it.l[k];
         }
         ZK_HIP(ctx, hipMemcpyAsync(tot + chunks * 9, hi, chunks * 36, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_inv_bwd, zk_grid(chunks, 64, 8192), 64, 0, ctx->stream, v_dev, n, (const uint32_t*)scr, (const uint32_t*)(tot + chunks * 9));
+        hipLaunchKernelGGL(k_inv_bwd, zk_grid(chunks, 64, 8192), 64, 0, ctx->stream, v_dev, n, ch, (const uint32_t*)scr, (const uint32_t*)(tot + chunks * 9));
         ZK_HIP(ctx, hipGetLastError());
         return ZK_OK;
     }
+    chunks = (n + INV_CH - 1) / INV_CH;
     hipLaunchKernelGGL(k_batch_inverse, zk_grid(chunks, 64, 8192), 64, 0, ctx->stream, v_dev, n, scr);
     ZK_HIP(ctx, hipGetLastError());
     return ZK_OK;
@@ -427,9 +435,13 @@ extern "C" int zk_poly_divide_by_linear_dev(zk_ctx* ctx, const void* coeffs_dev,
     void* partial = scr;
     void* carry = scr + (size_t)blocks * 32;
     void* rem_dev = scr + (size_t)blocks * 64;
-    hipLaunchKernelGGL(k_eval_spans1, blocks, 256, 0, ctx->stream, job, partial);
-    hipLaunchKernelGGL(k_span_carries, 1, 256, 0, ctx->stream, job, (const void*)partial, carry, rem ? rem_dev : nullptr);
-    if (n > 1) hipLaunchKernelGGL(k_fill_spans, blocks, 256, 0, ctx->stream, job, (const void*)carry, q_dev, -1);
+    if (blocks == 1 && n > 1) {
+        hipLaunchKernelGGL(k_fill_spans, 1, 256, 0, ctx->stream, job, (const void*)nullptr, q_dev, -1, rem ? rem_dev : nullptr);
+    } else {
+        hipLaunchKernelGGL(k_eval_spans1, blocks, 256, 0, ctx->stream, job, partial);
+        hipLaunchKernelGGL(k_span_carries, 1, 256, 0, ctx->stream, job, (const void*)partial, carry, rem ? rem_dev : nullptr);
+        if (n > 1) hipLaunchKernelGGL(k_fill_spans, blocks, 256, 0, ctx->stream, job, (const void*)carry, q_dev, -1, (void*)nullptr);
+    }
     ZK_HIP(ctx, hipGetLastError());
     if (rem) {
         uint32_t w[8];
