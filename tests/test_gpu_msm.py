@@ -529,3 +529,36 @@ def test_lane_group_additions_special_cases(ctx, group):
     for d in dev.values():
         d.free()
     bases.free()
+
+
+def test_sort_graph_replay_reads_fresh_data(ctx):
+    """core.hip::zk_graph_run: from the third sort with the same arguments on, the ~13 launches of a bucket sort are one captured graph.
+    The same device buffers with NEW scalars every round (what a prover's queue does), an MSM of another size through the same scratch
+    slot in between (its larger buffers move the scratch addresses: the generation count must retire the old graphs), and back."""
+    import ctypes as C
+    rs = np.random.RandomState(4711)
+    n, big = 6000, 20000
+
+    def rand_mont(m):
+        a = rs.randint(0, 1 << 62, size=(m, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+    km = rand_mont(big)
+    dk = ctx.upload(km)
+    bases = ctx.fixed_base(dk.ptr, big, 1, mont1(1))                 # plain table: n * W digits >= 2^16, the multi-launch sort
+    ks = cv.fr_from_mont(km)
+    r = O.R_MOD
+    ds = ctx.alloc(big * 32)
+
+    def run(m):
+        sm = rand_mont(m)
+        ctx._ck(ctx.lib.zk_memcpy_h2d(ctx.h, C.c_void_p(ds.ptr), sm.ctypes.data_as(C.c_void_p), sm.nbytes))     # same buffer, new contents
+        sc = cv.fr_from_mont(sm)
+        e = sum(s * k for s, k in zip(sc, ks[:m])) % r
+        assert cv.g1_projective_to_affine(ctx.msm_dev(bases, 0, ds.ptr, m)) == O.g1_mul(O.G1_GEN, e), m
+    for _ in range(5):
+        run(n)                     # plain, plain, captured, replayed, replayed
+    run(big)                       # larger scratch: addresses move
+    for _ in range(4):
+        run(n)
+    ds.free(); bases.free(); dk.free()
