@@ -104,6 +104,11 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
                 }
             }
             t_enq = lapus();
+            double t_dev = 0;
+            if (trace && rc == ZK_OK) {                // (trace only: wait for the device here, so that `finish` below is host time alone)
+                for (size_t k = 0; k < n_jobs; k++) if (jobs[k].reduce_done) (void)hipEventSynchronize(jobs[k].reduce_done);
+                t_dev = lapus();
+            }
             if (rc == ZK_OK) {
                 std::vector<ZkMsmJob*> jp(n_jobs);
                 std::vector<void*> op(n_jobs);
@@ -115,7 +120,7 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
             (void)hipStreamSynchronize(s_acc);
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipEventDestroy(e0);
-            if (trace) fprintf(stderr, "batch %zu jobs: prep %.0f sort %.0f enq %.0f finish %.0f sync %.0f us\n", n_jobs, t_prep, t_sort, t_enq, t_fin, lapus());
+            if (trace) fprintf(stderr, "batch %zu jobs: prep %.0f sort %.0f enq %.0f device done %.0f finish %.0f sync %.0f us\n", n_jobs, t_prep, t_sort, t_enq, t_dev, t_fin, lapus());
             return rc;
         }
     }
