@@ -2,7 +2,6 @@
 #include "../../include/zkmpc_hip.h"
 #include "groth16_int.hpp"
 #include <algorithm>
-#include <chrono>
 
 using namespace zk;
 
@@ -24,10 +23,6 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
         if (off + lens[k] > bases[k]->n) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_msm_batch_dev: a job reads past its base table");
     }
     if (n_jobs == 0) return ZK_OK;
-    static const bool trace = getenv("ZK_TRACE_BATCH") != nullptr;
-    const auto T0 = std::chrono::steady_clock::now();
-    auto lapus = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - T0).count(); };
-    double t_prep = 0, t_sort = 0, t_enq = 0, t_fin = 0;
     zk_presort_free(ctx);            // the batch rotates over the same scratch slots
     ZK_TRY(zk_prover_streams(ctx, 1));
     constexpr size_t SLOTS = 3;
@@ -73,7 +68,6 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
                     if (digits <= ((size_t)1 << 21))
                         for (size_t p = 0; p < cnt; p++) if (grp[p]->seg == 32) grp[p]->seg = 16;
                 }
-                t_prep = lapus();
                 {
                     // the jobs that take the one-block sort: one launch, a block per job (sort stream); the others (a job of more than
                     // 2^16 digits: ~10 short launches each) side by side on the other two streams
@@ -92,7 +86,6 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
                     if (rc == ZK_OK && nfit) rc = zk_msm_enqueue_sort_group(ctx, fit, (int)nfit, s_sort);
                 }
                 if (rc != ZK_OK) break;
-                t_sort = lapus();
                 if (cnt >= 2 && zk_msm_group_ok(grp, (int)cnt)) {
                     rc = zk_msm_enqueue_accum_group(ctx, grp, (int)cnt, s_sort);
                     if (rc == ZK_OK) rc = zk_msm_enqueue_reduce_group(ctx, grp, (int)cnt, s_sort);
@@ -103,24 +96,16 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
                     }
                 }
             }
-            t_enq = lapus();
-            double t_dev = 0;
-            if (trace && rc == ZK_OK) {                // (trace only: wait for the device here, so that `finish` below is host time alone)
-                for (size_t k = 0; k < n_jobs; k++) if (jobs[k].reduce_done) (void)hipEventSynchronize(jobs[k].reduce_done);
-                t_dev = lapus();
-            }
             if (rc == ZK_OK) {
                 std::vector<ZkMsmJob*> jp(n_jobs);
                 std::vector<void*> op(n_jobs);
                 for (size_t k = 0; k < n_jobs; k++) { jp[k] = &jobs[k]; op[k] = outs[perm[k]]; }
                 rc = zk_msm_finish_many(ctx, jp.data(), op.data(), (int)n_jobs);
             }
-            t_fin = lapus();
             (void)hipStreamSynchronize(s_sort);
             (void)hipStreamSynchronize(s_acc);
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipEventDestroy(e0);
-            if (trace) fprintf(stderr, "batch %zu jobs: prep %.0f sort %.0f enq %.0f device done %.0f finish %.0f sync %.0f us\n", n_jobs, t_prep, t_sort, t_enq, t_dev, t_fin, lapus());
             return rc;
         }
     }
