@@ -303,6 +303,11 @@ int zk_groth16_witness_map_post_dev(zk_ctx* ctx, const zk_r1cs* r1cs, void* ab_d
  * witness map, sort of h) behind its own kernels, where it runs under the reduce tail and the host time between two
  * proofs.  z_next_dev must stay unchanged until that proof is done; NULL withdraws; a different next call simply drops it. */
 int zk_groth16_hint_next_dev(zk_ctx* ctx, const void* z_next_dev);
+/* For a context that shares its GPU with other contexts proving small circuits (several host threads, one context each): whether
+ * the front enqueued for an announced small proof (domain <= 2^16) also carries that proof's accumulate launches and reduce chains.
+ * Default 1: one context working through a queue gains ~20 % (the device runs from one proof into the next while the host
+ * finishes the first); 0 leaves the hardware queues to the other contexts between two proofs. */
+int zk_groth16_chain_fronts(zk_ctx* ctx, int on);
 /* Optional: enqueue the sort of z[1..] that four of those MSMs share, ahead of zk_groth16_msms_dev on the same z_dev
  * (asynchronous; z_dev must stay unchanged).  The collaborative prover calls it before the Beaver open of
  * mpc-algebra/src/share/field.rs:97-129 so that the sort runs during the exchange.  Dropped if another MSM batch or a

@@ -170,6 +170,7 @@ PROTOTYPES = {
     "zk_groth16_msms_presort_dev": (_I, [_P, _P, _P, _P]),
     "zk_groth16_msms_begin_dev": (_I, [_P, _P, _P, _P]),
     "zk_groth16_hint_next_dev": (_I, [_P, _P]),
+    "zk_groth16_chain_fronts": (_I, [_P, _I]),
     "zk_groth16_prove_dev": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "zk_groth16_prove_multi": (_I, [_P, _P, _P, _I, _P, _P, _P, _P]),
     "zk_groth16_multi_plan": (_I, [_P, _P, _I, C.c_char_p, _SZ, C.POINTER(_SZ)]),

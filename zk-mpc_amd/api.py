@@ -640,6 +640,10 @@ class Context:
         """Announce the assignment of the next create_proof_dev call (same key and constraint system); None withdraws."""
         self._ck(self.lib.zk_groth16_hint_next_dev(self.h, C.c_void_p(int(z_next_dev)) if z_next_dev else None))
 
+    def groth16_chain_fronts(self, on: bool):
+        """zk_groth16_chain_fronts: whether an announced small proof's front carries its whole device chain (default on)."""
+        self._ck(self.lib.zk_groth16_chain_fronts(self.h, int(on)))
+
     def host_alloc(self, nbytes: int) -> "HostBuf":
         """Page-locked host memory (zk_host_alloc) viewed as a numpy uint64 array."""
         return HostBuf(self, nbytes)

@@ -127,6 +127,8 @@ struct zk_ctx {
     // idle one of two device slots while the current proof runs; next_z_ready is recorded behind that copy
     hipStream_t copy_stream = nullptr;
     hipEvent_t next_z_ready = nullptr;
+    bool chain_fronts = true;                 // zk_groth16_chain_fronts: a small proof's front carries the next proof's whole device chain
+    int front_parity = 0;                     // groth16_pipeline.hip: which pair of pinned result buffers the next chained front writes
     const void* next_z_host = nullptr;        // the host buffer that was announced (matched by address by zk_groth16_prove)
     const void* next_z_pk = nullptr;          // ... together with the key, the constraint system and the length it was announced for
     const void* next_z_r = nullptr;

@@ -69,6 +69,10 @@ struct ZkPresort {
     // under 12 ms of accumulate kernels that do not need h.
     bool begun = false;
     ZkMsmJob j1, j2, j3;
+    // a SMALL local proof's front carries its whole device chain (groth16_pipeline.hip: "chained"): besides the sorts and the witness
+    // map also the accumulate launches and reduce chains of all five jobs are enqueued behind the current proof's -- the device
+    // goes from one proof's chain into the next while the host still finishes the first
+    bool chained = false;
     ~ZkPresort() { if (wm_done) (void)hipEventDestroy(wm_done); }
 };
 

@@ -73,26 +73,28 @@ int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const vo
         pre = nullptr;
     }
     const bool begun = presorted && pre->begun && h_in && pre->r == r;     // the four z jobs are already enqueued to the end
+    const bool chained = fronted && pre->chained;                          // ... all five are (a small proof's front: see below)
     if (presorted) J[0] = &pre->job;
     if (fronted) J[4] = &pre->jobh;
-    if (begun) { J[1] = &pre->j1; J[2] = &pre->j2; J[3] = &pre->j3; }
+    if (begun || chained) { J[1] = &pre->j1; J[2] = &pre->j2; J[3] = &pre->j3; }
     // z was produced on the context stream.  (With a front that stream already carries this proof's witness map and H-sort:
     // waiting for it here would hold the sort stream -- and the G2 reduce chain on it -- until the H-sort is through.)
     if (!fronted) ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e0, 0));
     int rc = presorted ? ZK_OK : zk_msm_prepare(ctx, J[0], pk->b_g2, 1, zb + 32, nvars, 1);                 // src/groth16.rs:160 (query[1..])
-    if (rc == ZK_OK && !begun) rc = zk_msm_prepare(ctx, J[1], pk->a, 1, zb + 32, nvars, 2);              // :137
-    if (rc == ZK_OK && !begun) rc = zk_msm_prepare(ctx, J[2], pk->b_g1, 1, zb + 32, nvars, 3);           // :148
+    const bool have_z_jobs = begun || chained;
+    if (rc == ZK_OK && !have_z_jobs) rc = zk_msm_prepare(ctx, J[1], pk->a, 1, zb + 32, nvars, 2);              // :137
+    if (rc == ZK_OK && !have_z_jobs) rc = zk_msm_prepare(ctx, J[2], pk->b_g1, 1, zb + 32, nvars, 3);           // :148
     // :110: aux_assignment against l_query; over the padded table the same sum reads z[1..] (the instance meets infinity)
     const bool l_shared = pk->l_pad && pk->l_pad->n == nvars + 1 && (pk->l_pad->pre != nullptr) == (pk->a->pre != nullptr) &&
                           pk->l_pad->c_pre == pk->a->c_pre;
-    if (rc == ZK_OK && !begun) rc = l_shared ? zk_msm_prepare(ctx, J[3], pk->l_pad, 1, zb + 32, nvars, 4)
-                                             : zk_msm_prepare(ctx, J[3], pk->l, 0, zb + r->ni * 32, r->nw, 4);
+    if (rc == ZK_OK && !have_z_jobs) rc = l_shared ? zk_msm_prepare(ctx, J[3], pk->l_pad, 1, zb + 32, nvars, 4)
+                                                   : zk_msm_prepare(ctx, J[3], pk->l, 0, zb + r->ni * 32, r->nw, 4);
     if (rc == ZK_OK && !presorted) rc = zk_msm_enqueue_sort(ctx, J[0], s_sort, nullptr);
-    if (rc == ZK_OK && !begun) rc = zk_msm_enqueue_sort(ctx, J[1], s_sort, J[0]);
+    if (rc == ZK_OK && !have_z_jobs) rc = zk_msm_enqueue_sort(ctx, J[1], s_sort, J[0]);
     // (the G2 table may carry windows of another width than the G1 tables: then A sorts for itself and the other G1 jobs borrow A's)
     const ZkMsmJob* lender = J[0]->c == J[1]->c ? J[0] : J[1];
-    if (rc == ZK_OK && !begun) rc = zk_msm_enqueue_sort(ctx, J[2], s_sort, lender);
-    if (rc == ZK_OK && !begun && l_shared) rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, lender);
+    if (rc == ZK_OK && !have_z_jobs) rc = zk_msm_enqueue_sort(ctx, J[2], s_sort, lender);
+    if (rc == ZK_OK && !have_z_jobs && l_shared) rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, lender);
     const void* h = h_in;
     ZkPhaseTimer tm(ctx);
     // the first accumulate kernel is gated on the witness map, which would otherwise be starved beside it (un-gating it: within
@@ -117,7 +119,7 @@ int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const vo
         }
     }
     // L's sort after the witness map (it is not needed before the fourth accumulate kernel)
-    if (rc == ZK_OK && !l_shared && !begun) {
+    if (rc == ZK_OK && !l_shared && !have_z_jobs) {
         ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e1, 0));
         rc = zk_msm_enqueue_sort(ctx, J[3], s_sort, nullptr);
     }
@@ -134,25 +136,25 @@ int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const vo
     // they are ONE accumulate launch and one launch per level of the reduce chain, on the sort stream (round 5: two jobs per stream,
     // one behind the other, were 2 x (0.26 + 0.2) ms of a 1.2 ms proof at 2^10)
     ZkMsmJob* g1jobs[4] = {J[1], J[2], J[3], J[4]};
-    const bool grouped = small_jobs && rc == ZK_OK && zk_msm_group_ok(g1jobs, 4);
-    for (int k = 0; k < 5 && rc == ZK_OK; k++) {
+    const bool grouped = chained || (small_jobs && rc == ZK_OK && zk_msm_group_ok(g1jobs, 4));
+    for (int k = 0; k < 5 && rc == ZK_OK && !chained; k++) {
         if (grouped && ord[k] != 0) continue;
         if (!begun || ord[k] == 4) rc = zk_msm_enqueue_accum(ctx, J[ord[k]], small_jobs ? job_stream(ord[k]) : s_acc);
     }
-    if (grouped && rc == ZK_OK) rc = zk_msm_enqueue_accum_group(ctx, g1jobs, 4, s_sort);
+    if (grouped && !chained && rc == ZK_OK) rc = zk_msm_enqueue_accum_group(ctx, g1jobs, 4, s_sort);
     // B-in-G2's reduce chain (the long one) stays on the sort stream; the four G1 reduces go to the main stream, idle by
     // then, so that each runs right behind its own accumulate kernel instead of queueing behind the G2 chain (that
     // queueing left 4 x 0.7 ms of reduces after the last accumulate).
     // The last two reduce chains alternate between the two streams (the sort stream is idle again once the G2 chain is
     // through): on one stream the last job's chain queued behind its predecessor's, which was still waiting for slots
     // beside the last accumulate kernel, and ~0.6 ms of it ran after the GPU had otherwise gone idle.
-    for (int k = 0; k < 5 && rc == ZK_OK; k++) {
+    for (int k = 0; k < 5 && rc == ZK_OK && !chained; k++) {
         hipStream_t rs = small_jobs ? job_stream(ord[k]) : ((ord[k] == 0 || (k & 1) == 0) ? s_red : ctx->stream);
         if (begun && ord[k] == 0) continue;                 // B in G2's chain went out with zk_groth16_msms_begin_dev
         if (grouped && ord[k] != 0) continue;
         rc = zk_msm_enqueue_reduce(ctx, J[ord[k]], rs);
     }
-    if (grouped && rc == ZK_OK) rc = zk_msm_enqueue_reduce_group(ctx, g1jobs, 4, s_sort);
+    if (grouped && !chained && rc == ZK_OK) rc = zk_msm_enqueue_reduce_group(ctx, g1jobs, 4, s_sort);
     // The caller announced the next assignment (zk_groth16_hint_next_dev): enqueue that proof's front now, behind this
     // proof's kernels.  Its z-sort goes on the accumulate stream (in order behind the five accumulate kernels, the readers of
     // this proof's sort products; it also waits for the reduce chains, whose fold kernels read the segment tables), its
@@ -186,6 +188,35 @@ int zk_groth16_run_msms(zk_ctx* ctx, const zk_pk* pk, const zk_r1cs* r, const vo
             if (J[4]->reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, J[4]->reduce_done, 0));
             rc = zk_msm_prepare(ctx, &nf->jobh, pk->h, 0, h_scratch, std::min(pk->h->n, D), 5);
             if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &nf->jobh, ctx->stream, nullptr);
+        }
+        // A SMALL proof (its four G1 jobs one group): the next proof's whole device chain goes out as well -- accumulate launches and
+        // reduce chains of all five jobs, on the streams this proof's own chains are on, so stream order keeps every reader of a
+        // scratch buffer in front of its next writer.  The device then runs from one proof's chain into the next while the host
+        // finishes the first (Horner chains, the tail's scalar multiplications, the caller's next call: ~0.2 ms during which the
+        // chip used to wait).  The results land in the other pair of pinned buffers: this proof's are read below.
+        if (rc == ZK_OK && grouped && ctx->chain_fronts) {
+            const int par = (ctx->front_parity ^= 1);
+            nf->job.pin_key = 48 + par;
+            rc = zk_msm_prepare(ctx, &nf->j1, pk->a, 1, (const char*)zn + 32, nvars, 2);
+            if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &nf->j2, pk->b_g1, 1, (const char*)zn + 32, nvars, 3);
+            if (rc == ZK_OK) rc = zk_msm_prepare(ctx, &nf->j3, pk->l_pad, 1, (const char*)zn + 32, nvars, 4);
+            nf->j1.pin_key = 50 + par;                               // (the group's results travel in its first job's buffer)
+            if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &nf->j1, s_acc, &nf->job);
+            const ZkMsmJob* nl = nf->job.c == nf->j1.c ? &nf->job : &nf->j1;
+            if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &nf->j2, s_acc, nl);
+            if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &nf->j3, s_acc, nl);
+            ZkMsmJob* ng[4] = {&nf->j1, &nf->j2, &nf->j3, &nf->jobh};
+            if (rc == ZK_OK && zk_msm_group_ok(ng, 4)) {
+                rc = zk_msm_enqueue_accum(ctx, &nf->job, s_acc);
+                if (rc == ZK_OK) rc = zk_msm_enqueue_accum_group(ctx, ng, 4, s_sort);
+                if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, &nf->job, s_acc);
+                if (rc == ZK_OK) rc = zk_msm_enqueue_reduce_group(ctx, ng, 4, s_sort);
+                nf->chained = rc == ZK_OK;
+            }
+            if (rc != ZK_OK) {                                       // part of a chain is in flight: let it drain before its jobs go
+                ctx->presort = nf.release();
+                zk_presort_free(ctx);
+            }
         }
         if (rc == ZK_OK) { ctx->presort = nf.release(); front_enqueued = true; }
     }
@@ -229,6 +260,18 @@ extern "C" int zk_groth16_hint_next_dev(zk_ctx* ctx, const void* z_next_dev) {
     ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     ctx->next_z = z_next_dev;
+    return ZK_OK;
+    ZK_API_END
+}
+
+// Whether the front of an announced SMALL proof also carries that proof's accumulate launches and reduce chains (default: yes --
+// one context proving a queue goes from 0.54 to 0.43 ms per proof at 2^10).  Several contexts sharing one GPU do better without:
+// every context then keeps the hardware queues filled with its own next chain and they serialise (four contexts, eight queues:
+// 0.27 ms per proof without, 0.47 with; profiles/r5_small_throughput.jsonl).
+extern "C" int zk_groth16_chain_fronts(zk_ctx* ctx, int on) {
+    ZK_API_BEGIN(ctx)
+    if (!ctx) return ZK_ERR_ARG;
+    ctx->chain_fronts = on != 0;
     return ZK_OK;
     ZK_API_END
 }
