@@ -225,6 +225,41 @@ def test_hint_next_front_prefetch(ctx, n):
     pk.free()
 
 
+@pytest.mark.parametrize("n", [1000, 5000, (1 << 14) - 2])
+def test_chained_fronts_of_small_proofs(ctx, n):
+    """Round 5: the front of an announced SMALL proof carries its whole device chain (groth16_pipeline.hip: chained; accumulate
+    launches and reduce chains of all five jobs enqueued behind the current proof's, results in alternating pinned buffers).  A
+    queue of four assignments proved twelve times with hints equals the proofs without; the same with zk_groth16_chain_fronts off
+    and toggled in between; an announced proof that does not follow leaves a whole chain to drain."""
+    rng = O.Prng(1234 + n)
+    mont = lambda v: cv.fr_to_mont([v])[0]
+    td = [mont(rng.fr()) for _ in range(7)]
+    dr = ctx.r1cs_mul_chain(n)
+    pk = ctx.groth16_setup(dr, *td)
+    zs = [ctx.mul_chain_assignment_dev(n, mont(rng.fr()), mont(rng.fr())) for _ in range(4)]
+    rs = [(mont(rng.fr()), mont(rng.fr())) for _ in range(4)]
+    plain = [ctx.create_proof_dev(pk, dr, z.ptr, r, s) for z, (r, s) in zip(zs, rs)]
+    assert len(set(plain)) == 4
+    for mode in (True, False, True):
+        ctx.groth16_chain_fronts(mode)
+        for i in range(12):
+            ctx.groth16_hint_next_dev(zs[(i + 1) % 4].ptr)
+            assert ctx.create_proof_dev(pk, dr, zs[i % 4].ptr, *rs[i % 4]) == plain[i % 4], (mode, i)
+    # the chain of zs[1] is in flight; zs[3] is proved instead, then zs[1] after all
+    assert ctx.create_proof_dev(pk, dr, zs[3].ptr, *rs[3]) == plain[3]
+    assert ctx.create_proof_dev(pk, dr, zs[1].ptr, *rs[1]) == plain[1]
+    # toggled while a chained front is pending
+    ctx.groth16_hint_next_dev(zs[2].ptr)
+    assert ctx.create_proof_dev(pk, dr, zs[0].ptr, *rs[0]) == plain[0]
+    ctx.groth16_chain_fronts(False)
+    ctx.groth16_hint_next_dev(zs[3].ptr)
+    assert ctx.create_proof_dev(pk, dr, zs[2].ptr, *rs[2]) == plain[2]
+    assert ctx.create_proof_dev(pk, dr, zs[3].ptr, *rs[3]) == plain[3]
+    ctx.groth16_chain_fronts(True)
+    ctx.groth16_hint_next_dev(None)
+    pk.free()
+
+
 @pytest.mark.parametrize("n,label", [((1 << 20) - 2, "D=2^20 (BASELINE config 2, the benched shape)"),
                                      (1 << 20, "D=2^21 (the reference's natural sizing, src/groth16.rs:256-257)")])
 def test_headline_size_matches_known_trapdoor_prediction(ctx, n, label):
