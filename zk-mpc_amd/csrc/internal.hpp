@@ -94,6 +94,7 @@ struct ZkMsmJob {
     const uint32_t* bases_dev = nullptr;
     const void* scalars = nullptr;
     hipStream_t stream = nullptr;     // the stream the reduce phase (and the copy to hw) is on
+    hipStream_t sort_stream = nullptr, accum_stream = nullptr;   // where sort_done / accum_done were recorded: a consumer on the same stream needs no wait (3.9 us of host time each)
     hipEvent_t sort_done = nullptr;   // recorded once sorted/desc/order are final
     hipEvent_t accum_done = nullptr;  // recorded after the accumulate kernel
     hipEvent_t reduce_done = nullptr; // recorded after the copy of the partial sums to the host: what finish() waits for

@@ -863,8 +863,9 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
         job->sorted = share->sorted; job->desc = share->desc; job->order = share->order; job->ctr = share->ctr; job->heavy = share->heavy;
         job->heavy2 = share->heavy2;
         ZK_HIP(ctx, hipEventCreateWithFlags(&job->sort_done, hipEventDisableTiming));
-        ZK_HIP(ctx, hipStreamWaitEvent(st, share->sort_done, 0));
+        if (share->sort_stream != st) ZK_HIP(ctx, hipStreamWaitEvent(st, share->sort_done, 0));
         ZK_HIP(ctx, hipEventRecord(job->sort_done, st));
+        job->sort_stream = st;
         return ZK_OK;
     }
     MsmBufs<F> b;
@@ -917,6 +918,7 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
         job->sorted = b.sorted; job->desc = b.desc; job->order = b.order; job->ctr = ctr; job->heavy = b.heavy; job->heavy2 = b.heavy2;
         ZK_HIP(ctx, hipEventCreateWithFlags(&job->sort_done, hipEventDisableTiming));
         ZK_HIP(ctx, hipEventRecord(job->sort_done, st));
+        job->sort_stream = st;
         return ZK_OK;
     }
     // The ~13 launches of the sort as ONE graph launch from the third sort with the same arguments on (core.hip: zk_graph_run): a
@@ -959,6 +961,7 @@ int msm_enqueue_sort_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st, const ZkMsmJo
     job->sorted = b.sorted; job->desc = b.desc; job->order = b.order; job->ctr = ctr; job->heavy = b.heavy; job->heavy2 = b.heavy2;
     ZK_HIP(ctx, hipEventCreateWithFlags(&job->sort_done, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventRecord(job->sort_done, st));
+    job->sort_stream = st;
     return ZK_OK;
 }
 
@@ -972,7 +975,7 @@ int msm_enqueue_accum_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     const bool g1 = F::WORDS == 12;
     MsmBufs<F> b;
     ZK_TRY(msm_bufs_t<F>(ctx, job, b, false));
-    ZK_HIP(ctx, hipStreamWaitEvent(st, job->sort_done, 0));
+    if (job->sort_stream != st) ZK_HIP(ctx, hipStreamWaitEvent(st, job->sort_done, 0));
     ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
     job->timers.push_back(tm);
     tm->begin(g1 ? "msm_g1.accum" : "msm_g2.accum");
@@ -992,6 +995,7 @@ int msm_enqueue_accum_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     tm->end();
     ZK_HIP(ctx, hipEventCreateWithFlags(&job->accum_done, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventRecord(job->accum_done, st));
+    job->accum_stream = st;
     return ZK_OK;
 }
 
@@ -1003,7 +1007,7 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
     const bool g1 = F::WORDS == 12;
     MsmBufs<F> b;
     ZK_TRY(msm_bufs_t<F>(ctx, job, b, false));
-    ZK_HIP(ctx, hipStreamWaitEvent(st, job->accum_done, 0));
+    if (job->accum_stream != st) ZK_HIP(ctx, hipStreamWaitEvent(st, job->accum_done, 0));
     ZkPhaseTimer* tm = new ZkPhaseTimer(ctx, st);
     job->timers.push_back(tm);
     tm->begin(g1 ? "msm_g1.reduce" : "msm_g2.reduce");
@@ -1098,6 +1102,7 @@ static int msm_enqueue_sort_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count,
     for (int k = 0; k < count; k++) {
         ZK_HIP(ctx, hipEventCreateWithFlags(&jobs[k]->sort_done, hipEventDisableTiming));
         ZK_HIP(ctx, hipEventRecord(jobs[k]->sort_done, st));
+        jobs[k]->sort_stream = st;
     }
     return ZK_OK;
 }
@@ -1123,7 +1128,7 @@ static int msm_enqueue_accum_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count
         ZkMsmJob* job = jobs[k];
         MsmBufs<F> b;
         ZK_TRY(msm_bufs_t<F>(ctx, job, b, false));
-        ZK_HIP(ctx, hipStreamWaitEvent(st, job->sort_done, 0));
+        if (job->sort_stream != st) ZK_HIP(ctx, hipStreamWaitEvent(st, job->sort_done, 0));
         g.j[k] = AccumArgs{job->bases_dev, job->sorted, (const SegDesc*)job->desc, job->order, job->ctr, b.sums, job->stride};
         max_segs = std::max(max_segs, job->max_segs);
     }
@@ -1148,6 +1153,7 @@ static int msm_enqueue_accum_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count
     for (int k = 0; k < count; k++) {
         ZK_HIP(ctx, hipEventCreateWithFlags(&jobs[k]->accum_done, hipEventDisableTiming));
         ZK_HIP(ctx, hipEventRecord(jobs[k]->accum_done, st));
+        jobs[k]->accum_stream = st;
     }
     return ZK_OK;
 }
@@ -1164,7 +1170,7 @@ static int msm_enqueue_reduce_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int coun
         job->stream = st;
         MsmBufs<F> b;
         ZK_TRY(msm_bufs_t<F>(ctx, job, b, false));
-        ZK_HIP(ctx, hipStreamWaitEvent(st, job->accum_done, 0));
+        if (job->accum_stream != st) ZK_HIP(ctx, hipStreamWaitEvent(st, job->accum_done, 0));
         fg.j[k] = FoldArgs{(const HeavyDesc*)job->heavy, (const HeavyDesc*)job->heavy2, (const uint32_t*)job->ctr, b.fold_done, b.sums};
         src.p[k] = b.sums;
         max_heavy = std::max(max_heavy, job->max_heavy);
