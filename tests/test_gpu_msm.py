@@ -160,7 +160,7 @@ def test_msm_large_discrete_log_check(ctx, log_n):
         # reduce when c > 16 (2^20 points: c = 20, 16 slices; 2^18 points: c = 17, 2 slices)
         bases.precompute()
         c = ctx.lib.zk_bases_window_bits(bases.h)
-        assert c == (20 if m >= (1 << 20) else 15 if m == (1 << 16) else c) and c >= 13
+        assert c == (20 if m >= (1 << 19) else 17 if m >= (1 << 16) else c) and c >= 13
         assert to_aff(ctx.msm_dev(bases, 0, ds.ptr, m)) == want
         assert to_aff(ctx.msm_dev(bases, 3, ds.ptr, m - 3)) == to_aff(ctx.msm_dev(bases, 3, ds.ptr, m - 3))
         bases.free()

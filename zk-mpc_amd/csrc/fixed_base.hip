@@ -276,13 +276,16 @@ extern "C" int zk_fixed_base_g2_dev(zk_ctx* ctx, const zk_fr* gen_k, const void*
 static uint32_t precompute_window_bits(size_t n) {
     uint32_t lg = 0;                                   // round(log2 n): a 2^20 - 1 point query is a 2^20 one
     while (((size_t)3 << lg) <= 2 * n) lg++;
-    // >= 2^16 points, measured on whole proofs: 2^16 -> 15, 2^18 -> 16/17, 2^20..2^22 -> 20 (22 loses: 4x the buckets).
+    // >= 2^16 points, measured on whole proofs: 2^16 .. 2^18 -> 17, 2^19 .. 2^22 -> 20 (22 loses: 4x the buckets).
     // Smaller tables (round 5: the reference's own circuits are 2^2 .. 2^15 constraints) are latency, not throughput: a window
     // of about lg + 2 bits leaves ~W / 4 = 4-5 terms per bucket (the accumulate kernel lasts as long as its fullest bucket) and ONE
     // bucket set means the host's Horner chain over ~30 windows -- 0.7 ms of a 2 ms proof at 2^10 -- shrinks to ~2 log2(NB) additions.
     // (second half of round 5, with the reduce of small bucket sets on lane groups: lg + 1 from 2^13 up -- it only moves 2^14, 16 -> 15 bits:
     // proof 1.11 -> 0.94 ms; the other sizes land on the same width through the top-window rule below)
-    int c0 = lg >= 16 ? (int)lg - 1 : (lg >= 13 ? (int)lg + 1 : (int)lg + 2);
+    // (end of round 5, whole proofs on one box, admissible widths 15 / 16 / 17 / 20: 2^16 1.83 (15) -> 1.67 (17); 2^17 3.32 (16) ->
+    // 2.88 (17); 2^18 5.30 (17) = 5.23 (20); 2^19 9.46 (17) -> 8.4 (20))
+    // (... and 2^15: 1.46 (16) -> 1.21 (15))
+    int c0 = lg >= 19 ? 20 : lg >= 16 ? 17 : (lg >= 13 ? std::min((int)lg + 1, 15) : (int)lg + 2);
     const int lo = lg >= 16 ? 13 : 9, hi = lg >= 16 ? 20 : 16;
     if (c0 < lo) c0 = lo;
     if (c0 > hi) c0 = hi;
