@@ -1,5 +1,5 @@
 cd /root/repo
-for L in 17 18 19; do
+for L in 15 16 17 18 19; do
   python bench.py --log-constraints $L --steps 20 --warmup 4 --no-cpu-baseline --no-extras --no-micro 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
