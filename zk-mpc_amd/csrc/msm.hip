@@ -1115,7 +1115,9 @@ static bool msm_group_ok(ZkMsmJob* const* jobs, int count) {
     for (int k = 0; k < count; k++) {
         const ZkMsmJob* j = jobs[k];
         if (j->group != 1 || j->n == 0 || j->Wb != 1 || j->log_nb != jobs[0]->log_nb || (j->stride == 64) != (jobs[0]->stride == 64) || !j->sort_done) return false;
-        if ((size_t)j->n * j->W > ((size_t)1 << 21)) return false;       // (a job that fills the chip by itself gains nothing from company)
+        // (a job that fills the chip by itself gains nothing from company: Marlin rounds, same box, limit 2^21 / 2^23 / 2^24 digits --
+        // |H| = 2^16 11.4 / 10.6 / -, 2^17 16.2 / 14.8 / -, 2^18 22.0 / 21.7 / 21.0, 2^19 34.8 / 35.0 / 34.9, 2^20 62.9 / - / 64.1 ms)
+        if ((size_t)j->n * j->W > ((size_t)1 << 23)) return false;
     }
     return true;
 }

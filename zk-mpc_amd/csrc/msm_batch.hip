@@ -36,8 +36,8 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
     for (size_t k = 0; k < n_jobs; k++) perm[k] = k;
     std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
     std::vector<ZkMsmJob> jobs(n_jobs);
-    // Small G1 jobs over tables of window multiples (the commitments of a Marlin round at |H| <= 2^14: 4 - 7 jobs of 0.3 ms of
-    // latency each) go in GROUPS of up to four: sorts one behind the other, then one accumulate launch and one launch per level
+    // G1 jobs of up to 2^23 digits over tables of window multiples (the commitments of a Marlin round up to |H| = 2^18: 4 - 7 jobs) go
+    // in GROUPS of up to four: sorts one behind the other, then one accumulate launch and one launch per level
     // of the reduce chain for the group (msm.hip: zk_msm_enqueue_*_group).  Group position p uses scratch slot 1 + p; a slot's
     // next user waits for its previous user's chain.
     {
@@ -45,7 +45,7 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
         for (size_t k = 0; k < n_jobs && small; k++) {
             const zk_bases* b = bases[k];
             small = b->group == 1 && b->pre && lens[k] > 0 && (lens[k] >= 4096 || lens[k] * 8 >= b->n) && b->c_pre == bases[0]->c_pre &&
-                    (b->pre_stride == 64) == (bases[0]->pre_stride == 64) && lens[k] * ((255 + b->c_pre - 1) / b->c_pre) <= ((size_t)1 << 21);
+                    (b->pre_stride == 64) == (bases[0]->pre_stride == 64) && lens[k] * ((255 + b->c_pre - 1) / b->c_pre) <= ((size_t)1 << 23);
         }
         if (small) {
             int rc = ZK_OK;
