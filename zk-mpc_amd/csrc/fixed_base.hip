@@ -286,6 +286,9 @@ static uint32_t precompute_window_bits(size_t n) {
     // 2.88 (17); 2^18 5.30 (17) = 5.23 (20); 2^19 9.46 (17) -> 8.4 (20))
     // (... and 2^15: 1.46 (16) -> 1.21 (15))
     int c0 = lg >= 19 ? 20 : lg >= 16 ? 17 : (lg >= 13 ? std::min((int)lg + 1, 15) : (int)lg + 2);
+    // (the 2^16 class starts at 49 152 points: the tables of a Marlin proof at |H| = 2^14 -- 49 15x points -- take 15 bits, 6.1-6.2 ms
+    // against 6.2-6.4 with 17 and 6.4-6.6 with 16; Groth16 at 2^16 -- 65 536 points -- takes 17)
+    if (lg == 16 && n < 65000) c0 = 15;
     const int lo = lg >= 16 ? 13 : 9, hi = lg >= 16 ? 20 : 16;
     if (c0 < lo) c0 = lo;
     if (c0 > hi) c0 = hi;
