@@ -715,17 +715,37 @@ def launch_ranks(n: int, real_stdout: int) -> int:
     """Start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process (the launch line
     the driver uses for N > 1), relay the one JSON line rank 0 prints, return the launcher's exit code.  The rendezvous is on
     127.0.0.1 at a port the kernel has just handed out."""
+    import random
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this pool's driver only supports dmabuf IPC (RCCL across processes)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env)
-    out, _ = proc.communicate()
+
+    def pick_port():
+        # below the kernel's range for outgoing connections (32768 .. 60999): a port handed out by bind(0) can be taken again, as a
+        # SOURCE port of some connection, between the probe and the child's listen (seen once: EADDRINUSE in the TCPStore)
+        for _ in range(64):
+            cand = random.randint(20000, 32000)
+            with socket.socket() as sk:
+                try:
+                    sk.bind(("127.0.0.1", cand))
+                    return cand
+                except OSError:
+                    continue
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return sk.getsockname()[1]
+    for attempt in range(3):
+        port = pick_port()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        out, err = proc.communicate()
+        sys.stderr.write(err.decode(errors="replace"))
+        if proc.returncode != 0 and b"EADDRINUSE" in err and not any(ln.startswith(b"{") for ln in out.splitlines()):
+            sys.stderr.write("bench.py: rendezvous port %d was taken; another one (attempt %d)\n" % (port, attempt + 2))
+            continue
+        break
     lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
     if lines:
         try:

@@ -70,3 +70,22 @@ def marlin_test_system(n, rng):
     if isinstance(n, str) and n.startswith("tiny"):
         return circuit_system((int(n[4:]), 3, 2), rng.u64() & 0xffffffff)
     return O.mul_chain_r1cs(n, rng.fr(), rng.fr())
+
+
+def free_port():
+    """A rendezvous port on 127.0.0.1 below the kernel's range for outgoing connections (32768 .. 60999): a port handed out by
+    bind(0) can be taken again -- as the SOURCE port of some connection -- between the probe and the listener's bind (seen once:
+    EADDRINUSE in torch's TCPStore)."""
+    import random
+    import socket
+    for _ in range(64):
+        cand = random.randint(20000, 32000)
+        with socket.socket() as sk:
+            try:
+                sk.bind(("127.0.0.1", cand))
+                return cand
+            except OSError:
+                continue
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -38,10 +38,8 @@ def test_single_gpu_line_small():
 
 @pytest.mark.parametrize("world,extra", [(2, []), (3, ["--spdz"]), (2, ["--marlin"])])
 def test_n_party_line_over_gloo_on_one_gpu(world, extra):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    from helpers import free_port
+    port = free_port()
     d = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(port), "bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--log-constraints", "12",
                "--transport", "gloo", "--one-gpu"] + extra)

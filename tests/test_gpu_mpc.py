@@ -559,7 +559,8 @@ def test_rccl_multi_rank_opens_and_proof(world):
         pytest.skip("needs %d GPUs, this box has %d" % (world, torch.cuda.device_count()))
     import socket
     import torch.multiprocessing as mp
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    from helpers import free_port
+    port = free_port()
     c = mp.get_context("spawn")
     q = c.Queue()
     procs = [c.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
@@ -788,10 +789,8 @@ def test_collaborative_marlin_across_os_processes(world, spdz):
     import torch.multiprocessing as mp
     import marlin_full_ref as MF
     import marlin_ref as M
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    from helpers import free_port
+    port = free_port()
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     procs = [mpctx.Process(target=_marlin_proc_worker, args=(r, world, port, spdz, q)) for r in range(world)]
