@@ -16,7 +16,9 @@
 // msm_b2, tail, caller_matvec, caller_sub}} and a last line with the cache counters.  tests/test_gpu_trait_path.py compares the
 // bytes with the oracle's known-trapdoor prediction; bench.py's `trait_path` leg reports the times.
 //
-//   host_trait_groth16 <log2 of the QAP domain> <proofs> [cache|nocache] [packed|strided]
+//   host_trait_groth16 <log2 of the QAP domain> <proofs> [cache|nocache] [packed|strided] [verify|trust]
+// verify (default): every cache hit is confirmed by comparing the caller's whole table with the cached one on the device, under the
+// MSM; trust: zk_bases_cache_trust(ctx, 1) -- a fingerprint of 64 points decides (the caller vouches for its key).
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -121,11 +123,13 @@ int main(int argc, char** argv) {
     const int proofs = argc > 2 ? atoi(argv[2]) : 3;
     const bool cache = !(argc > 3 && std::string(argv[3]) == "nocache");
     const bool strided = argc > 4 && std::string(argv[4]) == "strided";
+    const bool trust = argc > 5 && std::string(argv[5]) == "trust";
     if (log_d < 2 || log_d > 24 || proofs < 1) { fprintf(stderr, "usage: %s <log2 domain 2..24> <proofs> [cache|nocache] [packed|strided]\n", argv[0]); return 2; }
     const size_t D = (size_t)1 << log_d, n = D - 2;                       // n constraints + 2 instance variables fill the domain
     CK(zk_ctx_create(0, 0, 1, &CTX));
     field_init();
     if (!cache) CK(zk_bases_cache_config(CTX, 0, 0));
+    if (trust) CK(zk_bases_cache_trust(CTX, 1));
     const zk_fr one = fr(1);
 
     // ---- set-up (not the path under test): constraint system, key with fixed toxic waste, assignment; everything ends up in HOST memory
@@ -267,14 +271,19 @@ int main(int argc, char** argv) {
         printf("]}\n");
         fflush(stdout);
     }
-    uint64_t st[10];
+    uint64_t st[10], st2[4], before[10];
+    CK(zk_bases_cache_stats(CTX, before));                 // how many tables had their window multiples when the last proof ended
+    CK(zk_bases_cache_sync(CTX));                          // ... and with every build that was still running or due finished
     CK(zk_bases_cache_stats(CTX, st));
+    CK(zk_bases_cache_stats2(CTX, st2));
     printf("{\"cache\": {\"hits\": %llu, \"misses\": %llu, \"evictions\": %llu, \"replaced\": %llu, \"uncached\": %llu, \"entries\": %llu, "
-           "\"with_window_multiples\": %llu, \"resident_bytes\": %llu, \"uploaded_bytes\": %llu, \"budget\": %llu}, \"log_d\": %u, \"constraints\": %zu, "
-           "\"layout\": \"%s\"}\n",
+           "\"with_window_multiples\": %llu, \"resident_bytes\": %llu, \"uploaded_bytes\": %llu, \"budget\": %llu, \"verified\": %llu, "
+           "\"verified_bytes\": %llu, \"builds\": %llu, \"with_window_multiples_at_last_proof\": %llu}, \"log_d\": %u, \"constraints\": %zu, "
+           "\"layout\": \"%s\", \"hits\": \"%s\"}\n",
            (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3], (unsigned long long)st[4],
            (unsigned long long)st[5], (unsigned long long)st[6], (unsigned long long)st[7], (unsigned long long)st[8], (unsigned long long)st[9],
-           log_d, n, strided ? "strided" : "packed");
+           (unsigned long long)st2[0], (unsigned long long)st2[1], (unsigned long long)st2[2], (unsigned long long)before[6],
+           log_d, n, strided ? "strided" : "packed", trust ? "trusted" : "verified");
     CK(zk_ctx_destroy(CTX));
     return 0;
 }

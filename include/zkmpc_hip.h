@@ -124,20 +124,32 @@ int zk_msm_g1_strided(zk_ctx* ctx, const void* bases_host, size_t n_bases, const
                       const zk_fr* scalars_host, size_t n_scalars, zk_g1_projective* out_host);
 int zk_msm_g2_strided(zk_ctx* ctx, const void* bases_host, size_t n_bases, const zk_affine_layout* layout,
                       const zk_fr* scalars_host, size_t n_scalars, zk_g2_projective* out_host);
-/* The four entry points above keep what they are shown: a base slice of >= 256 points stays resident in HBM, keyed by (group,
- * host address, length, layout) and a 64-bit fingerprint of 64 points spread over the slice, so that the next call with the same
- * slice -- the queries of a ProvingKey proof after proof (src/groth16.rs:106,110,193), the powers of an SRS -- reads 64 points
- * from the host instead of uploading 96 / 192 bytes per point; from its `precompute_after`-th re-use on (default 1) a slice of
- * >= 256 points also carries window multiples (zk_bases_precompute).  Base tables are key material and immutable for those
- * callers; a host that rewrites a table IN PLACE without touching any sampled point must call zk_bases_cache_drop.
+/* The MSM entry points on host slices (the four above, zk_mpc_msm_g1 / _g2 below) keep the tables they are shown: a base slice of
+ * >= 256 points stays resident in HBM, keyed by its CONTENT -- (group, length, a 64-bit fingerprint of 64 points spread over the
+ * slice, taken in the packed form whatever layout the caller holds the points in) -- never by its address: the collaborative
+ * caller presents the same table in a fresh Vec on every call (MpcGroup::all_public_or_shared, mpc-algebra/src/wire/group.rs:441-457).
+ * A fingerprint match is only a candidate: by default the caller's WHOLE slice crosses PCIe once more, under the MSM that already
+ * runs on the cached table, and is compared with it on the device word for word; if it differs (a table rewritten in place at
+ * points the sample misses) the entry takes the new content and the MSM runs again -- no call returns a sum over a stale table.
+ * From its `precompute_after`-th re-use on (default 1) a slice of >= 256 points gets window multiples (zk_bases_precompute),
+ * built on a side stream beside later calls and published when finished; until then the plain table serves.
  *   zk_bases_cache_config  budget_bytes: HBM the cache may hold, least recently used out first (default: a quarter of the device
  *                          memory; 0 switches the cache off and frees it); precompute_after: 0 = never build window multiples
+ *   zk_bases_cache_trust   fingerprint_only = 1: a fingerprint match IS a hit and nothing but the 64 sampled points is read from
+ *                          the host -- for a caller that vouches for its tables (the queries of a ProvingKey that outlives the
+ *                          prover: 2.4 ms of PCIe and host bandwidth less per 2^20-point G1 call); 0 (default): verified hits
  *   zk_bases_cache_drop    forget every table (frees the HBM)
- *   zk_bases_cache_stats   out[0..9] = hits, misses, evictions, replaced (same address, new content), uncached uploads,
- *                          entries, entries with window multiples, resident bytes, bytes uploaded in all, budget */
+ *   zk_bases_cache_sync    finish every window-multiple build that is running or due, and publish it (benchmarks, tests)
+ *   zk_bases_cache_stats   out[0..9] = hits, misses, evictions, replaced (a hit whose full comparison failed: the entry took the
+ *                          caller's content), uncached uploads, entries, entries with window multiples, resident bytes, bytes
+ *                          uploaded in all, budget
+ *   zk_bases_cache_stats2  out[0..3] = hits verified in full, bytes compared, window-multiple builds published, 1 while a build runs */
 int zk_bases_cache_config(zk_ctx* ctx, size_t budget_bytes, int precompute_after);
+int zk_bases_cache_trust(zk_ctx* ctx, int fingerprint_only);
 int zk_bases_cache_drop(zk_ctx* ctx);
+int zk_bases_cache_sync(zk_ctx* ctx);
 int zk_bases_cache_stats(zk_ctx* ctx, uint64_t out[10]);
+int zk_bases_cache_stats2(zk_ctx* ctx, uint64_t out[4]);
 /* Resident bases: upload once (proving-key queries), then MSM against device scalars. */
 int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* bases_host, size_t n, zk_bases** out);
 int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* bases_host, size_t n, zk_bases** out);
@@ -513,6 +525,56 @@ int zk_marlin_prove_shared_spdz(zk_ctx* ctx, const zk_marlin_index* index, const
                                 const void* const z_lanes_dev[2], zk_rng* zk_rng, int mask_on_device, const void* const tx_lanes[2],
                                 const void* const ty_lanes[2], const void* const tz_lanes[2], const zk_net_vtable* net,
                                 uint8_t* proof_out, size_t cap, size_t* proof_len, uint64_t* bytes_sent);
+
+/* ---- the trait surface for the COLLABORATIVE element types, on the caller's own slices (rows a6, a7, a8, a11) ----------------
+ * Under E = MpcPairingEngine the unchanged create_proof (src/groth16.rs:68-183,240-306) calls the same four dispatch points with
+ * Vec<MpcField<Fr, S>> and &[MpcG1Affine]: an element is the enum { Public(Fr), Shared(S) } (mpc-algebra/src/wire/field.rs:37-40;
+ * 40 bytes with S = AdditiveFieldShare, 72 with SpdzFieldShare { sh, mac }), a base the enum MpcGroup around a GroupAffine.  The
+ * entry points below read and write those elements IN PLACE; the binding describes the layout once, off a value:
+ *   stride      size_of::<MpcField<Fr, S>>()
+ *   off_tag     byte offset of the discriminant's low byte; tag_public / tag_shared: its two values
+ *   off_public  byte offset of the Fr inside Public(Fr)
+ *   off_share   ... of .val (additive) or .sh.val (SPDZ) inside Shared(S)
+ *   off_mac     ... of .mac.val inside Shared(SpdzFieldShare), or SIZE_MAX: additive shares (one lane)
+ * Semantics are the reference's operator impls (wire/field.rs:339-362,414-437,463-492): next to shared values a Public(x) acts as
+ * the share "x on the leader (party 0 of zk_ctx_create), 0 elsewhere", in the MAC lane too (mac_share = 1 on the leader). */
+typedef struct {
+    size_t stride, off_tag, off_public, off_share, off_mac;
+    uint8_t tag_public, tag_shared;
+} zk_mpc_field_layout;
+/* MpcG1Affine / MpcG2Affine { val: MpcGroup<G, S> }: where the GroupAffine of the Public variant sits, and the byte that tells the
+ * variants apart (off_tag = SIZE_MAX: plain GroupAffine elements, no wrapper).  Every base must be Public, as the reference asserts
+ * (wire/pairing.rs:716): ZK_ERR_ARG otherwise. */
+typedef struct {
+    zk_affine_layout point;
+    size_t off_tag;
+    uint8_t tag_public;
+} zk_mpc_group_layout;
+/* EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place(&mut Vec<MpcField>) (src/groth16.rs:278-303 over
+ * arkworks/algebra/poly/src/domain/mod.rs:78,89,138,154): n elements are read, 2^log_n written (the binding resizes the Vec with
+ * Public(0) first, as the reference does).  At least one Shared element: the transform of the party's lane vector(s), every output
+ * Shared; all Public: the transform of the values, outputs Public.  inverse / coset as zk_fr_ntt_dev. */
+int zk_mpc_fft_in_place(zk_ctx* ctx, void* vec_host, size_t n, const zk_mpc_field_layout* layout, uint32_t log_n, int inverse, int coset);
+/* EvaluationDomain::divide_by_vanishing_poly_on_coset_in_place(&mut [MpcField]) (domain/mod.rs:183-190): 2^log_n elements times
+ * the public constant 1 / (g^N - 1); every element keeps its variant. */
+int zk_mpc_divide_by_vanishing_on_coset_in_place(zk_ctx* ctx, void* evals_host, const zk_mpc_field_layout* layout, uint32_t log_n);
+/* MpcField::batch_product_in_place(selfs, others) (mpc-algebra/src/wire/field.rs:917-958).  Both slices Shared: FieldShare::batch_mul
+ * (share/field.rs:97-129) -- the two masked operands are opened through `net` (open_sum_fr_dev, or the context's RCCL communicator
+ * when that is NULL; SPDZ: each open followed by its MAC check, ZK_ERR_MAC on failure), selfs receives the product shares.
+ * triple_host: NULL = DummyFieldTripleSource (what the reference's wire passes: wire/field.rs:941-947), or 3 (additive) / 6 (SPDZ)
+ * host vectors of n zk_fr each: x, y, z of the share lane, then of the MAC lane.  Otherwise the element-wise `*a *= b`.  A slice
+ * that mixes variants is refused (the reference asserts).  *bytes_sent (optional): payload this party contributed to opens. */
+int zk_mpc_batch_product_in_place(zk_ctx* ctx, void* selfs_host, const void* others_host, size_t n, const zk_mpc_field_layout* layout,
+                                  const zk_fr* const* triple_host, const zk_net_vtable* net, uint64_t* bytes_sent);
+/* MpcG1Affine::multi_scalar_mul(bases, scalars) / the G2 form (mpc-algebra/src/wire/pairing.rs:714-777): min(len) terms.
+ * Some scalar Shared: GroupShare::multi_scale_pub_group (share/additive.rs:517-520; SPDZ share/spdz.rs:482-488) -- out_lanes[0] =
+ * the MSM over this party's share values, out_lanes[1] = the one over its MAC values (SPDZ; additive: a copy of lane 0), Public
+ * scalars read as from_public (wire/field.rs:75-100); *scalars_public = 0.  Every scalar Public: out_lanes[0] = the plain MSM (the
+ * wire wraps it with from_public), *scalars_public = 1.  The bases go through the table cache above, keyed by content. */
+int zk_mpc_msm_g1(zk_ctx* ctx, const void* bases_host, size_t n_bases, const zk_mpc_group_layout* base_layout, const void* scalars_host,
+                  size_t n_scalars, const zk_mpc_field_layout* scalar_layout, zk_g1_projective out_lanes[2], int* scalars_public);
+int zk_mpc_msm_g2(zk_ctx* ctx, const void* bases_host, size_t n_bases, const zk_mpc_group_layout* base_layout, const void* scalars_host,
+                  size_t n_scalars, const zk_mpc_field_layout* scalar_layout, zk_g2_projective out_lanes[2], int* scalars_public);
 
 /* ---- share algebra on device vectors (rows a11, a13) ------------------------------------- */
 /* out[i] = sum_p gathered[p*n + i] mod r: the receive side of AdditiveFieldShare::batch_open

@@ -1,9 +1,12 @@
 """The reference-shaped boundary, composed: examples/host_trait_groth16.cpp is src/groth16.rs:68-183,240-306 written over the
 trait-shaped entry points only (zk_fr_fft_in_place x7, zk_fr_batch_product_in_place, zk_fr_divide_by_vanishing_on_coset_in_place,
 zk_msm_g1 x4, zk_msm_g2 x1, the host group helpers), with the proving key in HOST vectors.  Its 192 bytes must be the oracle's
-known-trapdoor prediction at 2^10, 2^16 and 2^20 -- with the base-table cache (first call: uploads; second: window multiples are
-built; from then on: hits), without it, and with the key in a Rust-shaped {x, y, infinity} layout through zk_msm_*_strided.
-Then the cache's own contract through ctypes: hit, replacement when a sampled point changes, drop, budget, tiny tables."""
+known-trapdoor prediction at 2^10, 2^16 and 2^20 -- with the base-table cache (first call: uploads; then verified hits, window
+multiples built beside the calls), without it, and with the key in a Rust-shaped {x, y, infinity} layout through zk_msm_*_strided.
+examples/host_trait_collab_groth16.cpp is the same over E = MpcPairingEngine: P parties as threads, elements in the enum layouts of
+MpcField / MpcG1Affine (both discriminant positions), zk_mpc_* entry points and the transport vtable only; its revealed bytes must
+be the prediction on the SUMMED shares.  Then the cache's own contract through ctypes: content-addressed hits, a verified hit that
+catches a table rewritten in place at an unsampled point, two tables taking turns at one address, drop, budget, tiny tables."""
 import ctypes as C
 import json
 import subprocess
@@ -21,7 +24,7 @@ TD = (2, 3, 5, 7, 11, 1, 1)          # alpha beta gamma delta tau g1_k g2_k: the
 R, S, W0, W1 = 13, 17, 3, 5
 
 
-def predicted(log_d):
+def predicted(log_d, R=R, S=S):
     n = (1 << log_d) - 2
     if log_d <= 10:
         r1cs, z = O.mul_chain_r1cs(n, W0, W1)
@@ -50,16 +53,21 @@ def test_trait_path_proof_is_the_predicted_proof(tmp_path, log_d):
     proofs, last = run(exe, log_d, 4)
     assert [p["proof"] for p in proofs] == [want] * 4
     c = last["cache"]
-    # five slices: first proof 5 misses, then 15 hits; slices of >= 2^16 points got their window multiples on the first hit
+    # five slices: first proof 5 misses, then 15 hits -- every one of them confirmed against the caller's table in full
     assert (c["misses"], c["hits"], c["entries"], c["replaced"], c["uncached"]) == (5, 15, 5, 0, 0)
-    assert c["with_window_multiples"] == 5            # (from 256 points on: small tables are where the host's Horner chain hurts most)
+    assert c["verified"] == 15
+    assert c["with_window_multiples"] == 5 and c["builds"] == 5   # (from 256 points on; built beside the calls, the stragglers by zk_bases_cache_sync)
     D = 1 << log_d
-    assert c["uploaded_bytes"] == 96 * (2 * (D - 1) + 2 * D) + 192 * D                  # every table crossed PCIe exactly once
+    tables = 96 * (2 * (D - 1) + 2 * D) + 192 * D
+    assert c["uploaded_bytes"] == tables                                                 # every table became resident exactly once
+    assert c["verified_bytes"] == 3 * tables                                             # ... and was compared once per later proof
     if log_d >= 16:
         assert proofs[-1]["ms"]["lib"] < proofs[0]["ms"]["lib"]
+        # no call builds window multiples on the caller's time any more (round 5: the second proof of a 2^20 key took 356 - 410 ms)
+        assert proofs[1]["ms"]["lib"] < 2.5 * proofs[-1]["ms"]["lib"] + 5
 
 
-@pytest.mark.parametrize("mode", [("nocache",), ("cache", "strided"), ("nocache", "strided")])
+@pytest.mark.parametrize("mode", [("nocache",), ("cache", "strided"), ("nocache", "strided"), ("cache", "strided", "trust")])
 def test_trait_path_without_the_cache_and_with_a_rust_shaped_key(tmp_path, mode):
     exe = build(tmp_path, "host_trait_groth16")
     log_d = 16
@@ -71,6 +79,43 @@ def test_trait_path_without_the_cache_and_with_a_rust_shaped_key(tmp_path, mode)
         assert c["entries"] == 0 and c["hits"] == 0 and c["uncached"] == 15 and c["budget"] == 0
     else:
         assert (c["misses"], c["hits"], c["entries"]) == (5, 10, 5) and last["layout"] == "strided"
+        assert c["verified"] == (0 if "trust" in mode else 10)
+
+
+def run_collab(exe, log_d, proofs, parties, *mode):
+    r = subprocess.run([exe, str(log_d), str(proofs), str(parties), *mode], capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+    return lines[:-1], lines[-1]
+
+
+@pytest.mark.parametrize("log_d,parties,mode", [
+    (10, 3, ("additive", "tagfirst")), (16, 3, ("additive", "tagfirst")), (18, 3, ("additive", "tagfirst")),
+    (16, 2, ("spdz", "tagfirst")),
+    (10, 3, ("additive", "taglast")), (10, 2, ("spdz", "taglast")), (12, 1, ("additive", "tagfirst")), (12, 8, ("additive", "tagfirst")),
+    (12, 3, ("additive", "tagfirst", "trust")),
+])
+def test_collaborative_trait_path_reveals_the_predicted_proof(tmp_path, log_d, parties, mode):
+    """create_proof::<MpcPairingEngine> unchanged (VERDICT r5 item 1): the composer follows src/groth16.rs:68-183,240-306 over
+    Vec<MpcField> / &[MpcG1Affine] in their enum layouts and calls nothing but zk_mpc_fft_in_place x7, zk_mpc_batch_product_in_place
+    (Beaver through the vtable), zk_mpc_divide_by_vanishing_on_coset_in_place, zk_mpc_msm_g1 x4 / _g2 x1 and the host group helpers.
+    Every party must end with the same bytes (the program checks) and they must be create_proof on the summed shares."""
+    exe = build(tmp_path, "host_trait_collab_groth16")
+    nproofs = 3
+    proofs, last = run_collab(exe, log_d, nproofs, parties, *mode)
+    rr, ss = int.from_bytes(bytes.fromhex(last["r"]), "little"), int.from_bytes(bytes.fromhex(last["s"]), "little")
+    want = predicted(log_d, rr, ss).hex()
+    assert [p["proof"] for p in proofs] == [want] * nproofs
+    spdz = mode[0] == "spdz"
+    assert last["element_bytes"] == (72 if spdz else 40) and last["tag"] == ("last" if "taglast" in mode else "first")
+    c = last["cache"]                                  # party 0's context: its key's five tables, found again by CONTENT in every later proof
+    D = 1 << log_d
+    if D >= 512:
+        assert (c["misses"], c["hits"], c["entries"], c["replaced"], c["uncached"]) == (5, 5 * (nproofs - 1), 5, 0, 0)
+        assert c["verified"] == (0 if "trust" in mode else 5 * (nproofs - 1))
+        assert c["with_window_multiples"] == 5
+    if parties > 1:
+        assert proofs[0]["beaver_bytes_sent"] == (4 if spdz else 2) * 32 * D          # two masked operands (SPDZ: and their MAC checks)
 
 
 def _p(a):
@@ -83,55 +128,124 @@ def _stats(ctx):
     return dict(zip(("hits", "misses", "evictions", "replaced", "uncached", "entries", "pre", "resident", "uploaded", "budget"), [int(v) for v in out]))
 
 
+def _stats2(ctx):
+    out = np.zeros(4, dtype=np.uint64)
+    ctx._ck(ctx.lib.zk_bases_cache_stats2(ctx.h, _p(out)))
+    return dict(zip(("verified", "verified_bytes", "builds", "building"), [int(v) for v in out]))
+
+
 def test_cache_contract(ctx):
-    """Hit on the same slice, replacement when a sampled point changes in place, a sub-slice is its own table, drop, a budget too
-    small to keep anything, tables under 256 points never cached -- every result against the discrete-log identity."""
+    """Content-addressed hits (another address, another layout: the same table), a sub-slice is its own table, a sampled point
+    that changes is another table, an UNSAMPLED point that changes in place is caught by the verified hit (ADVICE r5 medium /
+    VERDICT r5 weak 4 ii), trusted mode reads nothing but the sample, two tables that take turns at one address both stay and both
+    get window multiples (VERDICT r5 missing 4), drop, budgets, tiny tables -- every result against the discrete-log identity."""
     n = 1000
     rng = O.Prng(515)
     ks = [rng.fr() for _ in range(n)]
+    ks_b = [rng.fr() for _ in range(n)]
     sc = [rng.fr() for _ in range(n)]
     dk = ctx.upload(cv.fr_to_mont(ks))
     tab = ctx.fixed_base(dk.ptr, n, 1, cv.fr_to_mont([1])[0])
     pts = np.ascontiguousarray(tab.download())                            # (n, 12) host table: k_i G
+    dkb = ctx.upload(cv.fr_to_mont(ks_b))
+    tab_b = ctx.fixed_base(dkb.ptr, n, 1, cv.fr_to_mont([1])[0])
+    pts_b = np.ascontiguousarray(tab_b.download())
     scal = cv.fr_to_mont(sc)
     want = lambda lo, m, kk=ks: O.g1_mul(O.G1_GEN, sum(s * k for s, k in zip(sc[:m], kk[lo:lo + m])) % O.R_MOD)
     msm = lambda arr, m: cv.g1_projective_to_affine(ctx.multi_scalar_mul_g1(arr, scal[:m]))
     ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
     ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 1 << 30, 1))
-    s0 = _stats(ctx)
+    ctx._ck(ctx.lib.zk_bases_cache_trust(ctx.h, 0))
+    s0, v0 = _stats(ctx), _stats2(ctx)
     assert msm(pts, n) == want(0, n)
     assert msm(pts, n) == want(0, n)
-    s1 = _stats(ctx)
-    assert (s1["misses"] - s0["misses"], s1["hits"] - s0["hits"], s1["entries"]) == (1, 1, 1)
-    sub = pts[100:]                                                       # `&query[1..]`-style sub-slice: another address, another table
+    assert msm(pts.copy(), n) == want(0, n)                                # the same table at ANOTHER address: a hit (keyed by content)
+    s1, v1 = _stats(ctx), _stats2(ctx)
+    assert (s1["misses"] - s0["misses"], s1["hits"] - s0["hits"], s1["entries"]) == (1, 2, 1)
+    assert v1["verified"] - v0["verified"] == 2 and v1["verified_bytes"] - v0["verified_bytes"] == 2 * 96 * n
+    sub = pts[100:]                                                       # `&query[1..]`-style sub-slice: another length, another table
     assert msm(sub, 800) == want(100, 800)
     assert _stats(ctx)["entries"] == 2
-    # the table changes IN PLACE at a sampled position (index 0 is always sampled): same address, new content -> replaced, right answer
+    # the table changes IN PLACE at a sampled position (index 0 is always sampled): another fingerprint, another table, right answer
     old0 = pts[0].copy()
     pts[0] = pts[1]
     ks2 = [ks[1]] + ks[1:]
     assert msm(pts, n) == want(0, n, ks2)
     s2 = _stats(ctx)
-    assert s2["replaced"] - s1["replaced"] == 1
+    assert s2["misses"] - s1["misses"] == 2 and s2["entries"] == 3 and s2["replaced"] == s1["replaced"]
     pts[0] = old0
     assert msm(pts, n) == want(0, n)
+    # ... and at a position the fingerprint does NOT sample (64 of 1000 points: indices k * 999 / 63 -- 7 is not one): the candidate
+    # hit is compared in full, fails, the entry takes the new content and the sum is the new table's
+    assert 7 not in [k * (n - 1) // 63 for k in range(64)]
+    old7 = pts[7].copy()
+    pts[7] = pts[8]
+    ks3 = ks[:7] + [ks[8]] + ks[8:]
+    s3 = _stats(ctx)
+    assert msm(pts, n) == want(0, n, ks3)
+    assert msm(pts, n) == want(0, n, ks3)                                  # (now a verified hit on the new content)
+    s4 = _stats(ctx)
+    assert s4["replaced"] - s3["replaced"] == 1 and s4["hits"] - s3["hits"] == 2 and s4["entries"] == s3["entries"]
+    pts[7] = old7
+    assert msm(pts, n) == want(0, n)                                       # and back: caught again
+    assert _stats(ctx)["replaced"] - s3["replaced"] == 2
+    # the same with window multiples on the entry (they are dropped with the stale content)
+    for _ in range(2):
+        assert msm(pts, n) == want(0, n)
+    ctx._ck(ctx.lib.zk_bases_cache_sync(ctx.h))
+    assert _stats(ctx)["pre"] >= 1
+    pts[7] = pts[8]
+    assert msm(pts, n) == want(0, n, ks3)
+    pts[7] = old7
+    assert msm(pts, n) == want(0, n)
+    # trusted mode: a fingerprint match IS the hit, the caller's table is not read beyond the sample
+    ctx._ck(ctx.lib.zk_bases_cache_trust(ctx.h, 1))
+    v2 = _stats2(ctx)
+    assert msm(pts, n) == want(0, n)
+    assert _stats2(ctx)["verified"] == v2["verified"]
+    ctx._ck(ctx.lib.zk_bases_cache_trust(ctx.h, 0))
     ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
     assert _stats(ctx)["entries"] == 0 and _stats(ctx)["resident"] == 0
-    # a budget that holds one table: the second one pushes the first out
-    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 1000 * 96 + 10, 1))
-    assert msm(pts, n) == want(0, n) and msm(sub, 800) == want(100, 800) and msm(pts, n) == want(0, n)
-    s3 = _stats(ctx)
-    assert s3["entries"] == 1 and s3["evictions"] >= 2
-    # building the window multiples of one table pushes the other one out (the entry list shifts under the hit: ADVICE-style trap)
+    # two tables of one length taking turns at ONE address (MpcGroup::all_public_or_shared's temporaries: A, B1, A, B1, ...): both
+    # stay resident, every call after the first pair is a hit, both get their window multiples
+    buf = np.empty_like(pts)
+    s5 = _stats(ctx)
+    for rnd in range(4):
+        buf[:] = pts
+        assert msm(buf, n) == want(0, n)
+        buf[:] = pts_b
+        assert msm(buf, n) == want(0, n, ks_b)
+    ctx._ck(ctx.lib.zk_bases_cache_sync(ctx.h))
+    s6 = _stats(ctx)
+    assert (s6["misses"] - s5["misses"], s6["hits"] - s5["hits"], s6["entries"], s6["pre"], s6["replaced"] - s5["replaced"]) == (2, 6, 2, 2, 0)
+    buf[:] = pts
+    assert msm(buf, n) == want(0, n)                                       # from the window multiples
+    buf[:] = pts_b
+    assert msm(buf, n) == want(0, n, ks_b)
     ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
-    need = 20 * 900 * (256 + 96)                                                     # sub: 900 points, c = 13 -> 20 copies, limb slots + the packed copy
-    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, need + 900 * 96 + 50_000, 1))           # room for sub's multiples and sub -- not for pts beside them
+    # a budget that holds one table (its device form and its packed copy): the second one pushes the first out
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 2 * 1000 * 96 + 10, 0))
+    assert msm(pts, n) == want(0, n) and msm(sub, 800) == want(100, 800) and msm(pts, n) == want(0, n)
+    s7 = _stats(ctx)
+    assert s7["entries"] == 1 and s7["evictions"] >= 2
+    # building the window multiples of one table pushes the other one out (the entry list shifts under the hit)
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    need = 20 * 900 * (256 + 96) + 900 * 240                                         # sub: 900 points, c = 13 -> 20 copies, limb slots + the packed copy + the build's scratch
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, need + 2 * 900 * 96 + 100_000, 1))      # room for sub's multiples and sub -- not for pts beside them
     assert msm(sub, 800) == want(100, 800) and msm(pts, n) == want(0, n)             # two plain tables resident (sub is the older one)
     assert _stats(ctx)["entries"] == 2
-    assert msm(sub, 800) == want(100, 800)                                           # first hit on sub: its multiples need 6.3 MB -> pts goes
-    s4 = _stats(ctx)
-    assert s4["entries"] == 1 and s4["pre"] == 1
+    assert msm(sub, 800) == want(100, 800)                                           # first hit on sub: its multiples need 6.5 MB -> pts goes
+    ctx._ck(ctx.lib.zk_bases_cache_sync(ctx.h))
+    s8 = _stats(ctx)
+    assert s8["entries"] == 1 and s8["pre"] == 1
     assert msm(sub, 800) == want(100, 800) and msm(pts, n) == want(0, n)             # sub from its multiples; pts uploaded again
+    # a table whose multiples can never fit evicts nothing (ADVICE r5)
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 2 * (1000 + 900) * 96 + 50_000, 1))
+    assert msm(sub, 800) == want(100, 800) and msm(pts, n) == want(0, n) and msm(pts, n) == want(0, n)
+    ctx._ck(ctx.lib.zk_bases_cache_sync(ctx.h))
+    s9 = _stats(ctx)
+    assert s9["entries"] == 2 and s9["pre"] == 0 and s9["evictions"] == s8["evictions"]
     # smaller than any table: nothing is kept, everything still right
     ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 1024, 1))
     assert msm(pts, n) == want(0, n)
@@ -141,7 +255,7 @@ def test_cache_contract(ctx):
     assert msm(pts[:200], 200) == want(0, 200) and _stats(ctx)["entries"] == 0
     ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
     ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 64 << 30, 1))                        # (the session's context goes on with a roomy cache)
-    tab.free(); dk.free()
+    tab.free(); dk.free(); tab_b.free(); dkb.free()
 
 
 def test_strided_tables_with_infinity_flags(ctx):

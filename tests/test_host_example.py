@@ -19,7 +19,7 @@ def build(tmp_path, name="host_groth16"):
     Z.load()                                                 # the library is there (built in-tree)
     libdir = os.path.join(ROOT, "zk-mpc_amd", "lib")
     exe = str(tmp_path / name)
-    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-pthread", "-I", os.path.join(ROOT, "include"),
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", "-I", os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "examples", name + ".cpp"), "-L", libdir, "-lzkmpc_hip", "-Wl,-rpath," + libdir,
                         "-Wl,--allow-shlib-undefined", "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -31,6 +31,7 @@ def test_compiled_host_builds_and_fails_loudly_without_a_gpu(tmp_path):
     exe = build(tmp_path)
     collab = build(tmp_path, "host_collab_groth16")
     trait = build(tmp_path, "host_trait_groth16")          # create_proof over the trait-shaped entry points (tests/test_gpu_trait_path.py)
+    tcollab = build(tmp_path, "host_trait_collab_groth16")  # ... over MpcPairingEngine's element types
     if torch.cuda.is_available():
         pytest.skip("GPU present: the gpu tests run them")
     r = subprocess.run([exe, "4"], capture_output=True, text=True, timeout=120)
@@ -38,6 +39,8 @@ def test_compiled_host_builds_and_fails_loudly_without_a_gpu(tmp_path):
     r = subprocess.run([collab, "2", "8"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "proof" not in r.stdout and "error" in r.stderr
     r = subprocess.run([trait, "4", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "proof" not in r.stdout and "zk_ctx_create" in r.stderr
+    r = subprocess.run([tcollab, "4", "1", "2"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "proof" not in r.stdout and "zk_ctx_create" in r.stderr
 
 

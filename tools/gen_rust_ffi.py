@@ -241,7 +241,8 @@ fn check(rc: i32) {
 
 // GroupAffine<P> is {x, y, infinity: bool} as rustc lays it out (104 / 200 bytes per point for BLS12-377): the library reads the
 // caller's slice IN PLACE -- stride and field offsets are taken off a value, whatever order rustc chose -- so nothing is copied per
-// call, and the slice's address keys the library's resident copy (zk_bases_cache_*): a proving key's queries cross PCIe once.
+// call; the library keeps a resident copy keyed by the table's CONTENT (zk_bases_cache_*): a proving key's queries are uploaded once,
+// and every later hit is confirmed against the caller's slice under the MSM (or taken on trust: trust_base_tables).
 fn layout_of<T, X, Y>(sample: &T, x: &X, y: &Y, infinity: &bool) -> ZkAffineLayout {
     let base = sample as *const T as usize;
     ZkAffineLayout { stride: std::mem::size_of::<T>(), off_x: x as *const X as usize - base, off_y: y as *const Y as usize - base,
@@ -272,7 +273,7 @@ pub fn multi_scalar_mul_g2(bases: &[G2Affine], scalars: &[Fr]) -> G2Projective {
     let f = |a: &[ZkFq; 2]| ark_bls12_377::Fq2::new(ark_ff::Fp384::new(ark_ff::BigInteger384(a[0].l)), ark_ff::Fp384::new(ark_ff::BigInteger384(a[1].l)));
     G2Projective::new(f(&out.x), f(&out.y), f(&out.z))
 }
-// a host that rewrites a base table in place (never done by the reference: keys and SRS are immutable) says so
+// (a host that rewrites a base table in place needs no call: a verified hit sees it.  In trusted mode it must say so:)
 pub fn bases_changed_in_place() { CTX.with(|c| check(unsafe { zk_bases_cache_drop(*c) })); }
 
 // ---- 2. EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place (poly/src/domain/mod.rs:78,89,138,154; radix2/mod.rs:98-114) ----
@@ -318,6 +319,102 @@ pub fn comm_init() {
 pub fn open_sum_fr_dev(v_dev: *const c_void, n: usize, out_dev: *mut c_void) {
     CTX.with(|c| check(unsafe { zk_open_sum_fr_dev(*c, v_dev, n, out_dev) }));
 }
+
+// ---- 5. the same dispatch points for the COLLABORATIVE element types: create_proof::<MpcPairingEngine, C> unchanged ----------------
+// Under E = MpcPairingEngine the callers hand over Vec<MpcField<Fr, S>> and &[MpcG1Affine] (enum wrappers: wire/field.rs:37-40,
+// wire/pairing.rs).  The library reads and writes those elements IN PLACE; the layouts are taken off values once.  Where the hooks
+// sit: (a) Field::batch_product_in_place is overridden by MpcField already (wire/field.rs:917-958) -- its body becomes
+// mpc_batch_product_in_place; (b) MpcG1Affine / MpcG2Affine::multi_scalar_mul (wire/pairing.rs:714-777) -- its body becomes
+// mpc_msm_g1 / _g2 on the key's OWN slice (no all_public_or_shared copy: wire/group.rs:441-457); (c) the transforms: FftField gains
+// `fn fft_in_place_hook(coeffs: &mut Vec<Self>, log_size: u32, inverse: bool, coset: bool) -> bool { false }` (the same kind of patch
+// as batch_product_in_place), Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place and
+// divide_by_vanishing_poly_on_coset_in_place call it first, Fr answers with fft_family_in_place, MpcField<Fr, S> with mpc_fft_in_place.
+use mpc_algebra::{AdditiveFieldShare, FieldShare, MpcField, Reveal, SpdzFieldShare};
+
+/// what the share types tell the binding about themselves (implemented next to the private fields: share/additive.rs, share/spdz.rs)
+pub trait HipLanes { fn lanes(&self) -> (*const Fr, Option<*const Fr>); }    // (&self.val, None) / (&self.sh.val, Some(&self.mac.val))
+
+pub fn mpc_field_layout<S: FieldShare<Fr> + HipLanes>() -> ZkMpcFieldLayout {
+    let p = MpcField::<Fr, S>::Public(Fr::zero());
+    let s = MpcField::<Fr, S>::Shared(S::from_add_shared(Fr::zero()));
+    let base_p = &p as *const _ as usize;
+    let base_s = &s as *const _ as usize;
+    let off_public = match &p { MpcField::Public(x) => x as *const Fr as usize - base_p, _ => unreachable!() };
+    let (off_share, off_mac) = match &s {
+        MpcField::Shared(sh) => { let (a, b) = sh.lanes(); (a as usize - base_s, b.map(|m| m as usize - base_s).unwrap_or(usize::MAX)) }
+        _ => unreachable!(),
+    };
+    // the discriminant: the one byte outside every payload in which the two values differ (all payload words are zero in both)
+    let size = std::mem::size_of::<MpcField<Fr, S>>();
+    let in_payload = |o: usize| (o >= off_public && o < off_public + 32) || (o >= off_share && o < off_share + 32) || (off_mac != usize::MAX && o >= off_mac && o < off_mac + 32);
+    let (bp, bs) = unsafe { (std::slice::from_raw_parts(base_p as *const u8, size), std::slice::from_raw_parts(base_s as *const u8, size)) };
+    let off_tag = (0..size).find(|&o| !in_payload(o) && bp[o] != bs[o]).expect("MpcField: no discriminant byte found");
+    ZkMpcFieldLayout { stride: size, off_tag, off_public, off_share, off_mac, tag_public: bp[off_tag], tag_shared: bs[off_tag] }
+}
+/// MpcG1Affine / MpcG2Affine { val: MpcGroup<G, _> }: the GroupAffine of the Public variant and the byte that says Public
+pub fn mpc_group_layout<W, G, X, Y>(public_sample: &W, inner: &G, x: &X, y: &Y, infinity: &bool, shared_sample: &W) -> ZkMpcGroupLayout {
+    let base = public_sample as *const W as usize;
+    let size = std::mem::size_of::<W>();
+    let point = ZkAffineLayout { stride: size, off_x: x as *const X as usize - base, off_y: y as *const Y as usize - base, off_infinity: infinity as *const bool as usize - base };
+    let lo = inner as *const G as usize - base;
+    let hi = lo + std::mem::size_of::<G>();
+    let (bp, bs) = unsafe { (std::slice::from_raw_parts(base as *const u8, size), std::slice::from_raw_parts(shared_sample as *const W as *const u8, size)) };
+    let off_tag = (0..size).find(|&o| (o < lo || o >= hi) && bp[o] != bs[o]).expect("MpcGroup: no discriminant byte found");
+    ZkMpcGroupLayout { point, off_tag, tag_public: bp[off_tag] }
+}
+
+// EvaluationDomain::*fft_in_place(&mut Vec<MpcField<Fr, S>>) (src/groth16.rs:278-303)
+pub fn mpc_fft_in_place<S: FieldShare<Fr> + HipLanes>(coeffs: &mut Vec<MpcField<Fr, S>>, size: usize, log_size: u32, inverse: bool, coset: bool) {
+    let n = coeffs.len();
+    coeffs.resize(size, MpcField::Public(Fr::zero()));
+    let lay = mpc_field_layout::<S>();
+    CTX.with(|c| check(unsafe { zk_mpc_fft_in_place(*c, coeffs.as_mut_ptr() as *mut c_void, n, &lay, log_size, inverse as i32, coset as i32) }));
+}
+pub fn mpc_divide_by_vanishing_poly_on_coset_in_place<S: FieldShare<Fr> + HipLanes>(evals: &mut [MpcField<Fr, S>], log_size: u32) {
+    assert_eq!(evals.len(), 1usize << log_size);
+    let lay = mpc_field_layout::<S>();
+    CTX.with(|c| check(unsafe { zk_mpc_divide_by_vanishing_on_coset_in_place(*c, evals.as_mut_ptr() as *mut c_void, &lay, log_size) }));
+}
+// MpcField::batch_product_in_place (wire/field.rs:917-958): Beaver through the vtable when both slices are shared
+pub fn mpc_batch_product_in_place<S: FieldShare<Fr> + HipLanes>(selfs: &mut [MpcField<Fr, S>], others: &[MpcField<Fr, S>]) {
+    let n = selfs.len().min(others.len());
+    let lay = mpc_field_layout::<S>();
+    let net = net_vtable();
+    let mut sent = 0u64;
+    CTX.with(|c| check(unsafe { zk_mpc_batch_product_in_place(*c, selfs.as_mut_ptr() as *mut c_void, others.as_ptr() as *const c_void, n, &lay,
+        std::ptr::null() /* DummyFieldTripleSource, as the wire passes (wire/field.rs:941-947) */, &net, &mut sent) }));
+}
+// MpcG1Affine::multi_scalar_mul (wire/pairing.rs:714-777) on the key's own slice: (share lane, MAC lane, every scalar public?)
+pub fn mpc_msm_g1<S: FieldShare<Fr> + HipLanes>(bases: *const c_void, n_bases: usize, base_layout: &ZkMpcGroupLayout, scalars: &[MpcField<Fr, S>]) -> ([G1Projective; 2], bool) {
+    let z = ZkG1Projective { x: ZkFq { l: [0; 6] }, y: ZkFq { l: [0; 6] }, z: ZkFq { l: [0; 6] } };
+    let mut out = [z, z];
+    let mut all_public = 0i32;
+    let lay = mpc_field_layout::<S>();
+    CTX.with(|c| check(unsafe { zk_mpc_msm_g1(*c, bases, n_bases, base_layout, scalars.as_ptr() as *const c_void, scalars.len(), &lay, out.as_mut_ptr(), &mut all_public) }));
+    let f = |o: &ZkG1Projective| G1Projective::new(ark_ff::Fp384::new(ark_ff::BigInteger384(o.x.l)), ark_ff::Fp384::new(ark_ff::BigInteger384(o.y.l)),
+                                                   ark_ff::Fp384::new(ark_ff::BigInteger384(o.z.l)));
+    ([f(&out[0]), f(&out[1])], all_public != 0)
+}
+pub fn mpc_msm_g2<S: FieldShare<Fr> + HipLanes>(bases: *const c_void, n_bases: usize, base_layout: &ZkMpcGroupLayout, scalars: &[MpcField<Fr, S>]) -> ([G2Projective; 2], bool) {
+    let z6 = ZkFq { l: [0; 6] };
+    let z = ZkG2Projective { x: [z6; 2], y: [z6; 2], z: [z6; 2] };
+    let mut out = [z, z];
+    let mut all_public = 0i32;
+    let lay = mpc_field_layout::<S>();
+    CTX.with(|c| check(unsafe { zk_mpc_msm_g2(*c, bases, n_bases, base_layout, scalars.as_ptr() as *const c_void, scalars.len(), &lay, out.as_mut_ptr(), &mut all_public) }));
+    let q = |a: &[ZkFq; 2]| ark_bls12_377::Fq2::new(ark_ff::Fp384::new(ark_ff::BigInteger384(a[0].l)), ark_ff::Fp384::new(ark_ff::BigInteger384(a[1].l)));
+    let f = |o: &ZkG2Projective| G2Projective::new(q(&o.x), q(&o.y), q(&o.z));
+    ([f(&out[0]), f(&out[1])], all_public != 0)
+}
+// The body of `fn multi_scalar_mul(bases: &[Self], scalars: &[Self::ScalarField])` in wire/pairing.rs:714 then reads
+//     let lay = mpc_group_layout(&bases[0], ...);                       // once per type: cache it in a OnceCell
+//     let (lanes, all_public) = mpc_msm_g1::<PS::FrShare>(bases.as_ptr() as *const c_void, bases.len(), &lay, scalars);
+//     $w_pro { val: MpcGroup::Shared(if all_public { <PS::$share_proj as Reveal>::from_public(lanes[0]) }      // :726-741
+//                                    else { PS::$share_proj::from_lanes(lanes[0], lanes[1]) }) }                // multi_scale_pub_group, :750-756
+// -- the assertion `bases.iter().all(|b| !b.is_shared())` is made by the library (ZK_ERR_ARG -> panic), the Vec copies of
+// all_public_or_shared are gone, and the key's tables are found again by content whatever Vec they arrive in.
+// A prover whose key outlives it may skip the per-hit comparison of the caller's table with the cached one:
+pub fn trust_base_tables(on: bool) { CTX.with(|c| check(unsafe { zk_bases_cache_trust(*c, on as i32) })); }
 
 // ---- whole provers (src/groth16.rs:68-183 over shares; the plain prover with a resident key) ----
 pub fn create_proof_shared(pk: *const ZkPk, r1cs: *const ZkR1cs, z_share_dev: *const c_void, r_share: &Fr, s_share: &Fr) -> [u8; 192] {

@@ -5,8 +5,11 @@ Each pass is `rocprofv3 --kernel-trace --pmc <counters> --output-format csv` of 
 the counters do not all fit one).  Values are summed over the instances (XCDs / SEs) of a dispatch, then averaged over the
 launches of a kernel.  Derived: valu_wave_insts_per_s = SQ_INSTS_VALU / kernel duration (from the same pass's kernel trace),
 to be read against the measured integer issue peak of 32.2 T lane-ops/s = 0.503 T wave-instructions/s (tools/ubench_int.hip)."""
-import csv, glob, json, re, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pmc_traffic as PT          # the hash of the kernel sources a counter file belongs to (bench.py refuses a file from other sources)
 
 
 def short(name):
@@ -52,7 +55,8 @@ def main():
         res[k] = e
     json.dump({"_note": "rocprofv3 --pmc passes (separate runs) over bench.py --steps 3 --warmup 1 --no-hint; per-launch averages, "
                         "counter values summed over XCDs / shader engines.  Kernels run serialised under counter collection, so "
-                        "durations are those of a kernel alone on the chip.", "kernels": res}, open(out, "w"), indent=1)
+                        "durations are those of a kernel alone on the chip.", "kernel_sources_sha256": PT.sources_sha256(),
+               "kernel_sources": PT.KERNEL_SOURCES, "kernels": res}, open(out, "w"), indent=1)
     for k in ("k_accum<G1>", "k_accum_g2pair<2>", "k_ntt_pass<0>", "k_reduce<G1>", "k_reduce_g2pair", "rocprim::radix_sort (onesweep)"):
         if k in res:
             print(k, {a: (round(b, 4) if b < 10 else round(b)) for a, b in res[k].items()})

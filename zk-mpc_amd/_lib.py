@@ -110,8 +110,16 @@ PROTOTYPES = {
     "zk_msm_g1_strided": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
     "zk_msm_g2_strided": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
     "zk_bases_cache_config": (_I, [_P, _SZ, _I]),
+    "zk_bases_cache_trust": (_I, [_P, _I]),
     "zk_bases_cache_drop": (_I, [_P]),
+    "zk_bases_cache_sync": (_I, [_P]),
     "zk_bases_cache_stats": (_I, [_P, _P]),
+    "zk_bases_cache_stats2": (_I, [_P, _P]),
+    "zk_mpc_fft_in_place": (_I, [_P, _P, _SZ, _P, _U32, _I, _I]),
+    "zk_mpc_divide_by_vanishing_on_coset_in_place": (_I, [_P, _P, _P, _U32]),
+    "zk_mpc_batch_product_in_place": (_I, [_P, _P, _P, _SZ, _P, _P, _P, _P]),
+    "zk_mpc_msm_g1": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _P, _P]),
+    "zk_mpc_msm_g2": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _P, _P]),
     "zk_fr_divide_by_vanishing_on_coset_in_place": (_I, [_P, _P, _U32]),
     "zk_bases_upload_g1": (_I, [_P, _P, _SZ, C.POINTER(_P)]),
     "zk_bases_upload_g2": (_I, [_P, _P, _SZ, C.POINTER(_P)]),

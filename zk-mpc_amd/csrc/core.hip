@@ -2,11 +2,20 @@
 #include "../../include/zkmpc_hip.h"
 #include "ctx.hpp"
 #include "internal.hpp"
+#include <atomic>
 #include <functional>
 #include <stdexcept>
 #include <string.h>
 
 extern "C" int zk_version(void) { ZK_API_BEGIN_NOCTX return 1; ZK_API_END }
+
+// Entry points in flight per device.  The only mutable process-wide state of the library, and advisory: the table cache's builder
+// thread (bases_cache.hip) hands out a slice of background work when it reads zero, so that building window multiples takes the
+// chip in the caller's own time between two calls, not from the kernels of a call.
+static std::atomic<int> g_calls[64];
+std::atomic<int>& zk_calls_in_flight(int device) { return g_calls[(unsigned)device & 63]; }
+void zk_call_enter(int device) { g_calls[(unsigned)device & 63].fetch_add(1, std::memory_order_relaxed); }
+void zk_call_leave(int device) { g_calls[(unsigned)device & 63].fetch_sub(1, std::memory_order_relaxed); }
 
 extern "C" int zk_selftest_exception_barrier(int kind) {
     ZK_API_BEGIN_NOCTX
@@ -202,13 +211,29 @@ int zk_scratch(zk_ctx* ctx, const char* name, size_t bytes, void** out) {
 int zk_graph_run(zk_ctx* ctx, const std::string& key, hipStream_t st, const std::function<int()>& enqueue) {
     static const bool off = getenv("ZK_GRAPHS") && atoi(getenv("ZK_GRAPHS")) == 0;
     if (off || ctx->profiling) return enqueue();
-    if (ctx->graphs.size() > 512) {                    // (keys that stopped matching: addresses moved, other sizes)
-        for (auto& kv : ctx->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-        ctx->graphs.clear();
-    }
+    // entries of an older scratch generation can never match again (the generation is part of every key): they go as soon as the
+    // generation moves, each executable behind the stream it last ran on (they used to pile up to 512 and were then
+    // destroyed all at once, in flight or not)
+    auto retire = [&](bool all) {
+        for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();) {
+            if (all || it->second.gen != ctx->scratch_gen) {
+                if (it->second.exec) {
+                    if (it->second.last) (void)hipStreamSynchronize(it->second.last);
+                    (void)hipGraphExecDestroy(it->second.exec);
+                }
+                it = ctx->graphs.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    };
+    if (ctx->graphs_gen != ctx->scratch_gen) { retire(false); ctx->graphs_gen = ctx->scratch_gen; }
+    if (ctx->graphs.size() > 512) retire(true);        // (keys that stopped matching for other reasons: other sizes)
     auto& e = ctx->graphs[key];
+    e.gen = ctx->scratch_gen;
     if (e.exec) {
         ZK_HIP(ctx, hipGraphLaunch(e.exec, st));
+        e.last = st;
         return ZK_OK;
     }
     if (e.seen++ == 0) return enqueue();
@@ -231,6 +256,7 @@ int zk_graph_run(zk_ctx* ctx, const std::string& key, hipStream_t st, const std:
     if (ie != hipSuccess || !x) { (void)hipGetLastError(); e.seen = -(1 << 30); return enqueue(); }
     e.exec = x;
     ZK_HIP(ctx, hipGraphLaunch(e.exec, st));
+    e.last = st;
     return ZK_OK;
 }
 

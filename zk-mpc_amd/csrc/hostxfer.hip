@@ -247,13 +247,28 @@ int zk_xfer_h2d(zk_ctx* ctx, void* dev, const void* host, size_t bytes, bool pin
         ZK_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
         return ZK_OK;
     }
-    if (bytes < XF_SMALL) {
+    const char* src = (const char*)host;
+    const ZkXferFill fill = [src](char* dst, size_t off, size_t len) { copy_to_ring(dst, src + off, len); };
+    return zk_xfer_h2d_fn(ctx, dev, bytes, fill, true, nullptr);
+}
+
+// The same with the bytes PRODUCED piece by piece: fill(dst, off, len) writes bytes [off, off + len) of the logical vector into
+// page-locked memory at dst (the team's threads call it side by side, one piece each: 256 KiB, the last one shorter) -- a gather
+// out of the caller's own struct layout (MpcField / MpcGroup wrappers, GroupAffine with its flag) costs no extra pass.
+// fence_ctx = false: the transfer is on the DMA stream ALONE (no wait for the context stream in front, none behind): for a
+// destination nothing on the context stream touches -- the verification copy of a cached table, which runs UNDER the MSM that
+// uses the cached one; the caller waits through zk_xfer_stream().  after_round(r0, rb, st): work to enqueue on the DMA stream
+// behind a round's copies (bytes [r0, r0 + rb) have landed when it runs).
+int zk_xfer_h2d_fn(zk_ctx* ctx, void* dev, size_t bytes, const ZkXferFill& fill_fn, bool fence_ctx,
+                   const std::function<int(size_t, size_t, hipStream_t)>* after_round) {
+    if (!bytes) return ZK_OK;
+    if (bytes < XF_SMALL && fence_ctx && !after_round) {
         ZkXferSmall* xs;
         unsigned slot;
         ZK_TRY(small_get(ctx, &xs));
         ZK_TRY(small_slot(ctx, xs, &slot));
         char* p = xs->buf + (size_t)slot * XF_SMALL;
-        memcpy(p, host, bytes);
+        fill_fn(p, 0, bytes);
         ZK_HIP(ctx, hipMemcpyAsync(dev, p, bytes, hipMemcpyHostToDevice, ctx->stream));
         ZK_HIP(ctx, hipEventRecord(xs->ev[slot], ctx->stream));
         xs->used[slot] = true;
@@ -263,14 +278,14 @@ int zk_xfer_h2d(zk_ctx* ctx, void* dev, const void* host, size_t bytes, bool pin
     ZK_TRY(xfer_get(ctx, &x));
     for (size_t r0 = 0; r0 < bytes; r0 += XF_RING) {                  // rounds of one ring each (a second round only beyond 2^21 elements)
         const size_t rb = std::min(XF_RING, bytes - r0), np = (rb + XF_PIECE - 1) / XF_PIECE;
-        ZK_TRY(fence_in(ctx, x));
+        if (fence_ctx) ZK_TRY(fence_in(ctx, x));
+        else ZK_HIP(ctx, hipStreamSynchronize(x->st));               // the ring is idle again (the previous round's chunks have left it)
         for (size_t p = 0; p < np; p++) x->filled[p].store(0, std::memory_order_relaxed);
         x->err.store((int)hipSuccess);
-        const char* src = (const char*)host + r0;
         char* dst = (char*)dev + r0;
         const std::function<void(size_t)> fill = [&](size_t p) {
             const size_t off = p * XF_PIECE, len = std::min(XF_PIECE, rb - off);
-            copy_to_ring(x->ring + off, src + off, len);
+            fill_fn(x->ring + off, r0 + off, len);
             x->filled[p].store(1, std::memory_order_release);
         };
         // the submitter: DMA for the filled prefix -- 1 MiB first, so that the engine starts early, then 2, then 4 MiB at a time: few
@@ -292,8 +307,16 @@ int zk_xfer_h2d(zk_ctx* ctx, void* dev, const void* host, size_t bytes, bool pin
         x->team->run(np, fill, &submit);
         while (sent < np && x->err.load() == (int)hipSuccess) submit();
         ZK_HIP(ctx, (hipError_t)x->err.load());
-        ZK_TRY(fence_out(ctx, x));
+        if (after_round) ZK_TRY((*after_round)(r0, rb, x->st));
+        if (fence_ctx) ZK_TRY(fence_out(ctx, x));
     }
+    return ZK_OK;
+}
+// the DMA stream of the context's ring (created on first use): what a fence_ctx = false transfer is waited for on
+int zk_xfer_stream(zk_ctx* ctx, hipStream_t* st) {
+    ZkXfer* x;
+    ZK_TRY(xfer_get(ctx, &x));
+    *st = x->st;
     return ZK_OK;
 }
 
@@ -305,6 +328,15 @@ int zk_xfer_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes, bool pin
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return ZK_OK;
     }
+    char* dst = (char*)host;
+    const ZkXferDrain drain = [dst](const char* src, size_t off, size_t len) { memcpy(dst + off, src, len); };
+    return zk_xfer_d2h_fn(ctx, dev, bytes, drain);
+}
+
+// The same with the bytes CONSUMED piece by piece: drain(src, off, len) takes bytes [off, off + len) of the device vector out of
+// page-locked memory at src (a scatter into the caller's own struct layout).
+int zk_xfer_d2h_fn(zk_ctx* ctx, const void* dev, size_t bytes, const ZkXferDrain& drain_fn) {
+    if (!bytes) return ZK_OK;
     if (bytes < XF_SMALL) {
         ZkXferSmall* xs;
         unsigned slot;
@@ -313,7 +345,7 @@ int zk_xfer_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes, bool pin
         char* p = xs->buf + (size_t)slot * XF_SMALL;
         ZK_HIP(ctx, hipMemcpyAsync(p, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
         ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        memcpy(host, p, bytes);
+        drain_fn(p, 0, bytes);
         return ZK_OK;
     }
     ZkXfer* x;
@@ -341,7 +373,6 @@ int zk_xfer_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes, bool pin
         }
         cpieces[nchunks] = np;
         std::atomic<size_t> arrived{0};           // chunks known to have landed
-        char* dst = (char*)host + r0;
         const std::function<void(size_t)> drain = [&](size_t p) {
             size_t c = 0;
             while (cpieces[c + 1] <= p) c++;
@@ -355,7 +386,7 @@ int zk_xfer_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes, bool pin
                 }
             }
             const size_t off = p * XF_PIECE, len = std::min(XF_PIECE, rb - off);
-            memcpy(dst + off, x->ring + off, len);
+            drain_fn(x->ring + off, r0 + off, len);
         };
         x->team->run(np, drain, nullptr);
         ZK_HIP(ctx, (hipError_t)x->err.load());

@@ -3,6 +3,7 @@
 #include "ctx.hpp"
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 #include <functional>
 #include <string>
 
@@ -49,20 +50,69 @@ struct zk_bases {
 // pinned = the caller's own page-locked memory (zk_host_alloc): one DMA on the context stream, in place
 int zk_xfer_h2d(zk_ctx* ctx, void* dev, const void* host, size_t bytes, bool pinned = false);
 int zk_xfer_d2h(zk_ctx* ctx, void* host, const void* dev, size_t bytes, bool pinned = false);
+// ... with the bytes produced / consumed piece by piece by the ring's thread team (gathers out of and scatters into the caller's own
+// struct layouts); fence_ctx = false: on the DMA stream alone (see hostxfer.hip)
+using ZkXferFill = std::function<void(char* dst, size_t off, size_t len)>;
+using ZkXferDrain = std::function<void(const char* src, size_t off, size_t len)>;
+int zk_xfer_h2d_fn(zk_ctx* ctx, void* dev, size_t bytes, const ZkXferFill& fill, bool fence_ctx,
+                   const std::function<int(size_t, size_t, hipStream_t)>* after_round);
+int zk_xfer_d2h_fn(zk_ctx* ctx, const void* dev, size_t bytes, const ZkXferDrain& drain);
+int zk_xfer_stream(zk_ctx* ctx, hipStream_t* st);
 void zk_xfer_free(zk_ctx* ctx);
 bool zk_host_is_pinned(const void* host);      // page-locked by HIP (hipHostMalloc / hipHostRegister): safe to hand to hipMemcpyAsync
 // a host table in the caller's own struct layout (zk_affine_layout of the ABI); off_inf == SIZE_MAX: no flag, all-zero bytes = infinity
 struct ZkAffineLayout { size_t stride, off_x, off_y, off_inf; };
 int zk_bases_upload_host(zk_ctx* ctx, int group, const void* host, size_t n, const ZkAffineLayout* layout, zk_bases** out);   // msm.hip
-// bases_cache.hip: the resident table for a host slice -- from the context's cache (then *temporary = false and the cache owns it)
-// or freshly uploaded for this call only (*temporary = true: the caller frees it)
-int zk_bases_cache_get(zk_ctx* ctx, int group, const void* host, size_t n, const ZkAffineLayout* layout, const zk_bases** out, bool* temporary);
+// msm.hip: an empty device-form table of n points / its content from the packed ABI form (n * 96 | 192 bytes on the device), on `st`
+int zk_bases_alloc_dev(zk_ctx* ctx, int group, size_t n, zk_bases** out);
+int zk_bases_import_launch(zk_ctx* ctx, zk_bases* b, const void* raw_dev, hipStream_t st);
+// bases_cache.hip: the resident table for a host slice, keyed by CONTENT.  A host table as the caller holds it: packed (stride = 96 |
+// 192, off_y = stride / 2, off_inf = off_tag = SIZE_MAX), GroupAffine<P> {x, y, infinity}, or that inside an MpcGroup wrapper whose
+// discriminant byte at off_tag must say Public (tag_public) for every element.
+struct ZkHostTable {
+    int group = 1;
+    const void* host = nullptr;
+    size_t stride = 0, off_x = 0, off_y = 0, off_inf = SIZE_MAX, off_tag = SIZE_MAX;
+    uint8_t tag_public = 0;
+};
+struct ZkBasesLease {
+    const zk_bases* b = nullptr;    // the table to run on
+    bool temporary = false;         // made for this call only (cache off / tiny / over budget): zk_bases_lease_release frees it
+    bool verify = false;            // a hit by fingerprint: zk_bases_cache_verify must confirm it before the result leaves the library
+    uint32_t* raw_tmp = nullptr;
+    void* stage = nullptr;          // device buffer the caller's slice is compared in
+    const void* entry = nullptr;
+};
+int zk_bases_cache_get(zk_ctx* ctx, const ZkHostTable& t, size_t n, ZkBasesLease* out);
+int zk_bases_cache_verify(zk_ctx* ctx, ZkBasesLease* l, const ZkHostTable& t, size_t n, bool* same);
+int zk_bases_cache_replace(zk_ctx* ctx, ZkBasesLease* l);
+void zk_bases_lease_release(zk_ctx* ctx, ZkBasesLease* l);
+// msm.hip: n_lanes MSMs (device scalar vectors of n elements) over ONE host table, through the cache -- verified hit and all
+int zk_msm_table_run(zk_ctx* ctx, const ZkHostTable& t, size_t n_table, int n_lanes, const void* const* scalars_dev, size_t n, void* const* outs);
+int zk_bases_cache_poll(zk_ctx* ctx);            // publish finished window multiples, start the next build (cheap: one event query)
 void zk_bases_cache_free(zk_ctx* ctx);
 extern "C" int zk_bases_free(zk_ctx* ctx, zk_bases* b);
 constexpr size_t ZK_PRECOMP_MIN_POINTS = 256;                    // tables below this keep the plain form (zk_bases_precompute is a no-op)
 extern "C" int zk_bases_precompute(zk_ctx* ctx, zk_bases* b);
 uint32_t zk_precompute_windows(size_t n);                            // fixed_base.hip: copies a table of n points would get
 int zk_bases_precompute_auto(zk_ctx* ctx, zk_bases* b);             // only when ZK_PRECOMP=1 (off by default: see fixed_base.hip)
+// fixed_base.hip: the window multiples of a resident table built in slices on a side stream, published by a later call
+// (bases_cache.hip drives it: begin = the allocations, step = the next few hundred microseconds of launches, finish = publish / drop)
+struct ZkPrecompJob {
+    zk_bases* b = nullptr;
+    uint32_t c = 0, W = 0, wide_words = 0;
+    uint32_t *packed = nullptr, *wide = nullptr, *xy = nullptr, *scr = nullptr;
+    int phase = 0;                  // 0: copy of level 0, 1: levels, 2: re-laid copy, 3: every slice enqueued
+    uint32_t w = 1;
+    size_t pos = 0;
+    hipError_t err = hipSuccess;
+};
+int zk_bases_precompute_begin(zk_ctx* ctx, zk_bases* b, size_t budget_bytes, ZkPrecompJob** out);   // *out = NULL: skipped (b->pre_note says why)
+hipError_t zk_bases_precompute_step(ZkPrecompJob* j, hipStream_t st, bool* more);
+int zk_bases_precompute_finish(zk_ctx* ctx, ZkPrecompJob* j, bool keep);
+// core.hip: library calls in flight on a device (every `extern "C" int` entry point that takes a context counts itself): the cache's
+// builder thread hands out its slices while this is zero
+std::atomic<int>& zk_calls_in_flight(int device);
 int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,
                void* out_host_projective);
 

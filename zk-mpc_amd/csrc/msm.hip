@@ -1365,9 +1365,51 @@ int bases_download_t(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, vo
     return ZK_OK;
 }
 
-// AffineCurve::multi_scalar_mul on host slices.  The bases come through the context's table cache (bases_cache.hip): a slice the
-// context has seen before -- the queries of a proving key, the powers of an SRS -- is resident already, with window multiples
-// from its second use on; only the scalars cross PCIe.
+// AffineCurve::multi_scalar_mul on host slices.  The bases come through the context's table cache (bases_cache.hip): a table the
+// context has seen before -- the queries of a proving key, the powers of an SRS -- is resident already (window multiples are built
+// beside later calls), and only the scalars cross PCIe for the arithmetic; the caller's slice crosses once more, UNDER the MSM, to
+// be compared in full with what the cached table was made from (a hit is a candidate until that comparison is through).
+// n_lanes MSMs over the same table (the two lanes of a SPDZ multi_scale_pub_group: share/spdz.rs:482-488): scalars_dev[l] -> outs[l].
+template <class F>
+int msm_table_run_t(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, const void* const* scalars_dev, size_t n, void* const* outs) {
+    constexpr size_t PROJ = 3 * F::WORDS * 4;              // bytes of a zk_g1_projective / zk_g2_projective
+    ZkBasesLease lease;
+    ZK_TRY(zk_bases_cache_get(ctx, t, nu, &lease));
+    int rc = ZK_OK;
+    for (int attempt = 0; attempt < 2 && rc == ZK_OK; attempt++) {
+        bool same = true;
+        int vrc = ZK_OK;
+        {
+            ZkTask<void> verifier;                           // (joins when this block is left, whatever the MSM did)
+            if (lease.verify)
+                verifier = zk_async(ctx, [&] { (void)hipSetDevice(ctx->device); vrc = zk_bases_cache_verify(ctx, &lease, t, nu, &same); });
+            if (n_lanes == 1) {
+                rc = msm_run_t<F>(ctx, lease.b, 0, scalars_dev[0], n, outs[0]);
+            } else {
+                const zk_bases* bs[2] = {lease.b, lease.b};
+                const size_t lens[2] = {n, n};
+                rc = zk_msm_batch_dev(ctx, (size_t)n_lanes, bs, nullptr, scalars_dev, lens, outs);
+            }
+        }
+        if (rc == ZK_OK) rc = vrc;
+        if (rc != ZK_OK || same) break;
+        rc = zk_bases_cache_replace(ctx, &lease);            // the table at the caller's address is not the cached one any more: again, on the right one
+    }
+    (void)PROJ;
+    zk_bases_lease_release(ctx, &lease);
+    return rc;
+}
+
+ZkHostTable host_table(int group, const void* host, const ZkAffineLayout* layout) {
+    ZkHostTable t;
+    t.group = group;
+    t.host = host;
+    const size_t FE = group == 1 ? 48 : 96;
+    if (layout) { t.stride = layout->stride; t.off_x = layout->off_x; t.off_y = layout->off_y; t.off_inf = layout->off_inf; }
+    else { t.stride = 2 * FE; t.off_x = 0; t.off_y = FE; t.off_inf = SIZE_MAX; }
+    return t;
+}
+
 template <class F>
 int msm_host_t(zk_ctx* ctx, const void* bases_host, size_t nb, const ZkAffineLayout* layout, const zk_fr* scalars, size_t ns, int group, void* out) {
     if (!ctx || !out) return ZK_ERR_ARG;
@@ -1378,15 +1420,12 @@ int msm_host_t(zk_ctx* ctx, const void* bases_host, size_t nb, const ZkAffineLay
         return ZK_OK;
     }
     const size_t nu = nb <= 2 * n ? nb : n;                  // the whole slice (it is the cache's key) unless most of it is unused
-    const zk_bases* b = nullptr;
-    bool temporary = false;
-    ZK_TRY(zk_bases_cache_get(ctx, group, bases_host, nu, layout, &b, &temporary));
     void* sdev = nullptr;
-    int rc = zk_scratch(ctx, "msm_scalars_host", n * 32, &sdev);
-    if (rc == ZK_OK) rc = zk_xfer_h2d(ctx, sdev, scalars, n * 32);
-    if (rc == ZK_OK) rc = msm_run_t<F>(ctx, b, 0, sdev, n, out);
-    if (temporary) zk_bases_free(ctx, const_cast<zk_bases*>(b));
-    return rc;
+    ZK_TRY(zk_scratch(ctx, "msm_scalars_host", n * 32, &sdev));
+    ZK_TRY(zk_xfer_h2d(ctx, sdev, scalars, n * 32));
+    const void* sc[1] = {sdev};
+    void* outs[1] = {out};
+    return msm_table_run_t<F>(ctx, host_table(group, bases_host, layout), nu, 1, sc, n, outs);
 }
 
 }  // namespace
@@ -1482,6 +1521,29 @@ int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const voi
 int zk_bases_upload_host(zk_ctx* ctx, int group, const void* host, size_t n, const ZkAffineLayout* layout, zk_bases** out) {
     if (group == 1) return bases_upload_t<G1Field>(ctx, host, n, 1, layout, out);
     return bases_upload_t<G2Field>(ctx, host, n, 2, layout, out);
+}
+int zk_bases_alloc_dev(zk_ctx* ctx, int group, size_t n, zk_bases** out) {
+    std::unique_ptr<zk_bases> b(new zk_bases());
+    b->group = group;
+    b->n = n;
+    if (n && hipMalloc((void**)&b->dev, n * (group == 1 ? 96 : 192)) != hipSuccess) {
+        (void)hipGetLastError();
+        ZK_FAIL(ctx, ZK_ERR_NOMEM, "base table: hipMalloc failed");
+    }
+    *out = b.release();
+    return ZK_OK;
+}
+int zk_bases_import_launch(zk_ctx* ctx, zk_bases* b, const void* raw, hipStream_t st) {
+    if (!b->n) return ZK_OK;
+    if (b->group == 1) hipLaunchKernelGGL(k_bases_import<G1Field>, zk_grid(b->n, 256), 256, 0, st, (const uint32_t*)raw, b->dev, b->n);
+    else hipLaunchKernelGGL(k_bases_import<G2Field>, zk_grid(b->n, 256), 256, 0, st, (const uint32_t*)raw, b->dev, b->n);
+    ZK_HIP(ctx, hipGetLastError());
+    return ZK_OK;
+}
+// the MSM of the MPC entry points (mpc_host.hip): n_lanes scalar vectors on the device against one host table
+int zk_msm_table_run(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, const void* const* scalars_dev, size_t n, void* const* outs) {
+    if (t.group == 1) return msm_table_run_t<G1Field>(ctx, t, nu, n_lanes, scalars_dev, n, outs);
+    return msm_table_run_t<G2Field>(ctx, t, nu, n_lanes, scalars_dev, n, outs);
 }
 extern "C" int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* h, size_t n, zk_bases** out) { ZK_API_BEGIN(ctx) return bases_upload_t<G1Field>(ctx, h, n, 1, nullptr, out); ZK_API_END }
 extern "C" int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* h, size_t n, zk_bases** out) { ZK_API_BEGIN(ctx) return bases_upload_t<G2Field>(ctx, h, n, 2, nullptr, out); ZK_API_END }
