@@ -506,18 +506,20 @@ def trait_path_collab_leg(log_d: int, resident_ms: float, proofs: int = 7):
         runs.append(("additive_p3_2p18", 18, 3, ("additive", "tagfirst", "verify")))
     for name, ld, parties, mode in runs:
         try:
-            r = subprocess.run([exe, str(ld), str(proofs), str(parties), *mode], capture_output=True, text=True, timeout=900)
+            # (sync2: the window-multiple builds are waited for after the second proof, outside the laps -- P parties share ONE GPU
+            # here and their builders find no quiet device; on a GPU per party they finish in the callers' own time, as trait_path shows)
+            r = subprocess.run([exe, str(ld), str(proofs), str(parties), *mode, "sync2"], capture_output=True, text=True, timeout=900)
             if r.returncode != 0:
                 out[name] = {"error": r.stderr[-400:]}
                 continue
             lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
             pr, last = lines[:-1], lines[-1]
-            steady = pr[3:] if len(pr) > 4 else pr[-1:]
+            steady = pr[2:] if len(pr) > 3 else pr[-1:]
             med = lambda k: round(float(np.median([p["ms"][k] for p in steady])), 3)
             out[name] = {"log_domain": ld, "parties": parties, "shares": last["shares"], "hits": last["hits"], "element_bytes": last["element_bytes"],
                          "first_call_ms": {k: pr[0]["ms"][k] for k in ("total", "lib")},
                          "second_call_ms": {k: pr[1]["ms"][k] for k in ("total", "lib")} if len(pr) > 1 else None,
-                         "third_call_ms": {k: pr[2]["ms"][k] for k in ("total", "lib")} if len(pr) > 2 else None,
+                         "lib_ms_every_call": [p["ms"]["lib"] for p in pr],
                          "steady_state_ms": {k: med(k) for k in pr[0]["ms"]}, "steady_state_over": len(steady),
                          "steady_state_max_lib_ms": round(float(np.median([p["ms_max_lib"] for p in steady])), 3),
                          "beaver_bytes_sent_per_party": pr[0]["beaver_bytes_sent"],

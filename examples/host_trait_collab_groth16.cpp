@@ -25,7 +25,9 @@
 // cache counters.  tests/test_gpu_trait_path.py compares the bytes with the oracle's known-trapdoor prediction on the summed
 // inputs; bench.py's `trait_path_collab` leg reports the times.
 //
-//   host_trait_collab_groth16 <log2 of the QAP domain> <proofs> <parties> [additive|spdz] [tagfirst|taglast] [verify|trust]
+//   host_trait_collab_groth16 <log2 of the QAP domain> <proofs> <parties> [additive|spdz] [tagfirst|taglast] [verify|trust] [sync2]
+// sync2: after the second proof every party waits for its window-multiple builds (zk_bases_cache_sync, outside the timed laps), so that
+// the proofs from the third on are the steady state -- for P parties on ONE GPU, whose builders otherwise find no quiet device.
 #include <chrono>
 #include <condition_variable>
 #include <cstddef>
@@ -376,6 +378,7 @@ int main(int argc, char** argv) {
     const bool spdz = argc > 4 && std::string(argv[4]) == "spdz";
     const bool tag_last = argc > 5 && std::string(argv[5]) == "taglast";
     const bool trust = argc > 6 && std::string(argv[6]) == "trust";
+    const bool sync2 = argc > 7 && std::string(argv[7]) == "sync2";
     if (log_d < 2 || log_d > 22 || proofs < 1 || P < 1 || P > 8) {
         fprintf(stderr, "usage: %s <log2 domain 2..22> <proofs> <parties 1..8> [additive|spdz] [tagfirst|taglast] [verify|trust]\n", argv[0]);
         return 2;
@@ -579,6 +582,7 @@ int main(int argc, char** argv) {
                          "\"beaver_bytes_sent\": %llu",
                          total, lib, t_fft, t_bp, t_div, t_msm[0], t_msm[1], t_msm[2], t_msm[3], t_msm[4], t_tail, t_mat, t_sub, (unsigned long long)sent);
                 lines[p].push_back(buf);
+                if (sync2 && it == 1) CKX(zk_bases_cache_sync(ctx));
             }
             net.bar.wait();
             uint64_t st[10], st2[4];

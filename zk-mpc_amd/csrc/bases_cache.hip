@@ -180,7 +180,6 @@ size_t resident(const ZkBasesCache* c) {
 
 void builder_main(zk_ctx* ctx, ZkBasesCache* c) {
     (void)hipSetDevice(ctx->device);
-    std::atomic<int>& in_flight = zk_calls_in_flight(ctx->device);
     std::unique_lock<std::mutex> lk(c->bm);
     for (;;) {
         c->bcv.wait(lk, [&] { return c->bstop || (c->building && !c->build_done.load()); });
@@ -189,12 +188,14 @@ void builder_main(zk_ctx* ctx, ZkBasesCache* c) {
         lk.unlock();
         bool more = true;
         while (more && !c->bcancel.load()) {
-            // a gap: no entry point executing on this device.  A caller that never leaves the library still gets its tables -- one
-            // slice (~0.2 ms of kernels) per 20 ms of waiting -- and zk_bases_cache_sync (rush) takes them at full speed.
+            // a gap: no entry point executing on this device, and none for the last 0.3 ms (the calls of a burst are microseconds
+            // apart; a slice handed out between two of them would run under the second).  A caller that never leaves the library
+            // still gets its tables -- one slice (~1 ms of kernels) per 50 ms of waiting -- and zk_bases_cache_sync (rush) takes
+            // them at full speed.
             const auto t0 = std::chrono::steady_clock::now();
-            while (in_flight.load(std::memory_order_relaxed) > 0 && !c->rush.load() && !c->bcancel.load() &&
-                   std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(20))
-                std::this_thread::sleep_for(std::chrono::microseconds(25));
+            while (!zk_device_quiet_for(ctx->device, 300000) && !c->rush.load() && !c->bcancel.load() &&
+                   std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50))
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
             hipError_t e = zk_bases_precompute_step(j, c->pre_stream, &more);
             if (e == hipSuccess) e = hipStreamSynchronize(c->pre_stream);
             if (e != hipSuccess) { j->err = e; (void)hipGetLastError(); break; }
@@ -260,7 +261,7 @@ int advance_builds(zk_ctx* ctx, ZkBasesCache* c, bool wait) {
             if (!wait && !c->build_done.load()) return ZK_OK;
             zk_bases* b = c->building->b;
             ZK_TRY(zk_bases_precompute_finish(ctx, builder_collect(c, false), true));
-            c->builds++;
+            if (b->pre) c->builds++;
             for (auto& y : c->e) if (y.b == b) y.bytes = table_bytes(b);
         }
         if (c->precompute_after <= 0) return ZK_OK;

@@ -346,52 +346,62 @@ extern "C" int zk_bases_precompute_as(zk_ctx* ctx, zk_bases* b, int layout) {
 // 40 ms path -- VERDICT r5 weak 4 iii; enqueued all at once on a side stream they still made the next four proofs 2 - 3x slower,
 // the accumulate kernels sharing the chip with the build: measured in round 6, profiles/r6_trait_first.jsonl.)
 namespace {
-constexpr size_t PRE_SLICE = (size_t)1 << 16;              // points per slice of a level: a multiple of NORM_CHUNK
-constexpr size_t PRE_REPACK_SLICE = (size_t)1 << 19;
+// points per slice of a level (a multiple of NORM_CHUNK): 2^18 lanes of twenty dependent doublings fill the chip (2^16 left it at one
+// wave per SIMD: the build crawled -- one table in seven proofs' gaps); ~1 ms of kernels, the most a call can find in its way
+constexpr size_t PRE_SLICE = (size_t)1 << 18;
+constexpr size_t PRE_REPACK_SLICE = (size_t)1 << 21;
 
 template <class F>
 int precompute_begin_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W, size_t budget, ZkPrecompJob** out) {
     const size_t n = b->n, PW = 2 * F::WORDS;
     const size_t packed_bytes = (size_t)W * n * PW * 4, xy_bytes = n * 4 * F::WORDS * 4, scr_bytes = n * F::WORDS * 4;
-    size_t mem_free = 0, mem_total = 0;
-    auto skip = [&](const char* why) {
+    if (packed_bytes + xy_bytes + scr_bytes > budget) {
         char msg[256];
-        snprintf(msg, sizeof msg, "window multiples skipped for a %zu-point G%d table (c = %u, W = %u: %.2f GB packed): %s; %.2f GB free",
-                 n, b->group, c, W, packed_bytes / 1e9, why, mem_free / 1e9);
+        snprintf(msg, sizeof msg, "window multiples skipped for a %zu-point G%d table (c = %u, W = %u: %.2f GB packed): more than the cache's budget", n, b->group, c, W, packed_bytes / 1e9);
         b->pre_note = msg;
         return ZK_OK;
-    };
-    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return skip("hipMemGetInfo failed");
-    budget = std::min(budget, mem_free / 3);
-    if (packed_bytes + xy_bytes + scr_bytes > budget) return skip("more than the cache's budget or a third of the free device memory");
+    }
+    // (no HIP call here: this runs inside the MSM call that earned the table its multiples -- hipMemGetInfo alone is ~10 ms with
+    // a few GB of tables resident; the memory check and the allocations are the builder's first step)
     std::unique_ptr<ZkPrecompJob> j(new ZkPrecompJob());
     j->b = b; j->c = c; j->W = W;
-    if (hipMalloc((void**)&j->packed, packed_bytes) != hipSuccess || hipMalloc((void**)&j->xy, xy_bytes) != hipSuccess ||
-        hipMalloc((void**)&j->scr, scr_bytes) != hipSuccess) {
-        for (void* p : {(void*)j->packed, (void*)j->xy, (void*)j->scr}) if (p) (void)hipFree(p);
-        (void)hipGetLastError();
-        return skip("hipMalloc failed");
-    }
-    if constexpr (F::WORDS == 12) {                        // the re-laid copy (see precompute_t): limbs with both signs, else a line per point
-        for (uint32_t words : {64u, 32u}) {
-            const size_t bytes = (size_t)W * n * words * 4;
-            if (packed_bytes + xy_bytes + scr_bytes + bytes > budget) continue;
-            if (hipMalloc((void**)&j->wide, bytes) != hipSuccess) { j->wide = nullptr; (void)hipGetLastError(); continue; }
-            j->wide_words = words;
-            break;
-        }
-    }
+    j->budget = budget;
     (void)ctx;
     *out = j.release();
     return ZK_OK;
 }
 
-// the next slice of the build on `st`; *more = false once the last one has been enqueued
+// the next slice of the build on `st`; *more = false once the last one has been enqueued (the caller waits for `st` between slices)
 template <class F>
 hipError_t precompute_step_t(ZkPrecompJob* j, hipStream_t st, bool* more) {
     const zk_bases* b = j->b;
     const size_t n = b->n, PW = 2 * F::WORDS;
     *more = true;
+    if (j->phase == -1) {
+        // the allocations (several GB: ~10 ms of page-table work) -- here, in the builder's time, not in the call that earned the
+        // table its multiples; a failure leaves the table plain
+        const size_t packed_bytes = (size_t)j->W * n * PW * 4, xy_bytes = n * 4 * F::WORDS * 4, scr_bytes = n * F::WORDS * 4;
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+        j->budget = std::min(j->budget, mem_free / 3);     // never more than a third of what is free (see precompute_t)
+        if (packed_bytes + xy_bytes + scr_bytes > j->budget) return hipErrorOutOfMemory;
+        if (hipMalloc((void**)&j->packed, packed_bytes) != hipSuccess || hipMalloc((void**)&j->xy, xy_bytes) != hipSuccess ||
+            hipMalloc((void**)&j->scr, scr_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return hipErrorOutOfMemory;
+        }
+        if constexpr (F::WORDS == 12) {                    // the re-laid copy (see precompute_t): limbs with both signs, else a line per point
+            for (uint32_t words : {64u, 32u}) {
+                const size_t bytes = (size_t)j->W * n * words * 4;
+                if (packed_bytes + xy_bytes + scr_bytes + bytes > j->budget) continue;
+                if (hipMalloc((void**)&j->wide, bytes) != hipSuccess) { j->wide = nullptr; (void)hipGetLastError(); continue; }
+                j->wide_words = words;
+                break;
+            }
+        }
+        j->phase = 0;
+        return hipSuccess;
+    }
     if (j->phase == 0) {                                   // level 0 = the table itself
         j->phase = j->W > 1 ? 1 : 2;
         j->w = 1; j->pos = 0;
@@ -413,11 +423,18 @@ hipError_t precompute_step_t(ZkPrecompJob* j, hipStream_t st, bool* more) {
                 if (j->wide_words == 64) hipLaunchKernelGGL(k_repack_limbs<F>, zk_grid(len, 256), 256, 0, st, (const uint32_t*)j->packed + lo * PW, j->wide + lo * 64, len);
                 else hipLaunchKernelGGL(k_repack<F>, zk_grid(len, 256), 256, 0, st, (const uint32_t*)j->packed + lo * PW, j->wide + lo * 32, len, 32u);
                 j->pos += len;
-                if (j->pos >= total) { j->phase = 3; *more = false; }
+                if (j->pos >= total) j->phase = 3;
                 return hipGetLastError();
             }
         }
         j->phase = 3;
+        return hipSuccess;
+    }
+    if (j->phase == 3) {                                   // (the stream has been waited for) the scratch goes, in the builder's time as well
+        (void)hipFree(j->xy); j->xy = nullptr;
+        (void)hipFree(j->scr); j->scr = nullptr;
+        if (j->wide) { (void)hipFree(j->packed); j->packed = nullptr; }
+        j->phase = 4;
     }
     *more = false;
     return hipSuccess;
@@ -439,12 +456,11 @@ hipError_t zk_bases_precompute_step(ZkPrecompJob* j, hipStream_t st, bool* more)
 // the stream the slices ran on has been waited for.  keep = false (or a slice failed): throw the table away
 int zk_bases_precompute_finish(zk_ctx* ctx, ZkPrecompJob* j, bool keep) {
     zk_bases* b = j->b;
-    (void)hipFree(j->xy);
-    (void)hipFree(j->scr);
+    if (j->xy) (void)hipFree(j->xy);
+    if (j->scr) (void)hipFree(j->scr);
     const hipError_t e = j->err;
-    if (e == hipSuccess && keep && j->phase == 3) {
+    if (e == hipSuccess && keep && j->phase == 4) {
         if (j->wide) {
-            (void)hipFree(j->packed);
             b->pre = j->wide;
             b->pre_stride = j->wide_words;
             b->pre_note = j->wide_words == 64 ? "limbs, both signs (256 B per point)" : "one point per 128-byte line";
@@ -456,8 +472,13 @@ int zk_bases_precompute_finish(zk_ctx* ctx, ZkPrecompJob* j, bool keep) {
         b->c_pre = j->c;
         b->W_pre = j->W;
     } else {
-        (void)hipFree(j->packed);
+        if (j->packed) (void)hipFree(j->packed);
         if (j->wide) (void)hipFree(j->wide);
+        if (e == hipErrorOutOfMemory) {                     // not an error of the call that happens to collect the job: the table stays plain
+            b->pre_note = "window multiples skipped: more than a third of the free device memory, or hipMalloc failed";
+            delete j;
+            return ZK_OK;
+        }
     }
     delete j;
     ZK_HIP(ctx, e);

@@ -102,9 +102,9 @@ struct ZkPrecompJob {
     zk_bases* b = nullptr;
     uint32_t c = 0, W = 0, wide_words = 0;
     uint32_t *packed = nullptr, *wide = nullptr, *xy = nullptr, *scr = nullptr;
-    int phase = 0;                  // 0: copy of level 0, 1: levels, 2: re-laid copy, 3: every slice enqueued
+    int phase = -1;                 // -1: allocations, 0: copy of level 0, 1: levels, 2: re-laid copy, 3: scratch to free, 4: complete
     uint32_t w = 1;
-    size_t pos = 0;
+    size_t pos = 0, budget = 0;
     hipError_t err = hipSuccess;
 };
 int zk_bases_precompute_begin(zk_ctx* ctx, zk_bases* b, size_t budget_bytes, ZkPrecompJob** out);   // *out = NULL: skipped (b->pre_note says why)
@@ -113,6 +113,7 @@ int zk_bases_precompute_finish(zk_ctx* ctx, ZkPrecompJob* j, bool keep);
 // core.hip: library calls in flight on a device (every `extern "C" int` entry point that takes a context counts itself): the cache's
 // builder thread hands out its slices while this is zero
 std::atomic<int>& zk_calls_in_flight(int device);
+bool zk_device_quiet_for(int device, int64_t ns);      // no entry point executing, and none has returned within the last `ns`
 int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,
                void* out_host_projective);
 
