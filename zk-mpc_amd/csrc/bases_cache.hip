@@ -188,12 +188,12 @@ void builder_main(zk_ctx* ctx, ZkBasesCache* c) {
         lk.unlock();
         bool more = true;
         while (more && !c->bcancel.load()) {
-            // a gap: no entry point executing on this device, and none for the last 0.3 ms (the calls of a burst are microseconds
+            // a gap: no entry point executing on this context, and none for the last 0.3 ms (the calls of a burst are microseconds
             // apart; a slice handed out between two of them would run under the second).  A caller that never leaves the library
             // still gets its tables -- one slice (~1 ms of kernels) per 50 ms of waiting -- and zk_bases_cache_sync (rush) takes
             // them at full speed.
             const auto t0 = std::chrono::steady_clock::now();
-            while (!zk_device_quiet_for(ctx->device, 300000) && !c->rush.load() && !c->bcancel.load() &&
+            while (!ctx->activity->quiet_for(300000) && !c->rush.load() && !c->bcancel.load() &&
                    std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50))
                 std::this_thread::sleep_for(std::chrono::microseconds(50));
             hipError_t e = zk_bases_precompute_step(j, c->pre_stream, &more);

@@ -9,26 +9,6 @@
 
 extern "C" int zk_version(void) { ZK_API_BEGIN_NOCTX return 1; ZK_API_END }
 
-// Entry points in flight per device.  The only mutable process-wide state of the library, and advisory: the table cache's builder
-// thread (bases_cache.hip) hands out a slice of background work when it reads zero, so that building window multiples takes the
-// chip in the caller's own time between two calls, not from the kernels of a call.
-static std::atomic<int> g_calls[64];
-static std::atomic<int64_t> g_last_leave_ns[64];        // steady-clock time of the last return from an entry point
-static inline int64_t steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-std::atomic<int>& zk_calls_in_flight(int device) { return g_calls[(unsigned)device & 63]; }
-// the device has been free of library calls for at least `ns` (two calls of a burst -- seven transforms, five MSMs -- are
-// microseconds apart: not a gap; the caller's own scalar loops between two bursts are milliseconds: a gap)
-bool zk_device_quiet_for(int device, int64_t ns) {
-    const unsigned d = (unsigned)device & 63;
-    return g_calls[d].load(std::memory_order_relaxed) == 0 && steady_ns() - g_last_leave_ns[d].load(std::memory_order_relaxed) >= ns;
-}
-void zk_call_enter(int device) { g_calls[(unsigned)device & 63].fetch_add(1, std::memory_order_relaxed); }
-void zk_call_leave(int device) {
-    const unsigned d = (unsigned)device & 63;
-    g_last_leave_ns[d].store(steady_ns(), std::memory_order_relaxed);
-    g_calls[d].fetch_sub(1, std::memory_order_relaxed);
-}
-
 extern "C" int zk_selftest_exception_barrier(int kind) {
     ZK_API_BEGIN_NOCTX
     if (kind == 0) throw std::bad_alloc();

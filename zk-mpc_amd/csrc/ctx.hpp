@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -96,7 +97,19 @@ class ZkHostPool {
     }
 };
 
+struct ZkActivity {
+    std::atomic<int> calls{0};
+    std::atomic<int64_t> last_leave_ns{0};
+    // no entry point of the context executing, and none has returned within the last `ns` (two calls of a burst -- seven transforms,
+    // five MSMs -- are microseconds apart: not a gap; the caller's own scalar loops between two bursts are milliseconds: a gap)
+    bool quiet_for(int64_t ns) const {
+        const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        return calls.load(std::memory_order_relaxed) == 0 && now - last_leave_ns.load(std::memory_order_relaxed) >= ns;
+    }
+};
+
 struct zk_ctx {
+    std::shared_ptr<ZkActivity> activity = std::make_shared<ZkActivity>();
     int device = 0;
     int party_id = 0;
     int n_parties = 1;
@@ -192,13 +205,17 @@ struct ZkDeviceGuard {
     ZkDeviceGuard& operator=(const ZkDeviceGuard&) = delete;
 };
 
-// core.hip: how many entry points are executing on a device right now (the table cache's builder thread works in the gaps)
-void zk_call_enter(int device);
-void zk_call_leave(int device);
+// Entry points executing on a context right now, and when the last one returned: the table cache's builder thread
+// (bases_cache.hip) hands out its background work in the gaps -- the caller's own time between two bursts of calls.  Held through
+// a shared pointer so that the mark of zk_ctx_destroy outlives the context it destroys.
 struct ZkCallMark {
-    int dev;
-    explicit ZkCallMark(int d) : dev(d) { zk_call_enter(dev); }
-    ~ZkCallMark() { zk_call_leave(dev); }
+    std::shared_ptr<ZkActivity> a;
+    explicit ZkCallMark(zk_ctx* c) : a(c->activity) { a->calls.fetch_add(1, std::memory_order_relaxed); }
+    ~ZkCallMark() {
+        a->last_leave_ns.store(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(),
+                               std::memory_order_relaxed);
+        a->calls.fetch_sub(1, std::memory_order_relaxed);
+    }
     ZkCallMark(const ZkCallMark&) = delete;
     ZkCallMark& operator=(const ZkCallMark&) = delete;
 };
@@ -208,7 +225,7 @@ static inline int zk_api_guarded(zk_ctx* ctx, Fn&& body) noexcept {
     // (ctx may be destroyed by the body -- zk_ctx_destroy -- so nothing below touches it after a normal return)
     try {
         if (!ctx) return body();
-        ZkCallMark mark(ctx->device);
+        ZkCallMark mark(ctx);
         ZkDeviceGuard guard(ctx->device);
         if (guard.err != hipSuccess) {
             // another party's GPU would take this context's pointers: silent corruption instead of an error code

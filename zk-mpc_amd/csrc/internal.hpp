@@ -110,10 +110,6 @@ struct ZkPrecompJob {
 int zk_bases_precompute_begin(zk_ctx* ctx, zk_bases* b, size_t budget_bytes, ZkPrecompJob** out);   // *out = NULL: skipped (b->pre_note says why)
 hipError_t zk_bases_precompute_step(ZkPrecompJob* j, hipStream_t st, bool* more);
 int zk_bases_precompute_finish(zk_ctx* ctx, ZkPrecompJob* j, bool keep);
-// core.hip: library calls in flight on a device (every `extern "C" int` entry point that takes a context counts itself): the cache's
-// builder thread hands out its slices while this is zero
-std::atomic<int>& zk_calls_in_flight(int device);
-bool zk_device_quiet_for(int device, int64_t ns);      // no entry point executing, and none has returned within the last `ns`
 int zk_msm_run(zk_ctx* ctx, const zk_bases* bases, size_t base_offset, const void* scalars_dev, size_t n,
                void* out_host_projective);
 
