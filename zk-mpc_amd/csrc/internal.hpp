@@ -168,6 +168,11 @@ int zk_msm_enqueue_sort_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hip
 int zk_msm_enqueue_accum_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st);
 int zk_msm_enqueue_reduce_group(zk_ctx* ctx, ZkMsmJob* const* jobs, int count, hipStream_t st);
 
+// msm_batch.hip: one or two MSMs over one scalar vector started ahead of a batch (Marlin: the oracles of a round that exist early)
+struct ZkEarlyMsm;
+int zk_msm_early_begin(zk_ctx* ctx, int count, const zk_bases* bases, const size_t* base_offsets, const void* scalars_dev, size_t len, ZkEarlyMsm** out);
+int zk_msm_early_finish(zk_ctx* ctx, ZkEarlyMsm* em, void* const* outs);      // outs = NULL: abandon (waits for its kernels); deletes the handle
+
 // msm_sort.hip: the bucket sort (msm_digits.cuh declares its interface)
 
 // msm_g2pair.hip: the G2 accumulate kernel with two lanes per point addition

@@ -414,6 +414,33 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     struct FsGuard { zk_rng* r; ~FsGuard() { zk_rng_free(r); } } guard{fs};
     auto sample_outside = [&](const Dom& d) { HF t = P.next_fr(fs); while (d.vanishing(t).is_zero()) t = P.next_fr(fs); return t; };
 
+    // Oracles of a round that exist before the round's last polynomial does -- the mask polynomial (round 1), t (round 2), g_2
+    // (round 3); none of them hiding, so no draw of the prover's rng depends on where their commitment is computed -- have their MSMs
+    // started as soon as their coefficients are on the device (msm_batch.hip: zk_msm_early_begin); the context stream goes on with
+    // the round's polynomial arithmetic, commit_round collects them.  ZK_MARLIN_EARLY=0 keeps every job in the round's batch (A/B).
+    struct Early {
+        zk_ctx* ctx;
+        std::map<std::string, ZkEarlyMsm*> jobs;
+        ~Early() { for (auto& kv : jobs) if (kv.second) (void)zk_msm_early_finish(ctx, kv.second, nullptr); }     // an error path: let them drain
+    } early{ctx, {}};
+    static const bool early_on = !(getenv("ZK_MARLIN_EARLY") && atoi(getenv("ZK_MARLIN_EARLY")) == 0);
+    auto start_early = [&](const char* l) -> int {
+        // from |H| = 2^18 up only: measured on one box, alternating (profiles/r6_marlin_early_ab.jsonl) -- 2^20 65.0 / 64.7 -> 63.9 / 64.0 ms,
+        // 2^18 21.8 -> 21.6; below that a round is a chain of latencies and the early job, which runs alone instead of in the round's
+        // group launches (its own one-block sort, accumulate launch, reduce chain and host half), makes the proof LONGER:
+        // 2^10 3.5 -> 4.2 ms, 2^12 4.3 -> 5.4, 2^14 6.1 -> 7.0, 2^16 9.5 -> 10.2
+        if (!early_on || H.size < ((size_t)1 << 18)) return ZK_OK;
+        const Poly& p = P.polys[l];
+        const bool bounded = P.bounds.count(l) != 0;
+        if (!p.n) return ZK_OK;
+        if (bounded && p.n - 1 > P.bounds[l]) return ZK_OK;                      // (commit_round reports it)
+        const size_t offs[2] = {0, bounded ? P.max_degree - P.bounds[l] : 0};
+        ZkEarlyMsm* em = nullptr;
+        ZK_TRY(zk_msm_early_begin(ctx, bounded ? 2 : 1, P.pg, offs, p.p, p.n, &em));
+        early.jobs[l] = em;
+        return ZK_OK;
+    };
+
     // MarlinKZG10::commit for one round (marlin_pc/mod.rs:172-243): blinding polynomials in the reference's rng order, all MSMs
     // of the round (every lane) as one pipelined batch; shared oracles' commitments opened; then the round's bytes into the transcript
     auto commit_round = [&](std::initializer_list<const char*> labels) -> int {
@@ -435,6 +462,7 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
             P.rands[l] = {blind, sblind};
             for (int lane = 0; lane < LANES; lane++) {
                 if (lane == 1 && !label_shared(l)) continue;                     // public oracles are the same on every lane: committed once
+                if (lane == 0 && early.jobs.count(l)) continue;                  // started early: collected below
                 const Poly& p = PL[lane].polys[l];
                 jb.push_back(P.pg); joff.push_back(0); jsc.push_back(p.p); jlen.push_back(p.n); slot.push_back({l, 0, lane});
                 if (bounded) {
@@ -450,7 +478,19 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         std::vector<void*> outp(jb.size());
         for (size_t i = 0; i < jb.size(); i++) outp[i] = &outs[i];
         laps.lap("commit.prep");
-        const int brc = zk_msm_batch_dev(ctx, jb.size(), jb.data(), joff.data(), jsc.data(), jlen.data(), outp.data());
+        int brc = zk_msm_batch_dev(ctx, jb.size(), jb.data(), joff.data(), jsc.data(), jlen.data(), outp.data());
+        for (const char* l : labels) {                                           // the jobs that were started early
+            auto it = early.jobs.find(l);
+            if (it == early.jobs.end()) continue;
+            zk_g1_projective eo[2];
+            void* eop[2] = {&eo[0], &eo[1]};
+            ZkEarlyMsm* em = it->second;
+            early.jobs.erase(it);
+            const int erc = zk_msm_early_finish(ctx, em, eop);
+            if (brc == ZK_OK) brc = erc;
+            acc[0][0][l] = eo[0];
+            if (P.bounds.count(l)) acc[0][1][l] = eo[1];
+        }
         laps.lap("commit.msm");
         std::vector<std::pair<std::pair<int, std::string>, zk_g1_projective>> bl;
         for (auto& b : blinds) bl.push_back({b.first, b.second.get()});          // joined before any return
@@ -517,6 +557,18 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     }
     const size_t nwq = n + 1 - X.size;
     char *z_a[2], *z_b[2], *xb[2], *wq[2], *mask[2], *tmp[2];
+    for (int l = 0; l < LANES; l++) {                                            // the mask polynomial first: its commitment (the round's longest job) starts now
+        Prover& Q = PL[l];
+        mask[l] = Q.dev("mask", md + 1);
+        char* mq = Q.dev("mask_q", md + 1); char* mr = Q.dev("mask_r", n);
+        Q.d2d(mask[l], rnd + 96, md + 1);
+        ZK_TRY(Q.rc);
+        ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, mask[l], md + 1, H.log, mq, mr));
+        Q.op(ZK_OP_SUB, mask[l], mr, mask[l], 1);                                // the sum over H becomes zero
+        Q.polys["mask_poly"] = Poly{mask[l], md + 1};
+        ZK_TRY(Q.rc);
+    }
+    if (!shared) ZK_TRY(start_early("mask_poly"));                               // (over shares it is a shared oracle: every lane's job stays in the batch)
     for (int l = 0; l < LANES; l++) {
         Prover& Q = PL[l];
         z_a[l] = Q.dev("z_a", n); z_b[l] = Q.dev("z_b", n);
@@ -547,13 +599,6 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
         Q.polys["w"] = Poly{wq[l], nwq};
         Q.polys["z_a"] = Q.blind(za, n, rnd + 32, "z_a_poly");
         Q.polys["z_b"] = Q.blind(zbb, n, rnd + 64, "z_b_poly");
-        mask[l] = Q.dev("mask", md + 1);
-        char* mq = Q.dev("mask_q", md + 1); char* mr = Q.dev("mask_r", n);
-        Q.d2d(mask[l], rnd + 96, md + 1);
-        ZK_TRY(Q.rc);
-        ZK_TRY(zk_poly_divide_by_vanishing_dev(ctx, mask[l], md + 1, H.log, mq, mr));
-        Q.op(ZK_OP_SUB, mask[l], mr, mask[l], 1);                                // the sum over H becomes zero
-        Q.polys["mask_poly"] = Poly{mask[l], md + 1};
         ZK_TRY(Q.rc);
     }
     laps.lap("polys");
@@ -586,6 +631,8 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
     }
     P.ntt_batch({t_ev, ra}, H, 1);
     for (int l = 0; l < LANES; l++) PL[l].polys["t"] = Poly{t_ev, n};
+    ZK_TRY(P.rc);
+    ZK_TRY(start_early("t"));                                                    // public: the product of the two witness vectors and h_1 are still to come
     const Poly r_alpha_poly{ra, n};
     const Dom MUL(std::max(std::max(md + 1, n + 2 * n + 1), n + n + 1));
     char* e_rp = P.padded(MUL, r_alpha_poly, "e_r"); char* e_tp = P.padded(MUL, P.polys["t"], "e_t");
@@ -654,6 +701,9 @@ int marlin_impl(zk_ctx* ctx, const zk_marlin_index* ix, const zk_bases* powers_g
       ZK_TRY(zk_marlin_round3_ab_evals_dev(ctx, ix->on_b, B.size, &al, &be, et, &v, a_ev, b_ev)); }
     P.ntt(f_ev, K, 1);
     const Poly f{f_ev, K.size};
+    for (int l = 0; l < LANES; l++) PL[l].polys["g_2"] = Poly{f_ev + 32, K.size - 1};
+    ZK_TRY(P.rc);
+    ZK_TRY(start_early("g_2"));                                                  // both of its commitments (degree bound |K| - 2), under the division that yields h_2
     char* f_on_b = P.fft(B, f, "f_on_b");                                       // a - b f on B itself (degree <= 4|K| - 4 < |B|)
     P.op(ZK_OP_MUL, b_ev, f_on_b, b_ev, B.size);
     P.op(ZK_OP_SUB, a_ev, b_ev, a_ev, B.size);

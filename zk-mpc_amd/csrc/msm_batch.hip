@@ -148,3 +148,68 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
     ZK_API_END
 }
 
+
+// ---- an MSM (or two over one scalar vector: a degree-bounded oracle's commitment and its shifted copy) started EARLY ----
+// Marlin commits a round's oracles together (lib.rs:171-247), but some of them exist long before the round's last polynomial does:
+// the mask polynomial of round 1 (prover.rs:381-399), t of round 2 (:454-462), g_2 of round 3 (:642-648) -- and none of them is
+// hiding, so no draw of the prover's rng depends on where their commitment is computed.  Their jobs are enqueued here, on the sort
+// and accumulate streams, as soon as the coefficients are on the device; the context stream goes on with the round's polynomial
+// arithmetic (launch-bound for small proofs: the device is otherwise idle under it); the round's batch (zk_msm_batch_dev) then
+// carries fewer jobs -- without its longest one in round 1 -- and zk_msm_early_finish collects the result.  Own scratch slots
+// (6, 7) and pinned result buffers: nothing the batch rotates over.
+struct ZkEarlyMsm {
+    ZkMsmJob jobs[2];
+    int count = 0;
+};
+int zk_msm_early_begin(zk_ctx* ctx, int count, const zk_bases* bases, const size_t* base_offsets, const void* scalars_dev, size_t len, ZkEarlyMsm** out) {
+    *out = nullptr;
+    if (count < 1 || count > 2 || !bases || !scalars_dev || !len) return ZK_ERR_ARG;
+    for (int k = 0; k < count; k++)
+        if (base_offsets[k] + len > bases->n) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_msm_early_begin: a job reads past its base table");
+    ZK_TRY(zk_prover_streams(ctx, 1));
+    hipStream_t s_acc = ctx->acc_stream, s_sort = ctx->aux[0];
+    hipEvent_t e0;
+    ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(e0, ctx->stream);          // the coefficients were produced on the context stream
+    if (e == hipSuccess) e = hipStreamWaitEvent(s_sort, e0, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s_acc, e0, 0);
+    (void)hipEventDestroy(e0);
+    ZK_HIP(ctx, e);
+    std::unique_ptr<ZkEarlyMsm> em(new ZkEarlyMsm());
+    em->count = count;
+    int rc = ZK_OK;
+    for (int k = 0; k < count && rc == ZK_OK; k++) {
+        ZkMsmJob& j = em->jobs[k];
+        j.pin_key = 40 + k;
+        rc = zk_msm_prepare(ctx, &j, bases, base_offsets[k], scalars_dev, len, 6 + k);
+        if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &j, s_sort, k ? &em->jobs[0] : nullptr);
+        if (rc == ZK_OK) rc = zk_msm_enqueue_accum(ctx, &j, s_acc);
+        // the reduce chain: a LARGE job's behind its accumulate kernel on the sort stream (the batch's sorts queue behind it; the
+        // accumulate stream stays free for the batch's kernels); a SMALL job's (latency chains: the batch will run as a group on the
+        // sort stream) on the accumulate stream, so that the two chains run side by side
+        const bool small = bases->pre && len * ((255 + bases->c_pre - 1) / bases->c_pre) <= ((size_t)1 << 23);
+        if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, &j, small ? s_acc : s_sort);
+    }
+    if (rc != ZK_OK) {                                       // whatever was enqueued reads the scratch: let it drain
+        (void)hipStreamSynchronize(s_sort);
+        (void)hipStreamSynchronize(s_acc);
+        return rc;
+    }
+    *out = em.release();
+    return ZK_OK;
+}
+// outs[k]: zk_g1_projective / zk_g2_projective of job k.  Always deletes the handle.
+int zk_msm_early_finish(zk_ctx* ctx, ZkEarlyMsm* em, void* const* outs) {
+    if (!em) return ZK_ERR_ARG;
+    std::unique_ptr<ZkEarlyMsm> own(em);
+    int rc = ZK_OK;
+    for (int k = 0; k < em->count; k++) {
+        const int r = outs ? zk_msm_finish(ctx, &em->jobs[k], outs[k]) : ZK_OK;
+        if (rc == ZK_OK) rc = r;
+    }
+    if (!outs || rc != ZK_OK) {                              // abandoned: its kernels may still read the scratch slots and the coefficient vector
+        (void)hipStreamSynchronize(ctx->aux[0]);
+        (void)hipStreamSynchronize(ctx->acc_stream);
+    }
+    return rc;
+}
