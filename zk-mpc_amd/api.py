@@ -155,6 +155,88 @@ class DevBuf:
             pass
 
 
+_SIZE_MAX = (1 << 64) - 1
+
+
+class _CMpcFieldLayout(C.Structure):
+    _fields_ = [("stride", C.c_size_t), ("off_tag", C.c_size_t), ("off_public", C.c_size_t), ("off_share", C.c_size_t), ("off_mac", C.c_size_t),
+                ("tag_public", C.c_uint8), ("tag_shared", C.c_uint8)]
+
+
+class _CAffineLayout(C.Structure):
+    _fields_ = [("stride", C.c_size_t), ("off_x", C.c_size_t), ("off_y", C.c_size_t), ("off_infinity", C.c_size_t)]
+
+
+class CMpcGroupLayout(C.Structure):
+    _fields_ = [("point", _CAffineLayout), ("off_tag", C.c_size_t), ("tag_public", C.c_uint8)]
+
+
+class MpcFieldLayout:
+    """zk_mpc_field_layout: MpcField<Fr, S> = enum { Public(Fr), Shared(S) } as rustc lays it out -- a discriminant byte and the
+    payload at 8-byte alignment; tag_last puts the discriminant behind the payload (and swaps its values): nothing may depend on it."""
+
+    def __init__(self, spdz: bool = False, tag_last: bool = False):
+        pay = 64 if spdz else 32
+        base = 0 if tag_last else 8
+        self.spdz, self.stride = spdz, pay + 8
+        self.off_tag = pay if tag_last else 0
+        self.off_public = self.off_share = base
+        self.off_mac = base + 32 if spdz else _SIZE_MAX
+        self.tag_public, self.tag_shared = (1, 0) if tag_last else (0, 1)
+        self.c = _CMpcFieldLayout(self.stride, self.off_tag, self.off_public, self.off_share, self.off_mac, self.tag_public, self.tag_shared)
+
+
+class MpcVec:
+    """A Vec<MpcField<Fr, S>> in host memory: raw bytes (n, stride) in the given layout (padding bytes deliberately non-zero)."""
+
+    def __init__(self, lay: MpcFieldLayout, n: int):
+        self.lay, self.n = lay, n
+        self.raw = np.full((n, lay.stride), 0xA5, dtype=np.uint8)
+
+    def set(self, shared, lane0, lane1=None):
+        """shared: (n,) bool; lane0: (n,4) uint64 -- the public value or the share; lane1: the MAC share (SPDZ)."""
+        L = self.lay
+        shared = np.asarray(shared, dtype=bool)
+        self.raw[:, L.off_tag] = np.where(shared, L.tag_shared, L.tag_public).astype(np.uint8)
+        b0 = np.ascontiguousarray(lane0, dtype=np.uint64).view(np.uint8).reshape(self.n, 32)
+        self.raw[:, L.off_public:L.off_public + 32] = b0                  # (Public and Shared payloads start at the same offset here)
+        if L.spdz:
+            b1 = np.ascontiguousarray(lane1 if lane1 is not None else lane0, dtype=np.uint64).view(np.uint8).reshape(self.n, 32)
+            self.raw[shared, L.off_mac:L.off_mac + 32] = b1[shared]
+        return self
+
+    def shared(self):
+        return self.raw[:, self.lay.off_tag] != self.lay.tag_public
+
+    def lane(self, k: int = 0):
+        off = self.lay.off_share if k == 0 else self.lay.off_mac
+        return np.ascontiguousarray(self.raw[:, off:off + 32]).view(np.uint64).reshape(self.n, 4)
+
+
+def mpc_group_layout(group: int, spdz: bool = False, tag_last: bool = False) -> CMpcGroupLayout:
+    """zk_mpc_group_layout of MpcG1Affine / MpcG2Affine: GroupAffine {x, y, infinity: bool} (2 fe + 8 bytes; a SPDZ share holds two)."""
+    fe = 48 if group == 1 else 96
+    aff = 2 * fe + 8
+    pay = 2 * aff if spdz else aff
+    gb = 0 if tag_last else 8
+    return CMpcGroupLayout(_CAffineLayout(pay + 8, gb, gb + fe, gb + 2 * fe), pay if tag_last else 0, 1 if tag_last else 0)
+
+
+def mpc_wrap_points(points: np.ndarray, lay: CMpcGroupLayout, shared_rows=()) -> np.ndarray:
+    """(n, 12 | 24) uint64 packed points -> (n, stride) bytes of Public(GroupAffine) wrappers; rows in shared_rows get the other tag."""
+    n, words = points.shape
+    fe = words * 4
+    raw = np.full((n, lay.point.stride), 0x5A, dtype=np.uint8)
+    b = np.ascontiguousarray(points, dtype=np.uint64).view(np.uint8).reshape(n, 2 * fe)
+    raw[:, lay.point.off_x:lay.point.off_x + fe] = b[:, :fe]
+    raw[:, lay.point.off_y:lay.point.off_y + fe] = b[:, fe:]
+    raw[:, lay.point.off_infinity] = (~b.any(axis=1)).astype(np.uint8)
+    raw[:, lay.off_tag] = lay.tag_public
+    for r in shared_rows:
+        raw[r, lay.off_tag] = lay.tag_public ^ 1
+    return raw
+
+
 class Context:
     """One MPC party / one GPU (zk_ctx)."""
 
@@ -260,6 +342,36 @@ class Context:
 
     def divide_by_vanishing_poly_on_coset_in_place_dev(self, buf, log_n: int):
         self._ck(self.lib.zk_fr_divide_by_vanishing_on_coset_dev(self.h, C.c_void_p(int(buf)), log_n))
+
+    # ---- the same dispatch points on MpcField / MpcG1Affine elements in the caller's enum layout (csrc/mpc_host.hip) ----
+    def mpc_fft_in_place(self, vec: "MpcVec", n: int, log_n: int, inverse: bool, coset: bool):
+        """EvaluationDomain::*fft_in_place(&mut Vec<MpcField>) (src/groth16.rs:278-303): n elements read, 2^log_n written in place."""
+        assert vec.raw.shape[0] >= (1 << log_n)
+        self._ck(self.lib.zk_mpc_fft_in_place(self.h, _ptr(vec.raw), n, C.byref(vec.lay.c), log_n, int(inverse), int(coset)))
+
+    def mpc_divide_by_vanishing_on_coset_in_place(self, vec: "MpcVec", log_n: int):
+        self._ck(self.lib.zk_mpc_divide_by_vanishing_on_coset_in_place(self.h, _ptr(vec.raw), C.byref(vec.lay.c), log_n))
+
+    def mpc_batch_product_in_place(self, selfs: "MpcVec", others: "MpcVec", n: int, net_vtable=None, triple=None) -> int:
+        """MpcField::batch_product_in_place (mpc-algebra/src/wire/field.rs:917-958).  triple: None (DummyFieldTripleSource) or a
+        list of 3 (additive) / 6 (SPDZ) (n,4) uint64 arrays.  Returns the payload bytes this party sent to opens."""
+        sent = C.c_uint64(0)
+        tp = None
+        if triple is not None:
+            triple = [np.ascontiguousarray(t, dtype=np.uint64) for t in triple]
+            tp = (C.c_void_p * len(triple))(*[t.ctypes.data for t in triple])
+        self._ck(self.lib.zk_mpc_batch_product_in_place(self.h, _ptr(selfs.raw), _ptr(others.raw), n, C.byref(selfs.lay.c), tp,
+                                                        C.byref(net_vtable) if net_vtable is not None else None, C.byref(sent)))
+        return int(sent.value)
+
+    def mpc_msm(self, group: int, bases_raw: np.ndarray, n_bases: int, base_layout, scalars: "MpcVec", n_scalars: int):
+        """MpcG1Affine / MpcG2Affine::multi_scalar_mul (wire/pairing.rs:714-777): (lane 0, lane 1, every scalar public?)."""
+        w = 18 if group == 1 else 36
+        out = np.zeros(2 * w, dtype=np.uint64)
+        pub = C.c_int(0)
+        fn = self.lib.zk_mpc_msm_g1 if group == 1 else self.lib.zk_mpc_msm_g2
+        self._ck(fn(self.h, _ptr(bases_raw), n_bases, C.byref(base_layout), _ptr(scalars.raw), n_scalars, C.byref(scalars.lay.c), _ptr(out), C.byref(pub)))
+        return out[:w].copy(), out[w:].copy(), bool(pub.value)
 
     # ---- AffineCurve::multi_scalar_mul ----
     def multi_scalar_mul_g1(self, bases: np.ndarray, scalars: np.ndarray) -> np.ndarray:
