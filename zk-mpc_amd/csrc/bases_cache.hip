@@ -44,6 +44,8 @@ struct CacheEntry {
     uint64_t fp;
     zk_bases* b;                  // device-form table (+ window multiples once published)
     uint32_t* raw;                // the packed form as it crossed PCIe: n * 96 | 192 bytes -- what a verified hit compares against
+    std::shared_ptr<std::vector<char>> host;   // ... and for a table of up to HOST_VERIFY_MAX bytes the same bytes in HOST memory: its hits are
+                                  // compared on host threads (no PCIe, no launch: the device path's fixed costs doubled a 0.4 ms MSM call)
     uint64_t last;
     uint32_t hits;
     bool pre_tried;
@@ -72,11 +74,13 @@ struct ZkBasesCache {
     uint32_t* flag_dev = nullptr;         // verification: set by k_words_differ
     uint32_t* flag_host = nullptr;        // page-locked
     const zk_bases* leased = nullptr;     // the table the call in progress runs on: never evicted under it
+    std::vector<char> fresh;              // host verification: the caller's table as it was packed for the comparison
 };
 
 constexpr size_t SAMPLE = 64;
 constexpr size_t MIN_CACHED = 256;        // smaller tables are cheaper to upload than to look up
 constexpr size_t MAX_ENTRIES = 64;
+constexpr size_t HOST_VERIFY_MAX = (size_t)8 << 20;   // packed bytes: a 2^16-point G1 / 2^15-point G2 table
 
 inline uint64_t mix(uint64_t h, uint64_t v) {
     h ^= v;
@@ -192,12 +196,17 @@ void builder_main(zk_ctx* ctx, ZkBasesCache* c) {
             // apart; a slice handed out between two of them would run under the second).  A caller that never leaves the library
             // still gets its tables -- one slice (~1 ms of kernels) per 50 ms of waiting -- and zk_bases_cache_sync (rush) takes
             // them at full speed.
+            const bool small_table = false;                  // (tables of up to 2^16 points never come here: advance_builds builds them inline)
             const auto t0 = std::chrono::steady_clock::now();
-            while (!ctx->activity->quiet_for(300000) && !c->rush.load() && !c->bcancel.load() &&
+            while (!small_table && !ctx->activity->quiet_for(300000) && !c->rush.load() && !c->bcancel.load() &&
                    std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50))
                 std::this_thread::sleep_for(std::chrono::microseconds(50));
-            hipError_t e = zk_bases_precompute_step(j, c->pre_stream, &more);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->pre_stream);
+            // a large table: one slice at a time, waited for (the next look at the context's activity comes after it); a small one: every
+            // slice enqueued back to back, one wait before the step that frees the build's scratch
+            hipError_t e = hipSuccess;
+            if (small_table && j->phase == 3) e = hipStreamSynchronize(c->pre_stream);
+            if (e == hipSuccess) e = zk_bases_precompute_step(j, c->pre_stream, &more);
+            if (e == hipSuccess && !small_table) e = hipStreamSynchronize(c->pre_stream);
             if (e != hipSuccess) { j->err = e; (void)hipGetLastError(); break; }
         }
         lk.lock();
@@ -217,6 +226,7 @@ ZkPrecompJob* builder_collect(ZkBasesCache* c, bool cancel) {
     }
     c->rush.store(false);
     c->bcancel.store(false);
+    std::lock_guard<std::mutex> lk(c->bm);                  // (the builder reads `building` in its wait predicate)
     ZkPrecompJob* j = c->building;
     c->building = nullptr;
     c->building_bytes = 0;
@@ -280,6 +290,15 @@ int advance_builds(zk_ctx* ctx, ZkBasesCache* c, bool wait) {
         if (table_bytes(xb) + need > c->budget) continue;    // can never fit: nothing is evicted for it
         make_room(ctx, c, need, xb, false);                  // (may erase other entries: indices are dead from here on)
         if (resident(c) + need > c->budget) continue;
+        if (n <= ((size_t)1 << 16)) {
+            // a small table: built here and now (1 - 4 ms, once per table: its whole build is shorter than the bookkeeping of handing it
+            // to the builder, and a proof over it has no gap of 0.3 ms for the builder to work in -- waiting for one, the builder
+            // starved and the MSMs of small circuits ran on plain tables: 2^10 0.36 -> 0.51 ms per G1 call, measured)
+            ZK_TRY(zk_bases_precompute(ctx, xb));
+            for (auto& y : c->e) if (y.b == xb) y.bytes = table_bytes(xb);
+            if (xb->pre) c->builds++;
+            continue;
+        }
         if (!c->pre_stream) ZK_HIP(ctx, zk_stream_create(&c->pre_stream, false));
         ZkPrecompJob* j = nullptr;
         ZK_TRY(zk_bases_precompute_begin(ctx, xb, c->budget - resident(c), &j));
@@ -314,31 +333,68 @@ int check_layout(zk_ctx* ctx, const ZkHostTable& t) {
     return ZK_OK;
 }
 
+// The caller's table packed into `dst` by up to eight helper tasks; with `old` also compared with it: *differs.  false: a wrapper
+// that is not Public.  ~25 ns per point and thread.
+bool pack_host(zk_ctx* ctx, const ZkHostTable& t, size_t n, char* dst, const char* old, bool* differs) {
+    const size_t PB = point_bytes(t.group);
+    const size_t T = std::max<size_t>(1, std::min<size_t>(8, n * PB / ((size_t)256 << 10)));
+    const size_t per = (n + T - 1) / T;
+    std::atomic<int> bad{0}, diff{0};
+    auto work = [&](size_t lo, size_t hi) {
+        bool ok = true, d = false;
+        for (size_t i = lo; i < hi; i++) {
+            ok = pack_point(t, i, dst + i * PB) && ok;
+            if (old) d = d || memcmp(dst + i * PB, old + i * PB, PB) != 0;
+        }
+        if (!ok) bad.store(1);
+        if (d) diff.store(1);
+    };
+    {
+        std::vector<ZkTask<void>> tasks;
+        for (size_t k = 1; k < T; k++) tasks.push_back(zk_async(ctx, [&, k] { work(std::min(n, k * per), std::min(n, (k + 1) * per)); }));
+        work(0, std::min(n, per));
+    }
+    if (differs) *differs = diff.load() != 0;
+    return bad.load() == 0;
+}
+
 // host table -> a packed copy on the device (through the ring, on the DMA stream) -> the device-form table; the context stream
 // continues behind the import.  What is queued on the context stream before this call (the sort of the MSM's scalars) runs
 // under the transfer.
-int upload_table(zk_ctx* ctx, const ZkHostTable& t, size_t n, uint32_t** raw_out, zk_bases** b_out) {
+int upload_table(zk_ctx* ctx, const ZkHostTable& t, size_t n, uint32_t** raw_out, zk_bases** b_out, std::shared_ptr<std::vector<char>>* host_out) {
     const size_t bytes = n * point_bytes(t.group);
     uint32_t* raw = nullptr;
     zk_bases* b = nullptr;
     if (hipMalloc((void**)&raw, bytes) != hipSuccess) { (void)hipGetLastError(); ZK_FAIL(ctx, ZK_ERR_NOMEM, "base table: hipMalloc of the packed copy failed"); }
     int rc = zk_bases_alloc_dev(ctx, t.group, n, &b);
-    std::atomic<int> bad{0};
-    hipStream_t xs = nullptr;
-    if (rc == ZK_OK) rc = zk_xfer_h2d_fn(ctx, raw, bytes, packer(t, &bad), false, nullptr);
-    if (rc == ZK_OK) rc = zk_xfer_stream(ctx, &xs);
-    if (rc == ZK_OK) rc = zk_bases_import_launch(ctx, b, raw, xs);
-    if (rc == ZK_OK) {
-        hipEvent_t ev = nullptr;                             // (an event per upload: tables are uploaded once)
-        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(ev, xs);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
-        if (ev) (void)hipEventDestroy(ev);
-        if (e != hipSuccess) { ctx->last_error = std::string("base table upload: ") + hipGetErrorString(e); rc = ZK_ERR_HIP; }
+    bool tags_ok = true;
+    if (rc == ZK_OK && host_out && bytes <= HOST_VERIFY_MAX) {
+        // a small table: packed on the host (kept: its hits are verified there), one plain transfer, the import on the context stream
+        auto hc = std::make_shared<std::vector<char>>(bytes);
+        tags_ok = pack_host(ctx, t, n, hc->data(), nullptr, nullptr);
+        rc = zk_xfer_h2d(ctx, raw, hc->data(), bytes);
+        if (rc == ZK_OK) rc = zk_bases_import_launch(ctx, b, raw, ctx->stream);
+        if (rc == ZK_OK) *host_out = hc;
+    } else if (rc == ZK_OK) {
+        std::atomic<int> bad{0};
+        hipStream_t xs = nullptr;
+        rc = zk_xfer_h2d_fn(ctx, raw, bytes, packer(t, &bad), false, nullptr);
+        if (rc == ZK_OK) rc = zk_xfer_stream(ctx, &xs);
+        if (rc == ZK_OK) rc = zk_bases_import_launch(ctx, b, raw, xs);
+        if (rc == ZK_OK) {
+            hipEvent_t ev = nullptr;                         // (an event per upload: tables are uploaded once)
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ev, xs);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
+            if (ev) (void)hipEventDestroy(ev);
+            if (e != hipSuccess) { ctx->last_error = std::string("base table upload: ") + hipGetErrorString(e); rc = ZK_ERR_HIP; }
+        }
+        if (rc != ZK_OK && xs) (void)hipStreamSynchronize(xs);
+        tags_ok = bad.load() == 0;
     }
-    if (rc == ZK_OK && bad.load()) { ctx->last_error = "multi_scalar_mul: a base is not Public (the reference asserts !b.is_shared(): wire/pairing.rs:716)"; rc = ZK_ERR_ARG; }
+    if (rc == ZK_OK && !tags_ok) { ctx->last_error = "multi_scalar_mul: a base is not Public (the reference asserts !b.is_shared(): wire/pairing.rs:716)"; rc = ZK_ERR_ARG; }
     if (rc != ZK_OK) {
-        if (xs) (void)hipStreamSynchronize(xs);
+        (void)hipStreamSynchronize(ctx->stream);
         free_table(ctx, nullptr, b, raw);
         return rc;
     }
@@ -385,7 +441,7 @@ int zk_bases_cache_get(zk_ctx* ctx, const ZkHostTable& t, size_t n, ZkBasesLease
     *out = ZkBasesLease();
     const size_t plain = n * point_bytes(t.group);
     if (c->budget == 0 || n < MIN_CACHED || 2 * plain > c->budget) {          // cache off, or not worth / not able to keep
-        ZK_TRY(upload_table(ctx, t, n, &out->raw_tmp, const_cast<zk_bases**>(&out->b)));
+        ZK_TRY(upload_table(ctx, t, n, &out->raw_tmp, const_cast<zk_bases**>(&out->b), nullptr));
         c->uncached++;
         c->uploaded += plain;
         out->temporary = true;
@@ -405,7 +461,9 @@ int zk_bases_cache_get(zk_ctx* ctx, const ZkHostTable& t, size_t n, ZkBasesLease
         out->entry = x.b;
         c->leased = x.b;
         out->verify = !c->trust;
-        if (out->verify) {                                   // everything the comparison allocates, before the MSM is in flight
+        if (out->verify && x.host) {
+            c->fresh.resize(plain);                          // (host comparison: the caller's table is packed into this)
+        } else if (out->verify) {                            // everything the comparison allocates, before the MSM is in flight
             ZK_TRY(zk_scratch(ctx, "bases_verify", plain, &out->stage));
             if (!c->flag_dev) {
                 ZK_HIP(ctx, hipMalloc((void**)&c->flag_dev, 16));
@@ -418,7 +476,7 @@ int zk_bases_cache_get(zk_ctx* ctx, const ZkHostTable& t, size_t n, ZkBasesLease
     c->misses++;
     make_room(ctx, c, 2 * plain, nullptr, true);
     CacheEntry x;
-    ZK_TRY(upload_table(ctx, t, n, &x.raw, &x.b));
+    ZK_TRY(upload_table(ctx, t, n, &x.raw, &x.b, &x.host));
     c->uploaded += plain;
     x.group = t.group; x.n = n; x.fp = fp; x.last = ++c->tick; x.hits = 0; x.pre_tried = false; x.bytes = table_bytes(x.b);
     c->e.push_back(x);
@@ -439,6 +497,15 @@ int zk_bases_cache_verify(zk_ctx* ctx, ZkBasesLease* l, const ZkHostTable& t, si
     CacheEntry* x = nullptr;
     for (auto& y : c->e) if (y.b == l->entry) x = &y;
     if (!x) ZK_FAIL(ctx, ZK_ERR_STATE, "bases cache: the leased entry is gone");
+    if (x->host) {                                           // a small table: packed and compared on host threads
+        bool differs = false;
+        if (!pack_host(ctx, t, n, c->fresh.data(), x->host->data(), &differs))
+            ZK_FAIL(ctx, ZK_ERR_ARG, "multi_scalar_mul: a base is not Public (the reference asserts !b.is_shared(): wire/pairing.rs:716)");
+        c->verified++;
+        c->verified_bytes += bytes;
+        *same = !differs;
+        return ZK_OK;
+    }
     hipStream_t xs;
     ZK_TRY(zk_xfer_stream(ctx, &xs));
     ZK_HIP(ctx, hipMemsetAsync(c->flag_dev, 0, 4, xs));
@@ -471,7 +538,12 @@ int zk_bases_cache_replace(zk_ctx* ctx, ZkBasesLease* l) {
     if (c->building && c->building->b == x->b) (void)zk_bases_precompute_finish(ctx, builder_collect(c, true), false);
     zk_bases* b = x->b;
     if (b->pre) { ZK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(b->pre); b->pre = nullptr; b->c_pre = b->W_pre = b->pre_stride = 0; b->pre_note.clear(); }
-    ZK_HIP(ctx, hipMemcpyAsync(x->raw, l->stage, x->n * point_bytes(x->group), hipMemcpyDeviceToDevice, ctx->stream));
+    if (x->host) {
+        x->host->swap(c->fresh);                             // (the caller's content, as packed for the comparison)
+        ZK_TRY(zk_xfer_h2d(ctx, x->raw, x->host->data(), x->host->size()));
+    } else {
+        ZK_HIP(ctx, hipMemcpyAsync(x->raw, l->stage, x->n * point_bytes(x->group), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     ZK_TRY(zk_bases_import_launch(ctx, b, x->raw, ctx->stream));
     x->hits = 0;
     x->pre_tried = false;

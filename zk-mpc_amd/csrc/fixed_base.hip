@@ -131,6 +131,22 @@ __global__ void __launch_bounds__(256) k_dbl_c(const uint32_t* in_aff, uint32_t*
     }
 }
 
+// out[j n + i] = 2^(c (j + 1)) * in[i], j < g: the next g levels of a table's window multiples from one level, one lane per (level,
+// point), c (j + 1) doublings.  For SMALL tables the level-by-level build is a chain of W latencies -- 20 levels x (20 dependent
+// doublings + a field inversion on a lone wave) = 14 ms for a 1 024-point table, whatever its size -- while g levels together are one
+// chain of c g doublings and ONE batched normalisation.  (g + 1) / 2 times the doublings, on a chip that is otherwise idle: tables of
+// up to 2^13 points take all levels at once (~2 ms; the reference's circuits), up to 2^16 four at a time, larger ones one (the work
+// is the bound there).
+template <class F>
+__global__ void __launch_bounds__(256) k_dbl_levels(const uint32_t* in_aff, uint32_t* out_xyzz, size_t n, uint32_t c, uint32_t g) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n * g; t += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t j = (uint32_t)(t / n);
+        XYZZ<F> p = xyzz_from_affine<F>(aff_load16<F>(in_aff, t - (size_t)j * n));
+        for (uint32_t k = 0; k < c * (j + 1); k++) p = xyzz_dbl<F>(p);
+        xyzz_store16<F>(out_xyzz, t, p);
+    }
+}
+
 // packed points (2 * WORDS words each) -> one point per `stride` words; the padding words are never read
 template <class F>
 __global__ void __launch_bounds__(256) k_repack(const uint32_t* in, uint32_t* out, size_t n, uint32_t stride) {
@@ -173,9 +189,11 @@ __global__ void __launch_bounds__(256) k_repack_limbs(const uint32_t* in, uint32
 template <class F>
 int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W, int layout) {
     const size_t n = b->n, PW = 2 * F::WORDS;
+    // levels per launch pair (k_dbl_levels); a forced packed layout keeps the level-by-level build: tests compare the two
+    const uint32_t G = layout == 1 || W < 2 ? 1u : (n <= 8192 ? W - 1 : (n <= 65536 ? 4u : 1u));
     uint32_t *xy, *scr;
-    ZK_TRY(zk_scratch(ctx, "fb_xyzz", n * 4 * F::WORDS * 4, (void**)&xy));
-    ZK_TRY(zk_scratch(ctx, "fb_scr", n * F::WORDS * 4, (void**)&scr));
+    ZK_TRY(zk_scratch(ctx, "fb_xyzz", (size_t)G * n * 4 * F::WORDS * 4, (void**)&xy));
+    ZK_TRY(zk_scratch(ctx, "fb_scr", (size_t)G * n * F::WORDS * 4, (void**)&scr));
     size_t mem_free = 0, mem_total = 0;
     const size_t packed_bytes = (size_t)W * n * PW * 4;
     auto skip = [&](const char* why) {
@@ -186,8 +204,11 @@ int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W, int layout) {
         ctx->last_error = msg;
         return layout ? ZK_ERR_NOMEM : ZK_OK;
     };
-    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return skip("hipMemGetInfo failed");
-    const size_t budget = mem_free / 3;
+    // (a small table just allocates: hipMemGetInfo is ~10 ms with a few GB resident -- most of what the window multiples of a
+    // 2^10-point table used to cost)
+    const bool ask = packed_bytes > ((size_t)64 << 20);
+    if (ask && hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return skip("hipMemGetInfo failed");
+    const size_t budget = ask ? mem_free / 3 : (size_t)1 << 30;
     if (packed_bytes > budget) return skip("more than a third of the free device memory");
     if (hipMalloc((void**)&b->pre, packed_bytes) != hipSuccess) {
         b->pre = nullptr;
@@ -202,7 +223,14 @@ int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W, int layout) {
     };
     hipError_t e = hipMemcpyAsync(b->pre, b->dev, n * PW * 4, hipMemcpyDeviceToDevice, ctx->stream);
     const size_t chunks = (n + NORM_CHUNK - 1) / NORM_CHUNK;
-    for (uint32_t w = 1; w < W && e == hipSuccess; w++) {
+    for (uint32_t w0 = 0; G > 1 && w0 + 1 < W && e == hipSuccess; w0 += G) {     // levels w0 + 1 .. w0 + g from level w0
+        const uint32_t g = std::min(G, W - 1 - w0);
+        const size_t total = (size_t)g * n, tchunks = (total + NORM_CHUNK - 1) / NORM_CHUNK;
+        hipLaunchKernelGGL(k_dbl_levels<F>, zk_grid(total, 256), 256, 0, ctx->stream, b->pre + (size_t)w0 * n * PW, xy, n, c, g);
+        hipLaunchKernelGGL(k_batch_affine<F>, (unsigned)((tchunks + 63) / 64), 64, 0, ctx->stream, xy, b->pre + (size_t)(w0 + 1) * n * PW, scr, total);
+        e = hipGetLastError();
+    }
+    for (uint32_t w = 1; w < W && e == hipSuccess && G == 1; w++) {
         hipLaunchKernelGGL(k_dbl_c<F>, zk_grid(n, 256), 256, 0, ctx->stream, b->pre + (size_t)(w - 1) * n * PW, xy, n, c);
         hipLaunchKernelGGL(k_batch_affine<F>, (unsigned)((chunks + 63) / 64), 64, 0, ctx->stream, xy, b->pre + (size_t)w * n * PW, scr, n);
         e = hipGetLastError();
@@ -381,9 +409,11 @@ hipError_t precompute_step_t(ZkPrecompJob* j, hipStream_t st, bool* more) {
         // the allocations (several GB: ~10 ms of page-table work) -- here, in the builder's time, not in the call that earned the
         // table its multiples; a failure leaves the table plain
         const size_t packed_bytes = (size_t)j->W * n * PW * 4, xy_bytes = n * 4 * F::WORDS * 4, scr_bytes = n * F::WORDS * 4;
-        size_t mem_free = 0, mem_total = 0;
-        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
-        j->budget = std::min(j->budget, mem_free / 3);     // never more than a third of what is free (see precompute_t)
+        if (packed_bytes + xy_bytes + scr_bytes > ((size_t)256 << 20)) {     // (a small table just allocates: hipMemGetInfo is ~10 ms)
+            size_t mem_free = 0, mem_total = 0;
+            if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+            j->budget = std::min(j->budget, mem_free / 3);     // never more than a third of what is free (see precompute_t)
+        }
         if (packed_bytes + xy_bytes + scr_bytes > j->budget) return hipErrorOutOfMemory;
         if (hipMalloc((void**)&j->packed, packed_bytes) != hipSuccess || hipMalloc((void**)&j->xy, xy_bytes) != hipSuccess ||
             hipMalloc((void**)&j->scr, scr_bytes) != hipSuccess) {
