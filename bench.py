@@ -441,14 +441,14 @@ def marlin_dense_leg(ctx, log_h: int):
     return rec
 
 
-def trait_path_leg(log_d: int, resident_ms: float, proofs: int = 7):
+def trait_path_leg(log_d: int, resident_ms: float, proofs: int = 10):
     """The reference-shaped boundary, composed and timed (outside the timed region): examples/host_trait_groth16.cpp is
     src/groth16.rs:68-183,240-306 over the trait-shaped entry points only -- zk_fr_fft_in_place x7, zk_fr_batch_product_in_place,
     zk_fr_divide_by_vanishing_on_coset_in_place, zk_msm_g1 x4, zk_msm_g2 x1, host group helpers -- with the proving key in HOST
     vectors and freshly allocated host Vecs per proof.  A child process with its own context (this process keeps its key resident:
     the two do not share anything but the device).  `lib` = time inside library calls; `total` adds the caller's own single-thread
     scalar loops (evaluate_constraint, ab -= c), as the reference runs them.  First proof: every base table crosses PCIe once;
-    second: the cache builds the window multiples; from the third on: steady state.  The proofs' bytes are checked against the
+    then the window multiples are built by a builder thread in the caller's gaps (no call pays for them); the last three: steady state.  The proofs' bytes are checked against the
     prediction by tests/test_gpu_trait_path.py (2^10, 2^16, 2^20); here they must agree with each other."""
     import hashlib
     import subprocess
@@ -465,7 +465,9 @@ def trait_path_leg(log_d: int, resident_ms: float, proofs: int = 7):
                 continue
             lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
             pr, last = lines[:-1], lines[-1]
-            steady = pr[2:] if len(pr) > 3 else pr[-1:]
+            # steady state = the last three calls: the window multiples of large tables are built in the caller's gaps over the
+            # first handful of proofs (lib_ms_every_call shows the approach)
+            steady = pr[-3:] if len(pr) > 5 else pr[-1:]
             med = lambda k: round(float(np.median([p["ms"][k] for p in steady])), 3)
             rec = {"first_call_ms": pr[0]["ms"], "second_call_ms": {k: pr[1]["ms"][k] for k in ("total", "lib")} if len(pr) > 1 else None,
                    "third_call_ms": {k: pr[2]["ms"][k] for k in ("total", "lib")} if len(pr) > 2 else None,
