@@ -135,13 +135,17 @@ __global__ void __launch_bounds__(256) k_dbl_c(const uint32_t* in_aff, uint32_t*
 // point), c (j + 1) doublings.  For SMALL tables the level-by-level build is a chain of W latencies -- 20 levels x (20 dependent
 // doublings + a field inversion on a lone wave) = 14 ms for a 1 024-point table, whatever its size -- while g levels together are one
 // chain of c g doublings and ONE batched normalisation.  (g + 1) / 2 times the doublings, on a chip that is otherwise idle: tables of
-// up to 2^13 points take all levels at once (~2 ms; the reference's circuits), up to 2^16 four at a time, larger ones one (the work
-// is the bound there).
-template <class F>
-__global__ void __launch_bounds__(256) k_dbl_levels(const uint32_t* in_aff, uint32_t* out_xyzz, size_t n, uint32_t c, uint32_t g) {
+// up to 2^13 points take all levels at once (~2 ms; the reference's circuits), up to 2^16 two at a time with the groups chained in
+// XYZZ form, larger ones one level at a time (the work is the bound there).
+// FROM_XYZZ: the level the group starts from is itself un-normalised (the previous group's last output): the groups of a table
+// chain without a normalisation in between, and ONE k_batch_affine over all levels ends the build -- one inversion latency per table
+// instead of one per group.
+template <class F, bool FROM_XYZZ>
+__global__ void __launch_bounds__(256) k_dbl_levels(const uint32_t* in, uint32_t* out_xyzz, size_t n, uint32_t c, uint32_t g) {
     for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n * g; t += (size_t)gridDim.x * blockDim.x) {
         const uint32_t j = (uint32_t)(t / n);
-        XYZZ<F> p = xyzz_from_affine<F>(aff_load16<F>(in_aff, t - (size_t)j * n));
+        const size_t i = t - (size_t)j * n;
+        XYZZ<F> p = FROM_XYZZ ? xyzz_load16<F>(in, i) : xyzz_from_affine<F>(aff_load16<F>(in, i));
         for (uint32_t k = 0; k < c * (j + 1); k++) p = xyzz_dbl<F>(p);
         xyzz_store16<F>(out_xyzz, t, p);
     }
@@ -190,10 +194,11 @@ template <class F>
 int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W, int layout) {
     const size_t n = b->n, PW = 2 * F::WORDS;
     // levels per launch pair (k_dbl_levels); a forced packed layout keeps the level-by-level build: tests compare the two
-    const uint32_t G = layout == 1 || W < 2 ? 1u : (n <= 8192 ? W - 1 : (n <= 65536 ? 4u : 1u));
+    const uint32_t G = layout == 1 || W < 2 ? 1u : (n <= 4096 ? W - 1 : (n <= 16384 ? 4u : (n <= 65536 ? 2u : 1u)));
+    const size_t lv = G > 1 ? W - 1 : 1;                       // levels the scratch holds at once (G > 1: every level above the table itself)
     uint32_t *xy, *scr;
-    ZK_TRY(zk_scratch(ctx, "fb_xyzz", (size_t)G * n * 4 * F::WORDS * 4, (void**)&xy));
-    ZK_TRY(zk_scratch(ctx, "fb_scr", (size_t)G * n * F::WORDS * 4, (void**)&scr));
+    ZK_TRY(zk_scratch(ctx, "fb_xyzz", lv * n * 4 * F::WORDS * 4, (void**)&xy));
+    ZK_TRY(zk_scratch(ctx, "fb_scr", lv * n * F::WORDS * 4, (void**)&scr));
     size_t mem_free = 0, mem_total = 0;
     const size_t packed_bytes = (size_t)W * n * PW * 4;
     auto skip = [&](const char* why) {
@@ -223,11 +228,17 @@ int precompute_t(zk_ctx* ctx, zk_bases* b, uint32_t c, uint32_t W, int layout) {
     };
     hipError_t e = hipMemcpyAsync(b->pre, b->dev, n * PW * 4, hipMemcpyDeviceToDevice, ctx->stream);
     const size_t chunks = (n + NORM_CHUNK - 1) / NORM_CHUNK;
-    for (uint32_t w0 = 0; G > 1 && w0 + 1 < W && e == hipSuccess; w0 += G) {     // levels w0 + 1 .. w0 + g from level w0
+    for (uint32_t w0 = 0; G > 1 && w0 + 1 < W && e == hipSuccess; w0 += G) {     // levels w0 + 1 .. w0 + g from level w0, un-normalised: xy[(w - 1) n + i]
         const uint32_t g = std::min(G, W - 1 - w0);
-        const size_t total = (size_t)g * n, tchunks = (total + NORM_CHUNK - 1) / NORM_CHUNK;
-        hipLaunchKernelGGL(k_dbl_levels<F>, zk_grid(total, 256), 256, 0, ctx->stream, b->pre + (size_t)w0 * n * PW, xy, n, c, g);
-        hipLaunchKernelGGL(k_batch_affine<F>, (unsigned)((tchunks + 63) / 64), 64, 0, ctx->stream, xy, b->pre + (size_t)(w0 + 1) * n * PW, scr, total);
+        const size_t total = (size_t)g * n;
+        uint32_t* out = xy + (size_t)w0 * n * 4 * F::WORDS;
+        if (w0 == 0) hipLaunchKernelGGL((k_dbl_levels<F, false>), zk_grid(total, 256), 256, 0, ctx->stream, (const uint32_t*)b->dev, out, n, c, g);
+        else hipLaunchKernelGGL((k_dbl_levels<F, true>), zk_grid(total, 256), 256, 0, ctx->stream, (const uint32_t*)(xy + (size_t)(w0 - 1) * n * 4 * F::WORDS), out, n, c, g);
+        e = hipGetLastError();
+    }
+    if (G > 1 && W > 1 && e == hipSuccess) {                  // ... and one normalisation for all of them
+        const size_t total = (size_t)(W - 1) * n, tchunks = (total + NORM_CHUNK - 1) / NORM_CHUNK;
+        hipLaunchKernelGGL(k_batch_affine<F>, (unsigned)((tchunks + 63) / 64), 64, 0, ctx->stream, xy, b->pre + n * PW, scr, total);
         e = hipGetLastError();
     }
     for (uint32_t w = 1; w < W && e == hipSuccess && G == 1; w++) {
