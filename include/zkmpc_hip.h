@@ -570,7 +570,10 @@ int zk_mpc_batch_product_in_place(zk_ctx* ctx, void* selfs_host, const void* oth
  * Some scalar Shared: GroupShare::multi_scale_pub_group (share/additive.rs:517-520; SPDZ share/spdz.rs:482-488) -- out_lanes[0] =
  * the MSM over this party's share values, out_lanes[1] = the one over its MAC values (SPDZ; additive: a copy of lane 0), Public
  * scalars read as from_public (wire/field.rs:75-100); *scalars_public = 0.  Every scalar Public: out_lanes[0] = the plain MSM (the
- * wire wraps it with from_public), *scalars_public = 1.  The bases go through the table cache above, keyed by content. */
+ * wire wraps it with from_public), *scalars_public = 1.  The bases go through the table cache above, keyed by content.
+ * (share/spdz.rs:484-485 feeds the SHARE values to both MSMs of a SpdzGroupShare; every state the reference can reach has mac = share
+ * on each party -- from_add_shared with the stand-in key 1 -- so the two readings give the same lanes there, and either one is a
+ * valid MAC of the sum anywhere: the MAC lane here is the MSM over the MAC values, as in zk_groth16_prove_shared_spdz.) */
 int zk_mpc_msm_g1(zk_ctx* ctx, const void* bases_host, size_t n_bases, const zk_mpc_group_layout* base_layout, const void* scalars_host,
                   size_t n_scalars, const zk_mpc_field_layout* scalar_layout, zk_g1_projective out_lanes[2], int* scalars_public);
 int zk_mpc_msm_g2(zk_ctx* ctx, const void* bases_host, size_t n_bases, const zk_mpc_group_layout* base_layout, const void* scalars_host,

@@ -196,17 +196,14 @@ void builder_main(zk_ctx* ctx, ZkBasesCache* c) {
             // apart; a slice handed out between two of them would run under the second).  A caller that never leaves the library
             // still gets its tables -- one slice (~1 ms of kernels) per 50 ms of waiting -- and zk_bases_cache_sync (rush) takes
             // them at full speed.
-            const bool small_table = false;                  // (tables of up to 2^16 points never come here: advance_builds builds them inline)
+            // (Tables of up to 2^16 points never come here: advance_builds builds them in the call that earns them.)
             const auto t0 = std::chrono::steady_clock::now();
-            while (!small_table && !ctx->activity->quiet_for(300000) && !c->rush.load() && !c->bcancel.load() &&
+            while (!ctx->activity->quiet_for(300000) && !c->rush.load() && !c->bcancel.load() &&
                    std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50))
                 std::this_thread::sleep_for(std::chrono::microseconds(50));
-            // a large table: one slice at a time, waited for (the next look at the context's activity comes after it); a small one: every
-            // slice enqueued back to back, one wait before the step that frees the build's scratch
-            hipError_t e = hipSuccess;
-            if (small_table && j->phase == 3) e = hipStreamSynchronize(c->pre_stream);
-            if (e == hipSuccess) e = zk_bases_precompute_step(j, c->pre_stream, &more);
-            if (e == hipSuccess && !small_table) e = hipStreamSynchronize(c->pre_stream);
+            // one slice at a time, waited for: the next look at the context's activity comes after it
+            hipError_t e = zk_bases_precompute_step(j, c->pre_stream, &more);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->pre_stream);
             if (e != hipSuccess) { j->err = e; (void)hipGetLastError(); break; }
         }
         lk.lock();
