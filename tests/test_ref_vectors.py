@@ -290,3 +290,25 @@ def test_marlin_pc_commit_rng_draw_order_oracle(kats):
             want += b"\x00"
         assert want.hex() == p["commitment"], p["label"]
     assert rng.next_u64() == m["rng_next_u64_after"]
+
+
+def test_mpc_element_layouts_are_expressible_and_match_the_composer(kats):
+    """(round 6) how the reference's toolchain lays MpcField / MpcG1Affine out, dumped by pattern search (dump_kats.rs section 14): every
+    field the zk_mpc_* layout descriptors need was found, and the layout the composer and the tests call `tagfirst` IS rustc's."""
+    if "mpc_layouts" not in kats:
+        pytest.skip("vectors from before round 6: no mpc_layouts section")
+    import zk_mpc_amd.api as A
+    by = {e["type"]: e for e in kats["mpc_layouts"]}
+    for name, spdz in (("MpcField<Fr, AdditiveFieldShare<Fr>>", False), ("MpcField<Fr, SpdzFieldShare<Fr>>", True)):
+        e = by[name]
+        assert min(e["off_tag"], e["off_public"], e["off_share"]) >= 0 and (e["off_mac"] >= 0) == spdz, e
+        ours = A.MpcFieldLayout(spdz, tag_last=e["off_tag"] > e["off_public"])
+        assert (e["size"], e["off_public"], e["off_share"]) == (ours.stride, ours.off_public, ours.off_share), (e, vars(ours))
+        if spdz:
+            assert e["off_mac"] == ours.off_mac
+        assert e["tag_public"] != e["tag_shared"]
+    for name, group in (("MpcG1Affine<Bls12_377, AdditivePairingShare>", 1), ("MpcG2Affine<Bls12_377, AdditivePairingShare>", 2)):
+        e = by[name]
+        assert min(e["off_x"], e["off_y"], e["off_infinity"]) >= 0, e
+        ours = A.mpc_group_layout(group, False, tag_last=e["off_x"] == 0)
+        assert (e["size"], e["off_x"], e["off_y"], e["off_infinity"]) == (ours.point.stride, ours.point.off_x, ours.point.off_y, ours.point.off_infinity), e

@@ -242,6 +242,62 @@ fn main() {
                  items.join(","), next_after, ck.max_degree, pts(&ck.powers), pts(ck.shifted_powers.as_ref().unwrap()),
                  pts(&ck.powers_of_gamma_g)).unwrap();
     }
+    // (14) how rustc lays the collaborative element types out (round 6): the zk_mpc_* entry points read Vec<MpcField<Fr, S>> and
+    //      &[MpcG1Affine] IN PLACE through layout descriptors (include/zkmpc_hip.h: zk_mpc_field_layout, zk_mpc_group_layout); the
+    //      binding takes them off values at run time (bindings/overrides.rs section 5), this dump pins what they are for the
+    //      reference's toolchain so that the composer's and the tests' enum layouts (examples/host_trait_collab_groth16.cpp,
+    //      zk-mpc_amd/api.py::MpcFieldLayout) can be held to it.  Offsets are found by pattern: a payload whose words are
+    //      distinctive is searched for in the value's bytes; the discriminant is the byte outside every payload in which
+    //      Public(0) and Shared(0) differ.  mpc-algebra/src/wire/field.rs:37-40, share/additive.rs:34-36, share/spdz.rs:50-53,
+    //      wire/pairing.rs:41-43, wire/group.rs (MpcGroup).
+    {
+        use mpc_algebra::{AdditiveFieldShare, MpcField, Reveal, SpdzFieldShare};
+        fn bytes_of<T>(v: &T) -> Vec<u8> { unsafe { std::slice::from_raw_parts(v as *const T as *const u8, std::mem::size_of::<T>()).to_vec() } }
+        fn find(hay: &[u8], needle: &[u8]) -> i64 { hay.windows(needle.len()).position(|w| w == needle).map(|p| p as i64).unwrap_or(-1) }
+        let x = Fr::rand(rng);
+        let xb = bytes_of(&x);
+        let mut items = Vec::new();
+        macro_rules! field_layout {
+            ($name:expr, $S:ty) => {{
+                let p = MpcField::<Fr, $S>::Public(x);
+                let s = MpcField::<Fr, $S>::Shared(<$S as Reveal>::from_add_shared(x));      // additive: val = x; SPDZ: sh = x, mac = x * 1
+                let (p0, s0) = (MpcField::<Fr, $S>::Public(Fr::from(0u64)), MpcField::<Fr, $S>::Shared(<$S as Reveal>::from_add_shared(Fr::from(0u64))));
+                let (bp, bs, b0, b1) = (bytes_of(&p), bytes_of(&s), bytes_of(&p0), bytes_of(&s0));
+                let off_public = find(&bp, &xb);
+                let off_share = find(&bs, &xb);
+                let off_mac = if bs.len() >= 64 + 8 { let o = off_share as usize + 32; find(&bs[o..], &xb).max(-1) + if find(&bs[o..], &xb) >= 0 { o as i64 } else { 0 } } else { -1 };
+                let tag = (0..b0.len()).find(|&o| b0[o] != b1[o]).map(|o| o as i64).unwrap_or(-1);   // payloads are zero in both: the first differing byte is the discriminant
+                items.push(format!("{{\"type\": \"{}\", \"size\": {}, \"off_tag\": {}, \"tag_public\": {}, \"tag_shared\": {}, \"off_public\": {}, \"off_share\": {}, \"off_mac\": {}}}",
+                                   $name, bp.len(), tag, if tag >= 0 { b0[tag as usize] as i64 } else { -1 }, if tag >= 0 { b1[tag as usize] as i64 } else { -1 },
+                                   off_public, off_share, off_mac));
+            }};
+        }
+        field_layout!("MpcField<Fr, AdditiveFieldShare<Fr>>", AdditiveFieldShare<Fr>);
+        field_layout!("MpcField<Fr, SpdzFieldShare<Fr>>", SpdzFieldShare<Fr>);
+        // the affine wrappers of the additive pairing share: a Public generator, x / y found by pattern, the infinity flag by flipping it
+        {
+            use mpc_algebra::{AdditivePairingShare, MpcG1Affine, MpcG2Affine, MpcGroup};
+            type PS = AdditivePairingShare<Bls12_377>;
+            let g1 = G1Affine::prime_subgroup_generator();
+            let w1 = MpcG1Affine::<Bls12_377, PS> { val: MpcGroup::Public(g1) };
+            let mut inf1 = g1; inf1.infinity = true;
+            let wi = MpcG1Affine::<Bls12_377, PS> { val: MpcGroup::Public(inf1) };
+            let (b, bi) = (bytes_of(&w1), bytes_of(&wi));
+            let off_inf = (0..b.len()).find(|&o| b[o] != bi[o]).map(|o| o as i64).unwrap_or(-1);
+            items.push(format!("{{\"type\": \"MpcG1Affine<Bls12_377, AdditivePairingShare>\", \"size\": {}, \"off_x\": {}, \"off_y\": {}, \"off_infinity\": {}, \"public_first_bytes\": \"{}\"}}",
+                               b.len(), find(&b, &bytes_of(&g1.x)), find(&b, &bytes_of(&g1.y)), off_inf, hex::encode(&b[..8])));
+            let g2 = G2Affine::prime_subgroup_generator();
+            let w2 = MpcG2Affine::<Bls12_377, PS> { val: MpcGroup::Public(g2) };
+            let mut inf2 = g2; inf2.infinity = true;
+            let wi2 = MpcG2Affine::<Bls12_377, PS> { val: MpcGroup::Public(inf2) };
+            let (b, bi) = (bytes_of(&w2), bytes_of(&wi2));
+            let off_inf = (0..b.len()).find(|&o| b[o] != bi[o]).map(|o| o as i64).unwrap_or(-1);
+            items.push(format!("{{\"type\": \"MpcG2Affine<Bls12_377, AdditivePairingShare>\", \"size\": {}, \"off_x\": {}, \"off_y\": {}, \"off_infinity\": {}, \"public_first_bytes\": \"{}\"}}",
+                               b.len(), find(&b, &bytes_of(&g2.x)), find(&b, &bytes_of(&g2.y)), off_inf, hex::encode(&b[..8])));
+        }
+        j.push_str(",\n");
+        writeln!(j, "\"mpc_layouts\": [{}]", items.join(",")).unwrap();
+    }
     j.push_str("}\n");
     std::fs::write(&out_path, j).unwrap();
     println!("wrote {}", out_path);

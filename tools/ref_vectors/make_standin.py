@@ -116,6 +116,14 @@ def main():
     out["marlin_pc_commit"] = dict(polys=items, rng_next_u64_after=crng.next_u64(), max_degree=16,
                                    powers=[u1(x).hex() for x in pp9.powers_of_g], shifted_powers=[u1(x).hex() for x in pp9.powers_of_g[8:]],
                                    powers_of_gamma_g=[u1(x).hex() for x in pp9.powers_of_gamma_g[:3]])
+    # (14) the layouts rustc is EXPECTED to give the collaborative element types (a discriminant byte first, the payload at 8-byte
+    # alignment): what dump_kats.rs finds by pattern search on the real types -- a stand-in pins nothing about the reference
+    out["mpc_layouts"] = [
+        dict(type="MpcField<Fr, AdditiveFieldShare<Fr>>", size=40, off_tag=0, tag_public=0, tag_shared=1, off_public=8, off_share=8, off_mac=-1),
+        dict(type="MpcField<Fr, SpdzFieldShare<Fr>>", size=72, off_tag=0, tag_public=0, tag_shared=1, off_public=8, off_share=8, off_mac=40),
+        dict(type="MpcG1Affine<Bls12_377, AdditivePairingShare>", size=112, off_x=8, off_y=56, off_infinity=104, public_first_bytes="00" * 8),
+        dict(type="MpcG2Affine<Bls12_377, AdditivePairingShare>", size=208, off_x=8, off_y=104, off_infinity=200, public_first_bytes="00" * 8),
+    ]
     json.dump(out, open(sys.argv[1], "w"))
 
 
