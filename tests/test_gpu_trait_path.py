@@ -292,3 +292,54 @@ def test_strided_tables_with_infinity_flags(ctx):
         assert fn(ctx.h, _p(raw), n, bad, _p(scal), n, _p(out)) != 0
         tab.free(); dk.free()
     ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+
+
+def test_cache_fuzz_against_the_discrete_log_identity(ctx):
+    """A randomised walk over what a caller can do to the table cache -- six G1 / G2 tables of 300 .. 5 000 points presented packed,
+    in the {x, y, infinity} layout and inside MpcGroup wrappers (both discriminant positions), through their own buffers and through
+    copies, rewritten IN PLACE at random points (sampled or not) between calls, under a budget that forces evictions while window
+    multiples are being built -- every sum against sum s_i k_i * G.  Whatever the cache decides (hit, verified hit, replacement,
+    eviction, upload for one call), no call may return the sum over a stale table."""
+    import zk_mpc_amd.api as A
+    rng = O.Prng(20261003)
+    rs = np.random.RandomState(7)
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    ctx._ck(ctx.lib.zk_bases_cache_trust(ctx.h, 0))
+    tables = []
+    for group, n in ((1, 300), (1, 1000), (1, 1000), (1, 5000), (2, 300), (2, 700)):
+        ks = [rng.fr() for _ in range(n)]
+        dk = ctx.upload(cv.fr_to_mont(ks))
+        tab = ctx.fixed_base(dk.ptr, n, group, cv.fr_to_mont([1])[0])
+        pts = np.ascontiguousarray(tab.download())
+        tab.free(); dk.free()
+        tables.append({"group": group, "n": n, "ks": ks, "pts": pts})
+    flay = A.MpcFieldLayout(False, False)
+    # room for about three of the six tables with their multiples: evictions and skipped builds on the way
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 12 << 20, 1))
+    for step in range(70):
+        t = tables[rs.randint(len(tables))]
+        group, n, pts, ks = t["group"], t["n"], t["pts"], t["ks"]
+        if rs.rand() < 0.35:                                       # rewrite a point in place: point j becomes a copy of point i
+            i, j = rs.randint(n), rs.randint(n)
+            pts[j] = pts[i]
+            ks[j] = ks[i]
+        m = n if rs.rand() < 0.7 else rs.randint(n // 2, n)
+        sc = [rng.fr() if rs.rand() < 0.9 else 0 for _ in range(m)]
+        want = (O.g1_mul(O.G1_GEN, sum(s * k for s, k in zip(sc, ks)) % O.R_MOD) if group == 1
+                else O.g2_mul(O.G2_GEN, sum(s * k for s, k in zip(sc, ks)) % O.R_MOD))
+        to_aff = cv.g1_projective_to_affine if group == 1 else cv.g2_projective_to_affine
+        src = pts if rs.rand() < 0.6 else pts.copy()               # its own buffer, or the same content elsewhere
+        form = rs.randint(3)
+        scal = cv.fr_to_mont(sc)
+        if form == 0:                                              # packed
+            got = (ctx.multi_scalar_mul_g1 if group == 1 else ctx.multi_scalar_mul_g2)(src, scal)
+        else:                                                      # MpcGroup wrappers (Public), discriminant first / last; scalars as Public MpcField
+            glay = A.mpc_group_layout(group, False, tag_last=(form == 2))
+            sv = A.MpcVec(flay, m).set([False] * m, scal)
+            got, _, all_pub = ctx.mpc_msm(group, A.mpc_wrap_points(src, glay), n, glay, sv, m)
+            assert all_pub
+        assert to_aff(got) == want, "step %d: table of %d G%d points, form %d" % (step, n, group, form)
+    st = _stats(ctx)
+    assert st["hits"] > 10 and st["replaced"] > 3 and st["evictions"] + st["misses"] > 6, st
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 64 << 30, 1))
