@@ -462,6 +462,7 @@ int main(int argc, char** argv) {
             auto CK = [&](int rc, const char* what) { if (rc) { fprintf(stderr, "party %d: %s -> %d: %s\n", p, what, rc, zk_last_error(ctx)); exit(1); } };
 #define CKX(expr) CK((expr), #expr)
             if (trust) CKX(zk_bases_cache_trust(ctx, 1));
+            if (P > 1) CKX(zk_msm_speculate(ctx, 0));        // P contexts on ONE device here: the MSMs a context starts ahead would only take the chip from the others
             Party me{&net, p, ctx};
             Env e;
             e.fl = L.f; e.lanes = lanes; e.leader = p == 0; e.me = &me;

@@ -343,3 +343,92 @@ def test_cache_fuzz_against_the_discrete_log_identity(ctx):
     assert st["hits"] > 10 and st["replaced"] > 3 and st["evictions"] + st["misses"] > 6, st
     ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
     ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 64 << 30, 1))
+
+
+def _spec_stats(ctx):
+    out = np.zeros(3, dtype=np.uint64)
+    ctx._ck(ctx.lib.zk_msm_speculate_stats(ctx.h, _p(out)))
+    return dict(zip(("started", "taken", "dropped"), [int(v) for v in out]))
+
+
+@pytest.mark.parametrize("n", [900, 40_000])
+def test_msms_started_ahead_are_taken_only_for_the_same_scalars(ctx, n):
+    """create_proof asks for A, B in G1, B in G2 over ONE `assignment`, one call behind the other (src/groth16.rs:137-160); the
+    library learns the succession and starts the next two MSMs ahead.  A result started ahead may only be handed out for the table
+    it was computed over AND scalars that are word for word the ones it ran on: a vector that differs at an unsampled element (same
+    fingerprint), another order of tables, a table that left the cache or changed content in between -- every sum must be the right
+    one, against the discrete-log identity.  n = 900: the jobs run beside the call (small); 40 000: behind it (serial)."""
+    rng = O.Prng(8800 + n)
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 8 << 30, 1))
+    ctx._ck(ctx.lib.zk_msm_speculate(ctx.h, 1))
+    tabs = []
+    for group in (1, 1, 2):
+        ks = [rng.fr() for _ in range(n)]
+        dk = ctx.upload(cv.fr_to_mont(ks))
+        tb = ctx.fixed_base(dk.ptr, n, group, cv.fr_to_mont([1])[0])
+        tabs.append((group, ks, np.ascontiguousarray(tb.download())))
+        tb.free(); dk.free()
+
+    def msm(k, sc, scal):
+        group, ks, pts = tabs[k]
+        got = (ctx.multi_scalar_mul_g1 if group == 1 else ctx.multi_scalar_mul_g2)(pts, scal)
+        e = sum(s * kk for s, kk in zip(sc, ks)) % O.R_MOD
+        want = O.g1_mul(O.G1_GEN, e) if group == 1 else O.g2_mul(O.G2_GEN, e)
+        assert (cv.g1_projective_to_affine if group == 1 else cv.g2_projective_to_affine)(got) == want, k
+
+    s0 = _spec_stats(ctx)
+    for rnd in range(4):                                            # round 0 learns A -> B1 -> B2; rounds 1.. take two results each
+        sc = [rng.fr() for _ in range(n)]
+        scal = cv.fr_to_mont(sc)
+        for k in (0, 1, 2):
+            msm(k, sc, scal)
+    s1 = _spec_stats(ctx)
+    assert s1["started"] - s0["started"] == 6 and s1["taken"] - s0["taken"] == 6 and s1["dropped"] == s0["dropped"], (s0, s1)
+    # the same fingerprint, other scalars: element 7 is not one of the 64 sampled ones
+    assert 7 not in [k * (n - 1) // 63 for k in range(64)]
+    sc = [rng.fr() for _ in range(n)]
+    scal = cv.fr_to_mont(sc)
+    msm(0, sc, scal)                                                # starts B1, B2 ahead on `sc`
+    sc2 = list(sc); sc2[7] = (sc2[7] + 1) % O.R_MOD
+    msm(1, sc2, cv.fr_to_mont(sc2))                                 # compared on the device: not the same vector -> dropped, computed afresh
+    msm(2, sc2, cv.fr_to_mont(sc2))
+    s2 = _spec_stats(ctx)
+    # both jobs over `sc` are dropped; the call for B1 on `sc2` may start B2 ahead on `sc2`, which the next call then takes
+    assert s2["dropped"] - s1["dropped"] == 2 and s2["taken"] - s1["taken"] <= 1, (s1, s2)
+    # another order of tables (A, then B2 directly), twice: dropped, right, and the pattern is given up
+    for _ in range(3):
+        sc = [rng.fr() for _ in range(n)]
+        scal = cv.fr_to_mont(sc)
+        msm(0, sc, scal); msm(2, sc, scal); msm(1, sc, scal)
+    # a table rewritten in place between the call that started a job over it and the call that asks for it
+    for _ in range(2):
+        sc = [rng.fr() for _ in range(n)]
+        scal = cv.fr_to_mont(sc)
+        for k in (0, 1, 2):
+            msm(k, sc, scal)
+    sc = [rng.fr() for _ in range(n)]
+    scal = cv.fr_to_mont(sc)
+    msm(0, sc, scal)
+    group, ks, pts = tabs[1]
+    pts[11] = pts[12]; ks[11] = ks[12]                              # (unsampled: the cache's verified hit replaces the entry, the job over the old content must not be used)
+    msm(1, sc, scal)
+    msm(2, sc, scal)
+    # ... and one that left the cache
+    sc = [rng.fr() for _ in range(n)]
+    scal = cv.fr_to_mont(sc)
+    msm(0, sc, scal)
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    msm(1, sc, scal); msm(2, sc, scal)
+    # switched off: nothing is started
+    ctx._ck(ctx.lib.zk_msm_speculate(ctx.h, 0))
+    s3 = _spec_stats(ctx)
+    for _ in range(2):
+        sc = [rng.fr() for _ in range(n)]
+        scal = cv.fr_to_mont(sc)
+        for k in (0, 1, 2):
+            msm(k, sc, scal)
+    assert _spec_stats(ctx)["started"] == s3["started"]
+    ctx._ck(ctx.lib.zk_msm_speculate(ctx.h, 1))
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 64 << 30, 1))

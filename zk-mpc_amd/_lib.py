@@ -111,6 +111,8 @@ PROTOTYPES = {
     "zk_msm_g2_strided": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P]),
     "zk_bases_cache_config": (_I, [_P, _SZ, _I]),
     "zk_bases_cache_trust": (_I, [_P, _I]),
+    "zk_msm_speculate": (_I, [_P, _I]),
+    "zk_msm_speculate_stats": (_I, [_P, _P]),
     "zk_bases_cache_drop": (_I, [_P]),
     "zk_bases_cache_sync": (_I, [_P]),
     "zk_bases_cache_stats": (_I, [_P, _P]),

@@ -235,6 +235,7 @@ ZkPrecompJob* builder_collect(ZkBasesCache* c, bool cancel) {
 void free_table(zk_ctx* ctx, ZkBasesCache* c, zk_bases* b, uint32_t* raw) {
     if (c && c->building && c->building->b == b)            // its multiples are being built: stop, throw them away
         (void)zk_bases_precompute_finish(ctx, builder_collect(c, true), false);
+    if (b) zk_msm_spec_forget(ctx, b);                      // (a job started ahead over this table, a learned succession through it)
     if (raw) (void)hipFree(raw);
     if (b) {
         if (b->owned && b->dev) (void)hipFree(b->dev);
@@ -534,6 +535,7 @@ int zk_bases_cache_replace(zk_ctx* ctx, ZkBasesLease* l) {
     if (!x) ZK_FAIL(ctx, ZK_ERR_STATE, "bases cache: the leased entry is gone");
     if (c->building && c->building->b == x->b) (void)zk_bases_precompute_finish(ctx, builder_collect(c, true), false);
     zk_bases* b = x->b;
+    zk_msm_spec_drop(ctx);                                   // (whatever was started ahead may read this table)
     if (b->pre) { ZK_HIP(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(b->pre); b->pre = nullptr; b->c_pre = b->W_pre = b->pre_stride = 0; b->pre_note.clear(); }
     if (x->host) {
         x->host->swap(c->fresh);                             // (the caller's content, as packed for the comparison)

@@ -80,6 +80,7 @@ extern "C" int zk_ctx_destroy(zk_ctx* ctx) {
     for (auto& kv : ctx->pinned)
         if (kv.second.p) (void)hipHostFree(kv.second.p);
     zk_presort_free(ctx);
+    zk_msm_spec_free(ctx);
     zk_bases_cache_free(ctx);
     for (auto& kv : ctx->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     ctx->graphs.clear();

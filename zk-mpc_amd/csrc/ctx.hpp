@@ -135,6 +135,7 @@ struct zk_ctx {
     void* xfer = nullptr;                     // hostxfer.hip: the page-locked ring host slices travel through (ZkXfer)
     void* xfer_small = nullptr;               // hostxfer.hip: rotating page-locked slots for transfers below 128 KiB
     void* bases_cache = nullptr;              // bases_cache.hip: resident copies of host base slices seen by zk_msm_g1 / _g2 (ZkBasesCache)
+    void* msm_spec = nullptr;                 // msm.hip: MSMs over the tables a caller asks for next with the same scalars, started ahead (ZkMsmSpec)
     void* presort = nullptr;                  // groth16_pipeline.hip: a sort of z[1..] enqueued ahead of zk_groth16_msms_dev (ZkPresort)
     const void* next_z = nullptr;             // groth16_pipeline.hip: zk_groth16_hint_next_dev
     // groth16_prove.hip: zk_groth16_hint_next (host-slice form): the announced assignment is uploaded on its own stream into the

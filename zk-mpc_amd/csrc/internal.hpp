@@ -88,7 +88,18 @@ int zk_bases_cache_verify(zk_ctx* ctx, ZkBasesLease* l, const ZkHostTable& t, si
 int zk_bases_cache_replace(zk_ctx* ctx, ZkBasesLease* l);
 void zk_bases_lease_release(zk_ctx* ctx, ZkBasesLease* l);
 // msm.hip: n_lanes MSMs (device scalar vectors of n elements) over ONE host table, through the cache -- verified hit and all
-int zk_msm_table_run(zk_ctx* ctx, const ZkHostTable& t, size_t n_table, int n_lanes, const void* const* scalars_dev, size_t n, void* const* outs);
+// scalars_fp: a fingerprint of the scalar vector taken from the caller's HOST memory (64 sampled elements and the length; 0 = none):
+// what the speculation below recognises a repeated vector by -- a candidate, confirmed word for word on the device before any
+// speculative result is handed out
+int zk_msm_table_run(zk_ctx* ctx, const ZkHostTable& t, size_t n_table, int n_lanes, const void* const* scalars_dev, size_t n, void* const* outs,
+                     uint64_t scalars_fp = 0);
+// msm.hip: MSMs started ahead for the tables a caller asks for next with the SAME scalar vector (create_proof: A, then B in G1, then B
+// in G2 over one `assignment`: src/groth16.rs:137-160).  drop: abandon what is in flight (waits for its kernels); forget: a table is
+// leaving the cache or changing content; free: with the context.
+void zk_msm_spec_drop(zk_ctx* ctx);
+void zk_msm_spec_forget(zk_ctx* ctx, const zk_bases* b);
+void zk_msm_spec_free(zk_ctx* ctx);
+int zk_prover_streams(zk_ctx* ctx, size_t k);      // groth16_pipeline.hip: the context's helper streams
 int zk_bases_cache_poll(zk_ctx* ctx);            // publish finished window multiples, start the next build (cheap: one event query)
 void zk_bases_cache_free(zk_ctx* ctx);
 extern "C" int zk_bases_free(zk_ctx* ctx, zk_bases* b);

@@ -34,6 +34,7 @@
 #include "ec_dual.cuh"
 #include <algorithm>
 #include <future>
+#include <map>
 #include <memory>
 #include <string.h>
 #include <vector>
@@ -1365,17 +1366,149 @@ int bases_download_t(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, vo
     return ZK_OK;
 }
 
+// ---- MSMs started AHEAD for the tables a caller asks for next with the same scalars -----------------------------------------------
+// The unchanged create_proof runs its MSMs one call behind the other, and three of them over ONE scalar vector: calculate_coeff with
+// &pk.a_query, then &pk.b_g1_query, then &pk.b_g2_query over `assignment` (src/groth16.rs:137-160).  Every call is synchronous -- the
+// trait returns the point -- so the upload, the sort, the reduce chain and the host's Horner half of one call never overlap the next
+// call's kernels, as they do in the resident prover.  What CAN be known: which table followed which with the same scalars last time.
+// So a context learns "after table T (scalars S) came table T' with the same S" (candidates by a fingerprint of 64 sampled scalars
+// taken from host memory), and when T is asked for again it also starts the MSMs over T' and T'' -- on a private copy of the scalars,
+// on the sort / accumulate streams, own scratch slots (6, 7) -- before it collects T's result.  The next call, if it names T' and
+// its scalars are WORD FOR WORD the ones the speculative job ran on (compared on the device), takes that result; anything else
+// drops the speculation (and after two wrong guesses for a table the pattern is forgotten).  Table hits are verified as always.
+// Nothing speculative is ever returned unverified; ZK_MSM_SPEC=0 switches the whole thing off (A/B).
+struct SpecJob { const zk_bases* table; ZkMsmJob job; };
+struct ZkMsmSpec {
+    const zk_bases* last_table = nullptr;
+    uint64_t last_fp = 0;
+    size_t last_n = 0;
+    std::map<const zk_bases*, const zk_bases*> succ;
+    std::map<const zk_bases*, int> bad;
+    std::vector<std::unique_ptr<SpecJob>> jobs;          // in the order they will be asked for
+    size_t n = 0;
+    uint64_t fp = 0;
+    uint32_t* flag_dev = nullptr;
+    uint32_t* flag_host = nullptr;
+    uint64_t started = 0, taken = 0, dropped = 0;
+    bool off = false;                                     // zk_msm_speculate(ctx, 0)
+};
+static bool spec_enabled() {
+    static const bool on = !(getenv("ZK_MSM_SPEC") && atoi(getenv("ZK_MSM_SPEC")) == 0);
+    return on;
+}
+static ZkMsmSpec* spec_of(zk_ctx* ctx) {
+    if (!ctx->msm_spec) ctx->msm_spec = new ZkMsmSpec();
+    return (ZkMsmSpec*)ctx->msm_spec;
+}
+__global__ void __launch_bounds__(256) k_scalars_differ(const uint4* a, const uint4* b, size_t n16, uint32_t* flag) {
+    bool diff = false;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 x = a[i], y = b[i];
+        diff = diff || x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w;
+    }
+    if (diff) *flag = 1;
+}
+// what is in flight is abandoned: its kernels read the scratch slots and the scalar copy, so they are waited for
+static void spec_drop(zk_ctx* ctx, ZkMsmSpec* sp) {
+    if (sp->jobs.empty()) return;
+    if (!ctx->aux.empty()) (void)hipStreamSynchronize(ctx->aux[0]);
+    if (ctx->acc_stream) (void)hipStreamSynchronize(ctx->acc_stream);
+    sp->dropped += sp->jobs.size();
+    sp->jobs.clear();
+}
+// scalars (n elements on the device, final on the context stream) == the copy the speculative jobs run on?
+static int spec_same_scalars(zk_ctx* ctx, ZkMsmSpec* sp, const void* scalars, size_t n, bool* same) {
+    void* copy;
+    ZK_TRY(zk_scratch(ctx, "spec_scalars", n * 32, &copy));
+    if (!sp->flag_dev) {
+        ZK_HIP(ctx, hipMalloc((void**)&sp->flag_dev, 16));
+        ZK_HIP(ctx, hipHostMalloc((void**)&sp->flag_host, 16, hipHostMallocDefault));
+    }
+    ZK_HIP(ctx, hipMemsetAsync(sp->flag_dev, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_scalars_differ, zk_grid(n * 2, 256), 256, 0, ctx->stream, (const uint4*)scalars, (const uint4*)copy, n * 2, sp->flag_dev);
+    ZK_HIP(ctx, hipGetLastError());
+    ZK_HIP(ctx, hipMemcpyAsync(sp->flag_host, sp->flag_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *same = *sp->flag_host == 0;
+    return ZK_OK;
+}
+// the tables that followed `b` last time, over a private copy of the scalars: sort on the sort stream, accumulate on the accumulate
+// stream, the reduce chain behind it (a small job's on the accumulate stream, a large one's on the sort stream: msm_batch.hip)
+static int spec_start(zk_ctx* ctx, ZkMsmSpec* sp, const zk_bases* b, const void* scalars, size_t n, uint64_t fp, bool serial) {
+    const zk_bases* next[2] = {nullptr, nullptr};
+    int cnt = 0;
+    auto it = sp->succ.find(b);
+    if (it != sp->succ.end() && it->second != b && sp->bad[it->second] < 2 && n <= it->second->n) {
+        next[cnt++] = it->second;
+        auto it2 = sp->succ.find(it->second);
+        if (it2 != sp->succ.end() && it2->second != b && it2->second != it->second && sp->bad[it2->second] < 2 && n <= it2->second->n) next[cnt++] = it2->second;
+    }
+    if (!cnt) return ZK_OK;
+    void* copy;
+    ZK_TRY(zk_scratch(ctx, "spec_scalars", n * 32, &copy));
+    ZK_TRY(zk_prover_streams(ctx, 1));
+    hipStream_t s_acc = ctx->acc_stream, s_sort = ctx->aux[0];
+    ZK_HIP(ctx, hipMemcpyAsync(copy, scalars, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    hipEvent_t e0;
+    ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(e0, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s_sort, e0, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s_acc, e0, 0);
+    (void)hipEventDestroy(e0);
+    ZK_HIP(ctx, e);
+    int rc = ZK_OK;
+    for (int k = 0; k < cnt && rc == ZK_OK; k++) {
+        std::unique_ptr<SpecJob> j(new SpecJob());
+        j->table = next[k];
+        j->job.pin_key = 40 + k;
+        rc = zk_msm_prepare(ctx, &j->job, next[k], 0, copy, n, 6 + k);
+        if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &j->job, s_sort, nullptr);
+        if (serial) {                                        // a LARGE call: one job wholly behind the other on one stream (see msm_table_run_t)
+            if (rc == ZK_OK) rc = zk_msm_enqueue_accum(ctx, &j->job, s_sort);
+            if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, &j->job, s_sort);
+        } else {
+            if (rc == ZK_OK) rc = zk_msm_enqueue_accum(ctx, &j->job, s_acc);
+            if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, &j->job, s_acc);
+        }
+        sp->jobs.push_back(std::move(j));                    // (even a half-enqueued one: spec_drop waits for whatever it launched)
+        if (rc == ZK_OK) sp->started++;
+    }
+    sp->n = n;
+    sp->fp = fp;
+    if (rc != ZK_OK) spec_drop(ctx, sp);
+    return rc;
+}
+
 // AffineCurve::multi_scalar_mul on host slices.  The bases come through the context's table cache (bases_cache.hip): a table the
 // context has seen before -- the queries of a proving key, the powers of an SRS -- is resident already (window multiples are built
 // beside later calls), and only the scalars cross PCIe for the arithmetic; the caller's slice crosses once more, UNDER the MSM, to
 // be compared in full with what the cached table was made from (a hit is a candidate until that comparison is through).
 // n_lanes MSMs over the same table (the two lanes of a SPDZ multi_scale_pub_group: share/spdz.rs:482-488): scalars_dev[l] -> outs[l].
 template <class F>
-int msm_table_run_t(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, const void* const* scalars_dev, size_t n, void* const* outs) {
-    constexpr size_t PROJ = 3 * F::WORDS * 4;              // bytes of a zk_g1_projective / zk_g2_projective
+int msm_table_run_t(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, const void* const* scalars_dev, size_t n, void* const* outs, uint64_t sfp) {
     ZkBasesLease lease;
     ZK_TRY(zk_bases_cache_get(ctx, t, nu, &lease));
+    const bool spec_ok = spec_enabled() && n_lanes == 1 && !lease.temporary && sfp != 0 && !ctx->profiling &&
+                         !(ctx->msm_spec && ((ZkMsmSpec*)ctx->msm_spec)->off);
+    ZkMsmSpec* sp = spec_ok || ctx->msm_spec ? spec_of(ctx) : nullptr;
     int rc = ZK_OK;
+    SpecJob* take = nullptr;
+    if (sp && !sp->jobs.empty()) {                           // is this the call the speculation was made for?
+        SpecJob* j = sp->jobs.front().get();
+        bool same = false;
+        if (spec_ok && j->table == lease.b && sp->n == n && sp->fp == sfp) rc = spec_same_scalars(ctx, sp, scalars_dev[0], n, &same);
+        if (rc == ZK_OK && same) take = j;
+        else {
+            if (spec_ok || j->table != lease.b) sp->bad[j->table]++;
+            spec_drop(ctx, sp);
+        }
+    }
+    if (sp && spec_ok && rc == ZK_OK) {                      // learn: the same scalars as the call before, another table
+        if (sp->last_table && sp->last_table != lease.b && sp->last_n == n && sp->last_fp == sfp) sp->succ[sp->last_table] = lease.b;
+        sp->last_table = lease.b; sp->last_n = n; sp->last_fp = sfp;
+    } else if (sp) {
+        sp->last_table = nullptr;
+    }
     for (int attempt = 0; attempt < 2 && rc == ZK_OK; attempt++) {
         bool same = true;
         int vrc = ZK_OK;
@@ -1383,8 +1516,29 @@ int msm_table_run_t(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, c
             ZkTask<void> verifier;                           // (joins when this block is left, whatever the MSM did)
             if (lease.verify)
                 verifier = zk_async(ctx, [&] { (void)hipSetDevice(ctx->device); vrc = zk_bases_cache_verify(ctx, &lease, t, nu, &same); });
-            if (n_lanes == 1) {
-                rc = msm_run_t<F>(ctx, lease.b, 0, scalars_dev[0], n, outs[0]);
+            if (take) {                                      // the result that was started during the previous call
+                rc = zk_msm_finish(ctx, &take->job, outs[0]);
+                sp->jobs.erase(sp->jobs.begin());
+                sp->taken++;
+                take = nullptr;
+            } else if (n_lanes == 1) {
+                // The MSMs this caller asked for next the last time it came with this table, on the side streams.  A SMALL call is a chain
+                // of latencies on a mostly idle chip: they start at once, behind nothing but the copy of the scalars, and run beside this
+                // call's own kernels (2^10 .. 2^16: -12 .. -18 % per proof).  A LARGE call fills the chip: started at once they only delay
+                // this call's result (2^20: the A call 4 -> 13.5 ms, the three calls 16.6 -> 21.6), so they queue behind this call's
+                // whole device chain (a reduce chain beside a running accumulate kernel is starved), one wholly behind the other on one
+                // stream, and run under this call's host half and the caller's way back into the library.
+                const bool want_spec = spec_ok && attempt == 0 && sp->jobs.empty();
+                const bool small_call = lease.b->pre ? n * ((255 + lease.b->c_pre - 1) / lease.b->c_pre) <= ((size_t)1 << 22) : n <= ((size_t)1 << 17);
+                if (want_spec && small_call) (void)spec_start(ctx, sp, lease.b, scalars_dev[0], n, sfp, false);
+                ZkMsmJob job;
+                rc = msm_prepare_t<F>(ctx, &job, lease.b, 0, scalars_dev[0], n, 0);
+                if (rc == ZK_OK) rc = msm_enqueue_sort_t<F>(ctx, &job, ctx->stream, nullptr);
+                if (rc == ZK_OK) rc = msm_enqueue_accum_t<F>(ctx, &job, ctx->stream);
+                if (rc == ZK_OK) rc = msm_enqueue_reduce_t<F>(ctx, &job, ctx->stream);
+                if (rc == ZK_OK && want_spec && !small_call) (void)spec_start(ctx, sp, lease.b, scalars_dev[0], n, sfp, true);
+                if (rc == ZK_OK) rc = msm_finish_t<F>(ctx, &job, outs[0]);
+                else (void)hipStreamSynchronize(ctx->stream);
             } else {
                 const zk_bases* bs[2] = {lease.b, lease.b};
                 const size_t lens[2] = {n, n};
@@ -1395,9 +1549,20 @@ int msm_table_run_t(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, c
         if (rc != ZK_OK || same) break;
         rc = zk_bases_cache_replace(ctx, &lease);            // the table at the caller's address is not the cached one any more: again, on the right one
     }
-    (void)PROJ;
+    if (rc != ZK_OK && sp) spec_drop(ctx, sp);
     zk_bases_lease_release(ctx, &lease);
     return rc;
+}
+
+// 64 sampled elements and the length: how a repeated scalar vector is recognised (a candidate: see spec_same_scalars)
+uint64_t scalars_fingerprint(const zk_fr* s, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+    const size_t S = n < 64 ? n : 64;
+    for (size_t k = 0; k < S; k++) {
+        const size_t i = S > 1 ? k * (n - 1) / (S - 1) : 0;
+        for (int w = 0; w < 4; w++) { h ^= s[i].l[w]; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+    }
+    return h ? h : 1;
 }
 
 ZkHostTable host_table(int group, const void* host, const ZkAffineLayout* layout) {
@@ -1425,7 +1590,7 @@ int msm_host_t(zk_ctx* ctx, const void* bases_host, size_t nb, const ZkAffineLay
     ZK_TRY(zk_xfer_h2d(ctx, sdev, scalars, n * 32));
     const void* sc[1] = {sdev};
     void* outs[1] = {out};
-    return msm_table_run_t<F>(ctx, host_table(group, bases_host, layout), nu, 1, sc, n, outs);
+    return msm_table_run_t<F>(ctx, host_table(group, bases_host, layout), nu, 1, sc, n, outs, scalars_fingerprint(scalars, n));
 }
 
 }  // namespace
@@ -1541,9 +1706,47 @@ int zk_bases_import_launch(zk_ctx* ctx, zk_bases* b, const void* raw, hipStream_
     return ZK_OK;
 }
 // the MSM of the MPC entry points (mpc_host.hip): n_lanes scalar vectors on the device against one host table
-int zk_msm_table_run(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, const void* const* scalars_dev, size_t n, void* const* outs) {
-    if (t.group == 1) return msm_table_run_t<G1Field>(ctx, t, nu, n_lanes, scalars_dev, n, outs);
-    return msm_table_run_t<G2Field>(ctx, t, nu, n_lanes, scalars_dev, n, outs);
+int zk_msm_table_run(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, const void* const* scalars_dev, size_t n, void* const* outs, uint64_t sfp) {
+    if (t.group == 1) return msm_table_run_t<G1Field>(ctx, t, nu, n_lanes, scalars_dev, n, outs, sfp);
+    return msm_table_run_t<G2Field>(ctx, t, nu, n_lanes, scalars_dev, n, outs, sfp);
+}
+void zk_msm_spec_drop(zk_ctx* ctx) {
+    if (ctx->msm_spec) spec_drop(ctx, (ZkMsmSpec*)ctx->msm_spec);
+}
+extern "C" int zk_msm_speculate(zk_ctx* ctx, int on) {
+    ZK_API_BEGIN(ctx)
+    if (!ctx) return ZK_ERR_ARG;
+    ZkMsmSpec* sp = spec_of(ctx);
+    sp->off = on == 0;
+    if (sp->off) { spec_drop(ctx, sp); sp->succ.clear(); sp->bad.clear(); sp->last_table = nullptr; }
+    return ZK_OK;
+    ZK_API_END
+}
+extern "C" int zk_msm_speculate_stats(zk_ctx* ctx, uint64_t out[3]) {
+    ZK_API_BEGIN(ctx)
+    if (!ctx || !out) return ZK_ERR_ARG;
+    ZkMsmSpec* sp = (ZkMsmSpec*)ctx->msm_spec;
+    out[0] = sp ? sp->started : 0; out[1] = sp ? sp->taken : 0; out[2] = sp ? sp->dropped : 0;
+    return ZK_OK;
+    ZK_API_END
+}
+void zk_msm_spec_forget(zk_ctx* ctx, const zk_bases* b) {
+    ZkMsmSpec* sp = (ZkMsmSpec*)ctx->msm_spec;
+    if (!sp) return;
+    for (auto& j : sp->jobs) if (j->table == b) { spec_drop(ctx, sp); break; }
+    if (sp->last_table == b) sp->last_table = nullptr;
+    sp->succ.erase(b);
+    sp->bad.erase(b);
+    for (auto it = sp->succ.begin(); it != sp->succ.end();) it = it->second == b ? sp->succ.erase(it) : std::next(it);
+}
+void zk_msm_spec_free(zk_ctx* ctx) {
+    ZkMsmSpec* sp = (ZkMsmSpec*)ctx->msm_spec;
+    if (!sp) return;
+    spec_drop(ctx, sp);
+    if (sp->flag_dev) (void)hipFree(sp->flag_dev);
+    if (sp->flag_host) (void)hipHostFree(sp->flag_host);
+    delete sp;
+    ctx->msm_spec = nullptr;
 }
 extern "C" int zk_bases_upload_g1(zk_ctx* ctx, const zk_g1_affine* h, size_t n, zk_bases** out) { ZK_API_BEGIN(ctx) return bases_upload_t<G1Field>(ctx, h, n, 1, nullptr, out); ZK_API_END }
 extern "C" int zk_bases_upload_g2(zk_ctx* ctx, const zk_g2_affine* h, size_t n, zk_bases** out) { ZK_API_BEGIN(ctx) return bases_upload_t<G2Field>(ctx, h, n, 2, nullptr, out); ZK_API_END }

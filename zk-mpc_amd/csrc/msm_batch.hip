@@ -166,6 +166,7 @@ int zk_msm_early_begin(zk_ctx* ctx, int count, const zk_bases* bases, const size
     if (count < 1 || count > 2 || !bases || !scalars_dev || !len) return ZK_ERR_ARG;
     for (int k = 0; k < count; k++)
         if (base_offsets[k] + len > bases->n) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_msm_early_begin: a job reads past its base table");
+    zk_msm_spec_drop(ctx);                                   // (msm.hip's speculative jobs use the same scratch slots)
     ZK_TRY(zk_prover_streams(ctx, 1));
     hipStream_t s_acc = ctx->acc_stream, s_sort = ctx->aux[0];
     hipEvent_t e0;
