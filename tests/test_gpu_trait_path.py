@@ -432,3 +432,57 @@ def test_msms_started_ahead_are_taken_only_for_the_same_scalars(ctx, n):
     ctx._ck(ctx.lib.zk_msm_speculate(ctx.h, 1))
     ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
     ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 64 << 30, 1))
+
+
+def test_fuzz_of_msms_started_ahead(ctx):
+    """A randomised walk through what can happen between an MSM that was started ahead and the call it was started for: bursts of calls
+    over one scalar vector in a recurring order (learnt), in other orders, with a table skipped; the scalars changed at ONE element
+    between two calls of a burst; a table rewritten in place, dropped from the cache, evicted under a tight budget; the switch thrown
+    mid-burst; shorter vectors.  Every sum against sum s_i k_i * G -- a result started ahead must never be handed out for anything but
+    the table content and the scalars it was computed over."""
+    rng = O.Prng(20261004)
+    rs = np.random.RandomState(11)
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    ctx._ck(ctx.lib.zk_bases_cache_trust(ctx.h, 0))
+    ctx._ck(ctx.lib.zk_msm_speculate(ctx.h, 1))
+    tables = []
+    for group, n in ((1, 1000), (1, 1000), (2, 1000), (1, 1200), (2, 700)):
+        ks = [rng.fr() for _ in range(n)]
+        dk = ctx.upload(cv.fr_to_mont(ks))
+        tab = ctx.fixed_base(dk.ptr, n, group, cv.fr_to_mont([1])[0])
+        pts = np.ascontiguousarray(tab.download())
+        tab.free(); dk.free()
+        tables.append({"group": group, "n": n, "ks": ks, "pts": pts})
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 24 << 20, 1))   # not all five with their multiples: evictions on the way
+    orders = [(0, 1, 2)] * 5 + [(3, 0, 2), (0, 2), (1, 0, 4), (0, 1, 2, 3, 4)]
+    s0 = _spec_stats(ctx)
+    on = True
+    for step in range(45):
+        order = orders[rs.randint(len(orders))]
+        m = 700 if rs.rand() < 0.8 else rs.randint(300, 700)
+        sc = [rng.fr() if rs.rand() < 0.9 else 0 for _ in range(m)]
+        for k in order:
+            t = tables[k]
+            group, n, pts, ks = t["group"], t["n"], t["pts"], t["ks"]
+            r = rs.rand()
+            if r < 0.12:                                           # the table changes in place (point j becomes a copy of point i)
+                i, j = rs.randint(n), rs.randint(n)
+                pts[j] = pts[i]; ks[j] = ks[i]
+            elif r < 0.24:                                         # the scalars change at one element
+                sc = list(sc); j = rs.randint(m); sc[j] = (sc[j] + 1 + rs.randint(5)) % O.R_MOD
+            elif r < 0.28:
+                ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+            elif r < 0.33:
+                on = not on
+                ctx._ck(ctx.lib.zk_msm_speculate(ctx.h, 1 if on else 0))
+            e = sum(s * kk for s, kk in zip(sc, ks)) % O.R_MOD
+            want = O.g1_mul(O.G1_GEN, e) if group == 1 else O.g2_mul(O.G2_GEN, e)
+            src = pts if rs.rand() < 0.7 else pts.copy()
+            got = (ctx.multi_scalar_mul_g1 if group == 1 else ctx.multi_scalar_mul_g2)(src, cv.fr_to_mont(sc))
+            assert (cv.g1_projective_to_affine if group == 1 else cv.g2_projective_to_affine)(got) == want, \
+                "step %d, table %d of %s, %d scalars" % (step, k, order, m)
+    s1 = _spec_stats(ctx)
+    assert s1["taken"] - s0["taken"] > 8 and s1["dropped"] - s0["dropped"] > 8, (s0, s1)   # both ends were walked
+    ctx._ck(ctx.lib.zk_msm_speculate(ctx.h, 1))
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 64 << 30, 1))

@@ -1518,6 +1518,7 @@ int msm_table_run_t(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, c
                 verifier = zk_async(ctx, [&] { (void)hipSetDevice(ctx->device); vrc = zk_bases_cache_verify(ctx, &lease, t, nu, &same); });
             if (take) {                                      // the result that was started during the previous call
                 rc = zk_msm_finish(ctx, &take->job, outs[0]);
+                sp->bad.erase(sp->jobs.front()->table);     // (two wrong guesses IN A ROW give a table up: spec_start)
                 sp->jobs.erase(sp->jobs.begin());
                 sp->taken++;
                 take = nullptr;
