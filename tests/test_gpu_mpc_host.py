@@ -248,3 +248,28 @@ def test_mpc_msm(group, spdz, tag_last):
             tab.free(); dk.free()
         finally:
             ctx.close()
+
+
+def test_arguments_that_do_not_fit_are_refused_before_anything_is_sized_by_them():
+    """EvaluationDomain::new refuses a size beyond the field's two-adicity (radix2/mod.rs:51-57: None); the host-slice transforms are
+    handed log_n by the override and must refuse a value they cannot serve BEFORE a buffer is sized by it -- and a layout whose fields
+    do not fit its stride, a vector longer than its domain."""
+    ctx = Z.Context(0, 0, 1)
+    try:
+        lay = A.MpcFieldLayout(False, False)
+        v = A.MpcVec(lay, 8).set([False] * 8, mont([1] * 8))
+        before = v.raw.copy()
+        for log_n in (29, 40, 64, 1 << 31):
+            ARG = -2                                                # ZK_ERR_ARG
+            raw = v.raw.ctypes.data_as(C.c_void_p)
+            assert ctx.lib.zk_mpc_fft_in_place(ctx.h, raw, 8, C.byref(lay.c), log_n, 0, 0) == ARG
+            assert "log_n" in ctx.lib.zk_last_error(ctx.h).decode()
+            assert ctx.lib.zk_mpc_divide_by_vanishing_on_coset_in_place(ctx.h, raw, C.byref(lay.c), log_n) == ARG
+            plain = mont([1] * 8)
+            assert ctx.lib.zk_fr_fft_in_place(ctx.h, plain.ctypes.data_as(C.c_void_p), 8, log_n, 0, 0) == ARG
+            assert ctx.lib.zk_fr_divide_by_vanishing_on_coset_in_place(ctx.h, plain.ctypes.data_as(C.c_void_p), log_n) == ARG
+        with pytest.raises(Z.ZkError, match="exceeds the domain"):
+            ctx.mpc_fft_in_place(v, 8, 2, 0, 0)
+        assert np.array_equal(v.raw, before)                        # nothing was touched
+    finally:
+        ctx.close()

@@ -203,6 +203,7 @@ extern "C" int zk_mpc_fft_in_place(zk_ctx* ctx, void* vec, size_t n, const zk_mp
     ZK_API_BEGIN(ctx)
     if (!ctx || !vec) return ZK_ERR_ARG;
     ZK_TRY(check_layout(ctx, lay));
+    if (log_n > 28) ZK_FAIL(ctx, ZK_ERR_ARG, "NTT size unsupported (log_n > 28)");
     const size_t N = (size_t)1 << log_n;
     if (n > N) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_mpc_fft_in_place: n exceeds the domain size");
     ZK_TRY(zk_bases_cache_poll(ctx));
@@ -227,6 +228,7 @@ extern "C" int zk_mpc_divide_by_vanishing_on_coset_in_place(zk_ctx* ctx, void* e
     ZK_API_BEGIN(ctx)
     if (!ctx || !evals) return ZK_ERR_ARG;
     ZK_TRY(check_layout(ctx, lay));
+    if (log_n > 28) ZK_FAIL(ctx, ZK_ERR_ARG, "NTT size unsupported (log_n > 28)");
     const size_t N = (size_t)1 << log_n;
     uint32_t zinv[9];
     ZK_TRY(zk_ntt_vanishing_inv(ctx, log_n, zinv));

@@ -454,6 +454,7 @@ extern "C" int zk_fr_ntt_dev(zk_ctx* ctx, void* buf, uint32_t log_n, int inverse
 extern "C" int zk_fr_fft_in_place(zk_ctx* ctx, zk_fr* vec, size_t n, uint32_t log_n, int inverse, int coset) {
     ZK_API_BEGIN(ctx)
     if (!ctx || !vec) return ZK_ERR_ARG;
+    if (log_n > 28) ZK_FAIL(ctx, ZK_ERR_ARG, "NTT size unsupported (log_n > 28)");       // (before anything is sized by it)
     size_t N = (size_t)1 << log_n;
     if (n > N) ZK_FAIL(ctx, ZK_ERR_ARG, "zk_fr_fft_in_place: n exceeds the domain size");
     void* d;
@@ -478,6 +479,7 @@ extern "C" int zk_fr_divide_by_vanishing_on_coset_dev(zk_ctx* ctx, void* evals, 
 extern "C" int zk_fr_divide_by_vanishing_on_coset_in_place(zk_ctx* ctx, zk_fr* evals, uint32_t log_n) {
     ZK_API_BEGIN(ctx)
     if (!ctx || !evals) return ZK_ERR_ARG;
+    if (log_n > 28) ZK_FAIL(ctx, ZK_ERR_ARG, "NTT size unsupported (log_n > 28)");
     const size_t N = (size_t)1 << log_n;
     zk_domain* dom;
     ZK_TRY(get_domain(ctx, log_n, false, &dom));
