@@ -24,14 +24,15 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
     }
     if (n_jobs == 0) return ZK_OK;
     zk_presort_free(ctx);            // the batch rotates over the same scratch slots
-    ZK_TRY(zk_prover_streams(ctx, 1));
+    ZK_TRY(zk_prover_streams(ctx, 2));
     constexpr size_t SLOTS = 3;
-    hipStream_t s_acc = ctx->acc_stream, s_sort = ctx->aux[0];
+    hipStream_t s_acc = ctx->acc_stream, s_sort = ctx->aux[0], s_sort2 = ctx->aux[1];
     hipEvent_t e0;
     ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
     ZK_HIP(ctx, hipEventRecord(e0, ctx->stream));        // the scalars were produced on the context stream
     ZK_HIP(ctx, hipStreamWaitEvent(s_sort, e0, 0));
     ZK_HIP(ctx, hipStreamWaitEvent(s_acc, e0, 0));
+    ZK_HIP(ctx, hipStreamWaitEvent(s_sort2, e0, 0));
     std::vector<size_t> perm(n_jobs);
     for (size_t k = 0; k < n_jobs; k++) perm[k] = k;
     std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t b) { return lens[a] > lens[b]; });
@@ -70,7 +71,10 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
                 }
                 {
                     // the jobs that take the one-block sort: one launch, a block per job (sort stream); the others (a job of more than
-                    // 2^16 digits: ~10 short launches each) side by side on the other two streams
+                    // 2^16 digits: ~10 short launches each) side by side on the other streams -- one each (two behind each other on two
+                    // streams: every job of a round at |H| = 2^14 is past the one-block sort; Marlin 2^13 .. 2^16, same box, two runs each:
+                    // 5.40 / 5.43 -> 5.27 / 5.14, 6.25 / 6.26 -> 6.13 / 5.99, 7.58 / 7.58 -> 7.50 / 7.24, 9.70 / 9.70 -> 9.59 / 9.37 ms)
+                    hipStream_t others[4] = {ctx->stream, s_acc, s_sort2, s_sort};
                     ZkMsmJob* fit[GM]; size_t nfit = 0, nother = 0;
                     ZkMsmJob* one[1];
                     for (size_t p = 0; p < cnt; p++) { one[0] = grp[p]; if (zk_msm_sort_group_ok(one, 1)) fit[nfit++] = grp[p]; }
@@ -79,7 +83,7 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
                         const size_t k = g0 + p;
                         bool in_fit = false;
                         for (size_t f = 0; f < nfit; f++) in_fit = in_fit || fit[f] == grp[p];
-                        hipStream_t ss = in_fit ? s_sort : (nother++ % 2 == 0 ? ctx->stream : s_acc);
+                        hipStream_t ss = in_fit ? s_sort : others[nother++ % (nfit ? 3 : 4)];
                         if (g0 && jobs[k - GM].reduce_done) ZK_HIP(ctx, hipStreamWaitEvent(ss, jobs[k - GM].reduce_done, 0));
                         if (!in_fit) rc = zk_msm_enqueue_sort(ctx, &jobs[k], ss, nullptr);
                     }
@@ -103,6 +107,7 @@ extern "C" int zk_msm_batch_dev(zk_ctx* ctx, size_t n_jobs, const zk_bases* cons
                 rc = zk_msm_finish_many(ctx, jp.data(), op.data(), (int)n_jobs);
             }
             (void)hipStreamSynchronize(s_sort);
+            (void)hipStreamSynchronize(s_sort2);
             (void)hipStreamSynchronize(s_acc);
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipEventDestroy(e0);
