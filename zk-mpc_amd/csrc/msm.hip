@@ -1057,8 +1057,11 @@ int msm_enqueue_reduce_t(zk_ctx* ctx, ZkMsmJob* job, hipStream_t st) {
 
 // ---- a group of small G1 jobs: one sort launch (a block per job), one accumulate launch, one launch per level of the reduce chain --
 // The sorts of a group: every job must qualify for the one-block sort (zk_msm_sort_group_ok; else the per-job calls).
-// (a block per job side by side: up to 2^17 digits each -- 160 us -- still beats ten launches per job one job behind the other)
-constexpr uint32_t SS_GROUP_MAX_ENTRIES = 1u << 17;
+// A block's time grows with its digits (~1.3 us per thousand), the multi-launch path is ~105 us flat plus ten launches of host
+// time, and since round 6 every job of a group that takes it has a stream of its own (msm_batch.hip).  Marlin, same box, limit
+// 2^16 / 3 * 2^15 .. 2^17 / 2^18: |H| = 2^11 (mask: 123 k digits) 3.84 / 4.12-4.19 / -, 2^12 (w, z_a, z_b: 78 k each; mask 233 k)
+// 4.80 / 4.32-4.38 / 5.4, 2^13 5.35 / 5.2-5.4 / 5.3-5.4: one block up to 96 k digits.
+constexpr uint32_t SS_GROUP_MAX_ENTRIES = 3u << 15;
 static bool sort_small_fits(const ZkMsmJob* j) {
     const bool merged = j->Wb == 1 && j->W > 1;
     return j->n > 0 && merged && (size_t)j->W * j->n <= SS_GROUP_MAX_ENTRIES && j->NB <= SS_MAX_NB && j->seg <= SS_MAX_SEG;
