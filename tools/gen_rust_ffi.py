@@ -415,6 +415,9 @@ pub fn mpc_msm_g2<S: FieldShare<Fr> + HipLanes>(bases: *const c_void, n_bases: u
 // all_public_or_shared are gone, and the key's tables are found again by content whatever Vec they arrive in.
 // A prover whose key outlives it may skip the per-hit comparison of the caller's table with the cached one:
 pub fn trust_base_tables(on: bool) { CTX.with(|c| check(unsafe { zk_bases_cache_trust(*c, on as i32) })); }
+// calculate_coeff's three MSMs run over ONE `assignment` (src/groth16.rs:137-160): the library starts the next two while the first
+// reduces and releases a result only for the same cached table and scalars equal word for word.  Off for provers sharing one GPU:
+pub fn start_msms_ahead(on: bool) { CTX.with(|c| check(unsafe { zk_msm_speculate(*c, on as i32) })); }
 
 // ---- whole provers (src/groth16.rs:68-183 over shares; the plain prover with a resident key) ----
 pub fn create_proof_shared(pk: *const ZkPk, r1cs: *const ZkR1cs, z_share_dev: *const c_void, r_share: &Fr, s_share: &Fr) -> [u8; 192] {
