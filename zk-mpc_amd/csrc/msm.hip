@@ -1502,12 +1502,19 @@ int msm_table_run_t(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, c
         if (spec_ok && j->table == lease.b && sp->n == n && sp->fp == sfp) rc = spec_same_scalars(ctx, sp, scalars_dev[0], n, &same);
         if (rc == ZK_OK && same) take = j;
         else {
-            if (spec_ok || j->table != lease.b) sp->bad[j->table]++;
+            if ((spec_ok || j->table != lease.b) && sp->bad[j->table] < 3) sp->bad[j->table]++;
             spec_drop(ctx, sp);
         }
     }
     if (sp && spec_ok && rc == ZK_OK) {                      // learn: the same scalars as the call before, another table
-        if (sp->last_table && sp->last_table != lease.b && sp->last_n == n && sp->last_fp == sfp) sp->succ[sp->last_table] = lease.b;
+        if (sp->last_table && sp->last_table != lease.b && sp->last_n == n && sp->last_fp == sfp) {
+            auto it = sp->succ.find(sp->last_table);
+            if (it != sp->succ.end() && it->second == lease.b) {     // the succession held again: a table given up after two wrong
+                auto bd = sp->bad.find(lease.b);                     // guesses in a row earns its way back, one confirmation at a time
+                if (bd != sp->bad.end() && bd->second > 0 && --bd->second == 0) sp->bad.erase(bd);
+            }
+            sp->succ[sp->last_table] = lease.b;
+        }
         sp->last_table = lease.b; sp->last_n = n; sp->last_fp = sfp;
     } else if (sp) {
         sp->last_table = nullptr;
