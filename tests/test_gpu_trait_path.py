@@ -404,6 +404,14 @@ def test_msms_started_ahead_are_taken_only_for_the_same_scalars(ctx, n):
         sc = [rng.fr() for _ in range(n)]
         scal = cv.fr_to_mont(sc)
         msm(0, sc, scal); msm(2, sc, scal); msm(1, sc, scal)
+    # ... and earned back: the old order again, and after a few rounds its jobs are started ahead and taken again
+    sb = _spec_stats(ctx)
+    for _ in range(6):
+        sc = [rng.fr() for _ in range(n)]
+        scal = cv.fr_to_mont(sc)
+        for k in (0, 1, 2):
+            msm(k, sc, scal)
+    assert _spec_stats(ctx)["taken"] - sb["taken"] >= 2, (sb, _spec_stats(ctx))
     # a table rewritten in place between the call that started a job over it and the call that asks for it
     for _ in range(2):
         sc = [rng.fr() for _ in range(n)]
