@@ -155,7 +155,9 @@ int zk_bases_cache_stats2(zk_ctx* ctx, uint64_t out[4]);
  * src/groth16.rs:137-160); a context remembers which table followed which with the same scalars and, the next time the first of them
  * is asked for, starts the MSMs over the others as well -- on a private copy of the scalars, on side streams.  A later call takes such
  * a result only if it names that table and its scalars are word for word the ones the job ran on (compared on the device); anything
- * else drops it.  Small circuits gain 12 - 18 % per proof, large ones 2 - 4 %.  Contexts that SHARE one GPU (several parties of one
+ * else drops it.  Likewise for `h = witness_map(..)`: the output of the last host-slice transform is the scalar vector of the call
+ * that follows (src/groth16.rs:100-106), so that MSM starts when such a transform ends -- same rule for its release.
+ * Small circuits gain 12 - 20 % per proof, large ones 3 - 6 %.  Contexts that SHARE one GPU (several parties of one
  * process on one device) do better without: zk_msm_speculate(ctx, 0).  stats: out[0..2] = jobs started ahead, results taken, dropped. */
 int zk_msm_speculate(zk_ctx* ctx, int on);
 int zk_msm_speculate_stats(zk_ctx* ctx, uint64_t out[3]);

@@ -471,6 +471,14 @@ def test_fuzz_of_msms_started_ahead(ctx):
     on = True
     for step in range(45):
         order = orders[rs.randint(len(orders))]
+        if rs.rand() < 0.3:                                        # a transform's output as the scalars of the MSM right behind it
+            a = rs.randint(0, 1 << 62, size=(1024, 4), dtype=np.uint64); a[:, 3] &= np.uint64((1 << 60) - 1)
+            h = ctx.coset_ifft_in_place(a, 10) if rs.rand() < 0.8 else ctx.ifft_in_place(a, 10)
+            if rs.rand() < 0.3:
+                h[rs.randint(1024), 0] ^= np.uint64(1)             # ... touched in between
+            t = tables[3]                                          # 1 200 points: all 1 024 scalars count
+            e = sum(int(s_) * kk for s_, kk in zip(cv.fr_from_mont(h), t["ks"])) % O.R_MOD
+            assert cv.g1_projective_to_affine(ctx.multi_scalar_mul_g1(t["pts"], h)) == O.g1_mul(O.G1_GEN, e), "step %d, after a transform" % step
         m = 700 if rs.rand() < 0.8 else rs.randint(300, 700)
         sc = [rng.fr() if rs.rand() < 0.9 else 0 for _ in range(m)]
         for k in order:
@@ -497,5 +505,61 @@ def test_fuzz_of_msms_started_ahead(ctx):
     if seed == 11:                                                 # (how often either end is walked is the seed's luck; the default's is known)
         assert s1["taken"] - s0["taken"] > 1 and s1["dropped"] - s0["dropped"] > 1, (s0, s1)
     ctx._ck(ctx.lib.zk_msm_speculate(ctx.h, 1))
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 64 << 30, 1))
+
+
+@pytest.mark.parametrize("log_n", [9, 15])
+def test_the_h_msm_started_at_the_end_of_the_transform(ctx, log_n):
+    """`h = witness_map(..)` ends in coset_ifft_in_place(&mut ab) and the very next library call is multi_scalar_mul(&pk.h_query, &h)
+    (src/groth16.rs:100-106, 296-305; D - 1 bases against D scalars: the min(len) rule).  The library learns that the output of a
+    transform of this kind and size was the next MSM's scalar vector and starts that MSM when the transform ends; the result is
+    released only if the scalars the call brings are the transform's output word for word.  Every sum against the discrete-log
+    identity on the transform's OWN output; a caller that touches one element in between, or runs another kind of transform last,
+    gets the right sum and no job's."""
+    N = 1 << log_n
+    n = N - 1
+    rng = O.Prng(4400 + log_n)
+    ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
+    ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 8 << 30, 1))
+    ctx._ck(ctx.lib.zk_msm_speculate(ctx.h, 1))
+    ks = [rng.fr() for _ in range(n)]
+    dk = ctx.upload(cv.fr_to_mont(ks))
+    tb = ctx.fixed_base(dk.ptr, n, 1, cv.fr_to_mont([1])[0])
+    pts = np.ascontiguousarray(tb.download())
+    tb.free(); dk.free()
+
+    def check(h, got):
+        sc = cv.fr_from_mont(h[:n])
+        e = sum(int(s) * kk for s, kk in zip(sc, ks)) % O.R_MOD
+        assert cv.g1_projective_to_affine(got) == O.g1_mul(O.G1_GEN, e)
+
+    rs = np.random.RandomState(log_n)
+    def rand_vec():
+        a = rs.randint(0, 1 << 62, size=(N, 4), dtype=np.uint64); a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+
+    s0 = _spec_stats(ctx)
+    for rnd in range(5):                                          # the first round learns, the others take
+        h = ctx.coset_ifft_in_place(rand_vec(), log_n)
+        check(h, ctx.multi_scalar_mul_g1(pts, h))                 # N scalars against N - 1 bases
+    s1 = _spec_stats(ctx)
+    assert s1["taken"] - s0["taken"] == 4 and s1["dropped"] == s0["dropped"], (s0, s1)
+    # one element changed between the transform and the MSM (not one of the 64 sampled ones)
+    h = ctx.coset_ifft_in_place(rand_vec(), log_n)
+    assert 5 not in [k * (N - 1) // 63 for k in range(64)] and 5 not in [k * (n - 1) // 63 for k in range(64)]
+    h[5, 0] ^= np.uint64(1)
+    check(h, ctx.multi_scalar_mul_g1(pts, h))
+    s2 = _spec_stats(ctx)
+    assert s2["dropped"] - s1["dropped"] == 1 and s2["taken"] == s1["taken"], (s1, s2)
+    # another kind of transform last (nothing is started for it), the learned kind before it (its job is dropped)
+    h = ctx.coset_ifft_in_place(rand_vec(), log_n)
+    h = ctx.ifft_in_place(h, log_n)
+    check(h, ctx.multi_scalar_mul_g1(pts, h))
+    # ... and the old order again, until it is trusted again
+    for rnd in range(5):
+        h = ctx.coset_ifft_in_place(rand_vec(), log_n)
+        check(h, ctx.multi_scalar_mul_g1(pts, h))
+    assert _spec_stats(ctx)["taken"] > s2["taken"]
     ctx._ck(ctx.lib.zk_bases_cache_drop(ctx.h))
     ctx._ck(ctx.lib.zk_bases_cache_config(ctx.h, 64 << 30, 1))

@@ -297,7 +297,7 @@ int advance_builds(zk_ctx* ctx, ZkBasesCache* c, bool wait) {
             if (xb->pre) c->builds++;
             continue;
         }
-        if (!c->pre_stream) ZK_HIP(ctx, zk_stream_create(&c->pre_stream, false));
+        if (!c->pre_stream) ZK_TRY(zk_side_stream(ctx, &c->pre_stream));      // (the context's: shared with the MSMs started ahead)
         ZkPrecompJob* j = nullptr;
         ZK_TRY(zk_bases_precompute_begin(ctx, xb, c->budget - resident(c), &j));
         if (!j) continue;                                    // skipped (the note says why)
@@ -413,7 +413,7 @@ void zk_bases_cache_free(zk_ctx* ctx) {
         c->bcv.notify_all();
         c->builder.join();
     }
-    if (c->pre_stream) { (void)hipStreamSynchronize(c->pre_stream); (void)hipStreamDestroy(c->pre_stream); }
+    if (c->pre_stream) (void)hipStreamSynchronize(c->pre_stream);      // (the context's side stream: it goes with the context)
     if (c->flag_dev) (void)hipFree(c->flag_dev);
     if (c->flag_host) (void)hipHostFree(c->flag_host);
     delete c;

@@ -18,6 +18,22 @@ void zk_presort_free(zk_ctx* ctx) {
     delete p;
 }
 
+// ONE side stream per context for everything that runs beside the caller's own calls on the trait-shaped path -- the slices of the
+// table cache's builder (bases_cache.hip) and the MSMs started ahead (msm.hip) -- and no accumulate stream with it: with the default
+// four hardware queues every stream beyond {null, context, transfer ring, this one} shares a queue with one of them, and the
+// host-slice transforms and products then run 8 - 30 % longer even while the extra streams sit idle (measured, round 6: seven
+// transforms at 2^20 12.9-13.4 -> 13.8-15.5 ms, the batch product 2.4 -> 3.1-3.3 ms with one to four idle streams more;
+// GPU_MAX_HW_QUEUES=8 takes the effect away, but that is the host application's setting, and the one-call provers lose with it).
+int zk_side_stream(zk_ctx* ctx, hipStream_t* out) {
+    if (ctx->aux.empty()) {
+        hipStream_t st;
+        ZK_HIP(ctx, zk_stream_create(&st, true));
+        ctx->aux.push_back(st);
+    }
+    *out = ctx->aux[0];
+    return ZK_OK;
+}
+
 int zk_prover_streams(zk_ctx* ctx, size_t k) {
     while (ctx->aux.size() < k) {
         hipStream_t st;

@@ -97,7 +97,11 @@ int zk_msm_table_run(zk_ctx* ctx, const ZkHostTable& t, size_t n_table, int n_la
 // in G2 over one `assignment`: src/groth16.rs:137-160).  drop: abandon what is in flight (waits for its kernels); forget: a table is
 // leaving the cache or changing content; free: with the context.
 void zk_msm_spec_drop(zk_ctx* ctx);
+int zk_side_stream(zk_ctx* ctx, hipStream_t* out);                       // groth16_pipeline.hip: the context's one side stream (= aux[0])
 void zk_msm_spec_forget(zk_ctx* ctx, const zk_bases* b);
+void zk_msm_spec_fft_begin(zk_ctx* ctx, const void* dev, size_t N, int kind);            // msm.hip: a host-slice transform's output as the next MSM's scalars
+void zk_msm_spec_fft_end(zk_ctx* ctx, size_t N, int kind, const std::function<uint64_t(size_t)>& fp_of);
+uint64_t zk_scalars_fingerprint(const void* fr, size_t n);                     // msm.hip: what zk_msm_g1/_g2 recognise a repeated scalar vector by
 void zk_msm_spec_free(zk_ctx* ctx);
 int zk_prover_streams(zk_ctx* ctx, size_t k);      // groth16_pipeline.hip: the context's helper streams
 int zk_bases_cache_poll(zk_ctx* ctx);            // publish finished window multiples, start the next build (cheap: one event query)

@@ -132,6 +132,24 @@ int gather_linear(zk_ctx* ctx, const FieldView& v, size_t n, void* const lane_de
     return ZK_OK;
 }
 
+// a fingerprint of a scalar vector from host memory (64 sampled elements: discriminant and first lane): what msm.hip's speculation
+// recognises the `assignment` of calculate_coeff's three calls -- and the `h` a transform has just written -- by (confirmed on the
+// device before anything is used)
+uint64_t mpc_scalars_fingerprint(const FieldView& v, size_t n) {
+    uint64_t sfp = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+    const size_t S = n < 64 ? n : 64;
+    for (size_t k = 0; k < S; k++) {
+        const size_t i = S > 1 ? k * (n - 1) / (S - 1) : 0;
+        const char* p = v.host + i * v.lay.stride;
+        const bool is_pub = (unsigned char)p[v.lay.off_tag] == v.lay.tag_public;
+        uint64_t w[4];
+        memcpy(w, p + (is_pub ? v.lay.off_public : v.lay.off_share), 32);
+        sfp ^= is_pub ? 0x5bd1e995u : 0;
+        for (int q = 0; q < 4; q++) { sfp ^= w[q]; sfp *= 0xFF51AFD7ED558CCDull; sfp ^= sfp >> 32; }
+    }
+    return sfp ? sfp : 1;
+}
+
 int lane_bufs(zk_ctx* ctx, const char* tag, size_t n, int lanes, void* out[2]) {
     char nm[48];
     out[0] = out[1] = nullptr;
@@ -175,23 +193,7 @@ int mpc_msm(zk_ctx* ctx, const void* bases, size_t nb, const zk_mpc_group_layout
     const int run = pub ? 1 : lanes;
     void* outs[2] = {out, out + PROJ};
     const void* sc[2] = {lane[0], lane[1]};
-    // a fingerprint of the scalar vector from host memory (64 sampled elements: discriminant and first lane): what msm.hip's
-    // speculation recognises the `assignment` of calculate_coeff's three calls by (confirmed on the device before use)
-    uint64_t sfp = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
-    {
-        const size_t S = n < 64 ? n : 64;
-        for (size_t k = 0; k < S; k++) {
-            const size_t i = S > 1 ? k * (n - 1) / (S - 1) : 0;
-            const char* p = v.host + i * sl->stride;
-            const bool is_pub = (unsigned char)p[sl->off_tag] == sl->tag_public;
-            uint64_t w[4];
-            memcpy(w, p + (is_pub ? sl->off_public : sl->off_share), 32);
-            sfp ^= is_pub ? 0x5bd1e995u : 0;
-            for (int q = 0; q < 4; q++) { sfp ^= w[q]; sfp *= 0xFF51AFD7ED558CCDull; sfp ^= sfp >> 32; }
-        }
-        if (!sfp) sfp = 1;
-    }
-    ZK_TRY(zk_msm_table_run(ctx, t, nu, run, sc, n, outs, sfp));
+    ZK_TRY(zk_msm_table_run(ctx, t, nu, run, sc, n, outs, mpc_scalars_fingerprint(v, n)));
     if (run == 1) memcpy(out + PROJ, out, PROJ);            // (one lane: the second slot mirrors it, never garbage)
     if (scalars_public) *scalars_public = pub ? 1 : 0;
     return ZK_OK;
@@ -217,7 +219,9 @@ extern "C" int zk_mpc_fft_in_place(zk_ctx* ctx, void* vec, size_t n, const zk_mp
         if (N > n) ZK_HIP(ctx, hipMemsetAsync((char*)lane[l] + n * 32, 0, (N - n) * 32, ctx->stream));   // Vec::resize(size, zero): Public(0)
     if (run == 1) ZK_TRY(zk_ntt_launch(ctx, lane[0], log_n, inverse, coset));
     else ZK_TRY(zk_ntt_launch_batch(ctx, lane, 2, log_n, inverse, coset));
+    if (run == 1) zk_msm_spec_fft_begin(ctx, lane[0], N, (inverse ? 2 : 0) + (coset ? 1 : 0));    // (msm.hip: `h = witness_map(..)` is the H query's scalar vector next)
     for (int l = 0; l < run; l++) ZK_TRY(zk_xfer_d2h_fn(ctx, lane[l], N * 32, scatterer(v, l, pub ? Out::Public : Out::Shared)));
+    if (run == 1) zk_msm_spec_fft_end(ctx, N, (inverse ? 2 : 0) + (coset ? 1 : 0), [&v](size_t m) { return mpc_scalars_fingerprint(v, m); });
     if (pub && N > n)                                       // the elements the caller appended are Public(0) already; say so for a caller that did not initialise them
         for (size_t i = n; i < N; i++) v.host[i * lay->stride + lay->off_tag] = (char)lay->tag_public;
     return ZK_OK;

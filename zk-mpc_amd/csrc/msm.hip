@@ -1376,7 +1376,7 @@ int bases_download_t(zk_ctx* ctx, const zk_bases* b, size_t offset, size_t n, vo
 // call's kernels, as they do in the resident prover.  What CAN be known: which table followed which with the same scalars last time.
 // So a context learns "after table T (scalars S) came table T' with the same S" (candidates by a fingerprint of 64 sampled scalars
 // taken from host memory), and when T is asked for again it also starts the MSMs over T' and T'' -- on a private copy of the scalars,
-// on the sort / accumulate streams, own scratch slots (6, 7) -- before it collects T's result.  The next call, if it names T' and
+// on the context's side stream, own scratch slots (6, 7) -- before it collects T's result.  The next call, if it names T' and
 // its scalars are WORD FOR WORD the ones the speculative job ran on (compared on the device), takes that result; anything else
 // drops the speculation (and after two wrong guesses for a table the pattern is forgotten).  Table hits are verified as always.
 // Nothing speculative is ever returned unverified; ZK_MSM_SPEC=0 switches the whole thing off (A/B).
@@ -1394,6 +1394,19 @@ struct ZkMsmSpec {
     uint32_t* flag_host = nullptr;
     uint64_t started = 0, taken = 0, dropped = 0;
     bool off = false;                                     // zk_msm_speculate(ctx, 0)
+    // the transform a caller ran last on a host vector (zk_msm_spec_fft_begin / _end): its size, the fingerprints its output has as
+    // a scalar vector of N and of N - 1 elements (the min(len) rule against a query of D - 1 points), and -- learned -- which
+    // table was asked for with exactly that output as scalars: `h = witness_map(..)` and then multi_scalar_mul(&pk.h_query, &h)
+    // (src/groth16.rs:100-106)
+    size_t fft_N = 0;
+    int fft_kind = 0;                                     // inverse * 2 + coset
+    uint64_t fft_fp[2] = {0, 0};
+    struct AfterFft { const zk_bases* table; size_t n; };
+    std::map<size_t, AfterFft> fft_succ;
+    bool fp_pending = false;                              // a job started by fft_begin whose fingerprint fft_end still owes
+    const void* late_dev = nullptr;                       // a LARGE job fft_begin left to fft_end
+    const zk_bases* late_table = nullptr;
+    size_t late_n = 0;
 };
 static bool spec_enabled() {
     static const bool on = !(getenv("ZK_MSM_SPEC") && atoi(getenv("ZK_MSM_SPEC")) == 0);
@@ -1418,6 +1431,7 @@ static void spec_drop(zk_ctx* ctx, ZkMsmSpec* sp) {
     if (ctx->acc_stream) (void)hipStreamSynchronize(ctx->acc_stream);
     sp->dropped += sp->jobs.size();
     sp->jobs.clear();
+    sp->fp_pending = false;
 }
 // scalars (n elements on the device, final on the context stream) == the copy the speculative jobs run on?
 static int spec_same_scalars(zk_ctx* ctx, ZkMsmSpec* sp, const void* scalars, size_t n, bool* same) {
@@ -1435,9 +1449,10 @@ static int spec_same_scalars(zk_ctx* ctx, ZkMsmSpec* sp, const void* scalars, si
     *same = *sp->flag_host == 0;
     return ZK_OK;
 }
-// the tables that followed `b` last time, over a private copy of the scalars: sort on the sort stream, accumulate on the accumulate
-// stream, the reduce chain behind it (a small job's on the accumulate stream, a large one's on the sort stream: msm_batch.hip)
-static int spec_start(zk_ctx* ctx, ZkMsmSpec* sp, const zk_bases* b, const void* scalars, size_t n, uint64_t fp, bool serial) {
+// the tables that followed `b` last time, over a private copy of the scalars: every phase of every job on the context's ONE side
+// stream, one job behind the other (groth16_pipeline.hip::zk_side_stream says why there is only one)
+static int spec_start_tables(zk_ctx* ctx, ZkMsmSpec* sp, const zk_bases* const* next, int cnt, const void* scalars, size_t n, uint64_t fp);
+static int spec_start(zk_ctx* ctx, ZkMsmSpec* sp, const zk_bases* b, const void* scalars, size_t n, uint64_t fp) {
     const zk_bases* next[2] = {nullptr, nullptr};
     int cnt = 0;
     auto it = sp->succ.find(b);
@@ -1447,16 +1462,18 @@ static int spec_start(zk_ctx* ctx, ZkMsmSpec* sp, const zk_bases* b, const void*
         if (it2 != sp->succ.end() && it2->second != b && it2->second != it->second && sp->bad[it2->second] < 2 && n <= it2->second->n) next[cnt++] = it2->second;
     }
     if (!cnt) return ZK_OK;
+    return spec_start_tables(ctx, sp, next, cnt, scalars, n, fp);
+}
+static int spec_start_tables(zk_ctx* ctx, ZkMsmSpec* sp, const zk_bases* const* next, int cnt, const void* scalars, size_t n, uint64_t fp) {
     void* copy;
     ZK_TRY(zk_scratch(ctx, "spec_scalars", n * 32, &copy));
-    ZK_TRY(zk_prover_streams(ctx, 1));
-    hipStream_t s_acc = ctx->acc_stream, s_sort = ctx->aux[0];
+    hipStream_t s_sort;                                      // every phase of every job on the context's ONE side stream (zk_side_stream)
+    ZK_TRY(zk_side_stream(ctx, &s_sort));
     ZK_HIP(ctx, hipMemcpyAsync(copy, scalars, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
     hipEvent_t e0;
     ZK_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
     hipError_t e = hipEventRecord(e0, ctx->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(s_sort, e0, 0);
-    if (e == hipSuccess) e = hipStreamWaitEvent(s_acc, e0, 0);
     (void)hipEventDestroy(e0);
     ZK_HIP(ctx, e);
     int rc = ZK_OK;
@@ -1466,13 +1483,8 @@ static int spec_start(zk_ctx* ctx, ZkMsmSpec* sp, const zk_bases* b, const void*
         j->job.pin_key = 40 + k;
         rc = zk_msm_prepare(ctx, &j->job, next[k], 0, copy, n, 6 + k);
         if (rc == ZK_OK) rc = zk_msm_enqueue_sort(ctx, &j->job, s_sort, nullptr);
-        if (serial) {                                        // a LARGE call: one job wholly behind the other on one stream (see msm_table_run_t)
-            if (rc == ZK_OK) rc = zk_msm_enqueue_accum(ctx, &j->job, s_sort);
-            if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, &j->job, s_sort);
-        } else {
-            if (rc == ZK_OK) rc = zk_msm_enqueue_accum(ctx, &j->job, s_acc);
-            if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, &j->job, s_acc);
-        }
+        if (rc == ZK_OK) rc = zk_msm_enqueue_accum(ctx, &j->job, s_sort);
+        if (rc == ZK_OK) rc = zk_msm_enqueue_reduce(ctx, &j->job, s_sort);
         sp->jobs.push_back(std::move(j));                    // (even a half-enqueued one: spec_drop waits for whatever it launched)
         if (rc == ZK_OK) sp->started++;
     }
@@ -1506,6 +1518,19 @@ int msm_table_run_t(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, c
             spec_drop(ctx, sp);
         }
     }
+    if (sp && sp->fft_N) {                                   // the transform before this call: were its outputs this call's scalars?
+        const size_t N = sp->fft_N;
+        if (spec_ok && rc == ZK_OK && (n == N || n + 1 == N) && sfp == sp->fft_fp[n == N ? 0 : 1]) {
+            const size_t key = N * 4 + (size_t)sp->fft_kind;
+            auto it = sp->fft_succ.find(key);
+            if (it != sp->fft_succ.end() && it->second.table == lease.b && it->second.n == n) {
+                auto bd = sp->bad.find(lease.b);
+                if (bd != sp->bad.end() && bd->second > 0 && --bd->second == 0) sp->bad.erase(bd);
+            }
+            sp->fft_succ[key] = ZkMsmSpec::AfterFft{lease.b, n};
+        }
+        sp->fft_N = 0;
+    }
     if (sp && spec_ok && rc == ZK_OK) {                      // learn: the same scalars as the call before, another table
         if (sp->last_table && sp->last_table != lease.b && sp->last_n == n && sp->last_fp == sfp) {
             auto it = sp->succ.find(sp->last_table);
@@ -1533,21 +1558,21 @@ int msm_table_run_t(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, c
                 sp->taken++;
                 take = nullptr;
             } else if (n_lanes == 1) {
-                // The MSMs this caller asked for next the last time it came with this table, on the side streams.  A SMALL call is a chain
+                // The MSMs this caller asked for next the last time it came with this table, on the side stream.  A SMALL call is a chain
                 // of latencies on a mostly idle chip: they start at once, behind nothing but the copy of the scalars, and run beside this
-                // call's own kernels (2^10 .. 2^16: -12 .. -18 % per proof).  A LARGE call fills the chip: started at once they only delay
+                // call's own kernels (2^10 .. 2^16: -12 .. -20 % per proof).  A LARGE call fills the chip: started at once they only delay
                 // this call's result (2^20: the A call 4 -> 13.5 ms, the three calls 16.6 -> 21.6), so they queue behind this call's
-                // whole device chain (a reduce chain beside a running accumulate kernel is starved), one wholly behind the other on one
-                // stream, and run under this call's host half and the caller's way back into the library.
+                // whole device chain (a reduce chain beside a running accumulate kernel is starved) and run under this call's host
+                // half and the caller's way back into the library.
                 const bool want_spec = spec_ok && attempt == 0 && sp->jobs.empty();
                 const bool small_call = lease.b->pre ? n * ((255 + lease.b->c_pre - 1) / lease.b->c_pre) <= ((size_t)1 << 22) : n <= ((size_t)1 << 17);
-                if (want_spec && small_call) (void)spec_start(ctx, sp, lease.b, scalars_dev[0], n, sfp, false);
+                if (want_spec && small_call) (void)spec_start(ctx, sp, lease.b, scalars_dev[0], n, sfp);
                 ZkMsmJob job;
                 rc = msm_prepare_t<F>(ctx, &job, lease.b, 0, scalars_dev[0], n, 0);
                 if (rc == ZK_OK) rc = msm_enqueue_sort_t<F>(ctx, &job, ctx->stream, nullptr);
                 if (rc == ZK_OK) rc = msm_enqueue_accum_t<F>(ctx, &job, ctx->stream);
                 if (rc == ZK_OK) rc = msm_enqueue_reduce_t<F>(ctx, &job, ctx->stream);
-                if (rc == ZK_OK && want_spec && !small_call) (void)spec_start(ctx, sp, lease.b, scalars_dev[0], n, sfp, true);
+                if (rc == ZK_OK && want_spec && !small_call) (void)spec_start(ctx, sp, lease.b, scalars_dev[0], n, sfp);
                 if (rc == ZK_OK) rc = msm_finish_t<F>(ctx, &job, outs[0]);
                 else (void)hipStreamSynchronize(ctx->stream);
             } else {
@@ -1721,15 +1746,51 @@ int zk_msm_table_run(zk_ctx* ctx, const ZkHostTable& t, size_t nu, int n_lanes, 
     if (t.group == 1) return msm_table_run_t<G1Field>(ctx, t, nu, n_lanes, scalars_dev, n, outs, sfp);
     return msm_table_run_t<G2Field>(ctx, t, nu, n_lanes, scalars_dev, n, outs, sfp);
 }
+uint64_t zk_scalars_fingerprint(const void* fr, size_t n) { return scalars_fingerprint((const zk_fr*)fr, n); }
 void zk_msm_spec_drop(zk_ctx* ctx) {
     if (ctx->msm_spec) spec_drop(ctx, (ZkMsmSpec*)ctx->msm_spec);
+}
+// A transform of 2^log_n elements on a caller's host vector has been enqueued (its result is in `dev`, final on the context stream,
+// not yet on its way back): if the MSM that followed such a transform last time took the output as its scalars, that MSM starts
+// now -- under the download of the result and the upload of the scalars the call will bring (which are compared with `dev`'s copy
+// before the result is released, like every job started ahead).
+void zk_msm_spec_fft_begin(zk_ctx* ctx, const void* dev, size_t N, int kind) {
+    ZkMsmSpec* sp = (ZkMsmSpec*)ctx->msm_spec;
+    if (!sp || sp->off || !spec_enabled() || ctx->profiling || !sp->jobs.empty()) return;
+    auto it = sp->fft_succ.find(N * 4 + (size_t)kind);        // (of the seven transforms of a witness map only the last -- the one coset
+    if (it == sp->fft_succ.end()) return;                     // inverse -- writes the H query's scalars: the kind is part of what is learned)
+    const zk_bases* t = it->second.table;
+    const size_t n = it->second.n;
+    if (sp->bad[t] >= 2 || n > t->n || n > N) return;
+    const bool small_call = t->pre ? n * ((255 + t->c_pre - 1) / t->c_pre) <= ((size_t)1 << 22) : n <= ((size_t)1 << 17);
+    // A small job starts now, under the download of the transform's result.  A large one would share a hardware queue with that
+    // download (2^20: the last transform 1.7 -> 3.2 ms, measured): it starts when the result is through (zk_msm_spec_fft_end) and
+    // runs under the caller's way back into the library and the upload of the scalars.
+    if (!small_call) { sp->late_dev = dev; sp->late_table = t; sp->late_n = n; return; }
+    if (spec_start_tables(ctx, sp, &t, 1, dev, n, 0) == ZK_OK && !sp->jobs.empty()) sp->fp_pending = true;
+}
+// ... and the result has arrived in the caller's vector: fp_of(n) = the fingerprint an MSM entry point would compute over its first n
+// elements (plain: scalars_fingerprint; MpcField: mpc_host.hip's)
+void zk_msm_spec_fft_end(zk_ctx* ctx, size_t N, int kind, const std::function<uint64_t(size_t)>& fp_of) {
+    if (!spec_enabled() || ctx->profiling || N < 2) return;
+    ZkMsmSpec* sp = spec_of(ctx);
+    if (sp->off) return;
+    sp->fft_N = N;
+    sp->fft_kind = kind;
+    sp->fft_fp[0] = fp_of(N);
+    sp->fft_fp[1] = fp_of(N - 1);
+    if (sp->fp_pending && !sp->jobs.empty()) sp->fp = sp->n == N ? sp->fft_fp[0] : sp->fft_fp[1];
+    sp->fp_pending = false;
+    if (sp->late_dev && sp->jobs.empty() && (sp->late_n == N || sp->late_n + 1 == N))
+        (void)spec_start_tables(ctx, sp, &sp->late_table, 1, sp->late_dev, sp->late_n, sp->fft_fp[sp->late_n == N ? 0 : 1]);
+    sp->late_dev = nullptr;
 }
 extern "C" int zk_msm_speculate(zk_ctx* ctx, int on) {
     ZK_API_BEGIN(ctx)
     if (!ctx) return ZK_ERR_ARG;
     ZkMsmSpec* sp = spec_of(ctx);
     sp->off = on == 0;
-    if (sp->off) { spec_drop(ctx, sp); sp->succ.clear(); sp->bad.clear(); sp->last_table = nullptr; }
+    if (sp->off) { spec_drop(ctx, sp); sp->succ.clear(); sp->bad.clear(); sp->fft_succ.clear(); sp->fft_N = 0; sp->last_table = nullptr; }
     return ZK_OK;
     ZK_API_END
 }
@@ -1748,6 +1809,8 @@ void zk_msm_spec_forget(zk_ctx* ctx, const zk_bases* b) {
     if (sp->last_table == b) sp->last_table = nullptr;
     sp->succ.erase(b);
     sp->bad.erase(b);
+    for (auto it = sp->fft_succ.begin(); it != sp->fft_succ.end();) it = it->second.table == b ? sp->fft_succ.erase(it) : std::next(it);
+    if (sp->late_table == b) sp->late_dev = nullptr;
     for (auto it = sp->succ.begin(); it != sp->succ.end();) it = it->second == b ? sp->succ.erase(it) : std::next(it);
 }
 void zk_msm_spec_free(zk_ctx* ctx) {

@@ -462,7 +462,9 @@ extern "C" int zk_fr_fft_in_place(zk_ctx* ctx, zk_fr* vec, size_t n, uint32_t lo
     ZK_TRY(zk_xfer_h2d(ctx, d, vec, n * 32));
     if (N > n) ZK_HIP(ctx, hipMemsetAsync((char*)d + n * 32, 0, (N - n) * 32, ctx->stream));
     ZK_TRY(zk_ntt_launch(ctx, d, log_n, inverse, coset));
+    zk_msm_spec_fft_begin(ctx, d, N, (inverse ? 2 : 0) + (coset ? 1 : 0));                        // (msm.hip: `h = witness_map(..)` is the H query's scalar vector next)
     ZK_TRY(zk_xfer_d2h(ctx, vec, d, N * 32));
+    zk_msm_spec_fft_end(ctx, N, (inverse ? 2 : 0) + (coset ? 1 : 0), [vec](size_t n) { return zk_scalars_fingerprint(vec, n); });
     return ZK_OK;
     ZK_API_END
 }
