@@ -147,3 +147,23 @@ def test_one_prover_line_over_three_contexts():
     assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["contexts"] == 3 and d["value"] > 0
     assert d["equals_single_context_proof"] is True and d["proof_matches_prediction"] is True
     assert sorted(set(p[0] for p in d["plan"])) == [0, 1, 2]
+
+
+def test_single_gpu_line_carries_the_composed_trait_paths():
+    """The default command's side legs at a small size: `trait_path` (examples/host_trait_groth16 = create_proof over the trait-shaped
+    entry points, plain element types) and `trait_path_collab` (the same over MpcField / MpcG1Affine, P parties) run, every proof of a
+    run has the same bytes, and the steady state says how it compares with the resident API."""
+    d = _line([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--log-constraints", "12", "--no-micro", "--no-cpu-baseline",
+               "--no-predict"])
+    tp = d["trait_path"]
+    assert "error" not in tp, tp
+    for mode in ("cache_packed", "cache_strided", "cache_strided_trust", "nocache_packed"):
+        leg = tp[mode]
+        assert "error" not in leg and leg["same_bytes_every_proof"] is True and leg["lib_vs_resident_api"] > 0, (mode, leg)
+    assert len({tp[m]["proof_sha"] for m in ("cache_packed", "cache_strided", "cache_strided_trust", "nocache_packed")}) == 1
+    tc = d["trait_path_collab"]
+    assert "error" not in tc, tc
+    legs = [k for k, v in tc.items() if isinstance(v, dict) and "parties" in v]
+    assert len(legs) >= 4, tc.keys()
+    for k in legs:
+        assert tc[k]["same_bytes_every_proof"] is True and tc[k]["steady_state_max_lib_ms"] > 0, (k, tc[k])
