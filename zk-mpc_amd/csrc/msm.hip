@@ -1756,6 +1756,7 @@ void zk_msm_spec_drop(zk_ctx* ctx) {
 // before the result is released, like every job started ahead).
 void zk_msm_spec_fft_begin(zk_ctx* ctx, const void* dev, size_t N, int kind) {
     ZkMsmSpec* sp = (ZkMsmSpec*)ctx->msm_spec;
+    if (sp) sp->late_dev = nullptr;                          // (a transform that failed between begin and end leaves nothing behind)
     if (!sp || sp->off || !spec_enabled() || ctx->profiling || !sp->jobs.empty()) return;
     auto it = sp->fft_succ.find(N * 4 + (size_t)kind);        // (of the seven transforms of a witness map only the last -- the one coset
     if (it == sp->fft_succ.end()) return;                     // inverse -- writes the H query's scalars: the kind is part of what is learned)
