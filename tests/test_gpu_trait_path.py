@@ -99,6 +99,7 @@ def run_collab(exe, log_d, proofs, parties, *mode):
     (10, 3, ("additive", "taglast")), (10, 2, ("spdz", "taglast")), (12, 1, ("additive", "tagfirst")), (12, 8, ("additive", "tagfirst")),
     (12, 3, ("additive", "tagfirst", "trust")),
     (20, 1, ("additive", "tagfirst")), (20, 3, ("additive", "tagfirst")),         # BASELINE's own size (three provers on one device)
+    (18, 2, ("spdz", "tagfirst")),
 ])
 def test_collaborative_trait_path_reveals_the_predicted_proof(tmp_path, log_d, parties, mode):
     """create_proof::<MpcPairingEngine> unchanged (VERDICT r5 item 1): the composer follows src/groth16.rs:68-183,240-306 over
